@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: Grows/s (+ achieved HBM GB/s) of the 1-billion-row i64 and f64
+column sums (configs[1]: "1B-row i64 and f64 sum/avg, null-free, 1 MI355X vs SIMD+Rayon CPU baseline").
+
+A step = one pass of the hot path over one batch: ma_i64_sum over a 10^9-row IntegerArray<i64> column plus
+ma_f64_sum_dd over a 10^9-row FloatArray<f64> column (the two loops of benches/benchmark_parallel_simd.rs:99-125),
+both already resident in HBM. With N GPUs every rank owns its own 10^9-row chunk of a N x 10^9-row column
+(row-chunk partition, weak scaling) and the step ends with the exchange of the per-rank scalars over RCCL
+(all-gather of 5 x 8 bytes; the fold is done in rank order so the f64 result stays within 1 ULP).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+
+
+def two_sum(a: float, b: float):
+    s = a + b
+    bp = s - a
+    return s, (a - (s - bp)) + (b - bp)
+
+
+def fold_dd(pairs):
+    """Sum of double-double (hi, lo) pairs in the given order; returns the rounded double."""
+    hi, lo = 0.0, 0.0
+    for h, l in pairs:
+        hi, e = two_sum(hi, h)
+        lo += e + l
+    return hi + lo
+
+
+def cpu_baseline(rows: int, budget_s: float):
+    """Times the oracle's restatement of rayon_simd_sum_{i64,f64} (benches/benchmark_parallel_simd.rs:81-98) on
+    this box's host cores over a bounded sample of the same workload."""
+    import numpy as np
+
+    from oracle import oracle
+
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    total_rows, total_time = 0, 0.0
+    detail = {}
+    for dtype, name in ((np.int64, "i64"), (np.float64, "f64")):
+        a = np.empty(rows, dtype=dtype)
+        oracle.par_fill_iota(a, 0, threads)
+        expect = rows * (rows - 1) // 2
+        got = oracle.par_sum(a, 1 << 20, 4, threads)  # warm-up (cf. benches/hotloop_benchmark_simd.rs:199-200)
+        assert got == (expect if name == "i64" else got)
+        times = []
+        t_end = time.perf_counter() + budget_s / 2
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+            t0 = time.perf_counter()
+            got = oracle.par_sum(a, 1 << 20, 4, threads)
+            times.append(time.perf_counter() - t0)
+        if name == "i64":
+            assert got == expect, (got, expect)
+        best = min(times)
+        detail[name] = {"best_ms": best * 1e3, "median_ms": sorted(times)[len(times) // 2] * 1e3, "reps": len(times),
+                        "grows_per_s": rows / best / 1e9}
+        total_rows += rows
+        total_time += best
+        del a
+    return {
+        "value": total_rows / total_time / 1e9,
+        "unit": "Grows/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, "
+                  f"{threads} threads, best of {detail['i64']['reps']}/{detail['f64']['reps']} reps "
+                  f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
+        "detail": detail,
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU per column")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 28, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: the library then shares torch's HIP runtime (same SONAME)
+    import torch.distributed as dist
+
+    from minarrow_amd.host import Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)",
+                  file=sys.stderr)
+            return 2
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows = args.rows
+    stream = torch.cuda.current_stream(dev)
+    ctx = Context(local_rank, stream=stream.cuda_stream)
+    ctx.set_variant(args.variant)
+    ctx.set_blocks_per_cu(args.blocks_per_cu)
+
+    # Columns resident in HBM before anything is timed (construction excluded, as in
+    # benches/benchmark_parallel_simd.rs:103-106). Rank r owns global rows [r*rows, (r+1)*rows).
+    col_i = torch.empty(rows, dtype=torch.int64, device=dev)
+    col_f = torch.empty(rows, dtype=torch.float64, device=dev)
+    ctx.synth_iota("i64", col_i, rows, rank * rows)
+    ctx.synth_iota("f64", col_f, rows, rank * rows)
+    # [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits, [4] f64 count
+    res = torch.zeros(8, dtype=torch.int64, device=dev)
+    gathered = torch.zeros(8 * world, dtype=torch.int64, device=dev)
+    base = res.data_ptr()
+    ctx.set_async(True)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        ctx.sum_into("i64", col_i, rows, out_sum=base, out_count=base + 8)
+        if ev:
+            ev[1].record(stream)
+        ctx.sum_into("f64", col_f, rows, out_sum=base + 16, dd_lo=base + 24, out_count=base + 32)
+        if ev:
+            ev[2].record(stream)
+        if distributed:
+            dist.all_gather_into_tensor(gathered, res)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.synchronize()
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    else:
+        gathered.copy_(res)
+    torch.cuda.synchronize(dev)
+
+    # ---- verify the job's answer (outside the timed region) ------------------------------------------
+    g = gathered.cpu().numpy().reshape(world, 8)
+    total_rows = rows * world
+    expect = total_rows * (total_rows - 1) // 2
+    got_i = int(g[:, 0].astype(object).sum()) & ((1 << 64) - 1)
+    pairs = [(float(g[r, 2:3].view(np.float64)[0]), float(g[r, 3:4].view(np.float64)[0])) for r in range(world)]
+    got_f = fold_dd(pairs)
+    exact_f = float(expect)
+    ok = (got_i == expect & ((1 << 64) - 1)) and int(g[:, 1].sum()) == total_rows and int(g[:, 4].sum()) == total_rows \
+        and abs(got_f - exact_f) <= math.ulp(exact_f)
+
+    ms_i = [e[0].elapsed_time(e[1]) for e in events]
+    ms_f = [e[1].elapsed_time(e[2]) for e in events]
+    avg_i, avg_f = sum(ms_i) / len(ms_i), sum(ms_f) / len(ms_f)
+    bytes_per_launch = rows * 8  # algorithmic: 8 B/row, one launch scans `rows` rows
+    dom_name, dom_ms = ("ma::sum_kernel<double>", avg_f) if avg_f >= avg_i else ("ma::sum_kernel<int64>", avg_i)
+    achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
+
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("sum_f64_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        value = total_rows * 2 * args.steps / elapsed / 1e9
+        out = {
+            "metric": "Grows/sec + achieved HBM GB/s, 1B-row i64/f64 sum",
+            "value": value,
+            "unit": "Grows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i64+f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{rows}-row IntegerArray<i64> sum + {rows}-row FloatArray<f64> sum per GPU, null-free, "
+                            f"HBM-resident (BASELINE configs[1])",
+                "rows_per_gpu_per_column": rows,
+                "columns": ["i64", "f64"],
+                "parallelism": f"row-chunk x{world}" + (" + RCCL all-gather of scalars" if distributed else ""),
+                "variant": args.variant,
+                "blocks_per_cu": args.blocks_per_cu or 8,
+            },
+            "hbm_gbps": total_rows * 2 * 8 * args.steps / elapsed / 1e9,
+            "parity_ok": bool(ok),
+            "result": {"i64_sum": got_i, "f64_sum": got_f, "f64_ulps_from_exact": abs(got_f - exact_f) / math.ulp(exact_f)},
+            "kernels": {
+                "sum_i64": {"avg_ms": avg_i, "min_ms": min(ms_i), "gbps": bytes_per_launch / (avg_i * 1e-3) / 1e9,
+                            "grows_per_s": rows / (avg_i * 1e-3) / 1e9},
+                "sum_f64": {"avg_ms": avg_f, "min_ms": min(ms_f), "gbps": bytes_per_launch / (avg_f * 1e-3) / 1e9,
+                            "grows_per_s": rows / (avg_f * 1e-3) / 1e9},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # free the HBM columns first so the host-side sample does not compete for anything
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+        if not ok:
+            print(f"PARITY FAILURE: i64 {got_i} vs {expect}, f64 {got_f} vs {exact_f}", file=sys.stderr)
+
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

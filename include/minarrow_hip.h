@@ -1,0 +1,194 @@
+/*
+ * minarrow_hip.h — C ABI of the MI355X (gfx950) kernel layer for Minarrow's src/kernels hot path.
+ *
+ * This is the drop-in boundary. Every entry point replaces one slice-in / slice-out Rust function of the
+ * reference (cited as `file:line`, relative to the reference repository) or one of the hand-written
+ * reductions in its bench binaries. Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ * -----------
+ *  - Every compute call takes a `ma_ctx*` (one device + one HIP stream) and returns `ma_status`.
+ *  - Buffers may live anywhere the device can reach:
+ *      * device memory (hipMalloc / ma_dev_alloc / a torch CUDA tensor's data_ptr)  → used in place (fast path),
+ *      * pinned host memory (ma_alloc64_pinned — the Vec64 stand-in)                → read/written in place over PCIe,
+ *      * ordinary pageable host memory (a Rust `&[T]`, a numpy array)               → staged through device scratch.
+ *    The library classifies each pointer with hipPointerGetAttributes; there is NO CPU compute fallback.
+ *  - The caller allocates every output (reference: `Vec64::with_capacity(len); set_len(len)`,
+ *    src/kernels/arithmetic/dispatch.rs:88-89; `Bitmask::new_set_all(len,true)`, :92).
+ *  - Validity bitmaps are Arrow layout (src/structs/bitmask.rs:66-71): bit i = byte i>>3, bit i&7, 1 = valid.
+ *    They are addressed as (bits pointer, bit offset, bit length). Output bitmaps must have room for
+ *    8*ceil(len/64) bytes (the reference also reads/writes them as whole u64 words,
+ *    src/structs/bitmask.rs:266-277); bits >= len are written as 0.
+ *  - Synchronous by default: a call returns after its result is available to the host. With
+ *    ma_ctx_set_async(ctx,1) calls only enqueue work on the context's stream; scalar outputs must then be
+ *    device-reachable memory and errors detected on the device are reported by ma_ctx_synchronize().
+ *  - Thread safety: a ctx may be shared between host threads (calls serialise on an internal lock);
+ *    independent ctxs are fully independent. No hidden global scratch.
+ *
+ * Status codes mirror KernelError (src/enums/error.rs:157-187) as far as the numeric kernels can raise them.
+ */
+#ifndef MINARROW_HIP_H
+#define MINARROW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MA_ABI_VERSION 1
+
+typedef struct ma_ctx ma_ctx;
+typedef int32_t ma_status;
+
+enum {
+    MA_OK = 0,
+    MA_ERR_LENGTH_MISMATCH = 1,  /* KernelError::LengthMismatch — src/utils.rs:163-171 */
+    MA_ERR_DIVIDE_BY_ZERO = 2,   /* dense integer Div/Rem/FloorDiv saw a zero divisor: the reference panics
+                                    (src/kernels/arithmetic/std.rs:53-77); output contents are unspecified */
+    MA_ERR_UNSUPPORTED = 3,      /* KernelError::UnsupportedType */
+    MA_ERR_INVALID_ARGUMENT = 4, /* KernelError::InvalidArguments: null pointer, misaligned pointer, bad op code */
+    MA_ERR_DEVICE = 5,           /* a HIP runtime call failed; see ma_last_error_string() */
+    MA_ERR_NO_DEVICE = 6         /* no usable GPU: the library never falls back to the CPU */
+};
+
+/* ArithmeticOperator — discriminant order of src/enums/operators.rs:18-48 */
+enum {
+    MA_OP_ADD = 0,
+    MA_OP_SUBTRACT = 1,
+    MA_OP_MULTIPLY = 2,
+    MA_OP_DIVIDE = 3,
+    MA_OP_REMAINDER = 4,
+    MA_OP_POWER = 5,
+    MA_OP_FLOORDIV = 6
+};
+
+/* LogicalOperator — src/enums/operators.rs:86-100 */
+enum { MA_LOGICAL_AND = 0, MA_LOGICAL_OR = 1, MA_LOGICAL_XOR = 2 };
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / context
+ * ---------------------------------------------------------------------------------------------- */
+
+int32_t ma_abi_version(void);
+/* Number of visible HIP devices (0 when there is none; never initialises a device context). */
+int32_t ma_device_count(void);
+/* Thread-local description of the last non-OK status returned on this thread. Never NULL. */
+const char* ma_last_error_string(void);
+const char* ma_status_name(ma_status s);
+
+/* One context = one device + one stream + that stream's reduction scratch. */
+ma_status ma_ctx_create(int32_t device_ordinal, ma_ctx** out_ctx);
+/* As above but enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+ma_status ma_ctx_create_on_stream(int32_t device_ordinal, void* hip_stream, ma_ctx** out_ctx);
+void ma_ctx_destroy(ma_ctx* ctx);
+ma_status ma_ctx_synchronize(ma_ctx* ctx);
+ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled);
+void* ma_ctx_stream(ma_ctx* ctx);
+int32_t ma_ctx_device(ma_ctx* ctx);
+int32_t ma_ctx_compute_units(ma_ctx* ctx);
+/* Launch geometry for the streaming kernels: workgroups per CU (0 = built-in default). */
+ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
+/* Kernel variant selector used by the tuning harness (0 = default). See DESIGN.md §kernels. */
+ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
+
+/* HIP-event timing on the context's stream (bench.py's roofline leg uses these). */
+ma_status ma_ctx_timer_start(ma_ctx* ctx);
+ma_status ma_ctx_timer_stop(ma_ctx* ctx);
+/* Waits for the stop event; milliseconds between start and stop. */
+ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Memory — the Vec64 stand-in (64-byte aligned, src/lib.rs:99; Cargo.toml:54 vec64 0.4.3) and
+ * device-resident buffers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* hipHostMalloc-backed, 64-byte aligned, device-mapped. The pointer is valid on the host and in kernels. */
+ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr);
+ma_status ma_free_pinned(void* ptr);
+ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
+ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
+ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t bytes);
+/* 0 = pageable host, 1 = pinned/registered host, 2 = device, 3 = managed. */
+int32_t ma_pointer_kind(const void* ptr);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic inputs generated in place on the device (patterns of
+ * benches/benchmark_parallel_simd.rs:103,115). `dst` must be device-reachable.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* dst[i] = start + i                                   (Vec64<i64> = (0..N).collect()) */
+ma_status ma_synth_iota_i64(ma_ctx* ctx, int64_t* dst, size_t n, int64_t start);
+/* dst[i] = (double)(start + i)                         ((0..N).map(|x| x as f64)) */
+ma_status ma_synth_iota_f64(ma_ctx* ctx, double* dst, size_t n, int64_t start);
+ma_status ma_synth_iota_i32(ma_ctx* ctx, int32_t* dst, size_t n, int32_t start);
+ma_status ma_synth_iota_f32(ma_ctx* ctx, float* dst, size_t n, int32_t start);
+/* dst[i] = splitmix64(seed + first_index + i) reinterpreted as i64 */
+ma_status ma_synth_splitmix_i64(ma_ctx* ctx, int64_t* dst, size_t n, uint64_t seed, uint64_t first_index);
+/* dst[i] = uniform [-1,1): (splitmix64(seed + first_index + i) >> 11) * 2^-52 - 1 */
+ma_status ma_synth_splitmix_f64(ma_ctx* ctx, double* dst, size_t n, uint64_t seed, uint64_t first_index);
+/* Validity bitmap: bit i = (splitmix64(seed + first_index + i) % null_every != 0); whole u64 words are
+ * written (8*ceil(n_bits/64) bytes), bits >= n_bits zero. null_every = 10 gives ~10 % nulls. */
+ma_status ma_synth_validity(ma_ctx* ctx, uint8_t* dst_bits, size_t n_bits, uint64_t seed, uint64_t first_index,
+                            uint32_t null_every);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reductions — the reference's only sum implementations are in its bench binaries:
+ *   simd_sum_i64 / simd_sum_f64        benches/benchmark_parallel_simd.rs:44-59, 63-78
+ *   rayon_simd_sum_{i64,f64}           benches/benchmark_parallel_simd.rs:81-98
+ *   4x-unrolled variants               benches/hotloop_benchmark_simd.rs:56-174
+ *   scalar loops                       benches/hotloop_benchmark_std.rs:49-57
+ * Hand-off shape follows NumericArrayV::guarantee_f64 (src/structs/views/collections/
+ * numeric_array_view.rs:302-317): `data` already points at the window, `mask_bits` is the un-windowed
+ * validity buffer (or NULL) with the window's first bit at `mask_bit_offset`, `null_count` is the cached
+ * null count of the window (-1 = unknown, 0 = take the dense kernel).
+ *
+ * Semantics: integers wrap (two's complement) exactly like the reference's release build; i32/u32 are
+ * accumulated in 64 bits (the wrapping 32-bit sum is the low half). f32/f64 are accumulated in
+ * double-double so the result is within 1 ULP of the exactly rounded sum whatever the order.
+ * Bitmask-gated sum, valid-count and mean do not exist in the reference: sum = Σ data[i] over set bits,
+ * count = popcount, mean = sum/count (NaN when count == 0).
+ * Any output pointer may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+
+ma_status ma_i64_sum(ma_ctx* ctx, const int64_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, int64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_u64_sum(ma_ctx* ctx, const uint64_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, uint64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_i32_sum(ma_ctx* ctx, const int32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, int64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_u32_sum(ma_ctx* ctx, const uint32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, uint64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_f64_sum(ma_ctx* ctx, const double* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, double* out_sum, uint64_t* out_valid_count);
+ma_status ma_f32_sum(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, double* out_sum, uint64_t* out_valid_count);
+/* As ma_f64_sum / ma_f32_sum but returns the unevaluated double-double (hi + lo) so partial sums of row
+ * chunks (one per GPU) can be combined without losing the 1-ULP guarantee. */
+ma_status ma_f64_sum_dd(ma_ctx* ctx, const double* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                        int64_t null_count, double* out_hi, double* out_lo, uint64_t* out_valid_count);
+ma_status ma_f32_sum_dd(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                        int64_t null_count, double* out_hi, double* out_lo, uint64_t* out_valid_count);
+
+/* Arithmetic mean = sum / valid_count as f64 (NaN when valid_count == 0). */
+ma_status ma_i64_mean(ma_ctx* ctx, const int64_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_u64_mean(ma_ctx* ctx, const uint64_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_i32_mean(ma_ctx* ctx, const int32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_u32_mean(ma_ctx* ctx, const uint32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_f64_mean(ma_ctx* ctx, const double* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* MINARROW_HIP_H */

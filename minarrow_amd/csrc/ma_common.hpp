@@ -1,0 +1,134 @@
+// Internal definitions shared by the HIP translation units of libminarrow_hip.so.
+// Nothing here is part of the C ABI (include/minarrow_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "minarrow_hip.h"
+
+namespace ma {
+
+constexpr int kBlock = 256;       // threads per workgroup: 4 wave64s, one per SIMD of a CU
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxGrid = 16384;   // upper bound on workgroups of a reduction launch (scratch is sized for it)
+constexpr int kDefaultBlocksPerCu = 8;
+
+// One reduction partial: 32 bytes so that a workgroup's record never straddles a 64-B line with
+// more than one neighbour.
+struct alignas(32) Partial {
+    uint64_t a;    // integer sum, or bit pattern of the double-double high part
+    uint64_t b;    // bit pattern of the double-double low part (0 for integers)
+    uint64_t cnt;  // number of valid rows seen
+    uint64_t pad;
+};
+
+// Pinned-host result slot a synchronous call reads after the stream drains.
+struct ResultSlot {
+    uint64_t a;
+    uint64_t b;
+    uint64_t cnt;
+    uint32_t flags;  // device-detected conditions (bit 0: integer divide by zero)
+    uint32_t pad;
+};
+
+void set_error(const char* fmt, ...);
+ma_status hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+}  // namespace ma
+
+#define MA_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return ::ma::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define MA_TRY(expr)                      \
+    do {                                  \
+        ma_status _s = (expr);            \
+        if (_s != MA_OK) return _s;       \
+    } while (0)
+
+#define MA_REQUIRE(cond, status, ...)     \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::ma::set_error(__VA_ARGS__); \
+            return (status);              \
+        }                                 \
+    } while (0)
+
+struct ma_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool async = false;
+    int num_cus = 0;
+    int blocks_per_cu = ma::kDefaultBlocksPerCu;
+    int variant = 0;
+    std::mutex mu;
+
+    ma::Partial* partials = nullptr;   // device, kMaxGrid records
+    unsigned int* ticket = nullptr;    // device, zero between launches
+    ma::ResultSlot* result = nullptr;  // pinned host, device-mapped
+    uint32_t* dev_flags = nullptr;     // device word for elementwise kernels (divide-by-zero latch)
+    hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_stop = nullptr;
+    bool pending_flags = false;        // async mode: dev_flags must be inspected at the next synchronize
+};
+
+namespace ma {
+
+enum PtrKind : int32_t { kPageable = 0, kPinned = 1, kDevice = 2, kManaged = 3 };
+PtrKind pointer_kind(const void* p);
+
+// Makes every buffer of one ABI call device-reachable. Pageable host inputs are copied into temporary
+// device buffers; pageable host outputs get a temporary that is copied back by finish(). Using any
+// temporary forces the call to be synchronous.
+class CallScope {
+  public:
+    explicit CallScope(ma_ctx* ctx) : ctx_(ctx) {}
+    ~CallScope();
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+
+    // Device-reachable alias of `bytes` bytes at `host_or_dev` (copied in when pageable).
+    ma_status in(const void* host_or_dev, size_t bytes, const void** out);
+    // Device-reachable destination for `bytes` bytes; copied back to `host_or_dev` by finish() when pageable.
+    ma_status out(void* host_or_dev, size_t bytes, void** out);
+    // Validity bitmap window -> (8-byte aligned word pointer, bit offset of the window's first bit).
+    // Reads whole u64 words like the reference (src/structs/bitmask.rs:266-268).
+    ma_status in_mask(const uint8_t* bits, size_t bit_offset, size_t len_bits, const uint64_t** out_words,
+                      size_t* out_bit_offset);
+    // Output bitmap of len_bits bits starting at bit 0: 8*ceil(len_bits/64) bytes are written.
+    ma_status out_mask(uint8_t* bits, size_t len_bits, uint64_t** out_words);
+    // Synchronises when needed and copies temporaries back.
+    ma_status finish();
+    bool staged() const { return !temps_.empty(); }
+
+  private:
+    struct Temp {
+        void* dev;
+        void* host_dst;  // nullptr for inputs
+        size_t bytes;
+    };
+    ma_ctx* ctx_;
+    std::vector<Temp> temps_;
+};
+
+inline int grid_for(const ma_ctx* ctx, size_t work_items) {
+    size_t cap = (size_t)ctx->num_cus * (size_t)(ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : kDefaultBlocksPerCu);
+    if (cap > (size_t)kMaxGrid) cap = kMaxGrid;
+    if (work_items < 1) work_items = 1;
+    return (int)(work_items < cap ? work_items : cap);
+}
+
+// Completes a call: in sync mode waits for the stream. Returns MA_ERR_DEVICE on failure.
+ma_status end_call(ma_ctx* ctx, CallScope& scope);
+
+}  // namespace ma

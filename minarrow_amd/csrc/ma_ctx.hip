@@ -1,0 +1,502 @@
+// Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
+// C ABI: include/minarrow_hip.h.
+#include "ma_common.hpp"
+
+namespace ma {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+ma_status hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    // A failed launch leaves a sticky "last error"; clear it so later calls report their own.
+    (void)hipGetLastError();
+    return e == hipErrorNoDevice ? MA_ERR_NO_DEVICE : MA_ERR_DEVICE;
+}
+
+PtrKind pointer_kind(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return kPageable;
+    }
+    switch (attr.type) {
+        case hipMemoryTypeDevice:
+        case hipMemoryTypeArray:
+            return kDevice;
+        case hipMemoryTypeHost:
+            return kPinned;
+        case hipMemoryTypeManaged:
+        case hipMemoryTypeUnified:
+            return kManaged;
+        default:
+            return kPageable;
+    }
+}
+
+CallScope::~CallScope() {
+    for (auto& t : temps_) {
+        if (t.dev) (void)hipFree(t.dev);
+    }
+}
+
+ma_status CallScope::in(const void* p, size_t bytes, const void** out) {
+    *out = p;
+    if (bytes == 0 || p == nullptr) return MA_OK;
+    if (pointer_kind(p) != kPageable) return MA_OK;
+    void* d = nullptr;
+    MA_HIP(hipMalloc(&d, bytes));
+    temps_.push_back({d, nullptr, bytes});
+    MA_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx_->stream));
+    *out = d;
+    return MA_OK;
+}
+
+ma_status CallScope::out(void* p, size_t bytes, void** out) {
+    *out = p;
+    if (bytes == 0 || p == nullptr) return MA_OK;
+    if (pointer_kind(p) != kPageable) return MA_OK;
+    void* d = nullptr;
+    MA_HIP(hipMalloc(&d, bytes));
+    temps_.push_back({d, p, bytes});
+    *out = d;
+    return MA_OK;
+}
+
+ma_status CallScope::in_mask(const uint8_t* bits, size_t bit_offset, size_t len_bits, const uint64_t** out_words,
+                             size_t* out_bit_offset) {
+    *out_words = nullptr;
+    *out_bit_offset = 0;
+    if (bits == nullptr || len_bits == 0) return MA_OK;
+    if (pointer_kind(bits) != kPageable) {
+        // Re-base onto the enclosing 8-byte aligned word; the few bytes in front belong to the same
+        // aligned word and are never interpreted.
+        uintptr_t addr = (uintptr_t)bits;
+        uintptr_t base = addr & ~(uintptr_t)7;
+        *out_words = (const uint64_t*)base;
+        *out_bit_offset = bit_offset + (size_t)(addr - base) * 8;
+        return MA_OK;
+    }
+    // Pageable: copy exactly the bytes that hold the window into a zero-padded word buffer.
+    size_t first_byte = bit_offset >> 3;
+    size_t end_byte = (bit_offset + len_bits + 7) >> 3;
+    size_t nbytes = end_byte - first_byte;
+    size_t padded = ((nbytes + 7) & ~(size_t)7) + 8;
+    void* d = nullptr;
+    MA_HIP(hipMalloc(&d, padded));
+    temps_.push_back({d, nullptr, padded});
+    MA_HIP(hipMemsetAsync(d, 0, padded, ctx_->stream));
+    MA_HIP(hipMemcpyAsync(d, bits + first_byte, nbytes, hipMemcpyHostToDevice, ctx_->stream));
+    *out_words = (const uint64_t*)d;
+    *out_bit_offset = bit_offset & 7;
+    return MA_OK;
+}
+
+ma_status CallScope::out_mask(uint8_t* bits, size_t len_bits, uint64_t** out_words) {
+    *out_words = nullptr;
+    if (bits == nullptr || len_bits == 0) return MA_OK;
+    MA_REQUIRE(((uintptr_t)bits & 7) == 0, MA_ERR_INVALID_ARGUMENT,
+               "output bitmap must be 8-byte aligned (got %p)", (const void*)bits);
+    size_t bytes = ((len_bits + 63) / 64) * 8;
+    void* d = nullptr;
+    MA_TRY(out(bits, bytes, &d));
+    *out_words = (uint64_t*)d;
+    return MA_OK;
+}
+
+ma_status CallScope::finish() {
+    bool need_sync = !ctx_->async || !temps_.empty();
+    bool any_out = false;
+    for (auto& t : temps_) {
+        if (t.host_dst) {
+            MA_HIP(hipMemcpyAsync(t.host_dst, t.dev, t.bytes, hipMemcpyDeviceToHost, ctx_->stream));
+            any_out = true;
+        }
+    }
+    (void)any_out;
+    if (need_sync) MA_HIP(hipStreamSynchronize(ctx_->stream));
+    return MA_OK;
+}
+
+ma_status end_call(ma_ctx* ctx, CallScope& scope) {
+    (void)ctx;
+    return scope.finish();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic inputs
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    // Public-domain SplitMix64 finaliser (Steele, Lea, Flood 2014); `x` is the already-advanced state.
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <typename T, typename F>
+__global__ __launch_bounds__(kBlock) void fill_kernel(T* __restrict__ dst, size_t n, F f) {
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = f(i);
+}
+
+__global__ __launch_bounds__(kBlock) void validity_kernel(uint64_t* __restrict__ words, size_t n_bits, uint64_t seed,
+                                                         uint64_t first_index, uint32_t null_every) {
+    // One wave64 produces one u64 word per step: lane k owns bit k.
+    size_t n_words = (n_bits + 63) / 64;
+    size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    unsigned lane = threadIdx.x & 63;
+    for (size_t w = wave; w < n_words; w += n_waves) {
+        size_t i = w * 64 + lane;
+        bool valid = i < n_bits && (splitmix64(seed + first_index + i) % null_every) != 0;
+        unsigned long long word = __ballot(valid);
+        if (lane == 0) words[w] = word;
+    }
+}
+
+template <typename T, typename F>
+static ma_status launch_fill(ma_ctx* ctx, T* dst, size_t n, F f) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n == 0) return MA_OK;
+    MA_REQUIRE(dst != nullptr, MA_ERR_INVALID_ARGUMENT, "dst is NULL");
+    MA_REQUIRE(pointer_kind(dst) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "synthetic generators need a device-reachable destination");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    int grid = grid_for(ctx, (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((fill_kernel<T, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, dst, n, f);
+    MA_HIP(hipGetLastError());
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+struct IotaI64 {
+    int64_t start;
+    __device__ int64_t operator()(size_t i) const { return (int64_t)((uint64_t)start + (uint64_t)i); }
+};
+struct IotaF64 {
+    int64_t start;
+    __device__ double operator()(size_t i) const { return (double)(int64_t)((uint64_t)start + (uint64_t)i); }
+};
+struct IotaI32 {
+    int32_t start;
+    __device__ int32_t operator()(size_t i) const { return (int32_t)((uint32_t)start + (uint32_t)i); }
+};
+struct IotaF32 {
+    int32_t start;
+    __device__ float operator()(size_t i) const { return (float)(int32_t)((uint32_t)start + (uint32_t)i); }
+};
+struct SplitI64 {
+    uint64_t seed, first;
+    __device__ int64_t operator()(size_t i) const { return (int64_t)splitmix64(seed + first + i); }
+};
+struct SplitF64 {
+    uint64_t seed, first;
+    __device__ double operator()(size_t i) const {
+        return (double)(splitmix64(seed + first + i) >> 11) * 0x1.0p-52 - 1.0;
+    }
+};
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+int32_t ma_abi_version(void) { return MA_ABI_VERSION; }
+
+int32_t ma_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* ma_last_error_string(void) { return g_err; }
+
+const char* ma_status_name(ma_status s) {
+    switch (s) {
+        case MA_OK: return "MA_OK";
+        case MA_ERR_LENGTH_MISMATCH: return "MA_ERR_LENGTH_MISMATCH";
+        case MA_ERR_DIVIDE_BY_ZERO: return "MA_ERR_DIVIDE_BY_ZERO";
+        case MA_ERR_UNSUPPORTED: return "MA_ERR_UNSUPPORTED";
+        case MA_ERR_INVALID_ARGUMENT: return "MA_ERR_INVALID_ARGUMENT";
+        case MA_ERR_DEVICE: return "MA_ERR_DEVICE";
+        case MA_ERR_NO_DEVICE: return "MA_ERR_NO_DEVICE";
+        default: return "MA_ERR_UNKNOWN";
+    }
+}
+
+static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_ctx** out_ctx) {
+    MA_REQUIRE(out_ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = ma_device_count();
+    if (n <= 0) {
+        set_error("no HIP device is visible; libminarrow_hip has no CPU fallback");
+        return MA_ERR_NO_DEVICE;
+    }
+    MA_REQUIRE(device >= 0 && device < n, MA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range [0,%d)", device, n);
+    MA_HIP(hipSetDevice(device));
+    ma_ctx* c = new ma_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return hip_fail(e, "hipGetDeviceProperties", __FILE__, __LINE__);
+    }
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (borrow) {
+        c->stream = (hipStream_t)stream;
+        c->owns_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+        }
+        c->owns_stream = true;
+    }
+    auto fail = [&](hipError_t err, const char* what) {
+        ma_status s = hip_fail(err, what, __FILE__, __LINE__);
+        ma_ctx_destroy(c);
+        return s;
+    };
+    if ((e = hipMalloc((void**)&c->partials, sizeof(Partial) * kMaxGrid)) != hipSuccess) return fail(e, "hipMalloc(partials)");
+    if ((e = hipMalloc((void**)&c->ticket, 256)) != hipSuccess) return fail(e, "hipMalloc(ticket)");
+    if ((e = hipMemset(c->ticket, 0, 256)) != hipSuccess) return fail(e, "hipMemset(ticket)");
+    c->dev_flags = c->ticket + 16;  // same zeroed allocation, a different 64-B line
+    if ((e = hipHostMalloc((void**)&c->result, sizeof(ResultSlot) * 4, hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc(result)");
+    memset(c->result, 0, sizeof(ResultSlot) * 4);
+    if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
+    *out_ctx = c;
+    return MA_OK;
+}
+
+ma_status ma_ctx_create(int32_t device_ordinal, ma_ctx** out_ctx) {
+    return ctx_create_impl(device_ordinal, nullptr, false, out_ctx);
+}
+
+ma_status ma_ctx_create_on_stream(int32_t device_ordinal, void* hip_stream, ma_ctx** out_ctx) {
+    return ctx_create_impl(device_ordinal, hip_stream, true, out_ctx);
+}
+
+void ma_ctx_destroy(ma_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
+    if (ctx->result) (void)hipHostFree(ctx->result);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+ma_status ma_ctx_synchronize(ma_ctx* ctx) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_flags) {
+        ctx->pending_flags = false;
+        uint32_t flags = 0;
+        MA_HIP(hipMemcpy(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        if (flags) {
+            MA_HIP(hipMemset(ctx->dev_flags, 0, sizeof(flags)));
+            if (flags & 1u) {
+                set_error("integer division by zero in a dense kernel enqueued before this synchronize");
+                return MA_ERR_DIVIDE_BY_ZERO;
+            }
+        }
+    }
+    return MA_OK;
+}
+
+ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->async = enabled != 0;
+    return MA_OK;
+}
+
+void* ma_ctx_stream(ma_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int32_t ma_ctx_device(ma_ctx* ctx) { return ctx ? ctx->device : -1; }
+int32_t ma_ctx_compute_units(ma_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 64, MA_ERR_INVALID_ARGUMENT, "blocks_per_cu %d out of range",
+               blocks_per_cu);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->blocks_per_cu = blocks_per_cu == 0 ? kDefaultBlocksPerCu : blocks_per_cu;
+    return MA_OK;
+}
+
+ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->variant = variant;
+    return MA_OK;
+}
+
+ma_status ma_ctx_timer_start(ma_ctx* ctx) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_ctx_timer_stop(ma_ctx* ctx) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms) {
+    MA_REQUIRE(ctx != nullptr && out_ms != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_ms is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipEventSynchronize(ctx->ev_stop));
+    MA_HIP(hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+    return MA_OK;
+}
+
+// ---- memory ---------------------------------------------------------------------------------
+
+ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr) {
+    MA_REQUIRE(out_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "out_ptr is NULL");
+    *out_ptr = nullptr;
+    if (ma_device_count() <= 0) {
+        set_error("no HIP device is visible; pinned allocation needs the HIP runtime");
+        return MA_ERR_NO_DEVICE;
+    }
+    // hipHostMalloc returns page-aligned memory, which satisfies Vec64's 64-byte contract.
+    void* p = nullptr;
+    MA_HIP(hipHostMalloc(&p, bytes == 0 ? 64 : bytes, hipHostMallocPortable | hipHostMallocMapped));
+    *out_ptr = p;
+    return MA_OK;
+}
+
+ma_status ma_free_pinned(void* ptr) {
+    if (!ptr) return MA_OK;
+    MA_HIP(hipHostFree(ptr));
+    return MA_OK;
+}
+
+ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
+    MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
+    *out_dev_ptr = nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipMalloc(out_dev_ptr, bytes == 0 ? 64 : bytes));
+    return MA_OK;
+}
+
+ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!dev_ptr) return MA_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_HIP(hipFree(dev_ptr));
+    return MA_OK;
+}
+
+ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (bytes == 0) return MA_OK;
+    MA_REQUIRE(dst_dev && src_host, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (bytes == 0) return MA_OK;
+    MA_REQUIRE(dst_host && src_dev, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (bytes == 0) return MA_OK;
+    MA_REQUIRE(dst_dev != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, ctx->stream));
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+int32_t ma_pointer_kind(const void* ptr) {
+    if (ma_device_count() <= 0) return kPageable;
+    return (int32_t)pointer_kind(ptr);
+}
+
+// ---- synthetic inputs -------------------------------------------------------------------------
+
+ma_status ma_synth_iota_i64(ma_ctx* ctx, int64_t* dst, size_t n, int64_t start) {
+    return launch_fill(ctx, dst, n, IotaI64{start});
+}
+ma_status ma_synth_iota_f64(ma_ctx* ctx, double* dst, size_t n, int64_t start) {
+    return launch_fill(ctx, dst, n, IotaF64{start});
+}
+ma_status ma_synth_iota_i32(ma_ctx* ctx, int32_t* dst, size_t n, int32_t start) {
+    return launch_fill(ctx, dst, n, IotaI32{start});
+}
+ma_status ma_synth_iota_f32(ma_ctx* ctx, float* dst, size_t n, int32_t start) {
+    return launch_fill(ctx, dst, n, IotaF32{start});
+}
+ma_status ma_synth_splitmix_i64(ma_ctx* ctx, int64_t* dst, size_t n, uint64_t seed, uint64_t first_index) {
+    return launch_fill(ctx, dst, n, SplitI64{seed, first_index});
+}
+ma_status ma_synth_splitmix_f64(ma_ctx* ctx, double* dst, size_t n, uint64_t seed, uint64_t first_index) {
+    return launch_fill(ctx, dst, n, SplitF64{seed, first_index});
+}
+
+ma_status ma_synth_validity(ma_ctx* ctx, uint8_t* dst_bits, size_t n_bits, uint64_t seed, uint64_t first_index,
+                            uint32_t null_every) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (n_bits == 0) return MA_OK;
+    MA_REQUIRE(dst_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "dst_bits is NULL");
+    MA_REQUIRE(null_every >= 1, MA_ERR_INVALID_ARGUMENT, "null_every must be >= 1");
+    MA_REQUIRE(((uintptr_t)dst_bits & 7) == 0, MA_ERR_INVALID_ARGUMENT, "validity bitmap must be 8-byte aligned");
+    MA_REQUIRE(pointer_kind(dst_bits) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "synthetic generators need a device-reachable destination");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    size_t n_words = (n_bits + 63) / 64;
+    int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(validity_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (uint64_t*)dst_bits, n_bits, seed,
+                       first_index, null_every);
+    MA_HIP(hipGetLastError());
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+}  // extern "C"

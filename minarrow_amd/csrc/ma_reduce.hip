@@ -1,0 +1,493 @@
+// Sum / valid-count / mean reductions for gfx950 (MI355X).
+//
+// Replaces the reference's only sum implementations, which live in its bench binaries:
+//   simd_sum_i64 / simd_sum_f64      benches/benchmark_parallel_simd.rs:44-59, 63-78
+//   rayon_simd_sum_{i64,f64}         benches/benchmark_parallel_simd.rs:81-98   (par_chunks(1<<20) + tree sum)
+//   4x-unrolled accumulators         benches/hotloop_benchmark_simd.rs:56-174
+//   scalar `for &v in slice`         benches/hotloop_benchmark_std.rs:49-57
+//
+// Design:
+//   * HBM-bound scan, 8 B/row (4 B/row for 32-bit types) + 1/8 B/row of validity. No MFMA.
+//   * A workgroup = 4 wave64s. A wave owns a contiguous run of UNROLL KiB: lane k issues UNROLL
+//     back-to-back 16-byte loads (global_load_dwordx4), 1 KiB per wave-instruction, before it consumes any.
+//   * Tiles are dealt round-robin to workgroups (tile t -> workgroup t mod grid), grid = CUs x blocks/CU,
+//     so at any instant all CUs stream neighbouring DRAM pages.
+//   * Validity: one u64 word covers 64 rows = one wave64. Lanes 0..W load the W+1 words that cover the
+//     wave's run, funnel-shift them onto the run's first bit (any bit offset works), popcount them for the
+//     valid-count, and hand each lane its R bits per load through a cross-lane read.
+//   * Integers accumulate in wrapping u64. Floats accumulate in double-double (Knuth two-sum): the
+//     kernel is bandwidth-bound with >6x VALU headroom, so the result is within 1 ULP of the exactly
+//     rounded sum regardless of order, and bit-reproducible for a fixed grid.
+//   * Wave reduce by shuffles -> 4 LDS slots -> one 32-byte partial per workgroup -> the workgroup that
+//     draws the last ticket folds all partials in index order (agent-scope release/acquire).
+#include <type_traits>
+
+#include "ma_common.hpp"
+
+namespace ma {
+
+// ------------------------------------------------------------------------------------------------
+// 16-byte vectors
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<int64_t> {
+    typedef long long type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<uint64_t> {
+    typedef unsigned long long type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<int32_t> {
+    typedef int type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<uint32_t> {
+    typedef unsigned int type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+
+// ------------------------------------------------------------------------------------------------
+// Accumulators
+// ------------------------------------------------------------------------------------------------
+
+// Wrapping 64-bit integer accumulator. i32 sign-extends, u32 zero-extends; i64/u64 pass through.
+struct IntAcc {
+    uint64_t s;
+    __device__ __forceinline__ void init() { s = 0; }
+    template <typename T>
+    __device__ __forceinline__ void add(T v) {
+        s += (uint64_t)(int64_t)v;  // (int64_t) of an unsigned 32-bit value is its zero extension
+    }
+    __device__ __forceinline__ void merge(const IntAcc& o) { s += o.s; }
+    __device__ __forceinline__ void shfl_down_merge(int off) {
+        s += (uint64_t)__shfl_down((unsigned long long)s, off, 64);
+    }
+    __device__ __forceinline__ void to_partial(Partial& p) const {
+        p.a = s;
+        p.b = 0;
+    }
+    __device__ __forceinline__ void from_words(uint64_t a, uint64_t) { s = a; }
+};
+
+// Double-double accumulator: hi + lo carries the running sum to ~106 bits.
+struct DDAcc {
+    double hi, lo;
+    __device__ __forceinline__ void init() {
+        hi = 0.0;
+        lo = 0.0;
+    }
+    // Knuth two-sum: t + e == hi + v exactly.
+    __device__ __forceinline__ void add_d(double v) {
+        double t = hi + v;
+        double bp = t - hi;
+        double e = (hi - (t - bp)) + (v - bp);
+        hi = t;
+        lo += e;
+    }
+    template <typename T>
+    __device__ __forceinline__ void add(T v) {
+        add_d((double)v);
+    }
+    __device__ __forceinline__ void merge(const DDAcc& o) {
+        double t = hi + o.hi;
+        double bp = t - hi;
+        double e = (hi - (t - bp)) + (o.hi - bp);
+        hi = t;
+        lo += e + o.lo;
+    }
+    __device__ __forceinline__ void shfl_down_merge(int off) {
+        DDAcc o;
+        o.hi = __shfl_down(hi, off, 64);
+        o.lo = __shfl_down(lo, off, 64);
+        merge(o);
+    }
+    // Renormalise so that hi is the correctly rounded value of hi + lo (fast two-sum).
+    __device__ __forceinline__ void normalise() {
+        // Inf/NaN in the data (or an overflow) poisons `lo` with NaN while `hi` already holds the IEEE
+        // answer a plain sum would give; only a finite pair is renormalised.
+        if (isfinite(hi) && isfinite(lo)) {
+            double t = hi + lo;
+            lo = lo - (t - hi);
+            hi = t;
+        } else {
+            lo = 0.0;
+        }
+    }
+    __device__ __forceinline__ void to_partial(Partial& p) const {
+        p.a = (uint64_t)__double_as_longlong(hi);
+        p.b = (uint64_t)__double_as_longlong(lo);
+    }
+    __device__ __forceinline__ void from_words(uint64_t a, uint64_t b) {
+        hi = __longlong_as_double((long long)a);
+        lo = __longlong_as_double((long long)b);
+    }
+};
+
+template <typename T>
+struct AccOf {
+    typedef IntAcc type;
+};
+template <>
+struct AccOf<double> {
+    typedef DDAcc type;
+};
+template <>
+struct AccOf<float> {
+    typedef DDAcc type;
+};
+
+template <typename V, bool NT>
+__device__ __forceinline__ V load16(const V* p) {
+    if constexpr (NT) {
+        return __builtin_nontemporal_load(p);
+    } else {
+        return *p;
+    }
+}
+
+// Agent-scope relaxed load: bypasses this CU's L1 (global_load ... sc1).
+__device__ __forceinline__ uint64_t load_agent(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct SumArgs {
+    const void* data;       // element pointer of the window
+    size_t n;               // rows in the window
+    size_t head;            // leading rows handled by the ragged path so that data+head is 16-byte aligned
+    size_t n_tiles;         // full workgroup tiles after `head`
+    const uint64_t* words;  // validity words (8-byte aligned base) or nullptr
+    size_t bit_off;         // bit index of row 0 relative to `words`
+    size_t last_word;       // index of the last word that holds a window bit
+    Partial* partials;
+    unsigned int* ticket;
+    uint64_t* out_a;        // integer sum / double bits (f64 result) — may be nullptr
+    uint64_t* out_b;        // double-double low part — may be nullptr
+    uint64_t* out_cnt;      // valid count — may be nullptr
+    double* out_mean;       // sum / count — may be nullptr
+    int mode;               // 0: out_a = final value (int, or rounded double); 1: out_a/out_b = double-double
+    int is_signed;          // integer mean: interpret the 64-bit sum as signed
+};
+
+template <typename T, int UNROLL, bool MASKED, bool NT>
+__global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
+    typedef typename Vec16<T>::type V;
+    typedef typename AccOf<T>::type Acc;
+    constexpr int R = 16 / (int)sizeof(T);           // rows per lane per load
+    constexpr int LPW = 64 / R;                      // lanes that share one validity word
+    constexpr int WPT = R * UNROLL;                  // validity words per wave run
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63;
+    const unsigned wave = tid >> 6;
+    const T* __restrict__ data = (const T*)a.data;
+
+    Acc acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r].init();
+    uint64_t cnt = 0;
+
+    // ---- full tiles: 16-byte loads, no bounds checks --------------------------------------------
+    for (size_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+        const V* __restrict__ p = (const V*)(data + row0) + lane;
+        V v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(p + (size_t)u * 64);
+
+        if constexpr (MASKED) {
+            const size_t bit0 = a.bit_off + row0;
+            const size_t w0 = bit0 >> 6;
+            const unsigned sh = (unsigned)(bit0 & 63);
+            uint64_t mw = 0;
+            if (lane <= (unsigned)WPT && w0 + lane <= a.last_word) mw = a.words[w0 + lane];
+            uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
+            uint64_t aw = sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;  // word `lane` of the run, bit 0 = run row 64*lane
+            if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                uint64_t w = (uint64_t)__shfl((unsigned long long)aw, u * R + (int)(lane / LPW), 64);
+                unsigned bits = (unsigned)(w >> ((lane % LPW) * R));
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    T x = ((bits >> r) & 1u) ? v[u][r] : (T)0;
+                    acc[r].add(x);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+            }
+        }
+    }
+
+    // ---- ragged rows: the unaligned head and whatever follows the last full tile -----------------
+    if (blockIdx.x == gridDim.x - 1) {
+        const size_t tail_start = a.head + a.n_tiles * TILE_ROWS;
+        const size_t n_ragged = a.head + (a.n - tail_start);
+        const uint8_t* bytes = (const uint8_t*)a.words;
+        for (size_t i = tid; i < n_ragged; i += kBlock) {
+            size_t row = i < a.head ? i : tail_start + (i - a.head);
+            T x = data[row];
+            if constexpr (MASKED) {
+                size_t bit = a.bit_off + row;
+                unsigned valid = (bytes[bit >> 3] >> (bit & 7)) & 1u;
+                cnt += valid;
+                x = valid ? x : (T)0;
+            }
+            acc[0].add(x);
+        }
+    }
+    if constexpr (!MASKED) {
+        // Dense: every row is valid; credit the count once.
+        if (blockIdx.x == 0 && tid == 0) cnt = a.n;
+    }
+
+    // ---- workgroup reduce -----------------------------------------------------------------------
+#pragma unroll
+    for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc[0].shfl_down_merge(off);
+        cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+    }
+    __shared__ Partial lds[kWaves];
+    __shared__ int is_last;
+    if (lane == 0) {
+        acc[0].to_partial(lds[wave]);
+        lds[wave].cnt = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Acc s;
+        s.from_words(lds[0].a, lds[0].b);
+        uint64_t c = lds[0].cnt;
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            Acc o;
+            o.from_words(lds[w].a, lds[w].b);
+            s.merge(o);
+            c += lds[w].cnt;
+        }
+        Partial p;
+        s.to_partial(p);
+        p.cnt = c;
+        p.pad = 0;
+        a.partials[blockIdx.x] = p;
+        // Publish: release at agent scope, drain, then take a ticket (MI355X guide, Guideline 16).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = ticket == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+
+    // ---- the last workgroup folds every partial, in index order per thread, then across threads ----
+    Acc tot;
+    tot.init();
+    uint64_t tc = 0;
+    for (unsigned i = tid; i < gridDim.x; i += kBlock) {
+        const uint64_t* q = (const uint64_t*)&a.partials[i];
+        Acc o;
+        o.from_words(load_agent(q), load_agent(q + 1));
+        tot.merge(o);
+        tc += load_agent(q + 2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot.shfl_down_merge(off);
+        tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
+    }
+    __syncthreads();  // lds[] is reused
+    if (lane == 0) {
+        tot.to_partial(lds[wave]);
+        lds[wave].cnt = tc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Acc s;
+        s.from_words(lds[0].a, lds[0].b);
+        uint64_t c = lds[0].cnt;
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            Acc o;
+            o.from_words(lds[w].a, lds[w].b);
+            s.merge(o);
+            c += lds[w].cnt;
+        }
+        double as_double;
+        if constexpr (std::is_same<Acc, DDAcc>::value) {
+            DDAcc& d = reinterpret_cast<DDAcc&>(s);
+            d.normalise();
+            as_double = d.hi;
+            if (a.mode == 1) {
+                if (a.out_a) *a.out_a = (uint64_t)__double_as_longlong(d.hi);
+                if (a.out_b) *a.out_b = (uint64_t)__double_as_longlong(d.lo);
+            } else {
+                if (a.out_a) *a.out_a = (uint64_t)__double_as_longlong(d.hi);
+            }
+        } else {
+            IntAcc& q = reinterpret_cast<IntAcc&>(s);
+            as_double = a.is_signed ? (double)(int64_t)q.s : (double)q.s;
+            if (a.out_a) *a.out_a = q.s;
+        }
+        if (a.out_cnt) *a.out_cnt = c;
+        if (a.out_mean) *a.out_mean = c ? as_double / (double)c : __longlong_as_double(0x7ff8000000000000ll);
+        *a.ticket = 0;  // ready for the next launch on this stream
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------
+
+template <typename T, int UNROLL, bool MASKED, bool NT>
+static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
+    hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+}
+
+template <typename T>
+static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                          int64_t null_count, int mode, bool is_signed, void* out_a, void* out_b,
+                          uint64_t* out_cnt, double* out_mean) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(n == 0 || data != nullptr, MA_ERR_INVALID_ARGUMENT, "data is NULL");
+    MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "data pointer %p is not aligned to its element size",
+               (const void*)data);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+
+    // The reference gates on the cached null count / all_true_mask before touching a mask
+    // (src/kernels/arithmetic/simd.rs:144,454): no mask, or a mask known to be all-valid => dense kernel.
+    const bool masked = mask_bits != nullptr && null_count != 0 && n != 0;
+
+    CallScope scope(ctx);
+    SumArgs a{};
+    const void* d = nullptr;
+    MA_TRY(scope.in(data, n * sizeof(T), &d));
+    a.data = d;
+    a.n = n;
+    if (masked) {
+        MA_TRY(scope.in_mask(mask_bits, mask_bit_offset, n, &a.words, &a.bit_off));
+        a.last_word = (a.bit_off + n - 1) >> 6;
+    }
+    // Scalar outputs: directly into caller memory when it is device-reachable, else via the pinned slot.
+    ResultSlot* slot = ctx->result;
+    auto route = [&](void* user) -> bool { return user != nullptr && pointer_kind(user) != kPageable; };
+    const bool direct_a = route(out_a), direct_b = route(out_b), direct_c = route(out_cnt), direct_m = route(out_mean);
+    const bool any_slot = (out_a && !direct_a) || (out_b && !direct_b) || (out_cnt && !direct_c) || (out_mean && !direct_m);
+    MA_REQUIRE(!(ctx->async && any_slot), MA_ERR_INVALID_ARGUMENT,
+               "async mode needs device-reachable (pinned or device) output pointers");
+    a.out_a = out_a ? (direct_a ? (uint64_t*)out_a : &slot->a) : nullptr;
+    a.out_b = out_b ? (direct_b ? (uint64_t*)out_b : &slot->b) : nullptr;
+    a.out_cnt = out_cnt ? (direct_c ? out_cnt : &slot->cnt) : nullptr;
+    double* mean_slot = (double*)&slot[1].a;
+    a.out_mean = out_mean ? (direct_m ? out_mean : mean_slot) : nullptr;
+    a.mode = mode;
+    a.is_signed = is_signed ? 1 : 0;
+    a.partials = ctx->partials;
+    a.ticket = ctx->ticket;
+
+    constexpr int R = 16 / (int)sizeof(T);
+    const int variant = ctx->variant;
+    const int unroll = (variant & 2) ? 4 : 8;
+    const bool nt = (variant & 1) != 0;
+    const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
+    // Rows in front of the first 16-byte boundary.
+    size_t head = 0;
+    if (n) {
+        uintptr_t mis = (uintptr_t)a.data & 15;
+        head = mis ? (16 - mis) / sizeof(T) : 0;
+        if (head > n) head = n;
+    }
+    a.head = head;
+    a.n_tiles = (n - head) / tile_rows;
+    int grid = grid_for(ctx, a.n_tiles);
+
+#define MA_LAUNCH(U, M, N) launch_sum<T, U, M, N>(ctx, a, grid)
+    if (masked) {
+        if (unroll == 8) { if (nt) MA_LAUNCH(8, true, true); else MA_LAUNCH(8, true, false); }
+        else             { if (nt) MA_LAUNCH(4, true, true); else MA_LAUNCH(4, true, false); }
+    } else {
+        if (unroll == 8) { if (nt) MA_LAUNCH(8, false, true); else MA_LAUNCH(8, false, false); }
+        else             { if (nt) MA_LAUNCH(4, false, true); else MA_LAUNCH(4, false, false); }
+    }
+#undef MA_LAUNCH
+    MA_HIP(hipGetLastError());
+    MA_TRY(end_call(ctx, scope));
+    if (!ctx->async) {
+        if (out_a && !direct_a) memcpy(out_a, &slot->a, 8);
+        if (out_b && !direct_b) memcpy(out_b, &slot->b, 8);
+        if (out_cnt && !direct_c) *out_cnt = slot->cnt;
+        if (out_mean && !direct_m) *out_mean = *mean_slot;
+    }
+    return MA_OK;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+#define MA_DEFINE_INT_SUM(NAME, T, OUT_T, SIGNED)                                                                   \
+    ma_status ma_##NAME##_sum(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset, \
+                              int64_t null_count, OUT_T* out_sum, uint64_t* out_valid_count) {                       \
+        return sum_impl<T>(ctx, data, n, mask_bits, mask_bit_offset, null_count, 0, SIGNED, out_sum, nullptr,       \
+                           out_valid_count, nullptr);                                                               \
+    }                                                                                                               \
+    ma_status ma_##NAME##_mean(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits,                       \
+                               size_t mask_bit_offset, int64_t null_count, double* out_mean,                        \
+                               uint64_t* out_valid_count) {                                                         \
+        return sum_impl<T>(ctx, data, n, mask_bits, mask_bit_offset, null_count, 0, SIGNED, nullptr, nullptr,       \
+                           out_valid_count, out_mean);                                                              \
+    }
+
+MA_DEFINE_INT_SUM(i64, int64_t, int64_t, true)
+MA_DEFINE_INT_SUM(u64, uint64_t, uint64_t, false)
+MA_DEFINE_INT_SUM(i32, int32_t, int64_t, true)
+MA_DEFINE_INT_SUM(u32, uint32_t, uint64_t, false)
+
+#define MA_DEFINE_FLOAT_SUM(NAME, T)                                                                                \
+    ma_status ma_##NAME##_sum(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset, \
+                              int64_t null_count, double* out_sum, uint64_t* out_valid_count) {                     \
+        return sum_impl<T>(ctx, data, n, mask_bits, mask_bit_offset, null_count, 0, true, out_sum, nullptr,         \
+                           out_valid_count, nullptr);                                                               \
+    }                                                                                                               \
+    ma_status ma_##NAME##_sum_dd(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits,                     \
+                                 size_t mask_bit_offset, int64_t null_count, double* out_hi, double* out_lo,        \
+                                 uint64_t* out_valid_count) {                                                       \
+        return sum_impl<T>(ctx, data, n, mask_bits, mask_bit_offset, null_count, 1, true, out_hi, out_lo,           \
+                           out_valid_count, nullptr);                                                               \
+    }                                                                                                               \
+    ma_status ma_##NAME##_mean(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits,                       \
+                               size_t mask_bit_offset, int64_t null_count, double* out_mean,                        \
+                               uint64_t* out_valid_count) {                                                         \
+        return sum_impl<T>(ctx, data, n, mask_bits, mask_bit_offset, null_count, 0, true, nullptr, nullptr,         \
+                           out_valid_count, out_mean);                                                              \
+    }
+
+MA_DEFINE_FLOAT_SUM(f64, double)
+MA_DEFINE_FLOAT_SUM(f32, float)
+
+}  // extern "C"

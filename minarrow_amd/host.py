@@ -1,0 +1,237 @@
+"""Host-side convenience layer over the C ABI (minarrow_amd.ffi) used by the tests and bench.py.
+
+It only moves addresses and sizes across the boundary; all arithmetic happens in the HIP kernels.
+Buffers may be numpy arrays (pageable host memory: the library stages them), `DeviceBuffer`s,
+`PinnedBuffer`s (the Vec64 stand-in), torch tensors, or raw integer addresses.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import ffi
+
+_DTYPE_TAG = {
+    np.dtype(np.int64): "i64",
+    np.dtype(np.uint64): "u64",
+    np.dtype(np.int32): "i32",
+    np.dtype(np.uint32): "u32",
+    np.dtype(np.float64): "f64",
+    np.dtype(np.float32): "f32",
+}
+_TAG_DTYPE = {v: k for k, v in _DTYPE_TAG.items()}
+
+
+def tag_of(dtype) -> str:
+    return _DTYPE_TAG[np.dtype(dtype)]
+
+
+def dtype_of(tag: str) -> np.dtype:
+    return _TAG_DTYPE[tag]
+
+
+def addr_of(x) -> int:
+    """Raw address of anything buffer-like. None -> 0 (NULL)."""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if isinstance(x, (DeviceBuffer, PinnedBuffer)):
+        return x.ptr
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("numpy buffers passed across the C ABI must be C-contiguous")
+        return x.ctypes.data
+    if hasattr(x, "data_ptr"):  # torch tensor
+        return int(x.data_ptr())
+    raise TypeError(f"cannot take the address of {type(x)!r}")
+
+
+class DeviceBuffer:
+    """Device-resident bytes owned through ma_dev_alloc / ma_dev_free."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ffi.check(ctx.lib.ma_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = int(p.value)
+
+    def offset(self, nbytes: int) -> int:
+        return self.ptr + int(nbytes)
+
+    def upload(self, arr: np.ndarray, byte_offset: int = 0) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        assert byte_offset + arr.nbytes <= self.nbytes
+        ffi.check(self.ctx.lib.ma_dev_upload(self.ctx.handle, self.ptr + byte_offset, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, count: int, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(int(count), dtype=dtype)
+        assert byte_offset + out.nbytes <= self.nbytes
+        ffi.check(self.ctx.lib.ma_dev_download(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.ctx.lib.ma_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """64-byte aligned pinned host memory from ma_alloc64_pinned (hipHostMalloc): the Vec64 stand-in.
+    `view(dtype)` exposes it to numpy without a copy; kernels read and write it in place."""
+
+    def __init__(self, nbytes: int):
+        self.lib = ffi.load_library()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ffi.check(self.lib.ma_alloc64_pinned(self.nbytes, C.byref(p)))
+        self.ptr = int(p.value)
+
+    def view(self, dtype, count: Optional[int] = None) -> np.ndarray:
+        dt = np.dtype(dtype)
+        count = self.nbytes // dt.itemsize if count is None else int(count)
+        buf = (C.c_uint8 * (count * dt.itemsize)).from_address(self.ptr)
+        return np.frombuffer(buf, dtype=dt, count=count)
+
+    def free(self) -> None:
+        if self.ptr:
+            self.lib.ma_free_pinned(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one HIP stream (ma_ctx)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = ffi.load_library()
+        h = C.c_void_p()
+        if stream is None:
+            ffi.check(self.lib.ma_ctx_create(int(device), C.byref(h)))
+        else:
+            ffi.check(self.lib.ma_ctx_create_on_stream(int(device), int(stream), C.byref(h)))
+        self.handle = h.value
+        self.device = int(device)
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def close(self) -> None:
+        if self.handle:
+            self.lib.ma_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self) -> None:
+        ffi.check(self.lib.ma_ctx_synchronize(self.handle))
+
+    def set_async(self, on: bool) -> None:
+        ffi.check(self.lib.ma_ctx_set_async(self.handle, 1 if on else 0))
+
+    def set_blocks_per_cu(self, n: int) -> None:
+        ffi.check(self.lib.ma_ctx_set_blocks_per_cu(self.handle, int(n)))
+
+    def set_variant(self, v: int) -> None:
+        ffi.check(self.lib.ma_ctx_set_variant(self.handle, int(v)))
+
+    @property
+    def compute_units(self) -> int:
+        return int(self.lib.ma_ctx_compute_units(self.handle))
+
+    def timer_start(self) -> None:
+        ffi.check(self.lib.ma_ctx_timer_start(self.handle))
+
+    def timer_stop(self) -> None:
+        ffi.check(self.lib.ma_ctx_timer_stop(self.handle))
+
+    def timer_elapsed_ms(self) -> float:
+        ms = C.c_float()
+        ffi.check(self.lib.ma_ctx_timer_elapsed_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    # -- memory ----------------------------------------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr: np.ndarray, pad_bytes: int = 0) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes + pad_bytes)
+        if pad_bytes:
+            ffi.check(self.lib.ma_dev_memset(self.handle, buf.ptr, 0, buf.nbytes))
+        if arr.nbytes:
+            buf.upload(arr)
+        return buf
+
+    # -- synthetic inputs ------------------------------------------------------------------------
+    def synth_iota(self, tag: str, dst, n: int, start: int = 0) -> None:
+        fn = getattr(self.lib, f"ma_synth_iota_{tag}")
+        ffi.check(fn(self.handle, addr_of(dst), int(n), int(start)))
+
+    def synth_splitmix(self, tag: str, dst, n: int, seed: int, first_index: int = 0) -> None:
+        fn = getattr(self.lib, f"ma_synth_splitmix_{tag}")
+        ffi.check(fn(self.handle, addr_of(dst), int(n), int(seed), int(first_index)))
+
+    def synth_validity(self, dst, n_bits: int, seed: int, first_index: int = 0, null_every: int = 10) -> None:
+        ffi.check(self.lib.ma_synth_validity(self.handle, addr_of(dst), int(n_bits), int(seed), int(first_index),
+                                             int(null_every)))
+
+    # -- reductions ------------------------------------------------------------------------------
+    def sum(self, tag: str, data, n: int, mask=None, mask_bit_offset: int = 0, null_count: int = -1) -> Tuple:
+        """(sum, valid_count). Integer sums come back as Python ints (wrapped to 64 bits), float sums as float."""
+        fn = getattr(self.lib, f"ma_{tag}_sum")
+        cnt = C.c_uint64()
+        if tag in ("f64", "f32"):
+            out = C.c_double()
+        elif tag in ("i64", "i32"):
+            out = C.c_int64()
+        else:
+            out = C.c_uint64()
+        ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
+                     C.addressof(out), C.addressof(cnt)))
+        return out.value, int(cnt.value)
+
+    def sum_dd(self, tag: str, data, n: int, mask=None, mask_bit_offset: int = 0, null_count: int = -1):
+        """(hi, lo, valid_count) — unevaluated double-double sum for f64/f32."""
+        fn = getattr(self.lib, f"ma_{tag}_sum_dd")
+        hi, lo, cnt = C.c_double(), C.c_double(), C.c_uint64()
+        ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
+                     C.addressof(hi), C.addressof(lo), C.addressof(cnt)))
+        return hi.value, lo.value, int(cnt.value)
+
+    def mean(self, tag: str, data, n: int, mask=None, mask_bit_offset: int = 0, null_count: int = -1):
+        fn = getattr(self.lib, f"ma_{tag}_mean")
+        out, cnt = C.c_double(), C.c_uint64()
+        ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
+                     C.addressof(out), C.addressof(cnt)))
+        return out.value, int(cnt.value)
+
+    def sum_into(self, tag: str, data, n: int, out_sum, out_count=None, mask=None, mask_bit_offset: int = 0,
+                 null_count: int = -1, dd_lo=None) -> None:
+        """Enqueue-style variant: results are written to caller-provided (device-reachable) addresses."""
+        if dd_lo is not None:
+            fn = getattr(self.lib, f"ma_{tag}_sum_dd")
+            ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
+                         addr_of(out_sum), addr_of(dd_lo), addr_of(out_count)))
+        else:
+            fn = getattr(self.lib, f"ma_{tag}_sum")
+            ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
+                         addr_of(out_sum), addr_of(out_count)))
