@@ -223,7 +223,7 @@ def main() -> int:
                 "columns": ["i64", "f64"],
                 "parallelism": f"row-chunk x{world}" + (" + RCCL all-gather of scalars" if distributed else ""),
                 "variant": args.variant,
-                "blocks_per_cu": args.blocks_per_cu or 8,
+                "blocks_per_cu": args.blocks_per_cu or "auto",
             },
             "hbm_gbps": total_rows * 2 * 8 * args.steps / elapsed / 1e9,
             "parity_ok": bool(ok),

@@ -18,7 +18,7 @@ namespace ma {
 constexpr int kBlock = 256;       // threads per workgroup: 4 wave64s, one per SIMD of a CU
 constexpr int kWaves = kBlock / 64;
 constexpr int kMaxGrid = 16384;   // upper bound on workgroups of a reduction launch (scratch is sized for it)
-constexpr int kDefaultBlocksPerCu = 8;
+constexpr int kDefaultBlocksPerCu = 2;  // streaming kernels: two waves per SIMD (profiles/r01_sweep_sum_v2.txt)
 
 // One reduction partial: 32 bytes so that a workgroup's record never straddles a 64-B line with
 // more than one neighbour.
@@ -69,7 +69,7 @@ struct ma_ctx {
     bool owns_stream = false;
     bool async = false;
     int num_cus = 0;
-    int blocks_per_cu = ma::kDefaultBlocksPerCu;
+    int blocks_per_cu = 0;  // 0 = each kernel's own default
     int variant = 0;
     std::mutex mu;
 
@@ -121,8 +121,9 @@ class CallScope {
     std::vector<Temp> temps_;
 };
 
-inline int grid_for(const ma_ctx* ctx, size_t work_items) {
-    size_t cap = (size_t)ctx->num_cus * (size_t)(ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : kDefaultBlocksPerCu);
+inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0) {
+    if (blocks_per_cu <= 0) blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : kDefaultBlocksPerCu;
+    size_t cap = (size_t)ctx->num_cus * (size_t)blocks_per_cu;
     if (cap > (size_t)kMaxGrid) cap = kMaxGrid;
     if (work_items < 1) work_items = 1;
     return (int)(work_items < cap ? work_items : cap);

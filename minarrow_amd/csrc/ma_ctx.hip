@@ -343,7 +343,7 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
     MA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 64, MA_ERR_INVALID_ARGUMENT, "blocks_per_cu %d out of range",
                blocks_per_cu);
     std::lock_guard<std::mutex> lock(ctx->mu);
-    ctx->blocks_per_cu = blocks_per_cu == 0 ? kDefaultBlocksPerCu : blocks_per_cu;
+    ctx->blocks_per_cu = blocks_per_cu;
     return MA_OK;
 }
 

@@ -409,9 +409,24 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     a.ticket = ctx->ticket;
 
     constexpr int R = 16 / (int)sizeof(T);
+    // Launch shape. Measured on MI355X at 10^9 rows (profiles/r01_sweep_sum_v2.txt): what matters is ~8 KiB of
+    // loads in flight per SIMD (unroll x workgroups/CU = 8); more only queues, less starves. Dense 8-byte
+    // scans are fastest with ONE wave per SIMD and 8 loads each; anything with per-row work between the
+    // loads (validity bits, 4 rows per lane) wants two waves per SIMD to overlap it.
+    // ctx->variant: bit 0 = plain (temporal) loads instead of non-temporal; bits 1-3 = unroll
+    // {0: auto, 1: 2, 2: 4, 3: 8, 4: 16}. ctx->blocks_per_cu: 0 = auto.
     const int variant = ctx->variant;
-    const int unroll = (variant & 2) ? 4 : 8;
-    const bool nt = (variant & 1) != 0;
+    const bool nt = (variant & 1) == 0;
+    const bool lean = !masked && R == 2;
+    int unroll = lean ? 8 : 4;
+    switch ((variant >> 1) & 7) {
+        case 1: unroll = 2; break;
+        case 2: unroll = 4; break;
+        case 3: unroll = 8; break;
+        case 4: unroll = (R * 16 < 64 && !masked) ? 16 : 8; break;
+        default: break;
+    }
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean ? 1 : 2);
     const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
     // Rows in front of the first 16-byte boundary.
     size_t head = 0;
@@ -422,17 +437,30 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     }
     a.head = head;
     a.n_tiles = (n - head) / tile_rows;
-    int grid = grid_for(ctx, a.n_tiles);
+    int grid = grid_for(ctx, a.n_tiles, bpc);
 
-#define MA_LAUNCH(U, M, N) launch_sum<T, U, M, N>(ctx, a, grid)
+#define MA_LAUNCH_U(U, M)                                     \
+    do {                                                      \
+        if (nt) launch_sum<T, U, M, true>(ctx, a, grid);      \
+        else launch_sum<T, U, M, false>(ctx, a, grid);        \
+    } while (0)
     if (masked) {
-        if (unroll == 8) { if (nt) MA_LAUNCH(8, true, true); else MA_LAUNCH(8, true, false); }
-        else             { if (nt) MA_LAUNCH(4, true, true); else MA_LAUNCH(4, true, false); }
+        switch (unroll) {
+            case 2: MA_LAUNCH_U(2, true); break;
+            case 8: MA_LAUNCH_U(8, true); break;
+            default: MA_LAUNCH_U(4, true); break;
+        }
     } else {
-        if (unroll == 8) { if (nt) MA_LAUNCH(8, false, true); else MA_LAUNCH(8, false, false); }
-        else             { if (nt) MA_LAUNCH(4, false, true); else MA_LAUNCH(4, false, false); }
+        switch (unroll) {
+            case 2: MA_LAUNCH_U(2, false); break;
+            case 8: MA_LAUNCH_U(8, false); break;
+            case 16:
+                if constexpr (R * 16 < 64) { MA_LAUNCH_U(16, false); } else { MA_LAUNCH_U(8, false); }
+                break;
+            default: MA_LAUNCH_U(4, false); break;
+        }
     }
-#undef MA_LAUNCH
+#undef MA_LAUNCH_U
     MA_HIP(hipGetLastError());
     MA_TRY(end_call(ctx, scope));
     if (!ctx->async) {

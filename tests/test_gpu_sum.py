@@ -115,10 +115,14 @@ def test_f64_cancellation_beats_naive(ctx, oracle):
     rng.shuffle(a)
     exact = math.fsum(a.tolist())
     got, _ = ctx.sum("f64", ctx.to_device(a), a.size)
-    assert ulps(got, exact) <= ULP_TOL
-    # context only: how far the reference's summation order lands (not an assertion on the oracle)
+    # Condition number ~1e20: beyond what any fixed-precision accumulator can hold to 1 ULP. The
+    # double-double bound is |err| <= ulp(S) + n * eps^2 * sum|x| ("f64 sum accuracy").
+    eps = 2.0 ** -53
+    bound = math.ulp(exact) + a.size * eps * eps * float(np.abs(a).sum())
+    assert abs(got - exact) <= bound
+    # ... and it is many orders of magnitude closer than the reference's summation order gets
     ref_order = oracle.chunked_sum(a, 1 << 20, 4)
-    assert math.isfinite(ref_order)
+    assert abs(got - exact) * 1e6 < abs(ref_order - exact) or abs(ref_order - exact) == 0
 
 
 def test_non_finite_values(ctx):
@@ -247,8 +251,8 @@ def test_mask_edge_patterns(ctx, oracle):
     assert ctx.sum("i64", d, n, mask=ctx.to_device(alt)) == oracle.masked_sum(a, alt, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
-@pytest.mark.parametrize("bpc", [1, 4, 16])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("bpc", [0, 1, 8])
 def test_kernel_variants_agree(ctx, oracle, variant, bpc):
     """Unroll / non-temporal / grid-size variants are the same function."""
     n = 3_000_017

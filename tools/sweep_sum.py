@@ -17,8 +17,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--variants", type=str, default="0,1,2,3")
-    ap.add_argument("--bpcs", type=str, default="2,4,8,16")
+    ap.add_argument("--variants", type=str, default="0,2,4,6,8,3,5,7")
+    ap.add_argument("--bpcs", type=str, default="0,1,2,3,4,8")
     ap.add_argument("--types", type=str, default="i64,f64")
     ap.add_argument("--out", type=str, default="")
     args = ap.parse_args()
@@ -52,7 +52,7 @@ def main():
         ctx.set_async(False)
         for (v, b, m), ms in sorted(best.items(), key=lambda kv: kv[1]):
             bytes_ = n * esz + (n / 8 if m else 0)
-            row = {"type": tag, "masked": m, "variant": v, "unroll": 4 if v & 2 else 8, "nt": bool(v & 1),
+            row = {"type": tag, "masked": m, "variant": v, "unroll": {0: "auto", 1: 2, 2: 4, 3: 8, 4: 16}[(v >> 1) & 7], "nt": not (v & 1),
                    "blocks_per_cu": b, "ms": ms, "gbps": bytes_ / ms / 1e6, "grows": n / ms / 1e6}
             results.append(row)
             print(f"{tag} masked={int(m)} unroll={row['unroll']} nt={int(row['nt'])} bpc={b:2d}  "
