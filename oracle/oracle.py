@@ -134,3 +134,297 @@ def masked_sum(a: np.ndarray, bits: np.ndarray, bit_offset: int = 0):
     else:
         raise TypeError(a.dtype)
     return out.value, int(cnt.value)
+
+
+# ---- elementwise arithmetic / FMA / bitmask kernels ---------------------------------------------------
+
+OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "remainder": 4, "power": 5, "floordiv": 6}
+OK, LENGTH_MISMATCH, PANIC_DIV_ZERO, PANIC_OVERFLOW = 0, 1, 2, 4
+
+_TAGS = {
+    np.dtype(np.int8): "i8", np.dtype(np.int16): "i16", np.dtype(np.int32): "i32", np.dtype(np.int64): "i64",
+    np.dtype(np.uint8): "u8", np.dtype(np.uint16): "u16", np.dtype(np.uint32): "u32", np.dtype(np.uint64): "u64",
+    np.dtype(np.float32): "f32", np.dtype(np.float64): "f64",
+}
+# build.rs:67-110 lane tables: AVX-512 / AVX2 / SSE2+NEON
+LANES = {"avx512": {1: 64, 2: 32, 4: 16, 8: 8}, "avx2": {1: 32, 2: 16, 4: 8, 8: 4}, "sse2": {1: 16, 2: 8, 4: 4, 8: 2}}
+
+
+def tag(dtype) -> str:
+    return _TAGS[np.dtype(dtype)]
+
+
+def aligned_empty(n: int, dtype, align: int = 64, offset_bytes: int = 0) -> np.ndarray:
+    """Uninitialised array whose data pointer is `offset_bytes` past an `align`-byte boundary
+    (Vec64 gives 64-byte alignment, src/lib.rs:99; offset_bytes != 0 forces the scalar fallback)."""
+    dt = np.dtype(dtype)
+    raw = np.empty(n * dt.itemsize + align + offset_bytes + 64, dtype=np.uint8)
+    start = (-raw.ctypes.data) % align + offset_bytes
+    return raw[start:start + n * dt.itemsize].view(dt)
+
+
+def aligned_copy(a: np.ndarray, align: int = 64, offset_bytes: int = 0) -> np.ndarray:
+    out = aligned_empty(a.size, a.dtype, align, offset_bytes)
+    out[:] = a
+    return out
+
+
+def pack_bits(valid) -> np.ndarray:
+    """bool sequence -> Arrow validity bytes (LSB first), padded so whole-u64-word reads stay in bounds."""
+    valid = np.asarray(valid, dtype=bool)
+    packed = np.packbits(valid, bitorder="little")
+    return pad_bits(packed, valid.size)
+
+
+def pad_bits(bits: np.ndarray, len_bits: int, extra_words: int = 2) -> np.ndarray:
+    n_bytes = ((len_bits + 63) // 64 + extra_words) * 8
+    out = aligned_empty(max(n_bytes, 8), np.uint8)
+    out[:] = 0
+    m = min(bits.size, out.size)
+    out[:m] = bits[:m]
+    return out
+
+
+def unpack_bits(bits: np.ndarray, n: int, offset: int = 0) -> np.ndarray:
+    return np.unpackbits(np.ascontiguousarray(bits), bitorder="little")[offset:offset + n].astype(bool)
+
+
+def _declare_kernels(l: C.CDLL) -> None:
+    vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+    for t in ("i8", "i16", "i32", "i64", "u8", "u16", "u32", "u64"):
+        getattr(l, f"mo_int_dense_std_{t}").argtypes = [i32, vp, vp, vp, sz]
+        getattr(l, f"mo_int_masked_std_{t}").argtypes = [i32, vp, vp, vp, vp, vp, sz]
+        getattr(l, f"mo_int_dense_simd_{t}").argtypes = [i32, vp, vp, vp, sz, i32]
+        getattr(l, f"mo_int_masked_simd_{t}").argtypes = [i32, vp, vp, vp, sz, vp, vp, sz, i32]
+        getattr(l, f"mo_apply_int_{t}").argtypes = [vp, sz, vp, sz, i32, vp, sz, vp, vp, i32, vp]
+    for t in ("f32", "f64"):
+        getattr(l, f"mo_float_dense_{t}").argtypes = [i32, vp, vp, vp, sz]
+        getattr(l, f"mo_float_masked_std_{t}").argtypes = [i32, vp, vp, vp, vp, vp, sz]
+        getattr(l, f"mo_float_masked_simd_{t}").argtypes = [i32, vp, vp, vp, sz, vp, vp, sz, i32]
+        getattr(l, f"mo_apply_float_{t}").argtypes = [vp, sz, vp, sz, i32, vp, sz, vp, vp, i32, vp]
+        getattr(l, f"mo_fma_dense_{t}").argtypes = [vp, vp, vp, vp, sz]
+        getattr(l, f"mo_fma_dense_{t}").restype = None
+        getattr(l, f"mo_fma_masked_{t}").argtypes = [vp, vp, vp, vp, vp, vp, sz]
+        getattr(l, f"mo_fma_masked_{t}").restype = None
+        getattr(l, f"mo_apply_fma_{t}").argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, i32]
+    l.mo_bitmask_new_set_all.argtypes = [vp, sz, i32]
+    l.mo_bitmask_new_set_all.restype = None
+    l.mo_bitmask_count_ones.argtypes = [vp, sz]
+    l.mo_bitmask_count_ones.restype = sz
+    l.mo_simd_mask_bits.argtypes = [vp, sz, sz, sz, i32]
+    l.mo_simd_mask_bits.restype = u64
+    l.mo_write_mask_bits.argtypes = [vp, sz, u64, i32]
+    l.mo_write_mask_bits.restype = None
+    for name in ("mo_all_true_mask_simd", "mo_all_false_mask_simd"):
+        getattr(l, name).argtypes = [vp, sz, i32]
+    for name in ("mo_all_true_mask_std", "mo_all_false_mask_std"):
+        getattr(l, name).argtypes = [vp, sz]
+    l.mo_bitmask_binop.argtypes = [i32, vp, sz, vp, sz, sz, vp]
+    l.mo_bitmask_binop.restype = None
+    l.mo_bitmask_not.argtypes = [vp, sz, sz, vp]
+    l.mo_bitmask_not.restype = None
+    l.mo_bitmask_in.argtypes = [vp, sz, vp, sz, sz, vp]
+    l.mo_bitmask_in.restype = None
+    l.mo_bitmask_not_in.argtypes = [vp, sz, vp, sz, sz, vp, vp]
+    l.mo_bitmask_not_in.restype = None
+    for name in ("mo_bitmask_eq", "mo_bitmask_ne"):
+        getattr(l, name).argtypes = [vp, sz, vp, sz, sz, vp]
+    for name in ("mo_bitmask_all_eq", "mo_bitmask_all_ne"):
+        getattr(l, name).argtypes = [vp, sz, vp, sz, sz]
+    l.mo_bitmask_popcount.argtypes = [vp, sz, sz]
+    l.mo_bitmask_popcount.restype = sz
+    l.mo_merge_bitmasks.argtypes = [vp, vp, sz, vp]
+    l.mo_bitmask_union.argtypes = [vp, vp, sz, vp]
+    l.mo_bitmask_union.restype = None
+    for t, ct in (("u8", C.c_uint8), ("u16", C.c_uint16), ("u32", C.c_uint32), ("u64", C.c_uint64)):
+        fn = getattr(l, f"mo_simd_eq_mask_{t}")
+        fn.argtypes = [vp, sz, ct, ct, vp]
+        fn.restype = None
+
+
+_kernels_declared = False
+
+
+def klib() -> C.CDLL:
+    global _kernels_declared
+    l = lib()
+    if not _kernels_declared:
+        _declare_kernels(l)
+        _kernels_declared = True
+    return l
+
+
+def _opcode(op) -> int:
+    return OPS[op] if isinstance(op, str) else int(op)
+
+
+def _mask_words(n: int) -> np.ndarray:
+    out = aligned_empty(((n + 63) // 64 + 2) * 8, np.uint8)
+    out[:] = 0
+    return out
+
+
+def apply_int(lhs: np.ndarray, rhs: np.ndarray, op, mask: np.ndarray | None = None, mask_len: int | None = None,
+              lanes: int = 8):
+    """apply_int_<t> (src/kernels/arithmetic/dispatch.rs:65-133). Inputs are used where they lie: 64-byte
+    aligned inputs take the SIMD body, anything else the scalar body, as in the reference.
+    Returns (status, out, out_mask_bits or None, used_simd)."""
+    t = tag(lhs.dtype)
+    out = aligned_empty(lhs.size, lhs.dtype)
+    out[:] = 0
+    out_mask = _mask_words(lhs.size) if mask is not None else None
+    used = C.c_int(0)
+    st = getattr(klib(), f"mo_apply_int_{t}")(_p(lhs), lhs.size, _p(rhs), rhs.size, _opcode(op), _p(mask),
+                                              lhs.size if mask_len is None else mask_len, _p(out), _p(out_mask), lanes,
+                                              C.addressof(used))
+    return st, out, out_mask, bool(used.value)
+
+
+def apply_float(lhs: np.ndarray, rhs: np.ndarray, op, mask: np.ndarray | None = None, mask_len: int | None = None,
+                lanes: int = 8):
+    """apply_float_<t> (dispatch.rs:138-206). Returns (status, out, out_mask_bits or None, used_simd)."""
+    t = tag(lhs.dtype)
+    out = aligned_empty(lhs.size, lhs.dtype)
+    out[:] = 0
+    out_mask = _mask_words(lhs.size) if mask is not None else None
+    used = C.c_int(0)
+    st = getattr(klib(), f"mo_apply_float_{t}")(_p(lhs), lhs.size, _p(rhs), rhs.size, _opcode(op), _p(mask),
+                                                lhs.size if mask_len is None else mask_len, _p(out), _p(out_mask),
+                                                lanes, C.addressof(used))
+    return st, out, out_mask, bool(used.value)
+
+
+def apply_fma(lhs, rhs, acc, mask=None, force_unfused: bool = False):
+    """apply_fma_<t> (dispatch.rs:211-290). Returns (status, out, out_mask_bits or None)."""
+    t = tag(lhs.dtype)
+    out = aligned_empty(lhs.size, lhs.dtype)
+    out[:] = 0
+    out_mask = _mask_words(lhs.size) if mask is not None else None
+    st = getattr(klib(), f"mo_apply_fma_{t}")(_p(lhs), lhs.size, _p(rhs), rhs.size, _p(acc), acc.size, _p(mask), _p(out),
+                                              _p(out_mask), 1 if force_unfused else 0)
+    return st, out, out_mask
+
+
+def int_body(kind: str, lhs, rhs, op, mask=None, mask_len=None, lanes: int = 8):
+    """One of the four integer bodies by name: dense_std | masked_std | dense_simd | masked_simd."""
+    t = tag(lhs.dtype)
+    n = lhs.size
+    out = aligned_empty(n, lhs.dtype)
+    out[:] = 0
+    l = klib()
+    if kind == "dense_std":
+        return getattr(l, f"mo_int_dense_std_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(out), n), out, None
+    if kind == "dense_simd":
+        return getattr(l, f"mo_int_dense_simd_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(out), n, lanes), out, None
+    out_mask = _mask_words(n)
+    l.mo_bitmask_new_set_all(_p(out_mask), n, 1)
+    if kind == "masked_std":
+        st = getattr(l, f"mo_int_masked_std_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(mask), _p(out), _p(out_mask), n)
+    else:
+        st = getattr(l, f"mo_int_masked_simd_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(mask), n if mask_len is None else mask_len,
+                                                   _p(out), _p(out_mask), n, lanes)
+    return st, out, out_mask
+
+
+def float_body(kind: str, lhs, rhs, op, mask=None, mask_len=None, lanes: int = 8):
+    t = tag(lhs.dtype)
+    n = lhs.size
+    out = aligned_empty(n, lhs.dtype)
+    out[:] = 0
+    l = klib()
+    if kind == "dense":
+        return getattr(l, f"mo_float_dense_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(out), n), out, None
+    out_mask = _mask_words(n)
+    l.mo_bitmask_new_set_all(_p(out_mask), n, 1)
+    if kind == "masked_std":
+        st = getattr(l, f"mo_float_masked_std_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(mask), _p(out), _p(out_mask), n)
+    else:
+        st = getattr(l, f"mo_float_masked_simd_{t}")(_opcode(op), _p(lhs), _p(rhs), _p(mask), n if mask_len is None else mask_len,
+                                                     _p(out), _p(out_mask), n, lanes)
+    return st, out, out_mask
+
+
+LOGICAL = {"and": 0, "or": 1, "xor": 2}
+
+
+def bitmask_binop(op, lhs, lhs_off, rhs, rhs_off, n):
+    out = _mask_words(n)
+    klib().mo_bitmask_binop(LOGICAL[op] if isinstance(op, str) else op, _p(lhs), lhs_off, _p(rhs), rhs_off, n, _p(out))
+    return out
+
+
+def bitmask_not(src, off, n):
+    out = _mask_words(n)
+    klib().mo_bitmask_not(_p(src), off, n, _p(out))
+    return out
+
+
+def bitmask_in(lhs, lhs_off, rhs, rhs_off, n):
+    out = _mask_words(n)
+    klib().mo_bitmask_in(_p(lhs), lhs_off, _p(rhs), rhs_off, n, _p(out))
+    return out
+
+
+def bitmask_not_in(lhs, lhs_off, rhs, rhs_off, n):
+    out, scratch = _mask_words(n), _mask_words(n)
+    klib().mo_bitmask_not_in(_p(lhs), lhs_off, _p(rhs), rhs_off, n, _p(out), _p(scratch))
+    return out
+
+
+def bitmask_eq(a, ao, b, bo, n, negate: bool = False):
+    """(panics, out_bits)"""
+    out = _mask_words(n)
+    fn = klib().mo_bitmask_ne if negate else klib().mo_bitmask_eq
+    return bool(fn(_p(a), ao, _p(b), bo, n, _p(out))), out
+
+
+def bitmask_all_eq(a, ao, b, bo, n) -> int:
+    return int(klib().mo_bitmask_all_eq(_p(a), ao, _p(b), bo, n))
+
+
+def bitmask_all_ne(a, ao, b, bo, n) -> int:
+    return int(klib().mo_bitmask_all_ne(_p(a), ao, _p(b), bo, n))
+
+
+def bitmask_popcount(bits, off, n) -> int:
+    return int(klib().mo_bitmask_popcount(_p(bits), off, n))
+
+
+def all_true(bits, n, lanes: int | None = 8) -> bool:
+    l = klib()
+    return bool(l.mo_all_true_mask_std(_p(bits), n) if lanes is None else l.mo_all_true_mask_simd(_p(bits), n, lanes))
+
+
+def all_false(bits, n, lanes: int | None = 8) -> bool:
+    l = klib()
+    return bool(l.mo_all_false_mask_std(_p(bits), n) if lanes is None else l.mo_all_false_mask_simd(_p(bits), n, lanes))
+
+
+def merge_bitmasks(l_bits, r_bits, n):
+    out = _mask_words(n)
+    some = klib().mo_merge_bitmasks(_p(l_bits), _p(r_bits), n, _p(out))
+    return out if some else None
+
+
+def bitmask_union(l_bits, r_bits, n):
+    out = _mask_words(n)
+    klib().mo_bitmask_union(_p(l_bits), _p(r_bits), n, _p(out))
+    return out
+
+
+def simd_eq_mask(data: np.ndarray, field_mask: int, target: int):
+    out = _mask_words(data.size)
+    getattr(klib(), f"mo_simd_eq_mask_{tag(data.dtype)}")(_p(data), data.size, field_mask, target, _p(out))
+    return out
+
+
+def count_ones(bits, n) -> int:
+    return int(klib().mo_bitmask_count_ones(_p(bits), n))
+
+
+def simd_mask_bits(bits, mask_len, offset, n, lanes) -> int:
+    return int(klib().mo_simd_mask_bits(_p(bits), mask_len, offset, n, lanes))
+
+
+def write_mask_bits(out_bits, offset, mbits, lanes) -> None:
+    klib().mo_write_mask_bits(_p(out_bits), offset, mbits, lanes)
