@@ -187,6 +187,96 @@ ma_status ma_f64_mean(ma_ctx* ctx, const double* data, size_t n, const uint8_t* 
 ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                       int64_t null_count, double* out_mean, uint64_t* out_valid_count);
 
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise arithmetic — same names, argument order and meaning as the reference's L3 functions:
+ *   apply_int_{i32,u32,i64,u64}(lhs, rhs, op, mask) -> Result<IntegerArray<T>, KernelError>
+ *                                            src/kernels/arithmetic/dispatch.rs:65-133, :376-379
+ *   apply_float_{f32,f64}(lhs, rhs, op, mask)  src/kernels/arithmetic/dispatch.rs:138-206, :389-402
+ *   apply_fma_{f32,f64}(lhs, rhs, acc, mask)   src/kernels/arithmetic/dispatch.rs:211-290, :404-418
+ * whose bodies are int_{dense,masked}_body_{std,simd}, float_{dense,masked}_body_*, fma_*_body_*
+ * (src/kernels/arithmetic/std.rs:41-230, src/kernels/arithmetic/simd.rs:52-751).
+ *
+ *  - `op` is an ArithmeticOperator code (MA_OP_*).
+ *  - lhs_len != rhs_len (or acc_len)  -> MA_ERR_LENGTH_MISMATCH            (confirm_equal_len, dispatch.rs:81)
+ *  - mask_bits == NULL  <=> `mask: None`: dense body, out_mask_bits is ignored (may be NULL).
+ *    mask_bits != NULL  <=> `Some(&mask)`: bit (mask_bit_offset + i) gates row i; null rows store 0
+ *    (simd.rs:315, std.rs:132); out_mask_bits receives the result validity, bits >= len zero.
+ *    The reference passes a whole Bitmask (offset 0); mask_bit_offset lets an Arrow slice be used as is.
+ *  - Integers: Add/Sub/Mul wrap; Power = repeated wrapping multiply with exponent `rhs.to_u32().unwrap_or(0)`;
+ *    FloorDiv rounds toward -inf; MIN / -1 wraps (the reference's SIMD lanes do, its scalar tail panics).
+ *    Dense Div/Rem/FloorDiv with a zero divisor -> MA_ERR_DIVIDE_BY_ZERO (the reference panics, std.rs:53-77).
+ *    Masked Div/Rem/FloorDiv with a zero divisor -> value 0 and validity bit cleared (simd.rs:170-181, 319-326).
+ *  - Floats: IEEE 754 (x/0 = +-Inf or NaN, never an error); Remainder = fmod; Power = exp(rhs * ln(lhs))
+ *    (std.rs:153 — two libm calls, so last-ulp differences to a given CPU libm are expected);
+ *    FloorDiv = floor(lhs / rhs). FMA is fused (mul_add).
+ *  - `*_scalar_rhs` / `*_scalar_lhs` are the fused form of a length-1 operand: the reference materialises
+ *    vec64![x; n] and runs the two-array kernel (src/kernels/routing/broadcast.rs:25-112,
+ *    src/kernels/broadcast/array.rs:139-184); results are identical, 8 B/row less traffic.
+ *  - Inputs may alias each other but not `out`.
+ * ---------------------------------------------------------------------------------------------- */
+
+ma_status ma_apply_int_i32(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, const int32_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, int32_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_i32_scalar_rhs(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, int32_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int32_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_i32_scalar_lhs(ma_ctx* ctx, int32_t scalar, const int32_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int32_t* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_int_u32(ma_ctx* ctx, const uint32_t* lhs, size_t lhs_len, const uint32_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, uint32_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_u32_scalar_rhs(ma_ctx* ctx, const uint32_t* lhs, size_t lhs_len, uint32_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint32_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u32_scalar_lhs(ma_ctx* ctx, uint32_t scalar, const uint32_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint32_t* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_int_i64(ma_ctx* ctx, const int64_t* lhs, size_t lhs_len, const int64_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, int64_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_i64_scalar_rhs(ma_ctx* ctx, const int64_t* lhs, size_t lhs_len, int64_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int64_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_i64_scalar_lhs(ma_ctx* ctx, int64_t scalar, const int64_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int64_t* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_int_u64(ma_ctx* ctx, const uint64_t* lhs, size_t lhs_len, const uint64_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, uint64_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_u64_scalar_rhs(ma_ctx* ctx, const uint64_t* lhs, size_t lhs_len, uint64_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint64_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u64_scalar_lhs(ma_ctx* ctx, uint64_t scalar, const uint64_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint64_t* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_float_f32(ma_ctx* ctx, const float* lhs, size_t lhs_len, const float* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, float* out, uint8_t* out_mask_bits);
+ma_status ma_apply_float_f32_scalar_rhs(ma_ctx* ctx, const float* lhs, size_t lhs_len, float scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_float_f32_scalar_lhs(ma_ctx* ctx, float scalar, const float* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_float_f64(ma_ctx* ctx, const double* lhs, size_t lhs_len, const double* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, double* out, uint8_t* out_mask_bits);
+ma_status ma_apply_float_f64_scalar_rhs(ma_ctx* ctx, const double* lhs, size_t lhs_len, double scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_float_f64_scalar_lhs(ma_ctx* ctx, double scalar, const double* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                     uint8_t* out_mask_bits);
+
+ma_status ma_apply_fma_f32(ma_ctx* ctx, const float* lhs, size_t lhs_len, const float* rhs, size_t rhs_len,
+                        const float* acc, size_t acc_len, const uint8_t* mask_bits, size_t mask_bit_offset,
+                        float* out, uint8_t* out_mask_bits);
+
+ma_status ma_apply_fma_f64(ma_ctx* ctx, const double* lhs, size_t lhs_len, const double* rhs, size_t rhs_len,
+                        const double* acc, size_t acc_len, const uint8_t* mask_bits, size_t mask_bit_offset,
+                        double* out, uint8_t* out_mask_bits);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

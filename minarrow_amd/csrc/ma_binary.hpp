@@ -1,0 +1,569 @@
+// Elementwise binary arithmetic and FMA for gfx950: kernel templates + host dispatch, instantiated once per
+// element type by ma_binary_<t>.hip.
+//
+// Replaces (reference paths relative to the minarrow repository root):
+//   apply_int_{i32,u32,i64,u64,...}   src/kernels/arithmetic/dispatch.rs:65-133, :376-387
+//   apply_float_{f32,f64}             src/kernels/arithmetic/dispatch.rs:138-206, :389-402
+//   apply_fma_{f32,f64}               src/kernels/arithmetic/dispatch.rs:211-290, :404-418
+//   int_dense_body_{std,simd}         src/kernels/arithmetic/std.rs:41-80,   simd.rs:52-113
+//   int_masked_body_{std,simd}        src/kernels/arithmetic/std.rs:86-138,  simd.rs:118-370
+//   float_{dense,masked}_body_*       src/kernels/arithmetic/std.rs:144-194, simd.rs:376-589
+//   fma_{dense,masked}_body_*         src/kernels/arithmetic/std.rs:196-230, simd.rs:591-751
+//   maybe_broadcast_scalar_array      src/kernels/routing/broadcast.rs:25-112 (fused here: the scalar is a
+//                                     kernel argument instead of a materialised vec64![x; n])
+//
+// Two kernels per operation:
+//   vec kernel  — the bandwidth path. A wave owns a contiguous run; each lane moves 16 bytes per access
+//                 (global_load_dwordx4 / global_store_dwordx4, non-temporal), UNROLL accesses per operand in
+//                 flight before the first use. Needs lhs, rhs and out to share their offset modulo 16.
+//   row kernel  — one row per lane. Handles the unaligned head / ragged tail of the vec kernel, operand sets
+//                 whose 16-byte phases differ, and masked integer Div/Rem/FloorDiv, whose output validity
+//                 (valid && divisor != 0) is one wave64 ballot per 64 rows = one u64 word of the bitmap.
+// Output validity of every other masked op equals the input validity: a word-wise funnel-shift copy
+// (mask_copy_kernel) writes it, so the vec kernel only READS validity (to zero the null slots).
+#pragma once
+
+#include "ma_device.hpp"
+
+namespace ma {
+
+enum : int { kAA = 0, kAS = 1, kSA = 2 };  // array⊕array, array⊕scalar, scalar⊕array
+
+// ------------------------------------------------------------------------------------------------
+// Element functions. `dz` is set when an integer divisor is zero (value 0 is returned, as the masked
+// reference bodies store; the dense reference bodies panic — the host turns the latch into a status).
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool IS_FLOAT = std::is_floating_point<T>::value>
+struct Elem;
+
+template <typename T>
+struct Elem<T, false> {
+    typedef typename std::make_unsigned<T>::type U;
+    static constexpr bool kSigned = std::is_signed<T>::value;
+
+    // rhs.to_u32().unwrap_or(0) — std.rs:67
+    static __device__ __forceinline__ uint32_t exponent(T e) {
+        if (kSigned && e < (T)0) return 0u;
+        if ((uint64_t)e > 0xFFFFFFFFull) return 0u;
+        return (uint32_t)e;
+    }
+    // x.pow(e) with wrapping multiplies (release-mode Rust; equals simd.rs:94-101's repeated wrapping_mul)
+    static __device__ __forceinline__ T pow(T base, uint32_t e) {
+        U acc = 1, b = (U)base;
+        while (e) {
+            if (e & 1u) acc = (U)(acc * b);
+            b = (U)(b * b);
+            e >>= 1;
+        }
+        return (T)acc;
+    }
+    static __device__ __forceinline__ T div(T a, T b) {
+        if (kSigned && b == (T)-1) return (T)((U)0 - (U)a);  // MIN / -1 wraps to MIN like the SIMD lanes
+        return (T)(a / b);
+    }
+    static __device__ __forceinline__ T rem(T a, T b) {
+        if (kSigned && b == (T)-1) return (T)0;
+        return (T)(a % b);
+    }
+    template <int OP>
+    static __device__ __forceinline__ T apply(T a, T b, bool& dz) {
+        if constexpr (OP == MA_OP_ADD) return (T)((U)a + (U)b);
+        if constexpr (OP == MA_OP_SUBTRACT) return (T)((U)a - (U)b);
+        if constexpr (OP == MA_OP_MULTIPLY) return (T)((U)a * (U)b);
+        if constexpr (OP == MA_OP_POWER) return pow(a, exponent(b));
+        if constexpr (OP == MA_OP_DIVIDE || OP == MA_OP_REMAINDER || OP == MA_OP_FLOORDIV) {
+            if (b == (T)0) {
+                dz = true;
+                return (T)0;
+            }
+            if constexpr (OP == MA_OP_DIVIDE) return div(a, b);
+            if constexpr (OP == MA_OP_REMAINDER) return rem(a, b);
+            // FloorDiv — std.rs:68-77
+            T d = div(a, b), r = rem(a, b);
+            if (kSigned && r != (T)0 && ((T)(a ^ b)) < (T)0) return (T)((U)d - (U)1);
+            return d;
+        }
+        return (T)0;
+    }
+    static __device__ __forceinline__ T apply_rt(int op, T a, T b, bool& dz) {
+        switch (op) {
+            case MA_OP_ADD: return apply<MA_OP_ADD>(a, b, dz);
+            case MA_OP_SUBTRACT: return apply<MA_OP_SUBTRACT>(a, b, dz);
+            case MA_OP_MULTIPLY: return apply<MA_OP_MULTIPLY>(a, b, dz);
+            case MA_OP_DIVIDE: return apply<MA_OP_DIVIDE>(a, b, dz);
+            case MA_OP_REMAINDER: return apply<MA_OP_REMAINDER>(a, b, dz);
+            case MA_OP_POWER: return apply<MA_OP_POWER>(a, b, dz);
+            default: return apply<MA_OP_FLOORDIV>(a, b, dz);
+        }
+    }
+};
+
+template <>
+struct Elem<double, true> {
+    template <int OP>
+    static __device__ __forceinline__ double apply(double a, double b, bool&) {
+        if constexpr (OP == MA_OP_ADD) return a + b;
+        if constexpr (OP == MA_OP_SUBTRACT) return a - b;
+        if constexpr (OP == MA_OP_MULTIPLY) return a * b;
+        if constexpr (OP == MA_OP_DIVIDE) return a / b;
+        if constexpr (OP == MA_OP_REMAINDER) return fmod(a, b);       // Rust `%` on floats = C fmod
+        if constexpr (OP == MA_OP_POWER) return exp(b * log(a));      // std.rs:153: (rhs * lhs.ln()).exp()
+        if constexpr (OP == MA_OP_FLOORDIV) return floor(a / b);
+        return 0.0;
+    }
+    static __device__ __forceinline__ double apply_rt(int op, double a, double b, bool& dz) {
+        switch (op) {
+            case MA_OP_ADD: return apply<MA_OP_ADD>(a, b, dz);
+            case MA_OP_SUBTRACT: return apply<MA_OP_SUBTRACT>(a, b, dz);
+            case MA_OP_MULTIPLY: return apply<MA_OP_MULTIPLY>(a, b, dz);
+            case MA_OP_DIVIDE: return apply<MA_OP_DIVIDE>(a, b, dz);
+            case MA_OP_REMAINDER: return apply<MA_OP_REMAINDER>(a, b, dz);
+            case MA_OP_POWER: return apply<MA_OP_POWER>(a, b, dz);
+            default: return apply<MA_OP_FLOORDIV>(a, b, dz);
+        }
+    }
+    static __device__ __forceinline__ double fma3(double a, double b, double c) { return fma(a, b, c); }
+};
+
+template <>
+struct Elem<float, true> {
+    template <int OP>
+    static __device__ __forceinline__ float apply(float a, float b, bool&) {
+        if constexpr (OP == MA_OP_ADD) return a + b;
+        if constexpr (OP == MA_OP_SUBTRACT) return a - b;
+        if constexpr (OP == MA_OP_MULTIPLY) return a * b;
+        if constexpr (OP == MA_OP_DIVIDE) return a / b;
+        if constexpr (OP == MA_OP_REMAINDER) return fmodf(a, b);
+        // (rhs * lhs.ln()).exp() — std.rs:153. The reference's ln/exp are the host libm's logf/expf, which are
+        // correctly rounded in all but a handful of cases; evaluating both through f64 and rounding at the same
+        // three points (ln, product, exp) reproduces those bits instead of adding a second set of libm errors
+        // that the exp() would amplify by |b ln a|.
+        if constexpr (OP == MA_OP_POWER) {
+            float l = (float)log((double)a);
+            float y = b * l;
+            return (float)exp((double)y);
+        }
+        if constexpr (OP == MA_OP_FLOORDIV) return floorf(a / b);
+        return 0.0f;
+    }
+    static __device__ __forceinline__ float apply_rt(int op, float a, float b, bool& dz) {
+        switch (op) {
+            case MA_OP_ADD: return apply<MA_OP_ADD>(a, b, dz);
+            case MA_OP_SUBTRACT: return apply<MA_OP_SUBTRACT>(a, b, dz);
+            case MA_OP_MULTIPLY: return apply<MA_OP_MULTIPLY>(a, b, dz);
+            case MA_OP_DIVIDE: return apply<MA_OP_DIVIDE>(a, b, dz);
+            case MA_OP_REMAINDER: return apply<MA_OP_REMAINDER>(a, b, dz);
+            case MA_OP_POWER: return apply<MA_OP_POWER>(a, b, dz);
+            default: return apply<MA_OP_FLOORDIV>(a, b, dz);
+        }
+    }
+    static __device__ __forceinline__ float fma3(float a, float b, float c) { return fmaf(a, b, c); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Kernel arguments
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct BinArgs {
+    const T* lhs;           // element pointers of row 0 (nullptr for a scalar side)
+    const T* rhs;
+    const T* acc;           // FMA addend (nullptr otherwise)
+    T* out;
+    T scalar;               // the scalar side's value
+    size_t n;               // rows
+    size_t head;            // rows before the first 16-byte boundary (vec kernel starts here)
+    size_t n_tiles;         // full workgroup tiles the vec kernel covers
+    const uint64_t* words;  // input validity (8-byte aligned base) or nullptr
+    size_t bit_off;         // bit index of row 0 relative to `words`
+    size_t last_word;       // last word index holding a window bit
+    uint64_t* out_words;    // output validity words (row kernel in ballot mode) or nullptr
+    uint32_t* flags;        // device latch: bit 0 = integer divide by zero seen in a dense kernel
+    int op;                 // row kernel: runtime ArithmeticOperator
+    int kind;               // row kernel: kAA / kAS / kSA
+    int ballot_mask;        // row kernel: 1 = produce out_words by ballot over the whole array
+};
+
+// ------------------------------------------------------------------------------------------------
+// vec kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int OP, int KIND, bool MASKED, int UNROLL>
+__global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
+    typedef typename Vec16<T>::type V;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int WPT = R * UNROLL;
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool dz = false;
+
+    for (size_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+        V va[UNROLL], vb[UNROLL];
+        if constexpr (KIND != kSA) {
+            const V* __restrict__ p = (const V*)(a.lhs + row0) + lane;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+        }
+        if constexpr (KIND != kAS) {
+            const V* __restrict__ q = (const V*)(a.rhs + row0) + lane;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+        }
+        uint64_t aw = 0;
+        if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
+        V* __restrict__ o = (V*)(a.out + row0) + lane;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            unsigned bits = ~0u;
+            if constexpr (MASKED) bits = lane_bits<R>(aw, u, lane);
+            V r;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                T x = KIND == kSA ? a.scalar : (T)va[u][k];
+                T y = KIND == kAS ? a.scalar : (T)vb[u][k];
+                T v = Elem<T>::template apply<OP>(x, y, dz);
+                if constexpr (MASKED) v = ((bits >> k) & 1u) ? v : (T)0;  // null slots hold 0 (simd.rs:315)
+                r[k] = v;
+            }
+            store16<V, true>(o + (size_t)u * 64, r);
+        }
+    }
+    if constexpr (!MASKED && std::is_integral<T>::value &&
+                  (OP == MA_OP_DIVIDE || OP == MA_OP_REMAINDER || OP == MA_OP_FLOORDIV)) {
+        if (__any(dz) && lane == 0) atomicOr(a.flags, 1u);
+    }
+}
+
+// FMA vec kernel: out = fma(lhs, rhs, acc)
+template <typename T, bool MASKED, int UNROLL>
+__global__ __launch_bounds__(kBlock) void fma_vec_kernel(BinArgs<T> a) {
+    typedef typename Vec16<T>::type V;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int WPT = R * UNROLL;
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+        V va[UNROLL], vb[UNROLL], vc[UNROLL];
+        const V* __restrict__ p = (const V*)(a.lhs + row0) + lane;
+        const V* __restrict__ q = (const V*)(a.rhs + row0) + lane;
+        const V* __restrict__ c = (const V*)(a.acc + row0) + lane;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) vc[u] = load16<V, true>(c + (size_t)u * 64);
+        uint64_t aw = 0;
+        if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
+        V* __restrict__ o = (V*)(a.out + row0) + lane;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            unsigned bits = ~0u;
+            if constexpr (MASKED) bits = lane_bits<R>(aw, u, lane);
+            V r;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                T v = Elem<T>::fma3((T)va[u][k], (T)vb[u][k], (T)vc[u][k]);
+                if constexpr (MASKED) v = ((bits >> k) & 1u) ? v : (T)0;
+                r[k] = v;
+            }
+            store16<V, true>(o + (size_t)u * 64, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row kernel: one row per lane; a wave owns 64 consecutive rows = one validity word of the output.
+// Processes rows [0, head) and [tail_start, n) when ballot_mask == 0, or every row when ballot_mask == 1.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool MASKED, bool FMA>
+__global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t tail_start) {
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    const size_t n_words = (a.n + 63) >> 6;
+    bool dz_any = false;
+    for (size_t w = wave_id; w < n_words; w += n_waves) {
+        const size_t row = w * 64 + lane;
+        bool in_range = row < a.n && (a.ballot_mask || row < a.head || row >= tail_start);
+        // whole words strictly inside the vec kernel's range: nothing to do (wave-uniform test)
+        if (!a.ballot_mask && w * 64 >= a.head && w * 64 + 64 <= tail_start) continue;
+        bool valid = in_range;
+        bool dz = false;
+        if (in_range) {
+            if constexpr (MASKED) valid = row_bit(a.words, a.bit_off + row) != 0;
+            T v;
+            if constexpr (FMA) {
+                v = Elem<T>::fma3(a.lhs[row], a.rhs[row], a.acc[row]);
+            } else {
+                T x = a.kind == kSA ? a.scalar : a.lhs[row];
+                T y = a.kind == kAS ? a.scalar : a.rhs[row];
+                v = Elem<T>::apply_rt(a.op, x, y, dz);
+            }
+            if constexpr (MASKED) v = valid ? v : (T)0;
+            a.out[row] = v;
+        }
+        if constexpr (MASKED) {
+            if (a.ballot_mask) {
+                // out-mask = source validity && !div_zero (simd.rs:319-326); rows >= n contribute 0 bits.
+                unsigned long long word = __ballot(valid && !dz);
+                if (lane == 0) a.out_words[w] = word;
+            }
+        } else {
+            dz_any |= dz;
+        }
+    }
+    if constexpr (!MASKED && !FMA && std::is_integral<T>::value) {
+        if (__any(dz_any) && lane == 0) atomicOr(a.flags, 1u);
+    }
+}
+
+// Output validity = input validity window re-based to bit 0 (bits >= n zero). Defined in ma_bitmask.hip.
+ma_status launch_mask_copy(ma_ctx* ctx, const uint64_t* words, size_t bit_off, size_t n, uint64_t* out_words);
+
+// ------------------------------------------------------------------------------------------------
+// Host dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct BinaryCall {
+    int op = 0;
+    int kind = kAA;
+    const T* lhs = nullptr;
+    size_t lhs_len = 0;
+    const T* rhs = nullptr;
+    size_t rhs_len = 0;
+    const T* acc = nullptr;  // FMA only
+    size_t acc_len = 0;
+    bool fma = false;
+    T scalar = T();
+    const uint8_t* mask_bits = nullptr;
+    size_t mask_bit_offset = 0;
+    T* out = nullptr;
+    uint8_t* out_mask_bits = nullptr;
+};
+
+template <typename T, int OP, int KIND, bool MASKED>
+static void launch_vec(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll) {
+    if (unroll == 8) {
+        if constexpr (16 / sizeof(T) * 8 < 64) {
+            hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+}
+
+template <typename T, int OP, bool MASKED>
+static void launch_vec_kind(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll, int kind) {
+    switch (kind) {
+        case kAS: launch_vec<T, OP, kAS, MASKED>(ctx, a, grid, unroll); break;
+        case kSA: launch_vec<T, OP, kSA, MASKED>(ctx, a, grid, unroll); break;
+        default: launch_vec<T, OP, kAA, MASKED>(ctx, a, grid, unroll); break;
+    }
+}
+
+template <typename T, bool MASKED>
+static void launch_vec_op(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll, int kind, int op) {
+    constexpr bool kInt = std::is_integral<T>::value;
+    switch (op) {
+        case MA_OP_ADD: launch_vec_kind<T, MA_OP_ADD, MASKED>(ctx, a, grid, unroll, kind); break;
+        case MA_OP_SUBTRACT: launch_vec_kind<T, MA_OP_SUBTRACT, MASKED>(ctx, a, grid, unroll, kind); break;
+        case MA_OP_MULTIPLY: launch_vec_kind<T, MA_OP_MULTIPLY, MASKED>(ctx, a, grid, unroll, kind); break;
+        case MA_OP_POWER: launch_vec_kind<T, MA_OP_POWER, MASKED>(ctx, a, grid, unroll, kind); break;
+        case MA_OP_DIVIDE:
+            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_DIVIDE, MASKED>(ctx, a, grid, unroll, kind);
+            break;
+        case MA_OP_REMAINDER:
+            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_REMAINDER, MASKED>(ctx, a, grid, unroll, kind);
+            break;
+        default:
+            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_FLOORDIV, MASKED>(ctx, a, grid, unroll, kind);
+            break;
+    }
+}
+
+template <typename T>
+ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
+    constexpr bool kInt = std::is_integral<T>::value;
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(!(c.fma && kInt), MA_ERR_UNSUPPORTED, "FMA is defined for f32/f64 only");
+    MA_REQUIRE(c.fma || (c.op >= MA_OP_ADD && c.op <= MA_OP_FLOORDIV), MA_ERR_INVALID_ARGUMENT,
+               "unknown ArithmeticOperator code %d", c.op);
+    // confirm_equal_len — src/utils.rs:163-171 via dispatch.rs:81,228-229
+    size_t n = c.kind == kSA ? c.rhs_len : c.lhs_len;
+    if (c.kind == kAA && c.lhs_len != c.rhs_len) {
+        set_error("apply numeric: length mismatch (lhs: %zu, rhs: %zu)", c.lhs_len, c.rhs_len);
+        return MA_ERR_LENGTH_MISMATCH;
+    }
+    if (c.fma && c.acc_len != n) {
+        set_error("acc length mismatch (lhs: %zu, rhs: %zu)", n, c.acc_len);
+        return MA_ERR_LENGTH_MISMATCH;
+    }
+    if (n == 0) return MA_OK;
+    const bool masked = c.mask_bits != nullptr;
+    MA_REQUIRE(c.out != nullptr, MA_ERR_INVALID_ARGUMENT, "out is NULL");
+    MA_REQUIRE(c.kind == kSA || c.lhs != nullptr, MA_ERR_INVALID_ARGUMENT, "lhs is NULL");
+    MA_REQUIRE(c.kind == kAS || c.rhs != nullptr, MA_ERR_INVALID_ARGUMENT, "rhs is NULL");
+    MA_REQUIRE(!c.fma || c.acc != nullptr, MA_ERR_INVALID_ARGUMENT, "acc is NULL");
+    MA_REQUIRE(!masked || c.out_mask_bits != nullptr, MA_ERR_INVALID_ARGUMENT,
+               "a masked call needs an output bitmap (reference: Bitmask::new_set_all(len, true), dispatch.rs:92)");
+    auto aligned_elem = [](const void* p) { return ((uintptr_t)p % sizeof(T)) == 0; };
+    MA_REQUIRE(aligned_elem(c.lhs) && aligned_elem(c.rhs) && aligned_elem(c.acc) && aligned_elem(c.out),
+               MA_ERR_INVALID_ARGUMENT, "a data pointer is not aligned to its element size");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    BinArgs<T> a{};
+    const void* p = nullptr;
+    if (c.kind != kSA) {
+        MA_TRY(scope.in(c.lhs, n * sizeof(T), &p));
+        a.lhs = (const T*)p;
+    }
+    if (c.kind != kAS) {
+        MA_TRY(scope.in(c.rhs, n * sizeof(T), &p));
+        a.rhs = (const T*)p;
+    }
+    if (c.fma) {
+        MA_TRY(scope.in(c.acc, n * sizeof(T), &p));
+        a.acc = (const T*)p;
+    }
+    void* po = nullptr;
+    MA_TRY(scope.out(c.out, n * sizeof(T), &po));
+    a.out = (T*)po;
+    a.scalar = c.scalar;
+    a.n = n;
+    a.op = c.op;
+    a.kind = c.kind;
+    a.flags = ctx->dev_flags;
+    if (masked) {
+        MA_TRY(scope.in_mask(c.mask_bits, c.mask_bit_offset, n, &a.words, &a.bit_off));
+        a.last_word = (a.bit_off + n - 1) >> 6;
+        MA_TRY(scope.out_mask(c.out_mask_bits, n, &a.out_words));
+    }
+
+    const bool int_div = kInt && !c.fma &&
+                         (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
+    const bool ballot = masked && int_div;  // output validity depends on the data: row kernel over everything
+    // The vec kernel needs every array operand on the same 16-byte phase.
+    uintptr_t phase = (uintptr_t)a.out & 15;
+    bool same_phase = (c.kind == kSA || ((uintptr_t)a.lhs & 15) == phase) &&
+                      (c.kind == kAS || ((uintptr_t)a.rhs & 15) == phase) &&
+                      (!c.fma || ((uintptr_t)a.acc & 15) == phase);
+    constexpr int R = 16 / (int)sizeof(T);
+    // unroll: loads in flight per operand. Two array operands -> 4, one -> 8 (ctx->variant bits 1-3 override).
+    int unroll = (c.kind == kAA || c.fma) ? 4 : 8;
+    switch ((ctx->variant >> 1) & 7) {
+        case 2: unroll = 4; break;
+        case 3: unroll = 8; break;
+        default: break;
+    }
+    if (c.fma) unroll = 4;
+    if (R * unroll >= 64) unroll = 4;
+    const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
+    size_t head = 0, n_tiles = 0;
+    if (same_phase && !ballot) {
+        head = phase ? (16 - phase) / sizeof(T) : 0;
+        if (head > n) head = n;
+        n_tiles = (n - head) / tile_rows;
+    }
+    a.head = head;
+    a.n_tiles = n_tiles;
+    a.ballot_mask = ballot ? 1 : 0;
+    const size_t tail_start = ballot ? 0 : head + n_tiles * tile_rows;
+
+    if (masked && !ballot) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+    if (n_tiles) {
+        int grid = grid_for(ctx, n_tiles);
+        if (c.fma) {
+            if constexpr (!kInt) {
+                if (masked) hipLaunchKernelGGL((fma_vec_kernel<T, true, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((fma_vec_kernel<T, false, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+            }
+        } else if (masked) {
+            launch_vec_op<T, true>(ctx, a, grid, unroll, c.kind, c.op);
+        } else {
+            launch_vec_op<T, false>(ctx, a, grid, unroll, c.kind, c.op);
+        }
+        MA_HIP(hipGetLastError());
+    }
+    if (ballot || head > 0 || tail_start < n) {
+        size_t words_touched = ballot ? (n + 63) / 64 : ((head + 63) / 64 + (n - tail_start + 63) / 64 + 1);
+        int grid = grid_for(ctx, (words_touched + kWaves - 1) / kWaves, 8);
+        if (c.fma) {
+            if constexpr (!kInt) {
+                if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+                else hipLaunchKernelGGL((binary_row_kernel<T, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+            }
+        } else {
+            if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+            else hipLaunchKernelGGL((binary_row_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+        }
+        MA_HIP(hipGetLastError());
+    }
+
+    const bool may_latch = int_div && !masked;
+    if (may_latch && (ctx->async && !scope.staged())) ctx->pending_flags = true;
+    MA_TRY(end_call(ctx, scope));
+    if (may_latch && (!ctx->async || scope.staged())) {
+        uint32_t flags = 0;
+        MA_HIP(hipMemcpyAsync(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(hipStreamSynchronize(ctx->stream));
+        if (flags & 1u) {
+            MA_HIP(hipMemsetAsync(ctx->dev_flags, 0, sizeof(flags), ctx->stream));
+            MA_HIP(hipStreamSynchronize(ctx->stream));
+            // The reference panics here: "Division by zero" / "Remainder by zero" / "Floor division by zero"
+            // (src/kernels/arithmetic/std.rs:53-77); asserted by src/kernels/arithmetic/mod.rs:161-177.
+            set_error("%s by zero in a dense integer kernel",
+                      c.op == MA_OP_DIVIDE ? "Division" : c.op == MA_OP_REMAINDER ? "Remainder" : "Floor division");
+            return MA_ERR_DIVIDE_BY_ZERO;
+        }
+    }
+    return MA_OK;
+}
+
+}  // namespace ma
+
+// ------------------------------------------------------------------------------------------------
+// C ABI stamping
+// ------------------------------------------------------------------------------------------------
+#define MA_DEFINE_APPLY(FAMILY, TAG, T)                                                                               \
+    extern "C" ma_status ma_apply_##FAMILY##_##TAG(ma_ctx* ctx, const T* lhs, size_t lhs_len, const T* rhs,           \
+                                                   size_t rhs_len, int32_t op, const uint8_t* mask_bits,              \
+                                                   size_t mask_bit_offset, T* out, uint8_t* out_mask_bits) {          \
+        ::ma::BinaryCall<T> c;                                                                                        \
+        c.op = op; c.kind = ::ma::kAA; c.lhs = lhs; c.lhs_len = lhs_len; c.rhs = rhs; c.rhs_len = rhs_len;            \
+        c.mask_bits = mask_bits; c.mask_bit_offset = mask_bit_offset; c.out = out; c.out_mask_bits = out_mask_bits;   \
+        return ::ma::binary_impl<T>(ctx, c);                                                                          \
+    }                                                                                                                 \
+    extern "C" ma_status ma_apply_##FAMILY##_##TAG##_scalar_rhs(ma_ctx* ctx, const T* lhs, size_t lhs_len, T scalar,  \
+                                                                int32_t op, const uint8_t* mask_bits,                 \
+                                                                size_t mask_bit_offset, T* out,                       \
+                                                                uint8_t* out_mask_bits) {                             \
+        ::ma::BinaryCall<T> c;                                                                                        \
+        c.op = op; c.kind = ::ma::kAS; c.lhs = lhs; c.lhs_len = lhs_len; c.scalar = scalar;                           \
+        c.mask_bits = mask_bits; c.mask_bit_offset = mask_bit_offset; c.out = out; c.out_mask_bits = out_mask_bits;   \
+        return ::ma::binary_impl<T>(ctx, c);                                                                          \
+    }                                                                                                                 \
+    extern "C" ma_status ma_apply_##FAMILY##_##TAG##_scalar_lhs(ma_ctx* ctx, T scalar, const T* rhs, size_t rhs_len,  \
+                                                                int32_t op, const uint8_t* mask_bits,                 \
+                                                                size_t mask_bit_offset, T* out,                       \
+                                                                uint8_t* out_mask_bits) {                             \
+        ::ma::BinaryCall<T> c;                                                                                        \
+        c.op = op; c.kind = ::ma::kSA; c.rhs = rhs; c.rhs_len = rhs_len; c.scalar = scalar;                           \
+        c.mask_bits = mask_bits; c.mask_bit_offset = mask_bit_offset; c.out = out; c.out_mask_bits = out_mask_bits;   \
+        return ::ma::binary_impl<T>(ctx, c);                                                                          \
+    }
+
+#define MA_DEFINE_APPLY_FMA(TAG, T)                                                                                   \
+    extern "C" ma_status ma_apply_fma_##TAG(ma_ctx* ctx, const T* lhs, size_t lhs_len, const T* rhs, size_t rhs_len,  \
+                                            const T* acc, size_t acc_len, const uint8_t* mask_bits,                   \
+                                            size_t mask_bit_offset, T* out, uint8_t* out_mask_bits) {                 \
+        ::ma::BinaryCall<T> c;                                                                                        \
+        c.fma = true; c.kind = ::ma::kAA; c.lhs = lhs; c.lhs_len = lhs_len; c.rhs = rhs; c.rhs_len = rhs_len;         \
+        c.acc = acc; c.acc_len = acc_len;                                                                             \
+        c.mask_bits = mask_bits; c.mask_bit_offset = mask_bit_offset; c.out = out; c.out_mask_bits = out_mask_bits;   \
+        return ::ma::binary_impl<T>(ctx, c);                                                                          \
+    }

@@ -1,0 +1,4 @@
+// apply_int_u32 and its fused scalar-broadcast forms — src/kernels/arithmetic/dispatch.rs:65-133, :376-379.
+#include "ma_binary.hpp"
+
+MA_DEFINE_APPLY(int, u32, uint32_t)

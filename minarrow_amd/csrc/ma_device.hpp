@@ -1,0 +1,113 @@
+// Device-side building blocks shared by the streaming kernels (gfx950 / wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "ma_common.hpp"
+
+namespace ma {
+
+// ------------------------------------------------------------------------------------------------
+// 16-byte vectors: one global_load_dwordx4 / global_store_dwordx4 per lane, 1 KiB per wave instruction.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<int64_t> {
+    typedef long long type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<uint64_t> {
+    typedef unsigned long long type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Vec16<int32_t> {
+    typedef int type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<uint32_t> {
+    typedef unsigned int type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec16<int16_t> {
+    typedef short type __attribute__((ext_vector_type(8)));
+};
+template <>
+struct Vec16<uint16_t> {
+    typedef unsigned short type __attribute__((ext_vector_type(8)));
+};
+template <>
+struct Vec16<int8_t> {
+    typedef signed char type __attribute__((ext_vector_type(16)));
+};
+template <>
+struct Vec16<uint8_t> {
+    typedef unsigned char type __attribute__((ext_vector_type(16)));
+};
+
+template <typename V, bool NT>
+__device__ __forceinline__ V load16(const V* p) {
+    if constexpr (NT) {
+        return __builtin_nontemporal_load(p);
+    } else {
+        return *p;
+    }
+}
+
+template <typename V, bool NT>
+__device__ __forceinline__ void store16(V* p, V v) {
+    if constexpr (NT) {
+        __builtin_nontemporal_store(v, p);
+    } else {
+        *p = v;
+    }
+}
+
+// Agent-scope relaxed load: bypasses this CU's L1 (global_load ... sc1).
+__device__ __forceinline__ uint64_t load_agent(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Validity words for one wave's contiguous run of rows.
+//
+// A run covers WPT consecutive u64 words once it is shifted onto its first bit. Lane k (k <= WPT) loads
+// word w0+k; the pair (k, k+1) is funnel-shifted by the run's sub-word bit offset, so lane k ends up with
+// run-word k: bit j of it is the validity of run row 64*k + j. Works for ANY bit offset.
+// ------------------------------------------------------------------------------------------------
+template <int WPT>
+__device__ __forceinline__ uint64_t load_run_words(const uint64_t* __restrict__ words, size_t bit0, size_t last_word,
+                                                   unsigned lane) {
+    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+    const size_t w0 = bit0 >> 6;
+    const unsigned sh = (unsigned)(bit0 & 63);
+    uint64_t mw = 0;
+    if (lane <= (unsigned)WPT && w0 + lane <= last_word) mw = words[w0 + lane];
+    uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
+    return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
+}
+
+// The R validity bits of this lane's rows for load step `u` of the run (R rows per lane per 16-byte load).
+template <int R>
+__device__ __forceinline__ unsigned lane_bits(uint64_t run_word_of_lane, int u, unsigned lane) {
+    constexpr int LPW = 64 / R;  // lanes per validity word
+    uint64_t w = (uint64_t)__shfl((unsigned long long)run_word_of_lane, u * R + (int)(lane / LPW), 64);
+    return (unsigned)(w >> ((lane % LPW) * R)) & ((1u << R) - 1u);
+}
+
+__device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
+    return (unsigned)(((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
+}
+
+}  // namespace ma

@@ -20,41 +20,9 @@
 //     rounded sum regardless of order, and bit-reproducible for a fixed grid.
 //   * Wave reduce by shuffles -> 4 LDS slots -> one 32-byte partial per workgroup -> the workgroup that
 //     draws the last ticket folds all partials in index order (agent-scope release/acquire).
-#include <type_traits>
-
-#include "ma_common.hpp"
+#include "ma_device.hpp"
 
 namespace ma {
-
-// ------------------------------------------------------------------------------------------------
-// 16-byte vectors
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-struct Vec16;
-template <>
-struct Vec16<int64_t> {
-    typedef long long type __attribute__((ext_vector_type(2)));
-};
-template <>
-struct Vec16<uint64_t> {
-    typedef unsigned long long type __attribute__((ext_vector_type(2)));
-};
-template <>
-struct Vec16<double> {
-    typedef double type __attribute__((ext_vector_type(2)));
-};
-template <>
-struct Vec16<int32_t> {
-    typedef int type __attribute__((ext_vector_type(4)));
-};
-template <>
-struct Vec16<uint32_t> {
-    typedef unsigned int type __attribute__((ext_vector_type(4)));
-};
-template <>
-struct Vec16<float> {
-    typedef float type __attribute__((ext_vector_type(4)));
-};
 
 // ------------------------------------------------------------------------------------------------
 // Accumulators
@@ -146,20 +114,6 @@ struct AccOf<float> {
     typedef DDAcc type;
 };
 
-template <typename V, bool NT>
-__device__ __forceinline__ V load16(const V* p) {
-    if constexpr (NT) {
-        return __builtin_nontemporal_load(p);
-    } else {
-        return *p;
-    }
-}
-
-// Agent-scope relaxed load: bypasses this CU's L1 (global_load ... sc1).
-__device__ __forceinline__ uint64_t load_agent(const uint64_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 struct SumArgs {
     const void* data;       // element pointer of the window
     size_t n;               // rows in the window
@@ -183,7 +137,6 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     typedef typename Vec16<T>::type V;
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);           // rows per lane per load
-    constexpr int LPW = 64 / R;                      // lanes that share one validity word
     constexpr int WPT = R * UNROLL;                  // validity words per wave run
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
@@ -208,18 +161,11 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(p + (size_t)u * 64);
 
         if constexpr (MASKED) {
-            const size_t bit0 = a.bit_off + row0;
-            const size_t w0 = bit0 >> 6;
-            const unsigned sh = (unsigned)(bit0 & 63);
-            uint64_t mw = 0;
-            if (lane <= (unsigned)WPT && w0 + lane <= a.last_word) mw = a.words[w0 + lane];
-            uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
-            uint64_t aw = sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;  // word `lane` of the run, bit 0 = run row 64*lane
+            const uint64_t aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
             if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                uint64_t w = (uint64_t)__shfl((unsigned long long)aw, u * R + (int)(lane / LPW), 64);
-                unsigned bits = (unsigned)(w >> ((lane % LPW) * R));
+                const unsigned bits = lane_bits<R>(aw, u, lane);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     T x = ((bits >> r) & 1u) ? v[u][r] : (T)0;
@@ -239,13 +185,11 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     if (blockIdx.x == gridDim.x - 1) {
         const size_t tail_start = a.head + a.n_tiles * TILE_ROWS;
         const size_t n_ragged = a.head + (a.n - tail_start);
-        const uint8_t* bytes = (const uint8_t*)a.words;
         for (size_t i = tid; i < n_ragged; i += kBlock) {
             size_t row = i < a.head ? i : tail_start + (i - a.head);
             T x = data[row];
             if constexpr (MASKED) {
-                size_t bit = a.bit_off + row;
-                unsigned valid = (bytes[bit >> 3] >> (bit & 7)) & 1u;
+                unsigned valid = row_bit(a.words, a.bit_off + row);
                 cnt += valid;
                 x = valid ? x : (T)0;
             }

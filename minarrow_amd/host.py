@@ -235,3 +235,33 @@ class Context:
             fn = getattr(self.lib, f"ma_{tag}_sum")
             ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
                          addr_of(out_sum), addr_of(out_count)))
+
+    # -- elementwise arithmetic --------------------------------------------------------------------
+    def apply(self, tag: str, lhs, rhs, op: int, out, n_lhs: int, n_rhs: int, mask=None, mask_bit_offset: int = 0,
+              out_mask=None) -> None:
+        """ma_apply_{int,float}_<tag>(lhs, rhs, op, mask) -> out (+ out_mask). Raises MinarrowHipError with
+        .status = MA_ERR_LENGTH_MISMATCH / MA_ERR_DIVIDE_BY_ZERO like the reference's Err / panic."""
+        fam = "float" if tag in ("f32", "f64") else "int"
+        fn = getattr(self.lib, f"ma_apply_{fam}_{tag}")
+        ffi.check(fn(self.handle, addr_of(lhs), int(n_lhs), addr_of(rhs), int(n_rhs), int(op), addr_of(mask),
+                     int(mask_bit_offset), addr_of(out), addr_of(out_mask)))
+
+    def apply_scalar(self, tag: str, side: str, arr, n: int, scalar, op: int, out, mask=None,
+                     mask_bit_offset: int = 0, out_mask=None) -> None:
+        """Fused scalar broadcast: side = "rhs" for array (op) scalar, "lhs" for scalar (op) array."""
+        fam = "float" if tag in ("f32", "f64") else "int"
+        fn = getattr(self.lib, f"ma_apply_{fam}_{tag}_scalar_{side}")
+        sc = float(scalar) if fam == "float" else int(scalar)
+        if side == "rhs":
+            st = fn(self.handle, addr_of(arr), int(n), sc, int(op), addr_of(mask), int(mask_bit_offset), addr_of(out),
+                    addr_of(out_mask))
+        else:
+            st = fn(self.handle, sc, addr_of(arr), int(n), int(op), addr_of(mask), int(mask_bit_offset), addr_of(out),
+                    addr_of(out_mask))
+        ffi.check(st)
+
+    def apply_fma(self, tag: str, lhs, rhs, acc, out, n_lhs: int, n_rhs: int, n_acc: int, mask=None,
+                  mask_bit_offset: int = 0, out_mask=None) -> None:
+        fn = getattr(self.lib, f"ma_apply_fma_{tag}")
+        ffi.check(fn(self.handle, addr_of(lhs), int(n_lhs), addr_of(rhs), int(n_rhs), addr_of(acc), int(n_acc),
+                     addr_of(mask), int(mask_bit_offset), addr_of(out), addr_of(out_mask)))

@@ -1,0 +1,475 @@
+"""GPU parity tests for the elementwise arithmetic / FMA kernels, called through the C ABI
+(ma_apply_int_*, ma_apply_float_*, ma_apply_fma_* and the fused scalar-broadcast forms).
+
+The first block replays the reference's own unit tests (src/kernels/arithmetic/mod.rs:117-537, vectors in
+tests/golden/arithmetic_kat.json, routing vectors in tests/golden/routing_kat.json). The second block compares
+against the CPU oracle (oracle/minarrow_oracle.c) on seeded random inputs.
+
+Bar: integers and validity bitmaps bit-exact; float Add/Sub/Mul/Div/Rem/FloorDiv/FMA bit-exact (NaN == NaN);
+float Power = exp(b * ln(a)) within (4 + 2|b ln a|) ULP of the oracle (two libm calls on each side).
+"""
+import json
+import math
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from minarrow_amd import ffi
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden"
+ARITH = json.loads((GOLD / "arithmetic_kat.json").read_text())
+ROUTE = json.loads((GOLD / "routing_kat.json").read_text())
+NP = {"i32": np.int32, "u32": np.uint32, "i64": np.int64, "u64": np.uint64, "f32": np.float32, "f64": np.float64}
+OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "remainder": 4, "power": 5, "floordiv": 6}
+INT_TAGS = ("i32", "u32", "i64", "u64")
+FLOAT_TAGS = ("f32", "f64")
+
+
+def seed_of(*parts):
+    return zlib.crc32(repr(parts).encode())
+
+
+def mask_bytes(n):
+    return ((n + 63) // 64) * 8
+
+
+class Gpu:
+    """Thin test helper: numpy in, numpy out, everything through the C ABI on device-resident buffers."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def apply(self, tag, lhs, rhs, op, mask=None, mask_off=0, device=True, shift=0):
+        dt = NP[tag]
+        lhs, rhs = np.asarray(lhs, dtype=dt), np.asarray(rhs, dtype=dt)
+        n = lhs.size
+        op = OPS[op] if isinstance(op, str) else op
+        if device:
+            sb = shift * np.dtype(dt).itemsize
+            dl = self.ctx.to_device(np.concatenate([np.zeros(shift, dt), lhs]), 64)
+            dr = self.ctx.to_device(np.concatenate([np.zeros(shift, dt), rhs]), 64)
+            do = self.ctx.alloc(max(n, 1) * lhs.itemsize + 64 + sb)
+            dm = self.ctx.to_device(mask, 16) if mask is not None else None
+            dom = self.ctx.alloc(mask_bytes(n) + 8) if mask is not None else None
+            self.ctx.apply(tag, dl.offset(sb), dr.offset(sb), op, do.offset(sb), n, rhs.size, mask=dm,
+                           mask_bit_offset=mask_off, out_mask=dom)
+            out = do.download(dt, n, sb)
+            om = dom.download(np.uint8, mask_bytes(n)) if mask is not None else None
+        else:
+            out = np.zeros(n, dtype=dt)
+            om = np.zeros(mask_bytes(n) + 8, dtype=np.uint8) if mask is not None else None
+            self.ctx.apply(tag, lhs, rhs, op, out, n, rhs.size, mask=mask, mask_bit_offset=mask_off, out_mask=om)
+        return out, om
+
+    def apply_scalar(self, tag, side, arr, scalar, op, mask=None, mask_off=0):
+        dt = NP[tag]
+        arr = np.asarray(arr, dtype=dt)
+        n = arr.size
+        da = self.ctx.to_device(arr, 64)
+        do = self.ctx.alloc(max(n, 1) * arr.itemsize + 64)
+        dm = self.ctx.to_device(mask, 16) if mask is not None else None
+        dom = self.ctx.alloc(mask_bytes(n) + 8) if mask is not None else None
+        self.ctx.apply_scalar(tag, side, da, n, scalar, OPS[op] if isinstance(op, str) else op, do, mask=dm,
+                              mask_bit_offset=mask_off, out_mask=dom)
+        return do.download(dt, n), (dom.download(np.uint8, mask_bytes(n)) if mask is not None else None)
+
+    def fma(self, tag, a, b, c, mask=None, mask_off=0):
+        dt = NP[tag]
+        a, b, c = (np.asarray(x, dtype=dt) for x in (a, b, c))
+        n = a.size
+        da, db, dc = (self.ctx.to_device(x, 64) for x in (a, b, c))
+        do = self.ctx.alloc(max(n, 1) * a.itemsize + 64)
+        dm = self.ctx.to_device(mask, 16) if mask is not None else None
+        dom = self.ctx.alloc(mask_bytes(n) + 8) if mask is not None else None
+        self.ctx.apply_fma(tag, da, db, dc, do, n, b.size, c.size, mask=dm, mask_bit_offset=mask_off, out_mask=dom)
+        return do.download(dt, n), (dom.download(np.uint8, mask_bytes(n)) if mask is not None else None)
+
+
+@pytest.fixture(scope="module")
+def gpu(ctx):
+    return Gpu(ctx)
+
+
+def bits_of(valid):
+    return np.packbits(np.asarray(valid, dtype=bool), bitorder="little")
+
+
+def unpack(bits, n, off=0):
+    return np.unpackbits(bits, bitorder="little")[off:off + n].astype(bool)
+
+
+def assert_float_bits_equal(got, want):
+    """Bit-exact including the sign of zero; any NaN equals any NaN (payload/sign of a generated NaN is
+    platform-defined: x86 produces the negative default NaN, gfx950 the positive one)."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    np.testing.assert_array_equal(nan_g, nan_w)
+    ui = np.uint32 if got.dtype == np.float32 else np.uint64
+    np.testing.assert_array_equal(got.view(ui)[~nan_g], want.view(ui)[~nan_w])
+
+
+# ======================================================================================================
+# 1. The reference's own tests, replayed through the C ABI
+# ======================================================================================================
+
+@pytest.mark.parametrize("tag", INT_TAGS)
+def test_ref_int_dense(gpu, tag):
+    """int_kernel_suite! $fn_dense — src/kernels/arithmetic/mod.rs:117-178"""
+    g = ARITH["int_dense"]
+    for op, expect in g["expect"].items():
+        out, om = gpu.apply(tag, g["lhs"], g["rhs"], op)
+        assert om is None
+        np.testing.assert_array_equal(out, np.array(expect, dtype=NP[tag]))
+    expect = []
+    for a, b in zip(g["lhs"], g["rhs"]):
+        acc = 1
+        for _ in range(b):
+            acc = (acc * a) % (1 << (8 * np.dtype(NP[tag]).itemsize))
+        expect.append(acc)
+    out, _ = gpu.apply(tag, g["lhs"], g["rhs"], "power")
+    np.testing.assert_array_equal(out.astype(object), expect)
+    # "Dense integer kernel division by zero must panic" -> MA_ERR_DIVIDE_BY_ZERO
+    for op in g["divide_by_zero_ops_must_panic"]:
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            gpu.apply(tag, g["lhs"], g["divide_by_zero_rhs"], op)
+        assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            gpu.apply(tag, g["lhs"], g["divide_by_zero_rhs"], op, device=False)
+        assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+    # the latch is cleared: the next call succeeds
+    out, _ = gpu.apply(tag, g["lhs"], g["rhs"], "divide")
+    np.testing.assert_array_equal(out, np.array(g["expect"]["divide"], dtype=NP[tag]))
+
+
+@pytest.mark.parametrize("tag", INT_TAGS)
+def test_ref_int_masked(gpu, tag):
+    """int_kernel_suite! $fn_masked — src/kernels/arithmetic/mod.rs:180-220"""
+    for case in ARITH["int_masked"]["cases"]:
+        for device in (True, False):
+            out, om = gpu.apply(tag, case["lhs"], case["rhs"], case["op"], mask=bits_of(case["mask"]), device=device)
+            np.testing.assert_array_equal(out, np.array(case["expect"], dtype=NP[tag]))
+            np.testing.assert_array_equal(unpack(om, 4), case["expect_mask"])
+
+
+@pytest.mark.parametrize("tag", INT_TAGS + FLOAT_TAGS)
+def test_ref_empty_and_length_mismatch(gpu, ctx, tag):
+    """$fn_empty — mod.rs:222-228; confirm_equal_len — src/utils.rs:163-171"""
+    out, _ = gpu.apply(tag, [], [], "add")
+    assert out.size == 0
+    a, b = np.zeros(3, NP[tag]), np.zeros(2, NP[tag])
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply(tag, a, b, 0, np.zeros(3, NP[tag]), 3, 2)
+    assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH and "length mismatch" in e.value.message
+
+
+@pytest.mark.parametrize("tag", FLOAT_TAGS)
+def test_ref_float_suite(gpu, tag):
+    """float_kernel_suite! — src/kernels/arithmetic/mod.rs:293-370"""
+    g = ARITH["float"]
+    eps = g["eps"][tag]
+    for op, expect in g["expect_exact"].items():
+        out, _ = gpu.apply(tag, g["lhs"], g["rhs"], op)
+        np.testing.assert_array_equal(out, np.array(expect, dtype=NP[tag]))
+    out, _ = gpu.apply(tag, g["lhs"], g["rhs"], "remainder")
+    assert np.all(np.abs(out) < eps)
+    out, _ = gpu.apply(tag, g["lhs"], g["rhs"], "power")
+    expect = np.exp(np.array(g["rhs"]) * np.log(np.array(g["lhs"])))
+    assert np.all(np.abs(out.astype(np.float64) - expect) < max(eps, 2e-5 if tag == "f32" else eps) * np.maximum(1, expect))
+    assert np.all(np.isinf(gpu.apply(tag, g["lhs"], g["divide_by_zero_rhs"], "divide")[0]))
+    assert np.all(np.isnan(gpu.apply(tag, g["lhs"], g["divide_by_zero_rhs"], "remainder")[0]))
+    m = g["masked"]
+    out, om = gpu.apply(tag, g["lhs"], g["rhs"], m["op"], mask=bits_of(m["mask"]))
+    np.testing.assert_array_equal(out, np.array(m["expect"], dtype=NP[tag]))
+    np.testing.assert_array_equal(unpack(om, 4), m["mask"])
+
+
+@pytest.mark.parametrize("tag", FLOAT_TAGS)
+def test_ref_fma(gpu, ctx, tag):
+    """fma_f32 / fma_f64 — src/kernels/arithmetic/mod.rs:372-399"""
+    g = ARITH["fma"]
+    out, om = gpu.fma(tag, g["lhs"], g["rhs"], g["acc"])
+    np.testing.assert_array_equal(out, np.array(g["expect"], dtype=NP[tag]))
+    assert om is None
+    out, om = gpu.fma(tag, g["lhs"], g["rhs"], g["acc"], mask=bits_of(g["masked"]["mask"]))
+    np.testing.assert_array_equal(out, np.array(g["masked"]["expect"], dtype=NP[tag]))
+    np.testing.assert_array_equal(unpack(om, 3), g["masked"]["expect_mask"])
+    assert gpu.fma(tag, [], [], [])[0].size == 0
+    a = np.zeros(3, NP[tag])
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply_fma(tag, a, a, a[:2].copy(), np.zeros(3, NP[tag]), 3, 3, 2)
+    assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH
+
+
+def test_ref_datetime_is_the_int_kernel(gpu, oracle):
+    """apply_datetime_i64 — mod.rs:418-505: AND-merged mask + the integer kernels unchanged"""
+    g = ARITH["datetime_i64"]
+    for case in g["cases"]:
+        out, _ = gpu.apply("i64", case["lhs"], case["rhs"], case["op"])
+        np.testing.assert_array_equal(out, case["expect"])
+    m = g["masked"]
+    merged = oracle.merge_bitmasks(oracle.pack_bits(m["lhs_mask"]), None, 4)
+    out, om = gpu.apply("i64", m["lhs"], m["rhs"], m["op"], mask=np.ascontiguousarray(merged[:8]))
+    np.testing.assert_array_equal(out, m["expect"])
+    np.testing.assert_array_equal(unpack(om, 4), m["expect_mask"])
+
+
+def test_ref_int_power_short_vs_long(gpu):
+    """test_int_dense_power_short_vs_long_input_simd — mod.rs:507-537"""
+    g = ARITH["int_power_short_vs_long"]
+    for n in g["lengths"]:
+        out, _ = gpu.apply("u32", np.full(n, g["base"]), np.full(n, g["exp"]), "power")
+        assert np.all(out == g["expect_each"])
+
+
+def test_ref_routing_vectors(gpu):
+    """Array(+)Array, Array(+)len-1 Array, Array(+)Scalar — src/kernels/broadcast/array.rs:485-556,685-700,
+    src/kernels/broadcast/super_array.rs:480-560, src/kernels/routing/binary_map.rs:76-152. A length-1 side is
+    handed to the fused scalar kernel instead of being materialised (routing/broadcast.rs:25-112)."""
+    def run(tag, op, lhs, rhs):
+        if len(lhs) == 1 and len(rhs) != 1:
+            return gpu.apply_scalar(tag, "lhs", rhs, lhs[0], op)[0]
+        if len(rhs) == 1 and len(lhs) != 1:
+            return gpu.apply_scalar(tag, "rhs", lhs, rhs[0], op)[0]
+        return gpu.apply(tag, lhs, rhs, op)[0]
+
+    for c in ROUTE["array_array"]["cases"] + ROUTE["super_array"]["cases"]:
+        np.testing.assert_array_equal(run("i32", c["op"], c["lhs"], c["rhs"]), c["expect"])
+    c = ROUTE["array_scalar"]
+    np.testing.assert_array_equal(run("i32", c["op"], c["lhs"], [c["scalar"]]), c["expect"])
+    c = ROUTE["super_array"]["chunked_add"]
+    for l, r, e in zip(c["lhs_chunks"], c["rhs_chunks"], c["expect_chunks"]):
+        np.testing.assert_array_equal(run("i32", "add", l, r), e)
+    for c in ROUTE["binary_map_f64"]["cases"]:
+        lhs = [float(x) for x in c.get("lhs", c.get("lhs_i32"))]
+        rhs = c.get("rhs", [c.get("scalar")])
+        np.testing.assert_array_equal(run("f64", c["op"], lhs, rhs), c["expect"])
+
+
+# ======================================================================================================
+# 2. Seeded random parity against the oracle
+# ======================================================================================================
+
+SIZES = [1, 5, 63, 64, 65, 1000, 4095, 4096, 4097, 8193, 100_003]
+
+
+def rand_ints(rng, tag, n, small=False):
+    info = np.iinfo(NP[tag])
+    if small:
+        lo, hi = (0, 40) if info.min == 0 else (-20, 40)
+        return rng.integers(lo, hi, size=n).astype(NP[tag])
+    a = rng.integers(info.min, info.max, size=n, dtype=NP[tag], endpoint=True)
+    # sprinkle the edge values
+    edges = np.array([info.min, info.max, 0, 1, info.max - 1] + ([-1] if info.min < 0 else [2]), dtype=NP[tag])
+    idx = rng.integers(0, n, size=max(1, n // 16))
+    a[idx] = edges[rng.integers(0, edges.size, size=idx.size)]
+    return a
+
+
+@pytest.mark.parametrize("tag", INT_TAGS)
+@pytest.mark.parametrize("op", list(OPS))
+def test_int_dense_random(gpu, oracle, tag, op):
+    rng = np.random.default_rng(seed_of(tag, op))
+    for n in SIZES:
+        lhs = rand_ints(rng, tag, n)
+        rhs = rand_ints(rng, tag, n, small=(op == "power"))
+        if op in ("divide", "remainder", "floordiv"):
+            rhs[rhs == 0] = 3  # the dense kernels panic on a zero divisor: covered by test_ref_int_dense
+        st, want, _, _ = oracle.apply_int(oracle.aligned_copy(lhs), oracle.aligned_copy(rhs), op)
+        assert st & ~oracle.PANIC_OVERFLOW == 0  # MIN / -1: wrapping value, as the reference's SIMD lanes give
+        for shift in (0, 1):
+            got, _ = gpu.apply(tag, lhs, rhs, op, shift=shift)
+            np.testing.assert_array_equal(got, want, err_msg=f"{tag} {op} n={n} shift={shift}")
+
+
+@pytest.mark.parametrize("tag", INT_TAGS)
+@pytest.mark.parametrize("op", list(OPS))
+def test_int_masked_random(gpu, oracle, tag, op):
+    rng = np.random.default_rng(seed_of(tag, op, "m"))
+    for n in SIZES:
+        lhs = rand_ints(rng, tag, n)
+        rhs = rand_ints(rng, tag, n, small=(op == "power"))
+        rhs[rng.integers(0, n, size=max(1, n // 7))] = 0  # zero divisors become nulls
+        for mask_off in (0, 3, 64, 77):
+            bits = rng.integers(0, 256, size=(mask_off + n + 7) // 8 + 8, dtype=np.uint8)
+            window = oracle.pad_bits(np.packbits(unpack(bits, n, mask_off), bitorder="little"), n)
+            st, want, want_mask = oracle.int_body("masked_std", lhs, rhs, op, mask=window)
+            assert st & ~oracle.PANIC_OVERFLOW == 0
+            st2, want2, want_mask2 = oracle.int_body("masked_simd", oracle.aligned_copy(lhs), oracle.aligned_copy(rhs), op,
+                                                     mask=window, lanes=8)
+            np.testing.assert_array_equal(want, want2)
+            got, got_mask = gpu.apply(tag, lhs, rhs, op, mask=bits, mask_off=mask_off)
+            np.testing.assert_array_equal(got, want, err_msg=f"{tag} {op} n={n} off={mask_off}")
+            np.testing.assert_array_equal(got_mask, want_mask[:mask_bytes(n)], err_msg=f"{tag} {op} n={n} off={mask_off} (validity)")
+            np.testing.assert_array_equal(want_mask[:mask_bytes(n)], want_mask2[:mask_bytes(n)])
+
+
+def rand_floats(rng, tag, n, positive=False):
+    dt = NP[tag]
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, size=n)).astype(dt)
+    if positive:
+        a = np.abs(a) + dt(1e-3)
+    else:
+        specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, np.finfo(dt).tiny / 4, -np.finfo(dt).tiny / 8,
+                             np.finfo(dt).max, 1.0, -1.0], dtype=dt)
+        idx = rng.integers(0, n, size=max(1, n // 10))
+        a[idx] = specials[rng.integers(0, specials.size, size=idx.size)]
+    return a
+
+
+@pytest.mark.parametrize("tag", FLOAT_TAGS)
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide", "remainder", "floordiv"])
+def test_float_exact_ops_random(gpu, oracle, tag, op):
+    rng = np.random.default_rng(seed_of(tag, op))
+    for n in SIZES:
+        lhs, rhs = rand_floats(rng, tag, n), rand_floats(rng, tag, n)
+        st, want, _, _ = oracle.apply_float(oracle.aligned_copy(lhs), oracle.aligned_copy(rhs), op)
+        assert st == 0
+        for shift in (0, 1):
+            got, _ = gpu.apply(tag, lhs, rhs, op, shift=shift)
+            assert_float_bits_equal(got, want)
+        bits = rng.integers(0, 256, size=(5 + n + 7) // 8 + 8, dtype=np.uint8)
+        window = oracle.pad_bits(np.packbits(unpack(bits, n, 5), bitorder="little"), n)
+        st, want, want_mask = oracle.float_body("masked_std", lhs, rhs, op, mask=window)
+        got, got_mask = gpu.apply(tag, lhs, rhs, op, mask=bits, mask_off=5)
+        assert_float_bits_equal(got, want)
+        np.testing.assert_array_equal(got_mask, want_mask[:mask_bytes(n)])
+
+
+@pytest.mark.parametrize("tag", FLOAT_TAGS)
+def test_float_power_random(gpu, oracle, tag):
+    rng = np.random.default_rng(17)
+    dt = NP[tag]
+    for n in (1000, 8193):
+        lhs = rand_floats(rng, tag, n, positive=True)
+        rhs = (rng.standard_normal(n) * 3).astype(dt)
+        st, want, _, _ = oracle.apply_float(oracle.aligned_copy(lhs), oracle.aligned_copy(rhs), "power")
+        got, _ = gpu.apply(tag, lhs, rhs, "power")
+        x = np.abs(rhs.astype(np.float64) * np.log(lhs.astype(np.float64)))
+        finite = np.isfinite(want)
+        ulp = np.spacing(np.abs(want).astype(dt)).astype(np.float64)
+        diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        if tag == "f32":
+            # ln, product and exp are rounded to f32 at the same three points as the reference and each of the
+            # two transcendental steps is correctly rounded, like the host libm's logf/expf in all but rare
+            # cases: the results are the reference's bits almost everywhere. A 1-ulp ln difference, where it
+            # happens, is amplified by |b ln a|.
+            assert np.mean(diff[finite] == 0) > 0.98
+            assert np.all(diff[finite] <= (2 + x[finite]) * ulp[finite])
+        else:
+            # f64: two independent libms (OCML vs glibc), each <= 1 ulp per call; exp amplifies the ln and
+            # product differences by |b ln a|.
+            assert np.all(diff[finite] <= (4 + 2 * x[finite]) * ulp[finite])
+        np.testing.assert_array_equal(got[~finite], want[~finite])
+    # ln of a negative base is NaN, of zero -inf: same special-case structure as the reference
+    got, _ = gpu.apply(tag, [-2.0, 0.0, 0.0, 1.0], [2.0, 2.0, -1.0, 1e30], "power")
+    assert np.isnan(got[0]) and got[1] == 0.0 and got[2] == np.inf and got[3] == 1.0
+
+
+@pytest.mark.parametrize("tag", INT_TAGS + FLOAT_TAGS)
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide", "floordiv"])
+def test_scalar_broadcast_equals_materialised(gpu, oracle, tag, op):
+    """Fused scalar kernels == the reference's vec64![x; n] + two-array kernel (routing/broadcast.rs:25-112)."""
+    rng = np.random.default_rng(seed_of(tag, op, "s"))
+    is_f = tag in FLOAT_TAGS
+    for n in (7, 4097, 50_001):
+        arr = rand_floats(rng, tag, n) if is_f else rand_ints(rng, tag, n)
+        scalar = NP[tag](2.5) if is_f else NP[tag](7)
+        full = np.full(n, scalar, dtype=NP[tag])
+        fn = oracle.apply_float if is_f else oracle.apply_int
+        if not is_f and op in ("divide", "floordiv"):
+            arr[arr == 0] = 5
+        for side in ("rhs", "lhs"):
+            l, r = (arr, full) if side == "rhs" else (full, arr)
+            st, want, _, _ = fn(oracle.aligned_copy(l), oracle.aligned_copy(r), op)
+            assert st & ~oracle.PANIC_OVERFLOW == 0
+            got, _ = gpu.apply_scalar(tag, side, arr, scalar, op)
+            (assert_float_bits_equal if is_f else np.testing.assert_array_equal)(got, want)
+        # masked
+        bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+        window = oracle.pad_bits(np.packbits(unpack(bits, n, 9), bitorder="little"), n)
+        body = oracle.float_body if is_f else oracle.int_body
+        st, want, want_mask = body("masked_std", arr, full, op, mask=window)
+        got, got_mask = gpu.apply_scalar(tag, "rhs", arr, scalar, op, mask=bits, mask_off=9)
+        (assert_float_bits_equal if is_f else np.testing.assert_array_equal)(got, want)
+        np.testing.assert_array_equal(got_mask, want_mask[:mask_bytes(n)])
+
+
+@pytest.mark.parametrize("tag", FLOAT_TAGS)
+def test_fma_random(gpu, oracle, tag):
+    rng = np.random.default_rng(23)
+    for n in SIZES:
+        a, b, c = (rand_floats(rng, tag, n) for _ in range(3))
+        st, want, _ = oracle.apply_fma(oracle.aligned_copy(a), oracle.aligned_copy(b), oracle.aligned_copy(c))
+        got, _ = gpu.fma(tag, a, b, c)
+        assert_float_bits_equal(got, want)  # fused on both sides (simd.rs:620, std.rs:210)
+        bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+        window = oracle.pad_bits(np.packbits(unpack(bits, n, 2), bitorder="little"), n)
+        st, want, want_mask = oracle.apply_fma(oracle.aligned_copy(a), oracle.aligned_copy(b), oracle.aligned_copy(c), mask=window)
+        got, got_mask = gpu.fma(tag, a, b, c, mask=bits, mask_off=2)
+        assert_float_bits_equal(got, want)
+        np.testing.assert_array_equal(got_mask, want_mask[:mask_bytes(n)])
+
+
+def test_mixed_phase_operands_take_the_row_kernel(gpu, ctx, oracle):
+    """lhs, rhs and out on different 16-byte phases: no vector path exists; results must not change."""
+    n = 10_001
+    rng = np.random.default_rng(3)
+    a, b = rand_ints(rng, "i64", n), rand_ints(rng, "i64", n)
+    da = ctx.to_device(np.concatenate([[0], a]).astype(np.int64), 64)
+    db = ctx.to_device(b, 64)
+    do = ctx.alloc(n * 8 + 64)
+    ctx.apply("i64", da.offset(8), db, 0, do, n, n)
+    np.testing.assert_array_equal(do.download(np.int64, n), (a.astype(np.uint64) + b.astype(np.uint64)).view(np.int64))
+
+
+def test_async_divide_by_zero_is_reported_at_synchronize(ctx):
+    n = 5000
+    a = ctx.to_device(np.arange(1, n + 1, dtype=np.int64))
+    z = ctx.to_device(np.zeros(n, dtype=np.int64))
+    out = ctx.alloc(n * 8)
+    ctx.set_async(True)
+    try:
+        ctx.apply("i64", a, z, OPS["divide"], out, n, n)  # enqueues; the latch is read later
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            ctx.synchronize()
+        assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+        ctx.synchronize()  # latch cleared
+    finally:
+        ctx.set_async(False)
+
+
+# ======================================================================================================
+# 3. BASELINE size (config 3): 1 B-row f64 add / mul, array (+) array and array (+) scalar
+# ======================================================================================================
+
+def test_one_billion_rows_f64_add_mul(ctx):
+    """a[i] = i, b[i] = n - i. a + b == n everywhere (sum == n^2, exact); a * 2.5 and a * b are checked on
+    windows against numpy and through the verified sum kernel (linearity: sum(a * 2.5) == 2.5 * sum(a))."""
+    n = 1_000_000_000
+    a, b, out = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * 8)
+    ctx.synth_iota("f64", a, n, 0)
+    # b = n - a  (scalar on the left: Scalar - Array)
+    ctx.apply_scalar("f64", "lhs", a, n, float(n), OPS["subtract"], b)
+    ctx.apply("f64", a, b, OPS["add"], out, n, n)
+    s, c = ctx.sum("f64", out, n)
+    assert c == n and s == float(n) * float(n)
+    for start in (0, 123_456_789, n - 4096):
+        np.testing.assert_array_equal(out.download(np.float64, 4096, start * 8), np.full(4096, float(n)))
+    ctx.apply_scalar("f64", "rhs", a, n, 2.5, OPS["multiply"], out)
+    s, _ = ctx.sum("f64", out, n)
+    exact = 5 * (n * (n - 1) // 2) / 2  # every product i * 2.5 is exact, so the sum is 2.5 * sum(i)
+    assert abs(s - exact) <= math.ulp(exact)
+    for start in (0, 500_000_000, n - 4096):
+        i = np.arange(start, start + 4096, dtype=np.float64)
+        np.testing.assert_array_equal(out.download(np.float64, 4096, start * 8), i * 2.5)
+    ctx.apply("f64", a, b, OPS["multiply"], out, n, n)
+    for start in (0, 500_000_000, n - 4096):
+        i = np.arange(start, start + 4096, dtype=np.float64)
+        np.testing.assert_array_equal(out.download(np.float64, 4096, start * 8), i * (n - i))
+    for buf in (a, b, out):
+        buf.free()
