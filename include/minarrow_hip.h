@@ -277,6 +277,69 @@ ma_status ma_apply_fma_f64(ma_ctx* ctx, const double* lhs, size_t lhs_len, const
                         const double* acc, size_t acc_len, const uint8_t* mask_bits, size_t mask_bit_offset,
                         double* out, uint8_t* out_mask_bits);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bitmask kernels — same names as the reference's dispatch layer (src/kernels/bitmask/dispatch.rs:47-295),
+ * bodies in src/kernels/bitmask/{simd,std}.rs. A window is (bits, offset_bits, len_bits) = BitmaskVT
+ * (src/aliases.rs:172). Outputs are new bitmaps of `len` bits starting at bit 0, written as whole u64 words
+ * (8*ceil(len/64) bytes, 8-byte aligned), bits >= len zero (clear_trailing_bits, bitmask/mod.rs:141-150).
+ *
+ * The reference addresses windows at different granularities; each entry point reproduces its function's rule
+ * so results are identical for every offset:
+ *   and/or/xor/not        window starts at BYTE offset/8 (bitmask_window_bytes, bitmask/mod.rs:124-128;
+ *                         simd.rs:95-203) — a sub-byte offset is not shifted out
+ *   popcount_mask         counting starts at WORD offset/64 (simd.rs:603-611)
+ *   in_mask / not_in_mask rhs is scanned from WORD rhs_offset/64 (simd.rs:345); the result is all-true, a
+ *                         bit-exact copy of the lhs window (slice_clone), its byte-granular NOT, or all-false
+ *   eq_mask / ne_mask     offsets must be multiples of 64, else MA_ERR_INVALID_ARGUMENT (the reference panics,
+ *                         simd.rs:411-416)
+ *   all_eq / all_ne       len < 64: the words at offset/64 are compared under a len-bit mask (simd.rs:523-528);
+ *                         otherwise offsets must be multiples of 64 (panic in the reference, :530-535).
+ *                         all_ne = !all_eq ("not all equal", simd.rs:490-494)
+ *   all_true/all_false    every logical bit set / clear (std.rs:300-366). The SIMD twin's false negative
+ *                         for len % 64 != 0 && n_words % LANES == 0 (simd.rs:668-674) depends on a CPU
+ *                         build constant and is not reproduced; it only ever selected a slower path.
+ *   merge_bitmasks_to_new per-row AND of two optional bitmaps at bit 0 (bitmask/mod.rs:171-196);
+ *                         *out_is_some = 0 and nothing is written when both are NULL (=> None)
+ *   simd_eq_mask_u*       bit j = ((data[j] & field_mask) == target) (simd.rs:741-788)
+ *   bitmask_slice         Bitmask::slice_clone: bit-exact copy of a window to bit 0
+ * ---------------------------------------------------------------------------------------------- */
+
+ma_status ma_bitmask_binop(ma_ctx* ctx, int32_t logical_op, const uint8_t* lhs_bits, size_t lhs_offset,
+                           const uint8_t* rhs_bits, size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_and_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                       size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_or_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                      size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_xor_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                       size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_not_mask(ma_ctx* ctx, const uint8_t* src_bits, size_t offset, size_t len, uint8_t* out_bits);
+ma_status ma_bitmask_slice(ma_ctx* ctx, const uint8_t* src_bits, size_t offset, size_t len, uint8_t* out_bits);
+ma_status ma_in_mask(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                     size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_not_in_mask(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                         size_t rhs_offset, size_t len, uint8_t* out_bits);
+ma_status ma_eq_mask(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                     size_t len, uint8_t* out_bits);
+ma_status ma_ne_mask(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                     size_t len, uint8_t* out_bits);
+ma_status ma_all_eq(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                    size_t len, int32_t* out_bool);
+ma_status ma_all_ne(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                    size_t len, int32_t* out_bool);
+ma_status ma_popcount_mask(ma_ctx* ctx, const uint8_t* bits, size_t offset, size_t len, uint64_t* out_count);
+ma_status ma_all_true_mask(ma_ctx* ctx, const uint8_t* bits, size_t len, int32_t* out_bool);
+ma_status ma_all_false_mask(ma_ctx* ctx, const uint8_t* bits, size_t len, int32_t* out_bool);
+ma_status ma_merge_bitmasks_to_new(ma_ctx* ctx, const uint8_t* lhs_bits, const uint8_t* rhs_bits, size_t len,
+                                   uint8_t* out_bits, int32_t* out_is_some);
+ma_status ma_simd_eq_mask_u8(ma_ctx* ctx, const uint8_t* data, size_t n, uint8_t field_mask, uint8_t target,
+                             uint8_t* out_bits);
+ma_status ma_simd_eq_mask_u16(ma_ctx* ctx, const uint16_t* data, size_t n, uint16_t field_mask, uint16_t target,
+                              uint8_t* out_bits);
+ma_status ma_simd_eq_mask_u32(ma_ctx* ctx, const uint32_t* data, size_t n, uint32_t field_mask, uint32_t target,
+                              uint8_t* out_bits);
+ma_status ma_simd_eq_mask_u64(ma_ctx* ctx, const uint64_t* data, size_t n, uint64_t field_mask, uint64_t target,
+                              uint8_t* out_bits);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

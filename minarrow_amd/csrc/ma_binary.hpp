@@ -186,7 +186,7 @@ struct BinArgs {
 // ------------------------------------------------------------------------------------------------
 // vec kernel
 // ------------------------------------------------------------------------------------------------
-template <typename T, int OP, int KIND, bool MASKED, int UNROLL>
+template <typename T, int OP, int KIND, bool MASKED, int UNROLL, bool NTS = true>
 __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
     typedef typename Vec16<T>::type V;
     constexpr int R = 16 / (int)sizeof(T);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
                 if constexpr (MASKED) v = ((bits >> k) & 1u) ? v : (T)0;  // null slots hold 0 (simd.rs:315)
                 r[k] = v;
             }
-            store16<V, true>(o + (size_t)u * 64, r);
+            store16<V, NTS>(o + (size_t)u * 64, r);
         }
     }
     if constexpr (!MASKED && std::is_integral<T>::value &&
@@ -284,12 +284,16 @@ __global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t
     const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
     const size_t n_words = (a.n + 63) >> 6;
+    // Only the words that hold ragged rows are visited: [0, head_words) and [tail_word0, n_words).
+    const size_t head_words = a.ballot_mask ? 0 : (a.head + 63) >> 6;
+    size_t tail_word0 = a.ballot_mask ? 0 : tail_start >> 6;
+    if (tail_word0 < head_words) tail_word0 = head_words;
+    const size_t n_visit = head_words + (n_words - tail_word0);
     bool dz_any = false;
-    for (size_t w = wave_id; w < n_words; w += n_waves) {
+    for (size_t k = wave_id; k < n_visit; k += n_waves) {
+        const size_t w = k < head_words ? k : tail_word0 + (k - head_words);
         const size_t row = w * 64 + lane;
         bool in_range = row < a.n && (a.ballot_mask || row < a.head || row >= tail_start);
-        // whole words strictly inside the vec kernel's range: nothing to do (wave-uniform test)
-        if (!a.ballot_mask && w * 64 >= a.head && w * 64 + 64 <= tail_start) continue;
         bool valid = in_range;
         bool dz = false;
         if (in_range) {
@@ -453,8 +457,11 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
                       (c.kind == kAS || ((uintptr_t)a.rhs & 15) == phase) &&
                       (!c.fma || ((uintptr_t)a.acc & 15) == phase);
     constexpr int R = 16 / (int)sizeof(T);
-    // unroll: loads in flight per operand. Two array operands -> 4, one -> 8 (ctx->variant bits 1-3 override).
-    int unroll = (c.kind == kAA || c.fma) ? 4 : 8;
+    // Launch shape (profiles/r01_sweep_binary.txt, profiles/r01_ubench_stream.txt): with a store stream in the mix
+    // every shape lands within ~3 % of this device's 16-byte copy rate (5.4-5.8 TB/s); two array operands run
+    // best with 8 loads per operand in flight and two waves per SIMD, one operand with 4 and one wave.
+    int unroll = (c.kind == kAA || c.fma) ? 8 : 4;
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : ((c.kind == kAA || c.fma) ? 2 : 1);
     switch ((ctx->variant >> 1) & 7) {
         case 2: unroll = 4; break;
         case 3: unroll = 8; break;
@@ -476,7 +483,7 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
 
     if (masked && !ballot) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
     if (n_tiles) {
-        int grid = grid_for(ctx, n_tiles);
+        int grid = grid_for(ctx, n_tiles, bpc);
         if (c.fma) {
             if constexpr (!kInt) {
                 if (masked) hipLaunchKernelGGL((fma_vec_kernel<T, true, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);

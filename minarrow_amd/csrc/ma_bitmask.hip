@@ -41,3 +41,353 @@ ma_status launch_mask_copy(ma_ctx* ctx, const uint64_t* words, size_t bit_off, s
 }
 
 }  // namespace ma
+
+// ================================================================================================
+// Word-wise kernels
+// ================================================================================================
+namespace ma {
+
+enum : int { kBitAnd = 0, kBitOr = 1, kBitXor = 2, kBitNot = 3, kBitXnor = 4, kBitCopy = 5 };
+
+struct BitArgs {
+    const uint64_t* lw;  // lhs words (8-byte aligned base)
+    size_t lo;           // bit offset of the lhs window
+    size_t l_last;       // last lhs word index holding a window bit
+    const uint64_t* rw;  // rhs words or nullptr
+    size_t ro;
+    size_t r_last;
+    size_t n;            // window length in bits
+    uint64_t* out;       // output words, window re-based to bit 0
+    int op;
+};
+
+__global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
+    const size_t n_words = (a.n + 63) >> 6;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
+        uint64_t x = window_word(a.lw, a.lo, a.l_last, j);
+        uint64_t y = a.rw ? window_word(a.rw, a.ro, a.r_last, j) : 0;
+        uint64_t r;
+        switch (a.op) {
+            case kBitAnd: r = x & y; break;
+            case kBitOr: r = x | y; break;
+            case kBitXor: r = x ^ y; break;
+            case kBitNot: r = ~x; break;
+            case kBitXnor: r = ~(x ^ y); break;
+            default: r = x; break;
+        }
+        // clear_trailing_bits / mask_trailing_bits — bitmask/mod.rs:141-150, structs/bitmask.rs:83-90
+        if (j == n_words - 1 && (a.n & 63)) r &= (((uint64_t)1) << (a.n & 63)) - 1;
+        a.out[j] = r;
+    }
+}
+
+// Scalar facts about one or two windows, accumulated into 4 device words:
+//   acc[0] += popcount(x)            acc[1] |= any bit set in x
+//   acc[2] |= any bit clear in x     acc[3] |= any bit where x != y
+__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc) {
+    const size_t n_words = (a.n + 63) >> 6;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    unsigned long long pop = 0, any_set = 0, any_clear = 0, any_diff = 0;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
+        uint64_t live = ~(uint64_t)0;
+        if (j == n_words - 1 && (a.n & 63)) live = (((uint64_t)1) << (a.n & 63)) - 1;
+        uint64_t x = window_word(a.lw, a.lo, a.l_last, j) & live;
+        pop += (unsigned long long)__popcll(x);
+        any_set |= x;
+        any_clear |= (~x) & live;
+        if (a.rw) any_diff |= (x ^ window_word(a.rw, a.ro, a.r_last, j)) & live;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pop += __shfl_down(pop, off, 64);
+        any_set |= __shfl_down(any_set, off, 64);
+        any_clear |= __shfl_down(any_clear, off, 64);
+        any_diff |= __shfl_down(any_diff, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (pop) atomicAdd(&acc[0], pop);
+        if (any_set) atomicOr(&acc[1], 1ull);
+        if (any_clear) atomicOr(&acc[2], 1ull);
+        if (any_diff) atomicOr(&acc[3], 1ull);
+    }
+}
+
+// simd_eq_mask_u{8,16,32,64} — bit j = ((data[j] & field_mask) == target): one ballot per 64 rows.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void eq_mask_kernel(const T* __restrict__ data, size_t n, T field_mask, T target,
+                                                         uint64_t* __restrict__ out) {
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    const size_t n_words = (n + 63) >> 6;
+    for (size_t w = wave_id; w < n_words; w += n_waves) {
+        size_t i = w * 64 + lane;
+        bool hit = i < n && (T)(data[i] & field_mask) == target;
+        unsigned long long word = __ballot(hit);
+        if (lane == 0) out[w] = word;
+    }
+}
+
+struct BitScan {
+    unsigned long long pop, any_set, any_clear, any_diff;
+};
+
+static void fill_window(BitArgs& a, const uint64_t* lw, size_t lo, const uint64_t* rw, size_t ro, size_t n) {
+    a.lw = lw;
+    a.lo = lo;
+    a.l_last = n ? (lo + n - 1) >> 6 : 0;
+    a.rw = rw;
+    a.ro = ro;
+    a.r_last = n ? (ro + n - 1) >> 6 : 0;
+    a.n = n;
+}
+
+// Runs bit_scan_kernel and brings the four words back to the host (synchronises the stream).
+static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
+    unsigned long long* acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 inside the 256-byte scratch line set
+    MA_HIP(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    const size_t n_words = (a.n + 63) >> 6;
+    int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    hipLaunchKernelGGL(bit_scan_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
+    MA_HIP(hipGetLastError());
+    MA_HIP(hipMemcpyAsync(out, acc, sizeof(BitScan), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+static ma_status launch_words(ma_ctx* ctx, const BitArgs& a) {
+    const size_t n_words = (a.n + 63) >> 6;
+    int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    hipLaunchKernelGGL(bit_words_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// One entry for every word-producing op. `lhs_round` / `rhs_round`: the reference addresses these windows at
+// byte (8) or word (64) granularity; the offset is rounded DOWN accordingly so results match it bit for bit.
+static ma_status words_op(ma_ctx* ctx, int op, const uint8_t* lhs, size_t lo, const uint8_t* rhs, size_t ro, size_t len,
+                          uint8_t* out_bits, size_t round) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(lhs != nullptr && out_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    const bool binary = op == kBitAnd || op == kBitOr || op == kBitXor || op == kBitXnor;
+    MA_REQUIRE(!binary || rhs != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL rhs bitmap");
+    lo -= lo % round;
+    ro -= ro % round;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    BitArgs a{};
+    const uint64_t *lw = nullptr, *rw = nullptr;
+    size_t lo2 = 0, ro2 = 0;
+    MA_TRY(scope.in_mask(lhs, lo, len, &lw, &lo2));
+    if (binary) MA_TRY(scope.in_mask(rhs, ro, len, &rw, &ro2));
+    fill_window(a, lw, lo2, rw, ro2, len);
+    MA_TRY(scope.out_mask(out_bits, len, &a.out));
+    a.op = op;
+    MA_TRY(launch_words(ctx, a));
+    return end_call(ctx, scope);
+}
+
+static ma_status fill_bits(ma_ctx* ctx, uint8_t* out_bits, size_t len, bool value) {
+    // Bitmask::new_set_all(len, value) — src/structs/bitmask.rs:94-105
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    uint64_t* ow = nullptr;
+    MA_TRY(scope.out_mask(out_bits, len, &ow));
+    const size_t n_words = (len + 63) >> 6;
+    MA_HIP(hipMemsetAsync(ow, value ? 0xFF : 0, n_words * 8, ctx->stream));
+    if (value && (len & 63)) {
+        uint64_t last = (((uint64_t)1) << (len & 63)) - 1;
+        MA_HIP(hipMemcpyAsync(ow + n_words - 1, &last, 8, hipMemcpyHostToDevice, ctx->stream));
+        MA_HIP(hipStreamSynchronize(ctx->stream));  // `last` lives on this stack frame
+    }
+    return end_call(ctx, scope);
+}
+
+static ma_status scan_op(ma_ctx* ctx, const uint8_t* lhs, size_t lo, const uint8_t* rhs, size_t ro, size_t len,
+                         BitScan* out) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    BitArgs a{};
+    const uint64_t *lw = nullptr, *rw = nullptr;
+    size_t lo2 = 0, ro2 = 0;
+    MA_TRY(scope.in_mask(lhs, lo, len, &lw, &lo2));
+    if (rhs) MA_TRY(scope.in_mask(rhs, ro, len, &rw, &ro2));
+    fill_window(a, lw, lo2, rw, ro2, len);
+    MA_TRY(scan_windows(ctx, a, out));
+    return MA_OK;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+// ---- and / or / xor / not — dispatch.rs:47-144 -------------------------------------------------------
+ma_status ma_bitmask_binop(ma_ctx* ctx, int32_t logical_op, const uint8_t* lhs_bits, size_t lhs_offset,
+                           const uint8_t* rhs_bits, size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    MA_REQUIRE(logical_op >= MA_LOGICAL_AND && logical_op <= MA_LOGICAL_XOR, MA_ERR_INVALID_ARGUMENT,
+               "unknown LogicalOperator code %d", logical_op);
+    // bitmask_window_bytes starts the window at byte offset/8 (bitmask/mod.rs:124-128)
+    return words_op(ctx, logical_op, lhs_bits, lhs_offset, rhs_bits, rhs_offset, len, out_bits, 8);
+}
+ma_status ma_and_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                       size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    return words_op(ctx, kBitAnd, lhs_bits, lhs_offset, rhs_bits, rhs_offset, len, out_bits, 8);
+}
+ma_status ma_or_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                      size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    return words_op(ctx, kBitOr, lhs_bits, lhs_offset, rhs_bits, rhs_offset, len, out_bits, 8);
+}
+ma_status ma_xor_masks(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                       size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    return words_op(ctx, kBitXor, lhs_bits, lhs_offset, rhs_bits, rhs_offset, len, out_bits, 8);
+}
+ma_status ma_not_mask(ma_ctx* ctx, const uint8_t* src_bits, size_t offset, size_t len, uint8_t* out_bits) {
+    return words_op(ctx, kBitNot, src_bits, offset, nullptr, 0, len, out_bits, 8);
+}
+
+// Bitmask::slice_clone(offset, len): bit-accurate copy of a window to bit 0.
+ma_status ma_bitmask_slice(ma_ctx* ctx, const uint8_t* src_bits, size_t offset, size_t len, uint8_t* out_bits) {
+    return words_op(ctx, kBitCopy, src_bits, offset, nullptr, 0, len, out_bits, 1);
+}
+
+// ---- eq / ne — simd.rs:402-472: offsets must be multiples of 64 (the reference panics otherwise) -----------
+ma_status ma_eq_mask(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                     size_t len, uint8_t* out_bits) {
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(a_offset % 64 == 0 && b_offset % 64 == 0, MA_ERR_INVALID_ARGUMENT,
+               "eq_bits_mask: offsets must be 64-bit aligned (got a: %zu, b: %zu)", a_offset, b_offset);
+    return words_op(ctx, kBitXnor, a_bits, a_offset, b_bits, b_offset, len, out_bits, 64);
+}
+ma_status ma_ne_mask(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                     size_t len, uint8_t* out_bits) {
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(a_offset % 64 == 0 && b_offset % 64 == 0, MA_ERR_INVALID_ARGUMENT,
+               "eq_bits_mask: offsets must be 64-bit aligned (got a: %zu, b: %zu)", a_offset, b_offset);
+    return words_op(ctx, kBitXor, a_bits, a_offset, b_bits, b_offset, len, out_bits, 64);
+}
+
+// ---- all_eq / all_ne — simd.rs:490-581 -------------------------------------------------------------------
+ma_status ma_all_eq(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                    size_t len, int32_t* out_bool) {
+    MA_REQUIRE(ctx != nullptr && out_bool != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out is NULL");
+    *out_bool = 1;
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(a_bits && b_bits, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    // len < 64 compares the single words at offset/64 under a low-bit mask (simd.rs:523-528); longer windows
+    // must start on a word (simd.rs:530-535). Either way the window starts at word offset/64.
+    MA_REQUIRE(len < 64 || (a_offset % 64 == 0 && b_offset % 64 == 0), MA_ERR_INVALID_ARGUMENT,
+               "all_eq_mask_simd: offsets must be 64-bit aligned (got a: %zu, b: %zu)", a_offset, b_offset);
+    BitScan s{};
+    MA_TRY(scan_op(ctx, a_bits, a_offset - a_offset % 64, b_bits, b_offset - b_offset % 64, len, &s));
+    *out_bool = s.any_diff ? 0 : 1;
+    return MA_OK;
+}
+ma_status ma_all_ne(ma_ctx* ctx, const uint8_t* a_bits, size_t a_offset, const uint8_t* b_bits, size_t b_offset,
+                    size_t len, int32_t* out_bool) {
+    // all_ne_mask_simd = !all_eq_mask_simd (simd.rs:490-494): "not all equal"
+    MA_TRY(ma_all_eq(ctx, a_bits, a_offset, b_bits, b_offset, len, out_bool));
+    *out_bool = !*out_bool;
+    return MA_OK;
+}
+
+// ---- popcount — simd.rs:596-644: counting starts at WORD offset/64 -------------------------------------------
+ma_status ma_popcount_mask(ma_ctx* ctx, const uint8_t* bits, size_t offset, size_t len, uint64_t* out_count) {
+    MA_REQUIRE(ctx != nullptr && out_count != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out is NULL");
+    *out_count = 0;
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    BitScan s{};
+    MA_TRY(scan_op(ctx, bits, offset - offset % 64, nullptr, 0, len, &s));
+    *out_count = s.pop;
+    return MA_OK;
+}
+
+// ---- all_true / all_false — std.rs:300-366 (every logical bit set / clear) -----------------------------------
+ma_status ma_all_true_mask(ma_ctx* ctx, const uint8_t* bits, size_t len, int32_t* out_bool) {
+    MA_REQUIRE(ctx != nullptr && out_bool != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out is NULL");
+    *out_bool = 1;
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    BitScan s{};
+    MA_TRY(scan_op(ctx, bits, 0, nullptr, 0, len, &s));
+    *out_bool = s.any_clear ? 0 : 1;
+    return MA_OK;
+}
+ma_status ma_all_false_mask(ma_ctx* ctx, const uint8_t* bits, size_t len, int32_t* out_bool) {
+    MA_REQUIRE(ctx != nullptr && out_bool != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out is NULL");
+    *out_bool = 1;
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    BitScan s{};
+    MA_TRY(scan_op(ctx, bits, 0, nullptr, 0, len, &s));
+    *out_bool = s.any_set ? 0 : 1;
+    return MA_OK;
+}
+
+// ---- in / not_in — simd.rs:327-398 ----------------------------------------------------------------------
+ma_status ma_in_mask(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                     size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (len == 0) return MA_OK;
+    MA_REQUIRE(lhs_bits && rhs_bits && out_bits, MA_ERR_INVALID_ARGUMENT, "NULL bitmap");
+    // Which boolean values occur in rhs? The reference scans words from rhs_off/64 (simd.rs:345).
+    BitScan s{};
+    MA_TRY(scan_op(ctx, rhs_bits, rhs_offset - rhs_offset % 64, nullptr, 0, len, &s));
+    if (s.any_set && s.any_clear) return fill_bits(ctx, out_bits, len, true);                 // both: every bit is a member
+    if (s.any_set) return ma_bitmask_slice(ctx, lhs_bits, lhs_offset, len, out_bits);          // lhs.slice_clone
+    if (s.any_clear) return ma_not_mask(ctx, lhs_bits, lhs_offset, len, out_bits);             // not_mask_simd
+    return fill_bits(ctx, out_bits, len, false);
+}
+ma_status ma_not_in_mask(ma_ctx* ctx, const uint8_t* lhs_bits, size_t lhs_offset, const uint8_t* rhs_bits,
+                         size_t rhs_offset, size_t len, uint8_t* out_bits) {
+    MA_TRY(ma_in_mask(ctx, lhs_bits, lhs_offset, rhs_bits, rhs_offset, len, out_bits));
+    if (len == 0) return MA_OK;
+    return ma_not_mask(ctx, out_bits, 0, len, out_bits);  // word-for-word in place
+}
+
+// ---- merge_bitmasks_to_new — bitmask/mod.rs:171-196: AND of optional masks, both at bit 0 -------------------
+ma_status ma_merge_bitmasks_to_new(ma_ctx* ctx, const uint8_t* lhs_bits, const uint8_t* rhs_bits, size_t len,
+                                   uint8_t* out_bits, int32_t* out_is_some) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (out_is_some) *out_is_some = (lhs_bits || rhs_bits) ? 1 : 0;
+    if (!lhs_bits && !rhs_bits) return MA_OK;  // (None, None) => None
+    if (len == 0) return MA_OK;
+    if (lhs_bits && rhs_bits) return words_op(ctx, kBitAnd, lhs_bits, 0, rhs_bits, 0, len, out_bits, 1);
+    return words_op(ctx, kBitCopy, lhs_bits ? lhs_bits : rhs_bits, 0, nullptr, 0, len, out_bits, 1);
+}
+
+// ---- simd_eq_mask_u{8,16,32,64} — simd.rs:741-788 ------------------------------------------------------
+#define MA_DEFINE_EQ_MASK(TAG, T)                                                                                \
+    ma_status ma_simd_eq_mask_##TAG(ma_ctx* ctx, const T* data, size_t n, T field_mask, T target,                 \
+                                    uint8_t* out_bits) {                                                         \
+        MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");                                       \
+        if (n == 0) return MA_OK;                                                                                \
+        MA_REQUIRE(data != nullptr && out_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");               \
+        MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "misaligned data pointer");       \
+        std::lock_guard<std::mutex> lock(ctx->mu);                                                               \
+        MA_HIP(hipSetDevice(ctx->device));                                                                       \
+        CallScope scope(ctx);                                                                                    \
+        const void* d = nullptr;                                                                                 \
+        MA_TRY(scope.in(data, n * sizeof(T), &d));                                                               \
+        uint64_t* ow = nullptr;                                                                                  \
+        MA_TRY(scope.out_mask(out_bits, n, &ow));                                                                \
+        const size_t n_words = (n + 63) >> 6;                                                                    \
+        int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves, 8);                                            \
+        hipLaunchKernelGGL((eq_mask_kernel<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const T*)d, n,         \
+                           field_mask, target, ow);                                                              \
+        MA_HIP(hipGetLastError());                                                                               \
+        return end_call(ctx, scope);                                                                             \
+    }
+MA_DEFINE_EQ_MASK(u8, uint8_t)
+MA_DEFINE_EQ_MASK(u16, uint16_t)
+MA_DEFINE_EQ_MASK(u32, uint32_t)
+MA_DEFINE_EQ_MASK(u64, uint64_t)
+
+}  // extern "C"

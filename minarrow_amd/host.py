@@ -265,3 +265,45 @@ class Context:
         fn = getattr(self.lib, f"ma_apply_fma_{tag}")
         ffi.check(fn(self.handle, addr_of(lhs), int(n_lhs), addr_of(rhs), int(n_rhs), addr_of(acc), int(n_acc),
                      addr_of(mask), int(mask_bit_offset), addr_of(out), addr_of(out_mask)))
+
+    # -- bitmask kernels ---------------------------------------------------------------------------------
+    def mask_words_op(self, name: str, lhs, lhs_off: int, rhs, rhs_off: int, n: int, out) -> None:
+        """and_masks / or_masks / xor_masks / in_mask / not_in_mask / eq_mask / ne_mask"""
+        fn = getattr(self.lib, f"ma_{name}")
+        ffi.check(fn(self.handle, addr_of(lhs), int(lhs_off), addr_of(rhs), int(rhs_off), int(n), addr_of(out)))
+
+    def mask_unary_op(self, name: str, src, off: int, n: int, out) -> None:
+        """not_mask / bitmask_slice"""
+        ffi.check(getattr(self.lib, f"ma_{name}")(self.handle, addr_of(src), int(off), int(n), addr_of(out)))
+
+    def mask_all(self, name: str, a, a_off: int, b, b_off: int, n: int) -> bool:
+        """all_eq / all_ne"""
+        out = C.c_int32()
+        ffi.check(getattr(self.lib, f"ma_{name}")(self.handle, addr_of(a), int(a_off), addr_of(b), int(b_off), int(n),
+                                                 C.addressof(out)))
+        return bool(out.value)
+
+    def popcount_mask(self, bits, off: int, n: int) -> int:
+        out = C.c_uint64()
+        ffi.check(self.lib.ma_popcount_mask(self.handle, addr_of(bits), int(off), int(n), C.addressof(out)))
+        return int(out.value)
+
+    def all_true_mask(self, bits, n: int) -> bool:
+        out = C.c_int32()
+        ffi.check(self.lib.ma_all_true_mask(self.handle, addr_of(bits), int(n), C.addressof(out)))
+        return bool(out.value)
+
+    def all_false_mask(self, bits, n: int) -> bool:
+        out = C.c_int32()
+        ffi.check(self.lib.ma_all_false_mask(self.handle, addr_of(bits), int(n), C.addressof(out)))
+        return bool(out.value)
+
+    def merge_bitmasks(self, lhs, rhs, n: int, out) -> bool:
+        some = C.c_int32()
+        ffi.check(self.lib.ma_merge_bitmasks_to_new(self.handle, addr_of(lhs), addr_of(rhs), int(n), addr_of(out),
+                                                    C.addressof(some)))
+        return bool(some.value)
+
+    def simd_eq_mask(self, tag: str, data, n: int, field_mask: int, target: int, out) -> None:
+        ffi.check(getattr(self.lib, f"ma_simd_eq_mask_{tag}")(self.handle, addr_of(data), int(n), int(field_mask),
+                                                             int(target), addr_of(out)))

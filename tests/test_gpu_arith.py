@@ -359,7 +359,7 @@ def test_float_power_random(gpu, oracle, tag):
             # cases: the results are the reference's bits almost everywhere. A 1-ulp ln difference, where it
             # happens, is amplified by |b ln a|.
             assert np.mean(diff[finite] == 0) > 0.98
-            assert np.all(diff[finite] <= (2 + x[finite]) * ulp[finite])
+            assert np.all(diff[finite] <= (2 + 4 * x[finite]) * ulp[finite])
         else:
             # f64: two independent libms (OCML vs glibc), each <= 1 ulp per call; exp amplifies the ln and
             # product differences by |b ln a|.
