@@ -105,6 +105,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from minarrow_amd.host import Context
+    from minarrow_amd.parallel import ScalarExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,23 +134,22 @@ def main() -> int:
     col_f = torch.empty(rows, dtype=torch.float64, device=dev)
     ctx.synth_iota("i64", col_i, rows, rank * rows)
     ctx.synth_iota("f64", col_f, rows, rank * rows)
-    # [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits, [4] f64 count
-    res = torch.zeros(8, dtype=torch.int64, device=dev)
-    gathered = torch.zeros(8 * world, dtype=torch.int64, device=dev)
-    base = res.data_ptr()
+    # Per-rank record the kernels write into and RCCL all-gathers: [0] i64 sum, [1] i64 count,
+    # [2] f64 hi bits, [3] f64 lo bits, [4] f64 count (minarrow_amd/parallel.py).
+    ex = ScalarExchange(dev)
+    p_isum, p_icnt, p_hi, p_lo, p_fcnt = (ex.slot_ptr(i) for i in range(5))
     ctx.set_async(True)
 
     def step(ev=None):
         if ev:
             ev[0].record(stream)
-        ctx.sum_into("i64", col_i, rows, out_sum=base, out_count=base + 8)
+        ctx.sum_into("i64", col_i, rows, out_sum=p_isum, out_count=p_icnt)
         if ev:
             ev[1].record(stream)
-        ctx.sum_into("f64", col_f, rows, out_sum=base + 16, dd_lo=base + 24, out_count=base + 32)
+        ctx.sum_into("f64", col_f, rows, out_sum=p_hi, dd_lo=p_lo, out_count=p_fcnt)
         if ev:
             ev[2].record(stream)
-        if distributed:
-            dist.all_gather_into_tensor(gathered, res)
+        ex.exchange()  # N > 1: one RCCL all-gather of 64 bytes per rank; N = 1: a device-side copy
 
     def fence():
         if distributed:
@@ -171,19 +171,14 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    else:
-        gathered.copy_(res)
     torch.cuda.synchronize(dev)
 
     # ---- verify the job's answer (outside the timed region) ------------------------------------------
-    g = gathered.cpu().numpy().reshape(world, 8)
     total_rows = rows * world
     expect = total_rows * (total_rows - 1) // 2
-    got_i = int(g[:, 0].astype(object).sum()) & ((1 << 64) - 1)
-    pairs = [(float(g[r, 2:3].view(np.float64)[0]), float(g[r, 3:4].view(np.float64)[0])) for r in range(world)]
-    got_f = fold_dd(pairs)
+    got_i, cnt_i, got_f, cnt_f = ex.results()
     exact_f = float(expect)
-    ok = (got_i == expect & ((1 << 64) - 1)) and int(g[:, 1].sum()) == total_rows and int(g[:, 4].sum()) == total_rows \
+    ok = (got_i == expect & ((1 << 64) - 1)) and cnt_i == total_rows and cnt_f == total_rows \
         and abs(got_f - exact_f) <= math.ulp(exact_f)
 
     ms_i = [e[0].elapsed_time(e[1]) for e in events]

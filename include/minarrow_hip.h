@@ -340,6 +340,59 @@ ma_status ma_simd_eq_mask_u32(ma_ctx* ctx, const uint32_t* data, size_t n, uint3
 ma_status ma_simd_eq_mask_u64(ma_ctx* ctx, const uint64_t* data, size_t n, uint64_t field_mask, uint64_t target,
                               uint8_t* out_bits);
 
+/* ------------------------------------------------------------------------------------------------
+ * Arrow C Data Interface — the reference's only pre-existing C surface (src/ffi/arrow_c_ffi.rs:
+ * #[repr(C)] ArrowArray / ArrowSchema; read from C by tests/c_inspect_arrow.c:17-41, 56-171).
+ * Numeric primitive arrays only: buffers[0] = validity bitmap or NULL, buffers[1] = values; format
+ * "i" i32, "I" u32, "l" i64, "L" u64, "f" f32, "g" f64 (tests/arrow_c_integration.rs:62-80).
+ * `offset` is honoured for both buffers (values: element offset, validity: bit offset); the reference always
+ * exports 0 (arrow_c_ffi.rs:1773) and ignores it on import (arrow_c_ffi.rs:1098-1111). `null_count` = 0 selects
+ * the dense kernel, -1 means unknown. `release` is never called: the producer keeps ownership.
+ * ---------------------------------------------------------------------------------------------- */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char* format;
+    const char* name;
+    const char* metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema** children;
+    struct ArrowSchema* dictionary;
+    void (*release)(struct ArrowSchema*);
+    void* private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void** buffers;
+    struct ArrowArray** children;
+    struct ArrowArray* dictionary;
+    void (*release)(struct ArrowArray*);
+    void* private_data;
+};
+#endif
+
+/* Sum of a primitive array. Integer formats: *out_sum_i64 = wrapping 64-bit sum (bit pattern) and
+ * *out_sum_f64 = that value converted; float formats: *out_sum_f64 only. Any output may be NULL. */
+ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                       double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count);
+ma_status ma_mean_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema, double* out_mean,
+                        uint64_t* out_valid_count);
+/* lhs (op) rhs for two primitive arrays of the same format, routed like resolve_binary_arithmetic
+ * (src/kernels/routing/arithmetic.rs:214-222): equal lengths, or one side of length 1, which is broadcast
+ * (src/kernels/routing/broadcast.rs:87-112 — fused, not materialised). Different formats ->
+ * MA_ERR_UNSUPPORTED (routing/arithmetic.rs:403-405). `out_values` receives max(len) elements.
+ * Validity: when neither operand carries nulls the dense kernel runs and *out_has_validity = 0; otherwise rows
+ * are gated by the AND of the attached bitmaps (merge_bitmasks_to_new, src/kernels/bitmask/mod.rs:171-196),
+ * `out_validity` (8*ceil(len/64) bytes) receives the result validity and *out_has_validity = 1. */
+ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, const struct ArrowSchema* lhs_schema,
+                         const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, void* out_values,
+                         uint8_t* out_validity, int32_t* out_has_validity);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

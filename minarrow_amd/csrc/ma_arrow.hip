@@ -1,0 +1,212 @@
+// Arrow C Data Interface entry points — the boundary format of the reference
+// (src/ffi/arrow_c_ffi.rs: #[repr(C)] ArrowArray / ArrowSchema; checked from C by tests/c_inspect_arrow.c:17-41).
+//
+// Numeric primitive arrays only: buffers[0] = validity bitmap (may be NULL), buffers[1] = values;
+// format "i" i32, "I" u32, "l" i64, "L" u64, "f" f32, "g" f64 (tests/arrow_c_integration.rs:62-80).
+// The reference always exports offset 0 (src/ffi/arrow_c_ffi.rs:1773) and ignores `offset` on import
+// (arrow_c_ffi.rs:1098-1111); other producers (PyArrow slices) set it, so it is honoured here for both buffers:
+// values start at element `offset`, validity at bit `offset`.
+// The library never calls `release`: the producer keeps ownership (arrow_c_ffi.rs:193-262).
+#include "ma_common.hpp"
+
+using namespace ma;
+
+namespace {
+
+struct Prim {
+    char code;
+    size_t size;
+};
+
+ma_status parse_primitive(const ArrowArray* array, const ArrowSchema* schema, Prim* out) {
+    MA_REQUIRE(array != nullptr && schema != nullptr, MA_ERR_INVALID_ARGUMENT, "ArrowArray or ArrowSchema is NULL");
+    MA_REQUIRE(schema->format != nullptr, MA_ERR_INVALID_ARGUMENT, "ArrowSchema.format is NULL");
+    MA_REQUIRE(array->length >= 0 && array->offset >= 0, MA_ERR_INVALID_ARGUMENT, "negative length or offset");
+    MA_REQUIRE(schema->dictionary == nullptr && array->dictionary == nullptr, MA_ERR_UNSUPPORTED,
+               "dictionary-encoded arrays are not numeric scans");
+    const char* f = schema->format;
+    MA_REQUIRE(f[0] != 0 && f[1] == 0, MA_ERR_UNSUPPORTED, "unsupported Arrow format \"%s\" (numeric primitives only)", f);
+    switch (f[0]) {
+        case 'i': case 'I': case 'f': *out = {f[0], 4}; break;
+        case 'l': case 'L': case 'g': *out = {f[0], 8}; break;
+        default:
+            set_error("unsupported Arrow format \"%s\" (numeric primitives only)", f);
+            return MA_ERR_UNSUPPORTED;
+    }
+    MA_REQUIRE(array->n_buffers == 2 && array->buffers != nullptr, MA_ERR_INVALID_ARGUMENT,
+               "a primitive array has exactly 2 buffers (validity, values); got %lld", (long long)array->n_buffers);
+    MA_REQUIRE(array->length == 0 || array->buffers[1] != nullptr, MA_ERR_INVALID_ARGUMENT, "values buffer is NULL");
+    return MA_OK;
+}
+
+// One element of a (host or device) values buffer -> host.
+ma_status fetch_scalar(ma_ctx* ctx, const void* src, size_t size, void* dst) {
+    if (pointer_kind(src) == kPageable || pointer_kind(src) == kPinned) {
+        memcpy(dst, src, size);
+        return MA_OK;
+    }
+    return ma_dev_download(ctx, dst, src, size);
+}
+
+}  // namespace
+
+extern "C" {
+
+ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                       double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count) {
+    Prim p{};
+    MA_TRY(parse_primitive(array, schema, &p));
+    const size_t n = (size_t)array->length, off = (size_t)array->offset;
+    const uint8_t* validity = (const uint8_t*)array->buffers[0];
+    const char* values = (const char*)array->buffers[1] + off * p.size;
+    // null_count: -1 = unknown; 0 = take the dense kernel even if a bitmap is attached
+    const int64_t nc = array->null_count;
+    if (out_sum_i64) *out_sum_i64 = 0;
+    if (out_sum_f64) *out_sum_f64 = 0.0;
+    switch (p.code) {
+        case 'l': {
+            int64_t s = 0;
+            MA_TRY(ma_i64_sum(ctx, (const int64_t*)values, n, validity, off, nc, &s, out_valid_count));
+            if (out_sum_i64) *out_sum_i64 = s;
+            if (out_sum_f64) *out_sum_f64 = (double)s;
+            return MA_OK;
+        }
+        case 'L': {
+            uint64_t s = 0;
+            MA_TRY(ma_u64_sum(ctx, (const uint64_t*)values, n, validity, off, nc, &s, out_valid_count));
+            if (out_sum_i64) *out_sum_i64 = (int64_t)s;
+            if (out_sum_f64) *out_sum_f64 = (double)s;
+            return MA_OK;
+        }
+        case 'i': {
+            int64_t s = 0;
+            MA_TRY(ma_i32_sum(ctx, (const int32_t*)values, n, validity, off, nc, &s, out_valid_count));
+            if (out_sum_i64) *out_sum_i64 = s;
+            if (out_sum_f64) *out_sum_f64 = (double)s;
+            return MA_OK;
+        }
+        case 'I': {
+            uint64_t s = 0;
+            MA_TRY(ma_u32_sum(ctx, (const uint32_t*)values, n, validity, off, nc, &s, out_valid_count));
+            if (out_sum_i64) *out_sum_i64 = (int64_t)s;
+            if (out_sum_f64) *out_sum_f64 = (double)s;
+            return MA_OK;
+        }
+        case 'f':
+            return ma_f32_sum(ctx, (const float*)values, n, validity, off, nc, out_sum_f64, out_valid_count);
+        default:
+            return ma_f64_sum(ctx, (const double*)values, n, validity, off, nc, out_sum_f64, out_valid_count);
+    }
+}
+
+ma_status ma_mean_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema, double* out_mean,
+                        uint64_t* out_valid_count) {
+    Prim p{};
+    MA_TRY(parse_primitive(array, schema, &p));
+    const size_t n = (size_t)array->length, off = (size_t)array->offset;
+    const uint8_t* validity = (const uint8_t*)array->buffers[0];
+    const char* values = (const char*)array->buffers[1] + off * p.size;
+    const int64_t nc = array->null_count;
+    switch (p.code) {
+        case 'l': return ma_i64_mean(ctx, (const int64_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'L': return ma_u64_mean(ctx, (const uint64_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'i': return ma_i32_mean(ctx, (const int32_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'I': return ma_u32_mean(ctx, (const uint32_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'f': return ma_f32_mean(ctx, (const float*)values, n, validity, off, nc, out_mean, out_valid_count);
+        default: return ma_f64_mean(ctx, (const double*)values, n, validity, off, nc, out_mean, out_valid_count);
+    }
+}
+
+// lhs (op) rhs for two primitive arrays of the same format, routed like resolve_binary_arithmetic
+// (src/kernels/routing/arithmetic.rs:214-222): equal lengths, or one side of length 1 which is broadcast
+// (routing/broadcast.rs:87-112, fused here). Validity: none attached -> dense kernel, `out_validity` untouched and
+// *out_has_validity = 0; otherwise the AND of the attached bitmaps gates the rows (merge_bitmasks_to_new,
+// src/kernels/bitmask/mod.rs:171-196 — the rule apply_datetime_* uses, dispatch.rs:321-322).
+ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, const struct ArrowSchema* lhs_schema,
+                         const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, void* out_values,
+                         uint8_t* out_validity, int32_t* out_has_validity) {
+    Prim pl{}, pr{};
+    MA_TRY(parse_primitive(lhs, lhs_schema, &pl));
+    MA_TRY(parse_primitive(rhs, rhs_schema, &pr));
+    if (pl.code != pr.code) {
+        // arithmetic_dispatch's `_ => UnsupportedType` arm (routing/arithmetic.rs:403-405); the i32<->f32/f64
+        // promotions (:342-373) are host-side casts, see INTEGRATION.md.
+        set_error("Unsupported array type combination for arithmetic operations (\"%s\" vs \"%s\")", lhs_schema->format,
+                  rhs_schema->format);
+        return MA_ERR_UNSUPPORTED;
+    }
+    const size_t nl = (size_t)lhs->length, nr = (size_t)rhs->length;
+    const size_t lo = (size_t)lhs->offset, ro = (size_t)rhs->offset;
+    if (out_has_validity) *out_has_validity = 0;
+    if (nl != nr && nl != 1 && nr != 1) {
+        set_error("cannot broadcast arrays of length %zu and %zu", nl, nr);
+        return MA_ERR_LENGTH_MISMATCH;
+    }
+    const size_t n = nl == nr ? nl : (nl == 1 ? nr : nl);
+    const uint8_t* lv = lhs->null_count == 0 ? nullptr : (const uint8_t*)lhs->buffers[0];
+    const uint8_t* rv = rhs->null_count == 0 ? nullptr : (const uint8_t*)rhs->buffers[0];
+    const bool scalar_l = nl == 1 && nr != 1, scalar_r = nr == 1 && nl != 1;
+    // A broadcast length-1 operand contributes no row validity (broadcast_length_1_array builds a mask-free
+    // array, routing/broadcast.rs:30-45).
+    if (scalar_l) lv = nullptr;
+    if (scalar_r) rv = nullptr;
+    const uint8_t* mask = nullptr;
+    size_t mask_off = 0;
+    if (lv && rv) {
+        MA_REQUIRE(out_validity != nullptr, MA_ERR_INVALID_ARGUMENT, "out_validity is NULL but both inputs carry nulls");
+        // AND of the two windows, written to out_validity at bit 0, then used as the gate.
+        uint8_t* la = nullptr;  // left window re-based to bit 0 (scratch = out_validity itself)
+        MA_TRY(ma_bitmask_slice(ctx, lv, lo, n, out_validity));
+        la = out_validity;
+        // rhs window -> temporary device bitmap, AND into out_validity
+        void* tmp = nullptr;
+        MA_TRY(ma_dev_alloc(ctx, ((n + 63) / 64) * 8 + 8, &tmp));
+        ma_status s = ma_bitmask_slice(ctx, rv, ro, n, (uint8_t*)tmp);
+        if (s == MA_OK) s = ma_and_masks(ctx, la, 0, (const uint8_t*)tmp, 0, n, out_validity);
+        (void)ma_dev_free(ctx, tmp);
+        MA_TRY(s);
+        mask = out_validity;
+        mask_off = 0;
+    } else if (lv) {
+        mask = lv;
+        mask_off = lo;
+    } else if (rv) {
+        mask = rv;
+        mask_off = ro;
+    }
+    MA_REQUIRE(mask == nullptr || out_validity != nullptr, MA_ERR_INVALID_ARGUMENT,
+               "out_validity is NULL but an input carries nulls");
+    if (out_has_validity) *out_has_validity = mask ? 1 : 0;
+    const char* a = (const char*)lhs->buffers[1] + lo * pl.size;
+    const char* b = (const char*)rhs->buffers[1] + ro * pr.size;
+
+#define MA_ROUTE(FAMILY, TAG, T)                                                                                      \
+    do {                                                                                                              \
+        if (scalar_l) {                                                                                               \
+            T sc;                                                                                                     \
+            MA_TRY(fetch_scalar(ctx, a, sizeof(T), &sc));                                                          \
+            return ma_apply_##FAMILY##_##TAG##_scalar_lhs(ctx, sc, (const T*)b, n, op, mask, mask_off, (T*)out_values, \
+                                                          out_validity);                                              \
+        }                                                                                                             \
+        if (scalar_r) {                                                                                               \
+            T sc;                                                                                                     \
+            MA_TRY(fetch_scalar(ctx, b, sizeof(T), &sc));                                                          \
+            return ma_apply_##FAMILY##_##TAG##_scalar_rhs(ctx, (const T*)a, n, sc, op, mask, mask_off, (T*)out_values, \
+                                                          out_validity);                                              \
+        }                                                                                                             \
+        return ma_apply_##FAMILY##_##TAG(ctx, (const T*)a, nl, (const T*)b, nr, op, mask, mask_off, (T*)out_values,    \
+                                         out_validity);                                                               \
+    } while (0)
+
+    switch (pl.code) {
+        case 'i': MA_ROUTE(int, i32, int32_t);
+        case 'I': MA_ROUTE(int, u32, uint32_t);
+        case 'l': MA_ROUTE(int, i64, int64_t);
+        case 'L': MA_ROUTE(int, u64, uint64_t);
+        case 'f': MA_ROUTE(float, f32, float);
+        default: MA_ROUTE(float, f64, double);
+    }
+#undef MA_ROUTE
+}
+
+}  // extern "C"

@@ -61,6 +61,7 @@ def parse_header(path: Path = HEADER_PATH):
     text = path.read_text()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#[^\n]*$", " ", text, flags=re.M)  # preprocessor lines
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(ma_\w+)\s*\(([^;{}()]*)\)\s*;", text):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -307,3 +307,24 @@ class Context:
     def simd_eq_mask(self, tag: str, data, n: int, field_mask: int, target: int, out) -> None:
         ffi.check(getattr(self.lib, f"ma_simd_eq_mask_{tag}")(self.handle, addr_of(data), int(n), int(field_mask),
                                                              int(target), addr_of(out)))
+
+    # -- Arrow C Data Interface --------------------------------------------------------------------------
+    def sum_arrow(self, array_ptr: int, schema_ptr: int):
+        """(sum as float, sum as wrapped int64, valid_count) of a primitive ArrowArray."""
+        f, i, c = C.c_double(), C.c_int64(), C.c_uint64()
+        ffi.check(self.lib.ma_sum_arrow(self.handle, int(array_ptr), int(schema_ptr), C.addressof(f), C.addressof(i),
+                                        C.addressof(c)))
+        return f.value, i.value, int(c.value)
+
+    def mean_arrow(self, array_ptr: int, schema_ptr: int):
+        m, c = C.c_double(), C.c_uint64()
+        ffi.check(self.lib.ma_mean_arrow(self.handle, int(array_ptr), int(schema_ptr), C.addressof(m), C.addressof(c)))
+        return m.value, int(c.value)
+
+    def apply_arrow(self, op: int, lhs_ptrs, rhs_ptrs, out_values, out_validity) -> bool:
+        """lhs_ptrs / rhs_ptrs = (ArrowArray*, ArrowSchema*). Returns True when out_validity was written."""
+        has = C.c_int32()
+        ffi.check(self.lib.ma_apply_arrow(self.handle, int(op), int(lhs_ptrs[0]), int(lhs_ptrs[1]), int(rhs_ptrs[0]),
+                                          int(rhs_ptrs[1]), addr_of(out_values), addr_of(out_validity),
+                                          C.addressof(has)))
+        return bool(has.value)
