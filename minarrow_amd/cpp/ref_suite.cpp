@@ -1,0 +1,255 @@
+// ref_suite.cpp — the reference's kernel tests, replayed in C++ through the typed host mirror
+// (include/minarrow_hip.hpp) on the GPU. Each function names the Rust test it restates:
+//   src/kernels/arithmetic/mod.rs:117-537   (int_kernel_suite!, float_kernel_suite!, fma_*, merge_masks_correctness,
+//                                            test_int_dense_power_short_vs_long_input_simd)
+//   src/kernels/bitmask/simd.rs:797-955     (simd_bitmask_suite!)
+//   benches/hotloop_benchmark_std.rs:49-57  (sum of 0..N)
+// Exit code 0 = every assertion held. Run by tests/test_gpu_cpp_host.py.
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "minarrow_hip.hpp"
+
+using namespace ma;
+using Op = ArithmeticOperator;
+
+static int g_failed = 0, g_checked = 0;
+#define ASSERT(cond)                                                              \
+    do {                                                                          \
+        ++g_checked;                                                              \
+        if (!(cond)) {                                                            \
+            ++g_failed;                                                           \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);           \
+        }                                                                         \
+    } while (0)
+
+template <typename F>
+static bool panics(F f) {  // std::panic::catch_unwind(...).is_err()
+    try {
+        f();
+    } catch (const Panic&) {
+        return true;
+    }
+    return false;
+}
+
+template <typename T>
+static void assert_int(const IntegerArray<T>& arr, const std::vector<T>& values, const std::vector<bool>* valid) {
+    ASSERT(arr.data == values);
+    if (valid) {
+        ASSERT(arr.null_mask.has_value());
+        if (arr.null_mask)
+            for (size_t i = 0; i < valid->size(); ++i) ASSERT(arr.null_mask->get(i) == (*valid)[i]);
+    } else if (arr.null_mask) {
+        ASSERT(arr.null_mask->all_true());
+    }
+}
+
+// int_kernel_suite! — mod.rs:117-230
+template <typename T, typename Apply>
+static void int_kernel_suite(const char* name, Apply apply) {
+    std::printf("int_kernel_suite %s\n", name);
+    {  // $fn_dense
+        Vec64<T> lhs{1, 4, 9, 16}, rhs{1, 2, 3, 4};
+        assert_int<T>(apply(lhs, rhs, Op::Add, nullptr), {2, 6, 12, 20}, nullptr);
+        assert_int<T>(apply(lhs, rhs, Op::Subtract, nullptr), {0, 2, 6, 12}, nullptr);
+        assert_int<T>(apply(lhs, rhs, Op::Multiply, nullptr), {1, 8, 27, 64}, nullptr);
+        assert_int<T>(apply(lhs, rhs, Op::Divide, nullptr), {1, 2, 3, 4}, nullptr);
+        assert_int<T>(apply(lhs, rhs, Op::Remainder, nullptr), {0, 0, 0, 0}, nullptr);
+        std::vector<T> expected;
+        for (size_t i = 0; i < 4; ++i) {
+            T acc = 1;
+            for (T k = 0; k < rhs[i]; ++k) acc = (T)(acc * lhs[i]);  // wrapping_mul
+            expected.push_back(acc);
+        }
+        assert_int<T>(apply(lhs, rhs, Op::Power, nullptr), expected, nullptr);
+        std::vector<T> rhs_divzero{0, 0, 0, 0};
+        ASSERT(panics([&] { apply(lhs, rhs_divzero, Op::Divide, nullptr); }));     // "must panic"
+        ASSERT(panics([&] { apply(lhs, rhs_divzero, Op::Remainder, nullptr); }));
+    }
+    {  // $fn_masked
+        Vec64<T> lhs{10, 20, 30, 40}, rhs{2, 0, 3, 5};
+        Bitmask mask = Bitmask::from_bools({true, false, true, false});
+        std::vector<bool> expect_mask{true, false, true, false};
+        assert_int<T>(apply(lhs, rhs, Op::Divide, &mask), {5, 0, 10, 0}, &expect_mask);
+        assert_int<T>(apply(lhs, rhs, Op::Remainder, &mask), {0, 0, 0, 0}, &expect_mask);
+        Bitmask mask_divzero = Bitmask::from_bools({true, true, true, true});
+        std::vector<T> rhs_divzero{1, 0, 2, 0}, lhs2{100, 100, 100, 100};  // plain slices: pageable memory, staged
+        assert_int<T>(apply(lhs2, rhs_divzero, Op::Divide, &mask_divzero), {100, 0, 50, 0}, &expect_mask);
+    }
+    {  // $fn_empty
+        Vec64<T> lhs, rhs;
+        ASSERT(apply(lhs, rhs, Op::Add, nullptr).is_empty());
+    }
+    {  // confirm_equal_len
+        Vec64<T> lhs{1, 2, 3}, rhs{1, 2};
+        bool mismatch = false;
+        try {
+            apply(lhs, rhs, Op::Add, nullptr);
+        } catch (const KernelError& e) {
+            mismatch = e.kind == KernelError::LengthMismatch;
+        }
+        ASSERT(mismatch);
+    }
+}
+
+// float_kernel_suite! — mod.rs:293-367
+template <typename T, typename Apply>
+static void float_kernel_suite(const char* name, Apply apply, T eps) {
+    std::printf("float_kernel_suite %s\n", name);
+    Vec64<T> lhs{1.0, 4.0, 9.0, 16.0}, rhs{0.5, 2.0, 3.0, 4.0};
+    ASSERT((apply(lhs, rhs, Op::Add, nullptr).data == std::vector<T>{1.5, 6.0, 12.0, 20.0}));
+    ASSERT((apply(lhs, rhs, Op::Subtract, nullptr).data == std::vector<T>{0.5, 2.0, 6.0, 12.0}));
+    ASSERT((apply(lhs, rhs, Op::Multiply, nullptr).data == std::vector<T>{0.5, 8.0, 27.0, 64.0}));
+    ASSERT((apply(lhs, rhs, Op::Divide, nullptr).data == std::vector<T>{2.0, 2.0, 3.0, 4.0}));
+    auto rem = apply(lhs, rhs, Op::Remainder, nullptr);
+    for (size_t i = 0; i < 4; ++i) ASSERT(std::fabs(rem.data[i] - std::fmod(lhs[i], rhs[i])) < eps);
+    auto pw = apply(lhs, rhs, Op::Power, nullptr);
+    for (size_t i = 0; i < 4; ++i) {
+        T expected = std::exp(rhs[i] * std::log(lhs[i]));
+        ASSERT(std::fabs(pw.data[i] - expected) <= eps * std::fmax((T)1, expected) * 64);
+    }
+    std::vector<T> rhs_divzero{0.0, 0.0, 0.0, 0.0};
+    auto dz = apply(lhs, rhs_divzero, Op::Divide, nullptr);
+    for (size_t i = 0; i < 4; ++i) ASSERT(std::isinf(dz.data[i]));  // "Float division by zero should yield Inf"
+    auto rz = apply(lhs, rhs_divzero, Op::Remainder, nullptr);
+    for (size_t i = 0; i < 4; ++i) ASSERT(std::isnan(rz.data[i]));
+    Bitmask mask = Bitmask::from_bools({true, false, true, false});
+    auto m = apply(lhs, rhs, Op::Multiply, &mask);
+    ASSERT((m.data == std::vector<T>{0.5, 0.0, 27.0, 0.0}));
+    ASSERT(m.null_mask && m.null_mask->len == 4);
+    Vec64<T> e1, e2;
+    ASSERT(apply(e1, e2, Op::Add, nullptr).is_empty());
+}
+
+template <typename T, typename Fma>
+static void fma_suite(const char* name, Fma fma) {  // fma_f32 / fma_f64 — mod.rs:372-399
+    std::printf("fma %s\n", name);
+    Vec64<T> lhs{1.0, 2.0, 3.0}, rhs{4.0, 5.0, 6.0}, acc{0.5, 0.5, 0.5};
+    auto out = fma(lhs, rhs, acc, nullptr);
+    ASSERT((out.data == std::vector<T>{4.5, 10.5, 18.5}));
+    ASSERT(!out.null_mask);
+    Bitmask mask = Bitmask::from_bools({true, false, true});
+    out = fma(lhs, rhs, acc, &mask);
+    ASSERT((out.data == std::vector<T>{4.5, 0.0, 18.5}));
+    ASSERT(out.null_mask && out.null_mask->get(0) && !out.null_mask->get(1) && out.null_mask->get(2));
+    Vec64<T> e;
+    ASSERT(fma(e, e, e, nullptr).is_empty());
+}
+
+static void merge_masks_correctness() {  // mod.rs:401-409
+    std::printf("merge_masks_correctness\n");
+    Bitmask a = Bitmask::from_bools({true, false, true, true}), b = Bitmask::from_bools({true, true, false, true});
+    auto merged = merge_bitmasks_to_new(&a, &b, 4);
+    ASSERT(merged.has_value());
+    std::vector<bool> expected{true, false, false, true};
+    for (size_t i = 0; i < 4; ++i) ASSERT(merged->get(i) == expected[i]);
+    ASSERT(!merge_bitmasks_to_new(nullptr, nullptr, 4).has_value());
+}
+
+static void int_power_short_vs_long() {  // mod.rs:507-537
+    std::printf("test_int_dense_power_short_vs_long_input\n");
+    for (size_t n : {(size_t)16, (size_t)128}) {
+        Vec64<uint32_t> lhs(n, 2u), rhs(n, 10u);
+        auto out = apply_int_u32(lhs, rhs, Op::Power);
+        for (size_t i = 0; i < n; ++i) ASSERT(out.data[i] == 1024u);
+    }
+}
+
+static void simd_bitmask_suite(size_t lanes) {  // bitmask/simd.rs:797-955
+    std::printf("simd_bitmask_suite LANES=%zu\n", lanes);
+    Bitmask a = Bitmask::from_bools({true, false, true, false, true, true, false, false});
+    Bitmask b = Bitmask::from_bools({true, true, false, false, true, false, true, false});
+    Bitmask c = and_masks(window(a), window(b)), o = or_masks(window(a), window(b)), x = xor_masks(window(a), window(b));
+    for (size_t i = 0; i < a.len; ++i) {
+        ASSERT(c.get(i) == (a.get(i) & b.get(i)));
+        ASSERT(o.get(i) == (a.get(i) | b.get(i)));
+        ASSERT(x.get(i) == (a.get(i) ^ b.get(i)));
+    }
+    Bitmask n4 = Bitmask::from_bools({true, false, true, false});
+    Bitmask nn = not_mask(window(n4));
+    for (size_t i = 0; i < 4; ++i) ASSERT(nn.get(i) == !n4.get(i));
+    {  // test_in_mask_simd_variants
+        Bitmask lhs = Bitmask::from_bools({true, false, true, false});
+        Bitmask rhs_true = Bitmask::from_bools({true, true, true, true}), rhs_false = Bitmask::from_bools({false, false, false, false});
+        Bitmask rhs_both = Bitmask::from_bools({true, false, true, false});
+        Bitmask out = in_mask(window(lhs), window(rhs_true));
+        for (size_t i = 0; i < 4; ++i) ASSERT(out.get(i) == lhs.get(i));
+        out = in_mask(window(lhs), window(rhs_false));
+        for (size_t i = 0; i < 4; ++i) ASSERT(out.get(i) == !lhs.get(i));
+        out = in_mask(window(lhs), window(rhs_both));
+        for (size_t i = 0; i < 4; ++i) ASSERT(out.get(i));
+        Bitmask in = in_mask(window(lhs), window(rhs_both)), not_in = not_in_mask(window(lhs), window(rhs_both));
+        for (size_t i = 0; i < 4; ++i) ASSERT(not_in.get(i) == !in.get(i));
+    }
+    {  // eq / ne
+        Bitmask p = Bitmask::from_bools({true, false, true, false}), q = Bitmask::from_bools({true, false, false, true});
+        Bitmask eq = eq_mask(window(p), window(q)), ne = ne_mask(window(p), window(q));
+        for (size_t i = 0; i < 4; ++i) {
+            ASSERT(eq.get(i) == (p.get(i) == q.get(i)));
+            ASSERT(ne.get(i) == (p.get(i) != q.get(i)));
+        }
+    }
+    {  // all_eq / all_ne
+        Bitmask b2 = a;
+        ASSERT(all_eq(window(a), window(b2)));
+        b2.set(0, false);
+        ASSERT(!all_eq(window(a), window(b2)));
+        Bitmask p = Bitmask::from_bools({true, false, true}), q = Bitmask::from_bools({false, true, false});
+        ASSERT(all_ne(window(p), window(q)));
+        ASSERT(!all_ne(window(p), window(p)));
+    }
+    ASSERT(popcount_mask(window(Bitmask::from_bools({true, false, true, false, true, false, false, true}))) == 4);
+    {  // all_true / all_false on 64 * LANES bits
+        Bitmask all_true = Bitmask::new_set_all(64 * lanes, true);
+        ASSERT(all_true_mask(all_true));
+        ASSERT(!all_false_mask(all_true));
+        Bitmask not_true = all_true;
+        not_true.set(3, false);
+        ASSERT(!all_true_mask(not_true));
+        ASSERT(all_false_mask(Bitmask::new_set_all(64 * lanes, false)));
+    }
+}
+
+static void bench_sums() {  // benches/hotloop_benchmark_std.rs:45-57, N = 1000; and N = 1_000_000 (config 1)
+    std::printf("bench sums\n");
+    for (size_t n : {(size_t)1000, (size_t)1000000}) {
+        Vec64<int64_t> v = Vec64<int64_t>::with_capacity(n);
+        Vec64<double> f = Vec64<double>::with_capacity(n);
+        for (size_t i = 0; i < n; ++i) {
+            v.push((int64_t)i);
+            f.push((double)i);
+        }
+        ASSERT(sum_i64(v) == (int64_t)(n * (n - 1) / 2));
+        ASSERT(sum_f64(f) == (double)(n * (n - 1) / 2));
+        ASSERT(mean_f64(f) == (double)(n * (n - 1) / 2) / (double)n);
+    }
+}
+
+int main() {
+    try {
+        int_kernel_suite<int32_t>("i32", [](Slice<int32_t> l, Slice<int32_t> r, Op op, const Bitmask* m) { return apply_int_i32(l, r, op, m); });
+        int_kernel_suite<uint32_t>("u32", [](Slice<uint32_t> l, Slice<uint32_t> r, Op op, const Bitmask* m) { return apply_int_u32(l, r, op, m); });
+        int_kernel_suite<int64_t>("i64", [](Slice<int64_t> l, Slice<int64_t> r, Op op, const Bitmask* m) { return apply_int_i64(l, r, op, m); });
+        int_kernel_suite<uint64_t>("u64", [](Slice<uint64_t> l, Slice<uint64_t> r, Op op, const Bitmask* m) { return apply_int_u64(l, r, op, m); });
+        float_kernel_suite<float>("f32", [](Slice<float> l, Slice<float> r, Op op, const Bitmask* m) { return apply_float_f32(l, r, op, m); }, 1e-6f);
+        float_kernel_suite<double>("f64", [](Slice<double> l, Slice<double> r, Op op, const Bitmask* m) { return apply_float_f64(l, r, op, m); }, 1e-12);
+        fma_suite<float>("f32", [](Slice<float> a, Slice<float> b, Slice<float> c, const Bitmask* m) { return apply_fma_f32(a, b, c, m); });
+        fma_suite<double>("f64", [](Slice<double> a, Slice<double> b, Slice<double> c, const Bitmask* m) { return apply_fma_f64(a, b, c, m); });
+        merge_masks_correctness();
+        int_power_short_vs_long();
+        for (size_t lanes : {(size_t)8, (size_t)16, (size_t)32, (size_t)64}) simd_bitmask_suite(lanes);
+        bench_sums();
+        // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
+        Vec64<int32_t> arr{10, 20, 30};
+        ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
+    } catch (const std::exception& e) {
+        std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
+        return 2;
+    }
+    std::printf("%d assertions, %d failed\n", g_checked, g_failed);
+    return g_failed ? 1 : 0;
+}
