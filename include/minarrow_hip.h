@@ -393,6 +393,22 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
                          const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, void* out_values,
                          uint8_t* out_validity, int32_t* out_has_validity);
 
+/* ------------------------------------------------------------------------------------------------
+ * Consolidation of a chunked numeric column (BASELINE config 5) —
+ *   Consolidate::consolidate / consolidate_concat / consolidate_arena  src/structs/chunked/super_table.rs:657-743
+ *   consolidate_{int,float}_variant!, extend_null_mask                 src/traits/consolidate.rs:80-207
+ *   Arena::write_slices                                                src/structs/arena.rs:264-308
+ * chunk i = (chunk_data[i], chunk_lens[i] rows of elem_size bytes, optional validity chunk_masks[i] whose row 0
+ * is bit chunk_mask_offsets[i]; chunk_masks / chunk_mask_offsets themselves may be NULL). Values are concatenated
+ * in chunk order into out_data. The result has validity iff at least one chunk has (*out_has_mask); chunks
+ * without a bitmap contribute all-valid rows (consolidate.rs:80-105). n_chunks == 0 -> MA_ERR_INVALID_ARGUMENT
+ * (the reference panics: "consolidate() called on empty SuperTable", super_table.rs:693-696).
+ * ---------------------------------------------------------------------------------------------- */
+ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, const void* const* chunk_data,
+                                const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
+                                int32_t* out_has_mask);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -1,0 +1,205 @@
+// SuperTable / SuperArray consolidation for gfx950: K chunks of one column -> one contiguous column (+ validity).
+//
+// Replaces, for numeric columns:
+//   Consolidate::consolidate -> consolidate_concat / consolidate_arena   src/structs/chunked/super_table.rs:657-743
+//   consolidate_{int,float}_variant!, extend_null_mask                   src/traits/consolidate.rs:80-207
+//   Arena::write_slices (memcpy per chunk + mask build)                  src/structs/arena.rs:264-308
+//   append_array (extend_from_slice + bit-by-bit mask extend)            src/macros.rs:311-345
+//
+// Semantics restated: values are concatenated in chunk order; the result has a validity bitmap iff at least one
+// chunk has one, and a chunk without a bitmap contributes all-valid rows (consolidate.rs:80-105).
+//
+// One launch copies every chunk (a descriptor table with prefix offsets is binary-searched once per wave run, then
+// walked), so 100 x 10 000-row batches (benches/consolidate.rs:21-58) cost one launch, not 100 memcpys; a second
+// launch assembles the output bitmap word by word from bit-granular pieces of the chunk bitmaps. HBM-bound:
+// 2 x elem_size bytes per row (+ 2/8 for validity).
+#include "ma_device.hpp"
+
+namespace ma {
+
+struct ChunkDesc {
+    const void* data;        // first element of the chunk window
+    size_t start;            // first output row of this chunk
+    size_t len;              // rows
+    const uint64_t* words;   // validity words (8-byte aligned base) or nullptr = all valid
+    size_t bit_off;          // bit index of the chunk's row 0 relative to `words`
+    size_t last_word;        // last word index holding a window bit
+};
+
+// Index of the chunk that contains output row `row` (row < total). Chunks of length 0 are skipped naturally.
+__device__ __forceinline__ int find_chunk(const ChunkDesc* __restrict__ c, int n_chunks, size_t row) {
+    int lo = 0, hi = n_chunks - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (c[mid].start <= row) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks, size_t total,
+                                                        T* __restrict__ out) {
+    const unsigned lane = threadIdx.x & 63;
+    constexpr size_t RUN = (size_t)64 * UNROLL;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    const size_t n_runs = (total + RUN - 1) / RUN;
+    for (size_t r = wave_id; r < n_runs; r += n_waves) {
+        const size_t row0 = r * RUN;
+        int c = find_chunk(chunks, n_chunks, row0);  // wave-uniform
+        T v[UNROLL];
+        bool live[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const size_t row = row0 + (size_t)u * 64 + lane;
+            live[u] = row < total;
+            if (live[u]) {
+                while (row >= chunks[c].start + chunks[c].len) ++c;  // walk forward over chunk boundaries
+                v[u] = __builtin_nontemporal_load((const T*)chunks[c].data + (row - chunks[c].start));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const size_t row = row0 + (size_t)u * 64 + lane;
+            if (live[u]) __builtin_nontemporal_store(v[u], out + row);
+        }
+    }
+}
+
+// One thread per output validity word: pieces of up to 64 bits are pulled from the chunk bitmaps.
+__global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
+                                                             size_t total, uint64_t* __restrict__ out_words) {
+    const size_t n_words = (total + 63) >> 6;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
+        size_t row = j << 6;
+        const size_t row_end = row + 64 < total ? row + 64 : total;
+        int c = find_chunk(chunks, n_chunks, row);
+        uint64_t word = 0;
+        unsigned filled = 0;
+        while (row < row_end) {
+            while (row >= chunks[c].start + chunks[c].len) ++c;
+            const size_t in_chunk = row - chunks[c].start;
+            size_t take = chunks[c].len - in_chunk;
+            if (take > row_end - row) take = row_end - row;
+            uint64_t piece;
+            if (chunks[c].words == nullptr) {
+                piece = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
+            } else {
+                const size_t b = chunks[c].bit_off + in_chunk;
+                const size_t w = b >> 6;
+                const unsigned sh = (unsigned)(b & 63);
+                uint64_t lo = chunks[c].words[w];
+                piece = lo >> sh;
+                if (sh && (w + 1) <= chunks[c].last_word) piece |= chunks[c].words[w + 1] << (64 - sh);
+            }
+            if (take < 64) piece &= (((uint64_t)1) << take) - 1;
+            word |= piece << filled;
+            filled += (unsigned)take;
+            row += take;
+        }
+        out_words[j] = word;  // bits >= total stay zero
+    }
+}
+
+template <typename T>
+static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t total, void* out) {
+    constexpr int U = 8;
+    size_t n_runs = (total + 64 * U - 1) / (64 * U);
+    int grid = grid_for(ctx, (n_runs + kWaves - 1) / kWaves, 4);
+    hipLaunchKernelGGL((concat_kernel<T, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_chunks, total, (T*)out);
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, const void* const* chunk_data,
+                                           const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                           const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
+                                           int32_t* out_has_mask) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, MA_ERR_UNSUPPORTED,
+               "element size %zu is not a numeric column width", elem_size);
+    // super_table.rs:693-696 / :728-731: "consolidate() called on empty SuperTable"
+    MA_REQUIRE(n_chunks > 0, MA_ERR_INVALID_ARGUMENT, "consolidate() called on empty SuperTable");
+    MA_REQUIRE(n_chunks < ((size_t)1 << 30), MA_ERR_INVALID_ARGUMENT, "too many chunks");
+    MA_REQUIRE(chunk_data != nullptr && chunk_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
+    bool has_mask = false;
+    size_t total = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        MA_REQUIRE(chunk_lens[i] == 0 || chunk_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "chunk %zu data is NULL", i);
+        MA_REQUIRE(((uintptr_t)chunk_data[i] % elem_size) == 0, MA_ERR_INVALID_ARGUMENT, "chunk %zu is misaligned", i);
+        if (chunk_masks && chunk_masks[i]) has_mask = true;
+        total += chunk_lens[i];
+    }
+    if (out_has_mask) *out_has_mask = has_mask ? 1 : 0;
+    if (total == 0) return MA_OK;
+    MA_REQUIRE(out_data != nullptr, MA_ERR_INVALID_ARGUMENT, "out_data is NULL");
+    MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    std::vector<ChunkDesc> desc(n_chunks);
+    size_t row = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        ChunkDesc& d = desc[i];
+        const void* p = nullptr;
+        MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
+        d.data = p;
+        d.start = row;
+        d.len = chunk_lens[i];
+        d.words = nullptr;
+        d.bit_off = 0;
+        d.last_word = 0;
+        if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
+            MA_TRY(scope.in_mask(chunk_masks[i], chunk_mask_offsets ? chunk_mask_offsets[i] : 0, chunk_lens[i], &d.words,
+                                 &d.bit_off));
+            d.last_word = (d.bit_off + d.len - 1) >> 6;
+        }
+        row += chunk_lens[i];
+    }
+    const void* ddesc = nullptr;
+    {
+        // descriptor table -> device (always staged: it lives in this frame)
+        void* t = nullptr;
+        MA_HIP(hipMalloc(&t, sizeof(ChunkDesc) * n_chunks));
+        hipError_t e = hipMemcpyAsync(t, desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(t);
+            return hip_fail(e, "descriptor upload", __FILE__, __LINE__);
+        }
+        ddesc = t;
+    }
+    struct FreeLater {
+        const void* p;
+        hipStream_t s;
+        ~FreeLater() {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree((void*)p);
+        }
+    } free_desc{ddesc, ctx->stream};
+
+    void* po = nullptr;
+    MA_TRY(scope.out(out_data, total * elem_size, &po));
+    const ChunkDesc* d = (const ChunkDesc*)ddesc;
+    switch (elem_size) {
+        case 1: launch_concat<uint8_t>(ctx, d, (int)n_chunks, total, po); break;
+        case 2: launch_concat<uint16_t>(ctx, d, (int)n_chunks, total, po); break;
+        case 4: launch_concat<uint32_t>(ctx, d, (int)n_chunks, total, po); break;
+        default: launch_concat<uint64_t>(ctx, d, (int)n_chunks, total, po); break;
+    }
+    MA_HIP(hipGetLastError());
+    if (has_mask) {
+        uint64_t* ow = nullptr;
+        MA_TRY(scope.out_mask(out_mask, total, &ow));
+        const size_t n_words = (total + 63) >> 6;
+        int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+        hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
+        MA_HIP(hipGetLastError());
+    }
+    return end_call(ctx, scope);
+}

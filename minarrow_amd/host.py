@@ -328,3 +328,20 @@ class Context:
                                           int(rhs_ptrs[1]), addr_of(out_values), addr_of(out_validity),
                                           C.addressof(has)))
         return bool(has.value)
+
+    # -- consolidation of a chunked column (SuperTable / SuperArray) ------------------------------------
+    def consolidate_column(self, elem_size: int, chunks, lens, out_data, masks=None, mask_offsets=None,
+                           out_mask=None) -> bool:
+        """chunks / masks: sequences of buffers (mask entries may be None). Returns True when out_mask was written."""
+        k = len(chunks)
+        data_arr = (C.c_void_p * k)(*[addr_of(c) or None for c in chunks])
+        len_arr = (C.c_size_t * k)(*[int(n) for n in lens])
+        mask_arr = (C.c_void_p * k)(*[addr_of(m) or None for m in masks]) if masks is not None else None
+        off_arr = (C.c_size_t * k)(*[int(o) for o in mask_offsets]) if mask_offsets is not None else None
+        has = C.c_int32()
+        ffi.check(self.lib.ma_consolidate_column(
+            self.handle, int(elem_size), k, C.cast(data_arr, C.c_void_p), C.cast(len_arr, C.c_void_p),
+            C.cast(mask_arr, C.c_void_p) if mask_arr is not None else None,
+            C.cast(off_arr, C.c_void_p) if off_arr is not None else None, addr_of(out_data), addr_of(out_mask),
+            C.addressof(has)))
+        return bool(has.value)

@@ -1178,3 +1178,36 @@ MO_DEFINE_EQ_MASK(u64, uint64_t)
 MO_API void mo_broadcast_len1(const void* one, size_t elem_size, size_t n, void* out) {
     for (size_t i = 0; i < n; ++i) memcpy((uint8_t*)out + i * elem_size, one, elem_size);
 }
+
+/* =================================================================================================
+ * Consolidation of a chunked numeric column — src/traits/consolidate.rs:80-207 (consolidate_{int,float}_variant!,
+ * extend_null_mask), reached from Consolidate::consolidate (src/structs/chunked/super_table.rs:657-722).
+ * Values: extend_from_slice per chunk. Validity: the result has a mask iff any chunk has one (`has_nulls`,
+ * consolidate.rs:118-124); chunks with a mask extend it bit by bit from [offset, offset+len), chunks without
+ * set their rows valid (consolidate.rs:86-103). Returns has_nulls.
+ * ============================================================================================== */
+MO_API int mo_consolidate_column(size_t elem_size, size_t n_chunks, const void* const* chunk_data, const size_t* chunk_lens,
+                                 const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, void* out_data,
+                                 uint8_t* out_mask) {
+    int has_nulls = 0;
+    size_t total = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (chunk_masks && chunk_masks[i]) has_nulls = 1;
+        total += chunk_lens[i];
+    }
+    if (has_nulls) memset(out_mask, 0, ((total + 63) / 64) * 8);
+    size_t cur = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        memcpy((uint8_t*)out_data + cur * elem_size, chunk_data[i], chunk_lens[i] * elem_size);
+        if (has_nulls) {
+            for (size_t k = 0; k < chunk_lens[i]; ++k) {
+                int v = (chunk_masks && chunk_masks[i])
+                            ? mo_get_bit(chunk_masks[i], (chunk_mask_offsets ? chunk_mask_offsets[i] : 0) + k)
+                            : 1;
+                if (v) mo_set_bit(out_mask, cur + k, 1);
+            }
+        }
+        cur += chunk_lens[i];
+    }
+    return has_nulls;
+}

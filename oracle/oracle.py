@@ -428,3 +428,23 @@ def simd_mask_bits(bits, mask_len, offset, n, lanes) -> int:
 
 def write_mask_bits(out_bits, offset, mbits, lanes) -> None:
     klib().mo_write_mask_bits(_p(out_bits), offset, mbits, lanes)
+
+
+def consolidate_column(chunks, masks=None, mask_offsets=None):
+    """(values, validity bits or None) — src/traits/consolidate.rs:80-207."""
+    l = klib()
+    k = len(chunks)
+    dt = chunks[0].dtype
+    total = sum(c.size for c in chunks)
+    out = np.zeros(total, dtype=dt)
+    out_mask = _mask_words(total)
+    data_arr = (C.c_void_p * k)(*[c.ctypes.data for c in chunks])
+    len_arr = (C.c_size_t * k)(*[c.size for c in chunks])
+    mask_arr = (C.c_void_p * k)(*[(m.ctypes.data if m is not None else None) for m in masks]) if masks is not None else None
+    off_arr = (C.c_size_t * k)(*mask_offsets) if mask_offsets is not None else None
+    l.mo_consolidate_column.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    has = l.mo_consolidate_column(dt.itemsize, k, C.cast(data_arr, C.c_void_p), C.cast(len_arr, C.c_void_p),
+                                  C.cast(mask_arr, C.c_void_p) if mask_arr is not None else None,
+                                  C.cast(off_arr, C.c_void_p) if off_arr is not None else None, _p(out), _p(out_mask))
+    return out, (out_mask if has else None)
