@@ -192,7 +192,8 @@ def main() -> int:
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get("sum_f64_hbm_bytes_per_launch")
+            key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
+            traffic = json.loads(pmc.read_text()).get(key)
         except Exception:
             traffic = None
 
@@ -240,7 +241,8 @@ def main() -> int:
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            # free the HBM columns first so the host-side sample does not compete for anything
+            del col_i, col_f
+            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
         print(json.dumps(out), flush=True)
         if not ok:

@@ -409,6 +409,64 @@ ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, 
                                 const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
                                 int32_t* out_has_mask);
 
+/* Narrow integers — the reference's `extended_numeric_types` feature (src/kernels/arithmetic/dispatch.rs:380-387).
+ * Same contract as ma_apply_int_i32 above. */
+ma_status ma_apply_int_i8(ma_ctx* ctx, const int8_t* lhs, size_t lhs_len, const int8_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, int8_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_i8_scalar_rhs(ma_ctx* ctx, const int8_t* lhs, size_t lhs_len, int8_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int8_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_i8_scalar_lhs(ma_ctx* ctx, int8_t scalar, const int8_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int8_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u8(ma_ctx* ctx, const uint8_t* lhs, size_t lhs_len, const uint8_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, uint8_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_u8_scalar_rhs(ma_ctx* ctx, const uint8_t* lhs, size_t lhs_len, uint8_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint8_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u8_scalar_lhs(ma_ctx* ctx, uint8_t scalar, const uint8_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint8_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_i16(ma_ctx* ctx, const int16_t* lhs, size_t lhs_len, const int16_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, int16_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_i16_scalar_rhs(ma_ctx* ctx, const int16_t* lhs, size_t lhs_len, int16_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int16_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_i16_scalar_lhs(ma_ctx* ctx, int16_t scalar, const int16_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, int16_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u16(ma_ctx* ctx, const uint16_t* lhs, size_t lhs_len, const uint16_t* rhs, size_t rhs_len, int32_t op,
+                          const uint8_t* mask_bits, size_t mask_bit_offset, uint16_t* out, uint8_t* out_mask_bits);
+ma_status ma_apply_int_u16_scalar_rhs(ma_ctx* ctx, const uint16_t* lhs, size_t lhs_len, uint16_t scalar, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint16_t* out,
+                                     uint8_t* out_mask_bits);
+ma_status ma_apply_int_u16_scalar_lhs(ma_ctx* ctx, uint16_t scalar, const uint16_t* rhs, size_t rhs_len, int32_t op,
+                                     const uint8_t* mask_bits, size_t mask_bit_offset, uint16_t* out,
+                                     uint8_t* out_mask_bits);
+
+/* apply_datetime_{i32,u32,i64,u64}(lhs: DatetimeAVT, rhs: DatetimeAVT, op) — src/kernels/arithmetic/dispatch.rs:309-372,
+ * :420-427: a DatetimeAVT is (array, offset, len). The data windows are data[offset .. offset+len]; the result
+ * validity is merge_bitmasks_to_new(lhs mask, rhs mask, len) = per-row AND counted from bit 0 of each bitmap
+ * (dispatch.rs:321-322 — the reference does not window the masks by the view offset), then the integer kernels run
+ * unchanged. lhs_len != rhs_len -> MA_ERR_LENGTH_MISMATCH ("apply_datetime: length mismatch").
+ * Both masks NULL -> dense kernel, *out_has_mask = 0, out_mask_bits untouched. */
+ma_status ma_apply_datetime_i32(ma_ctx* ctx, const int32_t* lhs_data, size_t lhs_offset, size_t lhs_len,
+                               const uint8_t* lhs_mask_bits, const int32_t* rhs_data, size_t rhs_offset, size_t rhs_len,
+                               const uint8_t* rhs_mask_bits, int32_t op, int32_t* out, uint8_t* out_mask_bits,
+                               int32_t* out_has_mask);
+ma_status ma_apply_datetime_u32(ma_ctx* ctx, const uint32_t* lhs_data, size_t lhs_offset, size_t lhs_len,
+                               const uint8_t* lhs_mask_bits, const uint32_t* rhs_data, size_t rhs_offset, size_t rhs_len,
+                               const uint8_t* rhs_mask_bits, int32_t op, uint32_t* out, uint8_t* out_mask_bits,
+                               int32_t* out_has_mask);
+ma_status ma_apply_datetime_i64(ma_ctx* ctx, const int64_t* lhs_data, size_t lhs_offset, size_t lhs_len,
+                               const uint8_t* lhs_mask_bits, const int64_t* rhs_data, size_t rhs_offset, size_t rhs_len,
+                               const uint8_t* rhs_mask_bits, int32_t op, int64_t* out, uint8_t* out_mask_bits,
+                               int32_t* out_has_mask);
+ma_status ma_apply_datetime_u64(ma_ctx* ctx, const uint64_t* lhs_data, size_t lhs_offset, size_t lhs_len,
+                               const uint8_t* lhs_mask_bits, const uint64_t* rhs_data, size_t rhs_offset, size_t rhs_len,
+                               const uint8_t* rhs_mask_bits, int32_t op, uint64_t* out, uint8_t* out_mask_bits,
+                               int32_t* out_has_mask);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -9,8 +9,8 @@
 // Semantics restated: values are concatenated in chunk order; the result has a validity bitmap iff at least one
 // chunk has one, and a chunk without a bitmap contributes all-valid rows (consolidate.rs:80-105).
 //
-// One launch copies every chunk (a descriptor table with prefix offsets is binary-searched once per wave run, then
-// walked), so 100 x 10 000-row batches (benches/consolidate.rs:21-58) cost one launch, not 100 memcpys; a second
+// One launch copies every chunk (a descriptor table with per-chunk tile prefix sums is binary-searched once per
+// workgroup tile), so 100 x 10 000-row batches (benches/consolidate.rs:21-58) cost one launch, not 100 memcpys; a second
 // launch assembles the output bitmap word by word from bit-granular pieces of the chunk bitmaps. HBM-bound:
 // 2 x elem_size bytes per row (+ 2/8 for validity).
 #include "ma_device.hpp"
@@ -24,6 +24,9 @@ struct ChunkDesc {
     const uint64_t* words;   // validity words (8-byte aligned base) or nullptr = all valid
     size_t bit_off;          // bit index of the chunk's row 0 relative to `words`
     size_t last_word;        // last word index holding a window bit
+    size_t tile0;            // index of this chunk's first copy tile (prefix sum over chunks)
+    unsigned head;           // rows in front of the first 16-byte boundary of the DESTINATION
+    unsigned vec;            // 1 when source and destination share their 16-byte phase (vector copy possible)
 };
 
 // Index of the chunk that contains output row `row` (row < total). Chunks of length 0 are skipped naturally.
@@ -36,33 +39,50 @@ __device__ __forceinline__ int find_chunk(const ChunkDesc* __restrict__ c, int n
     }
     return lo;
 }
+__device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ c, int n_chunks, size_t tile) {
+    int lo = 0, hi = n_chunks - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (c[mid].tile0 <= tile) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
 
+// Copy tiles: every chunk is cut into tiles of TILE_ROWS rows counted from its first 16-byte aligned destination
+// row (tile 0 also takes the `head` rows in front of it). A full tile of a phase-matched chunk moves 16 bytes per
+// lane per access (the bandwidth path); partial tiles and phase-mismatched chunks move one row per lane.
 template <typename T, int UNROLL>
-__global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks, size_t total,
-                                                        T* __restrict__ out) {
-    const unsigned lane = threadIdx.x & 63;
-    constexpr size_t RUN = (size_t)64 * UNROLL;
-    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
-    const size_t n_runs = (total + RUN - 1) / RUN;
-    for (size_t r = wave_id; r < n_runs; r += n_waves) {
-        const size_t row0 = r * RUN;
-        int c = find_chunk(chunks, n_chunks, row0);  // wave-uniform
-        T v[UNROLL];
-        bool live[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const size_t row = row0 + (size_t)u * 64 + lane;
-            live[u] = row < total;
-            if (live[u]) {
-                while (row >= chunks[c].start + chunks[c].len) ++c;  // walk forward over chunk boundaries
-                v[u] = __builtin_nontemporal_load((const T*)chunks[c].data + (row - chunks[c].start));
-            }
+__global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
+                                                        size_t n_tiles, T* __restrict__ out) {
+    typedef typename Vec16<T>::type V;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int c = find_chunk_by_tile(chunks, n_chunks, t);  // workgroup-uniform
+        const ChunkDesc d = chunks[c];
+        const size_t lt = t - d.tile0;
+        const T* __restrict__ src = (const T*)d.data;
+        T* __restrict__ dst = out + d.start;
+        const size_t r0 = d.head + lt * TILE_ROWS;  // first row of the aligned part of this tile
+        const size_t r1 = r0 + TILE_ROWS < d.len ? r0 + TILE_ROWS : d.len;
+        if (lt == 0) {
+            for (size_t i = threadIdx.x; i < d.head && i < d.len; i += kBlock) dst[i] = src[i];
         }
+        if (r0 >= d.len) continue;
+        if (d.vec && r1 - r0 == TILE_ROWS) {
+            const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = (const V*)(src + w0) + lane;
+            V* __restrict__ q = (V*)(dst + w0) + lane;
+            V v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const size_t row = row0 + (size_t)u * 64 + lane;
-            if (live[u]) __builtin_nontemporal_store(v[u], out + row);
+            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, true>(p + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) store16<V, true>(q + (size_t)u * 64, v[u]);
+        } else {
+            for (size_t i = r0 + threadIdx.x; i < r1; i += kBlock) dst[i] = src[i];
         }
     }
 }
@@ -104,11 +124,14 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
 }
 
 template <typename T>
-static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t total, void* out) {
-    constexpr int U = 8;
-    size_t n_runs = (total + 64 * U - 1) / (64 * U);
-    int grid = grid_for(ctx, (n_runs + kWaves - 1) / kWaves, 4);
-    hipLaunchKernelGGL((concat_kernel<T, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_chunks, total, (T*)out);
+static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t n_tiles, void* out) {
+    int grid = grid_for(ctx, n_tiles, 2);
+    hipLaunchKernelGGL((concat_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_chunks, n_tiles, (T*)out);
+}
+
+template <typename T>
+static size_t tile_rows_of() {
+    return (size_t)64 * (16 / sizeof(T)) * 4 * kWaves;
 }
 
 }  // namespace ma
@@ -143,7 +166,11 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     std::vector<ChunkDesc> desc(n_chunks);
-    size_t row = 0;
+    void* po = nullptr;
+    MA_TRY(scope.out(out_data, total * elem_size, &po));
+    const size_t tile_rows = elem_size == 1 ? tile_rows_of<uint8_t>() : elem_size == 2 ? tile_rows_of<uint16_t>()
+                           : elem_size == 4 ? tile_rows_of<uint32_t>() : tile_rows_of<uint64_t>();
+    size_t row = 0, n_tiles = 0;
     for (size_t i = 0; i < n_chunks; ++i) {
         ChunkDesc& d = desc[i];
         const void* p = nullptr;
@@ -159,6 +186,13 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
                                  &d.bit_off));
             d.last_word = (d.bit_off + d.len - 1) >> 6;
         }
+        // copy tiles of this chunk
+        const uintptr_t dst_addr = (uintptr_t)po + row * elem_size;
+        const uintptr_t mis = dst_addr & 15;
+        d.head = mis ? (unsigned)((16 - mis) / elem_size) : 0;
+        d.vec = (((uintptr_t)d.data & 15) == mis) ? 1u : 0u;
+        d.tile0 = n_tiles;
+        if (d.len) n_tiles += d.len > d.head ? (d.len - d.head + tile_rows - 1) / tile_rows : 1;
         row += chunk_lens[i];
     }
     const void* ddesc = nullptr;
@@ -183,14 +217,12 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
         }
     } free_desc{ddesc, ctx->stream};
 
-    void* po = nullptr;
-    MA_TRY(scope.out(out_data, total * elem_size, &po));
     const ChunkDesc* d = (const ChunkDesc*)ddesc;
     switch (elem_size) {
-        case 1: launch_concat<uint8_t>(ctx, d, (int)n_chunks, total, po); break;
-        case 2: launch_concat<uint16_t>(ctx, d, (int)n_chunks, total, po); break;
-        case 4: launch_concat<uint32_t>(ctx, d, (int)n_chunks, total, po); break;
-        default: launch_concat<uint64_t>(ctx, d, (int)n_chunks, total, po); break;
+        case 1: launch_concat<uint8_t>(ctx, d, (int)n_chunks, n_tiles, po); break;
+        case 2: launch_concat<uint16_t>(ctx, d, (int)n_chunks, n_tiles, po); break;
+        case 4: launch_concat<uint32_t>(ctx, d, (int)n_chunks, n_tiles, po); break;
+        default: launch_concat<uint64_t>(ctx, d, (int)n_chunks, n_tiles, po); break;
     }
     MA_HIP(hipGetLastError());
     if (has_mask) {

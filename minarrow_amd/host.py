@@ -20,6 +20,10 @@ _DTYPE_TAG = {
     np.dtype(np.uint32): "u32",
     np.dtype(np.float64): "f64",
     np.dtype(np.float32): "f32",
+    np.dtype(np.int8): "i8",
+    np.dtype(np.uint8): "u8",
+    np.dtype(np.int16): "i16",
+    np.dtype(np.uint16): "u16",
 }
 _TAG_DTYPE = {v: k for k, v in _DTYPE_TAG.items()}
 
@@ -344,4 +348,13 @@ class Context:
             C.cast(mask_arr, C.c_void_p) if mask_arr is not None else None,
             C.cast(off_arr, C.c_void_p) if off_arr is not None else None, addr_of(out_data), addr_of(out_mask),
             C.addressof(has)))
+        return bool(has.value)
+
+    def apply_datetime(self, tag: str, lhs, lhs_off: int, lhs_len: int, lhs_mask, rhs, rhs_off: int, rhs_len: int,
+                       rhs_mask, op: int, out, out_mask) -> bool:
+        """apply_datetime_<tag>((lhs, off, len), (rhs, off, len), op). Returns True when out_mask was written."""
+        has = C.c_int32()
+        fn = getattr(self.lib, f"ma_apply_datetime_{tag}")
+        ffi.check(fn(self.handle, addr_of(lhs), int(lhs_off), int(lhs_len), addr_of(lhs_mask), addr_of(rhs), int(rhs_off),
+                     int(rhs_len), addr_of(rhs_mask), int(op), addr_of(out), addr_of(out_mask), C.addressof(has)))
         return bool(has.value)

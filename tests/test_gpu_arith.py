@@ -23,9 +23,10 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 ARITH = json.loads((GOLD / "arithmetic_kat.json").read_text())
 ROUTE = json.loads((GOLD / "routing_kat.json").read_text())
-NP = {"i32": np.int32, "u32": np.uint32, "i64": np.int64, "u64": np.uint64, "f32": np.float32, "f64": np.float64}
+NP = {"i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32,
+      "i64": np.int64, "u64": np.uint64, "f32": np.float32, "f64": np.float64}
 OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "remainder": 4, "power": 5, "floordiv": 6}
-INT_TAGS = ("i32", "u32", "i64", "u64")
+INT_TAGS = ("i8", "u8", "i16", "u16", "i32", "u32", "i64", "u64")
 FLOAT_TAGS = ("f32", "f64")
 
 
@@ -132,7 +133,7 @@ def test_ref_int_dense(gpu, tag):
             acc = (acc * a) % (1 << (8 * np.dtype(NP[tag]).itemsize))
         expect.append(acc)
     out, _ = gpu.apply(tag, g["lhs"], g["rhs"], "power")
-    np.testing.assert_array_equal(out.astype(object), expect)
+    np.testing.assert_array_equal(out.astype(object) % (1 << (8 * out.itemsize)), expect)  # same bits, any signedness
     # "Dense integer kernel division by zero must panic" -> MA_ERR_DIVIDE_BY_ZERO
     for op in g["divide_by_zero_ops_must_panic"]:
         with pytest.raises(ffi.MinarrowHipError) as e:
@@ -205,17 +206,43 @@ def test_ref_fma(gpu, ctx, tag):
     assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH
 
 
-def test_ref_datetime_is_the_int_kernel(gpu, oracle):
-    """apply_datetime_i64 — mod.rs:418-505: AND-merged mask + the integer kernels unchanged"""
+def test_ref_datetime(ctx, gpu, oracle):
+    """datetime_add / datetime_all_ops / datetime_masked_and_empty / datetime_len_mismatch_panics —
+    src/kernels/arithmetic/mod.rs:418-505, through ma_apply_datetime_i64 (dispatch.rs:309-372)."""
     g = ARITH["datetime_i64"]
+
+    def run(lhs, rhs, op, lmask=None, rmask=None, loff=0, roff=0, n=None):
+        lhs, rhs = np.asarray(lhs, dtype=np.int64), np.asarray(rhs, dtype=np.int64)
+        n = lhs.size - loff if n is None else n
+        out = np.zeros(max(n, 1), dtype=np.int64)
+        om = np.zeros(mask_bytes(n) + 8, dtype=np.uint8)
+        has = ctx.apply_datetime("i64", lhs, loff, n, lmask, rhs, roff, rhs.size - roff if n == lhs.size - loff else n,
+                                 rmask, OPS[op], out, om)
+        return out[:n], (unpack(om, n) if has else None)
+
     for case in g["cases"]:
-        out, _ = gpu.apply("i64", case["lhs"], case["rhs"], case["op"])
+        out, valid = run(case["lhs"], case["rhs"], case["op"])
         np.testing.assert_array_equal(out, case["expect"])
+        assert valid is None  # "assert!(out.null_mask.is_none())"
     m = g["masked"]
-    merged = oracle.merge_bitmasks(oracle.pack_bits(m["lhs_mask"]), None, 4)
-    out, om = gpu.apply("i64", m["lhs"], m["rhs"], m["op"], mask=np.ascontiguousarray(merged[:8]))
+    out, valid = run(m["lhs"], m["rhs"], m["op"], lmask=np.concatenate([bits_of(m["lhs_mask"]), np.zeros(15, np.uint8)]))
     np.testing.assert_array_equal(out, m["expect"])
-    np.testing.assert_array_equal(unpack(om, 4), m["expect_mask"])
+    np.testing.assert_array_equal(valid, m["expect_mask"])
+    out, valid = run([], [], "add")
+    assert out.size == 0
+    with pytest.raises(ffi.MinarrowHipError) as e:  # #[should_panic(expected = "apply_datetime: length mismatch")]
+        ctx.apply_datetime("i64", np.array([1000, 2000]), 0, 2, None, np.array([10]), 0, 1, None, 0, np.zeros(2, np.int64), None)
+    assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH and "apply_datetime: length mismatch" in e.value.message
+    # both sides masked + view offsets: data is windowed, masks are AND-ed from bit 0 (dispatch.rs:321-324)
+    rng = np.random.default_rng(8)
+    n, loff, roff = 5000, 3, 10
+    a = rng.integers(-1000, 1000, size=n + loff).astype(np.int64)
+    b = rng.integers(1, 1000, size=n + roff).astype(np.int64)
+    ma_, mb_ = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8), rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    out, valid = run(a, b, "multiply", lmask=ma_, rmask=mb_, loff=loff, roff=roff, n=n)
+    want_valid = unpack(ma_, n) & unpack(mb_, n)
+    np.testing.assert_array_equal(valid, want_valid)
+    np.testing.assert_array_equal(out, np.where(want_valid, a[loff:loff + n] * b[roff:roff + n], 0))
 
 
 def test_ref_int_power_short_vs_long(gpu):

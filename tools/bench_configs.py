@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs (bench.py measures configs[1], the headline metric):
+
+  config 3  1B-row FloatArray<f64> elementwise add / mul, array (+) array and array (+) scalar (fused broadcast)
+  config 4  1B-row i64 sum with 10 % nulls via Bitmask, row-chunk partitioned across the ranks + scalar exchange
+  config 5  SuperTable of 8 chunks: consolidate (i64 + f64 columns, 10 % nulls) + per-column reduce
+
+Run on 1 GPU directly, or under torch.distributed.run for N ranks (config 4 partitions its 1B rows across them).
+Prints one JSON object per config on rank 0. HIP-event timing on the launch stream, HBM-resident inputs."""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+OPS = {"add": 0, "multiply": 2}
+
+
+def timed(ctx, fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    ctx.timer_stop()
+    return ctx.timer_elapsed_ms() / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--configs", type=str, default="3,4,5")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from minarrow_amd.host import Context
+    from minarrow_amd.parallel import ScalarExchange, row_chunks
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    stream = torch.cuda.current_stream(dev)
+    ctx = Context(local_rank, stream=stream.cuda_stream)
+    n = args.rows
+    configs = args.configs.split(",")
+    out = []
+
+    if "3" in configs and rank == 0:
+        a, b, o = (ctx.alloc(n * 8) for _ in range(3))
+        ctx.synth_iota("f64", a, n, 0)
+        ctx.apply_scalar("f64", "lhs", a, n, float(n), 1, b)  # b[i] = n - i
+        ctx.set_async(True)
+        res = {}
+        for op in ("add", "multiply"):
+            ms = timed(ctx, lambda: ctx.apply("f64", a, b, OPS[op], o, n, n), args.reps)
+            res[f"{op}_array_array"] = {"ms": ms, "grows_per_s": n / ms / 1e6, "gbps": 24 * n / ms / 1e6, "bytes_per_row": 24}
+            ms = timed(ctx, lambda: ctx.apply_scalar("f64", "rhs", a, n, 2.5, OPS[op], o), args.reps)
+            res[f"{op}_array_scalar"] = {"ms": ms, "grows_per_s": n / ms / 1e6, "gbps": 16 * n / ms / 1e6, "bytes_per_row": 16}
+        ctx.set_async(False)
+        ctx.synchronize()
+        s, _ = ctx.sum("f64", o, n)  # last op: a * 2.5
+        res["check_sum_a_times_2p5"] = s
+        out.append({"config": 3, "workload": f"{n}-row f64 add/mul, array(+)array and array(+)scalar, 1 MI355X", **res})
+        for buf in (a, b, o):
+            buf.free()
+
+    if "4" in configs:
+        lo, hi = row_chunks(n, world)[rank]
+        rows = hi - lo
+        data = ctx.alloc(max(rows, 1) * 8)
+        mask = ctx.alloc(max(rows, 64) // 8 + 64)
+        ctx.synth_iota("i64", data, rows, lo)
+        ctx.synth_validity(mask, rows, seed=0xC0FFEE, first_index=lo, null_every=10)
+        ex = ScalarExchange(dev)
+        ctx.set_async(True)
+
+        def step():
+            ctx.sum_into("i64", data, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1), mask=mask)
+            ex.exchange()
+
+        for _ in range(3):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.reps):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / args.reps
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        ctx.set_async(False)
+        total, cnt, _, _ = ex.results()
+        if rank == 0:
+            out.append({"config": 4, "workload": f"{n}-row i64 sum, 10 % nulls via Bitmask, row chunks over {world} GPU(s)"
+                        + (" + RCCL all-gather" if world > 1 else ""), "n_gpus": world, "ms_per_step": ms,
+                        "grows_per_s": n / ms / 1e6, "gbps": 8.125 * n / ms / 1e6, "bytes_per_row": 8.125,
+                        "sum_valid": total, "valid_count": cnt, "null_fraction": 1 - cnt / n})
+        data.free()
+        mask.free()
+
+    if "5" in configs and rank == 0:
+        k = 8
+        rows = n // k
+        res = {}
+        for tag in ("i64", "f64"):
+            chunks = [ctx.alloc(rows * 8) for _ in range(k)]
+            masks = [ctx.alloc(rows // 8 + 64) for _ in range(k)]
+            for c in range(k):
+                ctx.synth_iota(tag, chunks[c], rows, c)  # v[i] = i + chunk (benches/consolidate.rs:37-58 pattern)
+                ctx.synth_validity(masks[c], rows, seed=0xABC + c, null_every=10)
+            o = ctx.alloc(k * rows * 8)
+            om = ctx.alloc(k * rows // 8 + 64)
+            ms = timed(ctx, lambda: ctx.consolidate_column(8, chunks, [rows] * k, o, masks, [0] * k, om), max(2, args.reps // 2), 1)
+            parts = [ctx.sum(tag, chunks[c], rows, mask=masks[c]) for c in range(k)]
+            whole = ctx.sum(tag, o, k * rows, mask=om)
+            ctx.set_async(True)
+            slot = torch.zeros(8, dtype=torch.int64, device=dev)
+            ms_reduce_logical = timed(ctx, lambda: [ctx.sum_into(tag, chunks[c], rows, out_sum=slot.data_ptr(), out_count=slot.data_ptr() + 8,
+                                                                 mask=masks[c]) for c in range(k)], args.reps)
+            ms_reduce_physical = timed(ctx, lambda: ctx.sum_into(tag, o, k * rows, out_sum=slot.data_ptr(), out_count=slot.data_ptr() + 8,
+                                                                 mask=om), args.reps)
+            ctx.set_async(False)
+            ctx.synchronize()
+            res[tag] = {"consolidate_ms": ms, "consolidate_gbps": 16.25 * k * rows / ms / 1e6,
+                        "consolidate_grows_per_s": k * rows / ms / 1e6,
+                        "reduce_logical_ms": ms_reduce_logical, "reduce_logical_grows_per_s": k * rows / ms_reduce_logical / 1e6,
+                        "reduce_physical_ms": ms_reduce_physical, "reduce_physical_grows_per_s": k * rows / ms_reduce_physical / 1e6,
+                        "count_matches": whole[1] == sum(p[1] for p in parts),
+                        "sum_matches": (whole[0] == sum(p[0] for p in parts)) if tag == "i64" else
+                        abs(whole[0] - sum(p[0] for p in parts)) <= 8 * abs(whole[0]) * 2.0 ** -52}
+            for buf in chunks + masks + [o, om]:
+                buf.free()
+        out.append({"config": 5, "workload": f"SuperTable of {k} x {rows}-row chunks, columns i64 + f64 with 10 % nulls: "
+                                             f"consolidate + per-column reduce, 1 MI355X", **res})
+
+    if rank == 0:
+        for o_ in out:
+            print(json.dumps(o_), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
