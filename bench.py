@@ -81,7 +81,7 @@ def cpu_baseline(rows: int, budget_s: float):
         "cores": threads,
         "kind": "port",
         "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, "
-                  f"{threads} threads, best of {detail['i64']['reps']}/{detail['f64']['reps']} reps "
+                  f"persistent pool of {threads} threads, best of {detail['i64']['reps']}/{detail['f64']['reps']} reps "
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
         "detail": detail,
     }
@@ -93,7 +93,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU per column")
-    ap.add_argument("--cpu-rows", type=int, default=1 << 28, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 29, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)

@@ -214,21 +214,71 @@ static void* mo_par_worker(void* arg) {
     return NULL;
 }
 
-static int mo_par_run(mo_par_job* job, int n_threads) {
+/* A persistent worker pool (Rayon keeps its threads alive between calls too): workers sleep on a condition
+ * variable, a call publishes one job, everybody — the caller included — claims chunks from the shared counter. */
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_start, cv_done;
+    pthread_t* threads;
+    int n_workers;
+    void* (*fn)(void*);
+    void* arg;
+    unsigned long generation;
+    int remaining;
+    int initialised;
+} mo_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, NULL, 0, 0, 0};
+
+static void* mo_pool_worker(void* unused) {
+    (void)unused;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&mo_pool.mu);
+        while (mo_pool.generation == seen) pthread_cond_wait(&mo_pool.cv_start, &mo_pool.mu);
+        seen = mo_pool.generation;
+        void* (*fn)(void*) = mo_pool.fn;
+        void* arg = mo_pool.arg;
+        pthread_mutex_unlock(&mo_pool.mu);
+        fn(arg);
+        pthread_mutex_lock(&mo_pool.mu);
+        if (--mo_pool.remaining == 0) pthread_cond_signal(&mo_pool.cv_done);
+        pthread_mutex_unlock(&mo_pool.mu);
+    }
+    return NULL;
+}
+
+/* Runs fn(arg) on `n_threads` threads (n_threads - 1 pool workers + the caller) and waits for all of them. */
+static int mo_pool_run(void* (*fn)(void*), void* arg, int n_threads) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
-    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-    if (!th) return -1;
-    int started = 0;
-    for (int t = 0; t < n_threads - 1; ++t) {
-        if (pthread_create(&th[started], NULL, mo_par_worker, job) != 0) break;
-        ++started;
+    int want = n_threads - 1;
+    pthread_mutex_lock(&mo_pool.mu);
+    if (mo_pool.n_workers < want) {
+        pthread_t* grown = (pthread_t*)realloc(mo_pool.threads, sizeof(pthread_t) * (size_t)want);
+        if (grown) {
+            mo_pool.threads = grown;
+            while (mo_pool.n_workers < want) {
+                if (pthread_create(&mo_pool.threads[mo_pool.n_workers], NULL, mo_pool_worker, NULL) != 0) break;
+                pthread_detach(mo_pool.threads[mo_pool.n_workers]);
+                ++mo_pool.n_workers;
+            }
+        }
     }
-    mo_par_worker(job); /* the calling thread works too */
-    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-    free(th);
+    /* every pool worker wakes for every job; workers beyond `want` find the work counter exhausted */
+    int workers = mo_pool.n_workers;
+    mo_pool.fn = fn;
+    mo_pool.arg = arg;
+    mo_pool.remaining = workers;
+    ++mo_pool.generation;
+    pthread_cond_broadcast(&mo_pool.cv_start);
+    pthread_mutex_unlock(&mo_pool.mu);
+    fn(arg);
+    pthread_mutex_lock(&mo_pool.mu);
+    while (mo_pool.remaining) pthread_cond_wait(&mo_pool.cv_done, &mo_pool.mu);
+    pthread_mutex_unlock(&mo_pool.mu);
     return 0;
 }
+
+static int mo_par_run(mo_par_job* job, int n_threads) { return mo_pool_run(mo_par_worker, job, n_threads); }
 
 /* Work-sharing pool over chunks of `chunk` elements, partials combined in chunk order. */
 MO_API int64_t mo_par_sum_i64(const int64_t* data, size_t n, size_t chunk, int lanes, int n_threads) {
@@ -273,38 +323,28 @@ MO_API double mo_par_sum_f64(const double* data, size_t n, size_t chunk, int lan
  * (Vec64<i64> = (0..N).collect(), benches/benchmark_parallel_simd.rs:103,115). */
 typedef struct {
     void* data;
-    size_t n;
+    size_t n, chunk, n_chunks, next;
     int64_t start;
-    int is_f64, tid, nth;
+    int is_f64;
 } mo_fill_job;
 
 static void* mo_fill_worker(void* arg) {
     mo_fill_job* j = (mo_fill_job*)arg;
-    size_t lo = j->n * (size_t)j->tid / (size_t)j->nth, hi = j->n * (size_t)(j->tid + 1) / (size_t)j->nth;
-    if (j->is_f64)
-        for (size_t i = lo; i < hi; ++i) ((double*)j->data)[i] = (double)(j->start + (int64_t)i);
-    else
-        for (size_t i = lo; i < hi; ++i) ((int64_t*)j->data)[i] = j->start + (int64_t)i;
+    for (;;) {
+        size_t c = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (c >= j->n_chunks) break;
+        size_t lo = c * j->chunk, hi = lo + j->chunk < j->n ? lo + j->chunk : j->n;
+        if (j->is_f64)
+            for (size_t i = lo; i < hi; ++i) ((double*)j->data)[i] = (double)(j->start + (int64_t)i);
+        else
+            for (size_t i = lo; i < hi; ++i) ((int64_t*)j->data)[i] = j->start + (int64_t)i;
+    }
     return NULL;
 }
 
 MO_API void mo_par_fill_iota(void* data, size_t n, int64_t start, int is_f64, int n_threads) {
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > 256) n_threads = 256;
-    pthread_t th[256];
-    mo_fill_job jobs[256];
-    int started = 0;
-    for (int t = 0; t < n_threads; ++t) {
-        jobs[t] = (mo_fill_job){data, n, start, is_f64, t, n_threads};
-        if (t == n_threads - 1) {
-            mo_fill_worker(&jobs[t]);
-        } else if (pthread_create(&th[started], NULL, mo_fill_worker, &jobs[t]) == 0) {
-            ++started;
-        } else {
-            mo_fill_worker(&jobs[t]);
-        }
-    }
-    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    mo_fill_job job = {data, n, (size_t)1 << 20, (n + ((size_t)1 << 20) - 1) >> 20, 0, start, is_f64};
+    mo_pool_run(mo_fill_worker, &job, n_threads);
 }
 
 /* ---- Bitmask-gated sums (BUILD-DEFINED: no reference implementation) -------------

@@ -1,0 +1,136 @@
+// ubench_sum.hip — read-only stream experiments for the sum kernel (MI355X): single-buffered loop (what
+// ma_reduce.hip does) vs a software-pipelined loop that issues the next tile's loads before consuming the current one.
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench_sum.hip -o /tmp/ubench_sum && /tmp/ubench_sum
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                             \
+    do {                                                                  \
+        hipError_t e = (x);                                               \
+        if (e != hipSuccess) {                                            \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));        \
+            exit(1);                                                      \
+        }                                                                 \
+    } while (0)
+
+typedef long long l2 __attribute__((ext_vector_type(2)));
+
+template <int U, int BLOCK, bool PIPE, int PRIO>
+__global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, size_t n_tiles, long long* __restrict__ out) {
+    constexpr int WAVES = BLOCK / 64;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr size_t WAVE_VECS = (size_t)64 * U, TILE_VECS = WAVE_VECS * WAVES;
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    l2 acc = {0, 0};
+    if (!PIPE) {
+        for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
+            l2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    } else {
+        size_t t = blockIdx.x;
+        l2 v0[U], v1[U];
+        if (t < n_tiles) {
+            const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) v0[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+        }
+        while (t < n_tiles) {
+            size_t tn = t + gridDim.x;
+            if (tn < n_tiles) {
+                const l2* p = a + tn * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+                for (int u = 0; u < U; ++u) v1[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v0[u];
+            t = tn;
+            size_t tn2 = t + gridDim.x;
+            if (t < n_tiles) {
+                if (tn2 < n_tiles) {
+                    const l2* p = a + tn2 * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v0[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc += v1[u];
+                t = tn2;
+            }
+        }
+    }
+    long long s = acc.x + acc.y;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+
+struct Variant {
+    std::string name;
+    void (*launch)(const l2*, size_t, int, int, long long*, hipStream_t);
+    int bpc;
+    double best = 1e30;
+    long long result = 0;
+};
+
+template <int U, int BLOCK, bool PIPE, int PRIO>
+static void launch(const l2* a, size_t rows, int bpc, int cus, long long* out, hipStream_t s) {
+    size_t tile_rows = (size_t)2 * 64 * U * (BLOCK / 64);
+    size_t n_tiles = rows / tile_rows;
+    int grid = (int)std::min<size_t>(n_tiles, (size_t)cus * bpc);
+    hipLaunchKernelGGL((sum_kernel<U, BLOCK, PIPE, PRIO>), dim3(grid), dim3(BLOCK), 0, s, a, n_tiles, out);
+}
+
+#define ADD(U, B, PIPE, PRIO)                                                                               \
+    for (int bpc : bpcs)                                                                                    \
+        vars.push_back({std::string("U" #U " B" #B " pipe=" #PIPE " prio=" #PRIO), launch<U, B, PIPE, PRIO>, bpc});
+
+int main(int argc, char** argv) {
+    size_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000000ull;
+    int rounds = argc > 2 ? atoi(argv[2]) : 4, reps = 10;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    l2* a;
+    long long* out;
+    CK(hipMalloc(&a, rows * 8));
+    CK(hipMalloc(&out, 8));
+    CK(hipMemset(a, 1, rows * 8));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<Variant> vars;
+    std::vector<int> bpcs = {1, 2};
+    ADD(8, 256, false, 0) ADD(4, 256, false, 0) ADD(16, 256, false, 0)
+    ADD(8, 256, true, 0) ADD(4, 256, true, 0) ADD(2, 256, true, 0) ADD(16, 256, true, 0)
+    ADD(8, 256, false, 1) ADD(8, 256, true, 1)
+    ADD(4, 512, false, 0) ADD(4, 512, true, 0) ADD(8, 512, false, 0) ADD(2, 1024, true, 0) ADD(4, 1024, false, 0)
+    ADD(8, 128, false, 0) ADD(8, 128, true, 0) ADD(16, 128, false, 0) ADD(8, 64, true, 0) ADD(16, 64, false, 0) ADD(16, 64, true, 0)
+    for (int r = 0; r < rounds; ++r) {
+        for (auto& v : vars) {
+            CK(hipMemsetAsync(out, 0, 8, s));
+            v.launch(a, rows, v.bpc, cus, out, s);
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) v.launch(a, rows, v.bpc, cus, out, s);
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            v.best = std::min<double>(v.best, ms / reps);
+        }
+    }
+    std::sort(vars.begin(), vars.end(), [](const Variant& x, const Variant& y) { return x.best < y.best; });
+    for (auto& v : vars)
+        printf("%-34s bpc=%d  %8.4f ms  %8.1f GB/s  %5.1f%% of 8 TB/s\n", v.name.c_str(), v.bpc, v.best, rows * 8.0 / v.best / 1e6,
+               rows * 8.0 / v.best / 1e6 / 80.0);
+    return 0;
+}
