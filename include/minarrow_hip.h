@@ -382,10 +382,12 @@ ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct
                        double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count);
 ma_status ma_mean_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema, double* out_mean,
                         uint64_t* out_valid_count);
-/* lhs (op) rhs for two primitive arrays of the same format, routed like resolve_binary_arithmetic
+/* lhs (op) rhs for two primitive arrays, routed like resolve_binary_arithmetic
  * (src/kernels/routing/arithmetic.rs:214-222): equal lengths, or one side of length 1, which is broadcast
- * (src/kernels/routing/broadcast.rs:87-112 — fused, not materialised). Different formats ->
- * MA_ERR_UNSUPPORTED (routing/arithmetic.rs:403-405). `out_values` receives max(len) elements.
+ * (src/kernels/routing/broadcast.rs:87-112 — fused, not materialised). Type matrix of arithmetic_dispatch
+ * (routing/arithmetic.rs:278-406): same-format pairs; "i" with "g" or "f" in either order is promoted to the
+ * float type (result format = the float side's); anything else -> MA_ERR_UNSUPPORTED (:403-405).
+ * `out_values` receives max(len) elements of the result type.
  * Validity: when neither operand carries nulls the dense kernel runs and *out_has_validity = 0; otherwise rows
  * are gated by the AND of the attached bitmaps (merge_bitmasks_to_new, src/kernels/bitmask/mod.rs:171-196),
  * `out_validity` (8*ceil(len/64) bytes) receives the result validity and *out_has_validity = 1. */
@@ -466,6 +468,50 @@ ma_status ma_apply_datetime_u64(ma_ctx* ctx, const uint64_t* lhs_data, size_t lh
                                const uint8_t* lhs_mask_bits, const uint64_t* rhs_data, size_t rhs_offset, size_t rhs_len,
                                const uint8_t* rhs_mask_bits, int32_t op, uint64_t* out, uint8_t* out_mask_bits,
                                int32_t* out_has_mask);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mixed-type arithmetic with the promotion fused into the kernel — arithmetic_dispatch's promote_to_float64! /
+ * promote_to_float32! arms (src/kernels/routing/arithmetic.rs:244-269, 342-373): (Int32, Float64) and
+ * (Float64, Int32) -> f64, (Int32, Float32) and (Float32, Int32) -> f32. The reference materialises two casted
+ * Vec64s and calls apply_float_*; results here are bit-identical to that, without the two extra passes.
+ * Same contract as ma_apply_float_* (length check, optional mask, IEEE semantics).
+ * ---------------------------------------------------------------------------------------------- */
+ma_status ma_apply_promote_i32_f64(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, const double* rhs, size_t rhs_len,
+                                   int32_t op, const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                   uint8_t* out_mask_bits);
+ma_status ma_apply_promote_i32_f64_scalar_rhs(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, double scalar, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_i32_f64_scalar_lhs(ma_ctx* ctx, int32_t scalar, const double* rhs, size_t rhs_len, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f64_i32(ma_ctx* ctx, const double* lhs, size_t lhs_len, const int32_t* rhs, size_t rhs_len,
+                                   int32_t op, const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                   uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f64_i32_scalar_rhs(ma_ctx* ctx, const double* lhs, size_t lhs_len, int32_t scalar, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f64_i32_scalar_lhs(ma_ctx* ctx, double scalar, const int32_t* rhs, size_t rhs_len, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, double* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_i32_f32(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, const float* rhs, size_t rhs_len,
+                                   int32_t op, const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                   uint8_t* out_mask_bits);
+ma_status ma_apply_promote_i32_f32_scalar_rhs(ma_ctx* ctx, const int32_t* lhs, size_t lhs_len, float scalar, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_i32_f32_scalar_lhs(ma_ctx* ctx, int32_t scalar, const float* rhs, size_t rhs_len, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f32_i32(ma_ctx* ctx, const float* lhs, size_t lhs_len, const int32_t* rhs, size_t rhs_len,
+                                   int32_t op, const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                   uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f32_i32_scalar_rhs(ma_ctx* ctx, const float* lhs, size_t lhs_len, int32_t scalar, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                              uint8_t* out_mask_bits);
+ma_status ma_apply_promote_f32_i32_scalar_lhs(ma_ctx* ctx, float scalar, const int32_t* rhs, size_t rhs_len, int32_t op,
+                                              const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
+                                              uint8_t* out_mask_bits);
 
 #ifdef __cplusplus
 } /* extern "C" */

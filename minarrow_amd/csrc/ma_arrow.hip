@@ -117,7 +117,7 @@ ma_status ma_mean_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struc
     }
 }
 
-// lhs (op) rhs for two primitive arrays of the same format, routed like resolve_binary_arithmetic
+// lhs (op) rhs for two primitive arrays, routed like resolve_binary_arithmetic
 // (src/kernels/routing/arithmetic.rs:214-222): equal lengths, or one side of length 1 which is broadcast
 // (routing/broadcast.rs:87-112, fused here). Validity: none attached -> dense kernel, `out_validity` untouched and
 // *out_has_validity = 0; otherwise the AND of the attached bitmaps gates the rows (merge_bitmasks_to_new,
@@ -128,9 +128,11 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
     Prim pl{}, pr{};
     MA_TRY(parse_primitive(lhs, lhs_schema, &pl));
     MA_TRY(parse_primitive(rhs, rhs_schema, &pr));
-    if (pl.code != pr.code) {
-        // arithmetic_dispatch's `_ => UnsupportedType` arm (routing/arithmetic.rs:403-405); the i32<->f32/f64
-        // promotions (:342-373) are host-side casts, see INTEGRATION.md.
+    // Type matrix of arithmetic_dispatch (src/kernels/routing/arithmetic.rs:278-406): same-type pairs, plus
+    // Int32 <-> Float64 / Float32 promotions (:342-373); everything else is `UnsupportedType` (:403-405).
+    const bool promote = (pl.code == 'i' && (pr.code == 'g' || pr.code == 'f')) ||
+                         (pr.code == 'i' && (pl.code == 'g' || pl.code == 'f'));
+    if (pl.code != pr.code && !promote) {
         set_error("Unsupported array type combination for arithmetic operations (\"%s\" vs \"%s\")", lhs_schema->format,
                   rhs_schema->format);
         return MA_ERR_UNSUPPORTED;
@@ -197,6 +199,32 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
         return ma_apply_##FAMILY##_##TAG(ctx, (const T*)a, nl, (const T*)b, nr, op, mask, mask_off, (T*)out_values,    \
                                          out_validity);                                                               \
     } while (0)
+
+#define MA_ROUTE_PROMOTE(LTAG, LT, RTAG, RT, OT)                                                                        \
+    do {                                                                                                              \
+        if (scalar_l) {                                                                                               \
+            LT sc;                                                                                                    \
+            MA_TRY(fetch_scalar(ctx, a, sizeof(LT), &sc));                                                            \
+            return ma_apply_promote_##LTAG##_##RTAG##_scalar_lhs(ctx, sc, (const RT*)b, n, op, mask, mask_off,         \
+                                                                 (OT*)out_values, out_validity);                      \
+        }                                                                                                             \
+        if (scalar_r) {                                                                                               \
+            RT sc;                                                                                                    \
+            MA_TRY(fetch_scalar(ctx, b, sizeof(RT), &sc));                                                            \
+            return ma_apply_promote_##LTAG##_##RTAG##_scalar_rhs(ctx, (const LT*)a, n, sc, op, mask, mask_off,         \
+                                                                 (OT*)out_values, out_validity);                      \
+        }                                                                                                             \
+        return ma_apply_promote_##LTAG##_##RTAG(ctx, (const LT*)a, nl, (const RT*)b, nr, op, mask, mask_off,           \
+                                                (OT*)out_values, out_validity);                                       \
+    } while (0)
+
+    if (promote) {
+        if (pl.code == 'i' && pr.code == 'g') MA_ROUTE_PROMOTE(i32, int32_t, f64, double, double);
+        if (pl.code == 'g' && pr.code == 'i') MA_ROUTE_PROMOTE(f64, double, i32, int32_t, double);
+        if (pl.code == 'i' && pr.code == 'f') MA_ROUTE_PROMOTE(i32, int32_t, f32, float, float);
+        MA_ROUTE_PROMOTE(f32, float, i32, int32_t, float);
+    }
+#undef MA_ROUTE_PROMOTE
 
     switch (pl.code) {
         case 'i': MA_ROUTE(int, i32, int32_t);

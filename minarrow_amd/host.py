@@ -358,3 +358,10 @@ class Context:
         ffi.check(fn(self.handle, addr_of(lhs), int(lhs_off), int(lhs_len), addr_of(lhs_mask), addr_of(rhs), int(rhs_off),
                      int(rhs_len), addr_of(rhs_mask), int(op), addr_of(out), addr_of(out_mask), C.addressof(has)))
         return bool(has.value)
+
+    def apply_promote(self, ltag: str, rtag: str, lhs, rhs, op: int, out, n_lhs: int, n_rhs: int, mask=None,
+                      mask_bit_offset: int = 0, out_mask=None) -> None:
+        """(Int32, Float64/Float32) or (Float64/Float32, Int32): promotion fused (routing/arithmetic.rs:342-373)."""
+        fn = getattr(self.lib, f"ma_apply_promote_{ltag}_{rtag}")
+        ffi.check(fn(self.handle, addr_of(lhs), int(n_lhs), addr_of(rhs), int(n_rhs), int(op), addr_of(mask),
+                     int(mask_bit_offset), addr_of(out), addr_of(out_mask)))

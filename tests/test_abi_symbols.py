@@ -53,3 +53,17 @@ def test_product_package_never_imports_the_oracle():
         if re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M):
             offenders.append(str(path))
     assert not offenders, offenders
+
+
+def test_header_is_plain_c_and_the_cpp_mirror_compiles(tmp_path):
+    """The boundary header must be consumable by a C compiler (cgo / bindgen / JNI all start there)."""
+    import subprocess
+
+    inc = ffi.HEADER_PATH.parent
+    c_file = tmp_path / "use.c"
+    c_file.write_text('#include "minarrow_hip.h"\nint main(void) { return ma_abi_version() == MA_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(c_file)],
+                   check=True)
+    cpp_file = tmp_path / "use.cpp"
+    cpp_file.write_text('#include "minarrow_hip.hpp"\nint main() { return sizeof(ma::Bitmask) ? 0 : 1; }\n')
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{inc}", str(cpp_file)], check=True)
