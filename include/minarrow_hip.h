@@ -513,6 +513,22 @@ ma_status ma_apply_promote_f32_i32_scalar_lhs(ma_ctx* ctx, float scalar, const i
                                               const uint8_t* mask_bits, size_t mask_bit_offset, float* out,
                                               uint8_t* out_mask_bits);
 
+/* route_super_array_broadcast — src/kernels/broadcast/super_array.rs:180-251: SuperArray (op) SuperArray chunk by
+ * chunk (the reference loops sequentially, "// TODO: Parallelise", :193; here the chunks are enqueued back to
+ * back on the context's stream, and a host with one context per GPU gives each a subset of the chunks).
+ * format_code: Arrow format character of the element type ('i','I','l','L','f','g').
+ * chunk i: lhs_lens[i] != rhs_lens[i] -> MA_ERR_LENGTH_MISMATCH (:202-212). Common mask per chunk (:215-229):
+ * none -> dense; one side -> that bitmap; both -> lhs.union(rhs) = bitwise OR (src/structs/bitmask.rs:661 — not the
+ * AND of merge_bitmasks_to_new); `null_mask_override` replaces it for every chunk when non-NULL (:231).
+ * lhs_masks / rhs_masks / out_masks (tables or entries) may be NULL; out_has_mask[i] reports whether
+ * out_masks[i] was written. */
+ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
+                                         const void* const* lhs_data, const size_t* lhs_lens,
+                                         const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                         const size_t* rhs_lens, const uint8_t* const* rhs_masks,
+                                         const uint8_t* null_mask_override, void* const* out_data,
+                                         uint8_t* const* out_masks, int32_t* out_has_mask);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

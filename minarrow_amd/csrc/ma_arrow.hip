@@ -238,3 +238,71 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// route_super_array_broadcast — src/kernels/broadcast/super_array.rs:180-251.
+// SuperArray (op) SuperArray, chunk by chunk. The reference's loop is sequential with a literal
+// `// TODO: Parallelise` (:193); here every chunk pair is ENQUEUED on the context's stream back to back (no host
+// round trip between chunks), and a host that owns several contexts (one per GPU) hands each a subset of the chunks.
+//   * chunk i: len(lhs_i) != len(rhs_i) -> MA_ERR_LENGTH_MISMATCH ("Super Array broadcasting error", :202-212)
+//   * common mask (:215-229): neither has one -> dense kernel; one has -> that one; both -> lhs.union(rhs), i.e.
+//     bitwise OR (src/structs/bitmask.rs:661) — NOT the AND of merge_bitmasks_to_new. `null_mask_override`, when
+//     given, replaces the common mask of every chunk (:231).
+//   * resolve_binary_arithmetic(op, lhs_i, rhs_i, mask) (:236) = the same-type kernels.
+// ------------------------------------------------------------------------------------------------
+extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
+                                                    const void* const* lhs_data, const size_t* lhs_lens,
+                                                    const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                                    const size_t* rhs_lens, const uint8_t* const* rhs_masks,
+                                                    const uint8_t* null_mask_override, void* const* out_data,
+                                                    uint8_t* const* out_masks, int32_t* out_has_mask) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(n_chunks == 0 || (lhs_data && lhs_lens && rhs_data && rhs_lens && out_data), MA_ERR_INVALID_ARGUMENT,
+               "NULL chunk table");
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (lhs_lens[i] != rhs_lens[i]) {
+            set_error("Super Array broadcasting error - Chunk %zu: LHS %zu RHS %zu", i, lhs_lens[i], rhs_lens[i]);
+            return MA_ERR_LENGTH_MISMATCH;
+        }
+    }
+    for (size_t i = 0; i < n_chunks; ++i) {
+        const size_t n = lhs_lens[i];
+        const uint8_t* lm = lhs_masks ? lhs_masks[i] : nullptr;
+        const uint8_t* rm = rhs_masks ? rhs_masks[i] : nullptr;
+        const uint8_t* mask = nullptr;
+        uint8_t* om = out_masks ? out_masks[i] : nullptr;
+        void* union_tmp = nullptr;
+        if (null_mask_override) {
+            mask = null_mask_override;
+        } else if (lm && rm) {
+            MA_TRY(ma_dev_alloc(ctx, ((n + 63) / 64) * 8 + 8, &union_tmp));
+            ma_status s = n ? ma_or_masks(ctx, lm, 0, rm, 0, n, (uint8_t*)union_tmp) : MA_OK;  // Bitmask::union
+            if (s != MA_OK) {
+                (void)ma_dev_free(ctx, union_tmp);
+                return s;
+            }
+            mask = (const uint8_t*)union_tmp;
+        } else {
+            mask = lm ? lm : rm;
+        }
+        if (out_has_mask) out_has_mask[i] = mask ? 1 : 0;
+        ma_status st;
+        switch (format_code) {
+            case 'i': st = ma_apply_int_i32(ctx, (const int32_t*)lhs_data[i], n, (const int32_t*)rhs_data[i], n, op, mask, 0, (int32_t*)out_data[i], om); break;
+            case 'I': st = ma_apply_int_u32(ctx, (const uint32_t*)lhs_data[i], n, (const uint32_t*)rhs_data[i], n, op, mask, 0, (uint32_t*)out_data[i], om); break;
+            case 'l': st = ma_apply_int_i64(ctx, (const int64_t*)lhs_data[i], n, (const int64_t*)rhs_data[i], n, op, mask, 0, (int64_t*)out_data[i], om); break;
+            case 'L': st = ma_apply_int_u64(ctx, (const uint64_t*)lhs_data[i], n, (const uint64_t*)rhs_data[i], n, op, mask, 0, (uint64_t*)out_data[i], om); break;
+            case 'f': st = ma_apply_float_f32(ctx, (const float*)lhs_data[i], n, (const float*)rhs_data[i], n, op, mask, 0, (float*)out_data[i], om); break;
+            case 'g': st = ma_apply_float_f64(ctx, (const double*)lhs_data[i], n, (const double*)rhs_data[i], n, op, mask, 0, (double*)out_data[i], om); break;
+            default:
+                set_error("unsupported element format '%c'", (char)format_code);
+                st = MA_ERR_UNSUPPORTED;
+        }
+        if (union_tmp) {
+            ma_status fr = ma_dev_free(ctx, union_tmp);  // synchronises the stream first
+            if (st == MA_OK) st = fr;
+        }
+        if (st != MA_OK) return st;
+    }
+    return MA_OK;
+}

@@ -365,3 +365,21 @@ class Context:
         fn = getattr(self.lib, f"ma_apply_promote_{ltag}_{rtag}")
         ffi.check(fn(self.handle, addr_of(lhs), int(n_lhs), addr_of(rhs), int(n_rhs), int(op), addr_of(mask),
                      int(mask_bit_offset), addr_of(out), addr_of(out_mask)))
+
+    def route_super_array_broadcast(self, fmt: str, op: int, lhs_chunks, rhs_chunks, lens_l, lens_r, out_chunks,
+                                    lhs_masks=None, rhs_masks=None, out_masks=None, override=None):
+        """SuperArray (op) SuperArray, chunk by chunk (src/kernels/broadcast/super_array.rs:180-251).
+        Returns the per-chunk "has validity" flags."""
+        k = len(lhs_chunks)
+
+        def table(items):
+            return C.cast((C.c_void_p * k)(*[addr_of(x) or None for x in items]), C.c_void_p) if items is not None else None
+
+        ll = (C.c_size_t * k)(*[int(n) for n in lens_l])
+        lr = (C.c_size_t * k)(*[int(n) for n in lens_r])
+        has = (C.c_int32 * k)()
+        ffi.check(self.lib.ma_route_super_array_broadcast(
+            self.handle, ord(fmt), int(op), k, table(lhs_chunks), C.cast(ll, C.c_void_p), table(lhs_masks),
+            table(rhs_chunks), C.cast(lr, C.c_void_p), table(rhs_masks), addr_of(override), table(out_chunks),
+            table(out_masks), C.cast(has, C.c_void_p)))
+        return [bool(x) for x in has]

@@ -1,0 +1,72 @@
+"""GPU parity for ma_route_super_array_broadcast (src/kernels/broadcast/super_array.rs:180-251): the reference's
+own vectors (tests/golden/routing_kat.json, super_array.rs:520-560) and the OR-union mask rule against the oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from minarrow_amd import ffi
+
+pytestmark = pytest.mark.gpu
+ROUTE = json.loads((Path(__file__).resolve().parent / "golden" / "routing_kat.json").read_text())
+
+
+def nbytes(n):
+    return ((n + 63) // 64) * 8
+
+
+def test_ref_chunked_add(ctx):
+    c = ROUTE["super_array"]["chunked_add"]
+    lhs = [np.array(x, dtype=np.int32) for x in c["lhs_chunks"]]
+    rhs = [np.array(x, dtype=np.int32) for x in c["rhs_chunks"]]
+    outs = [np.zeros(3, dtype=np.int32) for _ in lhs]
+    has = ctx.route_super_array_broadcast("i", 0, lhs, rhs, [3, 3], [3, 3], outs)
+    assert has == [False, False]
+    for o, e in zip(outs, c["expect_chunks"]):
+        np.testing.assert_array_equal(o, e)
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.route_super_array_broadcast("i", 0, lhs, rhs, [3, 3], [3, 2], outs)
+    assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH and "Super Array broadcasting error" in e.value.message
+
+
+@pytest.mark.parametrize("fmt,dt", [("l", np.int64), ("g", np.float64), ("i", np.int32)])
+def test_mask_union_rule_and_many_chunks(ctx, oracle, fmt, dt):
+    rng = np.random.default_rng(2)
+    lens = [5, 64, 1000, 4097, 70_001, 0, 129]
+    k = len(lens)
+    lhs = [rng.integers(1, 100, size=n).astype(dt) for n in lens]
+    rhs = [rng.integers(1, 100, size=n).astype(dt) for n in lens]
+    lm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 2 == 0 else None for i, n in enumerate(lens)]
+    rm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 3 != 1 else None for i, n in enumerate(lens)]
+    d = lambda xs: [ctx.to_device(x, 64) if x is not None else None for x in xs]  # noqa: E731
+    outs = [ctx.alloc(max(n, 1) * np.dtype(dt).itemsize + 64) for n in lens]
+    oms = [ctx.alloc(nbytes(n) + 8) for n in lens]
+    for op, name in ((2, "multiply"), (3, "divide")):
+        has = ctx.route_super_array_broadcast(fmt, op, d(lhs), d(rhs), lens, lens, outs, d(lm), d(rm), oms)
+        for i, n in enumerate(lens):
+            if lm[i] is not None and rm[i] is not None:
+                common = oracle.bitmask_union(oracle.pad_bits(lm[i], n), oracle.pad_bits(rm[i], n), n)  # OR, not AND
+            else:
+                common = lm[i] if lm[i] is not None else rm[i]
+            assert has[i] == (common is not None)
+            if n == 0:
+                continue
+            if common is None:
+                fn = oracle.apply_float if np.dtype(dt).kind == "f" else oracle.apply_int
+                st, want, _, _ = fn(oracle.aligned_copy(lhs[i]), oracle.aligned_copy(rhs[i]), name)
+                np.testing.assert_array_equal(outs[i].download(dt, n), want)
+            else:
+                body = oracle.float_body if np.dtype(dt).kind == "f" else oracle.int_body
+                st, want, want_mask = body("masked_std", lhs[i], rhs[i], name, mask=oracle.pad_bits(common, n))
+                np.testing.assert_array_equal(outs[i].download(dt, n), want)
+                np.testing.assert_array_equal(oms[i].download(np.uint8, nbytes(n)), want_mask[:nbytes(n)])
+    # null_mask_override replaces every chunk's common mask
+    n = lens[3]
+    ov = rng.integers(0, 256, size=max(lens) // 8 + 16, dtype=np.uint8)
+    has = ctx.route_super_array_broadcast(fmt, 0, d(lhs[3:4]), d(rhs[3:4]), [n], [n], outs[3:4], d(lm[3:4]), d(rm[3:4]), oms[3:4],
+                                          override=ctx.to_device(ov, 16))
+    assert has == [True]
+    body = oracle.float_body if np.dtype(dt).kind == "f" else oracle.int_body
+    st, want, want_mask = body("masked_std", lhs[3], rhs[3], "add", mask=oracle.pad_bits(ov, n))
+    np.testing.assert_array_equal(outs[3].download(dt, n), want)
