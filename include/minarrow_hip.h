@@ -529,6 +529,28 @@ ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32
                                          const uint8_t* null_mask_override, void* const* out_data,
                                          uint8_t* const* out_masks, int32_t* out_has_mask);
 
+/* ------------------------------------------------------------------------------------------------
+ * Arrow C Stream ingestion — the reference moves chunked tables (SuperTable) through ArrowArrayStream
+ * (src/ffi/arrow_c_ffi.rs:160-184 struct, :2104-2260 export / import). Sum and valid count of one column over all
+ * record batches of a stream; `column` indexes the children of "+s" (record batch) arrays, or is -1 / 0 for a
+ * stream of primitive arrays. Double buffered: while the GPU reads batch k from pinned memory in place, the host
+ * copies batch k+1 out of the producer's buffers and releases it. The stream is consumed to its end but NOT
+ * released (the caller owns it). Outputs as ma_sum_arrow; *out_rows / *out_batches count what was read.
+ * ---------------------------------------------------------------------------------------------- */
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+    int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+    int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+    const char* (*get_last_error)(struct ArrowArrayStream*);
+    void (*release)(struct ArrowArrayStream*);
+    void* private_data;
+};
+#endif
+ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* stream, int64_t column, double* out_sum_f64,
+                              int64_t* out_sum_i64, uint64_t* out_valid_count, uint64_t* out_rows,
+                              uint64_t* out_batches);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -68,3 +68,36 @@ class Exported:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class ArrowArrayStream(C.Structure):
+    _fields_ = [
+        ("get_schema", C.c_void_p),
+        ("get_next", C.c_void_p),
+        ("get_last_error", C.c_void_p),
+        ("release", C.c_void_p),
+        ("private_data", C.c_void_p),
+    ]
+
+
+class ExportedStream:
+    """A RecordBatchReader (or anything with `_export_to_c`) exported as an ArrowArrayStream."""
+
+    def __init__(self, reader):
+        self.stream = ArrowArrayStream()
+        self._keep = reader
+        reader._export_to_c(C.addressof(self.stream))
+
+    @property
+    def ptr(self) -> int:
+        return C.addressof(self.stream)
+
+    def close(self) -> None:
+        if self.stream.release:
+            C.CFUNCTYPE(None, C.c_void_p)(self.stream.release)(C.addressof(self.stream))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

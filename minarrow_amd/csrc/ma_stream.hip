@@ -1,0 +1,230 @@
+// Arrow C Stream ingestion: sum / valid-count of one column of a stream of record batches, chunk by chunk —
+// how a SuperTable travels over the reference's C Stream interface (src/ffi/arrow_c_ffi.rs:160-184 ArrowArrayStream,
+// :2104-2260 export/import of chunked tables).
+//
+// Pipeline (double buffered): while the GPU reads batch k from pinned slot k&1 in place over PCIe, the host copies
+// batch k+1 out of the producer's buffers into the other slot and releases that batch. One event per slot
+// guards reuse. Per-batch partials are double-double / wrapping-i64 and folded on the host in batch order, so the
+// total obeys the same bounds as a single-array sum.
+#include "ma_common.hpp"
+
+#ifndef ARROW_C_STREAM_INTERFACE
+#error "minarrow_hip.h must define the Arrow C Stream interface"
+#endif
+
+using namespace ma;
+
+namespace {
+
+struct Slot {
+    void* values = nullptr;   // pinned
+    size_t values_cap = 0;
+    void* mask = nullptr;     // pinned
+    size_t mask_cap = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    uint64_t* result = nullptr;  // pinned: [0] sum / hi, [1] lo, [2] count
+    char code = 0;
+};
+
+ma_status grow(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return MA_OK;
+    if (*p) MA_HIP(hipHostFree(*p));
+    *p = nullptr;
+    size_t bytes = need + need / 2 + 4096;
+    MA_HIP(hipHostMalloc(p, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    *cap = bytes;
+    return MA_OK;
+}
+
+inline void two_sum_acc(double& hi, double& lo, double h, double l) {
+    double t = hi + h;
+    double bp = t - hi;
+    double e = (hi - (t - bp)) + (h - bp);
+    hi = t;
+    lo += e + l;
+}
+
+}  // namespace
+
+extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* stream, int64_t column, double* out_sum_f64,
+                                         int64_t* out_sum_i64, uint64_t* out_valid_count, uint64_t* out_rows,
+                                         uint64_t* out_batches) {
+    MA_REQUIRE(ctx != nullptr && stream != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or stream is NULL");
+    MA_REQUIRE(stream->get_schema && stream->get_next, MA_ERR_INVALID_ARGUMENT, "ArrowArrayStream callbacks are NULL");
+    struct ArrowSchema schema;
+    memset(&schema, 0, sizeof(schema));
+    if (stream->get_schema(stream, &schema) != 0) {
+        set_error("ArrowArrayStream.get_schema failed: %s",
+                  stream->get_last_error ? stream->get_last_error(stream) : "(no message)");
+        return MA_ERR_INVALID_ARGUMENT;
+    }
+    // which column: a "+s" (struct = record batch) stream needs a child index; a primitive stream uses -1
+    const struct ArrowSchema* col_schema = &schema;
+    const bool is_struct = schema.format && schema.format[0] == '+' && schema.format[1] == 's';
+    ma_status st = MA_OK;
+    char code = 0;
+    size_t esz = 0;
+    if (is_struct) {
+        if (column < 0 || column >= schema.n_children) {
+            set_error("column %lld out of range for a record batch stream with %lld columns", (long long)column,
+                      (long long)schema.n_children);
+            st = MA_ERR_INVALID_ARGUMENT;
+        } else {
+            col_schema = schema.children[column];
+        }
+    } else if (column > 0) {
+        set_error("a primitive stream has no column %lld", (long long)column);
+        st = MA_ERR_INVALID_ARGUMENT;
+    }
+    if (st == MA_OK) {
+        const char* f = col_schema->format;
+        if (!f || f[0] == 0 || f[1] != 0 || !strchr("iIlLfg", f[0]) || col_schema->dictionary) {
+            set_error("unsupported Arrow format \"%s\" (numeric primitives only)", f ? f : "(null)");
+            st = MA_ERR_UNSUPPORTED;
+        } else {
+            code = f[0];
+            esz = (code == 'l' || code == 'L' || code == 'g') ? 8 : 4;
+        }
+    }
+    if (schema.release) schema.release(&schema);
+    if (st != MA_OK) return st;
+
+    const bool is_float = code == 'f' || code == 'g';
+    Slot slots[2];
+    uint64_t* results = nullptr;
+    bool was_async = false;
+    double hi = 0.0, lo = 0.0;
+    uint64_t isum = 0, count = 0, rows = 0, batches = 0;
+
+    auto drain = [&](Slot& s) -> ma_status {
+        if (!s.busy) return MA_OK;
+        MA_HIP(hipEventSynchronize(s.done));
+        s.busy = false;
+        if (is_float) {
+            double h, l;
+            memcpy(&h, &s.result[0], 8);
+            memcpy(&l, &s.result[1], 8);
+            two_sum_acc(hi, lo, h, l);
+        } else {
+            isum += s.result[0];
+        }
+        count += s.result[2];
+        return MA_OK;
+    };
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& s : slots) {
+            if (s.values) (void)hipHostFree(s.values);
+            if (s.mask) (void)hipHostFree(s.mask);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+        if (results) (void)hipHostFree(results);
+        (void)ma_ctx_set_async(ctx, was_async ? 1 : 0);
+    };
+
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        was_async = ctx->async;
+    }
+    MA_HIP(hipSetDevice(ctx->device));
+    hipError_t he = hipHostMalloc((void**)&results, 64, hipHostMallocPortable | hipHostMallocMapped);
+    if (he != hipSuccess) return hip_fail(he, "hipHostMalloc(results)", __FILE__, __LINE__);
+    for (int i = 0; i < 2; ++i) {
+        slots[i].result = results + 4 * i;
+        he = hipEventCreateWithFlags(&slots[i].done, hipEventDisableTiming);
+        if (he != hipSuccess) {
+            cleanup();
+            return hip_fail(he, "hipEventCreate", __FILE__, __LINE__);
+        }
+    }
+    (void)ma_ctx_set_async(ctx, 1);
+
+    for (;;) {
+        struct ArrowArray batch;
+        memset(&batch, 0, sizeof(batch));
+        if (stream->get_next(stream, &batch) != 0) {
+            set_error("ArrowArrayStream.get_next failed: %s",
+                      stream->get_last_error ? stream->get_last_error(stream) : "(no message)");
+            st = MA_ERR_INVALID_ARGUMENT;
+            break;
+        }
+        if (batch.release == nullptr) break;  // end of stream
+        const struct ArrowArray* col = &batch;
+        if (is_struct) {
+            if (column >= batch.n_children) {
+                set_error("batch %llu has %lld columns, column %lld requested", (unsigned long long)batches,
+                          (long long)batch.n_children, (long long)column);
+                st = MA_ERR_INVALID_ARGUMENT;
+            } else {
+                col = batch.children[column];
+            }
+        }
+        if (st == MA_OK && (col->n_buffers != 2 || !col->buffers || (col->length > 0 && !col->buffers[1]))) {
+            set_error("batch %llu: not a primitive array (n_buffers = %lld)", (unsigned long long)batches,
+                      (long long)col->n_buffers);
+            st = MA_ERR_INVALID_ARGUMENT;
+        }
+        if (st != MA_OK) {
+            batch.release(&batch);
+            break;
+        }
+        const size_t n = (size_t)col->length;
+        // a struct array's own offset shifts every child (Arrow C Data Interface); PyArrow exports 0 here
+        const size_t off = (size_t)col->offset + (is_struct ? (size_t)batch.offset : 0);
+        Slot& s = slots[batches & 1];
+        st = drain(s);  // the kernel that last read this slot must be done before it is overwritten
+        if (st == MA_OK && n) st = grow(&s.values, &s.values_cap, n * esz + 64);
+        const uint8_t* validity = col->null_count == 0 ? nullptr : (const uint8_t*)col->buffers[0];
+        size_t mask_off = 0;
+        if (st == MA_OK && n && validity) {
+            const size_t first = off >> 3, end = (off + n + 7) >> 3;
+            st = grow(&s.mask, &s.mask_cap, end - first + 16);
+            if (st == MA_OK) {
+                memcpy(s.mask, validity + first, end - first);
+                memset((uint8_t*)s.mask + (end - first), 0, 16);
+                mask_off = off & 7;
+            }
+        }
+        if (st == MA_OK && n) memcpy(s.values, (const char*)col->buffers[1] + off * esz, n * esz);
+        batch.release(&batch);  // the producer's buffers are no longer needed
+        if (st != MA_OK) break;
+        rows += n;
+        ++batches;
+        if (n == 0) continue;
+        const uint8_t* m = validity ? (const uint8_t*)s.mask : nullptr;
+        const int64_t nc = validity ? -1 : 0;
+        s.result[0] = s.result[1] = s.result[2] = 0;
+        switch (code) {
+            case 'l': st = ma_i64_sum(ctx, (const int64_t*)s.values, n, m, mask_off, nc, (int64_t*)&s.result[0], &s.result[2]); break;
+            case 'L': st = ma_u64_sum(ctx, (const uint64_t*)s.values, n, m, mask_off, nc, &s.result[0], &s.result[2]); break;
+            case 'i': st = ma_i32_sum(ctx, (const int32_t*)s.values, n, m, mask_off, nc, (int64_t*)&s.result[0], &s.result[2]); break;
+            case 'I': st = ma_u32_sum(ctx, (const uint32_t*)s.values, n, m, mask_off, nc, &s.result[0], &s.result[2]); break;
+            case 'f': st = ma_f32_sum_dd(ctx, (const float*)s.values, n, m, mask_off, nc, (double*)&s.result[0], (double*)&s.result[1], &s.result[2]); break;
+            default: st = ma_f64_sum_dd(ctx, (const double*)s.values, n, m, mask_off, nc, (double*)&s.result[0], (double*)&s.result[1], &s.result[2]); break;
+        }
+        if (st != MA_OK) break;
+        he = hipEventRecord(s.done, ctx->stream);
+        if (he != hipSuccess) {
+            st = hip_fail(he, "hipEventRecord", __FILE__, __LINE__);
+            break;
+        }
+        s.busy = true;
+    }
+    if (st == MA_OK) st = drain(slots[batches & 1]);        // older batch first: fold in batch order
+    if (st == MA_OK) st = drain(slots[(batches + 1) & 1]);
+    cleanup();
+    if (st != MA_OK) return st;
+    if (is_float) {
+        double total = (hi == hi && lo == lo && hi - hi == 0.0 && lo - lo == 0.0) ? hi + lo : hi;
+        if (out_sum_f64) *out_sum_f64 = total;
+        if (out_sum_i64) *out_sum_i64 = 0;
+    } else {
+        if (out_sum_i64) *out_sum_i64 = (int64_t)isum;
+        if (out_sum_f64) *out_sum_f64 = (code == 'L' || code == 'I') ? (double)isum : (double)(int64_t)isum;
+    }
+    if (out_valid_count) *out_valid_count = count;
+    if (out_rows) *out_rows = rows;
+    if (out_batches) *out_batches = batches;
+    return MA_OK;
+}

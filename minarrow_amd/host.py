@@ -383,3 +383,11 @@ class Context:
             table(rhs_chunks), C.cast(lr, C.c_void_p), table(rhs_masks), addr_of(override), table(out_chunks),
             table(out_masks), C.cast(has, C.c_void_p)))
         return [bool(x) for x in has]
+
+    def sum_arrow_stream(self, stream_ptr: int, column: int = 0):
+        """(sum as float, sum as wrapped int64, valid_count, rows, batches) over every batch of an ArrowArrayStream."""
+        f, i = C.c_double(), C.c_int64()
+        c, r, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ffi.check(self.lib.ma_sum_arrow_stream(self.handle, int(stream_ptr), int(column), C.addressof(f), C.addressof(i),
+                                               C.addressof(c), C.addressof(r), C.addressof(b)))
+        return f.value, i.value, int(c.value), int(r.value), int(b.value)
