@@ -90,6 +90,8 @@ int32_t ma_ctx_device(ma_ctx* ctx);
 int32_t ma_ctx_compute_units(ma_ctx* ctx);
 /* Launch geometry for the streaming kernels: workgroups per CU (0 = built-in default). */
 ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
+/* Tuning harness: absolute workgroup count for the streaming kernels (0 = built-in default). */
+ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups);
 /* Kernel variant selector used by the tuning harness (0 = default). See DESIGN.md §kernels. */
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
 

@@ -471,18 +471,28 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
                       (c.kind == kAS || ((uintptr_t)a.rhs & 15) == phase) &&
                       (!c.fma || ((uintptr_t)a.acc & 15) == phase);
     constexpr int R = 16 / (int)sizeof(T);
-    // Launch shape (profiles/r01_sweep_binary.txt, profiles/r01_ubench_stream.txt): with a store stream in the mix
-    // every shape lands within ~3 % of this device's 16-byte copy rate (5.4-5.8 TB/s); two array operands run
-    // best with 8 loads per operand in flight and two waves per SIMD, one operand with 4 and one wave.
-    int unroll = (c.kind == kAA || c.fma) ? 8 : 4;
-    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : ((c.kind == kAA || c.fma) ? 2 : 1);
+    // Launch shape (profiles/r01_sweep_grid.json, r01_sweep_binary.txt, r01_ubench_stream.txt). With a store stream in
+    // the mix — unlike the read-only sums — MORE resident workgroups help (the memory system batches writes better
+    // with more of them queued), 8 accesses per operand in flight, and the 16-KiB tiles of UNROLL = 4 resonate with
+    // power-of-two grids (512/1024/2048: -5..-10 %). UNROLL = 8 with 6 workgroups per CU sits on the plateau
+    // (a(+)b 3.92 ms, a(+)scalar 2.59 ms, fma 5.36 ms at 10^9 f64 rows; device-to-device spread is ~10 %).
+    int unroll = 8;
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 6;
     switch ((ctx->variant >> 1) & 7) {
         case 2: unroll = 4; break;
         case 3: unroll = 8; break;
         default: break;
     }
-    if (c.fma) unroll = 4;
-    unroll = clamp_unroll<T>(unroll);
+    if (c.fma) {
+        unroll = 8;
+        switch ((ctx->variant >> 1) & 7) {
+            case 1: unroll = 2; break;
+            case 2: unroll = 4; break;
+            default: break;
+        }
+    } else {
+        unroll = clamp_unroll<T>(unroll);
+    }
     const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
     size_t head = 0, n_tiles = 0;
     if (same_phase && !ballot) {
@@ -500,8 +510,13 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
         int grid = grid_for(ctx, n_tiles, bpc);
         if (c.fma) {
             if constexpr (!kInt) {
-                if (masked) hipLaunchKernelGGL((fma_vec_kernel<T, true, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-                else hipLaunchKernelGGL((fma_vec_kernel<T, false, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+#define MA_FMA_LAUNCH(M, U) hipLaunchKernelGGL((fma_vec_kernel<T, M, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a)
+                if (masked) {
+                    if (unroll == 8) MA_FMA_LAUNCH(true, 8); else if (unroll == 2) MA_FMA_LAUNCH(true, 2); else MA_FMA_LAUNCH(true, 4);
+                } else {
+                    if (unroll == 8) MA_FMA_LAUNCH(false, 8); else if (unroll == 2) MA_FMA_LAUNCH(false, 2); else MA_FMA_LAUNCH(false, 4);
+                }
+#undef MA_FMA_LAUNCH
             }
         } else if (masked) {
             launch_vec_op<T, true>(ctx, a, grid, unroll, c.kind, c.op);

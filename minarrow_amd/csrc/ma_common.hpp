@@ -71,6 +71,7 @@ struct ma_ctx {
     int num_cus = 0;
     int blocks_per_cu = 0;  // 0 = each kernel's own default
     int variant = 0;
+    int grid_override = 0;  // tuning: absolute workgroup count for the streaming kernels (0 = auto)
     std::mutex mu;
 
     ma::Partial* partials = nullptr;   // device, kMaxGrid records
@@ -122,6 +123,11 @@ class CallScope {
 };
 
 inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0) {
+    if (ctx->grid_override > 0) {
+        size_t g = (size_t)ctx->grid_override < (size_t)kMaxGrid ? (size_t)ctx->grid_override : (size_t)kMaxGrid;
+        if (work_items < 1) work_items = 1;
+        return (int)(work_items < g ? work_items : g);
+    }
     if (blocks_per_cu <= 0) blocks_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : kDefaultBlocksPerCu;
     size_t cap = (size_t)ctx->num_cus * (size_t)blocks_per_cu;
     if (cap > (size_t)kMaxGrid) cap = kMaxGrid;

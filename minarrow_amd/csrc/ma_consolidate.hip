@@ -125,13 +125,13 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
 
 template <typename T>
 static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t n_tiles, void* out) {
-    int grid = grid_for(ctx, n_tiles, 2);
-    hipLaunchKernelGGL((concat_kernel<T, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_chunks, n_tiles, (T*)out);
+    int grid = grid_for(ctx, n_tiles, 6);  // store stream in the mix: more workgroups (profiles/r01_sweep_grid.json)
+    hipLaunchKernelGGL((concat_kernel<T, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_chunks, n_tiles, (T*)out);
 }
 
 template <typename T>
 static size_t tile_rows_of() {
-    return (size_t)64 * (16 / sizeof(T)) * 4 * kWaves;
+    return (size_t)64 * (16 / sizeof(T)) * 8 * kWaves;
 }
 
 }  // namespace ma

@@ -347,6 +347,14 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
     return MA_OK;
 }
 
+ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(workgroups >= 0, MA_ERR_INVALID_ARGUMENT, "workgroups must be >= 0");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->grid_override = workgroups;
+    return MA_OK;
+}
+
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);

@@ -154,6 +154,9 @@ class Context:
     def set_blocks_per_cu(self, n: int) -> None:
         ffi.check(self.lib.ma_ctx_set_blocks_per_cu(self.handle, int(n)))
 
+    def set_grid(self, workgroups: int) -> None:
+        ffi.check(self.lib.ma_ctx_set_grid(self.handle, int(workgroups)))
+
     def set_variant(self, v: int) -> None:
         ffi.check(self.lib.ma_ctx_set_variant(self.handle, int(v)))
 

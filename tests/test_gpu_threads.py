@@ -1,0 +1,47 @@
+"""Thread-safety of the boundary: the reference's kernels are pure and re-entrant and are called from Rayon workers
+(src/kernels/arithmetic/mod.rs:29-31); the C ABI must tolerate many host threads — sharing one context (calls
+serialise on its lock) or owning one context each (independent streams and scratch)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def worker(ctx, seed, n, errors, reps=20):
+    try:
+        rng = np.random.default_rng(seed)
+        a = rng.integers(-(1 << 40), 1 << 40, size=n, dtype=np.int64)
+        b = rng.integers(1, 1 << 20, size=n, dtype=np.int64)
+        da, db = ctx.to_device(a, 64), ctx.to_device(b, 64)
+        out = ctx.alloc(n * 8 + 64)
+        want_sum = int(a.sum())
+        want_mul = a * b
+        for _ in range(reps):
+            assert ctx.sum("i64", da, n) == (want_sum, n)
+            ctx.apply("i64", da, db, 2, out, n, n)
+            np.testing.assert_array_equal(out.download(np.int64, n), want_mul)
+    except Exception as e:  # noqa: BLE001
+        errors.append(repr(e))
+
+
+def test_many_threads_one_shared_context(ctx):
+    errors = []
+    threads = [threading.Thread(target=worker, args=(ctx, s, 50_000 + 1000 * s, errors)) for s in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
+def test_one_context_per_thread():
+    from minarrow_amd.host import Context
+
+    errors = []
+    ctxs = [Context(0) for _ in range(6)]
+    threads = [threading.Thread(target=worker, args=(c, 100 + i, 200_003, errors)) for i, c in enumerate(ctxs)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for c in ctxs:
+        c.close()
+    assert not errors, errors

@@ -149,6 +149,42 @@ def main():
         out.append({"config": 5, "workload": f"SuperTable of {k} x {rows}-row chunks, columns i64 + f64 with 10 % nulls: "
                                              f"consolidate + per-column reduce, 1 MI355X", **res})
 
+    if "x" in configs and rank == 0:
+        # extras for DESIGN.md's kernel table: FMA (32 B/row), masked elementwise, bitmask kernels on 8 Gbit windows
+        res = {}
+        a, b, c, o = (ctx.alloc(n * 8) for _ in range(4))
+        for buf, start in ((a, 1), (b, 2), (c, 3)):
+            ctx.synth_iota("f64", buf, n, start)
+        mask, om = ctx.alloc(n // 8 + 64), ctx.alloc(n // 8 + 64)
+        ctx.synth_validity(mask, n, seed=0xC0FFEE, null_every=10)
+        ctx.set_async(True)
+        ms = timed(ctx, lambda: ctx.apply_fma("f64", a, b, c, o, n, n, n), args.reps)
+        res["fma_f64"] = {"ms": ms, "gbps": 32 * n / ms / 1e6, "grows_per_s": n / ms / 1e6, "bytes_per_row": 32}
+        ms = timed(ctx, lambda: ctx.apply("f64", a, b, 0, o, n, n, mask=mask, out_mask=om), args.reps)
+        res["add_f64_masked"] = {"ms": ms, "gbps": 24.25 * n / ms / 1e6, "grows_per_s": n / ms / 1e6, "bytes_per_row": 24.25}
+        ia, ib, io = a, b, o  # reuse the buffers as i64
+        ctx.synth_iota("i64", ia, n, 1)
+        ctx.synth_iota("i64", ib, n, 1)
+        ms = timed(ctx, lambda: ctx.apply("i64", ia, ib, 3, io, n, n, mask=mask, out_mask=om), max(2, args.reps // 3))
+        res["div_i64_masked_row_kernel"] = {"ms": ms, "gbps": 24.25 * n / ms / 1e6, "grows_per_s": n / ms / 1e6}
+        ms = timed(ctx, lambda: ctx.apply("i64", ia, ib, 3, io, n, n), max(2, args.reps // 3))
+        res["div_i64_dense"] = {"ms": ms, "gbps": 24 * n / ms / 1e6, "grows_per_s": n / ms / 1e6}
+        ctx.set_async(False)
+        ctx.synchronize()
+        bits = 8 * n * 8  # treat an 8 GB buffer as a 64 Gbit bitmap
+        ctx.set_async(True)
+        ms = timed(ctx, lambda: ctx.mask_words_op("and_masks", a, 0, b, 0, bits, o), args.reps)
+        res["and_masks_64Gbit"] = {"ms": ms, "gbps": 3 * bits / 8 / ms / 1e6, "gbits_per_s": bits / ms / 1e6}
+        ctx.set_async(False)
+        ctx.synchronize()
+        import time as _t
+        t0 = _t.perf_counter()
+        pop = ctx.popcount_mask(a, 0, bits)
+        res["popcount_64Gbit"] = {"ms_host_sync": (_t.perf_counter() - t0) * 1e3, "gbps": bits / 8 / (_t.perf_counter() - t0) / 1e9, "popcount": pop}
+        out.append({"config": "extras", "workload": f"{n}-row fma / masked add / i64 div; 64 Gbit bitmap and/popcount, 1 MI355X", **res})
+        for buf in (a, b, c, o, mask, om):
+            buf.free()
+
     if rank == 0:
         for o_ in out:
             print(json.dumps(o_), flush=True)
