@@ -500,3 +500,26 @@ def test_one_billion_rows_f64_add_mul(ctx):
         np.testing.assert_array_equal(out.download(np.float64, 4096, start * 8), i * (n - i))
     for buf in (a, b, out):
         buf.free()
+
+
+def test_more_than_2_to_32_rows_elementwise(ctx):
+    """64-bit row indexing in the elementwise kernels: 2^32 + 1 000 003 u8 rows, array (+) scalar, checked on windows
+    at both ends and across the 2^32 boundary (values are (i mod 251) so every window is predictable)."""
+    n = (1 << 32) + 1_000_003
+    src = ctx.alloc(n + 64)
+    out = ctx.alloc(n + 64)
+    # fill with a 251-periodic pattern by consolidating repeats of one 251 * 4096-byte block (exercises concat too)
+    block = np.tile(np.arange(251, dtype=np.uint8), 4096)
+    d_block = ctx.to_device(block)
+    reps = n // block.size
+    rem = n - reps * block.size
+    chunks = [d_block] * reps + ([d_block] if rem else [])
+    lens = [block.size] * reps + ([rem] if rem else [])
+    ctx.consolidate_column(1, chunks, lens, src)
+    ctx.apply_scalar("u8", "rhs", src, n, 7, OPS["add"], out)
+    for start in (0, (1 << 32) - 1000, n - 5000):
+        i = np.arange(start, start + 2000, dtype=np.int64)
+        want = ((i % 251) + 7).astype(np.uint8)
+        np.testing.assert_array_equal(out.download(np.uint8, 2000, start), want)
+    src.free()
+    out.free()

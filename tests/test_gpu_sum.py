@@ -324,3 +324,17 @@ def test_one_billion_rows(ctx):
     assert abs(mean - 499_999_999.5) <= math.ulp(499_999_999.5)
     mask.free()
     buf.free()
+
+
+def test_more_than_2_to_32_rows(ctx):
+    """Row indices are 64-bit end to end: 2^32 + 300 000 007 i32 rows (18.4 GB). data[i] = wrap_i32(i); one full
+    cycle of i32 values sums to -2^31, the remainder is a plain arithmetic series."""
+    r = 300_000_007
+    n = (1 << 32) + r
+    buf = ctx.alloc(n * 4)
+    ctx.synth_iota("i32", buf, n, 0)
+    expect = -(1 << 31) + r * (r - 1) // 2
+    assert ctx.sum("i32", buf, n) == (expect, n)
+    # the tail window beyond the 2^32nd row
+    assert ctx.sum("i32", buf.offset((1 << 32) * 4), r) == (r * (r - 1) // 2, r)
+    buf.free()
