@@ -535,8 +535,8 @@ ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32
  * Arrow C Stream ingestion — the reference moves chunked tables (SuperTable) through ArrowArrayStream
  * (src/ffi/arrow_c_ffi.rs:160-184 struct, :2104-2260 export / import). Sum and valid count of one column over all
  * record batches of a stream; `column` indexes the children of "+s" (record batch) arrays, or is -1 / 0 for a
- * stream of primitive arrays. Double buffered: while the GPU reads batch k from pinned memory in place, the host
- * copies batch k+1 out of the producer's buffers and releases it. The stream is consumed to its end but NOT
+ * stream of primitive arrays. Each batch is uploaded at PCIe line rate, released, and its sum kernel runs while
+ * the host pulls the next batch from the producer. The stream is consumed to its end but NOT
  * released (the caller owns it). Outputs as ma_sum_arrow; *out_rows / *out_batches count what was read.
  * ---------------------------------------------------------------------------------------------- */
 #ifndef ARROW_C_STREAM_INTERFACE

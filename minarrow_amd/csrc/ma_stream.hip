@@ -2,10 +2,12 @@
 // how a SuperTable travels over the reference's C Stream interface (src/ffi/arrow_c_ffi.rs:160-184 ArrowArrayStream,
 // :2104-2260 export/import of chunked tables).
 //
-// Pipeline (double buffered): while the GPU reads batch k from pinned slot k&1 in place over PCIe, the host copies
-// batch k+1 out of the producer's buffers into the other slot and releases that batch. One event per slot
-// guards reuse. Per-batch partials are double-double / wrapping-i64 and folded on the host in batch order, so the
-// total obeys the same bounds as a single-array sum.
+// Per batch: the column's values (and the bytes of its validity window) go host -> device slot with the runtime's
+// pageable-copy path (measured 55 GB/s, i.e. PCIe Gen5 x16 line rate: profiles/r01_pcie.json — faster than a
+// hand-rolled threaded memcpy into pinned memory, 24 GB/s), the batch is released, and the sum kernel is enqueued; it
+// runs (microseconds) while the host pulls the next batch from the producer. Per-batch partials are double-double /
+// wrapping-i64 and folded on the host in batch order, so the total obeys the same bounds as a single-array sum
+// (DESIGN.md §3.1).
 #include "ma_common.hpp"
 
 #ifndef ARROW_C_STREAM_INTERFACE
@@ -16,23 +18,12 @@ using namespace ma;
 
 namespace {
 
-struct Slot {
-    void* values = nullptr;   // pinned
-    size_t values_cap = 0;
-    void* mask = nullptr;     // pinned
-    size_t mask_cap = 0;
-    hipEvent_t done = nullptr;
-    bool busy = false;
-    uint64_t* result = nullptr;  // pinned: [0] sum / hi, [1] lo, [2] count
-    char code = 0;
-};
-
-ma_status grow(void** p, size_t* cap, size_t need) {
+ma_status grow_dev(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return MA_OK;
-    if (*p) MA_HIP(hipHostFree(*p));
+    if (*p) MA_HIP(hipFree(*p));
     *p = nullptr;
     size_t bytes = need + need / 2 + 4096;
-    MA_HIP(hipHostMalloc(p, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    MA_HIP(hipMalloc(p, bytes));
     *cap = bytes;
     return MA_OK;
 }
@@ -91,35 +82,33 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
     if (st != MA_OK) return st;
 
     const bool is_float = code == 'f' || code == 'g';
-    Slot slots[2];
-    uint64_t* results = nullptr;
-    bool was_async = false;
+    void* d_values = nullptr;
+    size_t values_cap = 0;
+    void* d_mask = nullptr;
+    size_t mask_cap = 0;
+    uint64_t* record = nullptr;  // pinned: [0] sum / hi, [1] lo, [2] count — written by the batch's kernel
+    bool pending = false, was_async = false;
     double hi = 0.0, lo = 0.0;
     uint64_t isum = 0, count = 0, rows = 0, batches = 0;
 
-    auto drain = [&](Slot& s) -> ma_status {
-        if (!s.busy) return MA_OK;
-        MA_HIP(hipEventSynchronize(s.done));
-        s.busy = false;
+    auto fold = [&]() {
+        if (!pending) return;
+        pending = false;
         if (is_float) {
             double h, l;
-            memcpy(&h, &s.result[0], 8);
-            memcpy(&l, &s.result[1], 8);
+            memcpy(&h, &record[0], 8);
+            memcpy(&l, &record[1], 8);
             two_sum_acc(hi, lo, h, l);
         } else {
-            isum += s.result[0];
+            isum += record[0];
         }
-        count += s.result[2];
-        return MA_OK;
+        count += record[2];
     };
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream);
-        for (auto& s : slots) {
-            if (s.values) (void)hipHostFree(s.values);
-            if (s.mask) (void)hipHostFree(s.mask);
-            if (s.done) (void)hipEventDestroy(s.done);
-        }
-        if (results) (void)hipHostFree(results);
+        if (d_values) (void)hipFree(d_values);
+        if (d_mask) (void)hipFree(d_mask);
+        if (record) (void)hipHostFree(record);
         (void)ma_ctx_set_async(ctx, was_async ? 1 : 0);
     };
 
@@ -128,16 +117,8 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
         was_async = ctx->async;
     }
     MA_HIP(hipSetDevice(ctx->device));
-    hipError_t he = hipHostMalloc((void**)&results, 64, hipHostMallocPortable | hipHostMallocMapped);
-    if (he != hipSuccess) return hip_fail(he, "hipHostMalloc(results)", __FILE__, __LINE__);
-    for (int i = 0; i < 2; ++i) {
-        slots[i].result = results + 4 * i;
-        he = hipEventCreateWithFlags(&slots[i].done, hipEventDisableTiming);
-        if (he != hipSuccess) {
-            cleanup();
-            return hip_fail(he, "hipEventCreate", __FILE__, __LINE__);
-        }
-    }
+    hipError_t he = hipHostMalloc((void**)&record, 64, hipHostMallocPortable | hipHostMallocMapped);
+    if (he != hipSuccess) return hip_fail(he, "hipHostMalloc(record)", __FILE__, __LINE__);
     (void)ma_ctx_set_async(ctx, 1);
 
     for (;;) {
@@ -172,47 +153,54 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
         const size_t n = (size_t)col->length;
         // a struct array's own offset shifts every child (Arrow C Data Interface); PyArrow exports 0 here
         const size_t off = (size_t)col->offset + (is_struct ? (size_t)batch.offset : 0);
-        Slot& s = slots[batches & 1];
-        st = drain(s);  // the kernel that last read this slot must be done before it is overwritten
-        if (st == MA_OK && n) st = grow(&s.values, &s.values_cap, n * esz + 64);
         const uint8_t* validity = col->null_count == 0 ? nullptr : (const uint8_t*)col->buffers[0];
         size_t mask_off = 0;
+        // The previous batch's kernel reads the device slots: it must finish before they are overwritten (it has
+        // had the whole get_next() of this batch to do so).
+        he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) st = hip_fail(he, "hipStreamSynchronize", __FILE__, __LINE__);
+        fold();
+        if (st == MA_OK && n) st = grow_dev(&d_values, &values_cap, n * esz + 64);
         if (st == MA_OK && n && validity) {
             const size_t first = off >> 3, end = (off + n + 7) >> 3;
-            st = grow(&s.mask, &s.mask_cap, end - first + 16);
+            st = grow_dev(&d_mask, &mask_cap, end - first + 16);
             if (st == MA_OK) {
-                memcpy(s.mask, validity + first, end - first);
-                memset((uint8_t*)s.mask + (end - first), 0, 16);
+                he = hipMemsetAsync((uint8_t*)d_mask + (end - first), 0, 16, ctx->stream);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(d_mask, validity + first, end - first, hipMemcpyHostToDevice, ctx->stream);
+                if (he != hipSuccess) st = hip_fail(he, "validity upload", __FILE__, __LINE__);
                 mask_off = off & 7;
             }
         }
-        if (st == MA_OK && n) memcpy(s.values, (const char*)col->buffers[1] + off * esz, n * esz);
-        batch.release(&batch);  // the producer's buffers are no longer needed
+        if (st == MA_OK && n) {
+            he = hipMemcpyAsync(d_values, (const char*)col->buffers[1] + off * esz, n * esz, hipMemcpyHostToDevice, ctx->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);  // the producer's memory is about to go away
+            if (he != hipSuccess) st = hip_fail(he, "values upload", __FILE__, __LINE__);
+        }
+        batch.release(&batch);
         if (st != MA_OK) break;
         rows += n;
         ++batches;
         if (n == 0) continue;
-        const uint8_t* m = validity ? (const uint8_t*)s.mask : nullptr;
+        const uint8_t* m = validity ? (const uint8_t*)d_mask : nullptr;
         const int64_t nc = validity ? -1 : 0;
-        s.result[0] = s.result[1] = s.result[2] = 0;
+        record[0] = record[1] = record[2] = 0;
         switch (code) {
-            case 'l': st = ma_i64_sum(ctx, (const int64_t*)s.values, n, m, mask_off, nc, (int64_t*)&s.result[0], &s.result[2]); break;
-            case 'L': st = ma_u64_sum(ctx, (const uint64_t*)s.values, n, m, mask_off, nc, &s.result[0], &s.result[2]); break;
-            case 'i': st = ma_i32_sum(ctx, (const int32_t*)s.values, n, m, mask_off, nc, (int64_t*)&s.result[0], &s.result[2]); break;
-            case 'I': st = ma_u32_sum(ctx, (const uint32_t*)s.values, n, m, mask_off, nc, &s.result[0], &s.result[2]); break;
-            case 'f': st = ma_f32_sum_dd(ctx, (const float*)s.values, n, m, mask_off, nc, (double*)&s.result[0], (double*)&s.result[1], &s.result[2]); break;
-            default: st = ma_f64_sum_dd(ctx, (const double*)s.values, n, m, mask_off, nc, (double*)&s.result[0], (double*)&s.result[1], &s.result[2]); break;
+            case 'l': st = ma_i64_sum(ctx, (const int64_t*)d_values, n, m, mask_off, nc, (int64_t*)&record[0], &record[2]); break;
+            case 'L': st = ma_u64_sum(ctx, (const uint64_t*)d_values, n, m, mask_off, nc, &record[0], &record[2]); break;
+            case 'i': st = ma_i32_sum(ctx, (const int32_t*)d_values, n, m, mask_off, nc, (int64_t*)&record[0], &record[2]); break;
+            case 'I': st = ma_u32_sum(ctx, (const uint32_t*)d_values, n, m, mask_off, nc, &record[0], &record[2]); break;
+            case 'f': st = ma_f32_sum_dd(ctx, (const float*)d_values, n, m, mask_off, nc, (double*)&record[0], (double*)&record[1], &record[2]); break;
+            default: st = ma_f64_sum_dd(ctx, (const double*)d_values, n, m, mask_off, nc, (double*)&record[0], (double*)&record[1], &record[2]); break;
         }
         if (st != MA_OK) break;
-        he = hipEventRecord(s.done, ctx->stream);
-        if (he != hipSuccess) {
-            st = hip_fail(he, "hipEventRecord", __FILE__, __LINE__);
-            break;
-        }
-        s.busy = true;
+        pending = true;
     }
-    if (st == MA_OK) st = drain(slots[batches & 1]);        // older batch first: fold in batch order
-    if (st == MA_OK) st = drain(slots[(batches + 1) & 1]);
+    if (st == MA_OK) {
+        he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) st = hip_fail(he, "hipStreamSynchronize", __FILE__, __LINE__);
+        else fold();
+    }
     cleanup();
     if (st != MA_OK) return st;
     if (is_float) {
