@@ -128,6 +128,7 @@ struct SumArgs {
     uint64_t* out_b;        // double-double low part — may be nullptr
     uint64_t* out_cnt;      // valid count — may be nullptr
     double* out_mean;       // sum / count — may be nullptr
+    int interleave;         // dense only: 1 = n_tiles counts 1-KiB pieces dealt to ALL waves of the grid in turn
     int mode;               // 0: out_a = final value (int, or rounded double); 1: out_a/out_b = double-double
     int is_signed;          // integer mean: interpret the 64-bit sum as signed
 };
@@ -152,8 +153,36 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     for (int r = 0; r < R; ++r) acc[r].init();
     uint64_t cnt = 0;
 
+    // ---- dense, piece-interleaved: wave instruction u of round k reads piece (k*U + u) * n_waves + wave_id --------
+    // All waves of the grid sweep memory as one front, 1 KiB per wave instruction: at any moment the chip reads
+    // U contiguous spans of n_waves KiB instead of n_waves scattered runs. Optional (ctx variant bit 4).
+    if (!MASKED && a.interleave) {
+        const size_t n_waves = (size_t)gridDim.x * kWaves, wave_id = (size_t)blockIdx.x * kWaves + wave;
+        const size_t n_pieces = a.n_tiles, round = n_waves * UNROLL;
+        const V* __restrict__ base = (const V*)(data + a.head) + lane;
+        size_t k = 0;
+        for (; k + round <= n_pieces; k += round) {  // full rounds: no bounds checks
+            V v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(base + (k + (size_t)u * n_waves + wave_id) * 64);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {  // last, partial round
+            const size_t piece = k + (size_t)u * n_waves + wave_id;
+            if (piece < n_pieces) {
+                V v = load16<V, NT>(base + piece * 64);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r].add((T)v[r]);
+            }
+        }
+    }
     // ---- full tiles: 16-byte loads, no bounds checks --------------------------------------------
-    for (size_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+    for (size_t t = blockIdx.x; t < ((!MASKED && a.interleave) ? 0 : a.n_tiles); t += gridDim.x) {
         const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
         const V* __restrict__ p = (const V*)(data + row0) + lane;
         V v[UNROLL];
@@ -183,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
 
     // ---- ragged rows: the unaligned head and whatever follows the last full tile -----------------
     if (blockIdx.x == gridDim.x - 1) {
-        const size_t tail_start = a.head + a.n_tiles * TILE_ROWS;
+        const size_t tail_start = a.head + a.n_tiles * ((!MASKED && a.interleave) ? (size_t)64 * R : TILE_ROWS);
         const size_t n_ragged = a.head + (a.n - tail_start);
         for (size_t i = tid; i < n_ragged; i += kBlock) {
             size_t row = i < a.head ? i : tail_start + (i - a.head);
@@ -381,7 +410,16 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     }
     a.head = head;
     a.n_tiles = (n - head) / tile_rows;
-    int grid = grid_for(ctx, a.n_tiles, bpc);
+    // variant bit 4: piece-interleaved mapping for dense scans. A/B in one process: +2 % on one MI355X, -1 % on
+    // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
+    // tiled mapping stays the default.
+    a.interleave = (!masked && (variant & 16) != 0) ? 1 : 0;
+    size_t work = a.n_tiles;
+    if (a.interleave) {
+        a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces
+        work = (a.n_tiles + (size_t)unroll * kWaves - 1) / ((size_t)unroll * kWaves);
+    }
+    int grid = grid_for(ctx, work, bpc);
 
 #define MA_LAUNCH_U(U, M)                                     \
     do {                                                      \

@@ -20,14 +20,40 @@
 
 typedef long long l2 __attribute__((ext_vector_type(2)));
 
-template <int U, int BLOCK, bool PIPE, int PRIO>
+template <int U, int BLOCK, bool PIPE, int PRIO, int MAP = 0>
 __global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, size_t n_tiles, long long* __restrict__ out) {
     constexpr int WAVES = BLOCK / 64;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr size_t WAVE_VECS = (size_t)64 * U, TILE_VECS = WAVE_VECS * WAVES;
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     l2 acc = {0, 0};
-    if (!PIPE) {
+    if (MAP == 1) {
+        // every wave instruction of the whole grid reads the next 1 KiB piece: piece = (iter * U + u) * n_waves + wave_id
+        const size_t n_waves = (size_t)gridDim.x * WAVES, wave_id = (size_t)blockIdx.x * WAVES + wave;
+        const size_t n_pieces = n_tiles * WAVES * U;  // 64-vector pieces
+        for (size_t base = 0; base < n_pieces; base += n_waves * U) {
+            l2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                size_t piece = base + (size_t)u * n_waves + wave_id;
+                v[u] = piece < n_pieces ? __builtin_nontemporal_load(a + piece * 64 + lane) : l2{0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    } else if (MAP == 2) {
+        // each workgroup owns one contiguous span of tiles
+        size_t per = (n_tiles + gridDim.x - 1) / gridDim.x, t0 = (size_t)blockIdx.x * per;
+        size_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+        for (size_t t = t0; t < t1; ++t) {
+            const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
+            l2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
+    } else if (!PIPE) {
         for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
             const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
             l2 v[U];
@@ -80,14 +106,17 @@ struct Variant {
     long long result = 0;
 };
 
-template <int U, int BLOCK, bool PIPE, int PRIO>
+template <int U, int BLOCK, bool PIPE, int PRIO, int MAP = 0>
 static void launch(const l2* a, size_t rows, int bpc, int cus, long long* out, hipStream_t s) {
     size_t tile_rows = (size_t)2 * 64 * U * (BLOCK / 64);
     size_t n_tiles = rows / tile_rows;
     int grid = (int)std::min<size_t>(n_tiles, (size_t)cus * bpc);
-    hipLaunchKernelGGL((sum_kernel<U, BLOCK, PIPE, PRIO>), dim3(grid), dim3(BLOCK), 0, s, a, n_tiles, out);
+    hipLaunchKernelGGL((sum_kernel<U, BLOCK, PIPE, PRIO, MAP>), dim3(grid), dim3(BLOCK), 0, s, a, n_tiles, out);
 }
 
+#define ADDM(U, B, MAP)                                                                                     \
+    for (int bpc : bpcs)                                                                                    \
+        vars.push_back({std::string("U" #U " B" #B " map=" #MAP), launch<U, B, false, 0, MAP>, bpc});
 #define ADD(U, B, PIPE, PRIO)                                                                               \
     for (int bpc : bpcs)                                                                                    \
         vars.push_back({std::string("U" #U " B" #B " pipe=" #PIPE " prio=" #PRIO), launch<U, B, PIPE, PRIO>, bpc});
@@ -114,6 +143,7 @@ int main(int argc, char** argv) {
     ADD(8, 256, true, 0) ADD(4, 256, true, 0) ADD(2, 256, true, 0) ADD(16, 256, true, 0)
     ADD(8, 256, false, 1) ADD(8, 256, true, 1)
     ADD(4, 512, false, 0) ADD(4, 512, true, 0) ADD(8, 512, false, 0) ADD(2, 1024, true, 0) ADD(4, 1024, false, 0)
+    ADDM(8, 256, 1) ADDM(4, 256, 1) ADDM(16, 256, 1) ADDM(8, 256, 2) ADDM(4, 256, 2) ADDM(8, 512, 1) ADDM(8, 128, 1)
     ADD(8, 128, false, 0) ADD(8, 128, true, 0) ADD(16, 128, false, 0) ADD(8, 64, true, 0) ADD(16, 64, false, 0) ADD(16, 64, true, 0)
     for (int r = 0; r < rounds; ++r) {
         for (auto& v : vars) {
