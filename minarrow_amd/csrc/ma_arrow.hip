@@ -242,14 +242,20 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
 // ------------------------------------------------------------------------------------------------
 // route_super_array_broadcast — src/kernels/broadcast/super_array.rs:180-251.
 // SuperArray (op) SuperArray, chunk by chunk. The reference's loop is sequential with a literal
-// `// TODO: Parallelise` (:193); here every chunk pair is ENQUEUED on the context's stream back to back (no host
-// round trip between chunks), and a host that owns several contexts (one per GPU) hands each a subset of the chunks.
+// `// TODO: Parallelise` (:193); here ALL chunk pairs run in one launch (descriptor table + per-tile binary search,
+// ma_superarray.hip), and a host that owns several contexts (one per GPU) hands each a subset of the chunks.
 //   * chunk i: len(lhs_i) != len(rhs_i) -> MA_ERR_LENGTH_MISMATCH ("Super Array broadcasting error", :202-212)
 //   * common mask (:215-229): neither has one -> dense kernel; one has -> that one; both -> lhs.union(rhs), i.e.
 //     bitwise OR (src/structs/bitmask.rs:661) — NOT the AND of merge_bitmasks_to_new. `null_mask_override`, when
 //     given, replaces the common mask of every chunk (:231).
 //   * resolve_binary_arithmetic(op, lhs_i, rhs_i, mask) (:236) = the same-type kernels.
 // ------------------------------------------------------------------------------------------------
+extern "C" ma_status ma_internal_route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
+                                               const void* const* lhs_data, const size_t* lens,
+                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                               const uint8_t* const* rhs_masks, const uint8_t* override_mask,
+                                               void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask);
+
 extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
                                                     const void* const* lhs_data, const size_t* lhs_lens,
                                                     const uint8_t* const* lhs_masks, const void* const* rhs_data,
@@ -263,6 +269,20 @@ extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_
         if (lhs_lens[i] != rhs_lens[i]) {
             set_error("Super Array broadcasting error - Chunk %zu: LHS %zu RHS %zu", i, lhs_lens[i], rhs_lens[i]);
             return MA_ERR_LENGTH_MISMATCH;
+        }
+    }
+    // One launch for all chunks (ma_superarray.hip) unless output validity depends on the data: masked integer
+    // Div/Rem/FloorDiv clears the bit of a zero divisor (simd.rs:319-326) and goes chunk by chunk below.
+    {
+        const bool is_int = format_code == 'i' || format_code == 'I' || format_code == 'l' || format_code == 'L';
+        const bool divlike = op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV;
+        bool any_mask = null_mask_override != nullptr;
+        for (size_t i = 0; i < n_chunks && !any_mask; ++i)
+            any_mask = (lhs_masks && lhs_masks[i]) || (rhs_masks && rhs_masks[i]);
+        if (!(is_int && divlike && any_mask)) {
+            MA_REQUIRE(op >= MA_OP_ADD && op <= MA_OP_FLOORDIV, MA_ERR_INVALID_ARGUMENT, "unknown ArithmeticOperator code %d", op);
+            return ma_internal_route_batched(ctx, format_code, op, n_chunks, lhs_data, lhs_lens, lhs_masks, rhs_data, rhs_masks,
+                                             null_mask_override, out_data, out_masks, out_has_mask);
         }
     }
     for (size_t i = 0; i < n_chunks; ++i) {

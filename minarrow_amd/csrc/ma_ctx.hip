@@ -1,10 +1,13 @@
 // Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
 // C ABI: include/minarrow_hip.h.
+#include <atomic>
+
 #include "ma_common.hpp"
 
 namespace ma {
 
 static thread_local char g_err[512] = "";
+static std::atomic<unsigned> g_free_generation{0};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -21,6 +24,19 @@ ma_status hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 PtrKind pointer_kind(const void* p) {
+    // A chunked column hands over thousands of pointers into a few allocations (122 071 chunk pairs for 10^9 rows at
+    // the reference's default 8192-row chunking): remember the last device allocation's address range per thread.
+    constexpr int kRanges = 8;
+    static thread_local uintptr_t cached_lo[kRanges] = {0}, cached_hi[kRanges] = {0};
+    static thread_local unsigned cached_gen = 0, next_slot = 0;
+    const unsigned gen = g_free_generation.load(std::memory_order_relaxed);
+    if (cached_gen != gen) {  // something was freed through this library since the ranges were cached
+        for (int i = 0; i < kRanges; ++i) cached_lo[i] = cached_hi[i] = 0;
+        cached_gen = gen;
+    }
+    const uintptr_t addr = (uintptr_t)p;
+    for (int i = 0; i < kRanges; ++i)
+        if (addr >= cached_lo[i] && addr < cached_hi[i]) return kDevice;
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
@@ -28,7 +44,18 @@ PtrKind pointer_kind(const void* p) {
         return kPageable;
     }
     switch (attr.type) {
-        case hipMemoryTypeDevice:
+        case hipMemoryTypeDevice: {
+            hipDeviceptr_t base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
+                cached_lo[next_slot] = (uintptr_t)base;
+                cached_hi[next_slot] = (uintptr_t)base + size;
+                next_slot = (next_slot + 1) % kRanges;
+            } else {
+                (void)hipGetLastError();
+            }
+            return kDevice;
+        }
         case hipMemoryTypeArray:
             return kDevice;
         case hipMemoryTypeHost:
@@ -42,6 +69,7 @@ PtrKind pointer_kind(const void* p) {
 }
 
 CallScope::~CallScope() {
+    if (!temps_.empty()) g_free_generation.fetch_add(1, std::memory_order_relaxed);
     for (auto& t : temps_) {
         if (t.dev) (void)hipFree(t.dev);
     }
@@ -424,6 +452,7 @@ ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));
+    g_free_generation.fetch_add(1, std::memory_order_relaxed);
     MA_HIP(hipFree(dev_ptr));
     return MA_OK;
 }

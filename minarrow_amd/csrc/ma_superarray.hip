@@ -1,0 +1,284 @@
+// Batched chunk fan-out: SuperArray (op) SuperArray in ONE launch.
+//
+// route_super_array_broadcast (src/kernels/broadcast/super_array.rs:180-251) loops over chunk pairs sequentially
+// ("// TODO: Parallelise", :193). SuperArrays are rechunked to 8192 rows by default
+// (RechunkStrategy::Auto, src/structs/chunked/super_array.rs:51-59): a 10^9-row column is ~122 000 chunks, and a
+// launch per chunk would be launch-bound by three orders of magnitude. Here a descriptor table with per-chunk tile
+// prefix sums is uploaded once; every workgroup binary-searches its tile's chunk (like concat_kernel) and runs the
+// same 16-byte vector body as the single-array kernels, or a row body for ragged / phase-mismatched tiles.
+// Validity: the common mask of a chunk is lhs | rhs (Bitmask::union, :224) or whichever side has one; a second
+// launch assembles every chunk's output bitmap word by word.
+#include <vector>
+
+#include "ma_binary.hpp"
+
+namespace ma {
+
+struct PairDesc {
+    const void* lhs;
+    const void* rhs;
+    void* out;
+    const uint64_t* lw;   // lhs validity words or nullptr
+    size_t lo, l_last;
+    const uint64_t* rw;   // rhs validity words or nullptr
+    size_t ro, r_last;
+    uint64_t* ow;         // output validity words or nullptr
+    size_t len;
+    size_t tile0;         // first tile of this chunk
+    size_t word0;         // first output-bitmap word of this chunk in the global word numbering
+    unsigned head;        // rows before the first 16-byte boundary of `out`
+    unsigned vec;         // lhs, rhs and out share their 16-byte phase
+};
+
+__device__ __forceinline__ int find_pair_by_tile(const PairDesc* __restrict__ d, int n, size_t tile) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (d[mid].tile0 <= tile) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ int find_pair_by_word(const PairDesc* __restrict__ d, int n, size_t word) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (d[mid].word0 <= word) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint64_t window_word_at(const uint64_t* __restrict__ words, size_t bit_off, size_t last_word,
+                                                   size_t j) {
+    const size_t b = bit_off + (j << 6);
+    const size_t w = b >> 6;
+    const unsigned sh = (unsigned)(b & 63);
+    uint64_t lo = w <= last_word ? words[w] : 0;
+    if (sh == 0) return lo;
+    uint64_t hi = (w + 1) <= last_word ? words[w + 1] : 0;
+    return (lo >> sh) | (hi << (64 - sh));
+}
+
+// common validity of chunk row `row` (64-row word containing it, shifted so that bit 0 = row)
+__device__ __forceinline__ unsigned pair_row_valid(const PairDesc& d, size_t row) {
+    unsigned v = 0;
+    bool any = false;
+    if (d.lw) {
+        v |= row_bit(d.lw, d.lo + row);
+        any = true;
+    }
+    if (d.rw) {
+        v |= row_bit(d.rw, d.ro + row);
+        any = true;
+    }
+    return any ? v : 1u;
+}
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void batched_binary_kernel(const PairDesc* __restrict__ descs, int n_chunks,
+                                                                size_t n_tiles, int op, uint32_t* flags) {
+    typedef typename Vec16<T>::type V;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int WPT = R * UNROLL;
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool dz = false;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int c = find_pair_by_tile(descs, n_chunks, t);
+        const PairDesc d = descs[c];
+        const T* __restrict__ lhs = (const T*)d.lhs;
+        const T* __restrict__ rhs = (const T*)d.rhs;
+        T* __restrict__ out = (T*)d.out;
+        const bool masked = d.lw != nullptr || d.rw != nullptr;
+        const size_t lt = t - d.tile0;
+        const size_t r0 = d.head + lt * TILE_ROWS;
+        const size_t r1 = r0 + TILE_ROWS < d.len ? r0 + TILE_ROWS : d.len;
+        if (lt == 0) {
+            for (size_t i = threadIdx.x; i < d.head && i < d.len; i += kBlock) {
+                T v = Elem<T>::apply_rt(op, lhs[i], rhs[i], dz);
+                if (masked) v = pair_row_valid(d, i) ? v : (T)0;
+                out[i] = v;
+            }
+        }
+        if (r0 >= d.len) continue;
+        if (d.vec && r1 - r0 == TILE_ROWS) {
+            const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = (const V*)(lhs + w0) + lane;
+            const V* __restrict__ q = (const V*)(rhs + w0) + lane;
+            V* __restrict__ o = (V*)(out + w0) + lane;
+            V va[UNROLL], vb[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+            uint64_t aw = ~(uint64_t)0;
+            if (masked) {
+                aw = 0;
+                if (d.lw) aw |= load_run_words<WPT>(d.lw, d.lo + w0, d.l_last, lane);
+                if (d.rw) aw |= load_run_words<WPT>(d.rw, d.ro + w0, d.r_last, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                unsigned bits = ~0u;
+                if (masked) bits = lane_bits<R>(aw, u, lane);
+                V r;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    T v = Elem<T>::apply_rt(op, (T)va[u][k], (T)vb[u][k], dz);
+                    v = ((bits >> k) & 1u) ? v : (T)0;
+                    r[k] = v;
+                }
+                store16<V, true>(o + (size_t)u * 64, r);
+            }
+        } else {
+            for (size_t i = r0 + threadIdx.x; i < r1; i += kBlock) {
+                T v = Elem<T>::apply_rt(op, lhs[i], rhs[i], dz);
+                if (masked) v = pair_row_valid(d, i) ? v : (T)0;
+                out[i] = v;
+            }
+        }
+    }
+    if constexpr (std::is_integral<T>::value) {
+        // only dense chunks can latch (masked integer division is routed chunk by chunk on the host)
+        if (__any(dz) && lane == 0) atomicOr(flags, 1u);
+    }
+}
+
+// One thread per output validity word over all chunks: word = lhs window | rhs window (or the single one).
+__global__ __launch_bounds__(kBlock) void batched_mask_kernel(const PairDesc* __restrict__ descs, int n_chunks,
+                                                              size_t n_words) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < n_words; g += stride) {
+        const int c = find_pair_by_word(descs, n_chunks, g);
+        const PairDesc& d = descs[c];
+        if (d.ow == nullptr) continue;
+        const size_t j = g - d.word0;
+        const size_t chunk_words = (d.len + 63) >> 6;
+        if (j >= chunk_words) continue;
+        uint64_t w = 0;
+        if (d.lw) w |= window_word_at(d.lw, d.lo, d.l_last, j);
+        if (d.rw) w |= window_word_at(d.rw, d.ro, d.r_last, j);
+        if (j == chunk_words - 1 && (d.len & 63)) w &= (((uint64_t)1) << (d.len & 63)) - 1;
+        d.ow[j] = w;
+    }
+}
+
+template <typename T>
+static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
+                              const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                              const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
+                              uint8_t* const* out_masks, int32_t* out_has_mask) {
+    constexpr int U = 4;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr size_t TILE_ROWS = (size_t)64 * R * U * kWaves;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    std::vector<PairDesc> descs(n_chunks);
+    size_t n_tiles = 0, n_words = 0;
+    bool any_mask = false;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        PairDesc& d = descs[i];
+        memset(&d, 0, sizeof(d));
+        const size_t n = lens[i];
+        d.len = n;
+        d.tile0 = n_tiles;
+        d.word0 = n_words;
+        const uint8_t* lm = override_mask ? override_mask : (lhs_masks ? lhs_masks[i] : nullptr);
+        const uint8_t* rm = override_mask ? nullptr : (rhs_masks ? rhs_masks[i] : nullptr);
+        if (out_has_mask) out_has_mask[i] = (lm || rm) ? 1 : 0;
+        if (n == 0) continue;
+        MA_REQUIRE(lhs_data[i] && rhs_data[i] && out_data[i], MA_ERR_INVALID_ARGUMENT, "chunk %zu: NULL buffer", i);
+        const void* p = nullptr;
+        MA_TRY(scope.in(lhs_data[i], n * sizeof(T), &p));
+        d.lhs = p;
+        MA_TRY(scope.in(rhs_data[i], n * sizeof(T), &p));
+        d.rhs = p;
+        void* po = nullptr;
+        MA_TRY(scope.out(out_data[i], n * sizeof(T), &po));
+        d.out = po;
+        if (lm) {
+            MA_TRY(scope.in_mask(lm, 0, n, &d.lw, &d.lo));
+            d.l_last = (d.lo + n - 1) >> 6;
+        }
+        if (rm) {
+            MA_TRY(scope.in_mask(rm, 0, n, &d.rw, &d.ro));
+            d.r_last = (d.ro + n - 1) >> 6;
+        }
+        if (lm || rm) {
+            MA_REQUIRE(out_masks && out_masks[i], MA_ERR_INVALID_ARGUMENT, "chunk %zu carries nulls but has no output bitmap", i);
+            MA_TRY(scope.out_mask(out_masks[i], n, &d.ow));
+            any_mask = true;
+        }
+        const uintptr_t mis = (uintptr_t)d.out & 15;
+        d.head = mis ? (unsigned)((16 - mis) / sizeof(T)) : 0;
+        d.vec = (((uintptr_t)d.lhs & 15) == mis && ((uintptr_t)d.rhs & 15) == mis) ? 1u : 0u;
+        n_tiles += n > d.head ? (n - d.head + TILE_ROWS - 1) / TILE_ROWS : 1;
+        n_words += (n + 63) >> 6;
+    }
+    if (n_tiles == 0) return MA_OK;
+    void* ddesc = nullptr;
+    MA_HIP(hipMalloc(&ddesc, sizeof(PairDesc) * n_chunks));
+    struct FreeLater {
+        void* p;
+        hipStream_t s;
+        ~FreeLater() {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(p);
+        }
+    } free_desc{ddesc, ctx->stream};
+    MA_HIP(hipMemcpyAsync(ddesc, descs.data(), sizeof(PairDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));  // `descs` is pageable: the copy must leave it before we continue
+    const PairDesc* dd = (const PairDesc*)ddesc;
+    if (any_mask) {
+        int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+        hipLaunchKernelGGL(batched_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks, n_words);
+        MA_HIP(hipGetLastError());
+    }
+    {
+        int grid = grid_for(ctx, n_tiles, 6);
+        hipLaunchKernelGGL((batched_binary_kernel<T, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks, n_tiles,
+                           op, ctx->dev_flags);
+        MA_HIP(hipGetLastError());
+    }
+    MA_TRY(end_call(ctx, scope));
+    const bool int_div = std::is_integral<T>::value && (op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV);
+    if (int_div) {
+        uint32_t f = 0;
+        MA_HIP(hipMemcpyAsync(&f, ctx->dev_flags, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(hipStreamSynchronize(ctx->stream));
+        if (f & 1u) {
+            MA_HIP(hipMemsetAsync(ctx->dev_flags, 0, sizeof(f), ctx->stream));
+            MA_HIP(hipStreamSynchronize(ctx->stream));
+            set_error("Super Array broadcasting error - division by zero in a dense integer chunk");
+            return MA_ERR_DIVIDE_BY_ZERO;
+        }
+    }
+    return MA_OK;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+// Batched form of route_super_array_broadcast for same-type chunk pairs. Falls back to nothing: the caller
+// (ma_route_super_array_broadcast in ma_arrow.hip) decides which chunks need the per-chunk path.
+extern "C" ma_status ma_internal_route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
+                                               const void* const* lhs_data, const size_t* lens,
+                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                               const uint8_t* const* rhs_masks, const uint8_t* override_mask,
+                                               void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask) {
+    switch (format_code) {
+        case 'i': return batched_impl<int32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'I': return batched_impl<uint32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'l': return batched_impl<int64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'L': return batched_impl<uint64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'f': return batched_impl<float>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'g': return batched_impl<double>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        default:
+            set_error("unsupported element format '%c'", (char)format_code);
+            return MA_ERR_UNSUPPORTED;
+    }
+}

@@ -70,3 +70,68 @@ def test_mask_union_rule_and_many_chunks(ctx, oracle, fmt, dt):
     body = oracle.float_body if np.dtype(dt).kind == "f" else oracle.int_body
     st, want, want_mask = body("masked_std", lhs[3], rhs[3], "add", mask=oracle.pad_bits(ov, n))
     np.testing.assert_array_equal(outs[3].download(dt, n), want)
+
+
+def test_many_small_chunks_one_launch(ctx, oracle):
+    """RechunkStrategy::Auto = 8192 rows (src/structs/chunked/super_array.rs:51-59): thousands of chunk pairs, odd
+    lengths, mixed mask presence, run as one batched launch; compared chunk by chunk with the oracle."""
+    rng = np.random.default_rng(12)
+    k = 700
+    lens = [int(x) for x in rng.integers(0, 9000, size=k)]
+    lens[:4] = [8192, 8192, 1, 0]
+    total = sum(lens)
+    a = rng.integers(-1000, 1000, size=total).astype(np.int64)
+    b = rng.integers(1, 1000, size=total).astype(np.int64)
+    da, db, do = ctx.to_device(a, 64), ctx.to_device(b, 64), ctx.alloc(total * 8 + 64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    # per-chunk bitmaps live in one device arena, each starting on an 8-byte boundary
+    lm_host, rm_host, m_offs, pos = [], [], [], 0
+    for i, n in enumerate(lens):
+        nb = ((n + 63) // 64) * 8 + 8
+        lm_host.append(rng.integers(0, 256, size=nb, dtype=np.uint8) if i % 3 != 0 else None)
+        rm_host.append(rng.integers(0, 256, size=nb, dtype=np.uint8) if i % 4 == 1 else None)
+        m_offs.append(pos)
+        pos += nb
+    arena_l = np.zeros(pos + 8, dtype=np.uint8)
+    arena_r = np.zeros(pos + 8, dtype=np.uint8)
+    for i in range(k):
+        if lm_host[i] is not None:
+            arena_l[m_offs[i]:m_offs[i] + lm_host[i].size] = lm_host[i]
+        if rm_host[i] is not None:
+            arena_r[m_offs[i]:m_offs[i] + rm_host[i].size] = rm_host[i]
+    dl, dr, dom = ctx.to_device(arena_l), ctx.to_device(arena_r), ctx.alloc(pos + 8)
+    lhs = [da.offset(int(offs[i]) * 8) for i in range(k)]
+    rhs = [db.offset(int(offs[i]) * 8) for i in range(k)]
+    outs = [do.offset(int(offs[i]) * 8) for i in range(k)]
+    lms = [dl.offset(m_offs[i]) if lm_host[i] is not None else None for i in range(k)]
+    rms = [dr.offset(m_offs[i]) if rm_host[i] is not None else None for i in range(k)]
+    oms = [dom.offset(m_offs[i]) for i in range(k)]
+    for op, name in ((2, "multiply"), (0, "add")):
+        has = ctx.route_super_array_broadcast("l", op, lhs, rhs, lens, lens, outs, lms, rms, oms)
+        got = do.download(np.int64, total)
+        got_masks = dom.download(np.uint8, pos)
+        for i, n in enumerate(lens):
+            sl = slice(int(offs[i]), int(offs[i]) + n)
+            if lm_host[i] is not None and rm_host[i] is not None:
+                common = oracle.bitmask_union(oracle.pad_bits(lm_host[i], n), oracle.pad_bits(rm_host[i], n), n)
+            else:
+                common = lm_host[i] if lm_host[i] is not None else rm_host[i]
+            assert has[i] == (common is not None)
+            if n == 0:
+                continue
+            if common is None:
+                want = (a[sl] * b[sl]) if name == "multiply" else (a[sl] + b[sl])
+                np.testing.assert_array_equal(got[sl], want)
+            else:
+                st, want, want_mask = oracle.int_body("masked_std", a[sl], b[sl], name, mask=oracle.pad_bits(common, n))
+                np.testing.assert_array_equal(got[sl], want, err_msg=f"chunk {i}")
+                nb = ((n + 63) // 64) * 8
+                np.testing.assert_array_equal(got_masks[m_offs[i]:m_offs[i] + nb], want_mask[:nb], err_msg=f"chunk {i} validity")
+    # dense division by zero in one chunk is reported
+    zero_b = b.copy()
+    zero_b[int(offs[5])] = 0
+    db2 = ctx.to_device(zero_b, 64)
+    rhs2 = [db2.offset(int(offs[i]) * 8) for i in range(k)]
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.route_super_array_broadcast("l", 3, lhs, rhs2, lens, lens, outs)
+    assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
