@@ -45,45 +45,64 @@ def fold_dd(pairs):
     return hi + lo
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of quota the container may burn per period (cgroup v2 cpu.max), or None when unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else max(1, int(int(quota) / int(period)))
+    except Exception:
+        return None
+
+
 def cpu_baseline(rows: int, budget_s: float):
     """Times the oracle's restatement of rayon_simd_sum_{i64,f64} (benches/benchmark_parallel_simd.rs:81-98) on
-    this box's host cores over a bounded sample of the same workload."""
+    this box's host cores over a bounded sample of the same workload. The GPU boxes expose all host threads but cap
+    the container's CPU time (cgroup cpu.max), so several pool sizes are tried — quota, 4 x quota, every visible
+    thread — and the fastest is reported; best-of-N catches the un-throttled bursts."""
     import numpy as np
 
     from oracle import oracle
 
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    total_rows, total_time = 0, 0.0
-    detail = {}
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    candidates = sorted({visible} | ({min(visible, quota), min(visible, 4 * quota)} if quota else set()))
+    results = {}
+    arrays = {}
     for dtype, name in ((np.int64, "i64"), (np.float64, "f64")):
         a = np.empty(rows, dtype=dtype)
-        oracle.par_fill_iota(a, 0, threads)
-        expect = rows * (rows - 1) // 2
-        got = oracle.par_sum(a, 1 << 20, 4, threads)  # warm-up (cf. benches/hotloop_benchmark_simd.rs:199-200)
-        assert got == (expect if name == "i64" else got)
-        times = []
-        t_end = time.perf_counter() + budget_s / 2
-        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
-            t0 = time.perf_counter()
-            got = oracle.par_sum(a, 1 << 20, 4, threads)
-            times.append(time.perf_counter() - t0)
-        if name == "i64":
-            assert got == expect, (got, expect)
-        best = min(times)
-        detail[name] = {"best_ms": best * 1e3, "median_ms": sorted(times)[len(times) // 2] * 1e3, "reps": len(times),
-                        "grows_per_s": rows / best / 1e9}
-        total_rows += rows
-        total_time += best
-        del a
+        oracle.par_fill_iota(a, 0, min(visible, 4 * quota) if quota else visible)
+        arrays[name] = a
+    expect = rows * (rows - 1) // 2
+    per_case = budget_s / (2 * len(candidates))
+    for threads in candidates:
+        detail = {}
+        for name, a in arrays.items():
+            got = oracle.par_sum(a, 1 << 20, 4, threads)  # warm-up (cf. benches/hotloop_benchmark_simd.rs:199-200)
+            times = []
+            t_end = time.perf_counter() + per_case
+            while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+                t0 = time.perf_counter()
+                got = oracle.par_sum(a, 1 << 20, 4, threads)
+                times.append(time.perf_counter() - t0)
+            if name == "i64":
+                assert got == expect, (got, expect)
+            else:
+                assert abs(got - float(expect)) <= 64 * math.ulp(float(expect)), (got, expect)
+            detail[name] = {"best_ms": min(times) * 1e3, "median_ms": sorted(times)[len(times) // 2] * 1e3,
+                            "reps": len(times), "grows_per_s": rows / min(times) / 1e9}
+        total_time = (detail["i64"]["best_ms"] + detail["f64"]["best_ms"]) * 1e-3
+        results[threads] = {"value": 2 * rows / total_time / 1e9, **detail}
+    best_threads = max(results, key=lambda t: results[t]["value"])
     return {
-        "value": total_rows / total_time / 1e9,
+        "value": results[best_threads]["value"],
         "unit": "Grows/s",
-        "cores": threads,
+        "cores": best_threads,
         "kind": "port",
-        "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, "
-                  f"persistent pool of {threads} threads, best of {detail['i64']['reps']}/{detail['f64']['reps']} reps "
+        "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, persistent "
+                  f"pool of {best_threads} threads (tried {candidates}; {visible} host threads visible, cgroup CPU quota "
+                  f"{quota if quota else 'none'}), best of N reps "
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
-        "detail": detail,
+        "detail": {str(t): r for t, r in results.items()},
     }
 
 

@@ -133,7 +133,7 @@ struct SumArgs {
     int is_signed;          // integer mean: interpret the 64-bit sum as signed
 };
 
-template <typename T, int UNROLL, bool MASKED, bool NT>
+template <typename T, int UNROLL, bool MASKED, bool NT, bool IL = false>
 __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     typedef typename Vec16<T>::type V;
     typedef typename AccOf<T>::type Acc;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     // ---- dense, piece-interleaved: wave instruction u of round k reads piece (k*U + u) * n_waves + wave_id --------
     // All waves of the grid sweep memory as one front, 1 KiB per wave instruction: at any moment the chip reads
     // U contiguous spans of n_waves KiB instead of n_waves scattered runs. Optional (ctx variant bit 4).
-    if (!MASKED && a.interleave) {
+    if constexpr (!MASKED && IL) {
         const size_t n_waves = (size_t)gridDim.x * kWaves, wave_id = (size_t)blockIdx.x * kWaves + wave;
         const size_t n_pieces = a.n_tiles, round = n_waves * UNROLL;
         const V* __restrict__ base = (const V*)(data + a.head) + lane;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         }
     }
     // ---- full tiles: 16-byte loads, no bounds checks --------------------------------------------
-    for (size_t t = blockIdx.x; t < ((!MASKED && a.interleave) ? 0 : a.n_tiles); t += gridDim.x) {
+    for (size_t t = blockIdx.x; t < ((!MASKED && IL) ? 0 : a.n_tiles); t += gridDim.x) {
         const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
         const V* __restrict__ p = (const V*)(data + row0) + lane;
         V v[UNROLL];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
 
     // ---- ragged rows: the unaligned head and whatever follows the last full tile -----------------
     if (blockIdx.x == gridDim.x - 1) {
-        const size_t tail_start = a.head + a.n_tiles * ((!MASKED && a.interleave) ? (size_t)64 * R : TILE_ROWS);
+        const size_t tail_start = a.head + a.n_tiles * ((!MASKED && IL) ? (size_t)64 * R : TILE_ROWS);
         const size_t n_ragged = a.head + (a.n - tail_start);
         for (size_t i = tid; i < n_ragged; i += kBlock) {
             size_t row = i < a.head ? i : tail_start + (i - a.head);
@@ -336,7 +336,13 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
 
 template <typename T, int UNROLL, bool MASKED, bool NT>
 static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
-    hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    if constexpr (!MASKED && NT && UNROLL == 8) {
+        if (a.interleave) {  // tuning variant only (ctx variant bit 4)
+            hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
 template <typename T>
@@ -413,7 +419,7 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     // variant bit 4: piece-interleaved mapping for dense scans. A/B in one process: +2 % on one MI355X, -1 % on
     // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
     // tiled mapping stays the default.
-    a.interleave = (!masked && (variant & 16) != 0) ? 1 : 0;
+    a.interleave = (!masked && nt && unroll == 8 && (variant & 16) != 0) ? 1 : 0;
     size_t work = a.n_tiles;
     if (a.interleave) {
         a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces

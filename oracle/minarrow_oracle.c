@@ -225,15 +225,18 @@ static struct {
     void* arg;
     unsigned long generation;
     int remaining;
-    int initialised;
+    int active;      /* workers with index < active take part in the current job */
 } mo_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, NULL, 0, 0, 0};
 
-static void* mo_pool_worker(void* unused) {
-    (void)unused;
+static void* mo_pool_worker(void* index_ptr) {
+    const int index = (int)(intptr_t)index_ptr;
     unsigned long seen = 0;
     for (;;) {
         pthread_mutex_lock(&mo_pool.mu);
-        while (mo_pool.generation == seen) pthread_cond_wait(&mo_pool.cv_start, &mo_pool.mu);
+        while (mo_pool.generation == seen || index >= mo_pool.active) {
+            seen = mo_pool.generation;
+            pthread_cond_wait(&mo_pool.cv_start, &mo_pool.mu);
+        }
         seen = mo_pool.generation;
         void* (*fn)(void*) = mo_pool.fn;
         void* arg = mo_pool.arg;
@@ -257,16 +260,19 @@ static int mo_pool_run(void* (*fn)(void*), void* arg, int n_threads) {
         if (grown) {
             mo_pool.threads = grown;
             while (mo_pool.n_workers < want) {
-                if (pthread_create(&mo_pool.threads[mo_pool.n_workers], NULL, mo_pool_worker, NULL) != 0) break;
+                if (pthread_create(&mo_pool.threads[mo_pool.n_workers], NULL, mo_pool_worker,
+                                   (void*)(intptr_t)mo_pool.n_workers) != 0)
+                    break;
                 pthread_detach(mo_pool.threads[mo_pool.n_workers]);
                 ++mo_pool.n_workers;
             }
         }
     }
-    /* every pool worker wakes for every job; workers beyond `want` find the work counter exhausted */
-    int workers = mo_pool.n_workers;
+    /* exactly `want` workers (or as many as exist) take part; the others go back to sleep */
+    int workers = mo_pool.n_workers < want ? mo_pool.n_workers : want;
     mo_pool.fn = fn;
     mo_pool.arg = arg;
+    mo_pool.active = workers;
     mo_pool.remaining = workers;
     ++mo_pool.generation;
     pthread_cond_broadcast(&mo_pool.cv_start);

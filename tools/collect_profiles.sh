@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): produces the round's evidence under gpurun_out/profiles/ — copy what should be
+# judged into profiles/ afterwards. rocprofv3 gets the program itself after `--` (no wrappers), counters are
+# collected in their own passes (no --pmc together with trace domains other than kernel-trace).
+set -u
+export TMPDIR=/tmp
+R=${1:-r01}
+O=$GRAFT_REPO_ROOT/gpurun_out/profiles
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+echo "== bench" ; timeout 600 python3 bench.py --steps 20 --warmup 3 > $O/${R}_bench.json 2> $O/${R}_bench.err ; echo rc=$?
+echo "== rocprof stats" ; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/${R}_bench_under_rocprof.json 2>/dev/null ; echo rc=$?
+cp $O/stats/*/*_kernel_stats.csv $O/${R}_bench_kernel_stats.csv 2>/dev/null
+echo "== pmc fetch" ; timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 ; echo rc=$?
+echo "== pmc write" ; timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 ; echo rc=$?
+cp $O/pmc_fetch/*/*_counter_collection.csv $O/${R}_pmc_fetch_counter_collection.csv 2>/dev/null
+cp $O/pmc_write/*/*_counter_collection.csv $O/${R}_pmc_write_counter_collection.csv 2>/dev/null
+echo "== configs" ; timeout 900 python3 tools/bench_configs.py --configs 3,4,5,x > $O/${R}_configs.jsonl 2>/dev/null ; echo rc=$?
+echo "== configs under rocprof" ; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg -- python3 tools/bench_configs.py --configs 3,4,5,x > /dev/null 2>&1 ; echo rc=$?
+cp $O/stats_cfg/*/*_kernel_stats.csv $O/${R}_configs_kernel_stats.csv 2>/dev/null
+echo "== sweeps" ; timeout 900 python3 tools/sweep_sum.py --types i64,f64 --variants 0,16,6,22,4 --bpcs 0,1,2 --rounds 3 --reps 10 > $O/${R}_sweep_sum.txt 2>&1 ; echo rc=$?
+hipcc -O3 --offload-arch=gfx950 tools/ubench_sum.hip -o /tmp/ubench_sum 2>/dev/null && timeout 600 /tmp/ubench_sum 1000000000 3 > $O/${R}_ubench_sum.txt 2>&1
+rm -rf $O/stats $O/stats_cfg $O/pmc_fetch $O/pmc_write
+ls -la $O
+head -c 1500 $O/${R}_bench.json
