@@ -523,3 +523,22 @@ def test_more_than_2_to_32_rows_elementwise(ctx):
         np.testing.assert_array_equal(out.download(np.uint8, 2000, start), want)
     src.free()
     out.free()
+
+
+def test_output_bitmap_must_be_word_aligned(ctx):
+    n = 100
+    a = ctx.to_device(np.arange(n, dtype=np.int64), 64)
+    out = ctx.alloc(n * 8)
+    m = ctx.to_device(np.full(64, 0xFF, dtype=np.uint8))
+    om = ctx.alloc(64)
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply("i64", a, a, 0, out, n, n, mask=m, out_mask=om.offset(3))
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply("i64", a, a, 0, out, n, n, mask=m, out_mask=None)  # Some(mask) needs an output bitmap
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply("i64", a, a, 9, out, n, n)  # not an ArithmeticOperator
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+    ctx.apply("i64", a, a, 0, out, n, n, mask=m.offset(3), mask_bit_offset=1, out_mask=om)  # input masks may be anywhere
+    np.testing.assert_array_equal(out.download(np.int64, n), 2 * np.arange(n))

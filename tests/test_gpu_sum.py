@@ -338,3 +338,18 @@ def test_more_than_2_to_32_rows(ctx):
     # the tail window beyond the 2^32nd row
     assert ctx.sum("i32", buf.offset((1 << 32) * 4), r) == (r * (r - 1) // 2, r)
     buf.free()
+
+
+def test_byte_misaligned_mask_pointer(ctx, oracle):
+    """An Arrow validity buffer may start anywhere: the pointer is re-based onto its enclosing 8-byte word and the
+    byte delta folded into the bit offset (device and pageable memory alike)."""
+    rng = np.random.default_rng(77)
+    n = 70_001
+    a = rng.integers(-(1 << 50), 1 << 50, size=n, dtype=np.int64)
+    bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
+    d, m = ctx.to_device(a, 64), ctx.to_device(bits, 16)
+    for byte_delta, bit_off in ((1, 0), (3, 5), (7, 63), (13, 2)):
+        expect = oracle.masked_sum(a, bits, byte_delta * 8 + bit_off)
+        assert ctx.sum("i64", d, n, mask=m.offset(byte_delta), mask_bit_offset=bit_off) == expect
+        view = bits[byte_delta:]  # a numpy view: pageable memory at an odd address
+        assert ctx.sum("i64", a, n, mask=view, mask_bit_offset=bit_off) == expect
