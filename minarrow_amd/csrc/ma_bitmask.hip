@@ -61,21 +61,45 @@ struct BitArgs {
     int op;
 };
 
-__global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
+__device__ __forceinline__ uint64_t bit_op(int op, uint64_t x, uint64_t y) {
+    switch (op) {
+        case kBitAnd: return x & y;
+        case kBitOr: return x | y;
+        case kBitXor: return x ^ y;
+        case kBitNot: return ~x;
+        case kBitXnor: return ~(x ^ y);
+        default: return x;
+    }
+}
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// `vec`: both windows start on a word (bit offset % 64 == 0) and every pointer is 16-byte aligned at the window's
+// first word, so two words move per lane per access (global_load/store_dwordx4, non-temporal).
+__global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a, int vec) {
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
+    size_t first_scalar = 0;
+    if (vec) {
+        const size_t n_pairs = (n_words - 1) >> 1;  // the last word (trailing-bit mask) always goes through the scalar path
+        const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
+        const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
+        u64x2* __restrict__ op = (u64x2*)a.out;
+        for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs; j += stride) {
+            u64x2 x = __builtin_nontemporal_load(lp + j);
+            u64x2 y = {0, 0};
+            if (rp) y = __builtin_nontemporal_load(rp + j);
+            u64x2 r;
+            r.x = bit_op(a.op, x.x, y.x);
+            r.y = bit_op(a.op, x.y, y.y);
+            __builtin_nontemporal_store(r, op + j);
+        }
+        first_scalar = n_pairs << 1;
+    }
+    for (size_t j = first_scalar + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
         uint64_t x = window_word(a.lw, a.lo, a.l_last, j);
         uint64_t y = a.rw ? window_word(a.rw, a.ro, a.r_last, j) : 0;
-        uint64_t r;
-        switch (a.op) {
-            case kBitAnd: r = x & y; break;
-            case kBitOr: r = x | y; break;
-            case kBitXor: r = x ^ y; break;
-            case kBitNot: r = ~x; break;
-            case kBitXnor: r = ~(x ^ y); break;
-            default: r = x; break;
-        }
+        uint64_t r = bit_op(a.op, x, y);
         // clear_trailing_bits / mask_trailing_bits — bitmask/mod.rs:141-150, structs/bitmask.rs:83-90
         if (j == n_words - 1 && (a.n & 63)) r &= (((uint64_t)1) << (a.n & 63)) - 1;
         a.out[j] = r;
@@ -85,11 +109,28 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
 // Scalar facts about one or two windows, accumulated into 4 device words:
 //   acc[0] += popcount(x)            acc[1] |= any bit set in x
 //   acc[2] |= any bit clear in x     acc[3] |= any bit where x != y
-__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc) {
+__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc, int vec) {
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned long long pop = 0, any_set = 0, any_clear = 0, any_diff = 0;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
+    size_t first_scalar = 0;
+    if (vec) {
+        const size_t n_pairs = (n_words - 1) >> 1;
+        const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
+        const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
+        for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs; j += stride) {
+            u64x2 x = __builtin_nontemporal_load(lp + j);
+            pop += (unsigned long long)(__popcll(x.x) + __popcll(x.y));
+            any_set |= x.x | x.y;
+            any_clear |= ~(x.x & x.y);
+            if (rp) {
+                u64x2 y = __builtin_nontemporal_load(rp + j);
+                any_diff |= (x.x ^ y.x) | (x.y ^ y.y);
+            }
+        }
+        first_scalar = n_pairs << 1;
+    }
+    for (size_t j = first_scalar + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
         uint64_t live = ~(uint64_t)0;
         if (j == n_words - 1 && (a.n & 63)) live = (((uint64_t)1) << (a.n & 63)) - 1;
         uint64_t x = window_word(a.lw, a.lo, a.l_last, j) & live;
@@ -144,12 +185,21 @@ static void fill_window(BitArgs& a, const uint64_t* lw, size_t lo, const uint64_
 }
 
 // Runs bit_scan_kernel and brings the four words back to the host (synchronises the stream).
+// Two-words-per-lane path: windows start on words and the first word of every operand sits on a 16-byte boundary.
+static int vec_ok(const BitArgs& a, bool with_out) {
+    if ((a.lo & 63) || (a.rw && (a.ro & 63))) return 0;
+    if (((uintptr_t)(a.lw + (a.lo >> 6)) & 15) || (a.rw && ((uintptr_t)(a.rw + (a.ro >> 6)) & 15))) return 0;
+    if (with_out && ((uintptr_t)a.out & 15)) return 0;
+    return a.n >= 256 ? 1 : 0;
+}
+
 static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
     unsigned long long* acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 inside the 256-byte scratch line set
     MA_HIP(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const size_t n_words = (a.n + 63) >> 6;
-    int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
-    hipLaunchKernelGGL(bit_scan_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
+    const int vec = vec_ok(a, false);
+    int grid = grid_for(ctx, ((vec ? n_words / 2 : n_words) + kBlock - 1) / kBlock, 8);
+    hipLaunchKernelGGL(bit_scan_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc, vec);
     MA_HIP(hipGetLastError());
     MA_HIP(hipMemcpyAsync(out, acc, sizeof(BitScan), hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -158,8 +208,9 @@ static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
 
 static ma_status launch_words(ma_ctx* ctx, const BitArgs& a) {
     const size_t n_words = (a.n + 63) >> 6;
-    int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
-    hipLaunchKernelGGL(bit_words_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    const int vec = vec_ok(a, true);
+    int grid = grid_for(ctx, ((vec ? n_words / 2 : n_words) + kBlock - 1) / kBlock, 8);
+    hipLaunchKernelGGL(bit_words_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, vec);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
