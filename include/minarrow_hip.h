@@ -553,6 +553,28 @@ ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* stream, int6
                               int64_t* out_sum_i64, uint64_t* out_valid_count, uint64_t* out_rows,
                               uint64_t* out_batches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-chunk reductions over several GPUs driven from ONE process — the reference's Rayon path
+ * (`slice.par_chunks(1 << 20).map(simd_sum).sum()`, benches/benchmark_parallel_simd.rs:81-98) for a host such as the
+ * Rust library itself. A group owns one context per listed device ordinal (an ordinal may repeat). Member i scans
+ * chunk i (resident on, or reachable from, its device) concurrently with the others; the per-member
+ * {sum | hi, lo, count} records are folded on the host in member order (wrapping add; double-double for floats,
+ * so the f64 total stays within 1 ULP). Split rows with 64-row-aligned boundaries so that a chunk's validity
+ * window starts on a word (any bit offset works, aligned ones are free). Between processes the same exchange is one
+ * RCCL all-gather (bench.py, minarrow_amd/parallel.py).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ma_group ma_group;
+ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
+void ma_group_destroy(ma_group* group);
+int32_t ma_group_size(ma_group* group);
+ma_ctx* ma_group_ctx(ma_group* group, int32_t index);
+ma_status ma_group_sum_i64(ma_group* group, const int64_t* const* chunk_data, const size_t* chunk_lens,
+                           const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, int64_t* out_sum,
+                           uint64_t* out_valid_count);
+ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, const size_t* chunk_lens,
+                           const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_sum,
+                           uint64_t* out_valid_count);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif
