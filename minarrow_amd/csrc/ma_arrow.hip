@@ -250,12 +250,6 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
 //     given, replaces the common mask of every chunk (:231).
 //   * resolve_binary_arithmetic(op, lhs_i, rhs_i, mask) (:236) = the same-type kernels.
 // ------------------------------------------------------------------------------------------------
-extern "C" ma_status ma_internal_route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
-                                               const void* const* lhs_data, const size_t* lens,
-                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
-                                               const uint8_t* const* rhs_masks, const uint8_t* override_mask,
-                                               void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask);
-
 extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
                                                     const void* const* lhs_data, const size_t* lhs_lens,
                                                     const uint8_t* const* lhs_masks, const void* const* rhs_data,
@@ -281,7 +275,7 @@ extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_
             any_mask = (lhs_masks && lhs_masks[i]) || (rhs_masks && rhs_masks[i]);
         if (!(is_int && divlike && any_mask)) {
             MA_REQUIRE(op >= MA_OP_ADD && op <= MA_OP_FLOORDIV, MA_ERR_INVALID_ARGUMENT, "unknown ArithmeticOperator code %d", op);
-            return ma_internal_route_batched(ctx, format_code, op, n_chunks, lhs_data, lhs_lens, lhs_masks, rhs_data, rhs_masks,
+            return route_batched(ctx, format_code, op, n_chunks, lhs_data, lhs_lens, lhs_masks, rhs_data, rhs_masks,
                                              null_mask_override, out_data, out_masks, out_has_mask);
         }
     }

@@ -135,6 +135,12 @@ inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0)
     return (int)(work_items < cap ? work_items : cap);
 }
 
+// All chunk pairs of a SuperArray (op) SuperArray in one launch (ma_superarray.hip).
+ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks, const void* const* lhs_data,
+                        const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                        const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
+                        uint8_t* const* out_masks, int32_t* out_has_mask);
+
 // Completes a call: in sync mode waits for the stream. Returns MA_ERR_DEVICE on failure.
 ma_status end_call(ma_ctx* ctx, CallScope& scope);
 

@@ -261,15 +261,14 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
 
 }  // namespace ma
 
-using namespace ma;
+namespace ma {
 
-// Batched form of route_super_array_broadcast for same-type chunk pairs. Falls back to nothing: the caller
-// (ma_route_super_array_broadcast in ma_arrow.hip) decides which chunks need the per-chunk path.
-extern "C" ma_status ma_internal_route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks,
-                                               const void* const* lhs_data, const size_t* lens,
-                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
-                                               const uint8_t* const* rhs_masks, const uint8_t* override_mask,
-                                               void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask) {
+// Batched form of route_super_array_broadcast for same-type chunk pairs (internal: declared in ma_common.hpp). The
+// caller (ma_route_super_array_broadcast in ma_arrow.hip) decides which calls need the per-chunk path instead.
+ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks, const void* const* lhs_data,
+                        const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                        const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
+                        uint8_t* const* out_masks, int32_t* out_has_mask) {
     switch (format_code) {
         case 'i': return batched_impl<int32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
         case 'I': return batched_impl<uint32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
@@ -282,3 +281,5 @@ extern "C" ma_status ma_internal_route_batched(ma_ctx* ctx, int32_t format_code,
             return MA_ERR_UNSUPPORTED;
     }
 }
+
+}  // namespace ma

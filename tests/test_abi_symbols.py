@@ -67,3 +67,12 @@ def test_header_is_plain_c_and_the_cpp_mirror_compiles(tmp_path):
     cpp_file = tmp_path / "use.cpp"
     cpp_file.write_text('#include "minarrow_hip.hpp"\nint main() { return sizeof(ma::Bitmask) ? 0 : 1; }\n')
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{inc}", str(cpp_file)], check=True)
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", str(ffi.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    declared = set(ffi.parse_header())
+    assert exported == declared, (sorted(exported - declared)[:5], sorted(declared - exported)[:5])

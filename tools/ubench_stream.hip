@@ -33,7 +33,7 @@ __device__ __forceinline__ void st(d2* p, d2 v) {
     else *p = v;
 }
 
-// MODE 0: out = a + b   MODE 1: out = a * s   MODE 2: out = a (copy)
+// MODE 0: out = a + b   MODE 1: out = a * s   MODE 2: out = a (copy)   MODE 3: out = s (write only)   MODE 4: fma a*b+c
 // MAP 0: tile t -> workgroup t % grid (round robin)   MAP 1: each workgroup owns a contiguous span of tiles
 template <int MODE, int UNROLL, int BLOCK, bool NTL, bool NTS, int MAP>
 __global__ __launch_bounds__(BLOCK) void stream_kernel(const d2* __restrict__ a, const d2* __restrict__ b,
@@ -56,8 +56,10 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const d2* __restrict__ a,
     for (size_t t = t0; t < t1; t += step) {
         const size_t v0 = t * TILE_VECS + wave * WAVE_VECS + lane;
         d2 x[UNROLL], y[UNROLL];
+        if (MODE != 3) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) x[u] = ld<NTL>(a + v0 + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) x[u] = ld<NTL>(a + v0 + (size_t)u * 64);
+        }
         if (MODE == 0) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) y[u] = ld<NTL>(b + v0 + (size_t)u * 64);
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(BLOCK) void stream_kernel(const d2* __restrict__ a,
             d2 r;
             if (MODE == 0) r = x[u] + y[u];
             else if (MODE == 1) r = x[u] * s;
+            else if (MODE == 3) r = d2{s, s};
             else r = x[u];
             st<NTS>(out + v0 + (size_t)u * 64, r);
         }
@@ -93,9 +96,9 @@ static void launch(const d2* a, const d2* b, d2* out, size_t rows, int bpc, int 
 
 #define ADD(MODE, U, B, NTL, NTS, MAP)                                                                      \
     for (int bpc : bpcs)                                                                                    \
-        vars.push_back({std::string(MODE == 0 ? "add_aa" : MODE == 1 ? "mul_as" : "copy  ") + " U" #U " B" #B \
+        vars.push_back({std::string(MODE == 0 ? "add_aa" : MODE == 1 ? "mul_as" : MODE == 3 ? "write " : "copy  ") + " U" #U " B" #B \
                             " ntl" #NTL " nts" #NTS " map" #MAP,                                            \
-                        MODE, MODE == 0 ? 24 : 16, launch<MODE, U, B, NTL, NTS, MAP>, bpc});
+                        MODE, MODE == 0 ? 24 : MODE == 3 ? 8 : 16, launch<MODE, U, B, NTL, NTS, MAP>, bpc});
 
 int main(int argc, char** argv) {
     size_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000000ull;
@@ -117,19 +120,12 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
 
     std::vector<Variant> vars;
-    std::vector<int> bpcs = {1, 2, 4, 8};
-    // 2 reads + 1 write
-    ADD(0, 4, 256, true, true, 0) ADD(0, 8, 256, true, true, 0) ADD(0, 2, 256, true, true, 0)
-    ADD(0, 4, 256, true, false, 0) ADD(0, 8, 256, true, false, 0)
-    ADD(0, 4, 256, false, true, 0) ADD(0, 4, 256, false, false, 0)
-    ADD(0, 4, 512, true, true, 0) ADD(0, 4, 1024, true, true, 0) ADD(0, 2, 1024, true, true, 0)
-    ADD(0, 4, 256, true, true, 1) ADD(0, 8, 256, true, true, 1) ADD(0, 4, 256, true, false, 1)
-    // 1 read + 1 write
-    ADD(1, 4, 256, true, true, 0) ADD(1, 8, 256, true, true, 0) ADD(1, 8, 256, true, false, 0)
-    ADD(1, 4, 256, false, false, 0) ADD(1, 8, 512, true, true, 0) ADD(1, 8, 256, true, true, 1)
-    // copy ceiling
-    ADD(2, 8, 256, true, true, 0) ADD(2, 8, 256, false, false, 0) ADD(2, 4, 256, true, true, 0)
-
+    std::vector<int> bpcs = {2, 6, 10, 16, 32};
+    ADD(0, 8, 256, true, true, 0) ADD(0, 4, 256, true, true, 0) ADD(0, 16, 256, true, true, 0)
+    ADD(0, 8, 256, true, false, 0) ADD(0, 8, 512, true, true, 0)
+    ADD(1, 8, 256, true, true, 0) ADD(1, 4, 256, true, true, 0) ADD(1, 16, 256, true, true, 0)
+    ADD(2, 8, 256, true, true, 0)
+    ADD(3, 8, 256, true, true, 0) ADD(3, 4, 256, true, true, 0) ADD(3, 8, 256, true, false, 0) ADD(3, 16, 256, true, true, 0)
     for (int r = 0; r < rounds; ++r) {
         for (auto& v : vars) {
             v.launch(a, b, out, rows, v.bpc, cus, s);  // warm
