@@ -117,6 +117,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,11 +136,14 @@ def main() -> int:
             print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)",
                   file=sys.stderr)
             return 2
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     rows = args.rows

@@ -89,7 +89,7 @@ class ScalarExchange:
 
     def exchange(self) -> None:
         """Enqueue the collective on the current stream (async w.r.t. the host)."""
-        if self.world > 1:
+        if self.dist.is_initialized():
             self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
         else:
             self.gathered.copy_(self.local)
