@@ -397,6 +397,29 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
                          const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, void* out_values,
                          uint8_t* out_validity, int32_t* out_has_validity);
 
+/* Results as Arrow C Data — the producer side (create_arrow_export, src/ffi/arrow_c_ffi.rs:1742-1821).
+ * Same routing as ma_apply_arrow, but the library allocates the result: values and validity live in pinned host
+ * memory the kernels wrote directly (64-byte aligned as check_alignment asserts, arrow_c_ffi.rs:1722-1738) and are
+ * returned as an owned ArrowArray / ArrowSchema pair: offset 0 (:1773), n_buffers 2, buffers[0] = NULL and
+ * null_count 0 when no operand carried nulls (:1750) else the exact null count, format = the routed result type,
+ * flags = ARROW_FLAG_NULLABLE (2, what the reference's import tests, :2631) when a validity buffer is attached.
+ * The consumer owns both structs and must call their `release` (frees the pinned buffers; sets release = NULL).
+ * `name` NULL -> the left operand's field name. On failure nothing is allocated and both `release` are NULL. */
+ma_status ma_apply_arrow_export(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, const struct ArrowSchema* lhs_schema,
+                                const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, const char* name,
+                                struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+/* Table (op) Table over record batches (struct arrays, format "+s", one child per column — what the reference's
+ * record-batch stream yields, arrow_c_ffi.rs:1823-1834) = broadcast_table_with_operator
+ * (src/kernels/broadcast/table.rs:31-63): column counts must match ("Table column count mismatch", ->
+ * MA_ERR_LENGTH_MISMATCH), result column i = lhs.cols[i] (op) rhs.cols[i] routed as ma_apply_arrow_export under
+ * the LEFT table's field name (:55-57); the result struct carries the left table's name (:62). A struct-level
+ * `offset` is applied to the children; struct-level validity is MA_ERR_UNSUPPORTED. The first failing column's
+ * status is returned and everything already produced is freed. */
+ma_status ma_apply_arrow_batch_export(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs_batch,
+                                      const struct ArrowSchema* lhs_schema, const struct ArrowArray* rhs_batch,
+                                      const struct ArrowSchema* rhs_schema, struct ArrowArray* out_batch,
+                                      struct ArrowSchema* out_schema);
+
 /* ------------------------------------------------------------------------------------------------
  * Consolidation of a chunked numeric column (BASELINE config 5) —
  *   Consolidate::consolidate / consolidate_concat / consolidate_arena  src/structs/chunked/super_table.rs:657-743

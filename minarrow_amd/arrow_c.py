@@ -70,6 +70,45 @@ class Exported:
         self.close()
 
 
+class Owned:
+    """An ArrowArray / ArrowSchema pair PRODUCED by the library (ma_apply_arrow_export, ma_apply_arrow_batch_export).
+    Either hand it to a consumer with `to_pyarrow()` (which moves ownership: PyArrow calls `release` when the
+    array dies) or call `close()` to run the release callbacks here."""
+
+    def __init__(self):
+        self.array = ArrowArray()
+        self.schema = ArrowSchema()
+
+    @property
+    def array_ptr(self) -> int:
+        return C.addressof(self.array)
+
+    @property
+    def schema_ptr(self) -> int:
+        return C.addressof(self.schema)
+
+    @property
+    def released(self) -> bool:
+        return not self.array.release and not self.schema.release
+
+    def to_pyarrow(self, record_batch: bool = False):
+        import pyarrow as pa
+
+        cls = pa.RecordBatch if record_batch else pa.Array
+        return cls._import_from_c(self.array_ptr, self.schema_ptr)  # moves both structs (marks them released)
+
+    def close(self) -> None:
+        for st in (self.array, self.schema):
+            if st.release:
+                C.CFUNCTYPE(None, C.c_void_p)(st.release)(C.addressof(st))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class ArrowArrayStream(C.Structure):
     _fields_ = [
         ("get_schema", C.c_void_p),

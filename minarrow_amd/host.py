@@ -336,6 +336,27 @@ class Context:
                                           C.addressof(has)))
         return bool(has.value)
 
+    def apply_arrow_export(self, op: int, lhs_ptrs, rhs_ptrs, name: Optional[str] = None):
+        """lhs (op) rhs returned as a library-owned Arrow C Data pair (`arrow_c.Owned`)."""
+        from .arrow_c import Owned
+
+        out = Owned()
+        ffi.check(self.lib.ma_apply_arrow_export(self.handle, int(op), int(lhs_ptrs[0]), int(lhs_ptrs[1]),
+                                                 int(rhs_ptrs[0]), int(rhs_ptrs[1]),
+                                                 name.encode() if name is not None else None, out.array_ptr,
+                                                 out.schema_ptr))
+        return out
+
+    def apply_arrow_batch_export(self, op: int, lhs_ptrs, rhs_ptrs):
+        """Table (op) Table over two record batches (struct arrays); returns `arrow_c.Owned` holding a struct array."""
+        from .arrow_c import Owned
+
+        out = Owned()
+        ffi.check(self.lib.ma_apply_arrow_batch_export(self.handle, int(op), int(lhs_ptrs[0]), int(lhs_ptrs[1]),
+                                                       int(rhs_ptrs[0]), int(rhs_ptrs[1]), out.array_ptr,
+                                                       out.schema_ptr))
+        return out
+
     # -- consolidation of a chunked column (SuperTable / SuperArray) ------------------------------------
     def consolidate_column(self, elem_size: int, chunks, lens, out_data, masks=None, mask_offsets=None,
                            out_mask=None) -> bool:
