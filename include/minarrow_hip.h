@@ -436,6 +436,19 @@ ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, 
                                 const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
                                 int32_t* out_has_mask);
 
+/* Bit-packed columns — BooleanArray data bits and stand-alone bitmaps:
+ *   Bitmask::extend_from_bitmask_range / extend_from_slice   src/structs/bitmask.rs:520-592
+ *   BooleanArray::append_range                                src/structs/variants/boolean.rs:627-653
+ *   Arena::write_boolean_slices                               src/structs/arena.rs:391-430
+ * chunk i contributes bits [chunk_bit_offsets[i], +chunk_lens[i]) of chunk_bits[i] (LSB-first, Arrow order); the
+ * windows are joined at arbitrary bit positions into out_bits (8*ceil(total/64) bytes, 8-byte aligned, bits >=
+ * total zero). Validity as ma_consolidate_column: present iff any chunk has one, absent ones = all valid.
+ * The offset tables may be NULL (= 0). */
+ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks, const uint8_t* const* chunk_bits,
+                                        const size_t* chunk_bit_offsets, const size_t* chunk_lens,
+                                        const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
+                                        uint8_t* out_bits, uint8_t* out_mask, int32_t* out_has_mask);
+
 /* Narrow integers — the reference's `extended_numeric_types` feature (src/kernels/arithmetic/dispatch.rs:380-387).
  * Same contract as ma_apply_int_i32 above. */
 ma_status ma_apply_int_i8(ma_ctx* ctx, const int8_t* lhs, size_t lhs_len, const int8_t* rhs, size_t rhs_len, int32_t op,

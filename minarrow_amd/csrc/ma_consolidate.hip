@@ -235,3 +235,98 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     }
     return end_call(ctx, scope);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Bit-packed columns: BooleanArray data and stand-alone bitmaps.
+//   Bitmask::extend_from_bitmask_range / extend_from_slice      src/structs/bitmask.rs:520-592
+//   BooleanArray::append_range (data bits, then the mask rules)  src/structs/variants/boolean.rs:627-653
+//   Arena::write_boolean_slices                                  src/structs/arena.rs:391-430
+// Chunk i contributes bits [offset_i, offset_i + len_i) of its bitmap; joins fall on arbitrary bit positions. The
+// reference's unaligned paths go bit by bit (bitmask.rs:571-583); here every output word is assembled from at most
+// a few funnel-shifted source words (concat_mask_kernel above). Validity follows the numeric rule: present iff any
+// chunk has one, chunks without one contribute all-valid rows (boolean.rs:638-650, arena.rs:416-421).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DeviceDescs {
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    ~DeviceDescs() {
+        if (p) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(p);
+        }
+    }
+    ma_status upload(const std::vector<ChunkDesc>& host, hipStream_t stream) {
+        s = stream;
+        MA_HIP(hipMalloc(&p, sizeof(ChunkDesc) * host.size()));
+        MA_HIP(hipMemcpyAsync(p, host.data(), sizeof(ChunkDesc) * host.size(), hipMemcpyHostToDevice, stream));
+        MA_HIP(hipStreamSynchronize(stream));  // `host` lives in the caller's frame
+        return MA_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks, const uint8_t* const* chunk_bits,
+                                                   const size_t* chunk_bit_offsets, const size_t* chunk_lens,
+                                                   const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
+                                                   uint8_t* out_bits, uint8_t* out_mask, int32_t* out_has_mask) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(n_chunks > 0, MA_ERR_INVALID_ARGUMENT, "consolidate() called on empty SuperTable");
+    MA_REQUIRE(n_chunks < ((size_t)1 << 30), MA_ERR_INVALID_ARGUMENT, "too many chunks");
+    MA_REQUIRE(chunk_bits != nullptr && chunk_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
+    bool has_mask = false;
+    size_t total = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        MA_REQUIRE(chunk_lens[i] == 0 || chunk_bits[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "chunk %zu bits are NULL", i);
+        if (chunk_masks && chunk_masks[i]) has_mask = true;
+        total += chunk_lens[i];
+    }
+    if (out_has_mask) *out_has_mask = has_mask ? 1 : 0;
+    if (total == 0) return MA_OK;
+    MA_REQUIRE(out_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "out_bits is NULL");
+    MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    std::vector<ChunkDesc> data_desc(n_chunks), mask_desc(has_mask ? n_chunks : 0);
+    size_t row = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        ChunkDesc d{};
+        d.start = row;
+        d.len = chunk_lens[i];
+        ChunkDesc m = d;
+        if (d.len) {
+            MA_TRY(scope.in_mask(chunk_bits[i], chunk_bit_offsets ? chunk_bit_offsets[i] : 0, d.len, &d.words, &d.bit_off));
+            d.last_word = (d.bit_off + d.len - 1) >> 6;
+            if (has_mask && chunk_masks[i]) {
+                MA_TRY(scope.in_mask(chunk_masks[i], chunk_mask_offsets ? chunk_mask_offsets[i] : 0, m.len, &m.words,
+                                     &m.bit_off));
+                m.last_word = (m.bit_off + m.len - 1) >> 6;
+            }
+        }
+        data_desc[i] = d;
+        if (has_mask) mask_desc[i] = m;
+        row += chunk_lens[i];
+    }
+    const size_t n_words = (total + 63) >> 6;
+    const int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    DeviceDescs dd, md;
+    MA_TRY(dd.upload(data_desc, ctx->stream));
+    uint64_t* ow = nullptr;
+    MA_TRY(scope.out_mask(out_bits, total, &ow));
+    hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const ChunkDesc*)dd.p, (int)n_chunks,
+                       total, ow);
+    MA_HIP(hipGetLastError());
+    if (has_mask) {
+        MA_TRY(md.upload(mask_desc, ctx->stream));
+        uint64_t* mw = nullptr;
+        MA_TRY(scope.out_mask(out_mask, total, &mw));
+        hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const ChunkDesc*)md.p,
+                           (int)n_chunks, total, mw);
+        MA_HIP(hipGetLastError());
+    }
+    return end_call(ctx, scope);
+}

@@ -374,6 +374,24 @@ class Context:
             C.addressof(has)))
         return bool(has.value)
 
+    def consolidate_boolean_column(self, chunks, out_bits, masks=None, out_mask=None) -> bool:
+        """chunks: [(bits buffer, bit offset, len)]; masks: [(bits buffer, bit offset) or None]. Returns True when
+        out_mask was written (BooleanArray::append_range, src/structs/variants/boolean.rs:627-653)."""
+        k = len(chunks)
+        bits_arr = (C.c_void_p * k)(*[addr_of(c[0]) or None for c in chunks])
+        off_arr = (C.c_size_t * k)(*[int(c[1]) for c in chunks])
+        len_arr = (C.c_size_t * k)(*[int(c[2]) for c in chunks])
+        mask_arr = moff_arr = None
+        if masks is not None:
+            mask_arr = (C.c_void_p * k)(*[(addr_of(m[0]) if m is not None else None) for m in masks])
+            moff_arr = (C.c_size_t * k)(*[(int(m[1]) if m is not None else 0) for m in masks])
+        has = C.c_int32()
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        ffi.check(self.lib.ma_consolidate_boolean_column(self.handle, k, cast(bits_arr), cast(off_arr), cast(len_arr),
+                                                         cast(mask_arr), cast(moff_arr), addr_of(out_bits),
+                                                         addr_of(out_mask), C.addressof(has)))
+        return bool(has.value)
+
     def apply_datetime(self, tag: str, lhs, lhs_off: int, lhs_len: int, lhs_mask, rhs, rhs_off: int, rhs_len: int,
                        rhs_mask, op: int, out, out_mask) -> bool:
         """apply_datetime_<tag>((lhs, off, len), (rhs, off, len), op). Returns True when out_mask was written."""

@@ -1257,3 +1257,71 @@ MO_API int mo_consolidate_column(size_t elem_size, size_t n_chunks, const void* 
     }
     return has_nulls;
 }
+
+/* =================================================================================================
+ * Bit-packed column consolidation — Bitmask::extend_from_bitmask_range (src/structs/bitmask.rs:520-545) on top of
+ * Bitmask::extend_from_slice (:547-586), driven per chunk as BooleanArray::append_range does
+ * (src/structs/variants/boolean.rs:627-653) / Arena::write_boolean_slices (src/structs/arena.rs:391-430).
+ *  - source window not byte aligned: the bytes are first shifted down by (offset & 7) into a scratch run (:530-544);
+ *  - destination length byte aligned: whole source bytes are stored, then the tail bits are merged (:557-571);
+ *  - otherwise: one bit at a time (:573-584).
+ * `dst` must have room for ceil((dst_len + len) / 8) + 1 bytes; returns the new length in bits.
+ * ============================================================================================== */
+static size_t mo_extend_from_slice(uint8_t* dst, size_t dst_len, const uint8_t* src, size_t len) {
+    if ((dst_len & 7) == 0) {
+        size_t at = dst_len >> 3, full = len >> 3, tail = len & 7;
+        for (size_t i = 0; i < full; ++i) dst[at + i] = src[i];
+        if (tail) {
+            uint8_t keep = (uint8_t)((1u << tail) - 1u);
+            dst[at + full] = (uint8_t)((dst[at + full] & (uint8_t)~keep) | (src[full] & keep));
+        }
+    } else {
+        for (size_t i = 0; i < len; ++i) mo_set_bit(dst, dst_len + i, mo_get_bit(src, i));
+    }
+    /* mask_trailing_bits (bitmask.rs:83-90): bits past the new length in the last byte are zero */
+    size_t new_len = dst_len + len;
+    if (new_len & 7) dst[new_len >> 3] &= (uint8_t)((1u << (new_len & 7)) - 1u);
+    return new_len;
+}
+
+MO_API size_t mo_bitmask_extend_from_range(uint8_t* dst, size_t dst_len, const uint8_t* src, size_t src_bytes,
+                                           size_t offset, size_t len) {
+    if (len == 0) return dst_len;
+    if ((offset & 7) == 0) return mo_extend_from_slice(dst, dst_len, src + (offset >> 3), len);
+    size_t first = offset >> 3, shift = offset & 7;
+    size_t want = ((len + 7) >> 3) + 1;
+    size_t end = first + want < src_bytes ? first + want : src_bytes;
+    uint8_t* run = (uint8_t*)calloc(want + 1, 1);
+    for (size_t i = first; i < end; ++i) {
+        uint8_t lo = (uint8_t)(src[i] >> shift);
+        uint8_t hi = (i + 1 < src_bytes) ? (uint8_t)(src[i + 1] << (8 - shift)) : 0;
+        run[i - first] = (uint8_t)(lo | hi);
+    }
+    size_t r = mo_extend_from_slice(dst, dst_len, run, len);
+    free(run);
+    return r;
+}
+
+/* has_nulls rule as mo_consolidate_column. out_bits / out_mask: 8*ceil(total/64) + 8 zeroed bytes. */
+MO_API int mo_consolidate_boolean_column(size_t n_chunks, const uint8_t* const* chunk_bits, const size_t* chunk_bytes,
+                                         const size_t* chunk_bit_offsets, const size_t* chunk_lens,
+                                         const uint8_t* const* chunk_masks, const size_t* chunk_mask_bytes,
+                                         const size_t* chunk_mask_offsets, uint8_t* out_bits, uint8_t* out_mask) {
+    int has_nulls = 0;
+    for (size_t i = 0; i < n_chunks; ++i)
+        if (chunk_masks && chunk_masks[i]) has_nulls = 1;
+    size_t len = 0, mlen = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        len = mo_bitmask_extend_from_range(out_bits, len, chunk_bits[i], chunk_bytes[i],
+                                           chunk_bit_offsets ? chunk_bit_offsets[i] : 0, chunk_lens[i]);
+        if (!has_nulls) continue;
+        if (chunk_masks[i]) {
+            mlen = mo_bitmask_extend_from_range(out_mask, mlen, chunk_masks[i], chunk_mask_bytes[i],
+                                                chunk_mask_offsets ? chunk_mask_offsets[i] : 0, chunk_lens[i]);
+        } else { /* mask.resize(len + n, true) — boolean.rs:642-644, arena.rs:419 */
+            for (size_t k = 0; k < chunk_lens[i]; ++k) mo_set_bit(out_mask, mlen + k, 1);
+            mlen += chunk_lens[i];
+        }
+    }
+    return has_nulls;
+}

@@ -448,3 +448,31 @@ def consolidate_column(chunks, masks=None, mask_offsets=None):
                                   C.cast(mask_arr, C.c_void_p) if mask_arr is not None else None,
                                   C.cast(off_arr, C.c_void_p) if off_arr is not None else None, _p(out), _p(out_mask))
     return out, (out_mask if has else None)
+
+
+def consolidate_boolean_column(chunks, masks=None):
+    """chunks: [(bits uint8 array, bit offset, len)], masks: same shape or None entries.
+    Returns (data bits, validity bits or None), each 8*ceil(total/64) bytes — bitmask.rs:520-592,
+    boolean.rs:627-653."""
+    l = klib()
+    k = len(chunks)
+    total = sum(c[2] for c in chunks)
+    out = np.zeros(((total + 63) // 64) * 8 + 8, dtype=np.uint8)
+    out_mask = np.zeros_like(out)
+    arr = lambda vals, ty: (ty * k)(*vals)
+    bits_arr = arr([c[0].ctypes.data for c in chunks], C.c_void_p)
+    bytes_arr = arr([c[0].size for c in chunks], C.c_size_t)
+    off_arr = arr([c[1] for c in chunks], C.c_size_t)
+    len_arr = arr([c[2] for c in chunks], C.c_size_t)
+    if masks is None:
+        masks = [None] * k
+    m_arr = arr([(m[0].ctypes.data if m is not None else None) for m in masks], C.c_void_p)
+    mb_arr = arr([(m[0].size if m is not None else 0) for m in masks], C.c_size_t)
+    mo_arr = arr([(m[1] if m is not None else 0) for m in masks], C.c_size_t)
+    l.mo_consolidate_boolean_column.argtypes = [C.c_size_t] + [C.c_void_p] * 9
+    l.mo_consolidate_boolean_column.restype = C.c_int
+    cast = lambda a: C.cast(a, C.c_void_p)
+    has = l.mo_consolidate_boolean_column(k, cast(bits_arr), cast(bytes_arr), cast(off_arr), cast(len_arr), cast(m_arr),
+                                          cast(mb_arr), cast(mo_arr), _p(out), _p(out_mask))
+    nbytes = ((total + 63) // 64) * 8
+    return out[:nbytes], (out_mask[:nbytes] if has else None)

@@ -110,3 +110,94 @@ def test_config5_shape_consolidate_then_reduce(ctx):
     assert ctx.sum("i64", out, k * n)[0] == sum(n * (n - 1) // 2 + c * n for c in range(k))
     first = out.download(np.int64, 4, (3 * n) * 8)
     np.testing.assert_array_equal(first, np.arange(3, 7))
+
+
+# ---- bit-packed columns: ma_consolidate_boolean_column (BooleanArray data bits + validity) ----------------------
+
+def run_bool(ctx, chunks, masks=None, device=True):
+    total = sum(c[2] for c in chunks)
+    if device:
+        d_chunks = [(ctx.to_device(c[0], 16), c[1], c[2]) for c in chunks]
+        d_masks = [(ctx.to_device(m[0], 16), m[1]) if m is not None else None for m in masks] if masks is not None else None
+        out, om = ctx.alloc(nbytes(total) + 8), ctx.alloc(nbytes(total) + 8)
+        has = ctx.consolidate_boolean_column(d_chunks, out, d_masks, om)
+        return out.download(np.uint8, nbytes(total)), (om.download(np.uint8, nbytes(total)) if has else None)
+    out, om = np.zeros(nbytes(total) + 8, dtype=np.uint8), np.zeros(nbytes(total) + 8, dtype=np.uint8)
+    has = ctx.consolidate_boolean_column(chunks, out, masks, om)
+    return out[:nbytes(total)], (om[:nbytes(total)] if has else None)
+
+
+def _bits(oracle, bools):
+    return oracle.pack_bits(np.array(bools, dtype=bool)) if len(bools) else np.zeros(8, dtype=np.uint8)
+
+
+def test_ref_boolean_vectors(ctx, oracle):
+    b = KAT["boolean"]
+    for c in b["extend_from_slice"]["cases"]:
+        src = np.zeros(8, dtype=np.uint8)
+        src[: len(c["src_bytes"])] = c["src_bytes"]
+        out, mask = run_bool(ctx, [(_bits(oracle, c["start"]), 0, len(c["start"])), (src, 0, c["len"])])
+        assert mask is None and oracle.unpack_bits(out, len(c["expect"])).tolist() == c["expect"]
+    c = b["concat"]
+    for device in (True, False):
+        out, mask = run_bool(ctx, [(_bits(oracle, x), 0, len(x)) for x in c["chunks"]], device=device)
+        assert mask is None and oracle.unpack_bits(out, 5).tolist() == c["expect"]
+    c = b["concat_with_nulls"]
+    out, mask = run_bool(ctx, [(_bits(oracle, x), 0, len(x)) for x in c["chunks"]], [(_bits(oracle, v), 0) for v in c["validity"]])
+    data, valid = oracle.unpack_bits(out, 5), oracle.unpack_bits(mask, 5)
+    assert [bool(d) if ok else None for d, ok in zip(data, valid)] == c["expect_get"]
+    c = b["append_mask_onto_maskless"]
+    out, mask = run_bool(ctx, [(_bits(oracle, x), 0, len(x)) for x in c["chunks"]],
+                         [(_bits(oracle, v), 0) if v is not None else None for v in c["validity"]])
+    assert oracle.unpack_bits(out, 5).tolist() == c["expect_data"]
+    assert oracle.unpack_bits(mask, 5).tolist() == c["expect_validity"]
+
+
+@pytest.mark.parametrize("device", [True, False])
+def test_boolean_ragged_joins_match_oracle(ctx, oracle, device):
+    rng = np.random.default_rng(99)
+    for trial in range(12):
+        k = int(rng.integers(1, 9))
+        chunks, masks = [], []
+        for i in range(k):
+            n_bits = int(rng.choice([0, 1, 63, 64, 65, rng.integers(1, 5000), rng.integers(1, 200_000)]))
+            src = rng.integers(0, 256, size=((n_bits + 200) // 64 + 2) * 8, dtype=np.uint8)
+            off = int(rng.choice([0, 8, 64, rng.integers(0, 130)]))
+            chunks.append((src, off, n_bits))
+            if rng.random() < 0.5:
+                masks.append((rng.integers(0, 256, size=src.size, dtype=np.uint8), int(rng.integers(0, 130))))
+            else:
+                masks.append(None)
+        if sum(c[2] for c in chunks) == 0:
+            continue
+        want, want_mask = oracle.consolidate_boolean_column(chunks, masks)
+        out, mask = run_bool(ctx, chunks, masks, device=device)
+        np.testing.assert_array_equal(out, want)
+        assert (mask is None) == (want_mask is None)
+        if mask is not None:
+            np.testing.assert_array_equal(mask, want_mask)
+
+
+def test_boolean_large_column(ctx, oracle):
+    """8 chunks x 125 M bits joined at odd bit positions (a 10^9-row BooleanArray column), bit-exact vs the oracle."""
+    n = 125_000_003
+    src = ctx.alloc(nbytes(n + 128) + 8)
+    ctx.synth_validity(src, n + 128, seed=5, first_index=0, null_every=3)
+    chunks = [(src, 7 * i + 1, n - 11 * i) for i in range(8)]
+    total = sum(c[2] for c in chunks)
+    out = ctx.alloc(nbytes(total) + 8)
+    assert ctx.consolidate_boolean_column(chunks, out) is False
+    host_src = src.download(np.uint8, nbytes(n + 128) + 8)
+    want, _ = oracle.consolidate_boolean_column([(host_src, c[1], c[2]) for c in chunks])
+    got = out.download(np.uint8, nbytes(total))
+    assert np.array_equal(got, want)
+
+
+def test_boolean_errors(ctx):
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.consolidate_boolean_column([], None)
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "empty SuperTable" in e.value.message
+    bits = np.zeros(16, dtype=np.uint8)
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.consolidate_boolean_column([(bits, 0, 10)], np.zeros(16, dtype=np.uint8), [(bits, 0)], None)
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
