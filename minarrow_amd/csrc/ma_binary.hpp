@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
     constexpr int WPT = R * UNROLL;
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    // Masked integer Div/Rem/FloorDiv: the output validity depends on the data (a zero divisor nulls the row), so
+    // this kernel also produces the validity words instead of the mask-copy kernel.
+    constexpr bool DATA_VALIDITY = MASKED && std::is_integral<T>::value &&
+                                   (OP == MA_OP_DIVIDE || OP == MA_OP_REMAINDER || OP == MA_OP_FLOORDIV);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool dz = false;
 
@@ -216,16 +220,26 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
         for (int u = 0; u < UNROLL; ++u) {
             unsigned bits = ~0u;
             if constexpr (MASKED) bits = lane_bits<R>(aw, u, lane);
+            unsigned out_bits = bits;
             V r;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 T x = KIND == kSA ? a.scalar : (T)va[u][k];
                 T y = KIND == kAS ? a.scalar : (T)vb[u][k];
-                T v = Elem<T>::template apply<OP>(x, y, dz);
+                bool dzk = false;
+                T v = Elem<T>::template apply<OP>(x, y, dzk);
+                dz |= dzk;
                 if constexpr (MASKED) v = ((bits >> k) & 1u) ? v : (T)0;  // null slots hold 0 (simd.rs:315)
+                if constexpr (DATA_VALIDITY) out_bits &= ~((dzk ? 1u : 0u) << k);  // m & !div_zero (simd.rs:319-326)
                 r[k] = v;
             }
             store16<V, NTS>(o + (size_t)u * 64, r);
+            if constexpr (DATA_VALIDITY) {
+                // head == 0 here (host dispatch), so a step's 64*R rows are exactly R output validity words.
+                constexpr int LPW = 64 / R;
+                const uint64_t word = pack_lane_bits<R>(out_bits & ((1u << R) - 1u), lane);
+                if (lane % LPW == 0) a.out_words[(row0 >> 6) + (size_t)u * R + lane / LPW] = word;
+            }
         }
     }
     if constexpr (!MASKED && std::is_integral<T>::value &&
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(kBlock) void fma_vec_kernel(BinArgs<T> a) {
 
 // ------------------------------------------------------------------------------------------------
 // row kernel: one row per lane; a wave owns 64 consecutive rows = one validity word of the output.
-// Processes rows [0, head) and [tail_start, n) when ballot_mask == 0, or every row when ballot_mask == 1.
+// Processes rows [0, head) and [tail_start, n). With ballot_mask == 1 (masked integer Div/Rem/FloorDiv) head is 0 and
+// it also produces the output validity words of its rows by ballot (the vec kernel wrote the ones in front).
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool MASKED, bool FMA>
 __global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t tail_start) {
@@ -286,14 +301,14 @@ __global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t
     const size_t n_words = (a.n + 63) >> 6;
     // Only the words that hold ragged rows are visited: [0, head_words) and [tail_word0, n_words).
     const size_t head_words = a.ballot_mask ? 0 : (a.head + 63) >> 6;
-    size_t tail_word0 = a.ballot_mask ? 0 : tail_start >> 6;
+    size_t tail_word0 = tail_start >> 6;  // ballot mode: the vec kernel wrote the validity words in front of it
     if (tail_word0 < head_words) tail_word0 = head_words;
     const size_t n_visit = head_words + (n_words - tail_word0);
     bool dz_any = false;
     for (size_t k = wave_id; k < n_visit; k += n_waves) {
         const size_t w = k < head_words ? k : tail_word0 + (k - head_words);
         const size_t row = w * 64 + lane;
-        bool in_range = row < a.n && (a.ballot_mask || row < a.head || row >= tail_start);
+        bool in_range = row < a.n && (row < a.head || row >= tail_start);
         bool valid = in_range;
         bool dz = false;
         if (in_range) {
@@ -384,21 +399,14 @@ static void launch_vec_kind(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unro
 
 template <typename T, bool MASKED>
 static void launch_vec_op(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll, int kind, int op) {
-    constexpr bool kInt = std::is_integral<T>::value;
     switch (op) {
         case MA_OP_ADD: launch_vec_kind<T, MA_OP_ADD, MASKED>(ctx, a, grid, unroll, kind); break;
         case MA_OP_SUBTRACT: launch_vec_kind<T, MA_OP_SUBTRACT, MASKED>(ctx, a, grid, unroll, kind); break;
         case MA_OP_MULTIPLY: launch_vec_kind<T, MA_OP_MULTIPLY, MASKED>(ctx, a, grid, unroll, kind); break;
         case MA_OP_POWER: launch_vec_kind<T, MA_OP_POWER, MASKED>(ctx, a, grid, unroll, kind); break;
-        case MA_OP_DIVIDE:
-            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_DIVIDE, MASKED>(ctx, a, grid, unroll, kind);
-            break;
-        case MA_OP_REMAINDER:
-            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_REMAINDER, MASKED>(ctx, a, grid, unroll, kind);
-            break;
-        default:
-            if constexpr (!(kInt && MASKED)) launch_vec_kind<T, MA_OP_FLOORDIV, MASKED>(ctx, a, grid, unroll, kind);
-            break;
+        case MA_OP_DIVIDE: launch_vec_kind<T, MA_OP_DIVIDE, MASKED>(ctx, a, grid, unroll, kind); break;
+        case MA_OP_REMAINDER: launch_vec_kind<T, MA_OP_REMAINDER, MASKED>(ctx, a, grid, unroll, kind); break;
+        default: launch_vec_kind<T, MA_OP_FLOORDIV, MASKED>(ctx, a, grid, unroll, kind); break;
     }
 }
 
@@ -495,7 +503,9 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     }
     const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
     size_t head = 0, n_tiles = 0;
-    if (same_phase && !ballot) {
+    // Data-dependent validity: the vec kernel writes whole validity words, which needs row 0 on a 16-byte boundary
+    // (head == 0); otherwise the row kernel ballots over everything.
+    if (same_phase && !(ballot && phase != 0)) {
         head = phase ? (16 - phase) / sizeof(T) : 0;
         if (head > n) head = n;
         n_tiles = (n - head) / tile_rows;
@@ -503,7 +513,7 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     a.head = head;
     a.n_tiles = n_tiles;
     a.ballot_mask = ballot ? 1 : 0;
-    const size_t tail_start = ballot ? 0 : head + n_tiles * tile_rows;
+    const size_t tail_start = head + n_tiles * tile_rows;  // ballot mode: head == 0 and this is a multiple of 64
 
     if (masked && !ballot) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
     if (n_tiles) {
@@ -525,8 +535,8 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
         }
         MA_HIP(hipGetLastError());
     }
-    if (ballot || head > 0 || tail_start < n) {
-        size_t words_touched = ballot ? (n + 63) / 64 : ((head + 63) / 64 + (n - tail_start + 63) / 64 + 1);
+    if (head > 0 || tail_start < n) {
+        size_t words_touched = (head + 63) / 64 + (n - tail_start + 63) / 64 + 1;
         int grid = grid_for(ctx, (words_touched + kWaves - 1) / kWaves, 8);
         if (c.fma) {
             if constexpr (!kInt) {

@@ -154,19 +154,67 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned lo
     }
 }
 
-// simd_eq_mask_u{8,16,32,64} — bit j = ((data[j] & field_mask) == target): one ballot per 64 rows.
+// simd_eq_mask_u{8,16,32,64} — bit j = ((data[j] & field_mask) == target).
+// Vector path (16-byte aligned data): a lane loads 16 bytes = R rows, compares them in registers and the R result
+// bits of the 64/R lanes that share an output word are OR-ed together with a butterfly (pack_lane_bits); a wave
+// step covers 1 KiB of data and stores R words. Rows past the last full wave tile (and unaligned data) take the
+// one-ballot-per-64-rows path.
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict__ data, size_t n_tiles, T field_mask,
+                                                             T target, uint64_t* __restrict__ out) {
+    using V = typename Vec16<T>::type;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int LPW = 64 / R;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const V* __restrict__ vp = (const V*)data;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t step0 = (t * kWaves + wave) * UNROLL;  // index of this wave's first 1-KiB step
+        V x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) x[u] = load16<V, true>(vp + (step0 + u) * 64 + lane);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) bits |= ((T)((T)x[u][r] & field_mask) == target ? 1u : 0u) << r;
+            const uint64_t word = pack_lane_bits<R>(bits, lane);
+            if (lane % LPW == 0) out[(step0 + u) * R + lane / LPW] = word;
+        }
+    }
+}
+
 template <typename T>
-__global__ __launch_bounds__(kBlock) void eq_mask_kernel(const T* __restrict__ data, size_t n, T field_mask, T target,
-                                                         uint64_t* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void eq_mask_kernel(const T* __restrict__ data, size_t first_row, size_t n,
+                                                         T field_mask, T target, uint64_t* __restrict__ out) {
     const unsigned lane = threadIdx.x & 63;
     const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
     const size_t n_words = (n + 63) >> 6;
-    for (size_t w = wave_id; w < n_words; w += n_waves) {
+    for (size_t w = (first_row >> 6) + wave_id; w < n_words; w += n_waves) {
         size_t i = w * 64 + lane;
         bool hit = i < n && (T)(data[i] & field_mask) == target;
         unsigned long long word = __ballot(hit);
         if (lane == 0) out[w] = word;
+    }
+}
+
+template <typename T>
+static void launch_eq_mask(ma_ctx* ctx, const T* d, size_t n, T field_mask, T target, uint64_t* ow) {
+    constexpr int UNROLL = 4;
+    constexpr size_t kTileRows = (size_t)64 * (16 / sizeof(T)) * UNROLL * kWaves;
+    size_t done = 0;
+    if (((uintptr_t)d & 15) == 0 && n >= kTileRows) {
+        const size_t n_tiles = n / kTileRows;
+        int grid = grid_for(ctx, n_tiles, 8);
+        hipLaunchKernelGGL((eq_mask_vec_kernel<T, UNROLL>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_tiles,
+                           field_mask, target, ow);
+        done = n_tiles * kTileRows;  // a multiple of 64: the tail starts on a word
+    }
+    if (done < n) {
+        const size_t n_words = ((n - done) + 63) >> 6;
+        int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves, 8);
+        hipLaunchKernelGGL((eq_mask_kernel<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, done, n, field_mask, target,
+                           ow);
     }
 }
 
@@ -429,10 +477,7 @@ ma_status ma_merge_bitmasks_to_new(ma_ctx* ctx, const uint8_t* lhs_bits, const u
         MA_TRY(scope.in(data, n * sizeof(T), &d));                                                               \
         uint64_t* ow = nullptr;                                                                                  \
         MA_TRY(scope.out_mask(out_bits, n, &ow));                                                                \
-        const size_t n_words = (n + 63) >> 6;                                                                    \
-        int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves, 8);                                            \
-        hipLaunchKernelGGL((eq_mask_kernel<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const T*)d, n,         \
-                           field_mask, target, ow);                                                              \
+        launch_eq_mask<T>(ctx, (const T*)d, n, field_mask, target, ow);                                          \
         MA_HIP(hipGetLastError());                                                                               \
         return end_call(ctx, scope);                                                                             \
     }

@@ -50,8 +50,8 @@ __device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ 
 }
 
 // Copy tiles: every chunk is cut into tiles of TILE_ROWS rows counted from its first 16-byte aligned destination
-// row (tile 0 also takes the `head` rows in front of it). A full tile of a phase-matched chunk moves 16 bytes per
-// lane per access (the bandwidth path); partial tiles and phase-mismatched chunks move one row per lane.
+// row (tile 0 also takes the `head` rows in front of it). A full tile moves 16 bytes per lane per access (the
+// bandwidth path) whatever the source's byte phase; partial tiles move one row per lane.
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
                                                         size_t n_tiles, T* __restrict__ out) {
@@ -72,13 +72,18 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restr
             for (size_t i = threadIdx.x; i < d.head && i < d.len; i += kBlock) dst[i] = src[i];
         }
         if (r0 >= d.len) continue;
-        if (d.vec && r1 - r0 == TILE_ROWS) {
+        if (r1 - r0 == TILE_ROWS) {
+            // Stores are 16-byte aligned by construction of the tiles. The source shares that phase only when
+            // d.vec; otherwise the same global_load_dwordx4 is issued at an element-aligned address (gfx950 runs
+            // with unaligned access mode on under HSA; a lane's 16 bytes then straddle two 16-byte units, and a
+            // wave's 1 KiB one extra cache line).
+            typedef V VU __attribute__((aligned(1)));
             const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
-            const V* __restrict__ p = (const V*)(src + w0) + lane;
+            const VU* __restrict__ p = (const VU*)(src + w0) + lane;
             V* __restrict__ q = (V*)(dst + w0) + lane;
             V v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, true>(p + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) store16<V, true>(q + (size_t)u * 64, v[u]);
         } else {
@@ -87,39 +92,79 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restr
     }
 }
 
-// One thread per output validity word: pieces of up to 64 bits are pulled from the chunk bitmaps.
+// One output validity word starting at output row `row` (a multiple of 64): pieces of up to 64 bits are pulled from
+// the chunk bitmaps, starting the search at chunk `c`.
+__device__ __forceinline__ uint64_t gather_word(const ChunkDesc* __restrict__ chunks, int c, size_t row, size_t total) {
+    const size_t row_end = row + 64 < total ? row + 64 : total;
+    uint64_t word = 0;
+    unsigned filled = 0;
+    while (row < row_end) {
+        while (row >= chunks[c].start + chunks[c].len) ++c;
+        const size_t in_chunk = row - chunks[c].start;
+        size_t take = chunks[c].len - in_chunk;
+        if (take > row_end - row) take = row_end - row;
+        uint64_t piece;
+        if (chunks[c].words == nullptr) {
+            piece = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
+        } else {
+            const size_t b = chunks[c].bit_off + in_chunk;
+            const size_t w = b >> 6;
+            const unsigned sh = (unsigned)(b & 63);
+            uint64_t lo = chunks[c].words[w];
+            piece = lo >> sh;
+            if (sh && (w + 1) <= chunks[c].last_word) piece |= chunks[c].words[w + 1] << (64 - sh);
+        }
+        if (take < 64) piece &= (((uint64_t)1) << take) - 1;
+        word |= piece << filled;
+        filled += (unsigned)take;
+        row += take;
+    }
+    return word;  // bits >= total stay zero
+}
+
+// One thread per PAIR of output words (a 16-byte store). When the pair's 128 rows lie inside one chunk — all but
+// the few pairs at chunk joins — the two words are funnel-shifted out of three consecutive source words.
 __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
                                                              size_t total, uint64_t* __restrict__ out_words) {
+    typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
     const size_t n_words = (total + 63) >> 6;
+    const size_t n_pairs = (n_words + 1) >> 1;
     const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
-        size_t row = j << 6;
-        const size_t row_end = row + 64 < total ? row + 64 : total;
-        int c = find_chunk(chunks, n_chunks, row);
-        uint64_t word = 0;
-        unsigned filled = 0;
-        while (row < row_end) {
-            while (row >= chunks[c].start + chunks[c].len) ++c;
-            const size_t in_chunk = row - chunks[c].start;
-            size_t take = chunks[c].len - in_chunk;
-            if (take > row_end - row) take = row_end - row;
-            uint64_t piece;
-            if (chunks[c].words == nullptr) {
-                piece = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
+    const bool out16 = ((uintptr_t)out_words & 15) == 0;
+    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < n_pairs; p += stride) {
+        const size_t row = p << 7;
+        const int c = find_chunk(chunks, n_chunks, row);
+        const size_t c_start = chunks[c].start, c_len = chunks[c].len;
+        uint64_t w0, w1;
+        if (row + 128 <= c_start + c_len) {
+            const uint64_t* __restrict__ src = chunks[c].words;
+            if (src == nullptr) {
+                w0 = w1 = ~(uint64_t)0;
             } else {
-                const size_t b = chunks[c].bit_off + in_chunk;
-                const size_t w = b >> 6;
+                const size_t b = chunks[c].bit_off + (row - c_start);
+                const size_t w = b >> 6, last = chunks[c].last_word;
                 const unsigned sh = (unsigned)(b & 63);
-                uint64_t lo = chunks[c].words[w];
-                piece = lo >> sh;
-                if (sh && (w + 1) <= chunks[c].last_word) piece |= chunks[c].words[w + 1] << (64 - sh);
+                const uint64_t s0 = src[w];
+                const uint64_t s1 = src[w + 1];  // row + 64 is inside the chunk, so word w + 1 holds window bits
+                const uint64_t s2 = (sh && w + 2 <= last) ? src[w + 2] : 0;
+                w0 = sh ? (s0 >> sh) | (s1 << (64 - sh)) : s0;
+                w1 = sh ? (s1 >> sh) | (s2 << (64 - sh)) : s1;
             }
-            if (take < 64) piece &= (((uint64_t)1) << take) - 1;
-            word |= piece << filled;
-            filled += (unsigned)take;
-            row += take;
+        } else {
+            w0 = gather_word(chunks, c, row, total);
+            w1 = row + 64 < total ? gather_word(chunks, c, row + 64, total) : 0;
         }
-        out_words[j] = word;  // bits >= total stay zero
+        if (2 * p + 1 < n_words) {
+            if (out16) {
+                u2 v = {w0, w1};
+                *(u2*)(out_words + 2 * p) = v;
+            } else {
+                out_words[2 * p] = w0;
+                out_words[2 * p + 1] = w1;
+            }
+        } else {
+            out_words[2 * p] = w0;
+        }
     }
 }
 
@@ -228,8 +273,8 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     if (has_mask) {
         uint64_t* ow = nullptr;
         MA_TRY(scope.out_mask(out_mask, total, &ow));
-        const size_t n_words = (total + 63) >> 6;
-        int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+        const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
+        int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
         hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
         MA_HIP(hipGetLastError());
     }
@@ -311,8 +356,8 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
         if (has_mask) mask_desc[i] = m;
         row += chunk_lens[i];
     }
-    const size_t n_words = (total + 63) >> 6;
-    const int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
+    const int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
     DeviceDescs dd, md;
     MA_TRY(dd.upload(data_desc, ctx->stream));
     uint64_t* ow = nullptr;

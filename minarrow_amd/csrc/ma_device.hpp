@@ -106,6 +106,18 @@ __device__ __forceinline__ unsigned lane_bits(uint64_t run_word_of_lane, int u, 
     return (unsigned)(w >> ((lane % LPW) * R)) & ((1u << R) - 1u);
 }
 
+// The inverse of lane_bits: lane l holds R result bits for rows l*R .. l*R+R-1 of a 64*R-row step. Butterfly OR over
+// the 64/R lanes that share an output word; afterwards EVERY lane of such a group holds the finished word, and the
+// group's first lane (lane % (64/R) == 0) stores it as word lane / (64/R) of the step.
+template <int R>
+__device__ __forceinline__ uint64_t pack_lane_bits(unsigned bits, unsigned lane) {
+    constexpr int LPW = 64 / R;
+    uint64_t v = (uint64_t)bits << ((lane % LPW) * R);
+#pragma unroll
+    for (int s = 1; s < LPW; s <<= 1) v |= (uint64_t)__shfl_xor((unsigned long long)v, s, 64);
+    return v;
+}
+
 __device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
     return (unsigned)(((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
 }

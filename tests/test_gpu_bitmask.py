@@ -245,6 +245,16 @@ def test_simd_eq_mask_random(ctx, oracle, tag, dt):
         got = out.download(np.uint8, nbytes(n))
         np.testing.assert_array_equal(got, oracle.simd_eq_mask(data, 0x7, 0x3)[:nbytes(n)])
         np.testing.assert_array_equal(unpack(got, n), (data & 0x7) == 0x3)
+    # data that does not start on a 16-byte boundary (ballot path) and a host-resident column, > 1 vector tile
+    n = 300_001
+    data = rng.integers(0, 256, size=n + 1).astype(dt)
+    dev = ctx.to_device(data, 64)
+    out = ctx.alloc(nbytes(n) + 8)
+    ctx.simd_eq_mask(tag, dev.ptr + data.itemsize, n, 0xF, 0x9, out)
+    np.testing.assert_array_equal(unpack(out.download(np.uint8, nbytes(n)), n), (data[1:] & 0xF) == 0x9)
+    host_out = np.zeros(nbytes(n) + 8, dtype=np.uint8)
+    ctx.simd_eq_mask(tag, data[:n].copy(), n, 0xF, 0x9, host_out)
+    np.testing.assert_array_equal(unpack(host_out, n), (data[:n] & 0xF) == 0x9)
 
 
 def test_one_billion_bit_masks(ctx):

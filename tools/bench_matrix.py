@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Throughput of EVERY kernel family of the C ABI at HBM-bound sizes, one line each — the net that catches a slow
+outlier (a wrong grid, a row-at-a-time path taken by accident). Algorithmic bytes / HIP-event time on the launch
+stream, inputs resident in HBM. `--bytes` is the size of one operand column (default 4 GiB).
+
+    python tools/bench_matrix.py [--bytes 4294967296] [--reps 5] > profiles/rNN_matrix.jsonl
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+SIZE = {"i8": 1, "u8": 1, "i16": 2, "u16": 2, "i32": 4, "u32": 4, "f32": 4, "i64": 8, "u64": 8, "f64": 8}
+OP = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rem": 4, "pow": 5, "floordiv": 6}
+PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bytes", type=int, default=1 << 32)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    from minarrow_amd.host import Context
+
+    ctx = Context(0)
+    B = args.bytes
+    a, b, c, o = (ctx.alloc(B + 256) for _ in range(4))
+    n_bits_max = B  # one validity bit per row of the narrowest type
+    mask = ctx.alloc(n_bits_max // 8 + 64)
+    omask = ctx.alloc(n_bits_max // 8 + 64)
+    ctx.synth_validity(mask, n_bits_max, seed=7, null_every=10)
+    slot = ctx.alloc(256)
+
+    def emit(family, tag, variant, ms, nbytes, rows):
+        gbps = nbytes / ms / 1e6
+        print(json.dumps({"family": family, "type": tag, "variant": variant, "ms": round(ms, 4), "gbps": round(gbps, 1),
+                          "frac_of_8TBps": round(gbps / PEAK, 3), "grows_per_s": round(rows / ms / 1e6, 1)}), flush=True)
+
+    def timed(fn, sync=False):
+        fn()
+        fn()
+        ctx.synchronize()
+        ctx.timer_start()
+        for _ in range(args.reps):
+            fn()
+        ctx.timer_stop()
+        return ctx.timer_elapsed_ms() / args.reps
+
+    def want(name):
+        return not args.only or any(k in name for k in args.only.split(","))
+
+    def fill(tag):
+        """a = 1, 2, 3, ...; b = 3, 4, 5, ... in the widest generator that tiles the type (narrow types reinterpret)."""
+        n = B // SIZE[tag]
+        if tag in ("f64", "f32", "i32", "i64"):
+            ctx.synth_iota(tag, a, n, 1)
+            ctx.synth_iota(tag, b, n, 3)
+            ctx.synth_iota(tag, c, n, 5)
+        else:
+            ctx.synth_iota("i64", a, B // 8, 0x0102030405060708)
+            ctx.synth_iota("i64", b, B // 8, 0x0301070503010703)
+        return n
+
+    # ---- reductions ----
+    for tag in ("i64", "u64", "f64", "i32", "u32", "f32"):
+        if not want("sum"):
+            break
+        n = fill(tag)
+        ctx.set_async(True)
+        ms = timed(lambda: ctx.sum_into(tag, a, n, slot.ptr, slot.ptr + 64))
+        emit("sum", tag, "dense", ms, n * SIZE[tag], n)
+        ms = timed(lambda: ctx.sum_into(tag, a, n, slot.ptr, slot.ptr + 64, mask=mask))
+        emit("sum", tag, "masked 10% nulls", ms, n * SIZE[tag] + n / 8, n)
+        ms = timed(lambda: ctx.sum_into(tag, a, n - 64, slot.ptr, slot.ptr + 64, mask=mask, mask_bit_offset=13))
+        emit("sum", tag, "masked, validity at bit offset 13", ms, n * SIZE[tag] + n / 8, n)
+        ctx.set_async(False)
+        ctx.synchronize()
+
+    # ---- elementwise ----
+    for tag in SIZE:
+        if not want("apply"):
+            break
+        n = fill(tag)
+        sz = SIZE[tag]
+        is_float = tag in ("f32", "f64")
+        ctx.set_async(True)
+        for opname in ("add", "mul") + (("div",) if tag in ("f32", "f64", "i32", "i64") else ()):
+            ms = timed(lambda: ctx.apply(tag, a, b, OP[opname], o, n, n))
+            emit("apply a(op)b", tag, f"{opname} dense", ms, 3 * n * sz, n)
+        ms = timed(lambda: ctx.apply(tag, a, b, OP["add"], o, n, n, mask=mask, out_mask=omask))
+        emit("apply a(op)b", tag, "add masked", ms, 3 * n * sz + n / 4, n)
+        if not is_float:
+            ms = timed(lambda: ctx.apply(tag, a, b, OP["div"], o, n, n, mask=mask, out_mask=omask))
+            emit("apply a(op)b", tag, "div masked (validity from data)", ms, 3 * n * sz + n / 4, n)
+        ms = timed(lambda: ctx.apply_scalar(tag, "rhs", a, n, 3, OP["mul"], o))
+        emit("apply a(op)scalar", tag, "mul dense", ms, 2 * n * sz, n)
+        ms = timed(lambda: ctx.apply_scalar(tag, "lhs", a, n, 3, OP["sub"], o, mask=mask, out_mask=omask))
+        emit("apply scalar(op)a", tag, "sub masked", ms, 2 * n * sz + n / 4, n)
+        if tag in ("i64", "f64", "i32", "f32"):
+            ms = timed(lambda: ctx.apply_scalar(tag, "rhs", a, n, 3, OP["pow"], o))
+            emit("apply a(op)scalar", tag, "pow dense", ms, 2 * n * sz, n)
+            ms = timed(lambda: ctx.apply(tag, a, b, OP["floordiv"], o, n, n))
+            emit("apply a(op)b", tag, "floordiv dense", ms, 3 * n * sz, n)
+        if is_float:
+            ms = timed(lambda: ctx.apply_fma(tag, a, b, c, o, n, n, n))
+            emit("apply_fma", tag, "dense", ms, 4 * n * sz, n)
+            ms = timed(lambda: ctx.apply_fma(tag, a, b, c, o, n, n, n, mask=mask, out_mask=omask))
+            emit("apply_fma", tag, "masked", ms, 4 * n * sz + n / 4, n)
+        ctx.set_async(False)
+        ctx.synchronize()
+
+    # ---- promotions (Int32 x Float) ----
+    if want("promote"):
+        n = B // 8
+        ctx.synth_iota("i32", a, n, 1)
+        ctx.synth_iota("f64", b, n, 3)
+        ctx.set_async(True)
+        ms = timed(lambda: ctx.apply_promote("i32", "f64", a, b, OP["add"], o, n, n))
+        emit("apply_promote", "i32,f64", "add dense", ms, n * (4 + 8 + 8), n)
+        ms = timed(lambda: ctx.apply_promote("f64", "i32", b, a, OP["mul"], o, n, n, mask=mask, out_mask=omask))
+        emit("apply_promote", "f64,i32", "mul masked", ms, n * (4 + 8 + 8) + n / 4, n)
+        n = B // 4
+        ctx.synth_iota("f32", b, n, 3)
+        ctx.synth_iota("i32", a, n, 1)
+        ms = timed(lambda: ctx.apply_promote("i32", "f32", a, b, OP["add"], o, n, n))
+        emit("apply_promote", "i32,f32", "add dense", ms, n * 12, n)
+        ctx.set_async(False)
+        ctx.synchronize()
+
+    # ---- datetime (AND-merged masks + int kernel) ----
+    if want("datetime"):
+        n = B // 8
+        ctx.synth_iota("i64", a, n, 1)
+        ctx.synth_iota("i64", b, n, 3)
+        ms = timed(lambda: ctx.apply_datetime("i64", a, 0, n, mask, b, 0, n, mask, OP["add"], o, omask))
+        emit("apply_datetime", "i64", "add, both masked", ms, 3 * n * 8 + 3 * n / 8, n)
+
+    # ---- bitmask kernels ----
+    if want("bitmask"):
+        nb = min(B * 8, 1 << 36)  # bits
+        nb = min(nb, (B // 1) * 8)
+        bits = nb
+        # a, b as bitmaps of `bits` bits (already random-ish)
+        ctx.synth_iota("i64", a, B // 8, 0x0102030405060708)
+        ctx.synth_iota("i64", b, B // 8, 0x0301070503010703)
+        for name in ("and_masks", "or_masks", "xor_masks", "in_mask", "eq_mask"):
+            ms = timed(lambda: ctx.mask_words_op(name, a, 0, b, 0, bits, o))
+            emit("bitmask", "u64 words", name, ms, 3 * bits / 8, bits)
+        ms = timed(lambda: ctx.mask_words_op("and_masks", a, 8, b, 24, bits - 64, o))
+        emit("bitmask", "u64 words", "and_masks, byte offsets 1 and 3", ms, 3 * bits / 8, bits)
+        ms = timed(lambda: ctx.mask_unary_op("not_mask", a, 0, bits, o))
+        emit("bitmask", "u64 words", "not_mask", ms, 2 * bits / 8, bits)
+        ms = timed(lambda: ctx.mask_unary_op("bitmask_slice", a, 13, bits - 64, o))
+        emit("bitmask", "u64 words", "bitmask_slice (bit offset 13)", ms, 2 * bits / 8, bits)
+        ms = timed(lambda: ctx.popcount_mask(a, 0, bits))
+        emit("bitmask", "u64 words", "popcount_mask", ms, bits / 8, bits)
+        ms = timed(lambda: ctx.mask_all("all_eq", a, 0, a, 0, bits))
+        emit("bitmask", "u64 words", "all_eq (no early exit possible)", ms, 2 * bits / 8, bits)
+        ms = timed(lambda: ctx.merge_bitmasks(a, b, bits, o))
+        emit("bitmask", "u64 words", "merge_bitmasks_to_new", ms, 3 * bits / 8, bits)
+        for tag in ("u8", "u16", "u32", "u64"):
+            n = B // SIZE[tag]
+            ms = timed(lambda: ctx.simd_eq_mask(tag, a, n, 0x7, 0x3, o))
+            emit("simd_eq_mask", tag, "(data & 7) == 3", ms, B + n / 8, n)
+
+    # ---- consolidate ----
+    if want("consolidate"):
+        for sz in (1, 2, 4, 8):
+            n = (B // 2) // sz  # in + out fit the two buffers
+            k = 8
+            per = n // k
+            chunks = [a.ptr + i * per * sz for i in range(k)]
+            lens = [per - (i % 3) for i in range(k)]
+            masks = [mask.ptr + i * (per // 8 // 8 * 8) for i in range(k)]
+            offs = [i * 5 for i in range(k)]
+            ms = timed(lambda: ctx.consolidate_column(sz, chunks, lens, o))
+            emit("consolidate", f"{sz}-byte", "8 chunks, no validity", ms, 2 * sum(lens) * sz, sum(lens))
+            ms = timed(lambda: ctx.consolidate_column(sz, chunks, lens, o, masks, offs, omask))
+            emit("consolidate", f"{sz}-byte", "8 chunks + validity at odd bit offsets", ms, 2 * sum(lens) * sz + sum(lens) / 4, sum(lens))
+        bits = B * 4
+        per = bits // 8
+        chunks = [(a.ptr + i * (per // 64 * 8), 3 * i + 1, per - 200) for i in range(8)]
+        ms = timed(lambda: ctx.consolidate_boolean_column(chunks, o))
+        emit("consolidate_boolean", "bits", "8 chunks at odd bit offsets", ms, 2 * sum(c[2] for c in chunks) / 8, sum(c[2] for c in chunks))
+
+
+if __name__ == "__main__":
+    main()
