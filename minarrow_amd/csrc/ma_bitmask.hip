@@ -73,19 +73,47 @@ __device__ __forceinline__ uint64_t bit_op(int op, uint64_t x, uint64_t y) {
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+constexpr int kVecUnroll = 8;  // 16-byte accesses per operand a lane keeps in flight in the word-pair paths
+// Tile -> lane mapping of the word-pair paths, the one the elementwise kernels use: a wave owns kVecUnroll KiB of
+// consecutive pairs, lane l takes pair l of each KiB.
+__device__ __forceinline__ size_t pair_index(size_t tile, int u) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (tile * kWaves + wave) * ((size_t)kVecUnroll * 64) + (size_t)u * 64 + lane;
+}
 
 // `vec`: both windows start on a word (bit offset % 64 == 0) and every pointer is 16-byte aligned at the window's
 // first word, so two words move per lane per access (global_load/store_dwordx4, non-temporal).
-__global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a, int vec) {
+template <bool VEC>  // separate instantiations: the word-pair path's registers must not cost the scalar path its occupancy
+__global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     size_t first_scalar = 0;
-    if (vec) {
+    if constexpr (VEC) {
         const size_t n_pairs = (n_words - 1) >> 1;  // the last word (trailing-bit mask) always goes through the scalar path
         const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
         const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
         u64x2* __restrict__ op = (u64x2*)a.out;
-        for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs; j += stride) {
+        // Tiles of kVecUnroll * kBlock pairs: every lane issues its kVecUnroll loads per operand before the first use.
+        const size_t n_tiles = n_pairs / ((size_t)kVecUnroll * kBlock);
+        for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            u64x2 x[kVecUnroll], y[kVecUnroll];
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) x[u] = __builtin_nontemporal_load(lp + pair_index(t, u));
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) {
+                y[u] = u64x2{0, 0};
+                if (rp) y[u] = __builtin_nontemporal_load(rp + pair_index(t, u));
+            }
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) {
+                u64x2 r;
+                r.x = bit_op(a.op, x[u].x, y[u].x);
+                r.y = bit_op(a.op, x[u].y, y[u].y);
+                __builtin_nontemporal_store(r, op + pair_index(t, u));
+            }
+        }
+        for (size_t j = n_tiles * ((size_t)kVecUnroll * kBlock) + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs;
+             j += stride) {
             u64x2 x = __builtin_nontemporal_load(lp + j);
             u64x2 y = {0, 0};
             if (rp) y = __builtin_nontemporal_load(rp + j);
@@ -109,16 +137,35 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a, int vec) {
 // Scalar facts about one or two windows, accumulated into 4 device words:
 //   acc[0] += popcount(x)            acc[1] |= any bit set in x
 //   acc[2] |= any bit clear in x     acc[3] |= any bit where x != y
-__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc, int vec) {
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc) {
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned long long pop = 0, any_set = 0, any_clear = 0, any_diff = 0;
     size_t first_scalar = 0;
-    if (vec) {
+    if constexpr (VEC) {
         const size_t n_pairs = (n_words - 1) >> 1;
         const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
         const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
-        for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs; j += stride) {
+        const size_t n_tiles = n_pairs / ((size_t)kVecUnroll * kBlock);
+        for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            u64x2 x[kVecUnroll], y[kVecUnroll];
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) x[u] = __builtin_nontemporal_load(lp + pair_index(t, u));
+            if (rp) {
+#pragma unroll
+                for (int u = 0; u < kVecUnroll; ++u) y[u] = __builtin_nontemporal_load(rp + pair_index(t, u));
+            }
+#pragma unroll
+            for (int u = 0; u < kVecUnroll; ++u) {
+                pop += (unsigned long long)(__popcll(x[u].x) + __popcll(x[u].y));
+                any_set |= x[u].x | x[u].y;
+                any_clear |= ~(x[u].x & x[u].y);
+                if (rp) any_diff |= (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y);
+            }
+        }
+        for (size_t j = n_tiles * ((size_t)kVecUnroll * kBlock) + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs;
+             j += stride) {
             u64x2 x = __builtin_nontemporal_load(lp + j);
             pop += (unsigned long long)(__popcll(x.x) + __popcll(x.y));
             any_set |= x.x | x.y;
@@ -246,8 +293,11 @@ static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
     MA_HIP(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const size_t n_words = (a.n + 63) >> 6;
     const int vec = vec_ok(a, false);
-    int grid = grid_for(ctx, ((vec ? n_words / 2 : n_words) + kBlock - 1) / kBlock, 8);
-    hipLaunchKernelGGL(bit_scan_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc, vec);
+    // vec: read-only stream like the sums (2 workgroups per CU, 8 x 16 bytes per lane in flight)
+    int grid = vec ? grid_for(ctx, n_words / 2 / ((size_t)kVecUnroll * kBlock) + 1, 2)
+                   : grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    if (vec) hipLaunchKernelGGL(bit_scan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
+    else hipLaunchKernelGGL(bit_scan_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
     MA_HIP(hipGetLastError());
     MA_HIP(hipMemcpyAsync(out, acc, sizeof(BitScan), hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -257,8 +307,11 @@ static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
 static ma_status launch_words(ma_ctx* ctx, const BitArgs& a) {
     const size_t n_words = (a.n + 63) >> 6;
     const int vec = vec_ok(a, true);
-    int grid = grid_for(ctx, ((vec ? n_words / 2 : n_words) + kBlock - 1) / kBlock, 8);
-    hipLaunchKernelGGL(bit_words_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a, vec);
+    // vec: a store stream in the mix, the launch shape of the elementwise kernels (6 workgroups per CU)
+    int grid = vec ? grid_for(ctx, n_words / 2 / ((size_t)kVecUnroll * kBlock) + 1, 6)
+                   : grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
+    if (vec) hipLaunchKernelGGL(bit_words_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(bit_words_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }

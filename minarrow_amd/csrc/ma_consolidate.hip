@@ -29,16 +29,6 @@ struct ChunkDesc {
     unsigned vec;            // 1 when source and destination share their 16-byte phase (vector copy possible)
 };
 
-// Index of the chunk that contains output row `row` (row < total). Chunks of length 0 are skipped naturally.
-__device__ __forceinline__ int find_chunk(const ChunkDesc* __restrict__ c, int n_chunks, size_t row) {
-    int lo = 0, hi = n_chunks - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (c[mid].start <= row) lo = mid;
-        else hi = mid - 1;
-    }
-    return lo;
-}
 __device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ c, int n_chunks, size_t tile) {
     int lo = 0, hi = n_chunks - 1;
     while (lo < hi) {
@@ -92,27 +82,62 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restr
     }
 }
 
+// The part of a chunk descriptor the validity concat needs (40 bytes; up to kLdsChunks of them are staged in LDS so
+// that the per-pair binary search never leaves the CU).
+struct MaskDesc {
+    size_t start, len;
+    const uint64_t* words;
+    size_t bit_off, last_word;
+};
+constexpr int kLdsChunks = 256;
+
+template <bool LDS>
+struct DescTable {
+    const ChunkDesc* g;
+    const MaskDesc* s;
+    __device__ __forceinline__ MaskDesc get(int i) const {
+        if constexpr (LDS) return s[i];
+        const ChunkDesc& c = g[i];
+        return MaskDesc{c.start, c.len, c.words, c.bit_off, c.last_word};
+    }
+    __device__ __forceinline__ size_t start(int i) const {
+        if constexpr (LDS) return s[i].start;
+        return g[i].start;
+    }
+    // Index of the chunk that contains output row `row` (row < total).
+    __device__ __forceinline__ int find(int n_chunks, size_t row) const {
+        int lo = 0, hi = n_chunks - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (start(mid) <= row) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    }
+};
+
 // One output validity word starting at output row `row` (a multiple of 64): pieces of up to 64 bits are pulled from
 // the chunk bitmaps, starting the search at chunk `c`.
-__device__ __forceinline__ uint64_t gather_word(const ChunkDesc* __restrict__ chunks, int c, size_t row, size_t total) {
+template <bool LDS>
+__device__ __forceinline__ uint64_t gather_word(const DescTable<LDS>& tab, int c, size_t row, size_t total) {
     const size_t row_end = row + 64 < total ? row + 64 : total;
     uint64_t word = 0;
     unsigned filled = 0;
+    MaskDesc d = tab.get(c);
     while (row < row_end) {
-        while (row >= chunks[c].start + chunks[c].len) ++c;
-        const size_t in_chunk = row - chunks[c].start;
-        size_t take = chunks[c].len - in_chunk;
+        while (row >= d.start + d.len) d = tab.get(++c);
+        const size_t in_chunk = row - d.start;
+        size_t take = d.len - in_chunk;
         if (take > row_end - row) take = row_end - row;
         uint64_t piece;
-        if (chunks[c].words == nullptr) {
+        if (d.words == nullptr) {
             piece = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
         } else {
-            const size_t b = chunks[c].bit_off + in_chunk;
+            const size_t b = d.bit_off + in_chunk;
             const size_t w = b >> 6;
             const unsigned sh = (unsigned)(b & 63);
-            uint64_t lo = chunks[c].words[w];
-            piece = lo >> sh;
-            if (sh && (w + 1) <= chunks[c].last_word) piece |= chunks[c].words[w + 1] << (64 - sh);
+            piece = d.words[w] >> sh;
+            if (sh && (w + 1) <= d.last_word) piece |= d.words[w + 1] << (64 - sh);
         }
         if (take < 64) piece &= (((uint64_t)1) << take) - 1;
         word |= piece << filled;
@@ -124,35 +149,44 @@ __device__ __forceinline__ uint64_t gather_word(const ChunkDesc* __restrict__ ch
 
 // One thread per PAIR of output words (a 16-byte store). When the pair's 128 rows lie inside one chunk — all but
 // the few pairs at chunk joins — the two words are funnel-shifted out of three consecutive source words.
+template <bool LDS>
 __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
                                                              size_t total, uint64_t* __restrict__ out_words) {
     typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+    __shared__ MaskDesc staged[LDS ? kLdsChunks : 1];
+    if constexpr (LDS) {
+        for (int i = threadIdx.x; i < n_chunks; i += kBlock) {
+            const ChunkDesc& c = chunks[i];
+            staged[i] = MaskDesc{c.start, c.len, c.words, c.bit_off, c.last_word};
+        }
+        __syncthreads();
+    }
+    const DescTable<LDS> tab{chunks, staged};
     const size_t n_words = (total + 63) >> 6;
     const size_t n_pairs = (n_words + 1) >> 1;
     const size_t stride = (size_t)gridDim.x * kBlock;
     const bool out16 = ((uintptr_t)out_words & 15) == 0;
     for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < n_pairs; p += stride) {
         const size_t row = p << 7;
-        const int c = find_chunk(chunks, n_chunks, row);
-        const size_t c_start = chunks[c].start, c_len = chunks[c].len;
+        const int c = tab.find(n_chunks, row);
+        const MaskDesc d = tab.get(c);
         uint64_t w0, w1;
-        if (row + 128 <= c_start + c_len) {
-            const uint64_t* __restrict__ src = chunks[c].words;
-            if (src == nullptr) {
+        if (row + 128 <= d.start + d.len) {
+            if (d.words == nullptr) {
                 w0 = w1 = ~(uint64_t)0;
             } else {
-                const size_t b = chunks[c].bit_off + (row - c_start);
-                const size_t w = b >> 6, last = chunks[c].last_word;
+                const size_t b = d.bit_off + (row - d.start);
+                const size_t w = b >> 6;
                 const unsigned sh = (unsigned)(b & 63);
-                const uint64_t s0 = src[w];
-                const uint64_t s1 = src[w + 1];  // row + 64 is inside the chunk, so word w + 1 holds window bits
-                const uint64_t s2 = (sh && w + 2 <= last) ? src[w + 2] : 0;
+                const uint64_t s0 = d.words[w];
+                const uint64_t s1 = d.words[w + 1];  // row + 64 is inside the chunk: word w + 1 holds window bits
+                const uint64_t s2 = (sh && w + 2 <= d.last_word) ? d.words[w + 2] : 0;
                 w0 = sh ? (s0 >> sh) | (s1 << (64 - sh)) : s0;
                 w1 = sh ? (s1 >> sh) | (s2 << (64 - sh)) : s1;
             }
         } else {
-            w0 = gather_word(chunks, c, row, total);
-            w1 = row + 64 < total ? gather_word(chunks, c, row + 64, total) : 0;
+            w0 = gather_word<LDS>(tab, c, row, total);
+            w1 = row + 64 < total ? gather_word<LDS>(tab, c, row + 64, total) : 0;
         }
         if (2 * p + 1 < n_words) {
             if (out16) {
@@ -166,6 +200,15 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
             out_words[2 * p] = w0;
         }
     }
+}
+
+static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks, size_t total, uint64_t* ow) {
+    const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
+    const int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
+    if (n_chunks <= (size_t)kLdsChunks)
+        hipLaunchKernelGGL(concat_mask_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
+    else
+        hipLaunchKernelGGL(concat_mask_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
 }
 
 template <typename T>
@@ -273,9 +316,7 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     if (has_mask) {
         uint64_t* ow = nullptr;
         MA_TRY(scope.out_mask(out_mask, total, &ow));
-        const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
-        int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
-        hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
+        launch_concat_mask(ctx, d, n_chunks, total, ow);
         MA_HIP(hipGetLastError());
     }
     return end_call(ctx, scope);
@@ -356,21 +397,17 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
         if (has_mask) mask_desc[i] = m;
         row += chunk_lens[i];
     }
-    const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
-    const int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
     DeviceDescs dd, md;
     MA_TRY(dd.upload(data_desc, ctx->stream));
     uint64_t* ow = nullptr;
     MA_TRY(scope.out_mask(out_bits, total, &ow));
-    hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const ChunkDesc*)dd.p, (int)n_chunks,
-                       total, ow);
+    launch_concat_mask(ctx, (const ChunkDesc*)dd.p, n_chunks, total, ow);
     MA_HIP(hipGetLastError());
     if (has_mask) {
         MA_TRY(md.upload(mask_desc, ctx->stream));
         uint64_t* mw = nullptr;
         MA_TRY(scope.out_mask(out_mask, total, &mw));
-        hipLaunchKernelGGL(concat_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const ChunkDesc*)md.p,
-                           (int)n_chunks, total, mw);
+        launch_concat_mask(ctx, (const ChunkDesc*)md.p, n_chunks, total, mw);
         MA_HIP(hipGetLastError());
     }
     return end_call(ctx, scope);

@@ -89,6 +89,33 @@ def test_random_chunks(ctx, oracle, dt):
                 np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
 
 
+def test_many_small_chunks(ctx, oracle):
+    """700 chunks (more than the validity kernel stages in LDS), ragged lengths incl. empty ones, masks at odd bit
+    offsets on two thirds of them; values and validity vs the oracle; and the Boolean column twin."""
+    rng = np.random.default_rng(700)
+    lens = [int(x) for x in rng.choice([0, 1, 7, 63, 64, 65, 130, 500, 3000], size=700)]
+    chunks = [rng.integers(0, 1 << 30, size=n).astype(np.int32) for n in lens]
+    masks, offs = [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0:
+            masks.append(None)
+            offs.append(0)
+        else:
+            off = int(rng.integers(0, 100))
+            masks.append(rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8))
+            offs.append(off)
+    want, want_mask = oracle.consolidate_column(chunks, masks, offs)
+    out, mask = run(ctx, chunks, masks, offs)
+    np.testing.assert_array_equal(out, want)
+    np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
+    bchunks = [(rng.integers(0, 256, size=(n + 200) // 8 + 16, dtype=np.uint8), int(rng.integers(0, 100)), n) for n in lens]
+    bmasks = [(m, o) if m is not None else None for m, o in zip(masks, offs)]
+    want, want_mask = oracle.consolidate_boolean_column(bchunks, bmasks)
+    got, got_mask = run_bool(ctx, bchunks, bmasks)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_mask, want_mask)
+
+
 def test_config5_shape_consolidate_then_reduce(ctx):
     """8 chunks (one per GPU in config 5; here on one device, scaled to 8 x 2^24 rows), schema {i64 v = i + chunk,
     f64 v * 0.1} as in benches/consolidate.rs:37-58. The per-column reduce of the logically consolidated table
