@@ -35,7 +35,7 @@ namespace ma {
 enum class ArithmeticOperator : int32_t { Add = 0, Subtract, Multiply, Divide, Remainder, Power, FloorDiv };
 
 struct KernelError : std::runtime_error {
-    enum Kind { LengthMismatch, UnsupportedType, InvalidArguments, Device, NoDevice } kind;
+    enum Kind { LengthMismatch, UnsupportedType, InvalidArguments, Device, NoDevice, Broadcasting } kind;
     KernelError(Kind k, const std::string& what) : std::runtime_error(what), kind(k) {}
 };
 // The reference panics (it does not return Err) on dense integer ÷0; catch_unwind in its tests == catch here.

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "minarrow_hip.hpp"
+#include "minarrow_hip_routing.hpp"
 
 using namespace ma;
 using Op = ArithmeticOperator;
@@ -229,6 +230,132 @@ static void bench_sums() {  // benches/hotloop_benchmark_std.rs:45-57, N = 1000;
     }
 }
 
+// Routing / broadcast layer — the reference's enum-dispatch API (include/minarrow_hip_routing.hpp):
+//   src/kernels/broadcast/array.rs:485-556 (array (op) array, scalar expansion), :560-626 (array to table), :685-700
+//   src/kernels/broadcast/table.rs:431-566 (table (op) table / array / scalar, shape errors)
+//   src/kernels/routing/binary_map.rs:76-152 (f64 pairs, Int32 promotion), routing/arithmetic.rs:403-405
+static NumericArray i32s(std::initializer_list<int32_t> v) {
+    IntegerArray<int32_t> a;
+    a.data = Vec64<int32_t>(v);
+    return NumericArray::from_int32(std::move(a));
+}
+static NumericArray f64s(std::initializer_list<double> v) {
+    FloatArray<double> a;
+    a.data = Vec64<double>(v);
+    return NumericArray::from_float64(std::move(a));
+}
+static bool is_i32(const NumericArray& a, const std::vector<int32_t>& want) {
+    return a.try_i32_ref() != nullptr && a.try_i32_ref()->data == want;
+}
+static bool is_f64(const NumericArray& a, const std::vector<double>& want) {
+    return a.try_f64_ref() != nullptr && a.try_f64_ref()->data == want;
+}
+template <typename F>
+static bool kernel_error(KernelError::Kind kind, const char* needle, F f) {
+    try {
+        f();
+    } catch (const KernelError& e) {
+        return e.kind == kind && std::string(e.what()).find(needle) != std::string::npos;
+    }
+    return false;
+}
+static Table test_table(const char* name, std::initializer_list<int32_t> c1, std::initializer_list<int32_t> c2) {
+    Table t;  // create_test_table — table.rs:405-428
+    t.name = name;
+    t.cols.push_back({"col1", i32s(c1)});
+    t.cols.push_back({"col2", i32s(c2)});
+    return t;
+}
+
+static void routing_suite() {
+    std::printf("routing suite\n");
+    // test_broadcast_array_add / _scalar_expansion / _sub / _mul / _div — array.rs:485-556
+    ASSERT(is_i32(i32s({1, 2, 3}) + i32s({4, 5, 6}), {5, 7, 9}));
+    ASSERT(is_i32(i32s({1, 2, 3}) + i32s({10}), {11, 12, 13}));
+    ASSERT(is_i32(i32s({10}) + i32s({1, 2, 3}), {11, 12, 13}));
+    ASSERT(is_i32(i32s({10, 20, 30}) - i32s({1, 2, 3}), {9, 18, 27}));
+    ASSERT(is_i32(i32s({2, 3, 4}) * i32s({5, 6, 7}), {10, 18, 28}));
+    ASSERT(is_i32(i32s({100, 200, 300}) / i32s({10, 20, 30}), {10, 10, 10}));
+    // test_broadcast_array_to_scalar — array.rs:685-700
+    ASSERT(is_i32(broadcast_array_to_scalar(Op::Multiply, i32s({10, 20, 30}), Scalar(int32_t(2))), {20, 40, 60}));
+    ASSERT(is_i32(Scalar(int32_t(100)) - i32s({1, 2, 3}), {99, 98, 97}));
+    // binary_map.rs:76-152: f64 pairs, length-1 broadcast, Int32 promoted to Float64, array (op) scalar
+    ASSERT(is_f64(f64s({1.0, 2.0, 3.0}) + f64s({10.0, 20.0, 30.0}), {11.0, 22.0, 33.0}));
+    ASSERT(is_f64(f64s({1.0, 2.0, 3.0}) * f64s({10.0}), {10.0, 20.0, 30.0}));
+    ASSERT(is_f64(i32s({1, 2, 3}) + f64s({10.0, 20.0, 30.0}), {11.0, 22.0, 33.0}));
+    ASSERT(is_f64(f64s({10.0, 20.0, 30.0}) - i32s({1, 2, 3}), {9.0, 18.0, 27.0}));
+    ASSERT(is_f64(f64s({1.0, 2.0, 3.0}) + Scalar(10.0), {11.0, 12.0, 13.0}));
+    ASSERT(is_f64(i32s({1, 2, 3}) * Scalar(0.5), {0.5, 1.0, 1.5}));  // Int32 array (op) Float64 scalar promotes
+    {   // Int32 with Float32 -> Float32
+        FloatArray<float> f;
+        f.data = Vec64<float>{0.5f, 0.25f};
+        NumericArray r = i32s({1, 2}) + NumericArray::from_float32(std::move(f));
+        ASSERT((r.type() == NumericType::Float32 && r.try_f32_ref()->data == std::vector<float>{1.5f, 2.25f}));
+    }
+    // routing/broadcast.rs:109-111 and routing/arithmetic.rs:403-405
+    ASSERT(kernel_error(KernelError::LengthMismatch, "cannot broadcast arrays of length 3 and 2",
+                        [] { (void)(i32s({1, 2, 3}) + i32s({1, 2})); }));
+    {
+        IntegerArray<int64_t> l;
+        l.data = Vec64<int64_t>{1, 2, 3};
+        NumericArray i64 = NumericArray::from_int64(std::move(l));
+        ASSERT(kernel_error(KernelError::UnsupportedType, "Unsupported array type combination",
+                            [&] { (void)(i64 + f64s({1.0, 2.0, 3.0})); }));
+        ASSERT(kernel_error(KernelError::UnsupportedType, "Unsupported array type combination",
+                            [&] { (void)(i64 + Scalar(1.0)); }));  // the scalar keeps its own type (array.rs:146-163)
+        ASSERT(kernel_error(KernelError::UnsupportedType, "Unsupported array type combination",
+                            [&] { (void)(i64 + i32s({1, 2, 3})); }));
+    }
+    {   // views are sliced [offset, offset + len) (routing/arithmetic.rs:273-285); the caller's mask gates from bit 0
+        NumericArray a = i32s({1, 2, 3, 4, 5, 6}), b = i32s({10, 20, 30, 40, 50, 60});
+        NumericArray r = resolve_binary_arithmetic(Op::Add, NumericArrayV(a, 1, 3), NumericArrayV(b, 2, 3));
+        ASSERT(is_i32(r, {32, 43, 54}));
+        Bitmask m = Bitmask::from_bools({true, false, true});
+        r = resolve_binary_arithmetic(Op::Add, NumericArrayV(a, 1, 3), NumericArrayV(b, 2, 3), &m);
+        ASSERT(is_i32(r, {32, 0, 54}));
+        ASSERT(r.null_mask().has_value() && r.null_mask()->get(0) && !r.null_mask()->get(1) && r.null_mask()->get(2));
+        // a length-1 VIEW broadcasts data[0], not data[offset] (broadcast_length_1_array: `a.data[0]`)
+        r = resolve_binary_arithmetic(Op::Add, NumericArrayV(a, 0, 3), NumericArrayV(b, 4, 1));
+        ASSERT(is_i32(r, {11, 12, 13}));
+        // aggregates over a view use the array's own validity at the view offset (guarantee_f64 hand-off)
+        IntegerArray<int64_t> wm;
+        wm.data = Vec64<int64_t>{1, 2, 3, 4, 5, 6, 7, 8};
+        wm.null_mask = Bitmask::from_bools({true, true, false, true, false, true, true, true});
+        NumericArray w = NumericArray::from_int64(std::move(wm));
+        Aggregate g = sum(NumericArrayV(w, 1, 5));  // rows 2,3,4,5,6 -> valid 2,4,6
+        ASSERT(g.sum == 12.0 && g.valid_count == 3 && g.mean() == 4.0);
+        g = sum(NumericArrayV(f64s({0.5, 1.5, 2.0})));
+        ASSERT(g.sum == 4.0 && g.valid_count == 3);
+    }
+    // test_table_plus_table / multiply / to_array / to_scalar / shape errors — table.rs:431-566
+    {
+        Table r = broadcast_table_add(test_table("table1", {1, 2, 3}, {10, 20, 30}), test_table("table2", {4, 5, 6}, {40, 50, 60}));
+        ASSERT(r.n_cols() == 2 && r.n_rows() == 3 && r.name == "table1");
+        ASSERT(is_i32(r.cols[0].array, {5, 7, 9}) && is_i32(r.cols[1].array, {50, 70, 90}));
+        ASSERT(r.cols[0].name == "col1" && r.cols[1].name == "col2");
+        r = broadcast_table_with_operator(Op::Multiply, test_table("table1", {2, 3, 4}, {5, 6, 7}), test_table("table2", {10, 10, 10}, {2, 2, 2}));
+        ASSERT(is_i32(r.cols[0].array, {20, 30, 40}) && is_i32(r.cols[1].array, {10, 12, 14}));
+        r = broadcast_table_to_array(Op::Add, test_table("table1", {10, 20, 30}, {100, 200, 300}), i32s({1, 2, 3}));
+        ASSERT(is_i32(r.cols[0].array, {11, 22, 33}) && is_i32(r.cols[1].array, {101, 202, 303}));
+        r = broadcast_table_to_scalar(Op::Multiply, test_table("table1", {10, 20, 30}, {100, 200, 300}), Scalar(int32_t(5)));
+        ASSERT(is_i32(r.cols[0].array, {50, 100, 150}) && is_i32(r.cols[1].array, {500, 1000, 1500}));
+        // test_broadcast_array_to_table(_multiply) — array.rs:560-626
+        r = broadcast_array_to_table(Op::Add, i32s({1, 2, 3}), test_table("test", {10, 20, 30}, {100, 200, 300}));
+        ASSERT(is_i32(r.cols[0].array, {11, 22, 33}) && is_i32(r.cols[1].array, {101, 202, 303}));
+        Table one;
+        one.name = "table1";
+        one.cols.push_back({"col1", i32s({1, 2, 3})});
+        ASSERT(kernel_error(KernelError::Broadcasting, "column count mismatch",
+                            [&] { (void)broadcast_table_add(one, test_table("table2", {4, 5, 6}, {40, 50, 60})); }));
+        ASSERT(kernel_error(KernelError::Broadcasting, "row count mismatch", [&] {
+            (void)broadcast_table_add(test_table("table1", {1, 2}, {10, 20}), test_table("table2", {4, 5, 6}, {40, 50, 60}));
+        }));
+        ASSERT(kernel_error(KernelError::Broadcasting, "Table column count mismatch: 1 vs 2", [&] {
+            (void)broadcast_table_with_operator(Op::Add, one, test_table("table2", {4, 5, 6}, {40, 50, 60}));
+        }));
+    }
+}
+
 int main() {
     try {
         int_kernel_suite<int32_t>("i32", [](Slice<int32_t> l, Slice<int32_t> r, Op op, const Bitmask* m) { return apply_int_i32(l, r, op, m); });
@@ -243,6 +370,7 @@ int main() {
         int_power_short_vs_long();
         for (size_t lanes : {(size_t)8, (size_t)16, (size_t)32, (size_t)64}) simd_bitmask_suite(lanes);
         bench_sums();
+        routing_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
