@@ -189,6 +189,18 @@ ma_status ma_f64_mean(ma_ctx* ctx, const double* data, size_t n, const uint8_t* 
 ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                       int64_t null_count, double* out_mean, uint64_t* out_valid_count);
 
+/* Per-column {sum, valid count} of n_cols columns of ONE element type in two launches, whatever n_cols is — the
+ * per-column reduce of a wide Table or of the chunks of a SuperTable (BASELINE config 5). A launch costs ~4 us on
+ * MI355X, so the column-at-a-time loop of the reference (one pass per Array, benches/hotloop_benchmark_std.rs:109-127)
+ * is launch-bound for many small columns. format_code as in Arrow ('i','I','l','L','f','g'); column i =
+ * (col_data[i], col_lens[i]) with optional validity col_masks[i] whose row 0 is bit col_mask_offsets[i] (both
+ * tables may be NULL). Outputs are arrays of n_cols entries, any may be NULL: integer formats write the wrapping
+ * 64-bit sum to out_sums_i64 and its conversion to out_sums_f64; float formats write out_sums_f64 only (within 1 ULP
+ * of the exactly rounded sum, as ma_f64_sum). An empty column yields {0, 0}. The call is synchronous. */
+ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
+                         const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
+                         double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise arithmetic — same names, argument order and meaning as the reference's L3 functions:
  *   apply_int_{i32,u32,i64,u64}(lhs, rhs, op, mask) -> Result<IntegerArray<T>, KernelError>
@@ -341,6 +353,26 @@ ma_status ma_simd_eq_mask_u32(ma_ctx* ctx, const uint32_t* data, size_t n, uint3
                               uint8_t* out_bits);
 ma_status ma_simd_eq_mask_u64(ma_ctx* ctx, const uint64_t* data, size_t n, uint64_t field_mask, uint64_t target,
                               uint8_t* out_bits);
+
+/* ------------------------------------------------------------------------------------------------
+ * hipGraph capture — launch-bound loops (many small columns, the shape of the reference's 1000-row hot-loop
+ * benches, benches/hotloop_benchmark_avg_simd.rs:205-208) pay one graph launch instead of one kernel launch per call.
+ * Between ma_ctx_capture_begin and ma_ctx_capture_end every call on this context is RECORDED instead of executed
+ * (the context is in async mode for the duration): reductions / means into device-reachable outputs, ma_apply_*,
+ * ma_apply_fma_*, ma_apply_promote_*, ma_apply_datetime_*, the bitmask word ops (and/or/xor/not/slice/eq/ne/in with
+ * a non-constant rhs), ma_simd_eq_mask_*, ma_dev_memset and the synth generators. Every buffer must be
+ * device-reachable (device or pinned); calls that have to synchronise with the host — scans returning a value
+ * (popcount, all_*), staging of pageable memory, consolidation, the Arrow export / stream entry points, allocation,
+ * timers — fail with MA_ERR_INVALID_ARGUMENT and leave the capture intact. ma_graph_launch replays the recorded work on the context's
+ * stream against the SAME addresses (refill the buffers, replay); in sync mode it waits and reports a dense
+ * integer division by zero like the eager call, in async mode that is reported by the next ma_ctx_synchronize.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ma_graph ma_graph;
+ma_status ma_ctx_capture_begin(ma_ctx* ctx);
+ma_status ma_ctx_capture_end(ma_ctx* ctx, ma_graph** out_graph);
+ma_status ma_graph_launch(ma_ctx* ctx, ma_graph* graph);
+ma_status ma_graph_node_count(const ma_graph* graph, size_t* out_nodes);
+void ma_graph_destroy(ma_graph* graph);
 
 /* ------------------------------------------------------------------------------------------------
  * Arrow C Data Interface — the reference's only pre-existing C surface (src/ffi/arrow_c_ffi.rs:

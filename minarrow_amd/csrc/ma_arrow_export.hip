@@ -179,6 +179,7 @@ ma_status ma_apply_arrow_export(ma_ctx* ctx, int32_t op, const struct ArrowArray
                                 struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(out_array != nullptr && out_schema != nullptr, MA_ERR_INVALID_ARGUMENT, "output struct is NULL");
+    MA_NO_CAPTURE(ctx, "ma_apply_arrow_export");
     out_array->release = nullptr;
     out_schema->release = nullptr;
     return export_one(ctx, op, lhs, lhs_schema, rhs, rhs_schema, name ? name : (lhs_schema ? lhs_schema->name : nullptr),
@@ -195,6 +196,7 @@ ma_status ma_apply_arrow_batch_export(ma_ctx* ctx, int32_t op, const struct Arro
                                       struct ArrowSchema* out_schema) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(out_batch != nullptr && out_schema != nullptr, MA_ERR_INVALID_ARGUMENT, "output struct is NULL");
+    MA_NO_CAPTURE(ctx, "ma_apply_arrow_batch_export");
     out_batch->release = nullptr;
     out_schema->release = nullptr;
     MA_TRY(check_struct(lhs_batch, lhs_schema, "lhs"));

@@ -289,6 +289,7 @@ static int vec_ok(const BitArgs& a, bool with_out) {
 }
 
 static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
+    MA_NO_CAPTURE(ctx, "a bitmap scan that returns its result to the host");
     unsigned long long* acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 inside the 256-byte scratch line set
     MA_HIP(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const size_t n_words = (a.n + 63) >> 6;
@@ -345,6 +346,7 @@ static ma_status words_op(ma_ctx* ctx, int op, const uint8_t* lhs, size_t lo, co
 static ma_status fill_bits(ma_ctx* ctx, uint8_t* out_bits, size_t len, bool value) {
     // Bitmask::new_set_all(len, value) — src/structs/bitmask.rs:94-105
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "a constant bitmap fill");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     uint64_t* ow = nullptr;

@@ -81,7 +81,14 @@ struct ma_ctx {
     hipEvent_t ev_start = nullptr;
     hipEvent_t ev_stop = nullptr;
     bool pending_flags = false;        // async mode: dev_flags must be inspected at the next synchronize
+    bool capturing = false;            // between ma_ctx_capture_begin / _end: calls are recorded into a hipGraph
+    bool async_before_capture = false;
 };
+
+// Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
+#define MA_NO_CAPTURE(ctx, what)                                                                        \
+    MA_REQUIRE(!(ctx)->capturing, MA_ERR_INVALID_ARGUMENT,                                              \
+               "%s cannot be recorded into a graph: it synchronises with the host (use it outside capture)", what)
 
 namespace ma {
 

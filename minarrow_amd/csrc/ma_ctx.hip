@@ -79,6 +79,7 @@ ma_status CallScope::in(const void* p, size_t bytes, const void** out) {
     *out = p;
     if (bytes == 0 || p == nullptr) return MA_OK;
     if (pointer_kind(p) != kPageable) return MA_OK;
+    MA_NO_CAPTURE(ctx_, "staging a pageable host input");
     void* d = nullptr;
     MA_HIP(hipMalloc(&d, bytes));
     temps_.push_back({d, nullptr, bytes});
@@ -91,6 +92,7 @@ ma_status CallScope::out(void* p, size_t bytes, void** out) {
     *out = p;
     if (bytes == 0 || p == nullptr) return MA_OK;
     if (pointer_kind(p) != kPageable) return MA_OK;
+    MA_NO_CAPTURE(ctx_, "staging a pageable host output");
     void* d = nullptr;
     MA_HIP(hipMalloc(&d, bytes));
     temps_.push_back({d, p, bytes});
@@ -113,6 +115,7 @@ ma_status CallScope::in_mask(const uint8_t* bits, size_t bit_offset, size_t len_
         return MA_OK;
     }
     // Pageable: copy exactly the bytes that hold the window into a zero-padded word buffer.
+    MA_NO_CAPTURE(ctx_, "staging a pageable host bitmap");
     size_t first_byte = bit_offset >> 3;
     size_t end_byte = (bit_offset + len_bits + 7) >> 3;
     size_t nbytes = end_byte - first_byte;
@@ -338,6 +341,7 @@ void ma_ctx_destroy(ma_ctx* ctx) {
 ma_status ma_ctx_synchronize(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_ctx_synchronize");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->pending_flags) {
@@ -358,8 +362,98 @@ ma_status ma_ctx_synchronize(ma_ctx* ctx) {
 ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->capturing) {  // takes effect when the capture ends
+        ctx->async_before_capture = enabled != 0;
+        return MA_OK;
+    }
     ctx->async = enabled != 0;
     return MA_OK;
+}
+
+// ---- hipGraph capture -----------------------------------------------------------------------------
+}  // extern "C"
+
+struct ma_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int device = 0;
+    size_t nodes = 0;
+    bool may_latch = false;  // a dense integer Div/Rem/FloorDiv was recorded: dev_flags must be inspected after a replay
+};
+
+extern "C" {
+
+ma_status ma_ctx_capture_begin(ma_ctx* ctx) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_REQUIRE(!ctx->capturing, MA_ERR_INVALID_ARGUMENT, "a capture is already in progress on this context");
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    // Relaxed: the library's own pointer classification (hipPointerGetAttributes) stays legal while recording.
+    MA_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    ctx->capturing = true;
+    ctx->async_before_capture = ctx->async;
+    ctx->async = true;
+    ctx->pending_flags = false;
+    return MA_OK;
+}
+
+ma_status ma_ctx_capture_end(ma_ctx* ctx, ma_graph** out_graph) {
+    MA_REQUIRE(ctx != nullptr && out_graph != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_graph is NULL");
+    *out_graph = nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_REQUIRE(ctx->capturing, MA_ERR_INVALID_ARGUMENT, "no capture in progress on this context");
+    MA_HIP(hipSetDevice(ctx->device));
+    ctx->capturing = false;
+    ctx->async = ctx->async_before_capture;
+    const bool may_latch = ctx->pending_flags;
+    ctx->pending_flags = false;  // nothing has executed yet
+    hipGraph_t g = nullptr;
+    MA_HIP(hipStreamEndCapture(ctx->stream, &g));
+    MA_REQUIRE(g != nullptr, MA_ERR_DEVICE, "hipStreamEndCapture returned no graph (the capture was invalidated)");
+    ma_graph* out = new ma_graph();
+    out->graph = g;
+    out->device = ctx->device;
+    out->may_latch = may_latch;
+    hipError_t e = hipGraphGetNodes(g, nullptr, &out->nodes);
+    if (e == hipSuccess) e = hipGraphInstantiate(&out->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        delete out;
+        return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    *out_graph = out;
+    return MA_OK;
+}
+
+ma_status ma_graph_launch(ma_ctx* ctx, ma_graph* graph) {
+    MA_REQUIRE(ctx != nullptr && graph != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or graph is NULL");
+    MA_REQUIRE(graph->device == ctx->device, MA_ERR_INVALID_ARGUMENT, "the graph was recorded on device %d, this context is on %d",
+               graph->device, ctx->device);
+    bool wait = false;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        MA_NO_CAPTURE(ctx, "ma_graph_launch");
+        MA_HIP(hipSetDevice(ctx->device));
+        MA_HIP(hipGraphLaunch(graph->exec, ctx->stream));
+        if (graph->may_latch) ctx->pending_flags = true;
+        wait = !ctx->async;
+    }
+    return wait ? ma_ctx_synchronize(ctx) : MA_OK;
+}
+
+ma_status ma_graph_node_count(const ma_graph* graph, size_t* out_nodes) {
+    MA_REQUIRE(graph != nullptr && out_nodes != nullptr, MA_ERR_INVALID_ARGUMENT, "graph or out_nodes is NULL");
+    *out_nodes = graph->nodes;
+    return MA_OK;
+}
+
+void ma_graph_destroy(ma_graph* graph) {
+    if (!graph) return;
+    (void)hipSetDevice(graph->device);
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
 }
 
 void* ma_ctx_stream(ma_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -393,6 +487,7 @@ ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant) {
 ma_status ma_ctx_timer_start(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_ctx_timer_start");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     return MA_OK;
@@ -401,6 +496,7 @@ ma_status ma_ctx_timer_start(ma_ctx* ctx) {
 ma_status ma_ctx_timer_stop(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_ctx_timer_stop");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
     return MA_OK;
@@ -409,6 +505,7 @@ ma_status ma_ctx_timer_stop(ma_ctx* ctx) {
 ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms) {
     MA_REQUIRE(ctx != nullptr && out_ms != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_ms is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_ctx_timer_elapsed_ms");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventSynchronize(ctx->ev_stop));
     MA_HIP(hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
@@ -441,6 +538,7 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_dev_alloc");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMalloc(out_dev_ptr, bytes == 0 ? 64 : bytes));
     return MA_OK;
@@ -450,6 +548,7 @@ ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (!dev_ptr) return MA_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_dev_free");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));
     g_free_generation.fetch_add(1, std::memory_order_relaxed);
@@ -462,6 +561,7 @@ ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t
     if (bytes == 0) return MA_OK;
     MA_REQUIRE(dst_dev && src_host, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_dev_upload");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -473,6 +573,7 @@ ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size
     if (bytes == 0) return MA_OK;
     MA_REQUIRE(dst_host && src_dev, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_dev_download");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));

@@ -31,6 +31,7 @@ ma_status group_run(ma_group* g, const size_t* lens, Launch launch) {
     const size_t n = g->ctxs.size();
     std::vector<int> was_async(n);
     ma_status st = MA_OK;
+    for (size_t i = 0; i < n; ++i) MA_NO_CAPTURE(g->ctxs[i], "a group reduction");
     for (size_t i = 0; i < n; ++i) {
         {
             std::lock_guard<std::mutex> lock(g->ctxs[i]->mu);

@@ -1,0 +1,278 @@
+// Per-column sums of MANY columns in two launches — the "per-column reduce" of a wide or chunked table
+// (BASELINE config 5; the reference sums column by column, one loop per Array: benches/hotloop_benchmark_std.rs:
+// 109-127 through the enum, src/structs/chunked/super_table.rs columns). One kernel launch per column costs ~4 us of
+// dispatch on MI355X whatever its size (profiles/r01_graph.json), so a 1000-column table of 1000-row columns is
+// launch-bound by three orders of magnitude; here the launch count is independent of the column count.
+//
+//   pass 1  every column is cut into segments of kSegRows rows; one workgroup reduces one segment at a time
+//           (16-byte loads, validity words per wave run — the body of ma_reduce.hip's sum_kernel) and stores a
+//           32-byte partial per segment;
+//   pass 2  one wave per column folds that column's partials in index order and writes {sum, count}.
+// Same accumulators as the single-column kernel (wrapping u64 / double-double), so integer results are bit-exact and
+// float results within 1 ULP of the exactly rounded sum, independent of the segmentation.
+#include <vector>
+
+#include "ma_acc.hpp"
+#include "ma_device.hpp"
+
+namespace ma {
+
+struct ColDesc {
+    const void* data;       // first element of the column window
+    size_t len;             // rows
+    const uint64_t* words;  // validity words (8-byte aligned base) or nullptr = dense
+    size_t bit_off;         // bit index of row 0 relative to `words`
+    size_t last_word;       // last word index holding a window bit
+    size_t seg0;            // index of this column's first segment (prefix sum)
+};
+
+constexpr size_t kSegRows = (size_t)1 << 16;  // rows per segment: 512 KiB of 8-byte values
+
+__device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_cols, size_t seg) {
+    int lo = 0, hi = n_cols - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (c[mid].seg0 <= seg) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* __restrict__ cols, int n_cols,
+                                                                 size_t n_segs, Partial* __restrict__ partials) {
+    typedef typename Vec16<T>::type V;
+    typedef typename AccOf<T>::type Acc;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int WPT = R * UNROLL;
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ Partial lds[kWaves];
+
+    for (size_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
+        const int c = find_col(cols, n_cols, seg);  // workgroup-uniform
+        const ColDesc d = cols[c];
+        const size_t r_begin = (seg - d.seg0) * kSegRows;
+        const size_t r_end = r_begin + kSegRows < d.len ? r_begin + kSegRows : d.len;
+        const T* __restrict__ data = (const T*)d.data;
+        const bool masked = d.words != nullptr;
+
+        Acc acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r].init();
+        uint64_t cnt = 0;
+
+        // rows in front of the first 16-byte boundary of this segment, full tiles, then the rest
+        size_t head = 0;
+        if (r_begin < r_end) {
+            const uintptr_t mis = (uintptr_t)(data + r_begin) & 15;
+            head = mis ? (16 - mis) / sizeof(T) : 0;
+            if (head > r_end - r_begin) head = r_end - r_begin;
+        }
+        const size_t body0 = r_begin + head;
+        const size_t n_tiles = (r_end - body0) / TILE_ROWS;
+        for (size_t t = 0; t < n_tiles; ++t) {
+            const size_t row0 = body0 + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = (const V*)(data + row0) + lane;
+            V v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, true>(p + (size_t)u * 64);
+            if (masked) {
+                const uint64_t aw = load_run_words<WPT>(d.words, d.bit_off + row0, d.last_word, lane);
+                if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned bits = lane_bits<R>(aw, u, lane);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r].add(((bits >> r) & 1u) ? (T)v[u][r] : (T)0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                }
+            }
+        }
+        const size_t tail0 = body0 + n_tiles * TILE_ROWS;
+        const size_t n_ragged = head + (r_end - tail0);
+        for (size_t i = tid; i < n_ragged; i += kBlock) {
+            const size_t row = i < head ? r_begin + i : tail0 + (i - head);
+            T x = data[row];
+            if (masked) {
+                const unsigned valid = row_bit(d.words, d.bit_off + row);
+                cnt += valid;
+                x = valid ? x : (T)0;
+            }
+            acc[0].add(x);
+        }
+        if (!masked && tid == 0) cnt = r_end - r_begin;
+
+#pragma unroll
+        for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc[0].shfl_down_merge(off);
+            cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+        }
+        __syncthreads();  // lds[] of the previous segment has been consumed
+        if (lane == 0) {
+            acc[0].to_partial(lds[wave]);
+            lds[wave].cnt = cnt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            Acc s;
+            s.from_words(lds[0].a, lds[0].b);
+            uint64_t n = lds[0].cnt;
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) {
+                Acc o;
+                o.from_words(lds[w].a, lds[w].b);
+                s.merge(o);
+                n += lds[w].cnt;
+            }
+            Partial p;
+            s.to_partial(p);
+            p.cnt = n;
+            p.pad = 0;
+            partials[seg] = p;
+        }
+    }
+}
+
+// One wave per column: fold the column's partials in index order per lane, then across lanes.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __restrict__ cols, int n_cols, size_t n_segs,
+                                                             const Partial* __restrict__ partials, int is_signed,
+                                                             double* __restrict__ out_f64, uint64_t* __restrict__ out_i64,
+                                                             uint64_t* __restrict__ out_cnt) {
+    typedef typename AccOf<T>::type Acc;
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    for (size_t c = wave_id; c < (size_t)n_cols; c += n_waves) {
+        const size_t s0 = cols[c].seg0;
+        const size_t s1 = c + 1 < (size_t)n_cols ? cols[c + 1].seg0 : n_segs;
+        Acc tot;
+        tot.init();
+        uint64_t cnt = 0;
+        for (size_t s = s0 + lane; s < s1; s += 64) {
+            Acc o;
+            o.from_words(partials[s].a, partials[s].b);
+            tot.merge(o);
+            cnt += partials[s].cnt;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tot.shfl_down_merge(off);
+            cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+        }
+        if (lane == 0) {
+            if constexpr (std::is_same<Acc, DDAcc>::value) {
+                tot.normalise();
+                if (out_f64) out_f64[c] = tot.hi;
+            } else {
+                if (out_i64) out_i64[c] = tot.s;
+                if (out_f64) out_f64[c] = is_signed ? (double)(int64_t)tot.s : (double)tot.s;
+            }
+            if (out_cnt) out_cnt[c] = cnt;
+        }
+    }
+}
+
+template <typename T>
+static void launch_columns(ma_ctx* ctx, const ColDesc* d, size_t n_cols, size_t n_segs, Partial* partials, bool is_signed,
+                           double* of, uint64_t* oi, uint64_t* oc) {
+    constexpr int UNROLL = sizeof(T) == 8 ? 8 : 4;
+    const int grid1 = grid_for(ctx, n_segs, 2);
+    hipLaunchKernelGGL((column_segments_kernel<T, UNROLL>), dim3(grid1), dim3(kBlock), 0, ctx->stream, d, (int)n_cols,
+                       n_segs, partials);
+    const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
+    hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
+                       (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc);
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
+                                    const size_t* col_lens, const uint8_t* const* col_masks,
+                                    const size_t* col_mask_offsets, double* out_sums_f64, int64_t* out_sums_i64,
+                                    uint64_t* out_valid_counts) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    size_t elem = 0;
+    switch (format_code) {
+        case 'i': case 'I': case 'f': elem = 4; break;
+        case 'l': case 'L': case 'g': elem = 8; break;
+        default:
+            set_error("unsupported element format '%c' (numeric primitives only)", (char)format_code);
+            return MA_ERR_UNSUPPORTED;
+    }
+    if (n_cols == 0) return MA_OK;
+    MA_REQUIRE(n_cols < ((size_t)1 << 30), MA_ERR_INVALID_ARGUMENT, "too many columns");
+    MA_REQUIRE(col_data != nullptr && col_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL column table");
+    for (size_t i = 0; i < n_cols; ++i) {
+        MA_REQUIRE(col_lens[i] == 0 || col_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu data is NULL", i);
+        MA_REQUIRE(((uintptr_t)col_data[i] % elem) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu is misaligned", i);
+    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    std::vector<ColDesc> desc(n_cols);
+    size_t n_segs = 0;
+    for (size_t i = 0; i < n_cols; ++i) {
+        ColDesc& d = desc[i];
+        const void* p = nullptr;
+        MA_TRY(scope.in(col_data[i], col_lens[i] * elem, &p));
+        d.data = p;
+        d.len = col_lens[i];
+        d.words = nullptr;
+        d.bit_off = 0;
+        d.last_word = 0;
+        if (col_masks && col_masks[i] && d.len) {
+            MA_TRY(scope.in_mask(col_masks[i], col_mask_offsets ? col_mask_offsets[i] : 0, d.len, &d.words, &d.bit_off));
+            d.last_word = (d.bit_off + d.len - 1) >> 6;
+        }
+        d.seg0 = n_segs;
+        n_segs += d.len ? (d.len + kSegRows - 1) / kSegRows : 0;  // an empty column has no segment: its fold is {0, 0}
+    }
+    void *of = nullptr, *oi = nullptr, *oc = nullptr;
+    MA_TRY(scope.out(out_sums_f64, n_cols * 8, &of));
+    MA_TRY(scope.out(out_sums_i64, n_cols * 8, &oi));
+    MA_TRY(scope.out(out_valid_counts, n_cols * 8, &oc));
+
+    // descriptors + partials in one scratch allocation
+    const size_t desc_bytes = ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
+    const size_t bytes = desc_bytes + sizeof(Partial) * (n_segs ? n_segs : 1);
+    void* scratch = nullptr;
+    MA_HIP(hipMalloc(&scratch, bytes));
+    struct FreeLater {
+        void* p;
+        hipStream_t s;
+        ~FreeLater() {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(p);
+        }
+    } free_scratch{scratch, ctx->stream};
+    MA_HIP(hipMemcpyAsync(scratch, desc.data(), sizeof(ColDesc) * n_cols, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));  // `desc` is pageable: the copy must leave it before we continue
+    const ColDesc* d = (const ColDesc*)scratch;
+    Partial* partials = (Partial*)((char*)scratch + desc_bytes);
+    switch (format_code) {
+        case 'i': launch_columns<int32_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'l': launch_columns<int64_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'f': launch_columns<float>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        default: launch_columns<double>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+    }
+    MA_HIP(hipGetLastError());
+    // The scratch is freed when this frame unwinds, after a stream synchronise: the call is synchronous even in
+    // async mode (documented in the header).
+    return end_call(ctx, scope);
+}

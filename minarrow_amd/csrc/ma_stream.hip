@@ -114,6 +114,7 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
 
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
+        MA_NO_CAPTURE(ctx, "ma_sum_arrow_stream");
         was_async = ctx->async;
     }
     MA_HIP(hipSetDevice(ctx->device));

@@ -120,6 +120,33 @@ class PinnedBuffer:
             pass
 
 
+class Graph:
+    """A recorded sequence of calls (hipGraph). `launch()` replays it on the owning context's stream."""
+
+    def __init__(self, ctx: "Context", handle: int):
+        self.ctx, self.handle = ctx, handle
+
+    @property
+    def nodes(self) -> int:
+        n = C.c_size_t()
+        ffi.check(self.ctx.lib.ma_graph_node_count(self.handle, C.addressof(n)))
+        return int(n.value)
+
+    def launch(self) -> None:
+        ffi.check(self.ctx.lib.ma_graph_launch(self.ctx.handle, self.handle))
+
+    def destroy(self) -> None:
+        if self.handle:
+            self.ctx.lib.ma_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class Context:
     """One device + one HIP stream (ma_ctx)."""
 
@@ -174,6 +201,16 @@ class Context:
         ms = C.c_float()
         ffi.check(self.lib.ma_ctx_timer_elapsed_ms(self.handle, C.byref(ms)))
         return float(ms.value)
+
+    # -- hipGraph capture ------------------------------------------------------------------------------
+    def capture_begin(self) -> None:
+        """Record (instead of run) every following call on this context until `capture_end`."""
+        ffi.check(self.lib.ma_ctx_capture_begin(self.handle))
+
+    def capture_end(self) -> "Graph":
+        g = C.c_void_p()
+        ffi.check(self.lib.ma_ctx_capture_end(self.handle, C.addressof(g)))
+        return Graph(self, g.value)
 
     # -- memory ----------------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> DeviceBuffer:
@@ -242,6 +279,22 @@ class Context:
             fn = getattr(self.lib, f"ma_{tag}_sum")
             ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
                          addr_of(out_sum), addr_of(out_count)))
+
+    def sum_columns(self, fmt: str, columns, lens, masks=None, mask_offsets=None):
+        """Per-column (sums as float64 array, sums as wrapped int64 array or None for float formats, valid counts)
+        for many columns of one type in two launches (ma_sum_columns)."""
+        k = len(columns)
+        data_arr = (C.c_void_p * k)(*[addr_of(c) or None for c in columns])
+        len_arr = (C.c_size_t * k)(*[int(n) for n in lens])
+        mask_arr = (C.c_void_p * k)(*[addr_of(m) or None for m in masks]) if masks is not None else None
+        off_arr = (C.c_size_t * k)(*[int(o) for o in mask_offsets]) if mask_offsets is not None else None
+        f = np.zeros(k, dtype=np.float64)
+        i = np.zeros(k, dtype=np.int64)
+        c = np.zeros(k, dtype=np.uint64)
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        ffi.check(self.lib.ma_sum_columns(self.handle, ord(fmt), k, cast(data_arr), cast(len_arr), cast(mask_arr),
+                                          cast(off_arr), addr_of(f), addr_of(i), addr_of(c)))
+        return f, (i if fmt in "iIlL" else None), c
 
     # -- elementwise arithmetic --------------------------------------------------------------------
     def apply(self, tag: str, lhs, rhs, op: int, out, n_lhs: int, n_rhs: int, mask=None, mask_bit_offset: int = 0,

@@ -1,0 +1,111 @@
+"""GPU parity tests of ma_sum_columns: per-column {sum, valid count} of many columns in two launches. Every column
+must equal what the single-column entry point (and the oracle) gives: bit-exact for integers, <= 1 ULP of the exactly
+rounded sum for floats, for ragged lengths, empty columns, masks at odd bit offsets, device- and host-resident data."""
+import math
+
+import numpy as np
+import pytest
+
+from minarrow_amd import ffi
+
+pytestmark = pytest.mark.gpu
+
+NP = {"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64}
+TAG = {"i": "i32", "I": "u32", "l": "i64", "L": "u64", "f": "f32", "g": "f64"}
+
+
+def make_columns(rng, fmt, lens):
+    dt = NP[fmt]
+    cols = []
+    for n in lens:
+        if fmt in "fg":
+            cols.append((rng.standard_normal(n) * 1e3).astype(dt))
+        else:
+            info = np.iinfo(dt)
+            cols.append(rng.integers(info.min // 2, info.max // 2, size=n, dtype=dt))
+    return cols
+
+
+@pytest.mark.parametrize("fmt", list(NP))
+@pytest.mark.parametrize("device", [True, False])
+def test_ragged_columns_match_single_column_sums(ctx, fmt, device):
+    rng = np.random.default_rng(ord(fmt))
+    lens = [0, 1, 5, 63, 64, 65, 1000, 4095, 4096, 4097, 65_535, 65_536, 65_537, 200_003, 0, 17]
+    cols = make_columns(rng, fmt, lens)
+    masks, offs = [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0:
+            masks.append(None)
+            offs.append(0)
+        else:
+            off = [0, 3, 64, 77][i % 4]
+            masks.append(rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8))
+            offs.append(off)
+    if device:
+        # sub-allocate at odd element offsets so that segment heads are exercised
+        d_cols = [ctx.to_device(np.concatenate([np.zeros(1, c.dtype), c]), 64) for c in cols]
+        ptrs = [d.ptr + c.itemsize for d, c in zip(d_cols, cols)]
+        d_masks = [ctx.to_device(m, 16) if m is not None else None for m in masks]
+    else:
+        ptrs, d_masks = cols, masks
+    f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+    for k, (c, n) in enumerate(zip(cols, lens)):
+        valid = (np.unpackbits(masks[k], bitorder="little")[offs[k]:offs[k] + n].astype(bool)
+                 if masks[k] is not None else np.ones(n, dtype=bool))
+        assert cnt[k] == valid.sum(), k
+        sel = c[valid]
+        if fmt in "fg":
+            exact = math.fsum(sel.astype(np.float64).tolist())
+            assert abs(f[k] - exact) <= math.ulp(exact), (k, n)
+        else:
+            want = int(sel.astype(object).sum()) if n else 0
+            assert (int(i64[k]) - want) % (1 << 64) == 0, (k, n)
+        # identical to the single-column entry point
+        if n:
+            s1, c1 = ctx.sum(TAG[fmt], ptrs[k], n, mask=d_masks[k], mask_bit_offset=offs[k])
+            assert c1 == cnt[k]
+            if fmt in "fg":
+                assert abs(s1 - f[k]) <= math.ulp(f[k])
+            else:
+                assert (int(s1) - int(i64[k])) % (1 << 64) == 0
+
+
+def test_thousand_small_columns(ctx):
+    """1000 columns of 1000 rows (the launch-bound shape): iota data, closed forms."""
+    k, n = 1000, 1000
+    data = ctx.alloc(k * n * 8)
+    ctx.synth_iota("i64", data, k * n, 0)
+    f, i64, cnt = ctx.sum_columns("l", [data.ptr + i * n * 8 for i in range(k)], [n] * k)
+    base = np.arange(k, dtype=np.int64) * n
+    np.testing.assert_array_equal(i64, base * n + n * (n - 1) // 2)
+    np.testing.assert_array_equal(cnt, np.full(k, n, dtype=np.uint64))
+    np.testing.assert_array_equal(f, i64.astype(np.float64))
+
+
+def test_config5_per_column_reduce_in_one_call(ctx):
+    """8 chunks x 2^24 rows with 10 % nulls (config 5 scaled): per-chunk sums in one call == one call per chunk, and
+    their fold == the sum of the physically consolidated column."""
+    k, n = 8, 1 << 24
+    chunks = [ctx.alloc(n * 8) for _ in range(k)]
+    masks = [ctx.alloc(n // 8 + 64) for _ in range(k)]
+    for c in range(k):
+        ctx.synth_iota("f64", chunks[c], n, c)
+        ctx.synth_validity(masks[c], n, seed=0x55 + c, null_every=10)
+    f, _, cnt = ctx.sum_columns("g", chunks, [n] * k, masks, [0] * k)
+    for c in range(k):
+        s, v = ctx.sum("f64", chunks[c], n, mask=masks[c])
+        assert v == cnt[c] and abs(s - f[c]) <= math.ulp(s)
+    out, om = ctx.alloc(k * n * 8), ctx.alloc(k * n // 8 + 64)
+    assert ctx.consolidate_column(8, chunks, [n] * k, out, masks, [0] * k, om)
+    s, v = ctx.sum("f64", out, k * n, mask=om)
+    assert v == int(cnt.sum())
+    assert abs(s - math.fsum(f.tolist())) <= 2 * math.ulp(s)
+
+
+def test_errors(ctx):
+    a = np.arange(10, dtype=np.int64)
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.sum_columns("s", [a], [10])
+    assert e.value.status == ffi.MA_ERR_UNSUPPORTED
+    f, i64, cnt = ctx.sum_columns("l", [], [])
+    assert len(f) == 0

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Launch-bound shape: K independent small sums (the reference's hot-loop benches: 1000 rows, repeated 1000 times,
+benches/hotloop_benchmark_avg_simd.rs:205-208; and BASELINE configs[0]: one 10^6-row i64 sum).
+Compares per-call cost of (a) synchronous calls, (b) async calls + one synchronize, (c) one hipGraph replay,
+(d) ONE ma_sum_columns call for all K columns (two launches whatever K is).
+Host wall clock around each variant (this is a latency measurement, not a bandwidth one)."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import numpy as np
+    from minarrow_amd.host import Context
+
+    ctx = Context(0)
+    out = []
+    for n in (1000, 1_000_000):
+        k = args.k
+        data = ctx.alloc(k * n * 8)
+        res = ctx.alloc(k * 8)
+        ctx.synth_iota("i64", data, k * n, 0)
+        want = np.arange(k, dtype=np.int64) * n * n + n * (n - 1) // 2
+
+        def run_sync():
+            for i in range(k):
+                ctx.sum("i64", data.ptr + i * n * 8, n)
+
+        def run_async():
+            ctx.set_async(True)
+            for i in range(k):
+                ctx.sum_into("i64", data.ptr + i * n * 8, n, res.ptr + i * 8)
+            ctx.set_async(False)
+            ctx.synchronize()
+
+        ctx.capture_begin()
+        for i in range(k):
+            ctx.sum_into("i64", data.ptr + i * n * 8, n, res.ptr + i * 8)
+        g = ctx.capture_end()
+
+        def run_graph():
+            g.launch()
+
+        ptrs = [data.ptr + i * n * 8 for i in range(k)]
+        lens = [n] * k
+        batched = {}
+
+        def run_columns():
+            batched["i64"] = ctx.sum_columns("l", ptrs, lens)[1]
+
+        row = {"rows_per_call": n, "calls": k}
+        for name, fn in (("sync_calls", run_sync), ("async_calls_one_sync", run_async), ("one_graph_replay", run_graph),
+                         ("one_sum_columns_call", run_columns)):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                fn()
+            dt = (time.perf_counter() - t0) / args.reps
+            row[name + "_us_per_call"] = round(dt / k * 1e6, 3)
+            row[name + "_grows_per_s"] = round(k * n / dt / 1e9, 2)
+        assert np.array_equal(res.download(np.int64, k), want)
+        assert np.array_equal(batched["i64"], want)
+        out.append(row)
+        g.destroy()
+        data.free()
+        res.free()
+    # bandwidth shape: 8 chunks x 125 M rows (config 5's per-column reduce on one device)
+    k, n = 8, 125_000_000
+    chunks = [ctx.alloc(n * 8) for _ in range(k)]
+    for c in range(k):
+        ctx.synth_iota("i64", chunks[c], n, c)
+    ctx.sum_columns("l", chunks, [n] * k)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        ctx.sum_columns("l", chunks, [n] * k)
+    dt = (time.perf_counter() - t0) / args.reps
+    out.append({"rows_per_call": n, "calls": k, "one_sum_columns_call_ms": round(dt * 1e3, 3),
+                "one_sum_columns_call_gbps": round(k * n * 8 / dt / 1e9, 1)})
+    print(json.dumps({"bench": "launch-bound small sums, 1 MI355X", "results": out}))
+
+
+if __name__ == "__main__":
+    main()
