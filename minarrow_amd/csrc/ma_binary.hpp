@@ -206,12 +206,12 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
         if constexpr (KIND != kSA) {
             const V* __restrict__ p = (const V*)(a.lhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
         }
         if constexpr (KIND != kAS) {
             const V* __restrict__ q = (const V*)(a.rhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
         }
         uint64_t aw = 0;
         if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
@@ -264,11 +264,11 @@ __global__ __launch_bounds__(kBlock) void fma_vec_kernel(BinArgs<T> a) {
         const V* __restrict__ q = (const V*)(a.rhs + row0) + lane;
         const V* __restrict__ c = (const V*)(a.acc + row0) + lane;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) vc[u] = load16<V, true>(c + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) vc[u] = load16u<V, true>(c + (size_t)u * 64);
         uint64_t aw = 0;
         if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
         V* __restrict__ o = (V*)(a.out + row0) + lane;
@@ -473,11 +473,10 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     const bool int_div = kInt && !c.fma &&
                          (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
     const bool ballot = masked && int_div;  // output validity depends on the data: row kernel over everything
-    // The vec kernel needs every array operand on the same 16-byte phase.
+    // The vec kernel peels `head` rows so that its STORES are 16-byte aligned; the inputs may sit on any element-aligned
+    // phase (views sliced at different offsets, routing/arithmetic.rs:273-285): load16u.
     uintptr_t phase = (uintptr_t)a.out & 15;
-    bool same_phase = (c.kind == kSA || ((uintptr_t)a.lhs & 15) == phase) &&
-                      (c.kind == kAS || ((uintptr_t)a.rhs & 15) == phase) &&
-                      (!c.fma || ((uintptr_t)a.acc & 15) == phase);
+    const bool same_phase = true;
     constexpr int R = 16 / (int)sizeof(T);
     // Launch shape (profiles/r01_sweep_grid.json, r01_sweep_binary.txt, r01_ubench_stream.txt). With a store stream in
     // the mix — unlike the read-only sums — MORE resident workgroups help (the memory system batches writes better

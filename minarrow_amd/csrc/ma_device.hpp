@@ -65,6 +65,19 @@ __device__ __forceinline__ V load16(const V* p) {
     }
 }
 
+// The same 16-byte load from an address that is only ELEMENT aligned (a view that starts mid-vector, an operand on a
+// different 16-byte phase than the output). gfx950 under HSA runs with unaligned access mode on: one
+// global_load_dwordx4 either way; a misaligned wave access touches one extra cache line per KiB.
+template <typename V, bool NT>
+__device__ __forceinline__ V load16u(const V* p) {
+    typedef V VU __attribute__((aligned(1)));
+    if constexpr (NT) {
+        return __builtin_nontemporal_load((const VU*)p);
+    } else {
+        return *(const VU*)p;
+    }
+}
+
 template <typename V, bool NT>
 __device__ __forceinline__ void store16(V* p, V v) {
     if constexpr (NT) {

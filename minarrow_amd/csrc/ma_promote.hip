@@ -44,12 +44,12 @@ __global__ __launch_bounds__(kBlock) void promote_kernel(PromoteArgs<LT, RT, OT>
         if (a.kind != kSA) {
             const VL* __restrict__ p = (const VL*)(a.lhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vl[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) vl[u] = load16u<VL, true>(p + (size_t)u * 64);
         }
         if (a.kind != kAS) {
             const VR* __restrict__ q = (const VR*)(a.rhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vr[u] = __builtin_nontemporal_load(q + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) vr[u] = load16u<VR, true>(q + (size_t)u * 64);
         }
         uint64_t aw = 0;
         if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
@@ -135,12 +135,11 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
     constexpr int R = 16 / (int)sizeof(OT);
     constexpr int U = 4;
     const size_t tile_rows = (size_t)64 * R * U * kWaves;
-    // vector path: after `head` rows every operand must sit on a boundary of its R-element vector
+    // vector path: `head` rows are peeled so that the output stores are 16-byte aligned
     const uintptr_t mis = (uintptr_t)a.out & 15;
     size_t head = mis ? (16 - mis) / sizeof(OT) : 0;
     if (head > n) head = n;
-    const bool lhs_ok = kind == kSA || (((uintptr_t)(a.lhs + head)) % (R * sizeof(LT))) == 0;
-    const bool rhs_ok = kind == kAS || (((uintptr_t)(a.rhs + head)) % (R * sizeof(RT))) == 0;
+    const bool lhs_ok = true, rhs_ok = true;  // inputs are read with element-aligned vector loads (load16u)
     a.head = head;
     a.n_tiles = (lhs_ok && rhs_ok) ? (n - head) / tile_rows : 0;
     if (!(lhs_ok && rhs_ok)) a.head = 0;

@@ -5,7 +5,7 @@
 // (RechunkStrategy::Auto, src/structs/chunked/super_array.rs:51-59): a 10^9-row column is ~122 000 chunks, and a
 // launch per chunk would be launch-bound by three orders of magnitude. Here a descriptor table with per-chunk tile
 // prefix sums is uploaded once; every workgroup binary-searches its tile's chunk (like concat_kernel) and runs the
-// same 16-byte vector body as the single-array kernels, or a row body for ragged / phase-mismatched tiles.
+// same 16-byte vector body as the single-array kernels (inputs on any element phase), or a row body for ragged tiles.
 // Validity: the common mask of a chunk is lhs | rhs (Bitmask::union, :224) or whichever side has one; a second
 // launch assembles every chunk's output bitmap word by word.
 #include <vector>
@@ -103,16 +103,16 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const PairDesc* 
             }
         }
         if (r0 >= d.len) continue;
-        if (d.vec && r1 - r0 == TILE_ROWS) {
+        if (r1 - r0 == TILE_ROWS) {  // stores 16-byte aligned by construction; inputs on any element phase (load16u)
             const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
             const V* __restrict__ p = (const V*)(lhs + w0) + lane;
             const V* __restrict__ q = (const V*)(rhs + w0) + lane;
             V* __restrict__ o = (V*)(out + w0) + lane;
             V va[UNROLL], vb[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) va[u] = load16<V, true>(p + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vb[u] = load16<V, true>(q + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
             uint64_t aw = ~(uint64_t)0;
             if (masked) {
                 aw = 0;

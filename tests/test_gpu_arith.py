@@ -442,16 +442,49 @@ def test_fma_random(gpu, oracle, tag):
         np.testing.assert_array_equal(got_mask, want_mask[:mask_bytes(n)])
 
 
-def test_mixed_phase_operands_take_the_row_kernel(gpu, ctx, oracle):
-    """lhs, rhs and out on different 16-byte phases: no vector path exists; results must not change."""
-    n = 10_001
-    rng = np.random.default_rng(3)
-    a, b = rand_ints(rng, "i64", n), rand_ints(rng, "i64", n)
-    da = ctx.to_device(np.concatenate([[0], a]).astype(np.int64), 64)
-    db = ctx.to_device(b, 64)
-    do = ctx.alloc(n * 8 + 64)
-    ctx.apply("i64", da.offset(8), db, 0, do, n, n)
-    np.testing.assert_array_equal(do.download(np.int64, n), (a.astype(np.uint64) + b.astype(np.uint64)).view(np.int64))
+@pytest.mark.parametrize("tag", ["i8", "u16", "i32", "i64", "f32", "f64"])
+def test_mixed_phase_operands(ctx, oracle, tag):
+    """lhs, rhs and out on different 16-byte phases (views sliced at different offsets, routing/arithmetic.rs:273-285):
+    the stores stay 16-byte aligned after the head rows, the inputs are read with element-aligned vector loads.
+    Results must equal the oracle's, dense and masked, incl. data-dependent validity for integer division."""
+    dt = np.dtype({"i8": np.int8, "u16": np.uint16, "i32": np.int32, "i64": np.int64, "f32": np.float32, "f64": np.float64}[tag])
+    n = 150_001
+    rng = np.random.default_rng(dt.itemsize)
+    pad = 40
+    a = rng.integers(1, 100, size=n + pad).astype(dt)
+    b = rng.integers(0, 7, size=n + pad).astype(dt)  # zeros: masked integer division nulls those rows
+    da, db = ctx.to_device(a, 64), ctx.to_device(b, 64)
+    do = ctx.alloc((n + pad) * dt.itemsize + 64)
+    bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    dm, dom = ctx.to_device(bits, 16), ctx.alloc(n // 8 + 64)
+    is_float = tag in ("f32", "f64")
+    ref = oracle.apply_float if is_float else oracle.apply_int
+    for la, lb, lo in ((1, 0, 0), (0, 3, 1), (5, 2, 7), (1, 1, 2)):
+        x, y = np.ascontiguousarray(a[la:la + n]), np.ascontiguousarray(b[lb:lb + n])
+        pa, pb, po = da.ptr + la * dt.itemsize, db.ptr + lb * dt.itemsize, do.ptr + lo * dt.itemsize
+        for op in (0, 2) + ((3,) if is_float else ()):
+            ctx.apply(tag, pa, pb, op, po, n, n)
+            st, want, _, _ = ref(x, y, op)
+            assert st == 0
+            got = do.download(dt, n, lo * dt.itemsize)
+            np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+        # masked, with validity decided by the data for integer division
+        ctx.apply(tag, pa, pb, 3, po, n, n, mask=dm, out_mask=dom)
+        st, want, want_mask, _ = ref(x, y, 3, mask=bits)
+        assert st == 0
+        got = do.download(dt, n, lo * dt.itemsize)
+        np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+        nb = ((n + 63) // 64) * 8
+        np.testing.assert_array_equal(dom.download(np.uint8, nb), want_mask[:nb])
+        # scalar side
+        ctx.apply_scalar(tag, "rhs", pa, n, 3, 2, po)
+        np.testing.assert_array_equal(do.download(dt, n, lo * dt.itemsize), (x * dt.type(3)).astype(dt))
+    if tag in ("f32", "f64"):
+        c = rng.integers(1, 9, size=n + pad).astype(dt)
+        dc = ctx.to_device(c, 64)
+        ctx.apply_fma(tag, da.ptr + dt.itemsize, db.ptr + 2 * dt.itemsize, dc.ptr, do.ptr + 3 * dt.itemsize, n, n, n)
+        want = (a[1:1 + n].astype(np.float64) * b[2:2 + n] + c[:n]).astype(dt)  # exact in these ranges
+        np.testing.assert_array_equal(do.download(dt, n, 3 * dt.itemsize), want)
 
 
 def test_async_divide_by_zero_is_reported_at_synchronize(ctx):

@@ -93,6 +93,8 @@ def main():
             emit("apply a(op)b", tag, f"{opname} dense", ms, 3 * n * sz, n)
         ms = timed(lambda: ctx.apply(tag, a, b, OP["add"], o, n, n, mask=mask, out_mask=omask))
         emit("apply a(op)b", tag, "add masked", ms, 3 * n * sz + n / 4, n)
+        ms = timed(lambda: ctx.apply(tag, a.ptr + sz, b.ptr + 3 * sz, OP["add"], o, n - 64, n - 64))
+        emit("apply a(op)b", tag, "add dense, operands on three different 16-byte phases", ms, 3 * n * sz, n)
         if not is_float:
             ms = timed(lambda: ctx.apply(tag, a, b, OP["div"], o, n, n, mask=mask, out_mask=omask))
             emit("apply a(op)b", tag, "div masked (validity from data)", ms, 3 * n * sz + n / 4, n)
