@@ -73,6 +73,7 @@ __device__ __forceinline__ uint64_t bit_op(int op, uint64_t x, uint64_t y) {
 }
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef u64x2 u64x2_u __attribute__((aligned(1)));  // read at a byte-aligned address (window starting mid-word)
 constexpr int kVecUnroll = 8;  // 16-byte accesses per operand a lane keeps in flight in the word-pair paths
 // Tile -> lane mapping of the word-pair paths, the one the elementwise kernels use: a wave owns kVecUnroll KiB of
 // consecutive pairs, lane l takes pair l of each KiB.
@@ -90,8 +91,9 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
     size_t first_scalar = 0;
     if constexpr (VEC) {
         const size_t n_pairs = (n_words - 1) >> 1;  // the last word (trailing-bit mask) always goes through the scalar path
-        const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
-        const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
+        // windows start on BYTES here (vec_ok): a byte-shifted pointer is the window, no funnel shift needed
+        const u64x2_u* __restrict__ lp = (const u64x2_u*)((const uint8_t*)a.lw + (a.lo >> 3));
+        const u64x2_u* __restrict__ rp = a.rw ? (const u64x2_u*)((const uint8_t*)a.rw + (a.ro >> 3)) : nullptr;
         u64x2* __restrict__ op = (u64x2*)a.out;
         // Tiles of kVecUnroll * kBlock pairs: every lane issues its kVecUnroll loads per operand before the first use.
         const size_t n_tiles = n_pairs / ((size_t)kVecUnroll * kBlock);
@@ -145,8 +147,9 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned lo
     size_t first_scalar = 0;
     if constexpr (VEC) {
         const size_t n_pairs = (n_words - 1) >> 1;
-        const u64x2* __restrict__ lp = (const u64x2*)(a.lw + (a.lo >> 6));
-        const u64x2* __restrict__ rp = a.rw ? (const u64x2*)(a.rw + (a.ro >> 6)) : nullptr;
+        // windows start on BYTES here (vec_ok): a byte-shifted pointer is the window, no funnel shift needed
+        const u64x2_u* __restrict__ lp = (const u64x2_u*)((const uint8_t*)a.lw + (a.lo >> 3));
+        const u64x2_u* __restrict__ rp = a.rw ? (const u64x2_u*)((const uint8_t*)a.rw + (a.ro >> 3)) : nullptr;
         const size_t n_tiles = n_pairs / ((size_t)kVecUnroll * kBlock);
         for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
             u64x2 x[kVecUnroll], y[kVecUnroll];
@@ -280,10 +283,11 @@ static void fill_window(BitArgs& a, const uint64_t* lw, size_t lo, const uint64_
 }
 
 // Runs bit_scan_kernel and brings the four words back to the host (synchronises the stream).
-// Two-words-per-lane path: windows start on words and the first word of every operand sits on a 16-byte boundary.
+// Two-words-per-lane path: windows start on a byte (the granularity at which and/or/xor/not address their windows in
+// the reference anyway, bitmask/mod.rs:124-128); inputs are read with byte-aligned 16-byte loads, the output (always
+// re-based to bit 0) must sit on a 16-byte boundary.
 static int vec_ok(const BitArgs& a, bool with_out) {
-    if ((a.lo & 63) || (a.rw && (a.ro & 63))) return 0;
-    if (((uintptr_t)(a.lw + (a.lo >> 6)) & 15) || (a.rw && ((uintptr_t)(a.rw + (a.ro >> 6)) & 15))) return 0;
+    if ((a.lo & 7) || (a.rw && (a.ro & 7))) return 0;
     if (with_out && ((uintptr_t)a.out & 15)) return 0;
     return a.n >= 256 ? 1 : 0;
 }
