@@ -15,12 +15,13 @@
 // Two kernels per operation:
 //   vec kernel  — the bandwidth path. A wave owns a contiguous run; each lane moves 16 bytes per access
 //                 (global_load_dwordx4 / global_store_dwordx4, non-temporal), UNROLL accesses per operand in
-//                 flight before the first use. Needs lhs, rhs and out to share their offset modulo 16.
-//   row kernel  — one row per lane. Handles the unaligned head / ragged tail of the vec kernel, operand sets
-//                 whose 16-byte phases differ, and masked integer Div/Rem/FloorDiv, whose output validity
-//                 (valid && divisor != 0) is one wave64 ballot per 64 rows = one u64 word of the bitmap.
-// Output validity of every other masked op equals the input validity: a word-wise funnel-shift copy
-// (mask_copy_kernel) writes it, so the vec kernel only READS validity (to zero the null slots).
+//                 flight before the first use. `head` rows are peeled so that the stores are 16-byte aligned; the
+//                 inputs may sit on any element-aligned phase (load16u).
+//   row kernel  — one row per lane, for the unaligned head / ragged tail of the vec kernel.
+// Output validity of a masked op equals the input validity: a word-wise funnel-shift copy (mask_copy_kernel) writes
+// it, so the vec kernel only READS validity (to zero the null slots). The exception is masked integer
+// Div/Rem/FloorDiv, whose output validity is (valid && divisor != 0): the vec kernel packs each lane's result bits
+// into validity words (pack_lane_bits), the row kernel uses one wave64 ballot per 64 rows.
 #pragma once
 
 #include "ma_device.hpp"
@@ -176,11 +177,11 @@ struct BinArgs {
     const uint64_t* words;  // input validity (8-byte aligned base) or nullptr
     size_t bit_off;         // bit index of row 0 relative to `words`
     size_t last_word;       // last word index holding a window bit
-    uint64_t* out_words;    // output validity words (row kernel in ballot mode) or nullptr
+    uint64_t* out_words;    // output validity words (data-dependent validity only) or nullptr
     uint32_t* flags;        // device latch: bit 0 = integer divide by zero seen in a dense kernel
     int op;                 // row kernel: runtime ArithmeticOperator
     int kind;               // row kernel: kAA / kAS / kSA
-    int ballot_mask;        // row kernel: 1 = produce out_words by ballot over the whole array
+    int ballot_mask;        // row kernel: 1 = also produce the out_words of its rows, one ballot per 64 rows
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -472,7 +473,7 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
 
     const bool int_div = kInt && !c.fma &&
                          (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
-    const bool ballot = masked && int_div;  // output validity depends on the data: row kernel over everything
+    const bool ballot = masked && int_div;  // output validity depends on the data: the kernels write out_words themselves
     // The vec kernel peels `head` rows so that its STORES are 16-byte aligned; the inputs may sit on any element-aligned
     // phase (views sliced at different offsets, routing/arithmetic.rs:273-285): load16u.
     uintptr_t phase = (uintptr_t)a.out & 15;
