@@ -307,6 +307,184 @@ inline Table broadcast_table_to_scalar(ArithmeticOperator op, const Table& table
     return out;
 }
 
+// ---- chunked containers (src/structs/chunked/super_array.rs, super_table.rs) ----------------------------------------
+struct SuperArray {
+    std::vector<NumericArray> chunks_;
+    SuperArray() = default;
+    explicit SuperArray(std::vector<NumericArray> c) : chunks_(std::move(c)) {}
+    void push(NumericArray a) { chunks_.push_back(std::move(a)); }
+    const std::vector<NumericArray>& chunks() const { return chunks_; }
+    size_t n_chunks() const { return chunks_.size(); }
+    size_t len() const {
+        size_t n = 0;
+        for (const NumericArray& c : chunks_) n += c.len();
+        return n;
+    }
+};
+
+namespace detail {
+template <typename T>
+const void* chunk_data(const NumericArray& a) {
+    return std::visit([](const auto& p) -> const void* { return p->data.data(); }, a.v);
+}
+inline int32_t format_code(NumericType t) {
+    switch (t) {
+        case NumericType::Int32: return 'i';
+        case NumericType::Int64: return 'l';
+        case NumericType::UInt32: return 'I';
+        case NumericType::UInt64: return 'L';
+        case NumericType::Float32: return 'f';
+        default: return 'g';
+    }
+}
+inline size_t elem_size(NumericType t) {
+    return (t == NumericType::Int64 || t == NumericType::UInt64 || t == NumericType::Float64) ? 8 : 4;
+}
+template <typename T>
+NumericArray make_chunk(size_t n, bool with_mask) {
+    typename Family<T>::Array a;
+    a.data = Vec64<T>::with_capacity(n);
+    a.data.set_len(n);
+    if (with_mask) a.null_mask = Bitmask::new_set_all(n, true);
+    return Family<T>::wrap(std::move(a));
+}
+inline NumericArray make_chunk_of(NumericType t, size_t n, bool with_mask) {
+    switch (t) {
+        case NumericType::Int32: return make_chunk<int32_t>(n, with_mask);
+        case NumericType::Int64: return make_chunk<int64_t>(n, with_mask);
+        case NumericType::UInt32: return make_chunk<uint32_t>(n, with_mask);
+        case NumericType::UInt64: return make_chunk<uint64_t>(n, with_mask);
+        case NumericType::Float32: return make_chunk<float>(n, with_mask);
+        default: return make_chunk<double>(n, with_mask);
+    }
+}
+inline void* mutable_data(const NumericArray& a) {  // freshly made, uniquely owned output chunks only
+    return const_cast<void*>(std::visit([](const auto& p) -> const void* { return p->data.data(); }, a.v));
+}
+inline uint8_t* mutable_mask(const NumericArray& a) {
+    const std::optional<Bitmask>& m = a.null_mask();
+    return m ? const_cast<uint8_t*>(m->bits.data()) : nullptr;
+}
+}  // namespace detail
+
+// route_super_array_broadcast — src/kernels/broadcast/super_array.rs:180-251. Chunk i of the result is
+// resolve_binary_arithmetic(op, lhs_i, rhs_i, mask_i) where mask_i = null_mask_override, or the common mask of the
+// chunks' OWN null masks: none / the one present / lhs.union(rhs) = bitwise OR (:215-229). Chunk lengths must agree
+// pairwise (ShapeError "Super Array broadcasting error ..."). The reference loops sequentially ("// TODO: Parallelise",
+// :193); when every chunk pair has one common element type ALL pairs run in one launch (ma_route_super_array_broadcast).
+inline SuperArray route_super_array_broadcast(ArithmeticOperator op, const SuperArray& lhs, const SuperArray& rhs,
+                                              const Bitmask* null_mask_override = nullptr) {
+    const size_t k = lhs.n_chunks();
+    if (rhs.n_chunks() < k)
+        throw KernelError(KernelError::Broadcasting, "Super Array broadcasting error - RHS has fewer chunks than LHS");
+    bool one_type = k > 0;
+    for (size_t i = 0; i < k; ++i) {
+        if (lhs.chunks()[i].len() != rhs.chunks()[i].len())
+            throw KernelError(KernelError::Broadcasting,
+                              "Super Array broadcasting error - Chunk: LHS " + std::to_string(lhs.chunks()[i].len()) + " RHS " +
+                                  std::to_string(rhs.chunks()[i].len()));
+        one_type = one_type && lhs.chunks()[i].type() == lhs.chunks()[0].type() && rhs.chunks()[i].type() == lhs.chunks()[0].type();
+    }
+    SuperArray out;
+    if (k == 0) return out;
+    if (!one_type) {  // mixed element types: chunk by chunk through the type matrix (promotions, UnsupportedType)
+        for (size_t i = 0; i < k; ++i) {
+            const NumericArray &l = lhs.chunks()[i], &r = rhs.chunks()[i];
+            const Bitmask* m = null_mask_override;
+            Bitmask common;
+            if (!m) {
+                const std::optional<Bitmask>&lm = l.null_mask(), &rm = r.null_mask();
+                if (lm && rm) {
+                    common = or_masks(window(*lm), window(*rm));
+                    m = &common;
+                } else if (lm) {
+                    m = &*lm;
+                } else if (rm) {
+                    m = &*rm;
+                }
+            }
+            out.push(resolve_binary_arithmetic(op, l, r, m));
+        }
+        return out;
+    }
+    const NumericType t = lhs.chunks()[0].type();
+    std::vector<const void*> ld(k), rd(k);
+    std::vector<size_t> ll(k), rl(k);
+    std::vector<const uint8_t*> lm(k), rm(k);
+    std::vector<void*> od(k);
+    std::vector<uint8_t*> om(k);
+    std::vector<int32_t> has(k);
+    for (size_t i = 0; i < k; ++i) {
+        const NumericArray &l = lhs.chunks()[i], &r = rhs.chunks()[i];
+        ld[i] = detail::chunk_data<void>(l);
+        rd[i] = detail::chunk_data<void>(r);
+        ll[i] = l.len();
+        rl[i] = r.len();
+        lm[i] = l.null_mask() ? l.null_mask()->bits.data() : nullptr;
+        rm[i] = r.null_mask() ? r.null_mask()->bits.data() : nullptr;
+        out.push(detail::make_chunk_of(t, ll[i], null_mask_override || lm[i] || rm[i]));
+        od[i] = detail::mutable_data(out.chunks()[i]);
+        om[i] = detail::mutable_mask(out.chunks()[i]);
+    }
+    check(ma_route_super_array_broadcast(Context::global().get(), detail::format_code(t), (int32_t)op, k, ld.data(), ll.data(),
+                                         lm.data(), rd.data(), rl.data(), rm.data(),
+                                         null_mask_override ? null_mask_override->bits.data() : nullptr, od.data(), om.data(),
+                                         has.data()));
+    return out;
+}
+
+// Consolidate for a chunked column — src/traits/consolidate.rs:110-207: values concatenated in chunk order; the result
+// has a null mask iff any chunk has one, chunks without one contribute all-valid rows (:80-105).
+inline NumericArray consolidate(const SuperArray& sa) {
+    if (sa.n_chunks() == 0) throw Panic("consolidate() called on empty SuperTable");
+    const NumericType t = sa.chunks()[0].type();
+    const size_t k = sa.n_chunks();
+    std::vector<const void*> data(k);
+    std::vector<size_t> lens(k);
+    std::vector<const uint8_t*> masks(k);
+    bool any_mask = false;
+    for (size_t i = 0; i < k; ++i) {
+        const NumericArray& c = sa.chunks()[i];
+        if (c.type() != t) throw KernelError(KernelError::UnsupportedType, "consolidate: chunks of one column must share a type");
+        data[i] = detail::chunk_data<void>(c);
+        lens[i] = c.len();
+        masks[i] = c.null_mask() ? c.null_mask()->bits.data() : nullptr;
+        any_mask = any_mask || masks[i];
+    }
+    NumericArray out = detail::make_chunk_of(t, sa.len(), any_mask);
+    int32_t has = 0;
+    check(ma_consolidate_column(Context::global().get(), detail::elem_size(t), k, data.data(), lens.data(), masks.data(), nullptr,
+                                detail::mutable_data(out), detail::mutable_mask(out), &has));
+    return out;
+}
+
+// SuperTable: batches with one schema (src/structs/chunked/super_table.rs:78-83). consolidate() — :657-743: one
+// contiguous Table; column c = the consolidation of column c of every batch; the name is kept (:1646-1655).
+struct SuperTable {
+    std::vector<std::shared_ptr<const Table>> batches;
+    std::string name;
+    size_t n_rows() const {
+        size_t n = 0;
+        for (const auto& b : batches) n += b->n_rows();
+        return n;
+    }
+};
+inline Table consolidate(const SuperTable& st) {
+    if (st.batches.empty()) throw Panic("consolidate() called on empty SuperTable");  // super_table.rs:693-696
+    Table out;
+    out.name = st.name;
+    const size_t n_cols = st.batches[0]->n_cols();
+    for (size_t c = 0; c < n_cols; ++c) {
+        SuperArray col;
+        for (const auto& b : st.batches) {
+            if (b->n_cols() != n_cols) throw KernelError(KernelError::Broadcasting, "SuperTable batches disagree on the column count");
+            col.push(b->cols[c].array);
+        }
+        out.cols.push_back({st.batches[0]->cols[c].name, consolidate(col)});
+    }
+    return out;
+}
+
 // Aggregates over a view, with the hand-off shape of NumericArrayV::guarantee_f64
 // (src/structs/views/collections/numeric_array_view.rs:302-317): values advanced to the window, the array's OWN
 // un-windowed validity plus the view offset as bit offset. Integer variants: wrapping 64-bit sum converted to f64.

@@ -356,6 +356,87 @@ static void routing_suite() {
     }
 }
 
+// Chunked containers: src/kernels/broadcast/super_array.rs:520-560 (test_broadcast_super_array_add),
+// src/structs/chunked/super_table.rs:1305-1397, 1629-1655 (consolidate tests).
+static NumericArray i32s_masked(std::initializer_list<int32_t> v, std::initializer_list<bool> valid) {
+    IntegerArray<int32_t> a;
+    a.data = Vec64<int32_t>(v);
+    a.null_mask = Bitmask::from_bools(valid);
+    return NumericArray::from_int32(std::move(a));
+}
+static std::shared_ptr<const Table> batch(std::vector<FieldArray> cols) {
+    auto t = std::make_shared<Table>();
+    t->cols = std::move(cols);
+    return t;
+}
+
+static void chunked_suite() {
+    std::printf("chunked suite\n");
+    {   // test_broadcast_super_array_add
+        SuperArray a({i32s({1, 2, 3}), i32s({4, 5, 6})}), b({i32s({10, 10, 10}), i32s({20, 20, 20})});
+        SuperArray r = route_super_array_broadcast(Op::Add, a, b);
+        ASSERT(r.n_chunks() == 2 && is_i32(r.chunks()[0], {11, 12, 13}) && is_i32(r.chunks()[1], {24, 25, 26}));
+        ASSERT(!r.chunks()[0].null_mask().has_value());
+        // common mask = union (OR) of the chunks' own masks (super_array.rs:215-229)
+        SuperArray am({i32s_masked({1, 2, 3}, {true, false, false}), i32s({4, 5, 6})});
+        SuperArray bm({i32s_masked({10, 10, 10}, {false, false, true}), i32s_masked({20, 20, 20}, {true, false, true})});
+        r = route_super_array_broadcast(Op::Multiply, am, bm);
+        ASSERT(is_i32(r.chunks()[0], {10, 0, 30}) && is_i32(r.chunks()[1], {80, 0, 120}));
+        const auto& m0 = r.chunks()[0].null_mask();
+        ASSERT(m0.has_value() && m0->get(0) && !m0->get(1) && m0->get(2));
+        // null_mask_override replaces the common mask of every chunk (:231)
+        Bitmask ov = Bitmask::from_bools({false, true, true});
+        r = route_super_array_broadcast(Op::Add, a, b, &ov);
+        ASSERT(is_i32(r.chunks()[0], {0, 12, 13}) && is_i32(r.chunks()[1], {0, 25, 26}));
+        // mixed element types go chunk by chunk through the type matrix (Int32 with Float64 promotes)
+        SuperArray f({f64s({0.5, 0.5, 0.5}), f64s({1.5, 1.5, 1.5})});
+        r = route_super_array_broadcast(Op::Add, a, f);
+        ASSERT(is_f64(r.chunks()[0], {1.5, 2.5, 3.5}) && is_f64(r.chunks()[1], {5.5, 6.5, 7.5}));
+        // chunk shapes must agree pairwise (:202-212)
+        SuperArray ragged({i32s({1, 2}), i32s({4, 5, 6})});
+        ASSERT(kernel_error(KernelError::Broadcasting, "Super Array broadcasting error",
+                            [&] { (void)route_super_array_broadcast(Op::Add, ragged, b); }));
+        // dense integer division by zero panics in whichever chunk it happens (std.rs:53-77)
+        SuperArray z({i32s({1, 1, 1}), i32s({1, 0, 1})});
+        ASSERT(panics([&] { (void)route_super_array_broadcast(Op::Divide, a, z); }));
+    }
+    {   // test_consolidate_arena_integer_and_float / _three_batches / _preserves_name
+        SuperTable st;
+        st.name = "my_table";
+        FloatArray<double> f1, f2;
+        f1.data = Vec64<double>{1.5, 2.5, 3.5};
+        f2.data = Vec64<double>{4.5, 5.5};
+        st.batches.push_back(batch({{"ints", i32s({1, 2, 3})}, {"floats", NumericArray::from_float64(std::move(f1))}}));
+        st.batches.push_back(batch({{"ints", i32s({4, 5})}, {"floats", NumericArray::from_float64(std::move(f2))}}));
+        Table t = consolidate(st);
+        ASSERT(t.n_rows() == 5 && t.n_cols() == 2 && t.name == "my_table");
+        ASSERT(is_i32(t.cols[0].array, {1, 2, 3, 4, 5}) && is_f64(t.cols[1].array, {1.5, 2.5, 3.5, 4.5, 5.5}));
+        ASSERT(t.cols[0].name == "ints" && !t.cols[0].array.null_mask().has_value());
+        SuperTable three;
+        three.batches = {batch({{"x", i32s({1, 2})}}), batch({{"x", i32s({3})}}), batch({{"x", i32s({4, 5, 6})}})};
+        ASSERT(is_i32(consolidate(three).cols[0].array, {1, 2, 3, 4, 5, 6}));
+        // test_consolidate_arena_nullable_columns
+        SuperTable nul;
+        nul.batches = {batch({{"x", i32s_masked({10, 0, 30}, {true, false, true})}}), batch({{"x", i32s_masked({0, 50}, {false, true})}})};
+        Table tn = consolidate(nul);
+        const NumericArray& x = tn.cols[0].array;
+        ASSERT(is_i32(x, {10, 0, 30, 0, 50}) && x.null_mask().has_value());
+        const bool want_valid[5] = {true, false, true, false, true};
+        for (size_t i = 0; i < 5; ++i) ASSERT(x.null_mask()->get(i) == want_valid[i]);
+        // a chunk without a mask contributes all-valid rows (consolidate.rs:91-96)
+        SuperTable part;
+        part.batches = {batch({{"x", i32s({7, 8})}}), batch({{"x", i32s_masked({0, 50}, {false, true})}})};
+        const NumericArray px = consolidate(part).cols[0].array;
+        ASSERT(px.null_mask().has_value() && px.null_mask()->get(0) && px.null_mask()->get(1) && !px.null_mask()->get(2) &&
+               px.null_mask()->get(3));
+        // consolidate() on an empty SuperTable panics (super_table.rs:693-696)
+        ASSERT(panics([] { (void)consolidate(SuperTable{}); }));
+        // per-column reduce of the consolidated table == fold of the per-batch reduces (config 5)
+        Aggregate whole = sum(NumericArrayV(tn.cols[0].array));
+        ASSERT(whole.sum == 90.0 && whole.valid_count == 3);
+    }
+}
+
 int main() {
     try {
         int_kernel_suite<int32_t>("i32", [](Slice<int32_t> l, Slice<int32_t> r, Op op, const Bitmask* m) { return apply_int_i32(l, r, op, m); });
@@ -371,6 +452,7 @@ int main() {
         for (size_t lanes : {(size_t)8, (size_t)16, (size_t)32, (size_t)64}) simd_bitmask_suite(lanes);
         bench_sums();
         routing_suite();
+        chunked_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
