@@ -1,0 +1,241 @@
+"""Property-based GPU parity (hypothesis): shapes, element offsets (16-byte phases), bit offsets and null densities
+drawn at random around the boundaries the kernels care about (64 rows = one validity word, one wave tile, one
+workgroup tile, the segment size of ma_sum_columns). Every example is checked bit-exactly against numpy / the oracle.
+`MA_FUZZ_EXAMPLES` scales the campaign (default 40 examples per property; a 20 000-example-per-property campaign —
+120 000 cases — passed on an MI355X in round 1)."""
+import math
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+pytestmark = pytest.mark.gpu
+
+N_EXAMPLES = int(os.environ.get("MA_FUZZ_EXAMPLES", "40"))
+COMMON = dict(max_examples=N_EXAMPLES, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
+
+NP = {"i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32,
+      "i64": np.int64, "u64": np.uint64, "f32": np.float32, "f64": np.float64}
+# lengths clustered around the kernel boundaries
+EDGES = [0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192,
+         16383, 16384, 16385, 32767, 32768, 65535, 65536, 65537]
+lengths = st.one_of(st.sampled_from(EDGES), st.integers(0, 70_000), st.integers(100_000, 300_000))
+
+
+def unpack(bits, off, n):
+    return np.unpackbits(bits, bitorder="little")[off:off + n].astype(bool)
+
+
+def rand_values(rng, dt, n, small=False):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        return (rng.standard_normal(n) * 100).astype(dt)
+    info = np.iinfo(dt)
+    if small:
+        return rng.integers(max(info.min, -50), min(info.max, 50), size=n, endpoint=True).astype(dt)
+    return rng.integers(info.min, info.max, size=n, dtype=dt, endpoint=True)
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(["i32", "u32", "i64", "u64", "f32", "f64"]), n=lengths, elem_off=st.integers(0, 7),
+       mask_off=st.integers(0, 130), masked=st.booleans(), null_pct=st.sampled_from([0, 1, 10, 50, 100]),
+       seed=st.integers(0, 2**31))
+def test_sum(ctx, tag, n, elem_off, mask_off, masked, null_pct, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    vals = rand_values(rng, dt, n + elem_off)
+    dev = ctx.to_device(vals, 64)
+    x = vals[elem_off:]
+    bits = None
+    valid = np.ones(n, dtype=bool)
+    dmask = None
+    if masked:
+        nb = (mask_off + n) // 8 + 16
+        bits = (rng.random(nb * 8) >= null_pct / 100.0)
+        bits = np.packbits(bits, bitorder="little")
+        valid = unpack(bits, mask_off, n)
+        dmask = ctx.to_device(bits, 16)
+    s, c = ctx.sum(tag, dev.ptr + elem_off * dt.itemsize, n, mask=dmask, mask_bit_offset=mask_off)
+    assert c == int(valid.sum())
+    sel = x[valid]
+    if dt.kind == "f":
+        exact = math.fsum(sel.astype(np.float64).tolist())
+        assert abs(s - exact) <= math.ulp(exact)
+    else:
+        want = int(sel.astype(object).sum()) if sel.size else 0
+        assert (int(s) - want) % (1 << 64) == 0
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(list(NP)), op=st.sampled_from([0, 1, 2, 3, 4, 6]), kind=st.sampled_from(["aa", "as", "sa"]),
+       n=lengths, offs=st.tuples(st.integers(0, 5), st.integers(0, 5), st.integers(0, 5)), masked=st.booleans(),
+       mask_off=st.integers(0, 70), seed=st.integers(0, 2**31))
+def test_apply(ctx, oracle, tag, op, kind, n, offs, masked, mask_off, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    is_float = dt.kind == "f"
+    la, lb, lo = offs
+    a = rand_values(rng, dt, n + la, small=True)
+    b = rand_values(rng, dt, n + lb, small=True)
+    if not is_float and not masked and op in (3, 4, 6):
+        b[b == 0] = 1  # a dense integer zero divisor is an error status, covered elsewhere
+    if dt.kind == "i" and op in (3, 4, 6):
+        b[b == -1] = 1  # MIN / -1: lane vs scalar-tail behaviour differs inside the reference itself
+    sc = dt.type(3)
+    da, db = ctx.to_device(a, 64), ctx.to_device(b, 64)
+    do = ctx.alloc((n + lo) * dt.itemsize + 64)
+    pa, pb, po = da.ptr + la * dt.itemsize, db.ptr + lb * dt.itemsize, do.ptr + lo * dt.itemsize
+    x, y = np.ascontiguousarray(a[la:]), np.ascontiguousarray(b[lb:])
+    bits = dm = dom = None
+    if masked:
+        # the oracle gates from bit 0: give it the window, the GPU the un-windowed bitmap + offset
+        full = np.packbits(rng.random(((mask_off + n) // 8 + 16) * 8) >= 0.3, bitorder="little")
+        win = np.packbits(unpack(full, mask_off, n), bitorder="little") if n else np.zeros(0, np.uint8)
+        bits = np.concatenate([win, np.zeros(24, np.uint8)])
+        dm, dom = ctx.to_device(full, 16), ctx.alloc(n // 8 + 64)
+    if kind == "aa":
+        lhs, rhs = x, y
+        ctx.apply(tag, pa, pb, op, po, n, n, mask=dm, mask_bit_offset=mask_off, out_mask=dom)
+    elif kind == "as":
+        lhs, rhs = x, np.full(n, sc, dtype=dt)
+        ctx.apply_scalar(tag, "rhs", pa, n, sc, op, po, mask=dm, mask_bit_offset=mask_off, out_mask=dom)
+    else:
+        lhs, rhs = np.full(n, sc, dtype=dt), y
+        ctx.apply_scalar(tag, "lhs", pb, n, sc, op, po, mask=dm, mask_bit_offset=mask_off, out_mask=dom)
+    if n == 0:
+        return
+    ref = oracle.apply_float if is_float else oracle.apply_int
+    status, want, want_mask, _ = ref(np.ascontiguousarray(lhs), np.ascontiguousarray(rhs), op, mask=bits)
+    assert status == 0
+    got = do.download(dt, n, lo * dt.itemsize)
+    if is_float:
+        same = (got.view(np.uint8).reshape(n, -1) == want[:n].view(np.uint8).reshape(n, -1)).all(axis=1)
+        both_nan = np.isnan(got) & np.isnan(want[:n])
+        assert (same | both_nan).all()
+    else:
+        np.testing.assert_array_equal(got, want[:n])
+    if masked:
+        nb = ((n + 63) // 64) * 8
+        np.testing.assert_array_equal(dom.download(np.uint8, nb), want_mask[:nb])
+
+
+@settings(**COMMON)
+@given(op=st.sampled_from(["and_masks", "or_masks", "xor_masks", "not_mask", "bitmask_slice"]), n=lengths,
+       lo=st.integers(0, 200), ro=st.integers(0, 200), out_off=st.sampled_from([0, 8, 16]), seed=st.integers(0, 2**31))
+def test_bitmask_word_ops(ctx, op, n, lo, ro, out_off, seed):
+    if n == 0:
+        return
+    rng = np.random.default_rng(seed)
+    nb = (max(lo, ro) + n) // 8 + 24
+    a = rng.integers(0, 256, size=nb, dtype=np.uint8)
+    b = rng.integers(0, 256, size=nb, dtype=np.uint8)
+    da, db = ctx.to_device(a, 16), ctx.to_device(b, 16)
+    out = ctx.alloc(n // 8 + 64)
+    po = out.ptr + out_off
+    if op in ("not_mask", "bitmask_slice"):
+        ctx.mask_unary_op(op, da, lo, n, po)
+        # not_mask addresses its window at byte granularity (bitmask/mod.rs:124-128), slice at bit granularity
+        start = (lo // 8) * 8 if op == "not_mask" else lo
+        src = unpack(a, start, n)
+        want = ~src if op == "not_mask" else src
+    else:
+        ctx.mask_words_op(op, da, lo, db, ro, n, po)
+        x, y = unpack(a, (lo // 8) * 8, n), unpack(b, (ro // 8) * 8, n)
+        want = {"and_masks": x & y, "or_masks": x | y, "xor_masks": x ^ y}[op]
+    nbytes = ((n + 63) // 64) * 8
+    got = out.download(np.uint8, nbytes, out_off)
+    np.testing.assert_array_equal(unpack(got, 0, n), want)
+    assert not unpack(got, 0, nbytes * 8)[n:].any()  # trailing bits cleared
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(["u8", "u16", "u32", "u64"]), n=lengths, elem_off=st.integers(0, 17), seed=st.integers(0, 2**31))
+def test_simd_eq_mask(ctx, tag, n, elem_off, seed):
+    if n == 0:
+        return
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    data = rng.integers(0, 16, size=n + elem_off).astype(dt)
+    dev = ctx.to_device(data, 64)
+    out = ctx.alloc(n // 8 + 64)
+    ctx.simd_eq_mask(tag, dev.ptr + elem_off * dt.itemsize, n, 0x6, 0x4, out)
+    nbytes = ((n + 63) // 64) * 8
+    got = out.download(np.uint8, nbytes)
+    np.testing.assert_array_equal(unpack(got, 0, n), (data[elem_off:] & 0x6) == 0x4)
+    assert not unpack(got, 0, nbytes * 8)[n:].any()
+
+
+@settings(**COMMON)
+@given(elem=st.sampled_from([1, 2, 4, 8]), lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 40_000)), min_size=1, max_size=9),
+       starts=st.lists(st.integers(0, 9), min_size=9, max_size=9), with_masks=st.booleans(), seed=st.integers(0, 2**31))
+def test_consolidate(ctx, elem, lens, starts, with_masks, seed):
+    rng = np.random.default_rng(seed)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[elem]
+    chunks = [rand_values(rng, dt, n + s) for n, s in zip(lens, starts)]
+    devs = [ctx.to_device(c, 64) for c in chunks]
+    ptrs = [d.ptr + s * elem for d, s in zip(devs, starts)]
+    total = sum(lens)
+    masks = offs = dmasks = None
+    if with_masks:
+        masks, offs, dmasks = [], [], []
+        for i, n in enumerate(lens):
+            if i % 3 == 2:
+                masks.append(None)
+                offs.append(0)
+                dmasks.append(None)
+            else:
+                off = int(rng.integers(0, 100))
+                m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+                masks.append(m)
+                offs.append(off)
+                dmasks.append(ctx.to_device(m, 16))
+    out = ctx.alloc(max(total, 1) * elem + 64)
+    om = ctx.alloc(total // 8 + 64)
+    has = ctx.consolidate_column(elem, ptrs, lens, out, dmasks, offs, om)
+    want = np.concatenate([c[s:] for c, s in zip(chunks, starts)]) if total else np.zeros(0, dt)
+    np.testing.assert_array_equal(out.download(dt, total), want)
+    any_mask = with_masks and any(m is not None for m in masks)
+    assert has == any_mask
+    if any_mask and total:
+        want_valid = np.concatenate([unpack(m, o, n) if m is not None else np.ones(n, bool) for m, o, n in zip(masks, offs, lens)])
+        nbytes = ((total + 63) // 64) * 8
+        got = om.download(np.uint8, nbytes)
+        np.testing.assert_array_equal(unpack(got, 0, total), want_valid)
+        assert not unpack(got, 0, nbytes * 8)[total:].any()
+
+
+@settings(**COMMON)
+@given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g"]),
+       lens=st.lists(st.one_of(st.sampled_from(EDGES), st.integers(0, 150_000)), min_size=1, max_size=12),
+       starts=st.lists(st.integers(0, 5), min_size=12, max_size=12), with_masks=st.booleans(), seed=st.integers(0, 2**31))
+def test_sum_columns(ctx, fmt, lens, starts, with_masks, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype({"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64}[fmt])
+    cols = [rand_values(rng, dt, n + s) for n, s in zip(lens, starts)]
+    devs = [ctx.to_device(c, 64) for c in cols]
+    ptrs = [d.ptr + s * dt.itemsize for d, s in zip(devs, starts)]
+    masks = offs = dmasks = None
+    if with_masks:
+        masks, offs, dmasks = [], [], []
+        for i, n in enumerate(lens):
+            if i % 2:
+                masks.append(None); offs.append(0); dmasks.append(None)
+            else:
+                off = int(rng.integers(0, 100))
+                m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+                masks.append(m); offs.append(off); dmasks.append(ctx.to_device(m, 16))
+    f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, dmasks, offs)
+    for k, (c, s, n) in enumerate(zip(cols, starts, lens)):
+        x = c[s:]
+        valid = unpack(masks[k], offs[k], n) if with_masks and masks[k] is not None else np.ones(n, bool)
+        assert cnt[k] == valid.sum()
+        sel = x[valid]
+        if dt.kind == "f":
+            exact = math.fsum(sel.astype(np.float64).tolist())
+            assert abs(f[k] - exact) <= math.ulp(exact)
+        else:
+            want = int(sel.astype(object).sum()) if sel.size else 0
+            assert (int(i64[k]) - want) % (1 << 64) == 0
