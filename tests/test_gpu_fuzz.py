@@ -239,3 +239,150 @@ def test_sum_columns(ctx, fmt, lens, starts, with_masks, seed):
         else:
             want = int(sel.astype(object).sum()) if sel.size else 0
             assert (int(i64[k]) - want) % (1 << 64) == 0
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(["f32", "f64"]), n=lengths, offs=st.tuples(st.integers(0, 3), st.integers(0, 3), st.integers(0, 3), st.integers(0, 3)),
+       masked=st.booleans(), seed=st.integers(0, 2**31))
+def test_fma(ctx, oracle, tag, n, offs, masked, seed):
+    if n == 0:
+        return
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    la, lb, lc, lo = offs
+    a, b, c = (rand_values(rng, dt, n + k) for k in (la, lb, lc))
+    da, db, dc = ctx.to_device(a, 64), ctx.to_device(b, 64), ctx.to_device(c, 64)
+    do = ctx.alloc((n + lo) * dt.itemsize + 64)
+    bits = dm = dom = None
+    if masked:
+        bits = np.concatenate([np.packbits(rng.random(((n + 63) // 64) * 64) >= 0.25, bitorder="little"), np.zeros(24, np.uint8)])
+        dm, dom = ctx.to_device(bits, 16), ctx.alloc(n // 8 + 64)
+    ctx.apply_fma(tag, da.ptr + la * dt.itemsize, db.ptr + lb * dt.itemsize, dc.ptr + lc * dt.itemsize,
+                  do.ptr + lo * dt.itemsize, n, n, n, mask=dm, out_mask=dom)
+    # 64-byte aligned copies: the reference's dispatch takes its SIMD body (fused mul_add, simd.rs:620) only for
+    # aligned inputs; its scalar fallback is UNFUSED (dispatch.rs:266,280) — SURVEY a15. The GPU is always fused.
+    status, want, want_mask = oracle.apply_fma(oracle.aligned_copy(a[la:]), oracle.aligned_copy(b[lb:]),
+                                               oracle.aligned_copy(c[lc:]), mask=bits)
+    assert status == 0
+    got = do.download(dt, n, lo * dt.itemsize)
+    np.testing.assert_array_equal(got.view(np.uint8), want[:n].view(np.uint8))
+    if masked:
+        nb = ((n + 63) // 64) * 8
+        np.testing.assert_array_equal(dom.download(np.uint8, nb), want_mask[:nb])
+
+
+@settings(**COMMON)
+@given(pair=st.sampled_from([("i32", "f64"), ("f64", "i32"), ("i32", "f32"), ("f32", "i32")]), op=st.sampled_from([0, 1, 2, 3]),
+       n=lengths, offs=st.tuples(st.integers(0, 5), st.integers(0, 5), st.integers(0, 5)), masked=st.booleans(),
+       seed=st.integers(0, 2**31))
+def test_promote(ctx, pair, op, n, offs, masked, seed):
+    if n == 0:
+        return
+    rng = np.random.default_rng(seed)
+    lt, rt = np.dtype(NP[pair[0]]), np.dtype(NP[pair[1]])
+    ot = lt if lt.kind == "f" else rt
+    la, lb, lo = offs
+    a, b = rand_values(rng, lt, n + la, small=True), rand_values(rng, rt, n + lb, small=True)
+    da, db = ctx.to_device(a, 64), ctx.to_device(b, 64)
+    do = ctx.alloc((n + lo) * ot.itemsize + 64)
+    valid = np.ones(n, bool)
+    dm = dom = None
+    if masked:
+        bits = np.packbits(rng.random(((n + 63) // 64) * 64 + 64) >= 0.25, bitorder="little")
+        valid = unpack(bits, 0, n)
+        dm, dom = ctx.to_device(bits, 16), ctx.alloc(n // 8 + 64)
+    ctx.apply_promote(pair[0], pair[1], da.ptr + la * lt.itemsize, db.ptr + lb * rt.itemsize, op, do.ptr + lo * ot.itemsize, n, n,
+                      mask=dm, out_mask=dom)
+    x, y = a[la:].astype(ot), b[lb:].astype(ot)  # `x as f64` — routing/arithmetic.rs:244-269
+    with np.errstate(all="ignore"):
+        want = [x + y, x - y, x * y, x / y][op].astype(ot)
+    want = np.where(valid, want, ot.type(0))
+    got = do.download(ot, n, lo * ot.itemsize)
+    same = got.view(np.uint8).reshape(n, -1) == want.view(np.uint8).reshape(n, -1)
+    assert (same.all(axis=1) | (np.isnan(got) & np.isnan(want))).all()
+    if masked:
+        np.testing.assert_array_equal(unpack(dom.download(np.uint8, ((n + 63) // 64) * 8), 0, n), valid)
+
+
+@settings(**COMMON)
+@given(lens=st.lists(st.one_of(st.sampled_from(EDGES[:22]), st.integers(0, 100_000)), min_size=1, max_size=9),
+       with_masks=st.booleans(), seed=st.integers(0, 2**31))
+def test_consolidate_boolean(ctx, lens, with_masks, seed):
+    rng = np.random.default_rng(seed)
+    if sum(lens) == 0:
+        return
+    chunks, dchunks, masks, dmasks = [], [], [], []
+    for i, n in enumerate(lens):
+        off = int(rng.integers(0, 130))
+        src = rng.integers(0, 256, size=(off + n) // 8 + 24, dtype=np.uint8)
+        chunks.append((src, off, n))
+        dchunks.append((ctx.to_device(src, 16), off, n))
+        if with_masks and i % 2 == 0:
+            moff = int(rng.integers(0, 130))
+            m = rng.integers(0, 256, size=(moff + n) // 8 + 24, dtype=np.uint8)
+            masks.append((m, moff))
+            dmasks.append((ctx.to_device(m, 16), moff))
+        else:
+            masks.append(None)
+            dmasks.append(None)
+    total = sum(lens)
+    nbytes = ((total + 63) // 64) * 8
+    out, om = ctx.alloc(nbytes + 8), ctx.alloc(nbytes + 8)
+    has = ctx.consolidate_boolean_column(dchunks, out, dmasks, om)
+    want = np.concatenate([unpack(s, o, n) for s, o, n in chunks])
+    got = out.download(np.uint8, nbytes)
+    np.testing.assert_array_equal(unpack(got, 0, total), want)
+    assert not unpack(got, 0, nbytes * 8)[total:].any()
+    any_mask = any(m is not None for m in masks)
+    assert has == any_mask
+    if any_mask:
+        want_valid = np.concatenate([unpack(m[0], m[1], n) if m is not None else np.ones(n, bool) for m, (_, _, n) in zip(masks, chunks)])
+        np.testing.assert_array_equal(unpack(om.download(np.uint8, nbytes), 0, total), want_valid)
+
+
+@settings(**COMMON)
+@given(fmt=st.sampled_from(["i", "l", "f", "g"]), op=st.sampled_from([0, 1, 2]),
+       lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
+       mask_mode=st.sampled_from(["none", "mixed", "override"]), seed=st.integers(0, 2**31))
+def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype({"i": np.int32, "l": np.int64, "f": np.float32, "g": np.float64}[fmt])
+    k = len(lens)
+    L = [rand_values(rng, dt, n, small=True) for n in lens]
+    R = [rand_values(rng, dt, n, small=True) for n in lens]
+    dL, dR = [ctx.to_device(x, 64) for x in L], [ctx.to_device(x, 64) for x in R]
+    dO = [ctx.alloc(n * dt.itemsize + 64) for n in lens]
+    dOM = [ctx.alloc(n // 8 + 64) for n in lens]
+    lm = rm = [None] * k
+    override = None
+    if mask_mode == "mixed":
+        lm = [np.packbits(rng.random(((n + 63) // 64) * 64 + 64) >= 0.3, bitorder="little") if i % 3 != 0 else None for i, n in enumerate(lens)]
+        rm = [np.packbits(rng.random(((n + 63) // 64) * 64 + 64) >= 0.3, bitorder="little") if i % 2 == 0 else None for i, n in enumerate(lens)]
+    elif mask_mode == "override":
+        nmax = max(lens)
+        override = np.packbits(rng.random(((nmax + 63) // 64) * 64 + 64) >= 0.3, bitorder="little")
+    dlm = [ctx.to_device(m, 16) if m is not None else None for m in lm]
+    drm = [ctx.to_device(m, 16) if m is not None else None for m in rm]
+    dov = ctx.to_device(override, 16) if override is not None else None
+    has = ctx.route_super_array_broadcast(fmt, op, dL, dR, lens, lens, dO, dlm, drm, dOM, dov)
+    for i, n in enumerate(lens):
+        if override is not None:
+            valid = unpack(override, 0, n)
+            want_has = True
+        elif lm[i] is not None or rm[i] is not None:
+            a = unpack(lm[i], 0, n) if lm[i] is not None else np.zeros(n, bool)
+            b = unpack(rm[i], 0, n) if rm[i] is not None else np.zeros(n, bool)
+            valid = a | b  # Bitmask::union (super_array.rs:224)
+            want_has = True
+        else:
+            valid = np.ones(n, bool)
+            want_has = False
+        assert has[i] == want_has
+        if n == 0:
+            continue
+        with np.errstate(all="ignore"):
+            res = [L[i] + R[i], L[i] - R[i], L[i] * R[i]][op].astype(dt)
+        want = np.where(valid, res, dt.type(0))
+        np.testing.assert_array_equal(dO[i].download(dt, n).view(np.uint8), want.view(np.uint8))
+        if want_has:
+            np.testing.assert_array_equal(unpack(dOM[i].download(np.uint8, ((n + 63) // 64) * 8), 0, n), valid)
