@@ -621,6 +621,17 @@ ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* stream, int6
                               int64_t* out_sum_i64, uint64_t* out_valid_count, uint64_t* out_rows,
                               uint64_t* out_batches);
 
+/* SuperTable (op) SuperTable as a streaming operator — broadcast_super_table_with_operator
+ * (src/kernels/broadcast/super_table.rs:37-72) over the record-batch streams the reference moves SuperTables in
+ * (arrow_c_ffi.rs:2104-2260). Both input streams are MOVED into the operator (their `release` is set to NULL) and
+ * *out_stream becomes an ArrowArrayStream whose get_next pulls one batch from either side, computes every column pair
+ * on the GPU (ma_apply_arrow_batch_export) and returns an owned struct array in pinned memory; get_schema gives the
+ * routed result schema (left field names). Errors surface through the stream protocol (non-zero return +
+ * get_last_error): "Table column count mismatch", "SuperTable chunk count mismatch" when one side ends first, a row
+ * count or type-matrix failure in some batch. Releasing the operator releases both inputs. `ctx` must outlive it. */
+ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArrayStream* lhs_stream,
+                                       struct ArrowArrayStream* rhs_stream, struct ArrowArrayStream* out_stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-chunk reductions over several GPUs driven from ONE process — the reference's Rayon path
  * (`slice.par_chunks(1 << 20).map(simd_sum).sum()`, benches/benchmark_parallel_simd.rs:81-98) for a host such as the

@@ -479,6 +479,11 @@ class Context:
             table(out_masks), C.cast(has, C.c_void_p)))
         return [bool(x) for x in has]
 
+    def apply_arrow_stream_export(self, op: int, lhs_stream_ptr: int, rhs_stream_ptr: int, out_stream_ptr: int) -> None:
+        """SuperTable (op) SuperTable as a stream operator: moves both input ArrowArrayStreams, fills *out_stream."""
+        ffi.check(self.lib.ma_apply_arrow_stream_export(self.handle, int(op), int(lhs_stream_ptr), int(rhs_stream_ptr),
+                                                        int(out_stream_ptr)))
+
     def sum_arrow_stream(self, stream_ptr: int, column: int = 0):
         """(sum as float, sum as wrapped int64, valid_count, rows, batches) over every batch of an ArrowArrayStream."""
         f, i = C.c_double(), C.c_int64()
