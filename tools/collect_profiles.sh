@@ -20,6 +20,10 @@ echo "== configs under rocprof" ; timeout 900 rocprofv3 --kernel-trace --stats -
 cp $O/stats_cfg/*/*_kernel_stats.csv $O/${R}_configs_kernel_stats.csv 2>/dev/null
 echo "== sweeps" ; timeout 900 python3 tools/sweep_sum.py --types i64,f64 --variants 0,16,6,22,4 --bpcs 0,1,2 --rounds 3 --reps 10 > $O/${R}_sweep_sum.txt 2>&1 ; echo rc=$?
 hipcc -O3 --offload-arch=gfx950 tools/ubench_sum.hip -o /tmp/ubench_sum 2>/dev/null && timeout 600 /tmp/ubench_sum 1000000000 3 > $O/${R}_ubench_sum.txt 2>&1
-rm -rf $O/stats $O/stats_cfg $O/pmc_fetch $O/pmc_write
+echo "== matrix" ; timeout 900 python3 tools/bench_matrix.py > $O/${R}_matrix.jsonl 2> $O/${R}_matrix.err ; echo rc=$?
+echo "== matrix under rocprof" ; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mx -- python3 tools/bench_matrix.py --reps 2 > /dev/null 2>&1 ; echo rc=$?
+cp $O/stats_mx/*/*_kernel_stats.csv $O/${R}_matrix_kernel_stats.csv 2>/dev/null
+echo "== launch-bound shapes" ; timeout 600 python3 tools/bench_graph.py > $O/${R}_launch_bound.json 2>/dev/null ; echo rc=$?
+rm -rf $O/stats $O/stats_cfg $O/stats_mx $O/pmc_fetch $O/pmc_write
 ls -la $O
 head -c 1500 $O/${R}_bench.json
