@@ -174,6 +174,7 @@ def main() -> int:
         if ev:
             ev[2].record(stream)
         ex.exchange()  # N > 1: one RCCL all-gather of 64 bytes per rank; N = 1: a device-side copy
+        ex.fold_on_device(ctx)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
 
     def fence():
         if distributed:

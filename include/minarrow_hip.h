@@ -201,6 +201,16 @@ ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const 
                          const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
                          double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts);
 
+/* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
+ * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =
+ * stride_words x u64 (>= 5 used): [0] integer sum, [1] integer valid count, [2] f64 hi bits, [3] f64 lo bits (the
+ * ma_f64_sum_dd pair), [4] float valid count. Folded strictly in record order (wrapping adds; error-free two-sum for
+ * the pairs), so every rank obtains bit-identical finals and the f64 total stays within 1 ULP of the exactly rounded
+ * sum. out4 = [integer sum, integer count, f64 sum bits, float count]. Buffers: device-reachable for an async
+ * (enqueue-only) call, or host memory in sync mode. */
+ma_status ma_fold_sum_records(ma_ctx* ctx, const uint64_t* records, size_t n_records, size_t stride_words,
+                              uint64_t* out4);
+
 /* ------------------------------------------------------------------------------------------------
  * Elementwise arithmetic — same names, argument order and meaning as the reference's L3 functions:
  *   apply_int_{i32,u32,i64,u64}(lhs, rhs, op, mask) -> Result<IntegerArray<T>, KernelError>

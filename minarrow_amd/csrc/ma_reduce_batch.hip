@@ -1,7 +1,7 @@
 // Per-column sums of MANY columns in two launches — the "per-column reduce" of a wide or chunked table
 // (BASELINE config 5; the reference sums column by column, one loop per Array: benches/hotloop_benchmark_std.rs:
 // 109-127 through the enum, src/structs/chunked/super_table.rs columns). One kernel launch per column costs ~4 us of
-// dispatch on MI355X whatever its size (profiles/r01_graph.json), so a 1000-column table of 1000-row columns is
+// dispatch on MI355X whatever its size (profiles/r01_launch_bound.json), so a 1000-column table of 1000-row columns is
 // launch-bound by three orders of magnitude; here the launch count is independent of the column count.
 //
 //   pass 1  every column is cut into segments of kSegRows rows; one workgroup reduces one segment at a time
@@ -274,5 +274,57 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     MA_HIP(hipGetLastError());
     // The scratch is freed when this frame unwinds, after a stream synchronise: the call is synchronous even in
     // async mode (documented in the header).
+    return end_call(ctx, scope);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fold of per-rank reduction records — the step after the all-gather of a row-chunk partitioned reduction
+// (minarrow_amd/parallel.py; the Rayon `.sum()` over per-chunk partials, benches/benchmark_parallel_simd.rs:87).
+// record r = 8 x u64: [0] integer sum, [1] integer valid count, [2] f64 hi bits, [3] f64 lo bits, [4] float valid
+// count. Folded strictly in record order by ONE lane, so every rank computes bit-identical finals:
+// wrapping u64 adds; (hi, lo) pairs by Knuth two-sum, lo += e + l, final = hi + lo when both are finite.
+// out = 4 x u64: [0] integer sum, [1] integer count, [2] f64 sum bits, [3] float count.
+// ------------------------------------------------------------------------------------------------
+namespace ma {
+__global__ void fold_records_kernel(const uint64_t* __restrict__ rec, size_t n, size_t stride, uint64_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t isum = 0, icnt = 0, fcnt = 0;
+    double hi = 0.0, lo = 0.0;
+    for (size_t r = 0; r < n; ++r) {
+        const uint64_t* p = rec + r * stride;
+        isum += p[0];
+        icnt += p[1];
+        const double h = __longlong_as_double((long long)p[2]), l = __longlong_as_double((long long)p[3]);
+        const double s = hi + h;
+        const double bp = s - hi;
+        const double e = (hi - (s - bp)) + (h - bp);
+        hi = s;
+        lo += e + l;
+        fcnt += p[4];
+    }
+    const double total = (isfinite(hi) && isfinite(lo)) ? hi + lo : hi;
+    out[0] = isum;
+    out[1] = icnt;
+    out[2] = (uint64_t)__double_as_longlong(total);
+    out[3] = fcnt;
+}
+}  // namespace ma
+
+extern "C" ma_status ma_fold_sum_records(ma_ctx* ctx, const uint64_t* records, size_t n_records, size_t stride_words,
+                                         uint64_t* out4) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(records != nullptr && out4 != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_REQUIRE(stride_words >= 5, MA_ERR_INVALID_ARGUMENT, "a record has 5 words; stride_words = %zu", stride_words);
+    MA_REQUIRE(((uintptr_t)records & 7) == 0 && ((uintptr_t)out4 & 7) == 0, MA_ERR_INVALID_ARGUMENT, "misaligned buffer");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    const void* r = nullptr;
+    void* o = nullptr;
+    MA_TRY(scope.in(records, n_records * stride_words * 8, &r));
+    MA_TRY(scope.out(out4, 32, &o));
+    hipLaunchKernelGGL(fold_records_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)r, n_records, stride_words,
+                       (uint64_t*)o);
+    MA_HIP(hipGetLastError());
     return end_call(ctx, scope);
 }

@@ -296,6 +296,10 @@ class Context:
                                           cast(off_arr), addr_of(f), addr_of(i), addr_of(c)))
         return f, (i if fmt in "iIlL" else None), c
 
+    def fold_sum_records(self, records, n_records: int, stride_words: int, out4) -> None:
+        """Device-side, rank-ordered fold of gathered reduction records (ma_fold_sum_records)."""
+        ffi.check(self.lib.ma_fold_sum_records(self.handle, addr_of(records), int(n_records), int(stride_words), addr_of(out4)))
+
     # -- elementwise arithmetic --------------------------------------------------------------------
     def apply(self, tag: str, lhs, rhs, op: int, out, n_lhs: int, n_rhs: int, mask=None, mask_bit_offset: int = 0,
               out_mask=None) -> None:

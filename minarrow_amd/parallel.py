@@ -82,6 +82,8 @@ class ScalarExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local = torch.zeros(self.RECORD, dtype=torch.int64, device=device)
         self.gathered = torch.zeros(self.RECORD * self.world, dtype=torch.int64, device=device)
+        self.final = torch.zeros(4, dtype=torch.int64, device=device)  # written by fold_on_device
+        self._folded_on_device = False
 
     def slot_ptr(self, index: int) -> int:
         """Device address of slot `index` of this rank's record (what the kernels write into)."""
@@ -94,6 +96,12 @@ class ScalarExchange:
         else:
             self.gathered.copy_(self.local)
 
+    def fold_on_device(self, ctx) -> None:
+        """Enqueue the rank-ordered fold of the gathered records on `ctx`'s stream (ma_fold_sum_records): the job's
+        final scalars are then produced on the GPU, inside the step, identically on every rank."""
+        ctx.fold_sum_records(int(self.gathered.data_ptr()), self.world, self.RECORD, int(self.final.data_ptr()))
+        self._folded_on_device = True
+
     def set_local(self, int_sum: int = 0, int_count: int = 0, hi: float = 0.0, lo: float = 0.0, f_count: int = 0) -> None:
         """Host-side fill of the local record (used by the CPU tests; on GPUs the kernels write it)."""
         rec = np.zeros(self.RECORD, dtype=np.int64)
@@ -104,8 +112,11 @@ class ScalarExchange:
         self.local.copy_(self.torch.from_numpy(rec))
 
     def results(self):
-        """Host copy of every rank's record, folded in rank order:
-        (int_sum as unsigned 64-bit pattern, int_count, f64_sum, f64_count)."""
+        """(int_sum as unsigned 64-bit pattern, int_count, f64_sum, f64_count): the device-folded finals when
+        `fold_on_device` ran, else a host fold of every rank's record in rank order (the gloo / CPU path)."""
+        if self._folded_on_device:
+            f = self.final.cpu().numpy()
+            return int(f[0]) & _MASK64, int(f[1]), float(f[2:3].view(np.float64)[0]), int(f[3])
         g = self.gathered.cpu().numpy().reshape(self.world, self.RECORD)
         int_sum = fold_int([int(v) for v in g[:, 0]])
         pairs = [tuple(g[r, 2:4].view(np.float64).tolist()) for r in range(self.world)]

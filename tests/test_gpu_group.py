@@ -49,3 +49,37 @@ def test_group_sums_match_single_array(ctx, oracle, members):
         assert c.value == int(valid.sum()) and abs(f.value - exact) <= math.ulp(exact)
     finally:
         lib.ma_group_destroy(g)
+
+
+def test_device_fold_of_records_equals_the_host_fold(ctx):
+    """ma_fold_sum_records (the step after the all-gather) against minarrow_amd.parallel's host fold, bit for bit,
+    incl. cancellation between ranks, and against the exact sum."""
+    import math
+
+    from minarrow_amd.parallel import fold_dd, fold_int
+
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 8, 64):
+        rec = np.zeros((world, 8), dtype=np.uint64)
+        ints = rng.integers(-2**62, 2**62, size=world, dtype=np.int64)
+        his = (rng.standard_normal(world) * 1e17)
+        his[::2] *= -1
+        los = his * 2.0**-55 * rng.standard_normal(world)
+        rec[:, 0] = ints.view(np.uint64)
+        rec[:, 1] = rng.integers(0, 2**40, size=world, dtype=np.uint64)
+        rec[:, 2] = his.view(np.uint64)
+        rec[:, 3] = los.view(np.uint64)
+        rec[:, 4] = rng.integers(0, 2**40, size=world, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        ctx.fold_sum_records(rec, world, 8, out)
+        assert int(out[0]) == fold_int([int(v) for v in rec[:, 0]])
+        assert int(out[1]) == int(rec[:, 1].astype(object).sum()) and int(out[3]) == int(rec[:, 4].astype(object).sum())
+        want = fold_dd(list(zip(his.tolist(), los.tolist())))
+        got = float(out[2:3].view(np.float64)[0])
+        assert got == want
+        exact = math.fsum(his.tolist() + los.tolist())
+        assert abs(got - exact) <= 2 * math.ulp(exact) + abs(exact) * 2**-100
+        # device-resident records and output (the async bench path)
+        drec, dout = ctx.to_device(rec), ctx.alloc(32)
+        ctx.fold_sum_records(drec, world, 8, dout)
+        np.testing.assert_array_equal(dout.download(np.uint64, 4), out)

@@ -87,6 +87,7 @@ def main():
         def step():
             ctx.sum_into("i64", data, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1), mask=mask)
             ex.exchange()
+            ex.fold_on_device(ctx)
 
         for _ in range(3):
             step()
