@@ -83,6 +83,8 @@ struct ma_ctx {
     bool pending_flags = false;        // async mode: dev_flags must be inspected at the next synchronize
     bool capturing = false;            // between ma_ctx_capture_begin / _end: calls are recorded into a hipGraph
     bool async_before_capture = false;
+    void* scratch = nullptr;           // grow-only device scratch for descriptor tables / per-segment partials
+    size_t scratch_bytes = 0;          //   (one user at a time: callers hold `mu` and order their use on `stream`)
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
@@ -147,6 +149,10 @@ ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_c
                         const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
                         const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
                         uint8_t* const* out_masks, int32_t* out_has_mask);
+
+// `bytes` of device scratch owned by the context (256-byte aligned). Valid until the next ctx_scratch call on this
+// context; the caller holds ctx->mu and enqueues every use on ctx->stream, so successive users are stream-ordered.
+ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out);
 
 // Completes a call: in sync mode waits for the stream. Returns MA_ERR_DEVICE on failure.
 ma_status end_call(ma_ctx* ctx, CallScope& scope);

@@ -26,7 +26,6 @@ struct ChunkDesc {
     size_t last_word;        // last word index holding a window bit
     size_t tile0;            // index of this chunk's first copy tile (prefix sum over chunks)
     unsigned head;           // rows in front of the first 16-byte boundary of the DESTINATION
-    unsigned vec;            // 1 when source and destination share their 16-byte phase (vector copy possible)
 };
 
 __device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ c, int n_chunks, size_t tile) {
@@ -63,10 +62,9 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restr
         }
         if (r0 >= d.len) continue;
         if (r1 - r0 == TILE_ROWS) {
-            // Stores are 16-byte aligned by construction of the tiles. The source shares that phase only when
-            // d.vec; otherwise the same global_load_dwordx4 is issued at an element-aligned address (gfx950 runs
-            // with unaligned access mode on under HSA; a lane's 16 bytes then straddle two 16-byte units, and a
-            // wave's 1 KiB one extra cache line).
+            // Stores are 16-byte aligned by construction of the tiles; the source is read at whatever element-aligned
+            // phase it has with the same global_load_dwordx4 (gfx950 runs with unaligned access mode on under HSA; a
+            // misaligned wave access touches one extra cache line per KiB).
             typedef V VU __attribute__((aligned(1)));
             const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
             const VU* __restrict__ p = (const VU*)(src + w0) + lane;
@@ -279,32 +277,14 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
         const uintptr_t dst_addr = (uintptr_t)po + row * elem_size;
         const uintptr_t mis = dst_addr & 15;
         d.head = mis ? (unsigned)((16 - mis) / elem_size) : 0;
-        d.vec = (((uintptr_t)d.data & 15) == mis) ? 1u : 0u;
         d.tile0 = n_tiles;
         if (d.len) n_tiles += d.len > d.head ? (d.len - d.head + tile_rows - 1) / tile_rows : 1;
         row += chunk_lens[i];
     }
-    const void* ddesc = nullptr;
-    {
-        // descriptor table -> device (always staged: it lives in this frame)
-        void* t = nullptr;
-        MA_HIP(hipMalloc(&t, sizeof(ChunkDesc) * n_chunks));
-        hipError_t e = hipMemcpyAsync(t, desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            (void)hipFree(t);
-            return hip_fail(e, "descriptor upload", __FILE__, __LINE__);
-        }
-        ddesc = t;
-    }
-    struct FreeLater {
-        const void* p;
-        hipStream_t s;
-        ~FreeLater() {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree((void*)p);
-        }
-    } free_desc{ddesc, ctx->stream};
+    void* ddesc = nullptr;  // descriptor table -> device scratch (it lives in this frame: wait for the copy)
+    MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks, &ddesc));
+    MA_HIP(hipMemcpyAsync(ddesc, desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
 
     const ChunkDesc* d = (const ChunkDesc*)ddesc;
     switch (elem_size) {
@@ -333,28 +313,6 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
 // a few funnel-shifted source words (concat_mask_kernel above). Validity follows the numeric rule: present iff any
 // chunk has one, chunks without one contribute all-valid rows (boolean.rs:638-650, arena.rs:416-421).
 // ------------------------------------------------------------------------------------------------
-namespace {
-
-struct DeviceDescs {
-    void* p = nullptr;
-    hipStream_t s = nullptr;
-    ~DeviceDescs() {
-        if (p) {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(p);
-        }
-    }
-    ma_status upload(const std::vector<ChunkDesc>& host, hipStream_t stream) {
-        s = stream;
-        MA_HIP(hipMalloc(&p, sizeof(ChunkDesc) * host.size()));
-        MA_HIP(hipMemcpyAsync(p, host.data(), sizeof(ChunkDesc) * host.size(), hipMemcpyHostToDevice, stream));
-        MA_HIP(hipStreamSynchronize(stream));  // `host` lives in the caller's frame
-        return MA_OK;
-    }
-};
-
-}  // namespace
-
 extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks, const uint8_t* const* chunk_bits,
                                                    const size_t* chunk_bit_offsets, const size_t* chunk_lens,
                                                    const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
@@ -399,17 +357,22 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
         if (has_mask) mask_desc[i] = m;
         row += chunk_lens[i];
     }
-    DeviceDescs dd, md;
-    MA_TRY(dd.upload(data_desc, ctx->stream));
+    // both descriptor tables in one scratch region (they live in this frame: wait for the copies)
+    void* tables = nullptr;
+    MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks * 2, &tables));
+    ChunkDesc* dd = (ChunkDesc*)tables;
+    ChunkDesc* md = dd + n_chunks;
+    MA_HIP(hipMemcpyAsync(dd, data_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
+    if (has_mask) MA_HIP(hipMemcpyAsync(md, mask_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
     uint64_t* ow = nullptr;
     MA_TRY(scope.out_mask(out_bits, total, &ow));
-    launch_concat_mask(ctx, (const ChunkDesc*)dd.p, n_chunks, total, ow);
+    launch_concat_mask(ctx, dd, n_chunks, total, ow);
     MA_HIP(hipGetLastError());
     if (has_mask) {
-        MA_TRY(md.upload(mask_desc, ctx->stream));
         uint64_t* mw = nullptr;
         MA_TRY(scope.out_mask(out_mask, total, &mw));
-        launch_concat_mask(ctx, (const ChunkDesc*)md.p, n_chunks, total, mw);
+        launch_concat_mask(ctx, md, n_chunks, total, mw);
         MA_HIP(hipGetLastError());
     }
     return end_call(ctx, scope);

@@ -156,6 +156,25 @@ ma_status CallScope::finish() {
     return MA_OK;
 }
 
+ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
+    *out = nullptr;
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            MA_HIP(hipStreamSynchronize(ctx->stream));  // the previous user may still be running
+            g_free_generation.fetch_add(1, std::memory_order_relaxed);
+            MA_HIP(hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes + bytes / 2;
+        want = (want + 4095) & ~(size_t)4095;
+        MA_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return MA_OK;
+}
+
 ma_status end_call(ma_ctx* ctx, CallScope& scope) {
     (void)ctx;
     return scope.finish();
@@ -331,6 +350,7 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->result) (void)hipHostFree(ctx->result);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

@@ -250,15 +250,7 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     const size_t desc_bytes = ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
     const size_t bytes = desc_bytes + sizeof(Partial) * (n_segs ? n_segs : 1);
     void* scratch = nullptr;
-    MA_HIP(hipMalloc(&scratch, bytes));
-    struct FreeLater {
-        void* p;
-        hipStream_t s;
-        ~FreeLater() {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(p);
-        }
-    } free_scratch{scratch, ctx->stream};
+    MA_TRY(ctx_scratch(ctx, bytes, &scratch));
     MA_HIP(hipMemcpyAsync(scratch, desc.data(), sizeof(ColDesc) * n_cols, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));  // `desc` is pageable: the copy must leave it before we continue
     const ColDesc* d = (const ColDesc*)scratch;
@@ -272,8 +264,6 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
         default: launch_columns<double>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
     }
     MA_HIP(hipGetLastError());
-    // The scratch is freed when this frame unwinds, after a stream synchronise: the call is synchronous even in
-    // async mode (documented in the header).
     return end_call(ctx, scope);
 }
 

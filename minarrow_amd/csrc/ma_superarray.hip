@@ -27,7 +27,6 @@ struct PairDesc {
     size_t tile0;         // first tile of this chunk
     size_t word0;         // first output-bitmap word of this chunk in the global word numbering
     unsigned head;        // rows before the first 16-byte boundary of `out`
-    unsigned vec;         // lhs, rhs and out share their 16-byte phase
 };
 
 __device__ __forceinline__ int find_pair_by_tile(const PairDesc* __restrict__ d, int n, size_t tile) {
@@ -215,21 +214,12 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
         }
         const uintptr_t mis = (uintptr_t)d.out & 15;
         d.head = mis ? (unsigned)((16 - mis) / sizeof(T)) : 0;
-        d.vec = (((uintptr_t)d.lhs & 15) == mis && ((uintptr_t)d.rhs & 15) == mis) ? 1u : 0u;
         n_tiles += n > d.head ? (n - d.head + TILE_ROWS - 1) / TILE_ROWS : 1;
         n_words += (n + 63) >> 6;
     }
     if (n_tiles == 0) return MA_OK;
     void* ddesc = nullptr;
-    MA_HIP(hipMalloc(&ddesc, sizeof(PairDesc) * n_chunks));
-    struct FreeLater {
-        void* p;
-        hipStream_t s;
-        ~FreeLater() {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(p);
-        }
-    } free_desc{ddesc, ctx->stream};
+    MA_TRY(ctx_scratch(ctx, sizeof(PairDesc) * n_chunks, &ddesc));
     MA_HIP(hipMemcpyAsync(ddesc, descs.data(), sizeof(PairDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));  // `descs` is pageable: the copy must leave it before we continue
     const PairDesc* dd = (const PairDesc*)ddesc;
