@@ -196,7 +196,8 @@ ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* m
  * (col_data[i], col_lens[i]) with optional validity col_masks[i] whose row 0 is bit col_mask_offsets[i] (both
  * tables may be NULL). Outputs are arrays of n_cols entries, any may be NULL: integer formats write the wrapping
  * 64-bit sum to out_sums_i64 and its conversion to out_sums_f64; float formats write out_sums_f64 only (within 1 ULP
- * of the exactly rounded sum, as ma_f64_sum). An empty column yields {0, 0}. The call is synchronous. */
+ * of the exactly rounded sum, as ma_f64_sum). An empty column yields {0, 0}. Like every other entry point it
+ * waits for the results unless the context is in async mode and all buffers are device-reachable. */
 ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
                          const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
                          double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts);
