@@ -53,6 +53,20 @@ __global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, si
 #pragma unroll
             for (int u = 0; u < U; ++u) acc += v[u];
         }
+    } else if (MAP == 3) {
+        // XCD-partitioned: workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the x-th contiguous eighth of
+        // the tiles and its gridDim.x / 8 workgroups walk that eighth round-robin. (The default mapping, tile t ->
+        // workgroup t % grid, interleaves the XCDs at tile granularity instead.)
+        const size_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+        const size_t per = (n_tiles + 7) / 8, t0 = xcd * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+        for (size_t t = t0 + local; t < t1; t += per_xcd_blocks) {
+            const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
+            l2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        }
     } else if (!PIPE) {
         for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
             const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
@@ -143,7 +157,7 @@ int main(int argc, char** argv) {
     ADD(8, 256, true, 0) ADD(4, 256, true, 0) ADD(2, 256, true, 0) ADD(16, 256, true, 0)
     ADD(8, 256, false, 1) ADD(8, 256, true, 1)
     ADD(4, 512, false, 0) ADD(4, 512, true, 0) ADD(8, 512, false, 0) ADD(2, 1024, true, 0) ADD(4, 1024, false, 0)
-    ADDM(8, 256, 1) ADDM(4, 256, 1) ADDM(16, 256, 1) ADDM(8, 256, 2) ADDM(4, 256, 2) ADDM(8, 512, 1) ADDM(8, 128, 1)
+    ADDM(8, 256, 1) ADDM(4, 256, 1) ADDM(16, 256, 1) ADDM(8, 256, 2) ADDM(4, 256, 2) ADDM(8, 512, 1) ADDM(8, 128, 1) ADDM(8, 256, 3) ADDM(4, 256, 3)
     ADD(8, 128, false, 0) ADD(8, 128, true, 0) ADD(16, 128, false, 0) ADD(8, 64, true, 0) ADD(16, 64, false, 0) ADD(16, 64, true, 0)
     for (int r = 0; r < rounds; ++r) {
         for (auto& v : vars) {
