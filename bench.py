@@ -6,7 +6,9 @@ A step = one pass of the hot path over one batch: ma_i64_sum over a 10^9-row Int
 ma_f64_sum_dd over a 10^9-row FloatArray<f64> column (the two loops of benches/benchmark_parallel_simd.rs:99-125),
 both already resident in HBM. With N GPUs every rank owns its own 10^9-row chunk of a N x 10^9-row column
 (row-chunk partition, weak scaling) and the step ends with the exchange of the per-rank scalars over RCCL
-(all-gather of 5 x 8 bytes; the fold is done in rank order so the f64 result stays within 1 ULP).
+(all-gather of one 64-byte record per rank) and their rank-ordered fold on the GPU (ma_fold_sum_records: wrapping
+integer adds, error-free two-sum for the double-double pairs, so the f64 result stays within 1 ULP and every rank
+holds bit-identical finals).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
