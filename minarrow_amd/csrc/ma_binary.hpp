@@ -364,25 +364,25 @@ struct BinaryCall {
     uint8_t* out_mask_bits = nullptr;
 };
 
-// Largest unroll a type can use: the masked kernels need R * UNROLL validity words < 64 per wave run (a wave loads its
+// Largest unroll a type can use: the masked kernels need R * UNROLL validity words <= 64 per wave run (a wave loads its
 // run's words with one lane each); dense kernels have no such limit.
 template <typename T>
 constexpr int clamp_unroll(int unroll, bool masked) {
     constexpr int R = 16 / (int)sizeof(T);
     if (!masked) return unroll == 8 ? 8 : 4;
-    if (R * 4 >= 64) return 2;                  // 1-byte types
-    if (unroll == 8 && R * 8 >= 64) return 4;   // 2-byte types
+    if (R * 4 > 64) return 2;
+    if (unroll == 8 && R * 8 > 64) return 4;    // 1-byte types: 16 rows per lane x 4 = 64 validity words per run
     return unroll == 8 ? 8 : 4;
 }
 
 template <typename T, int OP, int KIND, bool MASKED>
 static void launch_vec(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll) {
     constexpr int R = 16 / (int)sizeof(T);
-    if constexpr (MASKED && R * 4 >= 64) {
+    if constexpr (MASKED && R * 4 > 64) {
         hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
         if (unroll == 8) {
-            if constexpr (!MASKED || R * 8 < 64) {
+            if constexpr (!MASKED || R * 8 <= 64) {
                 hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
                 return;
             }

@@ -95,19 +95,23 @@ __device__ __forceinline__ uint64_t load_agent(const uint64_t* p) {
 // ------------------------------------------------------------------------------------------------
 // Validity words for one wave's contiguous run of rows.
 //
-// A run covers WPT consecutive u64 words once it is shifted onto its first bit. Lane k (k <= WPT) loads
+// A run covers WPT <= 64 consecutive u64 words once it is shifted onto its first bit. Lane k (k <= WPT) loads
 // word w0+k; the pair (k, k+1) is funnel-shifted by the run's sub-word bit offset, so lane k ends up with
 // run-word k: bit j of it is the validity of run row 64*k + j. Works for ANY bit offset.
 // ------------------------------------------------------------------------------------------------
 template <int WPT>
 __device__ __forceinline__ uint64_t load_run_words(const uint64_t* __restrict__ words, size_t bit0, size_t last_word,
                                                    unsigned lane) {
-    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+    static_assert(WPT <= 64, "a wave loads its run's validity words with one lane each");
     const size_t w0 = bit0 >> 6;
     const unsigned sh = (unsigned)(bit0 & 63);
     uint64_t mw = 0;
     if (lane <= (unsigned)WPT && w0 + lane <= last_word) mw = words[w0 + lane];
     uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
+    if constexpr (WPT == 64) {
+        // all 64 lanes hold a run word; the last one needs word 64 for its funnel shift and fetches it itself
+        if (lane == 63) nx = (sh && w0 + 64 <= last_word) ? words[w0 + 64] : 0;
+    }
     return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
 }
 
