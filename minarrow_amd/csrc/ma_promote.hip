@@ -133,7 +133,7 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
         MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, out_words));  // float ops: validity out == validity in
     }
     constexpr int R = 16 / (int)sizeof(OT);
-    constexpr int U = 4;
+    constexpr int U = 8;  // launch shape of the elementwise kernels: 8 accesses per operand in flight, 6 workgroups per CU
     const size_t tile_rows = (size_t)64 * R * U * kWaves;
     // vector path: `head` rows are peeled so that the output stores are 16-byte aligned
     const uintptr_t mis = (uintptr_t)a.out & 15;
@@ -143,7 +143,7 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
     a.head = head;
     a.n_tiles = (lhs_ok && rhs_ok) ? (n - head) / tile_rows : 0;
     if (!(lhs_ok && rhs_ok)) a.head = 0;
-    int grid = a.n_tiles ? grid_for(ctx, a.n_tiles, 2) : grid_for(ctx, (n + kBlock - 1) / kBlock, 8);
+    int grid = a.n_tiles ? grid_for(ctx, a.n_tiles, 6) : grid_for(ctx, (n + kBlock - 1) / kBlock, 8);
     if (masked) hipLaunchKernelGGL((promote_kernel<LT, RT, OT, true, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     else hipLaunchKernelGGL((promote_kernel<LT, RT, OT, false, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     MA_HIP(hipGetLastError());
