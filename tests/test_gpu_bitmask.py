@@ -278,3 +278,36 @@ def test_one_billion_bit_masks(ctx):
     ctx.mask_words_op("or_masks", m, 0, inv, 0, n, both)
     assert ctx.all_true_mask(both, n)
     assert ctx.mask_all("all_ne", m, 0, inv, 0, n) and not ctx.mask_all("all_eq", m, 0, inv, 0, n)
+
+
+def test_bitmask_struct_vectors(ctx, oracle):
+    """The reference's Bitmask struct tests (src/structs/bitmask.rs:919-1108) through the C ABI."""
+    import json
+    from pathlib import Path
+
+    k = json.loads((Path(__file__).resolve().parent / "golden" / "bitmask_struct_kat.json").read_text())
+
+    def dev(bools):
+        return ctx.to_device(oracle.pad_bits(oracle.pack_bits(bools), len(bools)), 16)
+
+    for c in k["count_and_all"]["cases"]:
+        n = len(c["bits"])
+        d = dev(c["bits"])
+        assert ctx.popcount_mask(d, 0, n) == c["count_ones"]
+        assert ctx.all_true_mask(d, n) == c["all_set"] and ctx.all_false_mask(d, n) == c["all_unset"]
+    c = k["invert_union_intersect"]
+    a, b, out = dev(c["a"]), dev(c["b"]), ctx.alloc(64)
+    for name, key in (("or_masks", "union"), ("and_masks", "intersect")):
+        ctx.mask_words_op(name, a, 0, b, 0, 8, out)
+        assert unpack(out.download(np.uint8, 8), 8).tolist() == c[key]
+    ctx.mask_unary_op("not_mask", a, 0, 8, out)
+    assert unpack(out.download(np.uint8, 8), 8).tolist() == c["invert_a"]
+    c = k["union_opt"]
+    ctx.mask_words_op("or_masks", dev(c["a"]), 0, dev(c["b"]), 0, 4, out)
+    assert unpack(out.download(np.uint8, 8), 4).tolist() == c["expect"]
+    c = k["slice_clone"]
+    ctx.mask_unary_op("bitmask_slice", dev(c["bits"]), c["offset"], c["len"], out)
+    assert unpack(out.download(np.uint8, 8), c["len"]).tolist() == c["expect"]
+    c = k["concatenate"]
+    assert ctx.consolidate_boolean_column([(dev(c["m1"]), 0, 5), (dev(c["m2"]), 0, 4)], out) is False
+    assert unpack(out.download(np.uint8, 8), 9).tolist() == c["expect"]

@@ -302,3 +302,36 @@ def test_sum_closed_forms_kat(oracle):
             assert oracle.chunked_sum(a) == c["sum"] and oracle.simd_sum(a.astype(np.float64), 4) == float(c["sum"])
         assert c["n"] * (c["n"] - 1) // 2 == c["sum"]
         assert float(c["sum"]) == c["sum"]  # representable
+
+
+# ---- Bitmask struct tests (src/structs/bitmask.rs:919-1108) -----------------------------------------------------
+def _struct_kat():
+    import json
+    from pathlib import Path
+
+    return json.loads((Path(__file__).resolve().parent / "golden" / "bitmask_struct_kat.json").read_text())
+
+
+def test_bitmask_struct_vectors(oracle):
+    k = _struct_kat()
+    for c in k["count_and_all"]["cases"]:
+        bits = oracle.pad_bits(oracle.pack_bits(c["bits"]), len(c["bits"]))
+        n = len(c["bits"])
+        assert oracle.count_ones(bits, n) == c["count_ones"] == oracle.bitmask_popcount(bits, 0, n)
+        assert oracle.all_true(bits, n, lanes=None) == c["all_set"] and oracle.all_false(bits, n, lanes=None) == c["all_unset"]
+    c = k["invert_union_intersect"]
+    a, b = (oracle.pad_bits(oracle.pack_bits(c[x]), 8) for x in ("a", "b"))
+    assert oracle.unpack_bits(oracle.bitmask_binop("or", a, 0, b, 0, 8), 8).tolist() == c["union"]
+    assert oracle.unpack_bits(oracle.bitmask_union(a, b, 8), 8).tolist() == c["union"]
+    assert oracle.unpack_bits(oracle.bitmask_binop("and", a, 0, b, 0, 8), 8).tolist() == c["intersect"]
+    assert oracle.unpack_bits(oracle.bitmask_not(a, 0, 8), 8).tolist() == c["invert_a"]
+    c = k["union_opt"]
+    a, b = (oracle.pad_bits(oracle.pack_bits(c[x]), 4) for x in ("a", "b"))
+    assert oracle.unpack_bits(oracle.bitmask_union(a, b, 4), 4).tolist() == c["expect"]
+    c = k["concatenate"]
+    out, mask = oracle.consolidate_boolean_column([(oracle.pad_bits(oracle.pack_bits(c["m1"]), 5), 0, 5),
+                                                   (oracle.pad_bits(oracle.pack_bits(c["m2"]), 4), 0, 4)])
+    assert mask is None and oracle.unpack_bits(out, 9).tolist() == c["expect"]
+    c = k["slice_clone"]
+    out, _ = oracle.consolidate_boolean_column([(oracle.pad_bits(oracle.pack_bits(c["bits"]), 10), c["offset"], c["len"])])
+    assert oracle.unpack_bits(out, c["len"]).tolist() == c["expect"]
