@@ -236,6 +236,7 @@ inline NumericArray operator+(const NumericArray& l, const NumericArray& r) { re
 inline NumericArray operator-(const NumericArray& l, const NumericArray& r) { return resolve_binary_arithmetic(ArithmeticOperator::Subtract, l, r); }
 inline NumericArray operator*(const NumericArray& l, const NumericArray& r) { return resolve_binary_arithmetic(ArithmeticOperator::Multiply, l, r); }
 inline NumericArray operator/(const NumericArray& l, const NumericArray& r) { return resolve_binary_arithmetic(ArithmeticOperator::Divide, l, r); }
+inline NumericArray operator%(const NumericArray& l, const NumericArray& r) { return resolve_binary_arithmetic(ArithmeticOperator::Remainder, l, r); }
 inline NumericArray operator+(const NumericArray& l, const Scalar& r) { return broadcast_array_to_scalar(ArithmeticOperator::Add, l, r); }
 inline NumericArray operator-(const NumericArray& l, const Scalar& r) { return broadcast_array_to_scalar(ArithmeticOperator::Subtract, l, r); }
 inline NumericArray operator*(const NumericArray& l, const Scalar& r) { return broadcast_array_to_scalar(ArithmeticOperator::Multiply, l, r); }

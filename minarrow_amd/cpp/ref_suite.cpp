@@ -276,6 +276,19 @@ static void routing_suite() {
     ASSERT(is_i32(i32s({10, 20, 30}) - i32s({1, 2, 3}), {9, 18, 27}));
     ASSERT(is_i32(i32s({2, 3, 4}) * i32s({5, 6, 7}), {10, 18, 28}));
     ASSERT(is_i32(i32s({100, 200, 300}) / i32s({10, 20, 30}), {10, 10, 10}));
+    // Value-level operators — src/kernels/arithmetic/types.rs:921-1054 (test_value_addition, test_all_arithmetic_operators,
+    // test_scalar_array_addition, test_reference_operations, test_broadcasting)
+    ASSERT(is_i32(i32s({10, 20, 30}) + i32s({2, 4, 6}), {12, 24, 36}));
+    ASSERT(is_i32(i32s({10, 20, 30}) - i32s({2, 4, 6}), {8, 16, 24}));
+    ASSERT(is_i32(i32s({10, 20, 30}) * i32s({2, 4, 6}), {20, 80, 180}));
+    ASSERT(is_i32(i32s({10, 20, 30}) / i32s({2, 4, 6}), {5, 5, 5}));
+    ASSERT(is_i32(i32s({10, 20, 30}) % i32s({2, 4, 6}), {0, 0, 0}));
+    ASSERT(is_i32(Scalar(int32_t(5)) + i32s({1, 2, 3}), {6, 7, 8}));
+    ASSERT(is_i32(i32s({10, 20, 30}) / i32s({2, 4, 5}), {5, 5, 6}));
+    ASSERT(is_i32(i32s({10}) * i32s({1, 2, 3, 4, 5}), {10, 20, 30, 40, 50}));
+    // broadcast_scalar_to_array — src/kernels/broadcast/scalar.rs:1086-1116
+    ASSERT(is_i32(broadcast_scalar_to_array(Op::Add, Scalar(int32_t(5)), i32s({10, 20, 30})), {15, 25, 35}));
+    ASSERT(is_i32(broadcast_scalar_to_array(Op::Multiply, Scalar(int32_t(10)), i32s({2, 3, 4})), {20, 30, 40}));
     // test_broadcast_array_to_scalar — array.rs:685-700
     ASSERT(is_i32(broadcast_array_to_scalar(Op::Multiply, i32s({10, 20, 30}), Scalar(int32_t(2))), {20, 40, 60}));
     ASSERT(is_i32(Scalar(int32_t(100)) - i32s({1, 2, 3}), {99, 98, 97}));
