@@ -324,8 +324,7 @@ struct SuperArray {
 };
 
 namespace detail {
-template <typename T>
-const void* chunk_data(const NumericArray& a) {
+inline const void* chunk_data(const NumericArray& a) {
     return std::visit([](const auto& p) -> const void* { return p->data.data(); }, a.v);
 }
 inline int32_t format_code(NumericType t) {
@@ -417,8 +416,8 @@ inline SuperArray route_super_array_broadcast(ArithmeticOperator op, const Super
     std::vector<int32_t> has(k);
     for (size_t i = 0; i < k; ++i) {
         const NumericArray &l = lhs.chunks()[i], &r = rhs.chunks()[i];
-        ld[i] = detail::chunk_data<void>(l);
-        rd[i] = detail::chunk_data<void>(r);
+        ld[i] = detail::chunk_data(l);
+        rd[i] = detail::chunk_data(r);
         ll[i] = l.len();
         rl[i] = r.len();
         lm[i] = l.null_mask() ? l.null_mask()->bits.data() : nullptr;
@@ -447,7 +446,7 @@ inline NumericArray consolidate(const SuperArray& sa) {
     for (size_t i = 0; i < k; ++i) {
         const NumericArray& c = sa.chunks()[i];
         if (c.type() != t) throw KernelError(KernelError::UnsupportedType, "consolidate: chunks of one column must share a type");
-        data[i] = detail::chunk_data<void>(c);
+        data[i] = detail::chunk_data(c);
         lens[i] = c.len();
         masks[i] = c.null_mask() ? c.null_mask()->bits.data() : nullptr;
         any_mask = any_mask || masks[i];
