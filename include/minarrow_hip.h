@@ -443,11 +443,13 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
 /* Results as Arrow C Data — the producer side (create_arrow_export, src/ffi/arrow_c_ffi.rs:1742-1821).
  * Same routing as ma_apply_arrow, but the library allocates the result: values and validity live in pinned host
  * memory the kernels wrote directly (64-byte aligned as check_alignment asserts, arrow_c_ffi.rs:1722-1738) and are
- * returned as an owned ArrowArray / ArrowSchema pair: offset 0 (:1773), n_buffers 2, buffers[0] = NULL and
- * null_count 0 when no operand carried nulls (:1750) else the exact null count, format = the routed result type,
- * flags = ARROW_FLAG_NULLABLE (2, what the reference's import tests, :2631) when a validity buffer is attached.
- * The consumer owns both structs and must call their `release` (frees the pinned buffers; sets release = NULL).
- * `name` NULL -> the left operand's field name. On failure nothing is allocated and both `release` are NULL. */
+ * returned as an owned ArrowArray / ArrowSchema pair with the field values create_arrow_export writes: offset 0
+ * (:1773), n_buffers 2, buffers[0] = NULL and null_count 0 when no operand carried nulls, null_count -1 (unknown)
+ * otherwise (:1750), format = the routed result type, flags = ARROW_FLAG_NULLABLE (2, what the reference's import
+ * tests, :2631) when a validity buffer is attached. The consumer owns both structs and must call their `release`
+ * (sets release = NULL; the pinned memory — one allocation per call, shared by all columns of a batch — goes when the
+ * last array that points into it is released). `name` NULL -> the left operand's field name. On failure nothing is
+ * allocated and both `release` are NULL. */
 ma_status ma_apply_arrow_export(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, const struct ArrowSchema* lhs_schema,
                                 const struct ArrowArray* rhs, const struct ArrowSchema* rhs_schema, const char* name,
                                 struct ArrowArray* out_array, struct ArrowSchema* out_schema);

@@ -7,6 +7,7 @@
 // allocations (ma_alloc64_pinned — page aligned, device-mapped) that the kernels wrote directly, and `release`
 // returns them with ma_free_pinned. Record batches are struct arrays ("+s") with one child per column, the shape
 // the reference's record-batch stream yields (arrow_c_ffi.rs:1823-1834, 2104-2260).
+#include <atomic>
 #include <new>
 #include <string>
 
@@ -16,12 +17,28 @@ using namespace ma;
 
 namespace {
 
+// One pinned allocation per call, shared by every column it produced (hipHostMalloc costs ~100 us, as much as
+// moving a 1 M-row column over PCIe). Children may be moved out of their parent by a consumer, so each array holds
+// its own reference; the last release frees the slab.
+struct Slab {
+    void* base = nullptr;
+    std::atomic<long> refs{0};
+};
+
 struct ArrayHolder {
-    void* values = nullptr;    // pinned
-    void* validity = nullptr;  // pinned, or nullptr
+    Slab* slab = nullptr;      // owner of the memory `values` / `validity` point into
+    void* values = nullptr;
+    void* validity = nullptr;  // nullptr when the result carries no validity
     const void* buffers[2] = {nullptr, nullptr};
     std::vector<ArrowArray*> children;  // struct arrays only (each heap-allocated, released with the parent)
 };
+
+void slab_unref(Slab* s) {
+    if (s && s->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        (void)ma_free_pinned(s->base);
+        delete s;
+    }
+}
 
 struct SchemaHolder {
     std::string format;
@@ -39,8 +56,7 @@ void release_array(ArrowArray* a) {
                 delete c;
             }
         }
-        (void)ma_free_pinned(h->values);
-        (void)ma_free_pinned(h->validity);
+        slab_unref(h->slab);
         delete h;
     }
     a->private_data = nullptr;
@@ -94,9 +110,15 @@ char result_format(const char* lf, const char* rf) {
     return 0;
 }
 
-// Computes lhs (op) rhs into freshly allocated pinned buffers and wraps them in an owned ArrowArray / ArrowSchema.
-ma_status export_one(ma_ctx* ctx, int32_t op, const ArrowArray* lhs, const ArrowSchema* ls, const ArrowArray* rhs,
-                     const ArrowSchema* rs, const char* name, ArrowArray* out, ArrowSchema* out_schema) {
+struct ColumnPlan {
+    char fmt;
+    size_t n;
+    size_t values_off, validity_off;  // byte offsets into the slab (64-byte aligned, arrow_c_ffi.rs:1722-1738)
+};
+
+// Validates one column pair against the routing rules and reserves its place in the slab.
+ma_status plan_column(const ArrowArray* lhs, const ArrowSchema* ls, const ArrowArray* rhs, const ArrowSchema* rs, size_t* cursor,
+                      ColumnPlan* out) {
     MA_REQUIRE(lhs && ls && rhs && rs, MA_ERR_INVALID_ARGUMENT, "ArrowArray or ArrowSchema is NULL");
     const char fmt = result_format(ls->format, rs->format);
     if (fmt == 0) {
@@ -110,50 +132,93 @@ ma_status export_one(ma_ctx* ctx, int32_t op, const ArrowArray* lhs, const Arrow
         set_error("cannot broadcast arrays of length %zu and %zu", nl, nr);
         return MA_ERR_LENGTH_MISMATCH;
     }
-    const size_t n = nl == nr ? nl : (nl == 1 ? nr : nl);
-    ArrayHolder* h = new (std::nothrow) ArrayHolder();
-    SchemaHolder* sh = new (std::nothrow) SchemaHolder();
-    ma_status st = (h && sh) ? MA_OK : MA_ERR_DEVICE;
-    if (st == MA_OK) st = ma_alloc64_pinned(n * format_size(fmt), &h->values);
-    // The validity words are always provided; whether they become buffers[0] is decided by the routing.
-    if (st == MA_OK) st = ma_alloc64_pinned(((n + 63) / 64) * 8 + 8, &h->validity);
-    int32_t has_validity = 0;
-    if (st == MA_OK)
-        st = ma_apply_arrow(ctx, op, lhs, ls, rhs, rs, h->values, (uint8_t*)h->validity, &has_validity);
-    int64_t null_count = 0;
-    if (st == MA_OK && has_validity) {
-        uint64_t ones = 0;
-        st = ma_popcount_mask(ctx, (const uint8_t*)h->validity, 0, n, &ones);
-        null_count = (int64_t)n - (int64_t)ones;
-    }
+    out->fmt = fmt;
+    out->n = nl == nr ? nl : (nl == 1 ? nr : nl);
+    auto reserve = [&](size_t bytes) {
+        const size_t at = *cursor;
+        *cursor += (bytes + 63) & ~(size_t)63;
+        return at;
+    };
+    out->values_off = reserve(out->n * format_size(fmt));
+    out->validity_off = reserve(((out->n + 63) / 64) * 8 + 8);  // reserved even if the routing ends up dense
+    return MA_OK;
+}
+
+// lhs[c] (op) rhs[c] for n_cols column pairs: ONE pinned slab, every kernel enqueued back to back (the context is
+// switched to async for the duration), ONE synchronise, then the owned ArrowArray / ArrowSchema pairs are filled in.
+// null_count follows create_arrow_export (arrow_c_ffi.rs:1750): 0 without a validity buffer, -1 (unknown) with one.
+ma_status export_columns(ma_ctx* ctx, int32_t op, size_t n_cols, const ArrowArray* const* lhs, const ArrowSchema* const* ls,
+                         const ArrowArray* const* rhs, const ArrowSchema* const* rs, const char* const* names,
+                         ArrowArray* const* out, ArrowSchema* const* out_schema) {
+    std::vector<ColumnPlan> plan(n_cols);
+    size_t bytes = 0;
+    for (size_t c = 0; c < n_cols; ++c) MA_TRY(plan_column(lhs[c], ls[c], rhs[c], rs[c], &bytes, &plan[c]));
+    Slab* slab = new (std::nothrow) Slab();
+    MA_REQUIRE(slab != nullptr, MA_ERR_DEVICE, "out of host memory");
+    ma_status st = ma_alloc64_pinned(bytes ? bytes : 64, &slab->base);
     if (st != MA_OK) {
-        if (h) {
-            (void)ma_free_pinned(h->values);
-            (void)ma_free_pinned(h->validity);
-        }
-        delete h;
-        delete sh;
+        delete slab;
         return st;
     }
-    if (!has_validity) {  // create_arrow_export: no validity buffer <=> null_count 0 (arrow_c_ffi.rs:1750)
-        (void)ma_free_pinned(h->validity);
-        h->validity = nullptr;
+    bool was_async;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        was_async = ctx->async;
     }
-    h->buffers[0] = h->validity;
-    h->buffers[1] = h->values;
-    memset(out, 0, sizeof(*out));
-    out->length = (int64_t)n;
-    out->null_count = null_count;
-    out->offset = 0;  // arrow_c_ffi.rs:1773
-    out->n_buffers = 2;
-    out->n_children = 0;
-    out->buffers = h->buffers;
-    out->children = nullptr;
-    out->dictionary = nullptr;
-    out->release = release_array;
-    out->private_data = h;
-    const char f[2] = {fmt, 0};
-    fill_schema(out_schema, f, name, has_validity != 0, sh);
+    (void)ma_ctx_set_async(ctx, 1);
+    std::vector<int32_t> has_validity(n_cols, 0);
+    for (size_t c = 0; c < n_cols && st == MA_OK; ++c)
+        st = ma_apply_arrow(ctx, op, lhs[c], ls[c], rhs[c], rs[c], (char*)slab->base + plan[c].values_off,
+                            (uint8_t*)slab->base + plan[c].validity_off, &has_validity[c]);
+    // everything enqueued so far must drain before the buffers are handed out (or freed); a dense integer division by
+    // zero recorded by any column surfaces here
+    ma_status sync = ma_ctx_synchronize(ctx);
+    (void)ma_ctx_set_async(ctx, was_async ? 1 : 0);
+    if (st == MA_OK) st = sync;
+    if (st != MA_OK) {
+        (void)ma_free_pinned(slab->base);
+        delete slab;
+        return st;
+    }
+    std::vector<ArrayHolder*> holders(n_cols, nullptr);
+    std::vector<SchemaHolder*> sholders(n_cols, nullptr);
+    bool oom = false;
+    for (size_t c = 0; c < n_cols; ++c) {
+        holders[c] = new (std::nothrow) ArrayHolder();
+        sholders[c] = new (std::nothrow) SchemaHolder();
+        oom = oom || !holders[c] || !sholders[c];
+    }
+    if (oom) {
+        for (size_t c = 0; c < n_cols; ++c) {
+            delete holders[c];
+            delete sholders[c];
+        }
+        (void)ma_free_pinned(slab->base);
+        delete slab;
+        set_error("out of host memory");
+        return MA_ERR_DEVICE;
+    }
+    slab->refs.store((long)n_cols + 1, std::memory_order_relaxed);  // +1: this frame, dropped below
+    for (size_t c = 0; c < n_cols; ++c) {
+        ArrayHolder* h = holders[c];
+        h->slab = slab;
+        h->values = (char*)slab->base + plan[c].values_off;
+        h->validity = has_validity[c] ? (char*)slab->base + plan[c].validity_off : nullptr;
+        h->buffers[0] = h->validity;
+        h->buffers[1] = h->values;
+        ArrowArray* a = out[c];
+        memset(a, 0, sizeof(*a));
+        a->length = (int64_t)plan[c].n;
+        a->null_count = has_validity[c] ? -1 : 0;
+        a->offset = 0;  // arrow_c_ffi.rs:1773
+        a->n_buffers = 2;
+        a->buffers = h->buffers;
+        a->release = release_array;
+        a->private_data = h;
+        const char f[2] = {plan[c].fmt, 0};
+        fill_schema(out_schema[c], f, names[c], has_validity[c] != 0, sholders[c]);
+    }
+    slab_unref(slab);  // n_cols == 0: frees the (empty) slab
     return MA_OK;
 }
 
@@ -182,8 +247,8 @@ ma_status ma_apply_arrow_export(ma_ctx* ctx, int32_t op, const struct ArrowArray
     MA_NO_CAPTURE(ctx, "ma_apply_arrow_export");
     out_array->release = nullptr;
     out_schema->release = nullptr;
-    return export_one(ctx, op, lhs, lhs_schema, rhs, rhs_schema, name ? name : (lhs_schema ? lhs_schema->name : nullptr),
-                      out_array, out_schema);
+    const char* nm = name ? name : (lhs_schema ? lhs_schema->name : nullptr);
+    return export_columns(ctx, op, 1, &lhs, &lhs_schema, &rhs, &rhs_schema, &nm, &out_array, &out_schema);
 }
 
 // Table (op) Table — broadcast_table_with_operator, src/kernels/broadcast/table.rs:31-63: the tables must have the
@@ -210,34 +275,41 @@ ma_status ma_apply_arrow_batch_export(ma_ctx* ctx, int32_t op, const struct Arro
     ArrayHolder* h = new (std::nothrow) ArrayHolder();
     SchemaHolder* sh = new (std::nothrow) SchemaHolder();
     MA_REQUIRE(h && sh, MA_ERR_DEVICE, "out of host memory");
-    ma_status st = MA_OK;
-    for (size_t c = 0; c < n_cols && st == MA_OK; ++c) {
-        // A struct's offset applies to its children on top of their own (Arrow C Data Interface).
-        ArrowArray l = *lhs_batch->children[c], r = *rhs_batch->children[c];
-        l.offset += lhs_batch->offset;
-        r.offset += rhs_batch->offset;
-        if (lhs_batch->offset || lhs_batch->children[c]->length > lhs_batch->length) l.length = lhs_batch->length;
-        if (rhs_batch->offset || rhs_batch->children[c]->length > rhs_batch->length) r.length = rhs_batch->length;
+    // A struct's offset applies to its children on top of their own (Arrow C Data Interface).
+    std::vector<ArrowArray> lkids(n_cols), rkids(n_cols);
+    std::vector<const ArrowArray*> lp(n_cols), rp(n_cols);
+    std::vector<const ArrowSchema*> lsp(n_cols), rsp(n_cols);
+    std::vector<const char*> names(n_cols);
+    bool oom = false;
+    for (size_t c = 0; c < n_cols; ++c) {
+        lkids[c] = *lhs_batch->children[c];
+        rkids[c] = *rhs_batch->children[c];
+        lkids[c].offset += lhs_batch->offset;
+        rkids[c].offset += rhs_batch->offset;
+        if (lhs_batch->offset || lhs_batch->children[c]->length > lhs_batch->length) lkids[c].length = lhs_batch->length;
+        if (rhs_batch->offset || rhs_batch->children[c]->length > rhs_batch->length) rkids[c].length = rhs_batch->length;
+        lp[c] = &lkids[c];
+        rp[c] = &rkids[c];
+        lsp[c] = lhs_schema->children[c];
+        rsp[c] = rhs_schema->children[c];
+        names[c] = lhs_schema->children[c]->name;
         ArrowArray* oa = new (std::nothrow) ArrowArray();
         ArrowSchema* os = new (std::nothrow) ArrowSchema();
-        if (!oa || !os) {
-            delete oa;
-            delete os;
-            set_error("out of host memory");
-            st = MA_ERR_DEVICE;
-            break;
-        }
-        st = export_one(ctx, op, &l, lhs_schema->children[c], &r, rhs_schema->children[c], lhs_schema->children[c]->name,
-                        oa, os);
-        if (st != MA_OK) {
-            delete oa;
-            delete os;
-            break;
-        }
+        if (oa) memset(oa, 0, sizeof(*oa));
+        if (os) memset(os, 0, sizeof(*os));
+        oom = oom || !oa || !os;
         h->children.push_back(oa);
         sh->children.push_back(os);
     }
-    if (st != MA_OK) {
+    ma_status st = MA_OK;
+    if (oom) {
+        set_error("out of host memory");
+        st = MA_ERR_DEVICE;
+    } else {
+        st = export_columns(ctx, op, n_cols, lp.data(), lsp.data(), rp.data(), rsp.data(), names.data(), h->children.data(),
+                            sh->children.data());
+    }
+    if (st != MA_OK) {  // nothing was produced: the child structs are empty shells (release == NULL)
         ArrowArray tmp{};
         tmp.release = release_array;
         tmp.private_data = h;

@@ -45,8 +45,8 @@ def test_exported_array_is_importable_and_equal(ctx, fmt):
             assert owned.array.n_children == 0 and not owned.array.dictionary
             assert owned.schema.format == fmt.encode() and owned.schema.name == b"result"
             want = fn(lhs, rhs)
-            assert owned.array.null_count == want.null_count
             has_validity = bool(owned.array.buffers[0])
+            assert owned.array.null_count == (-1 if has_validity else 0)  # create_arrow_export, arrow_c_ffi.rs:1750
             assert has_validity == (lhs.null_count + rhs.null_count > 0)
             assert owned.schema.flags == (2 if has_validity else 0)
             for k in range(2):
@@ -177,3 +177,32 @@ def test_table_errors(ctx):
         with pytest.raises(ffi.MinarrowHipError) as e:
             ctx.apply_arrow_batch_export(0, (a.array_ptr, a.schema_ptr), (b.array_ptr, b.schema_ptr))
     assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH
+
+
+def test_wide_table_shares_one_pinned_slab_and_columns_outlive_the_batch(ctx):
+    """300 columns in one call: one pinned allocation, every kernel enqueued back to back, one synchronise. A column
+    kept alive after the batch is gone still reads its values (each array holds its own reference on the slab)."""
+    import gc
+    import time
+
+    rng = np.random.default_rng(30)
+    n, k = 1000, 300
+    L = pa.RecordBatch.from_pydict({f"c{i}": pa.array(rng.integers(0, 100, size=n), type=pa.int64()) for i in range(k)})
+    R = pa.RecordBatch.from_pydict({f"c{i}": pa.array(rng.integers(0, 100, size=n), type=pa.int64(),
+                                                       mask=(rng.random(n) < 0.1) if i % 2 else None) for i in range(k)})
+    with Exported(L) as a, Exported(R) as b:
+        t0 = time.perf_counter()
+        owned = ctx.apply_arrow_batch_export(OPS["add"], (a.array_ptr, a.schema_ptr), (b.array_ptr, b.schema_ptr))
+        dt = time.perf_counter() - t0
+    assert dt < 0.5  # was ~0.1 s of hipHostMalloc alone with two pinned allocations per column
+    # all value buffers come from one allocation: consecutive, 64-byte aligned offsets
+    ptrs = [owned.array.children[i].contents.buffers[1] for i in range(k)]
+    assert all(p % 64 == 0 for p in ptrs) and max(ptrs) - min(ptrs) < k * (n * 8 + 4096)
+    got = owned.to_pyarrow(record_batch=True)
+    keep = got.column(7)
+    want7 = pc.add(L.column(7), R.column(7))
+    for i in (0, 1, 150, 299):
+        assert got.column(i).equals(pc.add(L.column(i), R.column(i)))
+    del got, owned
+    gc.collect()
+    assert keep.equals(want7) and keep.null_count == want7.null_count
