@@ -138,9 +138,22 @@ def main():
                                                                  mask=om), args.reps)
             ctx.set_async(False)
             ctx.synchronize()
+            # the same per-chunk reduce as ONE ma_sum_columns call (two launches, host wall clock incl. the call overhead)
+            fmt = "l" if tag == "i64" else "g"
+            f_cols, i_cols, c_cols = ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
+            import time as _t
+            t0 = _t.perf_counter()
+            for _ in range(args.reps):
+                ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
+            ms_reduce_columns = (_t.perf_counter() - t0) / args.reps * 1e3
+            col_sums = [int(v) for v in i_cols] if tag == "i64" else [float(v) for v in f_cols]
+            assert [int(c) for c in c_cols] == [p[1] for p in parts]
+            assert all((a == b[0]) if tag == "i64" else (abs(a - b[0]) <= abs(b[0]) * 2**-52) for a, b in zip(col_sums, parts))
             res[tag] = {"consolidate_ms": ms, "consolidate_gbps": 16.25 * k * rows / ms / 1e6,
                         "consolidate_grows_per_s": k * rows / ms / 1e6,
                         "reduce_logical_ms": ms_reduce_logical, "reduce_logical_grows_per_s": k * rows / ms_reduce_logical / 1e6,
+                        "reduce_logical_one_call_ms_wall": ms_reduce_columns,
+                        "reduce_logical_one_call_grows_per_s": k * rows / ms_reduce_columns / 1e6,
                         "reduce_physical_ms": ms_reduce_physical, "reduce_physical_grows_per_s": k * rows / ms_reduce_physical / 1e6,
                         "count_matches": whole[1] == sum(p[1] for p in parts),
                         "sum_matches": (whole[0] == sum(p[0] for p in parts)) if tag == "i64" else
