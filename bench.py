@@ -95,6 +95,19 @@ def cpu_baseline(rows: int, budget_s: float):
         total_time = (detail["i64"]["best_ms"] + detail["f64"]["best_ms"]) * 1e-3
         results[threads] = {"value": 2 * rows / total_time / 1e9, **detail}
     best_threads = max(results, key=lambda t: results[t]["value"])
+    # BASELINE configs[0], the reference's own CPU-runnable case: the single-thread loops of
+    # benches/hotloop_benchmark_std.rs:49-57 (scalar) and hotloop_benchmark_simd.rs:56-114 (4 lanes) over 10^6 rows.
+    small = np.arange(1_000_000, dtype=np.int64)
+    assert oracle.sum_scalar(small) == 499_999_500_000 == oracle.simd_sum(small, 4)
+    config0 = {}
+    for name, fn in (("scalar_loop", lambda: oracle.sum_scalar(small)), ("simd4", lambda: oracle.simd_sum(small, 4))):
+        times = []
+        for _ in range(300):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        config0[name] = {"best_us": min(times) * 1e6, "median_us": sorted(times)[len(times) // 2] * 1e6,
+                         "grows_per_s": small.size / min(times) / 1e9}
     return {
         "value": results[best_threads]["value"],
         "unit": "Grows/s",
@@ -105,6 +118,7 @@ def cpu_baseline(rows: int, budget_s: float):
                   f"{quota if quota else 'none'}), best of N reps "
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
         "detail": {str(t): r for t, r in results.items()},
+        "config0_1m_rows": config0,
     }
 
 
@@ -183,6 +197,8 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
+    fence()
     for _ in range(args.warmup):
         step()
     fence()

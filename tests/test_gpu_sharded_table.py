@@ -1,0 +1,100 @@
+"""GPU side of the rank-sharded SuperTable path (minarrow_amd/parallel.py): the device fold of per-(batch, column)
+records and the bit-granular join of gathered validity pieces. The collectives themselves are covered over gloo in
+tests/test_parallel_gloo.py; a GPU box has one card, so the exchange here is the one-rank copy."""
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from minarrow_amd.host import Context
+
+    dev = torch.device("cuda", 0)
+    ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    yield torch, dev, ctx
+    ctx.close()
+
+
+def test_per_batch_records_fold_in_batch_order(env):
+    torch, dev, ctx = env
+    from minarrow_amd.parallel import ScalarExchange
+
+    rng = np.random.default_rng(5)
+    slots, rows = 3, [70_001, 64, 1]
+    ex = ScalarExchange(dev, n_columns=2, slots_per_rank=slots)
+    want_i, want_c, all_f = 0, 0, []
+    keep = []
+    ctx.set_async(True)
+    for slot in range(slots):
+        n = rows[slot]
+        ints = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+        flts = rng.standard_normal(n) * 10.0 ** rng.integers(0, 14, size=n)
+        bits = rng.integers(0, 256, size=n // 8 + 24, dtype=np.uint8)
+        valid = np.unpackbits(bits, bitorder="little")[5:5 + n].astype(bool)
+        d_i, d_f, d_m = (torch.from_numpy(a).to(dev) for a in (ints, flts, bits))
+        keep += [d_i, d_f, d_m]
+        ctx.sum_into("i64", d_i, n, out_sum=ex.slot_ptr(0, 0, slot), out_count=ex.slot_ptr(1, 0, slot), mask=d_m, mask_bit_offset=5)
+        ctx.sum_into("f64", d_f, n, out_sum=ex.slot_ptr(2, 1, slot), dd_lo=ex.slot_ptr(3, 1, slot),
+                     out_count=ex.slot_ptr(4, 1, slot), mask=d_m, mask_bit_offset=5)
+        want_i += int(ints[valid].astype(object).sum())
+        want_c += int(valid.sum())
+        all_f += flts[valid].tolist()
+    ex.exchange()
+    ex.fold_on_device(ctx)
+    ctx.set_async(False)
+    ctx.synchronize()
+    (isum, icnt, _, _), (_, _, fsum, fcnt) = ex.column_results()
+    exact = math.fsum(all_f)
+    assert isum == want_i & ((1 << 64) - 1) and icnt == want_c == fcnt
+    assert abs(fsum - exact) <= math.ulp(exact)
+    # the host fold of the same gathered records (the gloo path) agrees bit for bit
+    ex._folded_on_device = False
+    assert ex.column_results() == [(isum, icnt, 0.0, 0), (0, 0, fsum, fcnt)]
+
+
+@pytest.mark.parametrize("rows", [[13, 1, 64, 7], [1000, 999, 0, 1001], [5]])
+def test_bit_granular_join_of_gathered_validity(env, rows):
+    torch, dev, ctx = env
+    from minarrow_amd.parallel import join_bit_pieces
+
+    rng = np.random.default_rng(sum(rows))
+    width = max((r + 7) // 8 for r in rows) + 8
+    staged = np.zeros(len(rows) * width, dtype=np.uint8)
+    valid = []
+    for r, n in enumerate(rows):
+        v = rng.random(n) > 0.3
+        valid.append(v)
+        packed = np.packbits(v, bitorder="little")
+        staged[r * width:r * width + len(packed)] = packed
+    total = sum(rows)
+    out = torch.full(((total + 63) // 64 * 8,), 0xAA, dtype=torch.uint8, device=dev)
+    join_bit_pieces(ctx, torch.from_numpy(staged).to(dev), width, rows, out)
+    ctx.synchronize()
+    want = np.zeros((total + 63) // 64 * 8, dtype=np.uint8)
+    packed = np.packbits(np.concatenate(valid), bitorder="little")
+    want[:len(packed)] = packed
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_gather_consolidated_single_rank(env):
+    torch, dev, ctx = env
+    from minarrow_amd.parallel import gather_consolidated
+
+    vals = torch.arange(1000, dtype=torch.int64, device=dev)
+    bits = torch.from_numpy(np.packbits(np.arange(1000) % 3 != 0, bitorder="little")).to(dev)
+    out = torch.zeros(1000, dtype=torch.int64, device=dev)
+    out_bits = torch.zeros(128, dtype=torch.uint8, device=dev)
+    assert gather_consolidated(vals, [1000], out, bits, out_bits, ctx=ctx)
+    assert torch.equal(out, vals) and torch.equal(out_bits[:125], bits)
+    assert not gather_consolidated(vals, [1000], out)

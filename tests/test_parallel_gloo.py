@@ -105,3 +105,108 @@ def test_row_chunk_sum_over_gloo(world):
     int_sum, int_cnt, f_sum, f_cnt = results[0][1]
     assert int_sum == want_int and int_cnt == int(valid.sum()) == f_cnt
     assert abs(f_sum - want_f) <= math.ulp(want_f)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Rank-sharded SuperTable (BASELINE config 5): batches dealt to ranks in order, per-column reduce through one
+# exchange, physical consolidation only on request.
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_batch_ranges_are_contiguous_and_ordered():
+    from minarrow_amd.parallel import batch_ranges
+
+    for n in (0, 1, 5, 8, 17):
+        for world in (1, 2, 3, 8):
+            r = batch_ranges(n, world)
+            assert r[0][0] == 0 and r[-1][1] == n and all(b == c for (_, b), (c, _) in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    assert batch_ranges(8, 8) == [(i, i + 1) for i in range(8)]
+
+
+def _table(seed, n_batches, ragged):
+    """SuperTable stand-in: per batch an i64 column, an f64 column and their validity bitmaps (None = no mask)."""
+    rng = np.random.default_rng(seed)
+    batches = []
+    for b in range(n_batches):
+        rows = int(rng.integers(1, 40)) * 8 + (3 if ragged and b == n_batches - 1 else 0)
+        ints = rng.integers(-(1 << 62), 1 << 62, size=rows, dtype=np.int64)
+        flts = rng.standard_normal(rows) * 10.0 ** rng.integers(0, 12, size=rows)
+        mask = None if b % 3 == 1 else np.packbits(rng.random(rows) > 0.1, bitorder="little")
+        batches.append((ints, flts, mask))
+    return batches
+
+
+def _valid(mask, rows):
+    return np.ones(rows, dtype=bool) if mask is None else np.unpackbits(mask, bitorder="little")[:rows].astype(bool)
+
+
+def _table_worker(rank, world, port, seed, n_batches, ragged, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+
+    from minarrow_amd.parallel import ScalarExchange, batch_ranges, gather_consolidated
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batches = _table(seed, n_batches, ragged)
+        ranges = batch_ranges(n_batches, world)
+        lo, hi = ranges[rank]
+        slots = max(b - a for a, b in ranges)
+        ex = ScalarExchange("cpu", n_columns=2, slots_per_rank=slots)
+        for slot, (ints, flts, mask) in enumerate(batches[lo:hi]):
+            v = _valid(mask, len(ints))
+            sel = flts[v]
+            h = math.fsum(sel.tolist())
+            ex.set_local(int_sum=int(ints[v].astype(object).sum()), int_count=int(v.sum()), column=0, slot=slot)
+            ex.set_local(hi=h, lo=math.fsum(sel.tolist() + [-h]), f_count=int(v.sum()), column=1, slot=slot)
+        ex.exchange()
+        # physical consolidation of the i64 column: every rank first joins its own batches (the local
+        # ma_consolidate_column step; numpy stands in for it here), then the pieces are gathered in rank order
+        rows = [sum(len(b[0]) for b in batches[a:z]) for a, z in ranges]
+        own = batches[lo:hi]
+        piece = np.concatenate([b[0] for b in own]) if own else np.zeros(0, dtype=np.int64)
+        any_mask = any(b[2] is not None for b in own)
+        piece_bits = np.packbits(np.concatenate([_valid(b[2], len(b[0])) for b in own]), bitorder="little") \
+            if any_mask else None
+        out = torch.zeros(sum(rows), dtype=torch.int64)
+        out_bits = torch.zeros((sum(rows) + 63) // 64 * 8, dtype=torch.uint8)
+        wrote = gather_consolidated(torch.from_numpy(piece), rows, out,
+                                    torch.from_numpy(piece_bits) if piece_bits is not None else None, out_bits)
+        q.put((rank, ex.column_results(), out.numpy().tobytes(), out_bits.numpy().tobytes(), wrote))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_batches,ragged", [(2, 5, False), (3, 8, True), (2, 1, True)])
+def test_sharded_super_table_over_gloo(world, n_batches, ragged):
+    import torch.multiprocessing as mp
+
+    seed = 23
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_table_worker, args=(r, world, port, seed, n_batches, ragged, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    batches = _table(seed, n_batches, ragged)
+    ints = np.concatenate([b[0] for b in batches])
+    flts = np.concatenate([b[1] for b in batches])
+    valid = np.concatenate([_valid(b[2], len(b[0])) for b in batches])
+    want_bits = np.zeros((len(ints) + 63) // 64 * 8, dtype=np.uint8)
+    packed = np.packbits(valid, bitorder="little")
+    want_bits[:len(packed)] = packed
+    for _, cols, data, bits, wrote in results:
+        (isum, icnt, _, _), (_, _, fsum, fcnt) = cols
+        assert isum == int(ints[valid].astype(object).sum()) & ((1 << 64) - 1) and icnt == int(valid.sum()) == fcnt
+        exact = math.fsum(flts[valid].tolist())
+        assert abs(fsum - exact) <= math.ulp(exact)
+        assert data == ints.tobytes()  # == consolidate_concat of the batches in order
+        assert wrote and bits == want_bits.tobytes()
+    assert len({r[1][1][2] for r in results}) == 1  # bit-identical f64 finals on every rank

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE.json configs (bench.py measures configs[1], the headline metric):
 
+  config 1  1M-row IntegerArray<i64> sum as one GPU call (latency-bound; the host-side loop is timed by bench.py)
   config 3  1B-row FloatArray<f64> elementwise add / mul, array (+) array and array (+) scalar (fused broadcast)
   config 4  1B-row i64 sum with 10 % nulls via Bitmask, row-chunk partitioned across the ranks + scalar exchange
-  config 5  SuperTable of 8 chunks: consolidate (i64 + f64 columns, 10 % nulls) + per-column reduce
+  config 5  SuperTable of 8 batches (i64 + f64 columns, 10 % nulls) dealt to the ranks in order: per-column reduce
+            through one scalar exchange + consolidate of each rank's batches (--config5-rows 1000000000 = full size)
 
-Run on 1 GPU directly, or under torch.distributed.run for N ranks (config 4 partitions its 1B rows across them).
+Run on 1 GPU directly, or under torch.distributed.run for N ranks (configs 4 and 5 shard across them).
 Prints one JSON object per config on rank 0. HIP-event timing on the launch stream, HBM-resident inputs."""
 import argparse
 import json
@@ -29,18 +31,25 @@ def timed(ctx, fn, reps, warm=2):
     return ctx.timer_elapsed_ms() / reps
 
 
+def _timeit(fn, t):
+    t0 = t.perf_counter()
+    fn()
+    return t.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--configs", type=str, default="3,4,5")
+    ap.add_argument("--config5-rows", type=int, default=0, help="rows per SuperTable batch (default rows/8)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from minarrow_amd.host import Context
-    from minarrow_amd.parallel import ScalarExchange, row_chunks
+    from minarrow_amd.parallel import ScalarExchange, batch_ranges, row_chunks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -54,6 +63,27 @@ def main():
     n = args.rows
     configs = args.configs.split(",")
     out = []
+
+    if "1" in configs and rank == 0:
+        # configs[0] is the reference's own CPU-runnable case — the scalar loop of benches/hotloop_benchmark_std.rs:49-57
+        # over 10^6 rows; bench.py's cpu_baseline leg times it on the host ("config0_1m_rows"). Here: what the same
+        # column costs as one GPU call (8 MB is L2/MALL-resident, so this is a latency measurement, not bandwidth).
+        import time as _t
+
+        m = 1_000_000
+        col = ctx.alloc(m * 8)
+        ctx.synth_iota("i64", col, m, 0)
+        slot = torch.zeros(8, dtype=torch.int64, device=dev)
+        s, c = ctx.sum("i64", col, m)
+        sync_us = min(_timeit(lambda: ctx.sum("i64", col, m), _t) for _ in range(200)) * 1e6
+        ctx.set_async(True)
+        ms = timed(ctx, lambda: ctx.sum_into("i64", col, m, out_sum=slot.data_ptr(), out_count=slot.data_ptr() + 8), 200, 5)
+        ctx.set_async(False)
+        ctx.synchronize()
+        out.append({"config": 1, "workload": f"{m}-row IntegerArray<i64> sum as one GPU call (benches/hotloop_benchmark_std.rs shape)",
+                    "gpu_sync_call_us": sync_us, "gpu_enqueued_us": ms * 1e3, "gpu_enqueued_gbps": 8 * m / ms / 1e6,
+                    "sum": s, "expected": m * (m - 1) // 2, "count": c})
+        col.free()
 
     if "3" in configs and rank == 0:
         a, b, o = (ctx.alloc(n * 8) for _ in range(3))
@@ -115,53 +145,93 @@ def main():
         data.free()
         mask.free()
 
-    if "5" in configs and rank == 0:
+    if "5" in configs:
+        # The SuperTable's k batches are dealt to the ranks in order (batch_ranges); one column at a time so that the
+        # full-size case (--config5-rows 1000000000: 64 GB of chunks + 64 GB consolidated) fits one 288 GB MI355X.
         k = 8
-        rows = n // k
+        rows = args.config5_rows or n // k
+        ranges = batch_ranges(k, world)
+        lo, hi = ranges[rank]
+        local = hi - lo
+        slots = max(z - a for a, z in ranges)
         res = {}
         for tag in ("i64", "f64"):
-            chunks = [ctx.alloc(rows * 8) for _ in range(k)]
-            masks = [ctx.alloc(rows // 8 + 64) for _ in range(k)]
-            for c in range(k):
-                ctx.synth_iota(tag, chunks[c], rows, c)  # v[i] = i + chunk (benches/consolidate.rs:37-58 pattern)
-                ctx.synth_validity(masks[c], rows, seed=0xABC + c, null_every=10)
-            o = ctx.alloc(k * rows * 8)
-            om = ctx.alloc(k * rows // 8 + 64)
-            ms = timed(ctx, lambda: ctx.consolidate_column(8, chunks, [rows] * k, o, masks, [0] * k, om), max(2, args.reps // 2), 1)
-            parts = [ctx.sum(tag, chunks[c], rows, mask=masks[c]) for c in range(k)]
-            whole = ctx.sum(tag, o, k * rows, mask=om)
+            chunks = [ctx.alloc(rows * 8) for _ in range(local)]
+            masks = [ctx.alloc(rows // 8 + 64) for _ in range(local)]
+            for c in range(local):
+                ctx.synth_iota(tag, chunks[c], rows, lo + c)  # v[i] = i + chunk (benches/consolidate.rs:37-58 pattern)
+                ctx.synth_validity(masks[c], rows, seed=0xABC + lo + c, null_every=10)
+            o = ctx.alloc(max(local * rows, 1) * 8)
+            om = ctx.alloc(local * rows // 8 + 64)
+            # (1) per-column reduce, logically consolidated: every local batch into its own record, one exchange,
+            #     batch-ordered fold on the GPU — no column bytes move
+            ex = ScalarExchange(dev, n_columns=1, slots_per_rank=slots)
             ctx.set_async(True)
-            slot = torch.zeros(8, dtype=torch.int64, device=dev)
-            ms_reduce_logical = timed(ctx, lambda: [ctx.sum_into(tag, chunks[c], rows, out_sum=slot.data_ptr(), out_count=slot.data_ptr() + 8,
-                                                                 mask=masks[c]) for c in range(k)], args.reps)
-            ms_reduce_physical = timed(ctx, lambda: ctx.sum_into(tag, o, k * rows, out_sum=slot.data_ptr(), out_count=slot.data_ptr() + 8,
-                                                                 mask=om), args.reps)
+
+            def reduce_step():
+                for c in range(local):
+                    if tag == "i64":
+                        ctx.sum_into(tag, chunks[c], rows, out_sum=ex.slot_ptr(0, 0, c), out_count=ex.slot_ptr(1, 0, c), mask=masks[c])
+                    else:
+                        ctx.sum_into(tag, chunks[c], rows, out_sum=ex.slot_ptr(2, 0, c), dd_lo=ex.slot_ptr(3, 0, c),
+                                     out_count=ex.slot_ptr(4, 0, c), mask=masks[c])
+                ex.exchange()
+                ex.fold_on_device(ctx)
+
+            for _ in range(2):
+                reduce_step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.reps):
+                reduce_step()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms_reduce_logical = e0.elapsed_time(e1) / args.reps
+            # (2) this rank's batches joined into one contiguous piece (+ validity): ma_consolidate_column
+            ms = timed(ctx, lambda: ctx.consolidate_column(8, chunks, [rows] * local, o, masks, [0] * local, om),
+                       max(2, args.reps // 2), 1) if local else 0.0
+            ms_reduce_physical = timed(ctx, lambda: ctx.sum_into(tag, o, local * rows, out_sum=ex.slot_ptr(5), out_count=ex.slot_ptr(6),
+                                                                 mask=om), args.reps) if local else 0.0
+            if world > 1:
+                t = torch.tensor([ms_reduce_logical, ms, ms_reduce_physical], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms_reduce_logical, ms, ms_reduce_physical = (float(v) for v in t.tolist())
             ctx.set_async(False)
             ctx.synchronize()
-            # the same per-chunk reduce as ONE ma_sum_columns call (two launches, host wall clock incl. the call overhead)
-            fmt = "l" if tag == "i64" else "g"
-            f_cols, i_cols, c_cols = ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
-            import time as _t
-            t0 = _t.perf_counter()
-            for _ in range(args.reps):
-                ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
-            ms_reduce_columns = (_t.perf_counter() - t0) / args.reps * 1e3
-            col_sums = [int(v) for v in i_cols] if tag == "i64" else [float(v) for v in f_cols]
-            assert [int(c) for c in c_cols] == [p[1] for p in parts]
-            assert all((a == b[0]) if tag == "i64" else (abs(a - b[0]) <= abs(b[0]) * 2**-52) for a, b in zip(col_sums, parts))
-            res[tag] = {"consolidate_ms": ms, "consolidate_gbps": 16.25 * k * rows / ms / 1e6,
-                        "consolidate_grows_per_s": k * rows / ms / 1e6,
-                        "reduce_logical_ms": ms_reduce_logical, "reduce_logical_grows_per_s": k * rows / ms_reduce_logical / 1e6,
-                        "reduce_logical_one_call_ms_wall": ms_reduce_columns,
-                        "reduce_logical_one_call_grows_per_s": k * rows / ms_reduce_columns / 1e6,
-                        "reduce_physical_ms": ms_reduce_physical, "reduce_physical_grows_per_s": k * rows / ms_reduce_physical / 1e6,
-                        "count_matches": whole[1] == sum(p[1] for p in parts),
-                        "sum_matches": (whole[0] == sum(p[0] for p in parts)) if tag == "i64" else
-                        abs(whole[0] - sum(p[0] for p in parts)) <= 8 * abs(whole[0]) * 2.0 ** -52}
+            isum, icnt, fsum, fcnt = ex.results()
+            got_sum, got_cnt = (isum, icnt) if tag == "i64" else (fsum, fcnt)
+            whole = ctx.sum(tag, o, local * rows, mask=om) if local else (0, 0)
+            entry = {"consolidate_ms": ms, "consolidate_gbps": 16.25 * local * rows / ms / 1e6 if ms else None,
+                     "consolidate_grows_per_s": local * rows / ms / 1e6 if ms else None,
+                     "reduce_logical_ms": ms_reduce_logical, "reduce_logical_grows_per_s": k * rows / ms_reduce_logical / 1e6,
+                     "reduce_logical_gbps": 8.125 * k * rows / ms_reduce_logical / 1e6,
+                     "reduce_physical_ms": ms_reduce_physical,
+                     "reduce_physical_grows_per_s": local * rows / ms_reduce_physical / 1e6 if ms_reduce_physical else None,
+                     "sum": got_sum, "valid_count": got_cnt}
+            if world == 1:
+                # the same per-chunk reduce as ONE ma_sum_columns call (two launches, host wall clock incl. the call overhead)
+                fmt = "l" if tag == "i64" else "g"
+                f_cols, i_cols, c_cols = ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
+                import time as _t
+                t0 = _t.perf_counter()
+                for _ in range(args.reps):
+                    ctx.sum_columns(fmt, chunks, [rows] * k, masks, [0] * k)
+                ms_reduce_columns = (_t.perf_counter() - t0) / args.reps * 1e3
+                entry["reduce_logical_one_call_ms_wall"] = ms_reduce_columns
+                entry["reduce_logical_one_call_grows_per_s"] = k * rows / ms_reduce_columns / 1e6
+                entry["count_matches"] = whole[1] == got_cnt == int(sum(int(c) for c in c_cols))
+                entry["sum_matches"] = (whole[0] & ((1 << 64) - 1)) == got_sum if tag == "i64" else \
+                    abs(whole[0] - got_sum) <= abs(whole[0]) * 2.0 ** -52
+            res[tag] = entry
             for buf in chunks + masks + [o, om]:
                 buf.free()
-        out.append({"config": 5, "workload": f"SuperTable of {k} x {rows}-row chunks, columns i64 + f64 with 10 % nulls: "
-                                             f"consolidate + per-column reduce, 1 MI355X", **res})
+        if rank == 0:
+            out.append({"config": 5, "workload": f"SuperTable of {k} x {rows}-row batches, columns i64 + f64 with 10 % nulls: per-column "
+                                                 f"reduce (batch-sharded over {world} GPU(s), one scalar exchange) + consolidate of each "
+                                                 f"rank's batches", "n_gpus": world, **res})
 
     if "x" in configs and rank == 0:
         # extras for DESIGN.md's kernel table: FMA (32 B/row), masked elementwise, bitmask kernels on 8 Gbit windows
