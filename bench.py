@@ -108,6 +108,7 @@ def cpu_baseline(rows: int, budget_s: float):
             times.append(time.perf_counter() - t0)
         config0[name] = {"best_us": min(times) * 1e6, "median_us": sorted(times)[len(times) // 2] * 1e6,
                          "grows_per_s": small.size / min(times) / 1e9}
+    other = cpu_other_configs(oracle, np)
     return {
         "value": results[best_threads]["value"],
         "unit": "Grows/s",
@@ -119,7 +120,61 @@ def cpu_baseline(rows: int, budget_s: float):
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
         "detail": {str(t): r for t, r in results.items()},
         "config0_1m_rows": config0,
+        "other_configs_single_thread": other,
     }
+
+
+def cpu_other_configs(oracle, np):
+    """The reference's CPU cost of the other BASELINE configs on bounded samples, for tools/bench_configs.py's GPU
+    figures to stand beside. The reference's elementwise kernels, its broadcast and its consolidate are
+    single-threaded (src/kernels/arithmetic/mod.rs:29-31; "TODO: Parallelise", src/kernels/broadcast/super_array.rs:193),
+    so one thread is the faithful baseline here. Outputs are allocated and touched beforehand (the reference pays
+    first-touch page faults on its fresh Vec64 inside the call; leaving them out favours the CPU)."""
+    import ctypes as C
+
+    def best(fn, reps=5):
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        return min(times)
+
+    l = oracle.klib()
+    n = 1 << 25
+    a, b, out = (oracle.aligned_empty(n, np.float64) for _ in range(3))
+    a[:] = np.arange(n, dtype=np.float64)
+    b[:] = n - a
+    out[:] = 0
+    used = C.c_int(0)
+    res = {}
+    for op_name, op in (("add", 0), ("multiply", 2)):
+        call = lambda: l.mo_apply_float_f64(oracle._p(a), n, oracle._p(b), n, op, None, n, oracle._p(out), None, 8,
+                                            C.addressof(used))
+        t = best(call)
+        assert used.value == 1 and out[12345] == (a[12345] + b[12345] if op == 0 else a[12345] * b[12345])
+        res[f"config3_f64_{op_name}_array_array"] = {"rows": n, "best_ms": t * 1e3, "grows_per_s": n / t / 1e9,
+                                                     "gbps": 24 * n / t / 1e9}
+
+        def broadcast_then_apply():  # maybe_broadcast_scalar_array materialises vec64![x; n] (routing/broadcast.rs:30-45)
+            b[:] = 2.5
+            call()
+
+        t = best(broadcast_then_apply)
+        res[f"config3_f64_{op_name}_array_scalar"] = {"rows": n, "best_ms": t * 1e3, "grows_per_s": n / t / 1e9}
+    m = 1 << 26
+    ints = np.arange(m, dtype=np.int64)
+    bits = np.random.default_rng(1).integers(0, 256, size=m // 8 + 16, dtype=np.uint8)
+    t = best(lambda: oracle.masked_sum(ints, bits, 0))
+    res["config4_i64_sum_bitmask_gated"] = {"rows": m, "best_ms": t * 1e3, "grows_per_s": m / t / 1e9,
+                                            "note": "build-defined semantics (the reference has no masked sum): scalar loop"}
+    k, rows = 8, 1 << 22
+    chunks = [np.arange(rows, dtype=np.int64) + c for c in range(k)]
+    masks = [np.random.default_rng(c).integers(0, 256, size=rows // 8 + 16, dtype=np.uint8) for c in range(k)]
+    t = best(lambda: oracle.consolidate_column(chunks, masks, [0] * k), reps=3)
+    res["config5_consolidate_i64_column"] = {"rows": k * rows, "best_ms": t * 1e3, "grows_per_s": k * rows / t / 1e9,
+                                             "gbps": 16.25 * k * rows / t / 1e9}
+    return res
 
 
 def main() -> int:
