@@ -94,6 +94,13 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
 ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups);
 /* Kernel variant selector used by the tuning harness (0 = default). See DESIGN.md §kernels. */
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
+/* Host-resident (pageable) operands of the elementwise entry points — a Rust &[T] / Vec64<T> that was not allocated
+ * with ma_alloc64_pinned; the reference's kernels read such slices in place (src/kernels/arithmetic/dispatch.rs:74-133)
+ * — cross PCIe in tiles of tile_bytes per operand through a ring of device buffers owned by the context: the copy-in
+ * of tile k+1, the kernels of tile k and the copy-out of tile k-1 overlap, and the device footprint is 12 tiles
+ * whatever the column size. Default 32 MiB; calls shorter than two tiles, and every call when tile_bytes == 0, stage
+ * whole operands in temporary device buffers instead. Results are identical either way. */
+ma_status ma_ctx_set_staging_tile(ma_ctx* ctx, size_t tile_bytes);
 
 /* HIP-event timing on the context's stream (bench.py's roofline leg uses these). */
 ma_status ma_ctx_timer_start(ma_ctx* ctx);

@@ -413,6 +413,137 @@ static void launch_vec_op(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll
     }
 }
 
+// Enqueues the kernels of one call (or of one tile of a host-resident call) on ctx->stream. Every pointer of `a` is
+// device-reachable; a.words / a.bit_off / a.out_words describe the validity of row 0 onwards. copy_mask: also write the
+// output validity of a masked op whose validity is not data-dependent (the tiled path does that once for all tiles).
+template <typename T>
+ma_status enqueue_binary(ma_ctx* ctx, BinArgs<T> a, bool fma, bool masked, bool copy_mask) {
+    constexpr bool kInt = std::is_integral<T>::value;
+    const size_t n = a.n;
+    if (masked) a.last_word = (a.bit_off + n - 1) >> 6;
+    const bool int_div = kInt && !fma &&
+                         (a.op == MA_OP_DIVIDE || a.op == MA_OP_REMAINDER || a.op == MA_OP_FLOORDIV);
+    const bool ballot = masked && int_div;  // output validity depends on the data: the kernels write out_words themselves
+    // The vec kernel peels `head` rows so that its STORES are 16-byte aligned; the inputs may sit on any element-aligned
+    // phase (views sliced at different offsets, routing/arithmetic.rs:273-285): load16u.
+    uintptr_t phase = (uintptr_t)a.out & 15;
+    const bool same_phase = true;
+    constexpr int R = 16 / (int)sizeof(T);
+    // Launch shape (profiles/r01_sweep_grid.json, r01_sweep_binary.txt, r01_ubench_stream.txt). With a store stream in
+    // the mix — unlike the read-only sums — MORE resident workgroups help (the memory system batches writes better
+    // with more of them queued), 8 accesses per operand in flight, and the 16-KiB tiles of UNROLL = 4 resonate with
+    // power-of-two grids (512/1024/2048: -5..-10 %). UNROLL = 8 with 6 workgroups per CU sits on the plateau
+    // (a(+)b 3.92 ms, a(+)scalar 2.59 ms, fma 5.36 ms at 10^9 f64 rows; device-to-device spread is ~10 %).
+    int unroll = 8;
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 6;
+    switch ((ctx->variant >> 1) & 7) {
+        case 2: unroll = 4; break;
+        case 3: unroll = 8; break;
+        default: break;
+    }
+    if (fma) {
+        unroll = 8;
+        switch ((ctx->variant >> 1) & 7) {
+            case 1: unroll = 2; break;
+            case 2: unroll = 4; break;
+            default: break;
+        }
+    } else {
+        unroll = clamp_unroll<T>(unroll, masked);
+    }
+    const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
+    size_t head = 0, n_tiles = 0;
+    // Data-dependent validity: the vec kernel writes whole validity words, which needs row 0 on a 16-byte boundary
+    // (head == 0); otherwise the row kernel ballots over everything.
+    if (same_phase && !(ballot && phase != 0)) {
+        head = phase ? (16 - phase) / sizeof(T) : 0;
+        if (head > n) head = n;
+        n_tiles = (n - head) / tile_rows;
+    }
+    a.head = head;
+    a.n_tiles = n_tiles;
+    a.ballot_mask = ballot ? 1 : 0;
+    const size_t tail_start = head + n_tiles * tile_rows;  // ballot mode: head == 0 and this is a multiple of 64
+
+    if (masked && !ballot && copy_mask) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+    if (n_tiles) {
+        int grid = grid_for(ctx, n_tiles, bpc);
+        if (fma) {
+            if constexpr (!kInt) {
+#define MA_FMA_LAUNCH(M, U) hipLaunchKernelGGL((fma_vec_kernel<T, M, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a)
+                if (masked) {
+                    if (unroll == 8) MA_FMA_LAUNCH(true, 8); else if (unroll == 2) MA_FMA_LAUNCH(true, 2); else MA_FMA_LAUNCH(true, 4);
+                } else {
+                    if (unroll == 8) MA_FMA_LAUNCH(false, 8); else if (unroll == 2) MA_FMA_LAUNCH(false, 2); else MA_FMA_LAUNCH(false, 4);
+                }
+#undef MA_FMA_LAUNCH
+            }
+        } else if (masked) {
+            launch_vec_op<T, true>(ctx, a, grid, unroll, a.kind, a.op);
+        } else {
+            launch_vec_op<T, false>(ctx, a, grid, unroll, a.kind, a.op);
+        }
+        MA_HIP(hipGetLastError());
+    }
+    if (head > 0 || tail_start < n) {
+        size_t words_touched = (head + 63) / 64 + (n - tail_start + 63) / 64 + 1;
+        int grid = grid_for(ctx, (words_touched + kWaves - 1) / kWaves, 8);
+        if (fma) {
+            if constexpr (!kInt) {
+                if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+                else hipLaunchKernelGGL((binary_row_kernel<T, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+            }
+        } else {
+            if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+            else hipLaunchKernelGGL((binary_row_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
+        }
+        MA_HIP(hipGetLastError());
+    }
+
+    return MA_OK;
+}
+
+// After the kernels of a dense integer Div/Rem/FloorDiv have run: turns the device latch into the reference's panic.
+static ma_status check_divide_latch(ma_ctx* ctx, int op) {
+    uint32_t flags = 0;
+    MA_HIP(hipMemcpyAsync(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags & 1u) {
+        MA_HIP(hipMemsetAsync(ctx->dev_flags, 0, sizeof(flags), ctx->stream));
+        MA_HIP(hipStreamSynchronize(ctx->stream));
+        // The reference panics here: "Division by zero" / "Remainder by zero" / "Floor division by zero"
+        // (src/kernels/arithmetic/std.rs:53-77); asserted by src/kernels/arithmetic/mod.rs:161-177.
+        set_error("%s by zero in a dense integer kernel",
+                  op == MA_OP_DIVIDE ? "Division" : op == MA_OP_REMAINDER ? "Remainder" : "Floor division");
+        return MA_ERR_DIVIDE_BY_ZERO;
+    }
+    return MA_OK;
+}
+
+// One tile of a host-resident call (run_tiled, ma_pipeline.hip): operand order lhs, rhs, acc, out.
+template <typename T>
+struct TileCall {
+    ma_ctx* ctx;
+    BinArgs<T> base;  // scalar / op / kind / flags and the whole call's validity (words, bit_off, out_words)
+    bool fma, masked;
+    static ma_status run(void* user, size_t row0, size_t rows, void* const* ptrs) {
+        const TileCall& t = *(const TileCall*)user;
+        BinArgs<T> a = t.base;
+        a.lhs = (const T*)ptrs[0];
+        a.rhs = (const T*)ptrs[1];
+        a.acc = (const T*)ptrs[2];
+        a.out = (T*)ptrs[3];
+        a.n = rows;
+        if (t.masked) {  // row0 is a multiple of 64: the tile's output validity starts on a word
+            const size_t bit = t.base.bit_off + row0;
+            a.words = t.base.words + (bit >> 6);
+            a.bit_off = bit & 63;
+            a.out_words = t.base.out_words + (row0 >> 6);
+        }
+        return enqueue_binary<T>(t.ctx, a, t.fma, t.masked, false);
+    }
+};
+
 template <typename T>
 ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     constexpr bool kInt = std::is_integral<T>::value;
@@ -444,8 +575,44 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
 
     std::lock_guard<std::mutex> lock(ctx->mu);
     MA_HIP(hipSetDevice(ctx->device));
+    const bool int_div = kInt && !c.fma &&
+                         (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
+    const bool may_latch = int_div && !masked;
     CallScope scope(ctx);
     BinArgs<T> a{};
+    a.scalar = c.scalar;
+    a.n = n;
+    a.op = c.op;
+    a.kind = c.kind;
+    a.flags = ctx->dev_flags;
+
+    // Host-resident columns (a Rust &[T] that is not ma_alloc64_pinned memory) cross PCIe in tiles, both directions
+    // at once (ma_pipeline.hip); small calls and device-reachable operands take the direct path below.
+    const size_t tile_rows = (ctx->staging_tile_bytes / sizeof(T)) & ~(size_t)32767;  // whole vec tiles, whole words
+    if (tile_rows && n >= 2 * tile_rows && !ctx->capturing) {
+        PipeOperand ops[4] = {{c.kind != kSA ? c.lhs : nullptr, nullptr, sizeof(T), false},
+                              {c.kind != kAS ? c.rhs : nullptr, nullptr, sizeof(T), false},
+                              {c.fma ? c.acc : nullptr, nullptr, sizeof(T), false},
+                              {nullptr, c.out, sizeof(T), false}};
+        bool any = false;
+        for (auto& o : ops) {
+            const void* q = o.out ? o.out : o.in;
+            o.staged = q != nullptr && pointer_kind(q) == kPageable;
+            any = any || o.staged;
+        }
+        if (any) {
+            if (masked) {
+                MA_TRY(scope.in_mask(c.mask_bits, c.mask_bit_offset, n, &a.words, &a.bit_off));
+                MA_TRY(scope.out_mask(c.out_mask_bits, n, &a.out_words));
+                if (!int_div) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+            }
+            TileCall<T> call{ctx, a, c.fma, masked};
+            MA_TRY(run_tiled(ctx, n, tile_rows, ops, 4, &TileCall<T>::run, &call));
+            MA_TRY(scope.finish());  // validity temporaries back to the host
+            return may_latch ? check_divide_latch(ctx, c.op) : MA_OK;
+        }
+    }
+
     const void* p = nullptr;
     if (c.kind != kSA) {
         MA_TRY(scope.in(c.lhs, n * sizeof(T), &p));
@@ -462,113 +629,15 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     void* po = nullptr;
     MA_TRY(scope.out(c.out, n * sizeof(T), &po));
     a.out = (T*)po;
-    a.scalar = c.scalar;
-    a.n = n;
-    a.op = c.op;
-    a.kind = c.kind;
-    a.flags = ctx->dev_flags;
     if (masked) {
         MA_TRY(scope.in_mask(c.mask_bits, c.mask_bit_offset, n, &a.words, &a.bit_off));
-        a.last_word = (a.bit_off + n - 1) >> 6;
         MA_TRY(scope.out_mask(c.out_mask_bits, n, &a.out_words));
     }
+    MA_TRY(enqueue_binary<T>(ctx, a, c.fma, masked, true));
 
-    const bool int_div = kInt && !c.fma &&
-                         (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
-    const bool ballot = masked && int_div;  // output validity depends on the data: the kernels write out_words themselves
-    // The vec kernel peels `head` rows so that its STORES are 16-byte aligned; the inputs may sit on any element-aligned
-    // phase (views sliced at different offsets, routing/arithmetic.rs:273-285): load16u.
-    uintptr_t phase = (uintptr_t)a.out & 15;
-    const bool same_phase = true;
-    constexpr int R = 16 / (int)sizeof(T);
-    // Launch shape (profiles/r01_sweep_grid.json, r01_sweep_binary.txt, r01_ubench_stream.txt). With a store stream in
-    // the mix — unlike the read-only sums — MORE resident workgroups help (the memory system batches writes better
-    // with more of them queued), 8 accesses per operand in flight, and the 16-KiB tiles of UNROLL = 4 resonate with
-    // power-of-two grids (512/1024/2048: -5..-10 %). UNROLL = 8 with 6 workgroups per CU sits on the plateau
-    // (a(+)b 3.92 ms, a(+)scalar 2.59 ms, fma 5.36 ms at 10^9 f64 rows; device-to-device spread is ~10 %).
-    int unroll = 8;
-    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 6;
-    switch ((ctx->variant >> 1) & 7) {
-        case 2: unroll = 4; break;
-        case 3: unroll = 8; break;
-        default: break;
-    }
-    if (c.fma) {
-        unroll = 8;
-        switch ((ctx->variant >> 1) & 7) {
-            case 1: unroll = 2; break;
-            case 2: unroll = 4; break;
-            default: break;
-        }
-    } else {
-        unroll = clamp_unroll<T>(unroll, masked);
-    }
-    const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
-    size_t head = 0, n_tiles = 0;
-    // Data-dependent validity: the vec kernel writes whole validity words, which needs row 0 on a 16-byte boundary
-    // (head == 0); otherwise the row kernel ballots over everything.
-    if (same_phase && !(ballot && phase != 0)) {
-        head = phase ? (16 - phase) / sizeof(T) : 0;
-        if (head > n) head = n;
-        n_tiles = (n - head) / tile_rows;
-    }
-    a.head = head;
-    a.n_tiles = n_tiles;
-    a.ballot_mask = ballot ? 1 : 0;
-    const size_t tail_start = head + n_tiles * tile_rows;  // ballot mode: head == 0 and this is a multiple of 64
-
-    if (masked && !ballot) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
-    if (n_tiles) {
-        int grid = grid_for(ctx, n_tiles, bpc);
-        if (c.fma) {
-            if constexpr (!kInt) {
-#define MA_FMA_LAUNCH(M, U) hipLaunchKernelGGL((fma_vec_kernel<T, M, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a)
-                if (masked) {
-                    if (unroll == 8) MA_FMA_LAUNCH(true, 8); else if (unroll == 2) MA_FMA_LAUNCH(true, 2); else MA_FMA_LAUNCH(true, 4);
-                } else {
-                    if (unroll == 8) MA_FMA_LAUNCH(false, 8); else if (unroll == 2) MA_FMA_LAUNCH(false, 2); else MA_FMA_LAUNCH(false, 4);
-                }
-#undef MA_FMA_LAUNCH
-            }
-        } else if (masked) {
-            launch_vec_op<T, true>(ctx, a, grid, unroll, c.kind, c.op);
-        } else {
-            launch_vec_op<T, false>(ctx, a, grid, unroll, c.kind, c.op);
-        }
-        MA_HIP(hipGetLastError());
-    }
-    if (head > 0 || tail_start < n) {
-        size_t words_touched = (head + 63) / 64 + (n - tail_start + 63) / 64 + 1;
-        int grid = grid_for(ctx, (words_touched + kWaves - 1) / kWaves, 8);
-        if (c.fma) {
-            if constexpr (!kInt) {
-                if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
-                else hipLaunchKernelGGL((binary_row_kernel<T, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
-            }
-        } else {
-            if (masked) hipLaunchKernelGGL((binary_row_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
-            else hipLaunchKernelGGL((binary_row_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, tail_start);
-        }
-        MA_HIP(hipGetLastError());
-    }
-
-    const bool may_latch = int_div && !masked;
     if (may_latch && (ctx->async && !scope.staged())) ctx->pending_flags = true;
     MA_TRY(end_call(ctx, scope));
-    if (may_latch && (!ctx->async || scope.staged())) {
-        uint32_t flags = 0;
-        MA_HIP(hipMemcpyAsync(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-        MA_HIP(hipStreamSynchronize(ctx->stream));
-        if (flags & 1u) {
-            MA_HIP(hipMemsetAsync(ctx->dev_flags, 0, sizeof(flags), ctx->stream));
-            MA_HIP(hipStreamSynchronize(ctx->stream));
-            // The reference panics here: "Division by zero" / "Remainder by zero" / "Floor division by zero"
-            // (src/kernels/arithmetic/std.rs:53-77); asserted by src/kernels/arithmetic/mod.rs:161-177.
-            set_error("%s by zero in a dense integer kernel",
-                      c.op == MA_OP_DIVIDE ? "Division" : c.op == MA_OP_REMAINDER ? "Remainder" : "Floor division");
-            return MA_ERR_DIVIDE_BY_ZERO;
-        }
-    }
+    if (may_latch && (!ctx->async || scope.staged())) return check_divide_latch(ctx, c.op);
     return MA_OK;
 }
 

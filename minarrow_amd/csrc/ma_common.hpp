@@ -85,6 +85,8 @@ struct ma_ctx {
     bool async_before_capture = false;
     void* scratch = nullptr;           // grow-only device scratch for descriptor tables / per-segment partials
     size_t scratch_bytes = 0;          //   (one user at a time: callers hold `mu` and order their use on `stream`)
+    void* pipe = nullptr;              // staging ring of the tiled host-operand path (ma_pipeline.hip), made on first use
+    size_t staging_tile_bytes = (size_t)32 << 20;  // bytes of one operand per tile; 0 = stage whole operands
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
@@ -149,6 +151,22 @@ ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_c
                         const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
                         const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
                         uint8_t* const* out_masks, int32_t* out_has_mask);
+
+// Chunk-pipelined staging (ma_pipeline.hip). An entry point whose rows are independent describes its operands and
+// hands over a function that enqueues the kernels of one tile on ctx->stream; run_tiled moves the pageable operands
+// through a ring of device buffers (H2D of tile k+1, kernels of tile k and D2H of tile k-1 overlap) and returns when
+// every result has landed. ptrs[i] is operand i's device-reachable address of the tile's first row.
+constexpr int kMaxPipeOperands = 4;
+struct PipeOperand {
+    const void* in;     // source rows (inputs), or nullptr
+    void* out;          // destination rows (outputs), or nullptr
+    size_t elem_bytes;
+    bool staged;        // pageable host memory: goes through the ring; otherwise used in place
+};
+typedef ma_status (*TileFn)(void* user, size_t row0, size_t rows, void* const* ptrs);
+ma_status run_tiled(ma_ctx* ctx, size_t n_rows, size_t tile_rows, const PipeOperand* ops, int n_ops, TileFn fn,
+                    void* user);
+void pipe_destroy(ma_ctx* ctx);
 
 // `bytes` of device scratch owned by the context (256-byte aligned). Valid until the next ctx_scratch call on this
 // context; the caller holds ctx->mu and enqueues every use on ctx->stream, so successive users are stream-ordered.

@@ -351,6 +351,7 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ma::pipe_destroy(ctx);
     if (ctx->result) (void)hipHostFree(ctx->result);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

@@ -181,6 +181,10 @@ class Context:
     def set_blocks_per_cu(self, n: int) -> None:
         ffi.check(self.lib.ma_ctx_set_blocks_per_cu(self.handle, int(n)))
 
+    def set_staging_tile(self, tile_bytes: int) -> None:
+        """Bytes of one operand per tile of the pipelined host-operand path (0 = stage whole operands)."""
+        ffi.check(self.lib.ma_ctx_set_staging_tile(self.handle, int(tile_bytes)))
+
     def set_grid(self, workgroups: int) -> None:
         ffi.check(self.lib.ma_ctx_set_grid(self.handle, int(workgroups)))
 

@@ -1,0 +1,135 @@
+"""Host-resident (pageable) operands through the tiled staging pipeline (minarrow_amd/csrc/ma_pipeline.hip): the
+elementwise entry points must give the oracle's results — values, validity, divide-by-zero behaviour — exactly as they
+do for device-resident columns, whatever mix of host and device operands a call has and wherever the tile seams fall.
+
+The tile is shrunk with ma_ctx_set_staging_tile so that a few hundred thousand rows already span several tiles plus a
+ragged last one; the default 32-MiB tile is exercised once at 2^24 rows."""
+import numpy as np
+import pytest
+
+from minarrow_amd import ffi
+from test_gpu_arith import NP, OPS, assert_float_bits_equal, mask_bytes, rand_floats, rand_ints, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def tiled(ctx):
+    ctx.set_staging_tile(256 << 10)  # 32768 8-byte rows per tile
+    yield ctx
+    ctx.set_staging_tile(32 << 20)
+
+
+def rows_for(tag, tiles=4.4):
+    return int((256 << 10) / np.dtype(NP[tag]).itemsize * tiles) + 13
+
+
+@pytest.mark.parametrize("tag", ["i8", "u16", "i32", "u64", "i64"])
+@pytest.mark.parametrize("op", ["add", "multiply", "divide", "floordiv", "power"])
+def test_int_host_operands_masked_and_dense(tiled, oracle, tag, op):
+    ctx = tiled
+    rng = np.random.default_rng(hash((tag, op)) & 0xFFFF)
+    n = rows_for(tag)
+    lhs = rand_ints(rng, tag, n)
+    rhs = rand_ints(rng, tag, n, small=(op == "power"))
+    dense_rhs = rhs.copy()
+    dense_rhs[dense_rhs == 0] = 3
+    st, want, _, _ = oracle.apply_int(oracle.aligned_copy(lhs), oracle.aligned_copy(dense_rhs), op)
+    out = np.zeros(n, dtype=NP[tag])
+    ctx.apply(tag, lhs, dense_rhs, OPS[op], out, n, n)
+    np.testing.assert_array_equal(out, want)
+    # masked, validity window at bit offset 5 of a host bitmap; zero divisors become nulls (data-dependent validity)
+    rhs[rng.integers(0, n, size=n // 9)] = 0
+    bits = rng.integers(0, 256, size=(5 + n + 7) // 8 + 8, dtype=np.uint8)
+    window = oracle.pad_bits(np.packbits(unpack(bits, n, 5), bitorder="little"), n)
+    st, want, want_mask = oracle.int_body("masked_std", lhs, rhs, op, mask=window)
+    out = np.zeros(n, dtype=NP[tag])
+    om = np.full(mask_bytes(n) + 8, 0xAA, dtype=np.uint8)
+    ctx.apply(tag, lhs, rhs, OPS[op], out, n, n, mask=bits, mask_bit_offset=5, out_mask=om)
+    np.testing.assert_array_equal(out, want)
+    np.testing.assert_array_equal(om[:mask_bytes(n)], want_mask[:mask_bytes(n)])
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_float_host_operands_all_forms(tiled, oracle, tag):
+    ctx = tiled
+    rng = np.random.default_rng(77)
+    n = rows_for(tag, 3.2)
+    a, b, c = (rand_floats(rng, tag, n) for _ in range(3))
+    dt = NP[tag]
+    for op in ("add", "divide", "remainder"):
+        st, want, _, _ = oracle.apply_float(oracle.aligned_copy(a), oracle.aligned_copy(b), op)
+        out = np.zeros(n, dtype=dt)
+        ctx.apply(tag, a, b, OPS[op], out, n, n)
+        assert_float_bits_equal(out, want)
+    # fused scalar broadcast == the reference's materialised vec64![x; n] (routing/broadcast.rs:30-45)
+    scalar = dt(2.5)
+    full = np.full(n, scalar, dtype=dt)
+    for side in ("rhs", "lhs"):
+        l, r = (a, full) if side == "rhs" else (full, a)
+        st, want, _, _ = oracle.apply_float(oracle.aligned_copy(l), oracle.aligned_copy(r), "subtract")
+        out = np.zeros(n, dtype=dt)
+        ctx.apply_scalar(tag, side, a, n, float(scalar), OPS["subtract"], out)
+        assert_float_bits_equal(out, want)
+    # FMA, masked
+    bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    window = oracle.pad_bits(np.packbits(unpack(bits, n, 2), bitorder="little"), n)
+    st, want, want_mask = oracle.apply_fma(oracle.aligned_copy(a), oracle.aligned_copy(b), oracle.aligned_copy(c), mask=window)
+    out = np.zeros(n, dtype=dt)
+    om = np.zeros(mask_bytes(n) + 8, dtype=np.uint8)
+    ctx.apply_fma(tag, a, b, c, out, n, n, n, mask=bits, mask_bit_offset=2, out_mask=om)
+    assert_float_bits_equal(out, want)
+    np.testing.assert_array_equal(om[:mask_bytes(n)], want_mask[:mask_bytes(n)])
+
+
+def test_mixed_host_and_device_operands(tiled, oracle):
+    ctx = tiled
+    rng = np.random.default_rng(5)
+    n = rows_for("i64", 5.5)
+    lhs, rhs = rand_ints(rng, "i64", n), rand_ints(rng, "i64", n)
+    st, want, _, _ = oracle.apply_int(oracle.aligned_copy(lhs), oracle.aligned_copy(rhs), "subtract")
+    d_l, d_r = ctx.to_device(lhs, 64), ctx.to_device(rhs, 64)
+    d_o = ctx.alloc(n * 8 + 64)
+    # host lhs, device rhs, host out
+    out = np.zeros(n, dtype=np.int64)
+    ctx.apply("i64", lhs, d_r, OPS["subtract"], out, n, n)
+    np.testing.assert_array_equal(out, want)
+    # device inputs, host out (only the drain runs)
+    out[:] = 0
+    ctx.apply("i64", d_l, d_r, OPS["subtract"], out, n, n)
+    np.testing.assert_array_equal(out, want)
+    # host inputs, device out at an odd 8-byte phase (only the feeder runs; stores are not 16-byte aligned)
+    ctx.apply("i64", lhs, rhs, OPS["subtract"], d_o.offset(8), n, n)
+    np.testing.assert_array_equal(d_o.download(np.int64, n, 8), want)
+
+
+def test_dense_divide_by_zero_is_reported_from_any_tile(tiled):
+    ctx = tiled
+    n = rows_for("i32", 4.0)
+    lhs = np.arange(n, dtype=np.int32)
+    rhs = np.ones(n, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    ctx.apply("i32", lhs, rhs, OPS["divide"], out, n, n)
+    np.testing.assert_array_equal(out, lhs)
+    rhs[n - 7] = 0  # in the ragged last tile
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.apply("i32", lhs, rhs, OPS["divide"], out, n, n)
+    assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+    rhs[n - 7] = 1
+    ctx.apply("i32", lhs, rhs, OPS["remainder"], out, n, n)  # the latch was cleared
+    assert not out.any()
+
+
+def test_tiled_and_whole_operand_staging_agree_at_default_tile(ctx, oracle):
+    rng = np.random.default_rng(9)
+    n = (1 << 24) + 4099  # 4 tiles of 32 MiB
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    tiled_out, whole_out = np.zeros(n), np.zeros(n)
+    ctx.apply("f64", a, b, OPS["multiply"], tiled_out, n, n)
+    ctx.set_staging_tile(0)
+    try:
+        ctx.apply("f64", a, b, OPS["multiply"], whole_out, n, n)
+    finally:
+        ctx.set_staging_tile(32 << 20)
+    np.testing.assert_array_equal(tiled_out, whole_out)
+    np.testing.assert_array_equal(tiled_out, a * b)

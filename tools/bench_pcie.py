@@ -40,6 +40,25 @@ def main():
     dt = time.perf_counter() - t0
     assert int(pout.view(np.int64, n)[12345]) == 12345 + 3
     out["pinned_add_scalar"] = {"ms": dt * 1e3, "gbps_each_way": n * 8 / dt / 1e9}
+    # elementwise on pageable memory (a Rust &[T]): whole-operand staging vs the tiled pipeline (ma_pipeline.hip)
+    b = np.arange(n, dtype=np.int64)[::-1].copy()
+    res = np.zeros(n, dtype=np.int64)
+    for label, tile in [("whole_operand", 0)] + [(f"tiled_{t}MiB", t << 20) for t in (4, 8, 16, 32, 64)]:
+        ctx.set_staging_tile(tile)
+        for form in ("array_array", "array_scalar"):
+            fn = (lambda: ctx.apply("i64", a, b, 0, res, n, n)) if form == "array_array" else \
+                (lambda: ctx.apply_scalar("i64", "rhs", a, n, 3, 0, res))
+            fn()
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                times.append(time.perf_counter() - t0)
+            assert int(res[12345]) == (n - 1 if form == "array_array" else 12345 + 3)
+            moved = n * 8 * (3 if form == "array_array" else 2)
+            out[f"pageable_add_{form}_{label}"] = {"ms": min(times) * 1e3, "gbps_total": moved / min(times) / 1e9,
+                                                   "grows_per_s": n / min(times) / 1e9}
+    ctx.set_staging_tile(32 << 20)
     print(json.dumps({"rows": n, "host_sync_wall_clock": True, **out}))
 
 
