@@ -89,6 +89,51 @@ __global__ __launch_bounds__(kBlock) void promote_kernel(PromoteArgs<LT, RT, OT>
     }
 }
 
+// Enqueues one promote launch over device-reachable operands (a.lhs / a.rhs / a.out / a.n and, when masked,
+// a.words + a.bit_off set by the caller).
+template <typename LT, typename RT, typename OT>
+static ma_status enqueue_promote(ma_ctx* ctx, PromoteArgs<LT, RT, OT> a, bool masked) {
+    const size_t n = a.n;
+    if (masked) a.last_word = (a.bit_off + n - 1) >> 6;
+    constexpr int R = 16 / (int)sizeof(OT);
+    constexpr int U = 8;  // launch shape of the elementwise kernels: 8 accesses per operand in flight, 6 workgroups per CU
+    const size_t tile_rows = (size_t)64 * R * U * kWaves;
+    // vector path: `head` rows are peeled so that the output stores are 16-byte aligned; inputs are read with
+    // element-aligned vector loads (load16u)
+    const uintptr_t mis = (uintptr_t)a.out & 15;
+    size_t head = mis ? (16 - mis) / sizeof(OT) : 0;
+    if (head > n) head = n;
+    a.head = head;
+    a.n_tiles = (n - head) / tile_rows;
+    int grid = a.n_tiles ? grid_for(ctx, a.n_tiles, 6) : grid_for(ctx, (n + kBlock - 1) / kBlock, 8);
+    if (masked) hipLaunchKernelGGL((promote_kernel<LT, RT, OT, true, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((promote_kernel<LT, RT, OT, false, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// One tile of a host-resident call (run_tiled, ma_pipeline.hip): operand order lhs, rhs, out.
+template <typename LT, typename RT, typename OT>
+struct PromoteTile {
+    ma_ctx* ctx;
+    PromoteArgs<LT, RT, OT> base;
+    bool masked;
+    static ma_status run(void* user, size_t row0, size_t rows, void* const* ptrs) {
+        const PromoteTile& t = *(const PromoteTile*)user;
+        PromoteArgs<LT, RT, OT> a = t.base;
+        a.lhs = (const LT*)ptrs[0];
+        a.rhs = (const RT*)ptrs[1];
+        a.out = (OT*)ptrs[2];
+        a.n = rows;
+        if (t.masked) {
+            const size_t bit = t.base.bit_off + row0;
+            a.words = t.base.words + (bit >> 6);
+            a.bit_off = bit & 63;
+        }
+        return enqueue_promote<LT, RT, OT>(t.ctx, a, t.masked);
+    }
+};
+
 template <typename LT, typename RT, typename OT>
 static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_len, const RT* rhs, size_t rhs_len, OT scalar,
                               int op, const uint8_t* mask_bits, size_t mask_bit_offset, OT* out, uint8_t* out_mask_bits) {
@@ -109,6 +154,36 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     PromoteArgs<LT, RT, OT> a{};
+    a.scalar = scalar;
+    a.n = n;
+    a.op = op;
+    a.kind = kind;
+    uint64_t* out_words = nullptr;
+
+    // host-resident columns cross PCIe in tiles (ma_pipeline.hip); the tile is sized by the widest operand
+    const size_t tile_rows = (ctx->staging_tile_bytes / sizeof(OT)) & ~(size_t)32767;
+    if (tile_rows && n >= 2 * tile_rows && !ctx->capturing) {
+        PipeOperand ops[3] = {{kind != kSA ? lhs : nullptr, nullptr, sizeof(LT), false},
+                              {kind != kAS ? rhs : nullptr, nullptr, sizeof(RT), false},
+                              {nullptr, out, sizeof(OT), false}};
+        bool any = false;
+        for (auto& o : ops) {
+            const void* q = o.out ? o.out : o.in;
+            o.staged = q != nullptr && pointer_kind(q) == kPageable;
+            any = any || o.staged;
+        }
+        if (any) {
+            if (masked) {
+                MA_TRY(scope.in_mask(mask_bits, mask_bit_offset, n, &a.words, &a.bit_off));
+                MA_TRY(scope.out_mask(out_mask_bits, n, &out_words));
+                MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, out_words));
+            }
+            PromoteTile<LT, RT, OT> call{ctx, a, masked};
+            MA_TRY(run_tiled(ctx, n, tile_rows, ops, 3, &PromoteTile<LT, RT, OT>::run, &call));
+            return scope.finish();
+        }
+    }
+
     const void* p = nullptr;
     if (kind != kSA) {
         MA_TRY(scope.in(lhs, n * sizeof(LT), &p));
@@ -121,32 +196,12 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
     void* po = nullptr;
     MA_TRY(scope.out(out, n * sizeof(OT), &po));
     a.out = (OT*)po;
-    a.scalar = scalar;
-    a.n = n;
-    a.op = op;
-    a.kind = kind;
-    uint64_t* out_words = nullptr;
     if (masked) {
         MA_TRY(scope.in_mask(mask_bits, mask_bit_offset, n, &a.words, &a.bit_off));
-        a.last_word = (a.bit_off + n - 1) >> 6;
         MA_TRY(scope.out_mask(out_mask_bits, n, &out_words));
         MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, out_words));  // float ops: validity out == validity in
     }
-    constexpr int R = 16 / (int)sizeof(OT);
-    constexpr int U = 8;  // launch shape of the elementwise kernels: 8 accesses per operand in flight, 6 workgroups per CU
-    const size_t tile_rows = (size_t)64 * R * U * kWaves;
-    // vector path: `head` rows are peeled so that the output stores are 16-byte aligned
-    const uintptr_t mis = (uintptr_t)a.out & 15;
-    size_t head = mis ? (16 - mis) / sizeof(OT) : 0;
-    if (head > n) head = n;
-    const bool lhs_ok = true, rhs_ok = true;  // inputs are read with element-aligned vector loads (load16u)
-    a.head = head;
-    a.n_tiles = (lhs_ok && rhs_ok) ? (n - head) / tile_rows : 0;
-    if (!(lhs_ok && rhs_ok)) a.head = 0;
-    int grid = a.n_tiles ? grid_for(ctx, a.n_tiles, 6) : grid_for(ctx, (n + kBlock - 1) / kBlock, 8);
-    if (masked) hipLaunchKernelGGL((promote_kernel<LT, RT, OT, true, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((promote_kernel<LT, RT, OT, false, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    MA_HIP(hipGetLastError());
+    MA_TRY((enqueue_promote<LT, RT, OT>(ctx, a, masked)));
     return end_call(ctx, scope);
 }
 

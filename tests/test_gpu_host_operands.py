@@ -133,3 +133,30 @@ def test_tiled_and_whole_operand_staging_agree_at_default_tile(ctx, oracle):
         ctx.set_staging_tile(32 << 20)
     np.testing.assert_array_equal(tiled_out, whole_out)
     np.testing.assert_array_equal(tiled_out, a * b)
+
+
+@pytest.mark.parametrize("fl", [np.float64, np.float32])
+@pytest.mark.parametrize("int_side", ["lhs", "rhs"])
+def test_promote_host_operands(tiled, oracle, fl, int_side):
+    """Int32 <-> Float promotion (src/kernels/routing/arithmetic.rs:244-269): operands of different widths share the
+    ring; results equal cast-then-apply_float, as the reference computes them."""
+    ctx = tiled
+    rng = np.random.default_rng(31)
+    ftag = "f64" if fl == np.float64 else "f32"
+    n = int((256 << 10) / np.dtype(fl).itemsize * 3.3) + 5
+    ints = rng.integers(-(1 << 31), (1 << 31) - 1, size=n, dtype=np.int32)
+    flts = (rng.standard_normal(n) * 1e3).astype(fl)
+    lhs, rhs = (ints, flts) if int_side == "lhs" else (flts, ints)
+    ltag, rtag = ("i32", ftag) if int_side == "lhs" else (ftag, "i32")
+    st, want, _, _ = oracle.apply_float(oracle.aligned_copy(lhs.astype(fl)), oracle.aligned_copy(rhs.astype(fl)), "multiply")
+    out = np.zeros(n, dtype=fl)
+    ctx.apply_promote(ltag, rtag, lhs, rhs, OPS["multiply"], out, n, n)
+    assert_float_bits_equal(out, want)
+    bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    window = oracle.pad_bits(np.packbits(unpack(bits, n, 5), bitorder="little"), n)
+    st, want, want_mask = oracle.float_body("masked_std", lhs.astype(fl), rhs.astype(fl), "add", mask=window)
+    out = np.zeros(n, dtype=fl)
+    om = np.zeros(mask_bytes(n) + 8, dtype=np.uint8)
+    ctx.apply_promote(ltag, rtag, lhs, rhs, OPS["add"], out, n, n, mask=bits, mask_bit_offset=5, out_mask=om)
+    assert_float_bits_equal(out, want)
+    np.testing.assert_array_equal(om[:mask_bytes(n)], want_mask[:mask_bytes(n)])
