@@ -98,8 +98,11 @@ ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
  * with ma_alloc64_pinned; the reference's kernels read such slices in place (src/kernels/arithmetic/dispatch.rs:74-133)
  * — cross PCIe in tiles of tile_bytes per operand through a ring of device buffers owned by the context: the copy-in
  * of tile k+1, the kernels of tile k and the copy-out of tile k-1 overlap, and the device footprint is 12 tiles
- * whatever the column size. Default 32 MiB; calls shorter than two tiles, and every call when tile_bytes == 0, stage
- * whole operands in temporary device buffers instead. Results are identical either way. */
+ * whatever the column size. Pinned operands (ma_alloc64_pinned) of a synchronous call take the same route — the copy
+ * engines fill both directions of the link, a kernel addressing host memory in place does not; an async context
+ * leaves them in place so that the call can return early. Default 32 MiB; calls shorter than two tiles, and every call
+ * when tile_bytes == 0, stage whole pageable operands in temporary device buffers (and use pinned ones in place)
+ * instead. Results are identical either way. */
 ma_status ma_ctx_set_staging_tile(ma_ctx* ctx, size_t tile_bytes);
 
 /* HIP-event timing on the context's stream (bench.py's roofline leg uses these). */

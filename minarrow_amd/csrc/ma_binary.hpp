@@ -597,7 +597,7 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
         bool any = false;
         for (auto& o : ops) {
             const void* q = o.out ? o.out : o.in;
-            o.staged = q != nullptr && pointer_kind(q) == kPageable;
+            o.staged = q != nullptr && crosses_in_tiles(ctx, pointer_kind(q));
             any = any || o.staged;
         }
         if (any) {

@@ -98,6 +98,12 @@ namespace ma {
 
 enum PtrKind : int32_t { kPageable = 0, kPinned = 1, kDevice = 2, kManaged = 3 };
 PtrKind pointer_kind(const void* p);
+// Which operands of a large elementwise call go through the staging ring (ma_pipeline.hip): pageable host memory
+// always; pinned host memory — which kernels COULD address in place — in synchronous mode, because the copy engines
+// fill both directions of the link where a kernel reading and writing over it does not (a (+) scalar at 2^28 rows:
+// 45.8 vs 49.6 ms, profiles/r01_pcie_tiled.json). An async context keeps pinned operands in place: the call must
+// return before the work is done.
+inline bool crosses_in_tiles(const ma_ctx* ctx, PtrKind k) { return k == kPageable || (k == kPinned && !ctx->async); }
 
 // Makes every buffer of one ABI call device-reachable. Pageable host inputs are copied into temporary
 // device buffers; pageable host outputs get a temporary that is copied back by finish(). Using any

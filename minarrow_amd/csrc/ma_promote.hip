@@ -169,7 +169,7 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
         bool any = false;
         for (auto& o : ops) {
             const void* q = o.out ? o.out : o.in;
-            o.staged = q != nullptr && pointer_kind(q) == kPageable;
+            o.staged = q != nullptr && crosses_in_tiles(ctx, pointer_kind(q));
             any = any || o.staged;
         }
         if (any) {

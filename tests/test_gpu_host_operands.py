@@ -160,3 +160,28 @@ def test_promote_host_operands(tiled, oracle, fl, int_side):
     ctx.apply_promote(ltag, rtag, lhs, rhs, OPS["add"], out, n, n, mask=bits, mask_bit_offset=5, out_mask=om)
     assert_float_bits_equal(out, want)
     np.testing.assert_array_equal(om[:mask_bytes(n)], want_mask[:mask_bytes(n)])
+
+
+@pytest.mark.parametrize("async_mode", [False, True])
+def test_pinned_vec64_operands(tiled, oracle, async_mode):
+    """ma_alloc64_pinned memory (the Vec64 stand-in): through the ring in synchronous mode, addressed in place by the
+    kernels in async mode — same bits either way."""
+    from minarrow_amd.host import PinnedBuffer
+
+    ctx = tiled
+    rng = np.random.default_rng(41)
+    n = rows_for("f64", 3.7)
+    a, b = rand_floats(rng, "f64", n), rand_floats(rng, "f64", n)
+    st, want, _, _ = oracle.apply_float(oracle.aligned_copy(a), oracle.aligned_copy(b), "divide")
+    pa_, pb_, po_ = (PinnedBuffer(n * 8) for _ in range(3))
+    pa_.view(np.float64, n)[:] = a
+    pb_.view(np.float64, n)[:] = b
+    ctx.set_async(async_mode)
+    try:
+        ctx.apply("f64", pa_, pb_, OPS["divide"], po_, n, n)
+        ctx.synchronize()
+    finally:
+        ctx.set_async(False)
+    assert_float_bits_equal(po_.view(np.float64, n).copy(), want)
+    for buf in (pa_, pb_, po_):
+        buf.free()

@@ -1,7 +1,13 @@
 """GPU side of the rank-sharded SuperTable path (minarrow_amd/parallel.py): the device fold of per-(batch, column)
 records and the bit-granular join of gathered validity pieces. The collectives themselves are covered over gloo in
-tests/test_parallel_gloo.py; a GPU box has one card, so the exchange here is the one-rank copy."""
+tests/test_parallel_gloo.py; a GPU box has one card, so the exchange here is the one-rank copy.
+
+These checks hold device tensors, so torch must own the process's HIP runtime: it has to be imported BEFORE
+libminarrow_hip.so is loaded (as bench.py does), which cannot be arranged inside a pytest session whose other tests
+have already loaded the library. The checks therefore run in ONE child process (`python tests/test_gpu_sharded_table.py`)
+started by the single pytest test at the bottom."""
 import math
+import subprocess
 import sys
 from pathlib import Path
 
@@ -11,22 +17,18 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-pytestmark = pytest.mark.gpu
 
-
-@pytest.fixture(scope="module")
-def env():
-    import torch
+def make_env():
+    import torch  # first: the library then shares torch's HIP runtime
 
     from minarrow_amd.host import Context
 
     dev = torch.device("cuda", 0)
     ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
-    yield torch, dev, ctx
-    ctx.close()
+    return torch, dev, ctx
 
 
-def test_per_batch_records_fold_in_batch_order(env):
+def check_per_batch_records_fold_in_batch_order(env):
     torch, dev, ctx = env
     from minarrow_amd.parallel import ScalarExchange
 
@@ -63,8 +65,7 @@ def test_per_batch_records_fold_in_batch_order(env):
     assert ex.column_results() == [(isum, icnt, 0.0, 0), (0, 0, fsum, fcnt)]
 
 
-@pytest.mark.parametrize("rows", [[13, 1, 64, 7], [1000, 999, 0, 1001], [5]])
-def test_bit_granular_join_of_gathered_validity(env, rows):
+def check_bit_granular_join_of_gathered_validity(env, rows):
     torch, dev, ctx = env
     from minarrow_amd.parallel import join_bit_pieces
 
@@ -87,7 +88,7 @@ def test_bit_granular_join_of_gathered_validity(env, rows):
     assert out.cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_gather_consolidated_single_rank(env):
+def check_gather_consolidated_single_rank(env):
     torch, dev, ctx = env
     from minarrow_amd.parallel import gather_consolidated
 
@@ -98,3 +99,23 @@ def test_gather_consolidated_single_rank(env):
     assert gather_consolidated(vals, [1000], out, bits, out_bits, ctx=ctx)
     assert torch.equal(out, vals) and torch.equal(out_bits[:125], bits)
     assert not gather_consolidated(vals, [1000], out)
+
+
+def main():
+    env = make_env()
+    check_per_batch_records_fold_in_batch_order(env)
+    for rows in ([13, 1, 64, 7], [1000, 999, 0, 1001], [5]):
+        check_bit_granular_join_of_gathered_validity(env, rows)
+    check_gather_consolidated_single_rank(env)
+    env[2].close()
+    print("sharded-table checks ok")
+
+
+@pytest.mark.gpu
+def test_sharded_table_checks_in_a_torch_first_process():
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve())], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded-table checks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+if __name__ == "__main__":
+    main()

@@ -40,10 +40,28 @@ def main():
     dt = time.perf_counter() - t0
     assert int(pout.view(np.int64, n)[12345]) == 12345 + 3
     out["pinned_add_scalar"] = {"ms": dt * 1e3, "gbps_each_way": n * 8 / dt / 1e9}
+    # the same on pinned memory with the tiled pipeline off (kernel addresses host memory in place) and on (copy engines)
+    pin_b = PinnedBuffer(n * 8)
+    pin_b.view(np.int64, n)[:] = a[::-1]
+    for label, tile in (("in_place", 0), ("tiled_32MiB", 32 << 20)):
+        ctx.set_staging_tile(tile)
+        for form in ("array_array", "array_scalar"):
+            fn = (lambda: ctx.apply("i64", pin, pin_b, 0, pout, n, n)) if form == "array_array" else \
+                (lambda: ctx.apply_scalar("i64", "rhs", pin, n, 3, 0, pout))
+            fn()
+            times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                times.append(time.perf_counter() - t0)
+            assert int(pout.view(np.int64, n)[12345]) == (n - 1 if form == "array_array" else 12345 + 3)
+            moved = n * 8 * (3 if form == "array_array" else 2)
+            out[f"pinned_add_{form}_{label}"] = {"ms": min(times) * 1e3, "gbps_total": moved / min(times) / 1e9,
+                                                 "grows_per_s": n / min(times) / 1e9}
     # elementwise on pageable memory (a Rust &[T]): whole-operand staging vs the tiled pipeline (ma_pipeline.hip)
     b = np.arange(n, dtype=np.int64)[::-1].copy()
     res = np.zeros(n, dtype=np.int64)
-    for label, tile in [("whole_operand", 0)] + [(f"tiled_{t}MiB", t << 20) for t in (4, 8, 16, 32, 64)]:
+    for label, tile in [("whole_operand", 0)] + [(f"tiled_{t}MiB", t << 20) for t in (8, 32)]:
         ctx.set_staging_tile(tile)
         for form in ("array_array", "array_scalar"):
             fn = (lambda: ctx.apply("i64", a, b, 0, res, n, n)) if form == "array_array" else \
