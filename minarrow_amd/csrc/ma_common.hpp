@@ -110,7 +110,7 @@ inline bool crosses_in_tiles(const ma_ctx* ctx, PtrKind k) { return k == kPageab
 // temporary forces the call to be synchronous.
 class CallScope {
   public:
-    explicit CallScope(ma_ctx* ctx) : ctx_(ctx) {}
+    explicit CallScope(ma_ctx* ctx);  // pointer classifications are remembered until the scope ends
     ~CallScope();
     CallScope(const CallScope&) = delete;
     CallScope& operator=(const CallScope&) = delete;

@@ -7,7 +7,6 @@
 namespace ma {
 
 static thread_local char g_err[512] = "";
-static std::atomic<unsigned> g_free_generation{0};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -23,20 +22,29 @@ ma_status hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return e == hipErrorNoDevice ? MA_ERR_NO_DEVICE : MA_ERR_DEVICE;
 }
 
+// A chunked column hands over thousands of pointers into a few allocations (122 071 chunk pairs for 10^9 rows at the
+// reference's default 8192-row chunking), so the address ranges of the device allocations seen are remembered — but
+// only for the duration of ONE ABI call (the lifetime of its CallScope): while a call runs its caller cannot free
+// anything, whereas a range remembered across calls could have been freed behind the library's back (a torch tensor,
+// a hipFree by the host) and handed out again as host memory, which a kernel must never be pointed at.
+namespace {
+constexpr int kRanges = 8;
+thread_local uintptr_t t_lo[kRanges] = {0}, t_hi[kRanges] = {0};
+thread_local unsigned t_next_slot = 0;
+thread_local int t_scope_depth = 0;
+
+void forget_ranges() {
+    for (int i = 0; i < kRanges; ++i) t_lo[i] = t_hi[i] = 0;
+    t_next_slot = 0;
+}
+}  // namespace
+
 PtrKind pointer_kind(const void* p) {
-    // A chunked column hands over thousands of pointers into a few allocations (122 071 chunk pairs for 10^9 rows at
-    // the reference's default 8192-row chunking): remember the last device allocation's address range per thread.
-    constexpr int kRanges = 8;
-    static thread_local uintptr_t cached_lo[kRanges] = {0}, cached_hi[kRanges] = {0};
-    static thread_local unsigned cached_gen = 0, next_slot = 0;
-    const unsigned gen = g_free_generation.load(std::memory_order_relaxed);
-    if (cached_gen != gen) {  // something was freed through this library since the ranges were cached
-        for (int i = 0; i < kRanges; ++i) cached_lo[i] = cached_hi[i] = 0;
-        cached_gen = gen;
-    }
+    const bool remember = t_scope_depth > 0;
     const uintptr_t addr = (uintptr_t)p;
-    for (int i = 0; i < kRanges; ++i)
-        if (addr >= cached_lo[i] && addr < cached_hi[i]) return kDevice;
+    if (remember)
+        for (int i = 0; i < kRanges; ++i)
+            if (addr >= t_lo[i] && addr < t_hi[i]) return kDevice;
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
@@ -47,12 +55,14 @@ PtrKind pointer_kind(const void* p) {
         case hipMemoryTypeDevice: {
             hipDeviceptr_t base = nullptr;
             size_t size = 0;
-            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
-                cached_lo[next_slot] = (uintptr_t)base;
-                cached_hi[next_slot] = (uintptr_t)base + size;
-                next_slot = (next_slot + 1) % kRanges;
-            } else {
-                (void)hipGetLastError();
+            if (remember) {
+                if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
+                    t_lo[t_next_slot] = (uintptr_t)base;
+                    t_hi[t_next_slot] = (uintptr_t)base + size;
+                    t_next_slot = (t_next_slot + 1) % kRanges;
+                } else {
+                    (void)hipGetLastError();
+                }
             }
             return kDevice;
         }
@@ -68,11 +78,15 @@ PtrKind pointer_kind(const void* p) {
     }
 }
 
+CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
+    if (t_scope_depth++ == 0) forget_ranges();
+}
+
 CallScope::~CallScope() {
-    if (!temps_.empty()) g_free_generation.fetch_add(1, std::memory_order_relaxed);
     for (auto& t : temps_) {
         if (t.dev) (void)hipFree(t.dev);
     }
+    if (--t_scope_depth == 0 || !temps_.empty()) forget_ranges();
 }
 
 ma_status CallScope::in(const void* p, size_t bytes, const void** out) {
@@ -161,7 +175,7 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->scratch_bytes) {
         if (ctx->scratch) {
             MA_HIP(hipStreamSynchronize(ctx->stream));  // the previous user may still be running
-            g_free_generation.fetch_add(1, std::memory_order_relaxed);
+            forget_ranges();
             MA_HIP(hipFree(ctx->scratch));
             ctx->scratch = nullptr;
             ctx->scratch_bytes = 0;
@@ -572,7 +586,6 @@ ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
     MA_NO_CAPTURE(ctx, "ma_dev_free");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));
-    g_free_generation.fetch_add(1, std::memory_order_relaxed);
     MA_HIP(hipFree(dev_ptr));
     return MA_OK;
 }
