@@ -94,11 +94,12 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
 ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups);
 /* Kernel variant selector used by the tuning harness (0 = default). See DESIGN.md §kernels. */
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
-/* Host-resident (pageable) operands of the elementwise entry points — a Rust &[T] / Vec64<T> that was not allocated
- * with ma_alloc64_pinned; the reference's kernels read such slices in place (src/kernels/arithmetic/dispatch.rs:74-133)
- * — cross PCIe in tiles of tile_bytes per operand through a ring of device buffers owned by the context: the copy-in
- * of tile k+1, the kernels of tile k and the copy-out of tile k-1 overlap, and the device footprint is 12 tiles
- * whatever the column size. Pinned operands (ma_alloc64_pinned) of a synchronous call take the same route — the copy
+/* Host-resident (pageable) operands of the elementwise entry points and of the sum / mean reductions — a Rust &[T] /
+ * Vec64<T> that was not allocated with ma_alloc64_pinned; the reference's kernels read such slices in place
+ * (src/kernels/arithmetic/dispatch.rs:74-133) — cross PCIe in tiles of tile_bytes per operand through a ring of
+ * device buffers owned by the context: the copy-in of tile k+1, the kernels of tile k and the copy-out of tile k-1
+ * overlap, and the device footprint is 12 tiles whatever the column size (a reduction folds its per-tile
+ * {sum | hi, lo, count} records in tile order, so float sums keep their 1-ULP bound). Pinned operands (ma_alloc64_pinned) of a synchronous call take the same route — the copy
  * engines fill both directions of the link, a kernel addressing host memory in place does not; an async context
  * leaves them in place so that the call can return early. Default 32 MiB; calls shorter than two tiles, and every call
  * when tile_bytes == 0, stage whole pageable operands in temporary device buffers (and use pinned ones in place)

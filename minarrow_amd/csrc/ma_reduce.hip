@@ -20,6 +20,9 @@
 //     rounded sum regardless of order, and bit-reproducible for a fixed grid.
 //   * Wave reduce by shuffles -> 4 LDS slots -> one 32-byte partial per workgroup -> the workgroup that
 //     draws the last ticket folds all partials in index order (agent-scope release/acquire).
+#include <cmath>
+#include <limits>
+
 #include "ma_acc.hpp"
 #include "ma_device.hpp"
 
@@ -256,48 +259,13 @@ static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
     hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
+// Enqueues one sum launch on ctx->stream. `a` carries device-reachable data / validity (data, n, words, bit_off,
+// last_word) and output addresses; the launch shape is chosen here.
 template <typename T>
-static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
-                          int64_t null_count, int mode, bool is_signed, void* out_a, void* out_b,
-                          uint64_t* out_cnt, double* out_mean) {
-    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    MA_REQUIRE(n == 0 || data != nullptr, MA_ERR_INVALID_ARGUMENT, "data is NULL");
-    MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "data pointer %p is not aligned to its element size",
-               (const void*)data);
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    MA_HIP(hipSetDevice(ctx->device));
-
-    // The reference gates on the cached null count / all_true_mask before touching a mask
-    // (src/kernels/arithmetic/simd.rs:144,454): no mask, or a mask known to be all-valid => dense kernel.
-    const bool masked = mask_bits != nullptr && null_count != 0 && n != 0;
-
-    CallScope scope(ctx);
-    SumArgs a{};
-    const void* d = nullptr;
-    MA_TRY(scope.in(data, n * sizeof(T), &d));
-    a.data = d;
-    a.n = n;
-    if (masked) {
-        MA_TRY(scope.in_mask(mask_bits, mask_bit_offset, n, &a.words, &a.bit_off));
-        a.last_word = (a.bit_off + n - 1) >> 6;
-    }
-    // Scalar outputs: directly into caller memory when it is device-reachable, else via the pinned slot.
-    ResultSlot* slot = ctx->result;
-    auto route = [&](void* user) -> bool { return user != nullptr && pointer_kind(user) != kPageable; };
-    const bool direct_a = route(out_a), direct_b = route(out_b), direct_c = route(out_cnt), direct_m = route(out_mean);
-    const bool any_slot = (out_a && !direct_a) || (out_b && !direct_b) || (out_cnt && !direct_c) || (out_mean && !direct_m);
-    MA_REQUIRE(!(ctx->async && any_slot), MA_ERR_INVALID_ARGUMENT,
-               "async mode needs device-reachable (pinned or device) output pointers");
-    a.out_a = out_a ? (direct_a ? (uint64_t*)out_a : &slot->a) : nullptr;
-    a.out_b = out_b ? (direct_b ? (uint64_t*)out_b : &slot->b) : nullptr;
-    a.out_cnt = out_cnt ? (direct_c ? out_cnt : &slot->cnt) : nullptr;
-    double* mean_slot = (double*)&slot[1].a;
-    a.out_mean = out_mean ? (direct_m ? out_mean : mean_slot) : nullptr;
-    a.mode = mode;
-    a.is_signed = is_signed ? 1 : 0;
+static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
+    const size_t n = a.n;
     a.partials = ctx->partials;
     a.ticket = ctx->ticket;
-
     constexpr int R = 16 / (int)sizeof(T);
     // Launch shape. Measured on MI355X at 10^9 rows (profiles/r01_sweep_sum_v2.txt): what matters is ~8 KiB of
     // loads in flight per SIMD (unroll x workgroups/CU = 8); more only queues, less starves. Dense 8-byte
@@ -365,6 +333,151 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     }
 #undef MA_LAUNCH_U
     MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// Double-double / integer fold of per-tile records on the host (same operations as DDAcc::merge / normalise; the
+// translation unit is built with -ffp-contract=off, so host and device round identically).
+struct HostFold {
+    uint64_t isum = 0, cnt = 0;
+    double hi = 0.0, lo = 0.0;
+    void add(uint64_t a, uint64_t b, uint64_t c, bool is_float) {
+        cnt += c;
+        if (!is_float) {
+            isum += a;
+            return;
+        }
+        double oh, ol;
+        memcpy(&oh, &a, 8);
+        memcpy(&ol, &b, 8);
+        const double t = hi + oh;
+        const double bp = t - hi;
+        const double e = (hi - (t - bp)) + (oh - bp);
+        hi = t;
+        lo += e + ol;
+    }
+    void normalise() {
+        if (std::isfinite(hi) && std::isfinite(lo)) {
+            const double t = hi + lo;
+            lo = lo - (t - hi);
+            hi = t;
+        } else {
+            lo = 0.0;
+        }
+    }
+};
+
+// One tile of a host-resident column (run_tiled, ma_pipeline.hip): its {sum | hi, lo, count} lands in record k.
+template <typename T>
+struct SumTile {
+    ma_ctx* ctx;
+    SumArgs base;       // the whole call's validity (words, bit_off) and mode
+    bool masked;
+    uint64_t* records;  // device, 4 words per tile
+    size_t tile_rows;
+    static ma_status run(void* user, size_t row0, size_t rows, void* const* ptrs) {
+        const SumTile& t = *(const SumTile*)user;
+        SumArgs a = t.base;
+        a.data = ptrs[0];
+        a.n = rows;
+        if (t.masked) {
+            const size_t bit = t.base.bit_off + row0;
+            a.words = t.base.words + (bit >> 6);
+            a.bit_off = bit & 63;
+            a.last_word = (a.bit_off + rows - 1) >> 6;
+        }
+        uint64_t* rec = t.records + 4 * (row0 / t.tile_rows);
+        a.out_a = rec;
+        a.out_b = rec + 1;
+        a.out_cnt = rec + 2;
+        a.out_mean = nullptr;
+        return enqueue_sum<T>(t.ctx, a, t.masked);
+    }
+};
+
+template <typename T>
+static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                          int64_t null_count, int mode, bool is_signed, void* out_a, void* out_b,
+                          uint64_t* out_cnt, double* out_mean) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(n == 0 || data != nullptr, MA_ERR_INVALID_ARGUMENT, "data is NULL");
+    MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "data pointer %p is not aligned to its element size",
+               (const void*)data);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+
+    // The reference gates on the cached null count / all_true_mask before touching a mask
+    // (src/kernels/arithmetic/simd.rs:144,454): no mask, or a mask known to be all-valid => dense kernel.
+    const bool masked = mask_bits != nullptr && null_count != 0 && n != 0;
+
+    // A host-resident (pageable) column crosses PCIe in tiles through the context's staging ring instead of a
+    // temporary device copy of the whole column (ma_pipeline.hip): tile k's scan writes record k, the records are
+    // folded in tile order — error-free for the double-double pairs, so the result keeps its 1-ULP bound.
+    constexpr bool kFloat = std::is_floating_point<T>::value;
+    const size_t stage_rows = (ctx->staging_tile_bytes / sizeof(T)) & ~(size_t)32767;
+    if (stage_rows && n >= 2 * stage_rows && !ctx->capturing && pointer_kind(data) == kPageable) {
+        const size_t n_tiles = (n + stage_rows - 1) / stage_rows;
+        CallScope tscope(ctx);
+        SumArgs base{};
+        base.mode = 1;  // floats: keep (hi, lo) per tile
+        base.is_signed = is_signed ? 1 : 0;
+        if (masked) MA_TRY(tscope.in_mask(mask_bits, mask_bit_offset, n, &base.words, &base.bit_off));
+        void* rec = nullptr;
+        MA_TRY(ctx_scratch(ctx, n_tiles * 32, &rec));
+        SumTile<T> call{ctx, base, masked, (uint64_t*)rec, stage_rows};
+        PipeOperand op{data, nullptr, sizeof(T), true};
+        MA_TRY(run_tiled(ctx, n, stage_rows, &op, 1, &SumTile<T>::run, &call));
+        std::vector<uint64_t> host(n_tiles * 4);
+        MA_HIP(hipMemcpy(host.data(), rec, n_tiles * 32, hipMemcpyDeviceToHost));
+        HostFold f;
+        for (size_t k = 0; k < n_tiles; ++k) f.add(host[4 * k], host[4 * k + 1], host[4 * k + 2], kFloat);
+        f.normalise();
+        uint64_t word_a = f.isum, word_b = 0;
+        double as_double = is_signed ? (double)(int64_t)f.isum : (double)f.isum;
+        if (kFloat) {
+            as_double = f.hi;
+            memcpy(&word_a, &f.hi, 8);
+            memcpy(&word_b, &f.lo, 8);
+        }
+        const double mean = f.cnt ? as_double / (double)f.cnt : std::numeric_limits<double>::quiet_NaN();
+        auto put = [&](void* user, const void* value) -> ma_status {
+            if (!user) return MA_OK;
+            if (pointer_kind(user) == kDevice) MA_HIP(hipMemcpy(user, value, 8, hipMemcpyHostToDevice));
+            else memcpy(user, value, 8);
+            return MA_OK;
+        };
+        MA_TRY(put(out_a, &word_a));
+        if (mode == 1) MA_TRY(put(out_b, &word_b));
+        MA_TRY(put(out_cnt, &f.cnt));
+        MA_TRY(put(out_mean, &mean));
+        return MA_OK;
+    }
+
+    CallScope scope(ctx);
+    SumArgs a{};
+    const void* d = nullptr;
+    MA_TRY(scope.in(data, n * sizeof(T), &d));
+    a.data = d;
+    a.n = n;
+    if (masked) {
+        MA_TRY(scope.in_mask(mask_bits, mask_bit_offset, n, &a.words, &a.bit_off));
+        a.last_word = (a.bit_off + n - 1) >> 6;
+    }
+    // Scalar outputs: directly into caller memory when it is device-reachable, else via the pinned slot.
+    ResultSlot* slot = ctx->result;
+    auto route = [&](void* user) -> bool { return user != nullptr && pointer_kind(user) != kPageable; };
+    const bool direct_a = route(out_a), direct_b = route(out_b), direct_c = route(out_cnt), direct_m = route(out_mean);
+    const bool any_slot = (out_a && !direct_a) || (out_b && !direct_b) || (out_cnt && !direct_c) || (out_mean && !direct_m);
+    MA_REQUIRE(!(ctx->async && any_slot), MA_ERR_INVALID_ARGUMENT,
+               "async mode needs device-reachable (pinned or device) output pointers");
+    a.out_a = out_a ? (direct_a ? (uint64_t*)out_a : &slot->a) : nullptr;
+    a.out_b = out_b ? (direct_b ? (uint64_t*)out_b : &slot->b) : nullptr;
+    a.out_cnt = out_cnt ? (direct_c ? out_cnt : &slot->cnt) : nullptr;
+    double* mean_slot = (double*)&slot[1].a;
+    a.out_mean = out_mean ? (direct_m ? out_mean : mean_slot) : nullptr;
+    a.mode = mode;
+    a.is_signed = is_signed ? 1 : 0;
+    MA_TRY(enqueue_sum<T>(ctx, a, masked));
     MA_TRY(end_call(ctx, scope));
     if (!ctx->async) {
         if (out_a && !direct_a) memcpy(out_a, &slot->a, 8);

@@ -185,3 +185,44 @@ def test_pinned_vec64_operands(tiled, oracle, async_mode):
     assert_float_bits_equal(po_.view(np.float64, n).copy(), want)
     for buf in (pa_, pb_, po_):
         buf.free()
+
+
+@pytest.mark.parametrize("tag", ["i64", "u32", "f64", "f32"])
+def test_host_resident_column_sums_in_tiles(tiled, oracle, tag):
+    """Sum / valid count / mean of a pageable column: tile k's scan writes record k, records fold in tile order.
+    Integers bit-exact against the oracle; floats within 1 ULP of the exactly rounded sum, like resident columns."""
+    import math
+
+    ctx = tiled
+    rng = np.random.default_rng(17)
+    n = rows_for(tag, 5.3)
+    dt = NP[tag]
+    if tag in ("f64", "f32"):
+        data = (rng.standard_normal(n) * 10.0 ** rng.integers(0, 9, size=n)).astype(dt)
+    else:
+        data = rand_ints(rng, tag, n)
+    bits = rng.integers(0, 256, size=(n + 11 + 7) // 8 + 16, dtype=np.uint8)
+    valid = unpack(bits, n, 11)
+    for mask, off, sel in ((None, 0, data), (bits, 11, data[valid])):
+        s, c = ctx.sum(tag, data, n, mask=mask, mask_bit_offset=off)
+        m, c2 = ctx.mean(tag, data, n, mask=mask, mask_bit_offset=off)
+        assert c == c2 == sel.size
+        if tag in ("f64", "f32"):
+            exact = math.fsum(sel.astype(np.float64).tolist())
+            assert abs(s - exact) <= math.ulp(exact)
+            hi, lo, c3 = ctx.sum_dd(tag, data, n, mask=mask, mask_bit_offset=off)
+            assert hi == s and c3 == c and abs(lo) <= math.ulp(hi)
+            assert m == s / c
+        else:
+            want = int(sel.astype(object).sum())
+            wrap = ((want + (1 << 63)) % (1 << 64)) - (1 << 63) if tag == "i64" else want % (1 << 64)
+            assert s == wrap
+            assert m == float(s) / c
+    # same column resident in HBM: identical integer bits, float within the same bound
+    d = ctx.to_device(data, 64)
+    s_dev, _ = ctx.sum(tag, d, n)
+    s_host, _ = ctx.sum(tag, data, n)
+    if tag in ("f64", "f32"):
+        assert abs(s_dev - s_host) <= math.ulp(s_dev)
+    else:
+        assert s_dev == s_host
