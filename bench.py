@@ -188,6 +188,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
+                         "GPU(s) and the 64-byte records cross host memory; never a reported number")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -208,18 +211,23 @@ def main() -> int:
                   file=sys.stderr)
             return 2
     distributed = world > 1 or args.force_dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.backend == "gloo"
+    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     rows = args.rows
     stream = torch.cuda.current_stream(dev)
-    ctx = Context(local_rank, stream=stream.cuda_stream)
+    ctx = Context(device_index, stream=stream.cuda_stream)
     ctx.set_variant(args.variant)
     ctx.set_blocks_per_cu(args.blocks_per_cu)
 
@@ -266,7 +274,7 @@ def main() -> int:
     ctx.synchronize()
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     torch.cuda.synchronize(dev)
@@ -315,7 +323,8 @@ def main() -> int:
                             f"HBM-resident (BASELINE configs[1])",
                 "rows_per_gpu_per_column": rows,
                 "columns": ["i64", "f64"],
-                "parallelism": f"row-chunk x{world}" + (" + RCCL all-gather of scalars" if distributed else ""),
+                "parallelism": f"row-chunk x{world}" + ((" + gloo all-gather of scalars (REHEARSAL: ranks share a GPU)" if rehearsal
+                                                          else " + RCCL all-gather of scalars") if distributed else ""),
                 "variant": args.variant,
                 "blocks_per_cu": args.blocks_per_cu or "auto",
             },

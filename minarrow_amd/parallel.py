@@ -105,10 +105,17 @@ class ScalarExchange:
 
     def exchange(self) -> None:
         """Enqueue the collective on the current stream (async w.r.t. the host)."""
-        if self.dist.is_initialized():
-            self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
-        else:
+        if not self.dist.is_initialized():
             self.gathered.copy_(self.local)
+        elif self.local.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal of the multi-rank path on a box without RCCL peers (several ranks sharing one GPU): the records
+            # take the detour over host memory; everything around the collective is the production path
+            mine = self.local.cpu()
+            everyone = self.torch.empty(self.gathered.numel(), dtype=self.torch.int64)
+            self.dist.all_gather_into_tensor(everyone, mine, group=self.group)
+            self.gathered.copy_(everyone)
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
 
     def fold_on_device(self, ctx) -> None:
         """Enqueue the rank-ordered fold of the gathered records on `ctx`'s stream (ma_fold_sum_records): the job's

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--configs", type=str, default="3,4,5")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank logic with the ranks sharing the visible GPU(s)")
     ap.add_argument("--config5-rows", type=int, default=0, help="rows per SuperTable batch (default rows/8)")
     args = ap.parse_args()
 
@@ -54,12 +56,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.backend == "gloo"
+    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream(dev)
-    ctx = Context(local_rank, stream=stream.cuda_stream)
+    ctx = Context(device_index, stream=stream.cuda_stream)
     n = args.rows
     configs = args.configs.split(",")
     out = []
@@ -132,14 +139,14 @@ def main():
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / args.reps
         if world > 1:
-            t = torch.tensor([ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms = float(t.item())
         ctx.set_async(False)
         total, cnt, _, _ = ex.results()
         if rank == 0:
             out.append({"config": 4, "workload": f"{n}-row i64 sum, 10 % nulls via Bitmask, row chunks over {world} GPU(s)"
-                        + (" + RCCL all-gather" if world > 1 else ""), "n_gpus": world, "ms_per_step": ms,
+                        + ((" + gloo all-gather (REHEARSAL: ranks share a GPU)" if rehearsal else " + RCCL all-gather") if world > 1 else ""), "n_gpus": world, "ms_per_step": ms,
                         "grows_per_s": n / ms / 1e6, "gbps": 8.125 * n / ms / 1e6, "bytes_per_row": 8.125,
                         "sum_valid": total, "valid_count": cnt, "null_fraction": 1 - cnt / n})
         data.free()
@@ -196,7 +203,7 @@ def main():
             ms_reduce_physical = timed(ctx, lambda: ctx.sum_into(tag, o, local * rows, out_sum=ex.slot_ptr(5), out_count=ex.slot_ptr(6),
                                                                  mask=om), args.reps) if local else 0.0
             if world > 1:
-                t = torch.tensor([ms_reduce_logical, ms, ms_reduce_physical], dtype=torch.float64, device=dev)
+                t = torch.tensor([ms_reduce_logical, ms, ms_reduce_physical], dtype=torch.float64, device="cpu" if rehearsal else dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ms_reduce_logical, ms, ms_reduce_physical = (float(v) for v in t.tolist())
             ctx.set_async(False)
