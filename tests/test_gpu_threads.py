@@ -45,3 +45,38 @@ def test_one_context_per_thread():
     for c in ctxs:
         c.close()
     assert not errors, errors
+
+
+def host_worker(ctx, seed, n, errors, reps=4):
+    """Host-resident operands: every call runs the tiled staging pipeline (its own helper thread, the context's ring)."""
+    try:
+        rng = np.random.default_rng(seed)
+        a = rng.integers(-(1 << 40), 1 << 40, size=n, dtype=np.int64)
+        b = rng.integers(1, 1 << 20, size=n, dtype=np.int64)
+        out = np.zeros(n, dtype=np.int64)
+        want_sum, want_mul = int(a.sum()), a * b
+        for _ in range(reps):
+            assert ctx.sum("i64", a, n) == (want_sum, n)
+            ctx.apply("i64", a, b, 2, out, n, n)
+            np.testing.assert_array_equal(out, want_mul)
+    except Exception as e:  # noqa: BLE001
+        errors.append(repr(e))
+
+
+def test_tiled_host_operands_from_many_threads(ctx):
+    from minarrow_amd.host import Context
+
+    errors = []
+    own = [Context(0) for _ in range(3)]
+    for c in own + [ctx]:
+        c.set_staging_tile(256 << 10)
+    try:
+        threads = [threading.Thread(target=host_worker, args=(c, 7 + i, 150_011 + 4096 * i, errors)) for i, c in enumerate(own)]
+        threads += [threading.Thread(target=host_worker, args=(ctx, 50 + i, 140_003, errors)) for i in range(3)]  # shared
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    finally:
+        ctx.set_staging_tile(32 << 20)
+        for c in own:
+            c.close()
+    assert not errors, errors
