@@ -492,6 +492,33 @@ ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, 
                                 const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
                                 int32_t* out_has_mask);
 
+/* Whole-table consolidation into ONE arena — consolidate_tables_arena for the numeric columns of a SuperTable
+ *   consolidate_arena -> consolidate_tables_arena   src/structs/chunked/super_table.rs:727-743, src/structs/arena.rs:1187-1340
+ *   Arena::reserve_slice / align_cursor / write_slices   src/structs/arena.rs:152-232, 264-308
+ *   Arena::capacity_for_regions                          src/structs/arena.rs:442-447
+ * Layout (ma_arena_layout; pure host arithmetic, no device needed): per column, in column order, a data region of
+ * n_rows * elem_sizes[c] bytes at the next 64-byte boundary, then — iff has_nulls[c] — a validity region of
+ * ceil(n_rows / 8) bytes at the next 64-byte boundary. out_mask_offsets[c] = SIZE_MAX for a column without nulls.
+ * *out_capacity_bytes = sum of the 64-byte-rounded regions (what the reference allocates), *out_used_bytes = end of the
+ * last region (what Arena::freeze keeps). Any output pointer may be NULL.
+ *
+ * ma_consolidate_table_arena joins batch b = 0..n_batches-1 of every column c into that layout inside `arena`
+ * (device, pinned or pageable memory of at least the capacity, 64-byte aligned): cell (c, b) is
+ * cell_data[c * n_batches + b] with batch_rows[b] rows and optional validity cell_masks[c * n_batches + b] whose row 0
+ * is bit cell_mask_offsets[c * n_batches + b] (both tables may be NULL). A column has nulls iff any of its cells has a
+ * mask (arena.rs:1207-1209); cells without one contribute all-valid bits (arena.rs:291-296). All columns of one element
+ * width are copied by ONE launch, each nullable column's validity is assembled by one more, whatever n_batches is — the
+ * 100-batch x 20-column shape of benches/consolidate.rs costs a handful of launches and one descriptor upload instead of
+ * 2 000 memcpys. Region padding bytes are left untouched in a device-reachable arena and zero in a pageable one. */
+ma_status ma_arena_layout(size_t n_cols, const size_t* elem_sizes, const int32_t* has_nulls, size_t n_rows,
+                          size_t* out_data_offsets, size_t* out_mask_offsets, size_t* out_capacity_bytes,
+                          size_t* out_used_bytes);
+ma_status ma_consolidate_table_arena(ma_ctx* ctx, size_t n_cols, size_t n_batches, const size_t* elem_sizes,
+                                     const size_t* batch_rows, const void* const* cell_data,
+                                     const uint8_t* const* cell_masks, const size_t* cell_mask_offsets, void* arena,
+                                     size_t arena_bytes, size_t* out_data_offsets, size_t* out_mask_offsets,
+                                     size_t* out_used_bytes);
+
 /* Bit-packed columns — BooleanArray data bits and stand-alone bitmaps:
  *   Bitmask::extend_from_bitmask_range / extend_from_slice   src/structs/bitmask.rs:520-592
  *   BooleanArray::append_range                                src/structs/variants/boolean.rs:627-653

@@ -304,6 +304,160 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole-table consolidation into one arena: consolidate_tables_arena (src/structs/arena.rs:1187-1340) for numeric
+// columns. The layout is the reference's cursor rule (align_cursor + reserve_slice, arena.rs:152-232).
+// ------------------------------------------------------------------------------------------------
+extern "C" ma_status ma_arena_layout(size_t n_cols, const size_t* elem_sizes, const int32_t* has_nulls, size_t n_rows,
+                                     size_t* out_data_offsets, size_t* out_mask_offsets, size_t* out_capacity_bytes,
+                                     size_t* out_used_bytes) {
+    MA_REQUIRE(n_cols == 0 || elem_sizes != nullptr, MA_ERR_INVALID_ARGUMENT, "elem_sizes is NULL");
+    auto align64 = [](size_t b) { return (b + 63) & ~(size_t)63; };  // src/utils.rs:178-180
+    const size_t mask_bytes = (n_rows + 7) / 8;
+    size_t cursor = 0, capacity = 0;
+    for (size_t c = 0; c < n_cols; ++c) {
+        const size_t e = elem_sizes[c];
+        MA_REQUIRE(e == 1 || e == 2 || e == 4 || e == 8, MA_ERR_UNSUPPORTED, "column %zu: element size %zu is not a numeric width", c, e);
+        cursor = align64(cursor);
+        if (out_data_offsets) out_data_offsets[c] = cursor;
+        cursor += n_rows * e;
+        capacity += align64(n_rows * e);
+        const bool nulls = has_nulls && has_nulls[c];
+        if (nulls) {
+            cursor = align64(cursor);
+            if (out_mask_offsets) out_mask_offsets[c] = cursor;
+            cursor += mask_bytes;
+            capacity += align64(mask_bytes);
+        } else if (out_mask_offsets) {
+            out_mask_offsets[c] = SIZE_MAX;
+        }
+    }
+    if (out_capacity_bytes) *out_capacity_bytes = capacity;
+    if (out_used_bytes) *out_used_bytes = cursor;
+    return MA_OK;
+}
+
+extern "C" ma_status ma_consolidate_table_arena(ma_ctx* ctx, size_t n_cols, size_t n_batches, const size_t* elem_sizes,
+                                                const size_t* batch_rows, const void* const* cell_data,
+                                                const uint8_t* const* cell_masks, const size_t* cell_mask_offsets,
+                                                void* arena, size_t arena_bytes, size_t* out_data_offsets,
+                                                size_t* out_mask_offsets, size_t* out_used_bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    // arena.rs:1196: "consolidate called on empty table set"
+    MA_REQUIRE(n_batches > 0, MA_ERR_INVALID_ARGUMENT, "consolidate called on empty table set");
+    MA_REQUIRE(n_cols > 0 && elem_sizes && batch_rows && cell_data, MA_ERR_INVALID_ARGUMENT, "NULL or empty table description");
+    MA_REQUIRE(n_cols < ((size_t)1 << 20) && n_batches < ((size_t)1 << 30) && n_cols * n_batches < ((size_t)1 << 30),
+               MA_ERR_INVALID_ARGUMENT, "too many cells");
+    size_t n_rows = 0;
+    for (size_t b = 0; b < n_batches; ++b) n_rows += batch_rows[b];
+    std::vector<int32_t> has_nulls(n_cols, 0);
+    if (cell_masks)
+        for (size_t c = 0; c < n_cols; ++c)
+            for (size_t b = 0; b < n_batches; ++b)
+                if (cell_masks[c * n_batches + b]) has_nulls[c] = 1;
+    std::vector<size_t> data_off(n_cols), mask_off(n_cols);
+    size_t capacity = 0, used = 0;
+    MA_TRY(ma_arena_layout(n_cols, elem_sizes, has_nulls.data(), n_rows, data_off.data(), mask_off.data(), &capacity, &used));
+    if (out_data_offsets) memcpy(out_data_offsets, data_off.data(), sizeof(size_t) * n_cols);
+    if (out_mask_offsets) memcpy(out_mask_offsets, mask_off.data(), sizeof(size_t) * n_cols);
+    if (out_used_bytes) *out_used_bytes = used;
+    if (n_rows == 0) return MA_OK;
+    MA_REQUIRE(arena != nullptr, MA_ERR_INVALID_ARGUMENT, "arena is NULL");
+    MA_REQUIRE(((uintptr_t)arena & 63) == 0, MA_ERR_INVALID_ARGUMENT, "the arena must be 64-byte aligned (Vec64)");
+    // Arena::reserve_slice asserts "Arena overflow" (arena.rs:210-216); the reference sizes it with the rounded regions.
+    MA_REQUIRE(arena_bytes >= capacity, MA_ERR_INVALID_ARGUMENT, "Arena overflow: need %zu bytes, capacity is %zu", capacity, arena_bytes);
+    for (size_t c = 0; c < n_cols; ++c)
+        for (size_t b = 0; b < n_batches; ++b) {
+            const void* p = cell_data[c * n_batches + b];
+            MA_REQUIRE(batch_rows[b] == 0 || p != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu batch %zu: data is NULL", c, b);
+            MA_REQUIRE(((uintptr_t)p % elem_sizes[c]) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu batch %zu is misaligned", c, b);
+        }
+
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    void* pa = nullptr;
+    MA_TRY(scope.out(arena, capacity, &pa));
+    // A pageable arena is staged through a temporary that is copied back whole: give its padding defined (zero) bytes,
+    // as Arena::with_capacity pre-fills (arena.rs:125-130). A device-reachable arena keeps whatever its padding held.
+    if (pa != arena) MA_HIP(hipMemsetAsync(pa, 0, capacity, ctx->stream));
+    // Descriptor table: first the copy descriptors grouped by element width (one launch per width; `start` counts
+    // elements from the arena base — regions are 64-byte aligned, so every data offset is a whole number of elements),
+    // then one run of validity descriptors per nullable column (`start` = the batch's first row in the column).
+    struct Group { size_t first = 0, count = 0, n_tiles = 0; };
+    Group groups[4];
+    std::vector<ChunkDesc> desc;
+    desc.reserve(n_cols * n_batches * 2);
+    const size_t widths[4] = {1, 2, 4, 8};
+    for (int g = 0; g < 4; ++g) {
+        const size_t e = widths[g];
+        const size_t tile_rows = e == 1 ? tile_rows_of<uint8_t>() : e == 2 ? tile_rows_of<uint16_t>()
+                               : e == 4 ? tile_rows_of<uint32_t>() : tile_rows_of<uint64_t>();
+        groups[g].first = desc.size();
+        for (size_t c = 0; c < n_cols; ++c) {
+            if (elem_sizes[c] != e) continue;
+            size_t row = 0;
+            for (size_t b = 0; b < n_batches; ++b) {
+                ChunkDesc d{};
+                const void* p = nullptr;
+                MA_TRY(scope.in(cell_data[c * n_batches + b], batch_rows[b] * e, &p));
+                d.data = p;
+                d.start = data_off[c] / e + row;
+                d.len = batch_rows[b];
+                const uintptr_t mis = ((uintptr_t)pa + d.start * e) & 15;
+                d.head = mis ? (unsigned)((16 - mis) / e) : 0;
+                d.tile0 = groups[g].n_tiles;
+                if (d.len) groups[g].n_tiles += d.len > d.head ? (d.len - d.head + tile_rows - 1) / tile_rows : 1;
+                desc.push_back(d);
+                row += batch_rows[b];
+            }
+        }
+        groups[g].count = desc.size() - groups[g].first;
+    }
+    std::vector<size_t> mask_first(n_cols, 0);
+    for (size_t c = 0; c < n_cols; ++c) {
+        if (!has_nulls[c]) continue;
+        mask_first[c] = desc.size();
+        size_t row = 0;
+        for (size_t b = 0; b < n_batches; ++b) {
+            ChunkDesc d{};
+            d.start = row;
+            d.len = batch_rows[b];
+            const uint8_t* m = cell_masks[c * n_batches + b];
+            if (m && d.len) {
+                MA_TRY(scope.in_mask(m, cell_mask_offsets ? cell_mask_offsets[c * n_batches + b] : 0, d.len, &d.words, &d.bit_off));
+                d.last_word = (d.bit_off + d.len - 1) >> 6;
+            }
+            desc.push_back(d);
+            row += batch_rows[b];
+        }
+    }
+    void* ddesc = nullptr;
+    MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * desc.size(), &ddesc));
+    MA_HIP(hipMemcpyAsync(ddesc, desc.data(), sizeof(ChunkDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));  // `desc` lives in this frame: the copy must leave it before we continue
+    const ChunkDesc* d = (const ChunkDesc*)ddesc;
+    for (int g = 0; g < 4; ++g) {
+        if (!groups[g].n_tiles) continue;
+        const ChunkDesc* dg = d + groups[g].first;
+        const int k = (int)groups[g].count;
+        switch (widths[g]) {
+            case 1: launch_concat<uint8_t>(ctx, dg, k, groups[g].n_tiles, pa); break;
+            case 2: launch_concat<uint16_t>(ctx, dg, k, groups[g].n_tiles, pa); break;
+            case 4: launch_concat<uint32_t>(ctx, dg, k, groups[g].n_tiles, pa); break;
+            default: launch_concat<uint64_t>(ctx, dg, k, groups[g].n_tiles, pa); break;
+        }
+        MA_HIP(hipGetLastError());
+    }
+    for (size_t c = 0; c < n_cols; ++c) {
+        if (!has_nulls[c]) continue;
+        launch_concat_mask(ctx, d + mask_first[c], n_batches, n_rows, (uint64_t*)((char*)pa + mask_off[c]));
+        MA_HIP(hipGetLastError());
+    }
+    return end_call(ctx, scope);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bit-packed columns: BooleanArray data and stand-alone bitmaps.
 //   Bitmask::extend_from_bitmask_range / extend_from_slice      src/structs/bitmask.rs:520-592
 //   BooleanArray::append_range (data bits, then the mask rules)  src/structs/variants/boolean.rs:627-653

@@ -435,6 +435,30 @@ class Context:
             C.addressof(has)))
         return bool(has.value)
 
+    def consolidate_table_arena(self, elem_sizes, batch_rows, cells, arena, arena_bytes: int, cell_masks=None,
+                                cell_mask_offsets=None):
+        """Whole-table consolidation into one arena (ma_consolidate_table_arena; src/structs/arena.rs:1187-1340).
+        cells[c][b] = buffer of column c, batch b; cell_masks[c][b] = validity buffer or None. Returns
+        (data offsets, mask offsets with None for columns without nulls, used bytes)."""
+        n_cols, n_batches = len(elem_sizes), len(batch_rows)
+        k = n_cols * n_batches
+        flat = [cells[c][b] for c in range(n_cols) for b in range(n_batches)]
+        data_arr = (C.c_void_p * k)(*[addr_of(x) or None for x in flat])
+        mask_arr = off_arr = None
+        if cell_masks is not None:
+            mask_arr = (C.c_void_p * k)(*[addr_of(cell_masks[c][b]) or None for c in range(n_cols) for b in range(n_batches)])
+        if cell_mask_offsets is not None:
+            off_arr = (C.c_size_t * k)(*[int(cell_mask_offsets[c][b]) for c in range(n_cols) for b in range(n_batches)])
+        es = (C.c_size_t * n_cols)(*[int(e) for e in elem_sizes])
+        br = (C.c_size_t * n_batches)(*[int(r) for r in batch_rows])
+        d_off, m_off, used = (C.c_size_t * n_cols)(), (C.c_size_t * n_cols)(), C.c_size_t()
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        ffi.check(self.lib.ma_consolidate_table_arena(self.handle, n_cols, n_batches, cast(es), cast(br), cast(data_arr),
+                                                      cast(mask_arr), cast(off_arr), addr_of(arena), int(arena_bytes),
+                                                      cast(d_off), cast(m_off), C.addressof(used)))
+        none = (1 << 64) - 1
+        return list(d_off), [None if m == none else int(m) for m in m_off], int(used.value)
+
     def consolidate_boolean_column(self, chunks, out_bits, masks=None, out_mask=None) -> bool:
         """chunks: [(bits buffer, bit offset, len)]; masks: [(bits buffer, bit offset) or None]. Returns True when
         out_mask was written (BooleanArray::append_range, src/structs/variants/boolean.rs:627-653)."""
@@ -499,3 +523,19 @@ class Context:
         ffi.check(self.lib.ma_sum_arrow_stream(self.handle, int(stream_ptr), int(column), C.addressof(f), C.addressof(i),
                                                C.addressof(c), C.addressof(r), C.addressof(b)))
         return f.value, i.value, int(c.value), int(r.value), int(b.value)
+
+
+def arena_layout(elem_sizes, has_nulls, n_rows: int):
+    """(data offsets, mask offsets or None, capacity bytes, used bytes) of the reference's arena for these columns
+    (ma_arena_layout: host arithmetic only — works without a GPU)."""
+    lib = ffi.load_library()
+    n = len(elem_sizes)
+    es = (C.c_size_t * n)(*[int(e) for e in elem_sizes])
+    hn = (C.c_int32 * n)(*[1 if h else 0 for h in has_nulls])
+    d_off, m_off = (C.c_size_t * n)(), (C.c_size_t * n)()
+    cap, used = C.c_size_t(), C.c_size_t()
+    cast = lambda a: C.cast(a, C.c_void_p)
+    ffi.check(lib.ma_arena_layout(n, cast(es), cast(hn), int(n_rows), cast(d_off), cast(m_off), C.addressof(cap),
+                                  C.addressof(used)))
+    none = (1 << 64) - 1
+    return list(d_off), [None if m == none else int(m) for m in m_off], int(cap.value), int(used.value)

@@ -476,3 +476,62 @@ def consolidate_boolean_column(chunks, masks=None):
                                           cast(mb_arr), cast(mo_arr), _p(out), _p(out_mask))
     nbytes = ((total + 63) // 64) * 8
     return out[:nbytes], (out_mask[:nbytes] if has else None)
+
+
+# ---- arena consolidation (src/structs/arena.rs) --------------------------------------------------------------------
+
+def align64(n: int) -> int:
+    """src/utils.rs:178-180."""
+    return (n + 63) & ~63
+
+
+def arena_regions(regions):
+    """Cursor rule of Arena::push_slice / reserve_slice (arena.rs:152-232): every region starts at the next 64-byte
+    boundary and the cursor ends right after it. regions: [(elem_size, count)] -> (byte offsets, used bytes)."""
+    cursor, offsets = 0, []
+    for elem, count in regions:
+        cursor = align64(cursor)
+        offsets.append(cursor)
+        cursor += elem * count
+    return offsets, cursor
+
+
+def arena_capacity_for_regions(entries) -> int:
+    """Arena::capacity_for_regions (arena.rs:442-447): entries are (len, elem_size)."""
+    return sum(align64(n * e) for n, e in entries)
+
+
+def consolidate_table_arena(columns):
+    """consolidate_tables_arena for numeric columns (arena.rs:1187-1296 capacity pass, :1298-1340 write pass,
+    Arena::write_slices :264-308). columns: [(chunks, masks or None, mask_offsets or None)], every column with the
+    same batch row counts. Returns (arena bytes [capacity], data offsets, mask offsets (None = column without nulls),
+    used bytes). Per column in order: data region of n_rows elements, then — iff any batch of the column has a mask —
+    a validity region of ceil(n_rows / 8) bytes; batches without a mask contribute all-valid bits."""
+    n_rows = sum(c.size for c in columns[0][0])
+    mask_bytes = (n_rows + 7) // 8
+    capacity, regions, has_nulls = 0, [], []
+    for chunks, masks, _ in columns:
+        nulls = masks is not None and any(m is not None for m in masks)
+        has_nulls.append(nulls)
+        elem = chunks[0].dtype.itemsize
+        capacity += align64(n_rows * elem)
+        regions.append((elem, n_rows))
+        if nulls:
+            capacity += align64(mask_bytes)
+            regions.append((1, mask_bytes))
+    offsets, used = arena_regions(regions)
+    arena = np.zeros(capacity, dtype=np.uint8)  # Arena::with_capacity pre-fills with zeros (arena.rs:125-130)
+    data_offsets, mask_offsets, it = [], [], iter(offsets)
+    for (chunks, masks, mask_offs), nulls in zip(columns, has_nulls):
+        values, bits = consolidate_column(chunks, masks if nulls else None, mask_offs if nulls else None)
+        off = next(it)
+        data_offsets.append(off)
+        raw = values.view(np.uint8)
+        arena[off:off + raw.size] = raw
+        if nulls:
+            moff = next(it)
+            mask_offsets.append(moff)
+            arena[moff:moff + mask_bytes] = bits[:mask_bytes]
+        else:
+            mask_offsets.append(None)
+    return arena, data_offsets, mask_offsets, used

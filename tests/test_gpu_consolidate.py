@@ -228,3 +228,101 @@ def test_boolean_errors(ctx):
     with pytest.raises(ffi.MinarrowHipError) as e:
         ctx.consolidate_boolean_column([(bits, 0, 10)], np.zeros(16, dtype=np.uint8), [(bits, 0)], None)
     assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+# ---- whole-table consolidation into one arena (src/structs/arena.rs:1187-1340) ---------------------------------------
+
+def _arena_call(ctx, cols, batch_rows, pageable=False):
+    """cols: [(chunks, masks or None, mask offsets or None)] of numpy arrays -> (arena bytes, data offs, mask offs, used)."""
+    from minarrow_amd.host import arena_layout
+
+    n_rows = sum(batch_rows)
+    elem = [c[0][0].dtype.itemsize for c in cols]
+    nulls = [c[1] is not None and any(m is not None for m in c[1]) for c in cols]
+    _, _, capacity, _ = arena_layout(elem, nulls, n_rows)
+    cells = [[ctx.to_device(ch, 64) if ch.size else None for ch in c[0]] for c in cols]
+    masks = [[(ctx.to_device(m, 16) if m is not None else None) for m in c[1]] if c[1] is not None else [None] * len(batch_rows)
+             for c in cols]
+    offs = [c[2] if c[2] is not None else [0] * len(batch_rows) for c in cols]
+    if pageable:
+        arena = np.full(max(capacity, 64) + 64, 0xEE, dtype=np.uint8)
+        base = (-arena.ctypes.data) % 64
+        view = arena[base:base + max(capacity, 64)]
+        d_off, m_off, used = ctx.consolidate_table_arena(elem, batch_rows, cells, view, capacity, masks, offs)
+        return view[:capacity].copy(), d_off, m_off, used
+    arena = ctx.alloc(max(capacity, 64))
+    ffi.check(ctx.lib.ma_dev_memset(ctx.handle, arena.ptr, 0, max(capacity, 64)))
+    d_off, m_off, used = ctx.consolidate_table_arena(elem, batch_rows, cells, arena, capacity, masks, offs)
+    return arena.download(np.uint8, capacity), d_off, m_off, used
+
+
+def test_arena_layout_is_host_arithmetic():
+    from minarrow_amd.host import arena_layout
+
+    a = KAT["arena"]
+    assert arena_layout([8, 8], [False, True], 5) == ([0, 64], [None, 128], 192, a["full_table"]["expect_used"])
+    d, m, cap, used = arena_layout([8] * 10, [True] * 10, 100)
+    assert d == a["many_small"]["expect_data_offsets"] and m == a["many_small"]["expect_mask_offsets"]
+    assert cap == 10 * (832 + 64) and used == 8896 + 13
+
+
+def test_arena_reference_vectors(ctx, oracle):
+    a = KAT["arena"]["full_table"]
+    ids, prices = np.array(a["ids"], dtype=np.int64), np.array(a["prices"], dtype=np.float64)
+    cols = [([ids], None, None), ([prices], [oracle.pad_bits(oracle.pack_bits(a["price_validity"]), 5)], [0])]
+    arena, d_off, m_off, used = _arena_call(ctx, cols, [5])
+    want, wd, wm, wu = oracle.consolidate_table_arena(cols)
+    assert (d_off, m_off, used) == (wd, wm, wu) == ([0, 64], [None, 128], 129)
+    np.testing.assert_array_equal(arena, want)
+    m = KAT["arena"]["many_small"]
+    cols = [([np.arange(m["rows"], dtype=np.int64) + i * m["rows"]],
+             [oracle.pad_bits(oracle.pack_bits(np.ones(m["rows"], bool)), m["rows"])], [0]) for i in range(m["columns"])]
+    arena, d_off, m_off, used = _arena_call(ctx, cols, [m["rows"]])
+    assert [int(arena[o:o + 8].view(np.int64)[0]) for o in d_off] == m["expect_first_values"]
+    np.testing.assert_array_equal(arena, oracle.consolidate_table_arena(cols)[0])
+
+
+@pytest.mark.parametrize("pageable", [False, True])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_arena_random_tables_vs_oracle(ctx, oracle, seed, pageable):
+    rng = np.random.default_rng(100 + seed)
+    n_batches = int(rng.integers(1, 9))
+    batch_rows = [int(rng.choice([0, 1, 63, 64, 65, 1000, 40_000, rng.integers(0, 9000)])) for _ in range(n_batches)]
+    if sum(batch_rows) == 0:
+        batch_rows[0] = 77
+    types = [np.int64, np.float64, np.int32, np.float32, np.uint8, np.int16, np.uint64, np.int8]
+    cols = []
+    for dt in rng.permutation(types)[: int(rng.integers(1, len(types) + 1))]:
+        chunks = [(rng.integers(0, 120, size=r)).astype(dt) for r in batch_rows]
+        kind = rng.integers(0, 3)  # 0: no masks at all, 1: every batch masked, 2: some
+        if kind == 0:
+            cols.append((chunks, None, None))
+            continue
+        offs = [int(rng.integers(0, 70)) for _ in batch_rows]
+        masks = [None if (kind == 2 and rng.random() < 0.5) else rng.integers(0, 256, size=(o + r + 7) // 8 + 16, dtype=np.uint8)
+                 for r, o in zip(batch_rows, offs)]
+        cols.append((chunks, masks, offs))
+    arena, d_off, m_off, used = _arena_call(ctx, cols, batch_rows, pageable=pageable)
+    want, wd, wm, wu = oracle.consolidate_table_arena(cols)
+    assert (d_off, m_off, used) == (wd, wm, wu)
+    np.testing.assert_array_equal(arena, want)
+
+
+def test_arena_bench_shape_and_errors(ctx, oracle):
+    """benches/consolidate.rs:34-35: 100 tables x 10 000 rows; the numeric half of its 20-column table."""
+    n_batches, rows = 100, 10_000
+    cols = []
+    for col in range(10):
+        dt = np.int64 if col % 2 == 0 else np.float64
+        scale = 1 if col % 2 == 0 else 0.1
+        cols.append(([((np.arange(rows) + b * rows + col) * scale).astype(dt) for b in range(n_batches)], None, None))
+    arena, d_off, m_off, used = _arena_call(ctx, cols, [rows] * n_batches)
+    for c, off in enumerate(d_off):
+        got = arena[off:off + n_batches * rows * 8].view(cols[c][0][0].dtype)
+        np.testing.assert_array_equal(got, np.concatenate(cols[c][0]))
+    assert m_off == [None] * 10
+    with pytest.raises(ffi.MinarrowHipError) as e:  # Arena overflow (arena.rs:210-216)
+        ctx.consolidate_table_arena([8], [4], [[ctx.to_device(np.arange(4, dtype=np.int64), 64)]], ctx.alloc(64), 16)
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "Arena overflow" in str(e.value)
+    with pytest.raises(ffi.MinarrowHipError):  # "consolidate called on empty table set"
+        ctx.consolidate_table_arena([8], [], [[]], ctx.alloc(64), 64)

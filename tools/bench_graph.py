@@ -84,7 +84,46 @@ def main():
     dt = (time.perf_counter() - t0) / args.reps
     out.append({"rows_per_call": n, "calls": k, "one_sum_columns_call_ms": round(dt * 1e3, 3),
                 "one_sum_columns_call_gbps": round(k * n * 8 / dt / 1e9, 1)})
-    print(json.dumps({"bench": "launch-bound small sums, 1 MI355X", "results": out}))
+    for c in chunks:
+        c.free()
+    # the reference's consolidate bench (benches/consolidate.rs:34-58): 100 tables x 10 000 rows, 4 and 20 columns, of
+    # which the numeric half (int64 / float64 alternating) is consolidated here — column by column
+    # (ma_consolidate_column: one descriptor upload + launch + synchronise each) vs the whole table into one arena
+    # (ma_consolidate_table_arena: one upload, one launch, one synchronise)
+    from minarrow_amd.host import arena_layout
+    n_batches, rows = 100, 10_000
+    for n_cols in (2, 10):
+        cells = [[ctx.alloc(rows * 8) for _ in range(n_batches)] for _ in range(n_cols)]
+        for c in range(n_cols):
+            for b in range(n_batches):
+                ctx.synth_iota("i64" if c % 2 == 0 else "f64", cells[c][b], rows, b * rows + c)
+        outs = [ctx.alloc(n_batches * rows * 8) for _ in range(n_cols)]
+        _, _, capacity, _ = arena_layout([8] * n_cols, [False] * n_cols, n_batches * rows)
+        arena = ctx.alloc(capacity)
+
+        def per_column():
+            for c in range(n_cols):
+                ctx.consolidate_column(8, cells[c], [rows] * n_batches, outs[c])
+
+        def whole_table():
+            ctx.consolidate_table_arena([8] * n_cols, [rows] * n_batches, cells, arena, capacity)
+
+        row = {"consolidate": f"{n_batches} batches x {rows} rows x {n_cols} numeric columns", "bytes_moved": 16 * n_cols * n_batches * rows}
+        for name, fn in (("per_column_calls", per_column), ("one_arena_call", whole_table)):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                fn()
+            dt = (time.perf_counter() - t0) / args.reps
+            row[name + "_us"] = round(dt * 1e6, 1)
+            row[name + "_gbps"] = round(row["bytes_moved"] / dt / 1e9, 1)
+        s0 = ctx.sum("i64", outs[0], n_batches * rows)
+        s1 = ctx.sum("i64", arena, n_batches * rows)
+        assert s0 == s1, (s0, s1)
+        out.append(row)
+        for buf in [x for col in cells for x in col] + outs + [arena]:
+            buf.free()
+    print(json.dumps({"bench": "launch-bound shapes: small sums, many-batch consolidate; 1 MI355X", "results": out}))
 
 
 if __name__ == "__main__":
