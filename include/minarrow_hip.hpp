@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
 
 #include "minarrow_hip.h"
@@ -83,27 +84,50 @@ class Vec64 {
         reserve(init.size());
         for (const T& v : init) data_[len_++] = v;
     }
+    // Cloning a view of shared memory shares it (cheap, src/structs/arena.rs:1813-1826); cloning owned memory copies.
     Vec64(const Vec64& o) {
+        if (o.owner_) {
+            owner_ = o.owner_;
+            data_ = o.data_;
+            len_ = cap_ = o.len_;
+            return;
+        }
         reserve(o.len_);
         if (o.len_) std::memcpy(data_, o.data_, o.len_ * sizeof(T));
         len_ = o.len_;
     }
-    Vec64(Vec64&& o) noexcept : data_(o.data_), len_(o.len_), cap_(o.cap_) { o.data_ = nullptr; o.len_ = o.cap_ = 0; }
+    Vec64(Vec64&& o) noexcept : data_(o.data_), len_(o.len_), cap_(o.cap_), owner_(std::move(o.owner_)) {
+        o.data_ = nullptr;
+        o.len_ = o.cap_ = 0;
+    }
     Vec64& operator=(Vec64 o) noexcept {
         std::swap(data_, o.data_);
         std::swap(len_, o.len_);
         std::swap(cap_, o.cap_);
+        std::swap(owner_, o.owner_);
         return *this;
     }
     ~Vec64() {
-        if (data_) ma_free_pinned(data_);
+        if (data_ && !owner_) ma_free_pinned(data_);
     }
     static Vec64 with_capacity(size_t n) {
         Vec64 v;
         v.reserve(n);
         return v;
     }
+    // A window of memory kept alive by `owner` — Buffer::from_shared over a SharedBuffer (src/structs/buffer.rs:168-217,
+    // src/structs/shared_buffer/mod.rs:82-87); what ArenaRegion::to_buffer hands out (src/structs/arena.rs:502-517).
+    // Read access uses it in place; the first mutation copies it out (make_owned_mut, buffer.rs:474-507).
+    static Vec64 from_shared(std::shared_ptr<void> owner, T* ptr, size_t n) {
+        Vec64 v;
+        v.owner_ = std::move(owner);
+        v.data_ = ptr;
+        v.len_ = v.cap_ = n;
+        return v;
+    }
+    bool is_shared() const { return (bool)owner_; }
     void reserve(size_t n) {
+        if (owner_) make_owned(n);
         if (n <= cap_) return;
         void* p = nullptr;
         // round up so that whole-u64-word accesses of a bitmap stay inside the allocation
@@ -121,14 +145,21 @@ class Vec64 {
     }
     void set_len(size_t n) { len_ = n; }  // dispatch.rs:88-89 `unsafe { out.set_len(len) }`
     void push(T v) {
+        if (owner_) make_owned(len_ + 1);
         if (len_ == cap_) reserve(cap_ ? cap_ * 2 : 16);
         data_[len_++] = v;
     }
-    T* data() { return data_; }
+    T* data() {
+        if (owner_) make_owned(len_);
+        return data_;
+    }
     const T* data() const { return data_; }
     size_t size() const { return len_; }
     bool empty() const { return len_ == 0; }
-    T& operator[](size_t i) { return data_[i]; }
+    T& operator[](size_t i) {
+        if (owner_) make_owned(len_);
+        return data_[i];
+    }
     const T& operator[](size_t i) const { return data_[i]; }
     const T* begin() const { return data_; }
     const T* end() const { return data_ + len_; }
@@ -140,8 +171,21 @@ class Vec64 {
     }
 
   private:
+    // copy-on-write: leave the shared region, keep at least `n` elements of room
+    void make_owned(size_t n) {
+        const T* src = data_;
+        const size_t keep = len_;
+        std::shared_ptr<void> hold = std::move(owner_);
+        owner_.reset();
+        data_ = nullptr;
+        len_ = cap_ = 0;
+        reserve(n > keep ? n : keep);
+        if (keep) std::memcpy(data_, src, keep * sizeof(T));
+        len_ = keep;
+    }
     T* data_ = nullptr;
     size_t len_ = 0, cap_ = 0;
+    std::shared_ptr<void> owner_;
 };
 
 // Arrow validity bitmap — src/structs/bitmask.rs:66-71. LSB first, 1 = valid, bits >= len zero.

@@ -485,6 +485,73 @@ inline Table consolidate(const SuperTable& st) {
     return out;
 }
 
+// consolidate_arena — src/structs/chunked/super_table.rs:727-743 -> consolidate_tables_arena (src/structs/arena.rs:1187-1340):
+// ONE 64-byte aligned allocation holds every column's values and validity (layout: ma_arena_layout), written by one
+// ma_consolidate_table_arena call; the columns of the returned Table are windows into it that keep it alive
+// (ArenaRegion::to_buffer / to_bitmask, arena.rs:502-534) and copy themselves out on their first mutation.
+namespace detail {
+template <typename T, typename A>
+inline NumericArray arena_column(const std::shared_ptr<void>& arena, size_t data_off, size_t mask_off, size_t n_rows,
+                                 NumericArray (*wrap)(A)) {
+    A a;
+    char* base = static_cast<char*>(arena.get());
+    a.data = Vec64<T>::from_shared(arena, reinterpret_cast<T*>(base + data_off), n_rows);
+    if (mask_off != SIZE_MAX) {
+        Bitmask m;
+        m.len = n_rows;
+        m.bits = Vec64<uint8_t>::from_shared(arena, reinterpret_cast<uint8_t*>(base + mask_off), ((n_rows + 63) / 64) * 8);
+        a.null_mask = std::move(m);
+    }
+    return wrap(std::move(a));
+}
+}  // namespace detail
+inline Table consolidate_arena(const SuperTable& st) {
+    if (st.batches.empty()) throw Panic("consolidate called on empty table set");  // arena.rs:1196
+    const size_t n_cols = st.batches[0]->n_cols(), n_batches = st.batches.size();
+    std::vector<size_t> elem(n_cols), rows(n_batches), data_off(n_cols), mask_off(n_cols);
+    std::vector<const void*> cells(n_cols * n_batches);
+    std::vector<const uint8_t*> masks(n_cols * n_batches);
+    std::vector<int32_t> has_nulls(n_cols, 0);
+    for (size_t b = 0; b < n_batches; ++b) {
+        if (st.batches[b]->n_cols() != n_cols) throw KernelError(KernelError::Broadcasting, "SuperTable batches disagree on the column count");
+        rows[b] = st.batches[b]->n_rows();
+    }
+    for (size_t c = 0; c < n_cols; ++c) {
+        const NumericType t = st.batches[0]->cols[c].array.type();
+        elem[c] = detail::elem_size(t);
+        for (size_t b = 0; b < n_batches; ++b) {
+            const NumericArray& a = st.batches[b]->cols[c].array;
+            if (a.type() != t) throw KernelError(KernelError::UnsupportedType, "consolidate: batches of one column must share a type");
+            cells[c * n_batches + b] = detail::chunk_data(a);
+            masks[c * n_batches + b] = a.null_mask() ? a.null_mask()->bits.data() : nullptr;
+            if (masks[c * n_batches + b]) has_nulls[c] = 1;
+        }
+    }
+    size_t capacity = 0, used = 0;
+    check(ma_arena_layout(n_cols, elem.data(), has_nulls.data(), st.n_rows(), nullptr, nullptr, &capacity, &used));
+    void* raw = nullptr;
+    check(ma_alloc64_pinned(capacity ? capacity : 64, &raw));
+    std::shared_ptr<void> arena(raw, [](void* p) { (void)ma_free_pinned(p); });
+    check(ma_consolidate_table_arena(Context::global().get(), n_cols, n_batches, elem.data(), rows.data(), cells.data(), masks.data(),
+                                     nullptr, raw, capacity, data_off.data(), mask_off.data(), &used));
+    Table out;
+    out.name = st.name;
+    const size_t n = st.n_rows();
+    for (size_t c = 0; c < n_cols; ++c) {
+        NumericArray col;
+        switch (st.batches[0]->cols[c].array.type()) {
+            case NumericType::Int32: col = detail::arena_column<int32_t>(arena, data_off[c], mask_off[c], n, &NumericArray::from_int32); break;
+            case NumericType::Int64: col = detail::arena_column<int64_t>(arena, data_off[c], mask_off[c], n, &NumericArray::from_int64); break;
+            case NumericType::UInt32: col = detail::arena_column<uint32_t>(arena, data_off[c], mask_off[c], n, &NumericArray::from_uint32); break;
+            case NumericType::UInt64: col = detail::arena_column<uint64_t>(arena, data_off[c], mask_off[c], n, &NumericArray::from_uint64); break;
+            case NumericType::Float32: col = detail::arena_column<float>(arena, data_off[c], mask_off[c], n, &NumericArray::from_float32); break;
+            default: col = detail::arena_column<double>(arena, data_off[c], mask_off[c], n, &NumericArray::from_float64); break;
+        }
+        out.cols.push_back({st.batches[0]->cols[c].name, std::move(col)});
+    }
+    return out;
+}
+
 // Aggregates over a view, with the hand-off shape of NumericArrayV::guarantee_f64
 // (src/structs/views/collections/numeric_array_view.rs:302-317): values advanced to the window, the array's OWN
 // un-windowed validity plus the view offset as bit offset. Integer variants: wrapping 64-bit sum converted to f64.

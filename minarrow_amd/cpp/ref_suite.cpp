@@ -444,6 +444,36 @@ static void chunked_suite() {
                px.null_mask()->get(3));
         // consolidate() on an empty SuperTable panics (super_table.rs:693-696)
         ASSERT(panics([] { (void)consolidate(SuperTable{}); }));
+        // the same tests through the arena path (`arena` feature: consolidate() delegates to consolidate_tables_arena,
+        // super_table.rs:727-743): identical columns, all of them windows of ONE 64-byte aligned allocation
+        {
+            Table ta = consolidate_arena(st);
+            ASSERT(ta.n_rows() == 5 && ta.n_cols() == 2 && ta.name == "my_table");
+            ASSERT(is_i32(ta.cols[0].array, {1, 2, 3, 4, 5}) && is_f64(ta.cols[1].array, {1.5, 2.5, 3.5, 4.5, 5.5}));
+            const auto* ints = ta.cols[0].array.try_i32_ref();
+            const auto* flts = ta.cols[1].array.try_f64_ref();
+            ASSERT(ints->data.is_shared() && flts->data.is_shared() && !ta.cols[0].array.null_mask().has_value());
+            // arena.rs:1668-1689: every region starts on a 64-byte boundary; 5 i32 = 20 bytes, so the floats start at +64
+            ASSERT(((uintptr_t)ints->data.data() & 63) == 0 && (const char*)flts->data.data() - (const char*)ints->data.data() == 64);
+            ASSERT(is_i32(consolidate_arena(three).cols[0].array, {1, 2, 3, 4, 5, 6}));
+            Table an = consolidate_arena(nul);
+            const NumericArray& ax = an.cols[0].array;
+            ASSERT(is_i32(ax, {10, 0, 30, 0, 50}) && ax.null_mask().has_value() && ax.null_mask()->bits.is_shared());
+            for (size_t i = 0; i < 5; ++i) ASSERT(ax.null_mask()->get(i) == want_valid[i]);
+            const NumericArray apx = consolidate_arena(part).cols[0].array;
+            ASSERT(apx.null_mask().has_value() && apx.null_mask()->get(0) && apx.null_mask()->get(1) && !apx.null_mask()->get(2) &&
+                   apx.null_mask()->get(3));
+            ASSERT(panics([] { (void)consolidate_arena(SuperTable{}); }));
+            // clone is cheap, mutation copies out (arena.rs:1813-1842)
+            Vec64<int32_t> view = ints->data;
+            ASSERT(view.is_shared() && static_cast<const Vec64<int32_t>&>(view).data() == ints->data.data());
+            Vec64<int32_t> cow = ints->data;
+            cow[0] = 99;
+            ASSERT(!cow.is_shared() && cow[0] == 99 && ints->data[0] == 1 && cow.size() == 5 && cow[4] == 5);
+            // the arena columns feed the kernels like any other column
+            Aggregate s = sum(NumericArrayV(an.cols[0].array));
+            ASSERT(s.sum == 90.0 && s.valid_count == 3);
+        }
         // per-column reduce of the consolidated table == fold of the per-batch reduces (config 5)
         Aggregate whole = sum(NumericArrayV(tn.cols[0].array));
         ASSERT(whole.sum == 90.0 && whole.valid_count == 3);
