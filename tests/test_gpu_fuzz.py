@@ -386,3 +386,117 @@ def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed):
         np.testing.assert_array_equal(dO[i].download(dt, n).view(np.uint8), want.view(np.uint8))
         if want_has:
             np.testing.assert_array_equal(unpack(dOM[i].download(np.uint8, ((n + 63) // 64) * 8), 0, n), valid)
+
+
+# ---- host-resident operands through the tiled staging pipeline (ma_pipeline.hip) -------------------------------------
+TILE = 256 << 10  # bytes per operand per tile while these properties run
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(["i8", "u16", "i32", "i64", "f32", "f64"]), op=st.sampled_from([0, 1, 2, 3, 6]),
+       kind=st.sampled_from(["aa", "as", "sa"]), tiles=st.floats(2.0, 5.5), ragged=st.integers(0, 70),
+       where=st.tuples(st.booleans(), st.booleans(), st.booleans()), masked=st.booleans(), mask_off=st.integers(0, 70),
+       seed=st.integers(0, 2**31))
+def test_apply_host_resident(ctx, oracle, tag, op, kind, tiles, ragged, where, masked, mask_off, seed):
+    """Any mix of host (numpy, pageable) and device operands, lengths straddling tile seams: the oracle's bits."""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    is_float = dt.kind == "f"
+    n = int(TILE / dt.itemsize * tiles) + ragged
+    a, b = rand_values(rng, dt, n, small=True), rand_values(rng, dt, n, small=True)
+    if not is_float and not masked and op in (3, 6):
+        b[b == 0] = 1
+    if dt.kind == "i" and op in (3, 6):
+        b[b == -1] = 1
+    sc = dt.type(3)
+    host_a, host_b, host_o = where
+    if not (host_a or host_b or host_o):
+        host_o = True
+    pa = a if host_a else ctx.to_device(a, 64)
+    pb = b if host_b else ctx.to_device(b, 64)
+    out_host = np.zeros(n, dtype=dt)
+    po = out_host if host_o else ctx.alloc(n * dt.itemsize + 64)
+    bits = full = om = None
+    if masked:
+        full = np.packbits(rng.random(((mask_off + n) // 8 + 16) * 8) >= 0.3, bitorder="little")
+        bits = np.concatenate([np.packbits(unpack(full, mask_off, n), bitorder="little"), np.zeros(24, np.uint8)])
+        om = np.zeros(n // 8 + 64, dtype=np.uint8)
+    ctx.set_staging_tile(TILE)
+    try:
+        if kind == "aa":
+            lhs, rhs = a, b
+            ctx.apply(tag, pa, pb, op, po, n, n, mask=full, mask_bit_offset=mask_off, out_mask=om)
+        elif kind == "as":
+            lhs, rhs = a, np.full(n, sc, dtype=dt)
+            ctx.apply_scalar(tag, "rhs", pa, n, sc, op, po, mask=full, mask_bit_offset=mask_off, out_mask=om)
+        else:
+            lhs, rhs = np.full(n, sc, dtype=dt), b
+            ctx.apply_scalar(tag, "lhs", pb, n, sc, op, po, mask=full, mask_bit_offset=mask_off, out_mask=om)
+    finally:
+        ctx.set_staging_tile(32 << 20)
+    ref = oracle.apply_float if is_float else oracle.apply_int
+    status, want, want_mask, _ = ref(np.ascontiguousarray(lhs), np.ascontiguousarray(rhs), op, mask=bits)
+    assert status == 0
+    got = out_host if host_o else po.download(dt, n)
+    if is_float:
+        same = (got.view(np.uint8).reshape(n, -1) == want[:n].view(np.uint8).reshape(n, -1)).all(axis=1)
+        assert (same | (np.isnan(got) & np.isnan(want[:n]))).all()
+    else:
+        np.testing.assert_array_equal(got, want[:n])
+    if masked:
+        nb = ((n + 63) // 64) * 8
+        np.testing.assert_array_equal(om[:nb], want_mask[:nb])
+
+
+@settings(**COMMON)
+@given(tag=st.sampled_from(["i32", "u64", "f32", "f64"]), tiles=st.floats(2.0, 6.0), ragged=st.integers(0, 70),
+       masked=st.booleans(), mask_off=st.integers(0, 130), null_pct=st.sampled_from([0, 10, 100]), seed=st.integers(0, 2**31))
+def test_sum_host_resident(ctx, tag, tiles, ragged, masked, mask_off, null_pct, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(NP[tag])
+    n = int(TILE / dt.itemsize * tiles) + ragged
+    x = rand_values(rng, dt, n)
+    bits, valid = None, np.ones(n, dtype=bool)
+    if masked:
+        bits = np.packbits(rng.random(((mask_off + n) // 8 + 16) * 8) >= null_pct / 100.0, bitorder="little")
+        valid = unpack(bits, mask_off, n)
+    ctx.set_staging_tile(TILE)
+    try:
+        s, c = ctx.sum(tag, x, n, mask=bits, mask_bit_offset=mask_off)
+    finally:
+        ctx.set_staging_tile(32 << 20)
+    assert c == int(valid.sum())
+    sel = x[valid]
+    if dt.kind == "f":
+        exact = math.fsum(sel.astype(np.float64).tolist())
+        assert abs(s - exact) <= math.ulp(exact)
+    else:
+        assert (int(s) - (int(sel.astype(object).sum()) if sel.size else 0)) % (1 << 64) == 0
+
+
+# ---- whole-table consolidation into one arena (ma_consolidate_table_arena) ------------------------------------------
+@settings(**COMMON)
+@given(n_batches=st.integers(1, 7), n_cols=st.integers(1, 6), seed=st.integers(0, 2**31), pageable=st.booleans())
+def test_consolidate_table_arena(ctx, oracle, n_batches, n_cols, seed, pageable):
+    from test_gpu_consolidate import _arena_call
+
+    rng = np.random.default_rng(seed)
+    batch_rows = [int(rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 4096, 4097, int(rng.integers(0, 20_000))])) for _ in range(n_batches)]
+    if sum(batch_rows) == 0:
+        batch_rows[-1] = 1 + int(rng.integers(0, 300))
+    cols = []
+    for _ in range(n_cols):
+        dt = NP[str(rng.choice(list(NP)))]
+        chunks = [rand_values(rng, dt, r) for r in batch_rows]
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            cols.append((chunks, None, None))
+            continue
+        offs = [int(rng.integers(0, 70)) for _ in batch_rows]
+        masks = [None if (kind == 2 and rng.random() < 0.5) else rng.integers(0, 256, size=(o + r + 7) // 8 + 16, dtype=np.uint8)
+                 for r, o in zip(batch_rows, offs)]
+        cols.append((chunks, masks, offs))
+    arena, d_off, m_off, used = _arena_call(ctx, cols, batch_rows, pageable=pageable)
+    want, wd, wm, wu = oracle.consolidate_table_arena(cols)
+    assert (d_off, m_off, used) == (wd, wm, wu)
+    np.testing.assert_array_equal(arena, want)
