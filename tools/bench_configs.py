@@ -47,6 +47,11 @@ def main():
     ap.add_argument("--config5-rows", type=int, default=0, help="rows per SuperTable batch (default rows/8)")
     args = ap.parse_args()
 
+    # JSON lines only on stdout: native libraries (RCCL's version banner, gloo's connection messages) write to fd 1
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -278,7 +283,7 @@ def main():
 
     if rank == 0:
         for o_ in out:
-            print(json.dumps(o_), flush=True)
+            os.write(result_fd, (json.dumps(o_) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -23,6 +23,11 @@ hipcc -O3 --offload-arch=gfx950 tools/ubench_sum.hip -o /tmp/ubench_sum 2>/dev/n
 echo "== matrix" ; timeout 900 python3 tools/bench_matrix.py > $O/${R}_matrix.jsonl 2> $O/${R}_matrix.err ; echo rc=$?
 echo "== matrix under rocprof" ; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mx -- python3 tools/bench_matrix.py --reps 2 > /dev/null 2>&1 ; echo rc=$?
 cp $O/stats_mx/*/*_kernel_stats.csv $O/${R}_matrix_kernel_stats.csv 2>/dev/null
+echo "== config 1 / 5 and the full-size config 5 (8 x 10^9-row batches, one column at a time: ~130 GB of HBM)"
+timeout 600 python3 tools/bench_configs.py --configs 1,5 > $O/${R}_configs_1_5.jsonl 2>/dev/null ; echo rc=$?
+timeout 600 python3 tools/bench_configs.py --configs 5 --config5-rows 1000000000 > $O/${R}_config5_full_size_1gpu.jsonl 2>/dev/null ; echo rc=$?
+echo "== size sweep" ; timeout 600 python3 tools/sweep_sizes.py > $O/${R}_sweep_sizes.jsonl 2>/dev/null ; echo rc=$?
+echo "== host-resident operands (PCIe-inclusive, never the headline)" ; timeout 600 python3 tools/bench_pcie.py > $O/${R}_pcie_tiled.json 2>/dev/null ; echo rc=$?
 echo "== launch-bound shapes" ; timeout 600 python3 tools/bench_graph.py > $O/${R}_launch_bound.json 2>/dev/null ; echo rc=$?
 rm -rf $O/stats $O/stats_cfg $O/stats_mx $O/pmc_fetch $O/pmc_write
 ls -la $O
