@@ -135,8 +135,14 @@ class CallScope {
         void* host_dst;  // nullptr for inputs
         size_t bytes;
     };
+    // Temporaries are carved out of a few slabs: a chunked column hands over thousands of small host buffers, and a
+    // hipMalloc per buffer would cost more than the copies.
+    ma_status carve(size_t bytes, void** out);
     ma_ctx* ctx_;
     std::vector<Temp> temps_;
+    std::vector<void*> slabs_;
+    char* slab_cur_ = nullptr;
+    size_t slab_left_ = 0, slab_next_ = (size_t)1 << 20;
 };
 
 inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0) {

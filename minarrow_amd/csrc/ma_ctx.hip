@@ -83,10 +83,29 @@ CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
 }
 
 CallScope::~CallScope() {
-    for (auto& t : temps_) {
-        if (t.dev) (void)hipFree(t.dev);
-    }
+    for (void* slab : slabs_) (void)hipFree(slab);
     if (--t_scope_depth == 0 || !temps_.empty()) forget_ranges();
+}
+
+ma_status CallScope::carve(size_t bytes, void** out) {
+    const size_t need = (bytes + 255) & ~(size_t)255;  // every temporary starts on a 256-byte boundary
+    if (need > slab_left_) {
+        size_t want = need > slab_next_ ? need : slab_next_;
+        void* slab = nullptr;
+        MA_HIP(hipMalloc(&slab, want));
+        slabs_.push_back(slab);
+        if (need >= slab_next_) {  // a large operand gets its own allocation; the current slab stays open
+            *out = slab;
+            return MA_OK;
+        }
+        slab_cur_ = (char*)slab;
+        slab_left_ = want;
+        if (slab_next_ < ((size_t)64 << 20)) slab_next_ *= 4;
+    }
+    *out = slab_cur_;
+    slab_cur_ += need;
+    slab_left_ -= need;
+    return MA_OK;
 }
 
 ma_status CallScope::in(const void* p, size_t bytes, const void** out) {
@@ -95,7 +114,7 @@ ma_status CallScope::in(const void* p, size_t bytes, const void** out) {
     if (pointer_kind(p) != kPageable) return MA_OK;
     MA_NO_CAPTURE(ctx_, "staging a pageable host input");
     void* d = nullptr;
-    MA_HIP(hipMalloc(&d, bytes));
+    MA_TRY(carve(bytes, &d));
     temps_.push_back({d, nullptr, bytes});
     MA_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx_->stream));
     *out = d;
@@ -108,7 +127,7 @@ ma_status CallScope::out(void* p, size_t bytes, void** out) {
     if (pointer_kind(p) != kPageable) return MA_OK;
     MA_NO_CAPTURE(ctx_, "staging a pageable host output");
     void* d = nullptr;
-    MA_HIP(hipMalloc(&d, bytes));
+    MA_TRY(carve(bytes, &d));
     temps_.push_back({d, p, bytes});
     *out = d;
     return MA_OK;
@@ -135,7 +154,7 @@ ma_status CallScope::in_mask(const uint8_t* bits, size_t bit_offset, size_t len_
     size_t nbytes = end_byte - first_byte;
     size_t padded = ((nbytes + 7) & ~(size_t)7) + 8;
     void* d = nullptr;
-    MA_HIP(hipMalloc(&d, padded));
+    MA_TRY(carve(padded, &d));
     temps_.push_back({d, nullptr, padded});
     MA_HIP(hipMemsetAsync(d, 0, padded, ctx_->stream));
     MA_HIP(hipMemcpyAsync(d, bits + first_byte, nbytes, hipMemcpyHostToDevice, ctx_->stream));
