@@ -11,6 +11,7 @@
 // dispatch.rs:74-133); this is purely the cost model of the boundary for callers that keep columns on the host.
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <string>
 #include <thread>
 
@@ -108,7 +109,7 @@ ma_status run_tiled(ma_ctx* ctx, size_t n_rows, size_t tile_rows, const PipeOper
 
     Drain drain;
     std::thread helper;
-    if (any_out) {
+    if (any_out) try {
         helper = std::thread([&drain, p, ops, n_ops, tile_rows, n_rows, device]() {
             hipError_t e = hipSetDevice(device);
             for (;;) {
@@ -139,6 +140,9 @@ ma_status run_tiled(ma_ctx* ctx, size_t n_rows, size_t tile_rows, const PipeOper
                 drain.cv.notify_all();
             }
         });
+    } catch (const std::exception& e) {  // no thread to be had: nothing has been enqueued yet
+        set_error("cannot start the D2H drain thread: %s", e.what());
+        return MA_ERR_DEVICE;
     }
     auto finish = [&](ma_status s) -> ma_status {
         if (helper.joinable()) {

@@ -20,6 +20,12 @@
 
 typedef long long l2 __attribute__((ext_vector_type(2)));
 
+struct Scratch {
+    unsigned long long partials[4096 * 4];
+    unsigned int ticket;
+};
+__device__ Scratch g_scratch;
+
 template <int U, int BLOCK, bool PIPE, int PRIO, int MAP = 0>
 __global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, size_t n_tiles, long long* __restrict__ out) {
     constexpr int WAVES = BLOCK / 64;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, si
 #pragma unroll
             for (int u = 0; u < U; ++u) acc += v[u];
         }
-    } else if (!PIPE) {
+    } else if (!PIPE || MAP == 4) {
         for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
             const l2* p = a + t * TILE_VECS + wave * WAVE_VECS + lane;
             l2 v[U];
@@ -109,7 +115,49 @@ __global__ __launch_bounds__(BLOCK) void sum_kernel(const l2* __restrict__ a, si
     }
     long long s = acc.x + acc.y;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (MAP == 4) {
+        // the library's epilogue (ma_reduce.hip): wave sums -> LDS -> one 32-byte partial per workgroup, agent-scope
+        // release, ticket, and the workgroup that draws the last ticket folds every partial
+        __shared__ long long lds[BLOCK / 64];
+        __shared__ int is_last;
+        if (lane == 0) lds[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long w = 0;
+            for (int i = 0; i < BLOCK / 64; ++i) w += lds[i];
+            g_scratch.partials[blockIdx.x * 4] = (unsigned long long)w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned int t = __hip_atomic_fetch_add(&g_scratch.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int last = t == gridDim.x - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            is_last = last;
+        }
+        __syncthreads();
+        if (!is_last) return;
+        long long tot = 0;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += BLOCK)
+            tot += (long long)__hip_atomic_load(&g_scratch.partials[i * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+        __syncthreads();
+        if (lane == 0) lds[wave] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long w = 0;
+            for (int i = 0; i < BLOCK / 64; ++i) w += lds[i];
+            *out = w;
+            g_scratch.ticket = 0;
+        }
+        return;
+    }
     if (lane == 0) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+
+__global__ void iota_kernel(long long* a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = (long long)i;
 }
 
 struct Variant {
@@ -146,6 +194,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a, rows * 8));
     CK(hipMalloc(&out, 8));
     CK(hipMemset(a, 1, rows * 8));
+    if (argc > 3 && std::string(argv[3]) == "iota") {  // the bench's data (v[i] = i) instead of a constant byte pattern
+        hipLaunchKernelGGL(iota_kernel, dim3(4096), dim3(256), 0, 0, (long long*)a, rows);
+        CK(hipDeviceSynchronize());
+    }
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -157,7 +209,7 @@ int main(int argc, char** argv) {
     ADD(8, 256, true, 0) ADD(4, 256, true, 0) ADD(2, 256, true, 0) ADD(16, 256, true, 0)
     ADD(8, 256, false, 1) ADD(8, 256, true, 1)
     ADD(4, 512, false, 0) ADD(4, 512, true, 0) ADD(8, 512, false, 0) ADD(2, 1024, true, 0) ADD(4, 1024, false, 0)
-    ADDM(8, 256, 1) ADDM(4, 256, 1) ADDM(16, 256, 1) ADDM(8, 256, 2) ADDM(4, 256, 2) ADDM(8, 512, 1) ADDM(8, 128, 1) ADDM(8, 256, 3) ADDM(4, 256, 3)
+    ADDM(8, 256, 1) ADDM(4, 256, 1) ADDM(16, 256, 1) ADDM(8, 256, 2) ADDM(4, 256, 2) ADDM(8, 512, 1) ADDM(8, 128, 1) ADDM(8, 256, 3) ADDM(4, 256, 3) ADDM(8, 256, 4)
     ADD(8, 128, false, 0) ADD(8, 128, true, 0) ADD(16, 128, false, 0) ADD(8, 64, true, 0) ADD(16, 64, false, 0) ADD(16, 64, true, 0)
     for (int r = 0; r < rounds; ++r) {
         for (auto& v : vars) {
