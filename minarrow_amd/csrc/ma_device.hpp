@@ -56,6 +56,18 @@ struct Vec16<uint8_t> {
     typedef unsigned char type __attribute__((ext_vector_type(16)));
 };
 
+// Idle cycles between two consecutive load instructions of a wave. A wave that fires its UNROLL loads back to back
+// hands the memory pipeline a burst and then nothing; a few cycles between them read 1-2 % faster on MI355X
+// (tools/ubench_pace.hip, profiles/r01_ubench_pace.txt: 91.9 vs 90.2 % of 8 TB/s for 8 loads per wave, one wave per
+// SIMD). Compile-time cycle count (s_nop n idles n + 1 cycles); the memory clobber keeps the loads in program order.
+template <int CYCLES>
+__device__ __forceinline__ void pace_loads() {
+    static_assert(CYCLES >= 0 && CYCLES <= 32, "pace_loads: 0..32 cycles");
+    if constexpr (CYCLES > 16) asm volatile("s_nop 15" ::: "memory");
+    if constexpr (CYCLES % 16 != 0) asm volatile("s_nop %0" ::"n"(CYCLES % 16 - 1) : "memory");
+    if constexpr (CYCLES == 16 || CYCLES == 32) asm volatile("s_nop 15" ::: "memory");
+}
+
 template <typename V, bool NT>
 __device__ __forceinline__ V load16(const V* p) {
     if constexpr (NT) {

@@ -42,12 +42,13 @@ struct SumArgs {
     uint64_t* out_b;        // double-double low part — may be nullptr
     uint64_t* out_cnt;      // valid count — may be nullptr
     double* out_mean;       // sum / count — may be nullptr
+    int pace;               // host side only: idle cycles between a wave's consecutive loads (selects the instantiation)
     int interleave;         // dense only: 1 = n_tiles counts 1-KiB pieces dealt to ALL waves of the grid in turn
     int mode;               // 0: out_a = final value (int, or rounded double); 1: out_a/out_b = double-double
     int is_signed;          // integer mean: interpret the 64-bit sum as signed
 };
 
-template <typename T, int UNROLL, bool MASKED, bool NT, bool IL = false>
+template <typename T, int UNROLL, bool MASKED, bool NT, bool IL = false, int PACE = 0>
 __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     typedef typename Vec16<T>::type V;
     typedef typename AccOf<T>::type Acc;
@@ -101,7 +102,13 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         const V* __restrict__ p = (const V*)(data + row0) + lane;
         V v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(p + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) {
+            v[u] = load16<V, NT>(p + (size_t)u * 64);
+            if (u + 1 < UNROLL) pace_loads<PACE>();
+        }
+        // the paced loads are all issued before anything is consumed (the asm statements split the scheduling region,
+        // and the scheduler would otherwise start on v[0] after three loads)
+        if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
 
         if constexpr (MASKED) {
             const uint64_t aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
@@ -256,6 +263,16 @@ static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
             return;
         }
     }
+    // Load pacing (pace_loads) is instantiated for the non-temporal scans: a.pace picks the cycle count.
+    if constexpr (NT) {
+        switch (a.pace) {
+            case 16: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 16>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            case 20: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 20>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            case 24: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 24>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            case 32: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 32>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            default: break;
+        }
+    }
     hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
@@ -303,6 +320,17 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
     // tiled mapping stays the default.
     a.interleave = (!masked && nt && unroll == 8 && (variant & 16) != 0) ? 1 : 0;
+    // Load pacing (pace_loads): idle cycles between a wave's consecutive loads. Swept per type at 10^9 rows
+    // (profiles/r01_sweep_sum_pace.txt): dense i64 1.117 -> 1.099 ms at 24 cycles, f64 1.106 -> 1.095 at 20, i32 0.586 ->
+    // 0.583 at 16, f32 0.591 -> 0.566 at 16-32; the masked kernels, which already spend cycles on validity words between
+    // their loads, only lose by it (i64 1.124 -> 1.135 at 16). ctx->variant bits 5-7 override for tuning: 0 = these
+    // defaults, 1 = none, 2..5 = 16 / 20 / 24 / 32 cycles.
+    {
+        static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
+        const int sel = kPace[(variant >> 5) & 7];
+        const int dense_default = std::is_same<T, float>::value ? 24 : std::is_same<T, double>::value ? 20 : (R == 2 ? 24 : 16);
+        a.pace = sel >= 0 ? sel : (masked ? 0 : dense_default);
+    }
     size_t work = a.n_tiles;
     if (a.interleave) {
         a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces

@@ -53,10 +53,10 @@ def main():
         for (v, b, m), ms in sorted(best.items(), key=lambda kv: kv[1]):
             bytes_ = n * esz + (n / 8 if m else 0)
             row = {"type": tag, "masked": m, "variant": v, "unroll": {0: "auto", 1: 2, 2: 4, 3: 8, 4: 16}[(v >> 1) & 7], "nt": not (v & 1),
-                   "interleaved": bool(v & 16),
+                   "interleaved": bool(v & 16), "pace": {0: "auto", 1: 0, 2: 16, 3: 20, 4: 24, 5: 32}.get((v >> 5) & 7, 0),
                    "blocks_per_cu": b, "ms": ms, "gbps": bytes_ / ms / 1e6, "grows": n / ms / 1e6}
             results.append(row)
-            print(f"{tag} masked={int(m)} unroll={row['unroll']} nt={int(row['nt'])} il={int(row['interleaved'])} bpc={b:2d}  "
+            print(f"{tag} masked={int(m)} unroll={row['unroll']} nt={int(row['nt'])} il={int(row['interleaved'])} pace={row['pace']} bpc={b:2d}  "
                   f"{ms:8.4f} ms  {row['gbps']:8.1f} GB/s  {row['grows']:7.1f} Grows/s", flush=True)
         buf.free()
     if args.out:
