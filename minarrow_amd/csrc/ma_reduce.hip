@@ -9,7 +9,8 @@
 // Design:
 //   * HBM-bound scan, 8 B/row (4 B/row for 32-bit types) + 1/8 B/row of validity. No MFMA.
 //   * A workgroup = 4 wave64s. A wave owns a contiguous run of UNROLL KiB: lane k issues UNROLL
-//     back-to-back 16-byte loads (global_load_dwordx4), 1 KiB per wave-instruction, before it consumes any.
+//     16-byte loads (global_load_dwordx4), 1 KiB per wave-instruction, before it consumes any; the dense scans leave
+//     16-24 idle cycles between consecutive loads (pace_loads: +1-2 % read rate, tools/ubench_pace.hip).
 //   * Tiles are dealt round-robin to workgroups (tile t -> workgroup t mod grid), grid = CUs x blocks/CU,
 //     so at any instant all CUs stream neighbouring DRAM pages.
 //   * Validity: one u64 word covers 64 rows = one wave64. Lanes 0..W load the W+1 words that cover the
