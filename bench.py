@@ -365,7 +365,11 @@ def main() -> int:
             },
             "hbm_gbps": total_rows * 2 * 8 * args.steps / elapsed / 1e9,
             "parity_ok": bool(ok),
-            "result": {"i64_sum": got_i, "f64_sum": got_f, "f64_ulps_from_exact": abs(got_f - exact_f) / math.ulp(exact_f)},
+            # avg = sum / valid count from the same scan (the reference has no mean kernel; its "avg" benches average
+            # timings): derived here from the job's finals; the wrapping i64 total only means something while it fits
+            "result": {"i64_sum": got_i, "f64_sum": got_f, "f64_ulps_from_exact": abs(got_f - exact_f) / math.ulp(exact_f),
+                       "rows": cnt_i, "i64_avg": (got_i / cnt_i) if expect < (1 << 63) and cnt_i else None,
+                       "f64_avg": (got_f / cnt_f) if cnt_f else None},
             "kernels": {
                 "sum_i64": {"avg_ms": avg_i, "min_ms": min(ms_i), "gbps": bytes_per_launch / (avg_i * 1e-3) / 1e9,
                             "grows_per_s": rows / (avg_i * 1e-3) / 1e9},
