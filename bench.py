@@ -281,7 +281,7 @@ def main() -> int:
             scanned[k].record(stream)
             with torch.cuda.stream(side):
                 side.wait_event(scanned[k])
-                ex.exchange()  # N > 1: one RCCL all-gather of 64 bytes per rank; N = 1: a device-side copy
+                ex.exchange()  # N > 1: one RCCL all-gather of 64 bytes per rank; N = 1: nothing to exchange
                 ex.fold_on_device(ctx_side)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
                 exchanged[k].record(side)
             in_use[k] = True

@@ -106,7 +106,7 @@ class ScalarExchange:
     def exchange(self) -> None:
         """Enqueue the collective on the current stream (async w.r.t. the host)."""
         if not self.dist.is_initialized():
-            self.gathered.copy_(self.local)
+            self.gathered = self.local  # one rank, no process group: the local records ARE the gathered ones
         elif self.local.is_cuda and self.dist.get_backend(self.group) == "gloo":
             # rehearsal of the multi-rank path on a box without RCCL peers (several ranks sharing one GPU): the records
             # take the detour over host memory; everything around the collective is the production path
