@@ -120,6 +120,14 @@ ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
 /* hipHostMalloc-backed, 64-byte aligned, device-mapped. The pointer is valid on the host and in kernels. */
 ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr);
 ma_status ma_free_pinned(void* ptr);
+/* Pins an EXISTING host allocation in place (hipHostRegister, portable + mapped) — for a host that cannot change the
+ * allocator of buffers it already owns: a Vec64<T> from the stock vec64 crate (Cargo.toml:54), a foreign buffer behind
+ * SharedBuffer::from_owner (src/structs/shared_buffer/mod.rs:187-206), an mmap. From then on the range classifies as
+ * pinned: kernels and the copy engines address it directly, no pageable staging. Registration costs a page-table walk
+ * (milliseconds per GiB): do it once per long-lived buffer, not per call. ma_host_unregister before the memory is
+ * freed. `ptr` need not be page aligned; a range may be registered once. */
+ma_status ma_host_register(void* ptr, size_t bytes);
+ma_status ma_host_unregister(void* ptr);
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
 ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

@@ -588,6 +588,22 @@ ma_status ma_free_pinned(void* ptr) {
     return MA_OK;
 }
 
+ma_status ma_host_register(void* ptr, size_t bytes) {
+    MA_REQUIRE(ptr != nullptr && bytes > 0, MA_ERR_INVALID_ARGUMENT, "nothing to register");
+    if (ma_device_count() <= 0) {
+        set_error("no HIP device is visible; pinning host memory needs the HIP runtime");
+        return MA_ERR_NO_DEVICE;
+    }
+    MA_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    return MA_OK;
+}
+
+ma_status ma_host_unregister(void* ptr) {
+    if (!ptr) return MA_OK;
+    MA_HIP(hipHostUnregister(ptr));
+    return MA_OK;
+}
+
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;

@@ -42,7 +42,7 @@ def addr_of(x) -> int:
         return 0
     if isinstance(x, int):
         return x
-    if isinstance(x, (DeviceBuffer, PinnedBuffer)):
+    if isinstance(x, (DeviceBuffer, PinnedBuffer, Registered)):
         return x.ptr
     if isinstance(x, np.ndarray):
         if not x.flags["C_CONTIGUOUS"]:
@@ -118,6 +118,27 @@ class PinnedBuffer:
             self.free()
         except Exception:
             pass
+
+
+class Registered:
+    """An existing host buffer (numpy array) pinned in place for its lifetime: ma_host_register / ma_host_unregister."""
+
+    def __init__(self, arr: np.ndarray):
+        self.arr = arr
+        self.ptr = arr.ctypes.data
+        ffi.check(ffi.load_library().ma_host_register(self.ptr, arr.nbytes))
+        self._live = True
+
+    def release(self) -> None:
+        if self._live:
+            self._live = False
+            ffi.check(ffi.load_library().ma_host_unregister(self.ptr))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
 
 
 class Graph:

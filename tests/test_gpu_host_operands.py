@@ -226,3 +226,30 @@ def test_host_resident_column_sums_in_tiles(tiled, oracle, tag):
         assert abs(s_dev - s_host) <= math.ulp(s_dev)
     else:
         assert s_dev == s_host
+
+
+def test_registering_an_existing_host_buffer(ctx, oracle):
+    """ma_host_register pins a buffer the host already owns: it then classifies as pinned (kernels address it in place)
+    and gives the same bits; after ma_host_unregister it is ordinary pageable memory again."""
+    from minarrow_amd.host import Registered
+
+    lib = ctx.lib
+    rng = np.random.default_rng(3)
+    n = 300_001
+    a, b = rand_ints(rng, "i64", n), rand_ints(rng, "i64", n)
+    out = np.zeros(n, dtype=np.int64)
+    st, want, _, _ = oracle.apply_int(oracle.aligned_copy(a), oracle.aligned_copy(b), "add")
+    assert lib.ma_pointer_kind(a.ctypes.data) == 0
+    with Registered(a) as ra, Registered(b) as rb, Registered(out) as ro:
+        assert [lib.ma_pointer_kind(x.ptr + 8 * 1000) for x in (ra, rb, ro)] == [1, 1, 1]
+        ctx.set_async(True)  # async: pinned operands are addressed in place by the kernels
+        try:
+            ctx.apply("i64", ra, rb, OPS["add"], ro, n, n)
+            ctx.synchronize()
+        finally:
+            ctx.set_async(False)
+        np.testing.assert_array_equal(out, want)
+        assert ctx.sum("i64", ra, n)[0] == int(a.astype(object).sum()) % (1 << 64) - (1 << 64) * (int(a.astype(object).sum()) % (1 << 64) >= (1 << 63))
+    assert lib.ma_pointer_kind(a.ctypes.data) == 0
+    with pytest.raises(ffi.MinarrowHipError):
+        ffi.check(lib.ma_host_register(None, 0))
