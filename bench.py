@@ -384,6 +384,9 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this "
+                                  "command (tools/collect_profiles.sh), FETCH_SIZE doubled per the gfx950 correction"
+                                  if traffic is not None else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
