@@ -14,7 +14,8 @@ from hypothesis import strategies as st
 pytestmark = pytest.mark.gpu
 
 N_EXAMPLES = int(os.environ.get("MA_FUZZ_EXAMPLES", "40"))
-COMMON = dict(max_examples=N_EXAMPLES, deadline=None, derandomize=True,
+# MA_FUZZ_RANDOM=1: fresh random examples on every run (campaign mode) instead of the reproducible default set
+COMMON = dict(max_examples=N_EXAMPLES, deadline=None, derandomize=os.environ.get("MA_FUZZ_RANDOM", "0") != "1", database=None,
               suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
 
 NP = {"i8": np.int8, "u8": np.uint8, "i16": np.int16, "u16": np.uint16, "i32": np.int32, "u32": np.uint32,
