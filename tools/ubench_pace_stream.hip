@@ -77,6 +77,65 @@ static void launch(const d2* a, const d2* b, d2* out, size_t rows, int grid, hip
         vars.push_back({std::string(MODE == 0 ? "a+b " : "a*s ") + "U" #U " PL=" #PL " PS=" #PS " bpc=" + std::to_string(bpc), \
                         MODE == 0 ? 24 : 16, launch<MODE, U, PL, PS>, cus * bpc});
 
+
+// ORDER 1: loads of a and b alternate (a0 b0 a1 b1 ...). ORDER 2: software pipelined — the next tile's loads are issued
+// before the current tile's stores.
+template <int U, int ORDER>
+__global__ __launch_bounds__(256) void add_kernel(const d2* __restrict__ a, const d2* __restrict__ b, d2* __restrict__ out,
+                                                  size_t n_tiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr size_t WAVE_VECS = (size_t)64 * U, TILE_VECS = WAVE_VECS * 4;
+    if (ORDER == 1) {
+        for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+            const size_t v0 = t * TILE_VECS + wave * WAVE_VECS + lane;
+            d2 x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[u] = __builtin_nontemporal_load(a + v0 + (size_t)u * 64);
+                y[u] = __builtin_nontemporal_load(b + v0 + (size_t)u * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) __builtin_nontemporal_store(x[u] + y[u], out + v0 + (size_t)u * 64);
+        }
+    } else {
+        size_t t = blockIdx.x;
+        d2 x[U], y[U], r[U];
+        if (t < n_tiles) {
+            const size_t v0 = t * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(a + v0 + (size_t)u * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(b + v0 + (size_t)u * 64);
+        }
+        while (t < n_tiles) {
+            const size_t v0 = t * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = x[u] + y[u];
+            const size_t tn = t + gridDim.x;
+            if (tn < n_tiles) {
+                const size_t v1 = tn * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(a + v1 + (size_t)u * 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) y[u] = __builtin_nontemporal_load(b + v1 + (size_t)u * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) __builtin_nontemporal_store(r[u], out + v0 + (size_t)u * 64);
+            t = tn;
+        }
+    }
+}
+
+template <int U, int ORDER>
+static void launch_add(const d2* a, const d2* b, d2* out, size_t rows, int grid, hipStream_t s) {
+    size_t n_tiles = rows / ((size_t)2 * 64 * U * 4);
+    hipLaunchKernelGGL((add_kernel<U, ORDER>), dim3(grid), dim3(256), 0, s, a, b, out, n_tiles);
+}
+
+#define ADDO(U, ORDER)                                                                                          \
+    for (int bpc : {2, 4, 6})                                                                                   \
+        vars.push_back({std::string("a+b U" #U " order=" #ORDER " bpc=") + std::to_string(bpc), 24, launch_add<U, ORDER>, cus * bpc});
+
 int main(int argc, char** argv) {
     size_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000000ull;
     int rounds = argc > 2 ? atoi(argv[2]) : 3, reps = 5;
@@ -97,6 +156,7 @@ int main(int argc, char** argv) {
     std::vector<Variant> vars;
     ADD(0, 8, 0, 0) ADD(0, 8, 8, 0) ADD(0, 8, 16, 0) ADD(0, 8, 24, 0) ADD(0, 8, 0, 8) ADD(0, 8, 0, 16) ADD(0, 8, 8, 8) ADD(0, 8, 16, 16) ADD(0, 8, 16, 8)
     ADD(1, 8, 0, 0) ADD(1, 8, 8, 0) ADD(1, 8, 16, 0) ADD(1, 8, 24, 0) ADD(1, 8, 0, 8) ADD(1, 8, 0, 16) ADD(1, 8, 8, 8) ADD(1, 8, 16, 16) ADD(1, 8, 16, 8)
+    ADDO(8, 1) ADDO(8, 2) ADDO(4, 2)
     ADD(0, 4, 0, 0) ADD(0, 4, 16, 0) ADD(0, 4, 16, 16) ADD(1, 4, 0, 0) ADD(1, 4, 16, 0) ADD(1, 4, 16, 16)
     for (int r = 0; r < rounds; ++r) {
         for (auto& v : vars) {
