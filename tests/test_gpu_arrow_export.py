@@ -225,7 +225,7 @@ def test_large_host_resident_arrow_arrays_cross_in_tiles(ctx):
     assert np.all(raw[~np.asarray(got.is_valid())] == 0)
     # sums of the same arrays through the Arrow entry point (tiled reduction of a pageable column)
     with Exported(lhs) as a:
-        s, c = ctx.sum_arrow(a.array_ptr, a.schema_ptr)
+        s, _, c = ctx.sum_arrow(a.array_ptr, a.schema_ptr)
     import math
     exact = math.fsum(a_vals[3:3 + n - 7][~a_null[3:3 + n - 7]].tolist())
     assert c == int((~a_null[3:3 + n - 7]).sum()) and abs(s - exact) <= math.ulp(exact)
