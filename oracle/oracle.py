@@ -18,11 +18,30 @@ REF_INSPECT_PATH = _HERE / "_ref" / "libcinspect_arrow.so"
 _lib = None
 
 
+def _host_cpu_flags() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return " ".join(sorted(line.split(":", 1)[1].split()))
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force: bool = False) -> None:
-    """Compiles the oracle (and oracle/_ref when /root/reference is present) with gcc."""
+    """Compiles the oracle (and oracle/_ref when /root/reference is present) with gcc. The library is built with
+    -march=native, and a prebuilt copy travels with the repo to the GPU box: it is rebuilt there when that host's CPU
+    feature set differs from the build host's (an AVX-512 build must not run on a host without it)."""
     src = _HERE / "minarrow_oracle.c"
-    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    stamp = _HERE / "_build" / "build_host_cpu_flags.txt"
+    flags = _host_cpu_flags()
+    same_host = stamp.exists() and stamp.read_text() == flags
+    if force or not same_host or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        if LIB_PATH.exists():
+            LIB_PATH.unlink()  # make must not consider it up to date
         subprocess.run(["make", "-C", str(_HERE), "-s"], check=True)
+        stamp.parent.mkdir(parents=True, exist_ok=True)
+        stamp.write_text(flags)
 
 
 def lib() -> C.CDLL:
