@@ -210,3 +210,19 @@ def test_sharded_super_table_over_gloo(world, n_batches, ragged):
         assert data == ints.tobytes()  # == consolidate_concat of the batches in order
         assert wrote and bits == want_bits.tobytes()
     assert len({r[1][1][2] for r in results}) == 1  # bit-identical f64 finals on every rank
+
+
+def test_gather_consolidated_without_a_process_group():
+    """One rank, no torch.distributed: the piece is the column; several advertised ranks are an error, not a hang."""
+    import torch
+
+    from minarrow_amd.parallel import gather_consolidated
+
+    vals = torch.arange(37, dtype=torch.int64)
+    bits = torch.from_numpy(np.packbits(np.arange(37) % 2 == 0, bitorder="little"))
+    out, out_bits = torch.zeros(37, dtype=torch.int64), torch.zeros(8, dtype=torch.uint8)
+    assert gather_consolidated(vals, [37], out, bits, out_bits)
+    assert torch.equal(out, vals) and torch.equal(out_bits[:5], bits)
+    assert not gather_consolidated(vals, [37], out)  # no validity anywhere
+    with pytest.raises(ValueError):
+        gather_consolidated(vals, [20, 17], out)
