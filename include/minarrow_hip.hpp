@@ -74,6 +74,26 @@ class Context {
     ma_ctx* ctx_ = nullptr;
 };
 
+// Where the typed API allocates its RESULTS. Host (default): pinned host memory, the Vec64 stand-in, readable and
+// writable by the CPU. Device: HBM (ma_dev_alloc) — a column that stays resident across several operations runs every
+// one of them at HBM rate instead of crossing PCIe twice per call; the CPU must not dereference such a
+// vector: download it with to_host(). Inputs may live anywhere regardless (the library classifies every pointer).
+enum class Placement { Host, Device };
+namespace detail {
+inline Placement& result_placement() {
+    static thread_local Placement p = Placement::Host;
+    return p;
+}
+}  // namespace detail
+// RAII: results of apply_* / consolidate / ... made on this thread while the scope lives are allocated in HBM.
+struct DeviceScope {
+    Placement saved;
+    DeviceScope() : saved(detail::result_placement()) { detail::result_placement() = Placement::Device; }
+    ~DeviceScope() { detail::result_placement() = saved; }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // 64-byte aligned, pinned, device-mapped vector: the Vec64 stand-in.
 template <typename T>
 class Vec64 {
@@ -90,30 +110,61 @@ class Vec64 {
             owner_ = o.owner_;
             data_ = o.data_;
             len_ = cap_ = o.len_;
+            device_ = o.device_;
             return;
         }
         reserve(o.len_);
         if (o.len_) std::memcpy(data_, o.data_, o.len_ * sizeof(T));
         len_ = o.len_;
     }
-    Vec64(Vec64&& o) noexcept : data_(o.data_), len_(o.len_), cap_(o.cap_), owner_(std::move(o.owner_)) {
+    Vec64(Vec64&& o) noexcept : data_(o.data_), len_(o.len_), cap_(o.cap_), owner_(std::move(o.owner_)), device_(o.device_) {
         o.data_ = nullptr;
         o.len_ = o.cap_ = 0;
+        o.device_ = false;
     }
     Vec64& operator=(Vec64 o) noexcept {
         std::swap(data_, o.data_);
         std::swap(len_, o.len_);
         std::swap(cap_, o.cap_);
         std::swap(owner_, o.owner_);
+        std::swap(device_, o.device_);
         return *this;
     }
     ~Vec64() {
         if (data_ && !owner_) ma_free_pinned(data_);
     }
     static Vec64 with_capacity(size_t n) {
+        if (detail::result_placement() == Placement::Device) return on_device(n, 0);
         Vec64 v;
         v.reserve(n);
         return v;
+    }
+    // `cap` elements of HBM owned by the returned vector (a window whose owner frees the allocation), length `len`.
+    // Padded like the host form so that whole-u64-word bitmap writes stay inside it.
+    static Vec64 on_device(size_t cap, size_t len) {
+        void* p = nullptr;
+        ma_ctx* ctx = Context::global().get();
+        check(ma_dev_alloc(ctx, ((cap * sizeof(T) + 63) / 64) * 64 + 64, &p));
+        Vec64 v = from_shared(std::shared_ptr<void>(p, [ctx](void* q) { (void)ma_dev_free(ctx, q); }), static_cast<T*>(p), len);
+        v.cap_ = cap;
+        v.device_ = true;
+        return v;
+    }
+    bool is_device() const { return device_; }
+    // Upload / download (ma_dev_upload / ma_dev_download); a vector already on the requested side is shared, not copied.
+    Vec64 to_device() const {
+        if (device_) return *this;
+        Vec64 d = on_device(len_, len_);
+        if (len_) check(ma_dev_upload(Context::global().get(), d.data_, data_, len_ * sizeof(T)));
+        return d;
+    }
+    Vec64 to_host() const {
+        if (!device_) return *this;
+        Vec64 h;
+        h.reserve(len_);
+        if (len_) check(ma_dev_download(Context::global().get(), h.data_, data_, len_ * sizeof(T)));
+        h.len_ = len_;
+        return h;
     }
     // A window of memory kept alive by `owner` — Buffer::from_shared over a SharedBuffer (src/structs/buffer.rs:168-217,
     // src/structs/shared_buffer/mod.rs:82-87); what ArenaRegion::to_buffer hands out (src/structs/arena.rs:502-517).
@@ -143,14 +194,17 @@ class Vec64 {
         for (size_t i = len_; i < n; ++i) data_[i] = fill;
         len_ = n;
     }
-    void set_len(size_t n) { len_ = n; }  // dispatch.rs:88-89 `unsafe { out.set_len(len) }`
+    void set_len(size_t n) {  // dispatch.rs:88-89 `unsafe { out.set_len(len) }`
+        if (device_ && n > cap_) throw KernelError(KernelError::InvalidArguments, "set_len beyond a device vector's capacity");
+        len_ = n;
+    }
     void push(T v) {
         if (owner_) make_owned(len_ + 1);
         if (len_ == cap_) reserve(cap_ ? cap_ * 2 : 16);
         data_[len_++] = v;
     }
-    T* data() {
-        if (owner_) make_owned(len_);
+    T* data() {  // a device vector is handed out as is: its only writers are kernels
+        if (owner_ && !device_) make_owned(len_);
         return data_;
     }
     const T* data() const { return data_; }
@@ -160,10 +214,14 @@ class Vec64 {
         if (owner_) make_owned(len_);
         return data_[i];
     }
-    const T& operator[](size_t i) const { return data_[i]; }
+    const T& operator[](size_t i) const {
+        if (device_) throw KernelError(KernelError::InvalidArguments, "a device-resident Vec64 cannot be read by the CPU: to_host() first");
+        return data_[i];
+    }
     const T* begin() const { return data_; }
     const T* end() const { return data_ + len_; }
     bool operator==(const std::vector<T>& o) const {
+        if (device_) return to_host() == o;
         if (o.size() != len_) return false;
         for (size_t i = 0; i < len_; ++i)
             if (!(data_[i] == o[i])) return false;
@@ -173,6 +231,7 @@ class Vec64 {
   private:
     // copy-on-write: leave the shared region, keep at least `n` elements of room
     void make_owned(size_t n) {
+        if (device_) throw KernelError(KernelError::InvalidArguments, "a device-resident Vec64 cannot be modified by the CPU: to_host() first");
         const T* src = data_;
         const size_t keep = len_;
         std::shared_ptr<void> hold = std::move(owner_);
@@ -186,6 +245,7 @@ class Vec64 {
     T* data_ = nullptr;
     size_t len_ = 0, cap_ = 0;
     std::shared_ptr<void> owner_;
+    bool device_ = false;
 };
 
 // Arrow validity bitmap — src/structs/bitmask.rs:66-71. LSB first, 1 = valid, bits >= len zero.
@@ -199,6 +259,10 @@ class Bitmask {
     static Bitmask new_set_all(size_t len, bool set) {
         Bitmask m;
         m.len = len;
+        if (detail::result_placement() == Placement::Device) {  // a result bitmap in HBM: the kernel writes every word
+            m.bits = Vec64<uint8_t>::on_device(((len + 63) / 64) * 8, ((len + 63) / 64) * 8);
+            return m;
+        }
         m.bits.resize(((len + 63) / 64) * 8, 0);  // word-padded capacity (the kernels write whole u64 words)
         size_t n_bytes = (len + 7) / 8;
         for (size_t i = 0; i < n_bytes; ++i) m.bits[i] = set ? 0xFF : 0;
@@ -215,13 +279,28 @@ class Bitmask {
         if (len == 0 || (len & 7) == 0) return;
         bits[(len + 7) / 8 - 1] &= (uint8_t)((1u << (len & 7)) - 1);
     }
-    bool get(size_t i) const { return (bits[i >> 3] >> (i & 7)) & 1; }  // bitmask.rs:745-748
+    bool get(size_t i) const {  // bitmask.rs:745-748
+        if (bits.is_device()) throw KernelError(KernelError::InvalidArguments, "Bitmask::get on a device-resident bitmap: to_host() first");
+        return (bits[i >> 3] >> (i & 7)) & 1;
+    }
     void set(size_t i, bool v) {                                        // bitmask.rs:248-258
         if (v) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
         else bits[i >> 3] &= (uint8_t)~(1u << (i & 7));
     }
     size_t count_ones() const;
     bool all_true() const;
+    Bitmask to_device() const {
+        Bitmask m;
+        m.len = len;
+        m.bits = bits.to_device();
+        return m;
+    }
+    Bitmask to_host() const {
+        Bitmask m;
+        m.len = len;
+        m.bits = bits.to_host();
+        return m;
+    }
 };
 
 // BitmaskVT = (&Bitmask, offset, len) — src/aliases.rs:172

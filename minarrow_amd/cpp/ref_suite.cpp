@@ -480,6 +480,54 @@ static void chunked_suite() {
     }
 }
 
+// Columns that stay resident in HBM across a chain of operations (DeviceScope / Vec64::to_device): every step reads
+// and writes device memory, only the final scalar or an explicit to_host() crosses PCIe — and the bits are those of the
+// same chain on host-resident (pinned) columns.
+static void device_residency_suite() {
+    printf("device residency suite\n");
+    const size_t n = 100003;
+    Vec64<double> a(n), b(n), c(n);
+    for (size_t i = 0; i < n; ++i) {
+        a[i] = 0.5 * (double)i;
+        b[i] = 1.0 / (double)(i + 1);
+        c[i] = (double)(i % 7) - 3.0;
+    }
+    Bitmask m = Bitmask::new_set_all(n, true);
+    for (size_t i = 0; i < n; i += 5) m.set(i, false);
+    // host chain: (a + b) * c, masked, then the sum of the valid rows
+    FloatArray<double> h1 = apply_float_f64(a, b, Op::Add, &m);
+    FloatArray<double> h2 = apply_float_f64(h1.data, c, Op::Multiply, &*h1.null_mask);
+    uint64_t h_valid = 0;
+    const double h_sum = sum_f64(h2.data, &*h2.null_mask, &h_valid);
+    // the same chain with every operand and every result in HBM
+    const Vec64<double> da = a.to_device(), db = b.to_device(), dc = c.to_device();
+    const Bitmask dm = m.to_device();
+    ASSERT(da.is_device() && dm.bits.is_device() && da.size() == n);
+    FloatArray<double> d2;
+    {
+        DeviceScope on_device;
+        FloatArray<double> d1 = apply_float_f64(da, db, Op::Add, &dm);
+        ASSERT(d1.data.is_device() && d1.null_mask->bits.is_device());
+        d2 = apply_float_f64(d1.data, dc, Op::Multiply, &*d1.null_mask);
+    }
+    ASSERT(d2.data.is_device() && d2.data.size() == n);
+    uint64_t d_valid = 0;
+    const double d_sum = sum_f64(d2.data, &*d2.null_mask, &d_valid);
+    ASSERT(d_valid == h_valid && d_sum == h_sum);
+    const Vec64<double> back = d2.data.to_host();
+    const Bitmask back_mask = d2.null_mask->to_host();
+    ASSERT(!back.is_device() && back.size() == n);
+    bool same = true;
+    for (size_t i = 0; i < n; ++i) same = same && std::memcmp(&back[i], &h2.data[i], 8) == 0 && back_mask.get(i) == h2.null_mask->get(i);
+    ASSERT(same);
+    // the CPU is kept away from device memory
+    ASSERT(kernel_error(KernelError::InvalidArguments, "to_host", [&] { (void)d2.data[0]; }));
+    ASSERT(kernel_error(KernelError::InvalidArguments, "to_host", [&] { Vec64<double> w = d2.data; w.push(1.0); }));
+    // results made outside a DeviceScope land in pinned host memory again, whatever the inputs
+    FloatArray<double> mixed = apply_float_f64(da, b, Op::Add);
+    ASSERT(!mixed.data.is_device() && mixed.data[1] == a[1] + b[1]);
+}
+
 int main() {
     try {
         int_kernel_suite<int32_t>("i32", [](Slice<int32_t> l, Slice<int32_t> r, Op op, const Bitmask* m) { return apply_int_i32(l, r, op, m); });
@@ -496,6 +544,7 @@ int main() {
         bench_sums();
         routing_suite();
         chunked_suite();
+        device_residency_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
