@@ -523,6 +523,24 @@ static void device_residency_suite() {
     // the CPU is kept away from device memory
     ASSERT(kernel_error(KernelError::InvalidArguments, "to_host", [&] { (void)d2.data[0]; }));
     ASSERT(kernel_error(KernelError::InvalidArguments, "to_host", [&] { Vec64<double> w = d2.data; w.push(1.0); }));
+    // the enum-dispatch layer on resident columns: NumericArray operators route to the same kernels
+    {
+        FloatArray<double> fa, fb;
+        fa.data = da;
+        fb.data = db;
+        const NumericArray na = NumericArray::from_float64(std::move(fa)), nb = NumericArray::from_float64(std::move(fb));
+        NumericArray nr;
+        {
+            DeviceScope on_device;
+            nr = na + nb;
+        }
+        const FloatArray<double>* r = nr.try_f64_ref();
+        ASSERT(r != nullptr && r->data.is_device() && r->data.size() == n);
+        const Vec64<double> rh = r->data.to_host();
+        bool ok = true;
+        for (size_t i = 0; i < n; ++i) ok = ok && rh[i] == a[i] + b[i];
+        ASSERT(ok);
+    }
     // results made outside a DeviceScope land in pinned host memory again, whatever the inputs
     FloatArray<double> mixed = apply_float_f64(da, b, Op::Add);
     ASSERT(!mixed.data.is_device() && mixed.data[1] == a[1] + b[1]);
