@@ -5,6 +5,8 @@
 //   src/kernels/bitmask/simd.rs:797-955     (simd_bitmask_suite!)
 //   benches/hotloop_benchmark_std.rs:49-57  (sum of 0..N)
 // Exit code 0 = every assertion held. Run by tests/test_gpu_cpp_host.py.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -540,6 +542,33 @@ static void device_residency_suite() {
         bool ok = true;
         for (size_t i = 0; i < n; ++i) ok = ok && rh[i] == a[i] + b[i];
         ASSERT(ok);
+    }
+    // what residency buys: the chain (x + y) * z -> sum over 2^25 rows, columns in pinned host memory vs in HBM
+    {
+        const size_t big = (size_t)1 << 25;
+        Vec64<double> x(big, 1.5), y(big, 0.25), z(big, 2.0);
+        auto chain = [&](const Vec64<double>& p, const Vec64<double>& q, const Vec64<double>& r) {
+            FloatArray<double> s1 = apply_float_f64(p, q, Op::Add);
+            FloatArray<double> s2 = apply_float_f64(s1.data, r, Op::Multiply);
+            return sum_f64(s2.data);
+        };
+        auto time_ms = [&](const std::function<double()>& f, double* out) {
+            *out = f();  // warm
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                const auto t0 = std::chrono::steady_clock::now();
+                *out = f();
+                best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+            return best;
+        };
+        double host_sum = 0, dev_sum = 0;
+        const double host_ms = time_ms([&] { return chain(x, y, z); }, &host_sum);
+        const Vec64<double> dx = x.to_device(), dy = y.to_device(), dz = z.to_device();
+        const double dev_ms = time_ms([&] { DeviceScope on_device; return chain(dx, dy, dz); }, &dev_sum);
+        ASSERT(host_sum == dev_sum && dev_sum == 3.5 * (double)big);
+        std::printf("  chain (x + y) * z -> sum, %zu rows: pinned host columns %.2f ms, HBM-resident columns %.3f ms (%.0fx)\n", big,
+                    host_ms, dev_ms, host_ms / dev_ms);
     }
     // results made outside a DeviceScope land in pinned host memory again, whatever the inputs
     FloatArray<double> mixed = apply_float_f64(da, b, Op::Add);
