@@ -117,9 +117,14 @@ ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
  * device-resident buffers
  * ---------------------------------------------------------------------------------------------- */
 
-/* hipHostMalloc-backed, 64-byte aligned, device-mapped. The pointer is valid on the host and in kernels. */
+/* hipHostMalloc-backed, 64-byte aligned, device-mapped. The pointer is valid on the host and in kernels. Blocks of
+ * 1 MiB and more are recycled through a size-class cache (pinning pages costs ~40 ms per 256 MiB; a Vec64 allocator
+ * built on raw hipHostMalloc would be 50x slower than malloc for large columns): ma_free_pinned parks them,
+ * ma_alloc64_pinned reuses them. ma_pinned_pool_trim(keep) releases cached blocks down to `keep` bytes and makes that the
+ * new cache limit (default 2 GiB; 0 = no caching). Thread safe. */
 ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr);
 ma_status ma_free_pinned(void* ptr);
+ma_status ma_pinned_pool_trim(size_t keep_bytes);
 /* Pins an EXISTING host allocation in place (hipHostRegister, portable + mapped) — for a host that cannot change the
  * allocator of buffers it already owns: a Vec64<T> from the stock vec64 crate (Cargo.toml:54), a foreign buffer behind
  * SharedBuffer::from_owner (src/structs/shared_buffer/mod.rs:187-206), an mmap. From then on the range classifies as

@@ -1,12 +1,37 @@
 // Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
 // C ABI: include/minarrow_hip.h.
 #include <atomic>
+#include <utility>
+#include <vector>
 
 #include "ma_common.hpp"
 
 namespace ma {
 
 static thread_local char g_err[512] = "";
+
+// Pinned blocks of 1 MiB and more are recycled: hipHostMalloc pins pages at a few GB/s (a 256-MiB Vec64 costs ~40 ms to
+// allocate and as much to free), which would make an allocator built on it 50x slower than malloc for exactly the
+// columns the device path is for. Freed blocks wait in per-size-class lists (sizes rounded up to a power of two) until
+// the cache holds more than the limit; smaller blocks go straight to hipHostMalloc / hipHostFree.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<void*> free_blocks[48];                  // by log2(size class)
+    std::vector<std::pair<void*, int>> live;             // blocks handed out from a size class (ptr, class)
+    size_t cached_bytes = 0;
+    size_t limit_bytes = (size_t)2 << 30;
+};
+PinnedPool& pinned_pool() {
+    static PinnedPool* pool = new PinnedPool();  // intentionally leaked: frees may arrive during process teardown
+    return *pool;
+}
+constexpr size_t kPoolMinBytes = (size_t)1 << 20;
+int size_class_of(size_t bytes) {
+    int c = 20;
+    while (((size_t)1 << c) < bytes) ++c;
+    return c;
+}
+
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -577,14 +602,68 @@ ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr) {
     }
     // hipHostMalloc returns page-aligned memory, which satisfies Vec64's 64-byte contract.
     void* p = nullptr;
-    MA_HIP(hipHostMalloc(&p, bytes == 0 ? 64 : bytes, hipHostMallocPortable | hipHostMallocMapped));
+    if (bytes < kPoolMinBytes) {
+        MA_HIP(hipHostMalloc(&p, bytes == 0 ? 64 : bytes, hipHostMallocPortable | hipHostMallocMapped));
+        *out_ptr = p;
+        return MA_OK;
+    }
+    PinnedPool& pool = pinned_pool();
+    const int c = size_class_of(bytes);
+    MA_REQUIRE(c < 48, MA_ERR_INVALID_ARGUMENT, "pinned allocation of %zu bytes is too large", bytes);
+    {
+        std::lock_guard<std::mutex> lock(pool.mu);
+        if (!pool.free_blocks[c].empty()) {
+            p = pool.free_blocks[c].back();
+            pool.free_blocks[c].pop_back();
+            pool.cached_bytes -= (size_t)1 << c;
+            pool.live.emplace_back(p, c);
+            *out_ptr = p;
+            return MA_OK;
+        }
+    }
+    MA_HIP(hipHostMalloc(&p, (size_t)1 << c, hipHostMallocPortable | hipHostMallocMapped));
+    std::lock_guard<std::mutex> lock(pool.mu);
+    pool.live.emplace_back(p, c);
     *out_ptr = p;
     return MA_OK;
 }
 
 ma_status ma_free_pinned(void* ptr) {
     if (!ptr) return MA_OK;
+    PinnedPool& pool = pinned_pool();
+    {
+        std::lock_guard<std::mutex> lock(pool.mu);
+        for (size_t i = pool.live.size(); i-- > 0;) {
+            if (pool.live[i].first != ptr) continue;
+            const int c = pool.live[i].second;
+            pool.live[i] = pool.live.back();
+            pool.live.pop_back();
+            if (pool.cached_bytes + ((size_t)1 << c) <= pool.limit_bytes) {
+                pool.free_blocks[c].push_back(ptr);
+                pool.cached_bytes += (size_t)1 << c;
+                return MA_OK;
+            }
+            break;  // the cache is full: give it back to the runtime
+        }
+    }
     MA_HIP(hipHostFree(ptr));
+    return MA_OK;
+}
+
+ma_status ma_pinned_pool_trim(size_t keep_bytes) {
+    PinnedPool& pool = pinned_pool();
+    std::vector<void*> victims;
+    {
+        std::lock_guard<std::mutex> lock(pool.mu);
+        pool.limit_bytes = keep_bytes;
+        for (int c = 47; c >= 20 && pool.cached_bytes > keep_bytes; --c)
+            while (!pool.free_blocks[c].empty() && pool.cached_bytes > keep_bytes) {
+                victims.push_back(pool.free_blocks[c].back());
+                pool.free_blocks[c].pop_back();
+                pool.cached_bytes -= (size_t)1 << c;
+            }
+    }
+    for (void* v : victims) MA_HIP(hipHostFree(v));
     return MA_OK;
 }
 

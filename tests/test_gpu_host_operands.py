@@ -253,3 +253,29 @@ def test_registering_an_existing_host_buffer(ctx, oracle):
     assert lib.ma_pointer_kind(a.ctypes.data) == 0
     with pytest.raises(ffi.MinarrowHipError):
         ffi.check(lib.ma_host_register(None, 0))
+
+
+def test_pinned_allocator_recycles_large_blocks(ctx):
+    """ma_alloc64_pinned / ma_free_pinned: blocks of 1 MiB and more come back from a size-class cache (pinning pages is
+    the expensive part of a pinned Vec64), small ones do not; ma_pinned_pool_trim empties it."""
+    import ctypes as C
+
+    lib = ctx.lib
+    p1, p2, small = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ffi.check(lib.ma_pinned_pool_trim(2 << 30))
+    ffi.check(lib.ma_alloc64_pinned(3 << 20, C.byref(p1)))
+    assert p1.value % 64 == 0 and lib.ma_pointer_kind(p1.value) == 1
+    C.memset(p1.value, 0x5A, 3 << 20)
+    ffi.check(lib.ma_free_pinned(p1.value))
+    ffi.check(lib.ma_alloc64_pinned(4 << 20, C.byref(p2)))  # same 4-MiB class: the parked block
+    assert p2.value == p1.value
+    arr = np.ctypeslib.as_array(C.cast(p2.value, C.POINTER(C.c_int64)), shape=(1 << 19,))
+    arr[:] = np.arange(1 << 19)
+    assert ctx.sum("i64", p2.value, 1 << 19) == ((1 << 19) * ((1 << 19) - 1) // 2, 1 << 19)
+    ffi.check(lib.ma_free_pinned(p2.value))
+    ffi.check(lib.ma_pinned_pool_trim(0))       # nothing stays cached ...
+    ffi.check(lib.ma_alloc64_pinned(4 << 20, C.byref(p2)))
+    ffi.check(lib.ma_free_pinned(p2.value))     # ... and with a zero limit nothing is parked again
+    ffi.check(lib.ma_alloc64_pinned(1000, C.byref(small)))
+    ffi.check(lib.ma_free_pinned(small.value))
+    ffi.check(lib.ma_pinned_pool_trim(2 << 30))
