@@ -1,6 +1,8 @@
 // Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
 // C ABI: include/minarrow_hip.h.
 #include <atomic>
+#include <map>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -12,12 +14,14 @@ static thread_local char g_err[512] = "";
 
 // Pinned blocks of 1 MiB and more are recycled: hipHostMalloc pins pages at a few GB/s (a 256-MiB Vec64 costs ~40 ms to
 // allocate and as much to free), which would make an allocator built on it 50x slower than malloc for exactly the
-// columns the device path is for. Freed blocks wait in per-size-class lists (sizes rounded up to a power of two) until
-// the cache holds more than the limit; smaller blocks go straight to hipHostMalloc / hipHostFree.
+// columns the device path is for. Sizes are rounded up to one of eight steps per power of two (at most 12.5 % of slack);
+// freed blocks wait in per-size lists until the cache holds more than the limit. Smaller blocks go straight to
+// hipHostMalloc / hipHostFree.
+namespace {
 struct PinnedPool {
     std::mutex mu;
-    std::vector<void*> free_blocks[48];                  // by log2(size class)
-    std::vector<std::pair<void*, int>> live;             // blocks handed out from a size class (ptr, class)
+    std::map<size_t, std::vector<void*>> parked;   // rounded size -> free blocks of that size
+    std::unordered_map<void*, size_t> live;        // blocks handed out by the pool -> their rounded size
     size_t cached_bytes = 0;
     size_t limit_bytes = (size_t)2 << 30;
 };
@@ -26,12 +30,13 @@ PinnedPool& pinned_pool() {
     return *pool;
 }
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
-int size_class_of(size_t bytes) {
-    int c = 20;
-    while (((size_t)1 << c) < bytes) ++c;
-    return c;
+size_t pool_size_of(size_t bytes) {  // bytes >= kPoolMinBytes
+    size_t top = kPoolMinBytes;
+    while ((top << 1) != 0 && (top << 1) <= bytes) top <<= 1;  // largest power of two <= bytes
+    const size_t step = top >> 3;
+    return ((bytes + step - 1) / step) * step;
 }
-
+}  // namespace
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -607,23 +612,24 @@ ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr) {
         *out_ptr = p;
         return MA_OK;
     }
+    MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "pinned allocation of %zu bytes is too large", bytes);
     PinnedPool& pool = pinned_pool();
-    const int c = size_class_of(bytes);
-    MA_REQUIRE(c < 48, MA_ERR_INVALID_ARGUMENT, "pinned allocation of %zu bytes is too large", bytes);
+    const size_t rounded = pool_size_of(bytes);
     {
         std::lock_guard<std::mutex> lock(pool.mu);
-        if (!pool.free_blocks[c].empty()) {
-            p = pool.free_blocks[c].back();
-            pool.free_blocks[c].pop_back();
-            pool.cached_bytes -= (size_t)1 << c;
-            pool.live.emplace_back(p, c);
+        auto it = pool.parked.find(rounded);
+        if (it != pool.parked.end() && !it->second.empty()) {
+            p = it->second.back();
+            it->second.pop_back();
+            pool.cached_bytes -= rounded;
+            pool.live.emplace(p, rounded);
             *out_ptr = p;
             return MA_OK;
         }
     }
-    MA_HIP(hipHostMalloc(&p, (size_t)1 << c, hipHostMallocPortable | hipHostMallocMapped));
+    MA_HIP(hipHostMalloc(&p, rounded, hipHostMallocPortable | hipHostMallocMapped));
     std::lock_guard<std::mutex> lock(pool.mu);
-    pool.live.emplace_back(p, c);
+    pool.live.emplace(p, rounded);
     *out_ptr = p;
     return MA_OK;
 }
@@ -633,17 +639,16 @@ ma_status ma_free_pinned(void* ptr) {
     PinnedPool& pool = pinned_pool();
     {
         std::lock_guard<std::mutex> lock(pool.mu);
-        for (size_t i = pool.live.size(); i-- > 0;) {
-            if (pool.live[i].first != ptr) continue;
-            const int c = pool.live[i].second;
-            pool.live[i] = pool.live.back();
-            pool.live.pop_back();
-            if (pool.cached_bytes + ((size_t)1 << c) <= pool.limit_bytes) {
-                pool.free_blocks[c].push_back(ptr);
-                pool.cached_bytes += (size_t)1 << c;
+        auto it = pool.live.find(ptr);
+        if (it != pool.live.end()) {
+            const size_t rounded = it->second;
+            pool.live.erase(it);
+            if (pool.cached_bytes + rounded <= pool.limit_bytes) {
+                pool.parked[rounded].push_back(ptr);
+                pool.cached_bytes += rounded;
                 return MA_OK;
             }
-            break;  // the cache is full: give it back to the runtime
+            // the cache is full: give the block back to the runtime
         }
     }
     MA_HIP(hipHostFree(ptr));
@@ -656,11 +661,11 @@ ma_status ma_pinned_pool_trim(size_t keep_bytes) {
     {
         std::lock_guard<std::mutex> lock(pool.mu);
         pool.limit_bytes = keep_bytes;
-        for (int c = 47; c >= 20 && pool.cached_bytes > keep_bytes; --c)
-            while (!pool.free_blocks[c].empty() && pool.cached_bytes > keep_bytes) {
-                victims.push_back(pool.free_blocks[c].back());
-                pool.free_blocks[c].pop_back();
-                pool.cached_bytes -= (size_t)1 << c;
+        for (auto it = pool.parked.rbegin(); it != pool.parked.rend() && pool.cached_bytes > keep_bytes; ++it)  // largest first
+            while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
+                victims.push_back(it->second.back());
+                it->second.pop_back();
+                pool.cached_bytes -= it->first;
             }
     }
     for (void* v : victims) MA_HIP(hipHostFree(v));

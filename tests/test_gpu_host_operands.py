@@ -263,11 +263,11 @@ def test_pinned_allocator_recycles_large_blocks(ctx):
     lib = ctx.lib
     p1, p2, small = C.c_void_p(), C.c_void_p(), C.c_void_p()
     ffi.check(lib.ma_pinned_pool_trim(2 << 30))
-    ffi.check(lib.ma_alloc64_pinned(3 << 20, C.byref(p1)))
+    ffi.check(lib.ma_alloc64_pinned((4 << 20) + 5, C.byref(p1)))  # rounded up to 4.5 MiB (eight steps per power of two)
     assert p1.value % 64 == 0 and lib.ma_pointer_kind(p1.value) == 1
-    C.memset(p1.value, 0x5A, 3 << 20)
+    C.memset(p1.value, 0x5A, (4 << 20) + 5)
     ffi.check(lib.ma_free_pinned(p1.value))
-    ffi.check(lib.ma_alloc64_pinned(4 << 20, C.byref(p2)))  # same 4-MiB class: the parked block
+    ffi.check(lib.ma_alloc64_pinned((4 << 20) + 4096, C.byref(p2)))  # same 4.5-MiB class: the parked block
     assert p2.value == p1.value
     arr = np.ctypeslib.as_array(C.cast(p2.value, C.POINTER(C.c_int64)), shape=(1 << 19,))
     arr[:] = np.arange(1 << 19)
