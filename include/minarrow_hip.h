@@ -134,8 +134,15 @@ ma_status ma_pinned_pool_trim(size_t keep_bytes);
  * freed. `ptr` need not be page aligned; a range may be registered once. */
 ma_status ma_host_register(void* ptr, size_t bytes);
 ma_status ma_host_unregister(void* ptr);
+/* Device (HBM) blocks. ma_dev_free waits for the context's stream, then — for blocks of 1 MiB and more — parks the block
+ * in a per-device size-class cache instead of calling hipFree, which synchronises the whole device and stalls every other
+ * stream (~160 us); ma_dev_alloc reuses parked blocks and, when HBM runs out, releases the cache and retries.
+ * ma_dev_pool_trim(ctx, keep) releases parked blocks of the context's device down to `keep` bytes and makes that the new
+ * limit (default 16 GiB per device). A parked block may be handed out again at once: work that OTHER contexts or streams
+ * enqueued on it must have completed before it is freed (hipFree used to hide that by stalling the device). */
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
+ma_status ma_dev_pool_trim(ma_ctx* ctx, size_t keep_bytes);
 ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t bytes);

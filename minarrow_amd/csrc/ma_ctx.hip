@@ -25,16 +25,84 @@ struct PinnedPool {
     size_t cached_bytes = 0;
     size_t limit_bytes = (size_t)2 << 30;
 };
-PinnedPool& pinned_pool() {
-    static PinnedPool* pool = new PinnedPool();  // intentionally leaked: frees may arrive during process teardown
-    return *pool;
-}
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
 size_t pool_size_of(size_t bytes) {  // bytes >= kPoolMinBytes
     size_t top = kPoolMinBytes;
     while ((top << 1) != 0 && (top << 1) <= bytes) top <<= 1;  // largest power of two <= bytes
     const size_t step = top >> 3;
     return ((bytes + step - 1) / step) * step;
+}
+PinnedPool& pinned_pool() {
+    static PinnedPool* pool = new PinnedPool();  // intentionally leaked: frees may arrive during process teardown
+    return *pool;
+}
+// The same cache for device blocks, one per device: hipFree synchronises the WHOLE device (~160 us, and every other
+// stream stalls with it), so a chain of resident results that frees its temporaries would serialise all contexts.
+constexpr int kMaxPooledDevices = 64;
+PinnedPool& device_pool(int device) {
+    static PinnedPool* pools = [] {
+        PinnedPool* p = new PinnedPool[kMaxPooledDevices];
+        for (int i = 0; i < kMaxPooledDevices; ++i) p[i].limit_bytes = (size_t)16 << 30;
+        return p;
+    }();
+    return pools[device];
+}
+
+// hipMalloc / hipFree through the device's block cache (the caller has made the device current and, for a free, has
+// made sure nothing in flight still touches the block).
+hipError_t dev_block_alloc(int device, size_t bytes, void** out) {
+    *out = nullptr;
+    if (bytes < kPoolMinBytes || device < 0 || device >= kMaxPooledDevices) return hipMalloc(out, bytes == 0 ? 64 : bytes);
+    PinnedPool& pool = device_pool(device);
+    const size_t rounded = pool_size_of(bytes);
+    {
+        std::lock_guard<std::mutex> plock(pool.mu);
+        auto it = pool.parked.find(rounded);
+        if (it != pool.parked.end() && !it->second.empty()) {
+            *out = it->second.back();
+            it->second.pop_back();
+            pool.cached_bytes -= rounded;
+            pool.live.emplace(*out, rounded);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, rounded);
+    if (e == hipErrorOutOfMemory) {  // HBM is full of parked blocks: release them and try once more
+        (void)hipGetLastError();
+        std::vector<void*> victims;
+        {
+            std::lock_guard<std::mutex> plock(pool.mu);
+            for (auto& kv : pool.parked) {
+                victims.insert(victims.end(), kv.second.begin(), kv.second.end());
+                kv.second.clear();
+            }
+            pool.cached_bytes = 0;
+        }
+        for (void* v : victims) (void)hipFree(v);
+        e = hipMalloc(out, rounded);
+    }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> plock(pool.mu);
+    pool.live.emplace(*out, rounded);
+    return hipSuccess;
+}
+
+hipError_t dev_block_free(int device, void* ptr) {
+    if (device >= 0 && device < kMaxPooledDevices) {
+        PinnedPool& pool = device_pool(device);
+        std::lock_guard<std::mutex> plock(pool.mu);
+        auto it = pool.live.find(ptr);
+        if (it != pool.live.end()) {
+            const size_t rounded = it->second;
+            pool.live.erase(it);
+            if (pool.cached_bytes + rounded <= pool.limit_bytes) {
+                pool.parked[rounded].push_back(ptr);
+                pool.cached_bytes += rounded;
+                return hipSuccess;
+            }
+        }
+    }
+    return hipFree(ptr);
 }
 }  // namespace
 
@@ -113,7 +181,7 @@ CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
 }
 
 CallScope::~CallScope() {
-    for (void* slab : slabs_) (void)hipFree(slab);
+    for (void* slab : slabs_) (void)dev_block_free(ctx_->device, slab);  // staged calls end synchronised: safe to park
     if (--t_scope_depth == 0 || !temps_.empty()) forget_ranges();
 }
 
@@ -122,7 +190,7 @@ ma_status CallScope::carve(size_t bytes, void** out) {
     if (need > slab_left_) {
         size_t want = need > slab_next_ ? need : slab_next_;
         void* slab = nullptr;
-        MA_HIP(hipMalloc(&slab, want));
+        MA_HIP(dev_block_alloc(ctx_->device, want, &slab));
         slabs_.push_back(slab);
         if (need >= slab_next_) {  // a large operand gets its own allocation; the current slab stays open
             *out = slab;
@@ -691,10 +759,11 @@ ma_status ma_host_unregister(void* ptr) {
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;
+    MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "device allocation of %zu bytes is too large", bytes);
     std::lock_guard<std::mutex> lock(ctx->mu);
     MA_NO_CAPTURE(ctx, "ma_dev_alloc");
     MA_HIP(hipSetDevice(ctx->device));
-    MA_HIP(hipMalloc(out_dev_ptr, bytes == 0 ? 64 : bytes));
+    MA_HIP(dev_block_alloc(ctx->device, bytes, out_dev_ptr));
     return MA_OK;
 }
 
@@ -704,8 +773,29 @@ ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     MA_NO_CAPTURE(ctx, "ma_dev_free");
     MA_HIP(hipSetDevice(ctx->device));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
-    MA_HIP(hipFree(dev_ptr));
+    MA_HIP(hipStreamSynchronize(ctx->stream));  // nothing enqueued through this context still touches the block
+    MA_HIP(dev_block_free(ctx->device, dev_ptr));
+    return MA_OK;
+}
+
+ma_status ma_dev_pool_trim(ma_ctx* ctx, size_t keep_bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(ctx->device >= 0 && ctx->device < kMaxPooledDevices, MA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_HIP(hipSetDevice(ctx->device));
+    PinnedPool& pool = device_pool(ctx->device);
+    std::vector<void*> victims;
+    {
+        std::lock_guard<std::mutex> plock(pool.mu);
+        pool.limit_bytes = keep_bytes;
+        for (auto it = pool.parked.rbegin(); it != pool.parked.rend() && pool.cached_bytes > keep_bytes; ++it)
+            while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
+                victims.push_back(it->second.back());
+                it->second.pop_back();
+                pool.cached_bytes -= it->first;
+            }
+    }
+    for (void* v : victims) MA_HIP(hipFree(v));
     return MA_OK;
 }
 

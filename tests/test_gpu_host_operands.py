@@ -279,3 +279,27 @@ def test_pinned_allocator_recycles_large_blocks(ctx):
     ffi.check(lib.ma_alloc64_pinned(1000, C.byref(small)))
     ffi.check(lib.ma_free_pinned(small.value))
     ffi.check(lib.ma_pinned_pool_trim(2 << 30))
+
+
+def test_device_blocks_are_recycled(ctx):
+    """ma_dev_free parks blocks of 1 MiB and more per device (hipFree would stall every stream of the device);
+    ma_dev_alloc hands them out again; ma_dev_pool_trim releases them."""
+    import ctypes as C
+
+    lib = ctx.lib
+    ffi.check(lib.ma_dev_pool_trim(ctx.handle, 16 << 30))
+    a = ctx.alloc((8 << 20) + 3)
+    first = a.ptr
+    a.upload(np.arange(1 << 20, dtype=np.int64))
+    a.free()
+    b = ctx.alloc((8 << 20) + 1000)  # same 9-MiB size step
+    assert b.ptr == first
+    b.upload(np.arange(1 << 20, dtype=np.int64)[::-1].copy())
+    assert ctx.sum("i64", b, 1 << 20) == ((1 << 20) * ((1 << 20) - 1) // 2, 1 << 20)
+    b.free()
+    ffi.check(lib.ma_dev_pool_trim(ctx.handle, 0))
+    c = ctx.alloc((8 << 20) + 1000)
+    c.free()  # limit 0: released, not parked
+    ffi.check(lib.ma_dev_pool_trim(ctx.handle, 16 << 30))
+    small = ctx.alloc(4096)
+    small.free()
