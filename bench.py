@@ -11,8 +11,13 @@ integer adds, error-free two-sum for the double-double pairs, so the f64 result 
 holds bit-identical finals).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            # ONE process drives N GPUs through ma_group_* (RCCL exchange, no torch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W   # one process per GPU, ma_comm_* (RCCL) for the exchange
+
+At N = 1 the line also carries `other_configs` (BASELINE configs 3, 4, 5 at 10^9 rows: per-kernel ms / GB/s / fraction of
+peak / fraction of the same-process copy rate / parity), measured after and outside the timed headline region, and
+`cpu_baseline`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -112,7 +117,11 @@ def cpu_baseline(rows: int, budget_s: float):
     return {
         "value": results[best_threads]["value"],
         "unit": "Grows/s",
-        "cores": best_threads,
+        # cores = CPUs' worth of time the pool can actually burn: the container's cgroup quota caps a larger pool
+        "cores": min(best_threads, quota) if quota else best_threads,
+        "pool_threads": best_threads,
+        "cgroup_cpu_quota": quota,
+        "host_threads_visible": visible,
         "kind": "port",
         "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, persistent "
                   f"pool of {best_threads} threads (tried {candidates}; {visible} host threads visible, cgroup CPU quota "
@@ -177,49 +186,366 @@ def cpu_other_configs(oracle, np):
     return res
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU per column")
-    ap.add_argument("--cpu-rows", type=int, default=1 << 29, help="rows of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
-                         "GPU(s) and the 64-byte records cross host memory; never a reported number")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run each step's scalar exchange on a side stream, overlapped with the next step's scans (off by "
-                         "default: at N = 1 the concurrent copy + fold cost the scan more than they save, 876 vs 889 Grows/s)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
-    args = ap.parse_args()
+def _timed(ctx, fn, reps, warm=2):
+    """Mean milliseconds per call of `fn` (enqueue-only calls on ctx's stream), HIP events on that stream."""
+    for _ in range(warm):
+        fn()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    ctx.timer_stop()
+    return ctx.timer_elapsed_ms() / reps
 
-    # The contract is ONE JSON line on stdout. RCCL prints a version banner and gloo its connection messages to the
-    # process's stdout (fd 1) from native code, on every rank, and torch.distributed.run merges all ranks' stdout: keep
-    # the real stdout aside for the result line and point fd 1 at stderr for everything else.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
 
+def gpu_other_configs(ctx, n: int, reps: int):
+    """BASELINE configs 3, 4 and 5 at `n` rows on ONE MI355X, after and outside the timed headline region: per kernel
+    {ms, gbps, frac_of_peak, frac_of_copy, parity}. Algorithmic bytes per row are SURVEY.md §8(d)'s. Parity here is by
+    closed forms of the synthetic inputs, numpy on downloaded windows, and partition identities (the CPU oracle stays
+    with the test-suite and the cpu_baseline leg). `frac_of_copy` divides by the best same-process copy rate
+    (this library's 16-byte load->store kernel, and the runtime's hipMemcpyAsync) so that box-to-box spread of the
+    read+write mix does not hide in the fraction of the 8 TB/s spec."""
+    import numpy as np
+
+    from minarrow_amd.parallel import row_chunks
+
+    M64 = (1 << 64) - 1
+    res = {}
+
+    def entry(ms, bytes_per_row, rows, parity=None, **extra):
+        gbps = bytes_per_row * rows / ms / 1e6
+        e = {"ms": ms, "gbps": gbps, "grows_per_s": rows / ms / 1e6, "bytes_per_row": bytes_per_row,
+             "frac_of_peak": gbps / HBM_PEAK_GBPS}
+        if parity is not None:
+            e["parity"] = bool(parity)
+        e.update(extra)
+        return e
+
+    a, b, o = (ctx.alloc(n * 8) for _ in range(3))
+    mask_bytes = ((n + 511) // 512) * 64 + 64
+    mask, om = ctx.alloc(mask_bytes), ctx.alloc(mask_bytes)
+    slot = ctx.alloc(256)
+    ctx.synth_iota("f64", a, n, 0)
+    ctx.apply_scalar("f64", "lhs", a, n, float(n), 1, b)  # b[i] = n - i (SURVEY.md §8(d) C3)
+
+    # ---- the same-process reference: a plain copy (8 B read + 8 B written per row) ------------------------------
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.consolidate_column(8, [a], [n], o), reps)
+    res["copy_kernel_16B_per_lane"] = entry(ms, 16, n)
+    ms = _timed(ctx, lambda: ctx.dev_copy(o, a, n * 8), reps)
+    res["copy_hipMemcpyDtoD"] = entry(ms, 16, n)
+    copy_gbps = max(res["copy_kernel_16B_per_lane"]["gbps"], res["copy_hipMemcpyDtoD"]["gbps"])
+
+    # ---- config 3: f64 add / mul, array (+) array and array (+) scalar (fused broadcast) ---------------------------
+    def windows_equal(buf, fn, starts, count=4096):
+        ok = True
+        for s0 in starts:
+            i = np.arange(s0, s0 + count, dtype=np.float64)
+            ok = ok and bool(np.array_equal(buf.download(np.float64, count, s0 * 8), fn(i)))
+        return ok
+
+    starts = (0, n // 2, n - 4096)
+    fn_n = float(n)
+    tri = n * (n - 1) // 2
+    c3 = {}
+    ms = _timed(ctx, lambda: ctx.apply("f64", a, b, OPS["add"], o, n, n), reps)
+    ctx.set_async(False)
+    s, c = ctx.sum("f64", o, n)  # a + b == n everywhere: the sum is n^2, exact
+    ok = c == n and s == fn_n * fn_n and windows_equal(o, lambda i: i + (fn_n - i), starts)
+    c3["add_array_array"] = entry(ms, 24, n, ok)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.apply("f64", a, b, OPS["multiply"], o, n, n), reps)
+    ctx.set_async(False)
+    s, c = ctx.sum("f64", o, n)
+    exact = (n ** 3 - n) // 6  # sum of i * (n - i); each product is rounded once, so the sum is within n * 2^-53 relative
+    ok = c == n and abs(s - exact) <= abs(exact) * 2.0 ** -50 and windows_equal(o, lambda i: i * (fn_n - i), starts)
+    c3["multiply_array_array"] = entry(ms, 24, n, ok)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.apply_scalar("f64", "rhs", a, n, 2.5, OPS["add"], o), reps)
+    ctx.set_async(False)
+    s, c = ctx.sum("f64", o, n)
+    exact = tri + 2.5 * n  # every i + 2.5 is exact
+    ok = c == n and abs(s - exact) <= math.ulp(exact) and windows_equal(o, lambda i: i + 2.5, starts)
+    c3["add_array_scalar"] = entry(ms, 16, n, ok)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.apply_scalar("f64", "rhs", a, n, 2.5, OPS["multiply"], o), reps)
+    ctx.set_async(False)
+    s, c = ctx.sum("f64", o, n)
+    exact = 2.5 * tri  # every i * 2.5 is exact
+    ok = c == n and abs(s - exact) <= math.ulp(exact) and windows_equal(o, lambda i: i * 2.5, starts)
+    c3["multiply_array_scalar"] = entry(ms, 16, n, ok)
+    res["config3_f64_elementwise"] = c3
+
+    # ---- extras named by the round-1 review: FMA, masked add, bitmap AND ------------------------------------------
+    ex = {}
+    acc = ctx.alloc(n * 8)
+    ctx.synth_iota("f64", acc, n, 3)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.apply_fma("f64", a, b, acc, o, n, n, n), reps)
+    ctx.set_async(False)
+    ok = True
+    for s0 in starts:  # fused: ONE rounding of the exact i * (n - i) + (i + 3) — Python's int -> float is correctly rounded
+        want = np.array([float(i * (n - i) + i + 3) for i in range(s0, s0 + 1024)])
+        ok = ok and bool(np.array_equal(o.download(np.float64, 1024, s0 * 8), want))
+    ex["fma_f64"] = entry(ms, 32, n, ok)
+    acc.free()
+    ctx.synth_validity(mask, n, seed=0xC0FFEE, null_every=10)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.apply("f64", a, b, OPS["add"], o, n, n, mask=mask, out_mask=om), reps)
+    ctx.set_async(False)
+    s, c = ctx.sum("f64", o, n, mask=om)
+    pop = ctx.popcount_mask(mask, 0, n)
+    ok = c == pop and s == fn_n * pop and \
+        bool(np.array_equal(om.download(np.uint8, 4096), mask.download(np.uint8, 4096)))
+    ex["add_f64_masked"] = entry(ms, 24.25, n, ok)
+    bits = 8 * n * 8  # an 8-GB buffer as a 64-Gbit bitmap
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.mask_words_op("and_masks", a, 0, b, 0, bits, o), reps)
+    ctx.set_async(False)
+    wa, wb, wo = (x.download(np.uint64, 4096, (n // 2) * 8) for x in (a, b, o))
+    ex["and_masks_64Gbit"] = entry(ms, 24, n, bool(np.array_equal(wa & wb, wo)), note="bytes_per_row counts 8-byte words")
+    res["extras"] = ex
+
+    # ---- config 4: i64 sum with 10 % nulls via Bitmask -----------------------------------------------------------
+    ctx.synth_iota("i64", a, n, 0)
+    ctx.set_async(True)
+    ms = _timed(ctx, lambda: ctx.sum_into("i64", a, n, out_sum=slot.ptr, out_count=slot.ptr + 8, mask=mask), reps)
+    ctx.set_async(False)
+    whole, cnt = ctx.sum("i64", a, n, mask=mask)
+    part_s, part_c = 0, 0
+    for lo, hi in row_chunks(n, 8):  # the 8-way row-chunk partition of the multi-GPU config: checksum of checksums
+        ps, pc = ctx.sum("i64", a.offset(lo * 8), hi - lo, mask=mask, mask_bit_offset=lo)
+        part_s, part_c = (part_s + ps) & M64, part_c + pc
+    w0, wn = (n // 2 // 64) * 64 + 192, 1 << 20
+    wd = a.download(np.int64, wn, w0 * 8)
+    wm = np.unpackbits(mask.download(np.uint8, wn // 8, w0 // 8), bitorder="little").astype(bool)
+    ws, wc = ctx.sum("i64", a.offset(w0 * 8), wn, mask=mask, mask_bit_offset=w0)
+    ok = part_s == (whole & M64) and part_c == cnt == pop and ws == int(wd[wm].sum()) and wc == int(wm.sum())
+    res["config4_i64_sum_10pct_nulls"] = entry(ms, 8.125, n, ok, sum_valid=whole, valid_count=cnt, null_fraction=1 - cnt / n)
+
+    # ---- config 5: SuperTable of 8 batches, consolidate + per-column reduce ---------------------------------------
+    k = 8
+    rows = n // k
+    total = rows * k
+    mstride = ((rows + 511) // 512) * 64
+    chunk_masks = ctx.alloc(k * mstride + 64)
+    recs = ctx.alloc(k * 64)
+    fin = ctx.alloc(64)
+    ctx.dev_memset(recs, 0, k * 64)
+    c5 = {}
+    for tag in ("i64", "f64"):
+        chunks = [a.offset(c * rows * 8) for c in range(k)]
+        masks = [chunk_masks.offset(c * mstride) for c in range(k)]
+        for c in range(k):
+            ctx.synth_iota(tag, chunks[c], rows, c)  # v[i] = i + batch (benches/consolidate.rs:37-58 pattern)
+            ctx.synth_validity(masks[c], rows, seed=0xABC + c, null_every=10)
+        ctx.set_async(True)
+
+        def reduce_logical():  # per-batch sums into records + the batch-ordered fold: no column bytes move
+            for c in range(k):
+                r = recs.ptr + 64 * c
+                if tag == "i64":
+                    ctx.sum_into(tag, chunks[c], rows, out_sum=r, out_count=r + 8, mask=masks[c])
+                else:
+                    ctx.sum_into(tag, chunks[c], rows, out_sum=r + 16, dd_lo=r + 24, out_count=r + 32, mask=masks[c])
+            ctx.fold_sum_records(recs.ptr, k, 8, fin.ptr)
+
+        ms_red = _timed(ctx, reduce_logical, reps)
+        ms_con = _timed(ctx, lambda: ctx.consolidate_column(8, chunks, [rows] * k, o, masks, [0] * k, om), max(2, reps // 2), 1)
+        ms_phys = _timed(ctx, lambda: ctx.sum_into(tag, o, total, out_sum=slot.ptr, out_count=slot.ptr + 8, mask=om), reps)
+        ctx.set_async(False)
+        ctx.synchronize()
+        f = fin.download(np.uint64, 4)
+        phys_s, phys_c = ctx.sum(tag, o, total, mask=om)
+        if tag == "i64":
+            same = int(f[0]) == (phys_s & M64) and int(f[1]) == phys_c
+        else:
+            log_s = float(f[2:3].view(np.float64)[0])
+            same = int(f[3]) == phys_c and abs(log_s - phys_s) <= 2 * math.ulp(phys_s)
+        seam = rows - 2048  # a window across the join of batches 0 and 1 must equal the source bytes
+        got = o.download(np.uint64, 4096, seam * 8)
+        want = np.concatenate([a.download(np.uint64, 2048, seam * 8), a.download(np.uint64, 2048, rows * 8)])
+        gm = om.download(np.uint8, 512, seam // 8)
+        wmk = np.concatenate([chunk_masks.download(np.uint8, 256, seam // 8), chunk_masks.download(np.uint8, 256, mstride)])
+        same = same and bool(np.array_equal(got, want)) and (rows % 8 != 0 or bool(np.array_equal(gm, wmk)))
+        c5[tag] = {"reduce_per_batch": entry(ms_red, 8.125, total, same),
+                   "consolidate": entry(ms_con, 16.25, total, same),
+                   "reduce_consolidated": entry(ms_phys, 8.125, total, same)}
+    res["config5_supertable_8_batches"] = {"batches": k, "rows_per_batch": rows, **c5}
+
+    def add_frac(d):
+        for v in d.values():
+            if isinstance(v, dict):
+                if "gbps" in v and v.get("bytes_per_row", 0) > 8.2:  # read+write kernels only
+                    v["frac_of_copy"] = v["gbps"] / copy_gbps
+                add_frac(v)
+
+    add_frac(res)
+    res["rows"] = n
+    res["copy_reference_gbps"] = copy_gbps
+    for buf in (a, b, o, mask, om, slot, chunk_masks, recs, fin):
+        buf.free()
+    return res
+
+
+def _emit(result_fd, out):
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+
+
+def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallelism, exchange, extra_config=None):
+    rows = args.rows
+    got_i, cnt_i, got_f, cnt_f = finals
+    total_rows = rows * world
+    exact_f = float(total_rows * (total_rows - 1) // 2)
+    avg_i, avg_f = kernels["sum_i64"]["avg_ms"], kernels["sum_f64"]["avg_ms"]
+    bytes_per_launch = rows * 8  # algorithmic: 8 B/row (SURVEY.md §8(d)), one launch scans `rows` rows
+    dom_name, dom_ms = ("ma::sum_kernel<double>", avg_f) if avg_f >= avg_i else ("ma::sum_kernel<int64>", avg_i)
+    achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        try:
+            key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
+            traffic = json.loads(pmc.read_text()).get(key)
+        except Exception:
+            traffic = None
+    for kname, kk in kernels.items():
+        kk["gbps"] = bytes_per_launch / (kk["avg_ms"] * 1e-3) / 1e9
+        kk["grows_per_s"] = rows / (kk["avg_ms"] * 1e-3) / 1e9
+    config = {
+        "workload": f"{rows}-row IntegerArray<i64> sum + {rows}-row FloatArray<f64> sum per GPU, null-free, "
+                    f"HBM-resident (BASELINE configs[1])",
+        "rows_per_gpu_per_column": rows,
+        "columns": ["i64", "f64"],
+        "parallelism": parallelism,
+        "exchange": exchange,
+        "variant": args.variant,
+        "blocks_per_cu": args.blocks_per_cu or "auto",
+    }
+    config.update(extra_config or {})
+    return {
+        "metric": "Grows/sec + achieved HBM GB/s, 1B-row i64/f64 sum",
+        "value": value_rows / elapsed / 1e9,
+        "unit": "Grows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "i64+f64",
+        "data": "synthetic",
+        "config": config,
+        "hbm_gbps": value_rows * 8 / elapsed / 1e9,
+        "parity_ok": bool(ok),
+        # avg = sum / valid count from the same scan (the reference has no mean kernel; its "avg" benches average
+        # timings): derived here from the job's finals; the wrapping i64 total only means something while it fits
+        "result": {"i64_sum": got_i, "f64_sum": got_f, "f64_ulps_from_exact": abs(got_f - exact_f) / math.ulp(exact_f),
+                   "rows": cnt_i, "i64_avg": (got_i / cnt_i) if exact_f < 2.0 ** 63 and cnt_i else None,
+                   "f64_avg": (got_f / cnt_f) if cnt_f else None},
+        "kernels": kernels,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dom_name,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this "
+                              "command (tools/collect_profiles.sh), FETCH_SIZE doubled per the gfx950 correction"
+                              if traffic is not None else None,
+        },
+    }
+
+
+def _check(total_rows, finals):
+    got_i, cnt_i, got_f, cnt_f = finals
+    expect = total_rows * (total_rows - 1) // 2
+    exact_f = float(expect)
+    return (got_i & ((1 << 64) - 1)) == (expect & ((1 << 64) - 1)) and cnt_i == total_rows and cnt_f == total_rows \
+        and abs(got_f - exact_f) <= math.ulp(exact_f)
+
+
+def run_group(args, result_fd) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher: ONE process drives the N GPUs through the C ABI's group
+    API (one context per device, enqueue-only scans, one grouped RCCL all-gather + device fold per step) — the shape a
+    Rust host takes. No torch: device memory comes from ma_dev_alloc on each member's context."""
+    from minarrow_amd import ffi
+    from minarrow_amd.host import Group
+
+    n_dev = ffi.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    rows, world = args.rows, args.gpus
+    group = Group(list(range(world)), exchange="host" if args.exchange == "host" else "rccl-or-host")
+    ctxs = [group.member_ctx(i) for i in range(world)]
+    for c in ctxs:
+        c.set_variant(args.variant)
+        c.set_blocks_per_cu(args.blocks_per_cu)
+    cols_i = [c.alloc(rows * 8) for c in ctxs]
+    cols_f = [c.alloc(rows * 8) for c in ctxs]
+    for r, c in enumerate(ctxs):  # member r owns global rows [r*rows, (r+1)*rows); generation is enqueue-only too
+        c.synth_iota("i64", cols_i[r], rows, r * rows)
+        c.synth_iota("f64", cols_f[r], rows, r * rows)
+    lens = [rows] * world
+
+    def step():
+        group.enqueue_sum("i64", 0, cols_i, lens)
+        group.enqueue_sum("f64", 0, cols_f, lens)
+        group.exchange()
+
+    step()  # set-up, never timed: first use of the communicator and of the fold kernel
+    group.synchronize()
+    for _ in range(args.warmup):
+        step()
+    group.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    group.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    finals = group.result(0)
+    total_rows = rows * world
+    ok = _check(total_rows, finals) and all(group.result(0, m) == finals for m in range(world))
+    # Kernel durations (outside the timed region): HIP events on member 0's stream around 5 launches of each scan.
+    c0 = ctxs[0]
+    slot = c0.alloc(64)
+    kernels = {}
+    for name, tag, col in (("sum_i64", "i64", cols_i[0]), ("sum_f64", "f64", cols_f[0])):
+        fn = (lambda: c0.sum_into("i64", col, rows, out_sum=slot.ptr, out_count=slot.ptr + 8)) if tag == "i64" else \
+            (lambda: c0.sum_into("f64", col, rows, out_sum=slot.ptr, dd_lo=slot.ptr + 8, out_count=slot.ptr + 16))
+        ms = _timed(c0, fn, 5, 1)
+        kernels[name] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
+    out = _result_line(args, world, total_rows * 2 * args.steps, elapsed, kernels, ok, finals,
+                       f"row-chunk x{world}, ONE process (ma_group_*)",
+                       ("RCCL all-gather (ncclCommInitAll, grouped) + device fold, on the scan streams"
+                        if group.exchange_kind == "rccl" else "host fold of pinned records") +
+                       (f" [{group.exchange_note}]" if group.exchange_note else ""),
+                       {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process"})
+    _emit(result_fd, out)
+    if not ok:
+        print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
+    for b in cols_i + cols_f + [slot]:
+        b.free()
+    group.close()
+    return 0 if ok else 1
+
+
+def run_ranks(args, result_fd) -> int:
+    """N = 1, or one process per GPU under torch.distributed.run."""
     import numpy as np
     import torch  # first: the library then shares torch's HIP runtime (same SONAME)
     import torch.distributed as dist
 
-    from minarrow_amd.host import Context
+    from minarrow_amd.host import Comm, Context
     from minarrow_amd.parallel import ScalarExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)",
-                  file=sys.stderr)
-            return 2
     distributed = world > 1 or args.force_dist
     rehearsal = args.backend == "gloo"
     device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
@@ -247,18 +573,35 @@ def main() -> int:
     col_f = torch.empty(rows, dtype=torch.float64, device=dev)
     ctx.synth_iota("i64", col_i, rows, rank * rows)
     ctx.synth_iota("f64", col_f, rows, rank * rows)
-    # Per-rank record the kernels write into and RCCL all-gathers: [0] i64 sum, [1] i64 count,
-    # [2] f64 hi bits, [3] f64 lo bits, [4] f64 count (minarrow_amd/parallel.py).
-    # --overlap: the exchange + fold of step k run on a side stream while the main stream already scans step k + 1;
-    # two records alternate, and a record is reused only after its exchange (two steps back) has completed. Every
-    # step's exchange and fold still happen inside the timed region — the closing fence drains both streams.
-    overlap = args.overlap
+
+    # The exchange. Native: the library's own RCCL communicator (ma_comm_*: ncclCommInitRank from an id rank 0 made and
+    # torch.distributed's store carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up
+    # on every rank (or --exchange torch) the same records go through torch.distributed's all-gather instead.
+    comm, comm_note = None, ""
+    if distributed and not rehearsal and args.exchange != "torch":
+        try:
+            ids = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = Comm(ctx, ids[0], rank, world)
+        except Exception as e:  # noqa: BLE001 — any failure means the torch path
+            comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            comm_note = "native communicator unavailable on another rank"
+
+    # Per-rank record the kernels write into: [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits,
+    # [4] f64 count (minarrow_amd/parallel.py). --overlap: the exchange + fold of step k run on a side stream while
+    # the main stream already scans step k + 1 (torch exchange only).
+    overlap = args.overlap and comm is None
     side = torch.cuda.Stream(dev) if overlap else stream
     ctx_side = Context(device_index, stream=side.cuda_stream) if overlap else ctx
     ctx_side.set_async(True)
     exs = [ScalarExchange(dev) for _ in range(2 if overlap else 1)]
-    scanned = [torch.cuda.Event() for _ in exs]    # main stream: the record of this buffer is written
-    exchanged = [torch.cuda.Event() for _ in exs]  # side stream: its exchange + fold are done
+    scanned = [torch.cuda.Event() for _ in exs]
+    exchanged = [torch.cuda.Event() for _ in exs]
     in_use = [False for _ in exs]
     ctx.set_async(True)
     counter = [0]
@@ -277,17 +620,20 @@ def main() -> int:
         ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if ev:
             ev[2].record(stream)
-        if overlap:
+        if comm is not None:
+            comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
+            ex._folded_on_device = True
+        elif overlap:
             scanned[k].record(stream)
             with torch.cuda.stream(side):
                 side.wait_event(scanned[k])
-                ex.exchange()  # N > 1: one RCCL all-gather of 64 bytes per rank; N = 1: nothing to exchange
-                ex.fold_on_device(ctx_side)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
+                ex.exchange()
+                ex.fold_on_device(ctx_side)
                 exchanged[k].record(side)
             in_use[k] = True
         else:
-            ex.exchange()
-            ex.fold_on_device(ctx)
+            ex.exchange()  # N > 1: one all-gather of 64 bytes per rank; N = 1: nothing to exchange
+            ex.fold_on_device(ctx)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
 
     def fence():
         if distributed:
@@ -315,95 +661,117 @@ def main() -> int:
 
     # ---- verify the job's answer (outside the timed region) ------------------------------------------
     total_rows = rows * world
-    expect = total_rows * (total_rows - 1) // 2
-    got_i, cnt_i, got_f, cnt_f = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
-    exact_f = float(expect)
-    ok = (got_i == expect & ((1 << 64) - 1)) and cnt_i == total_rows and cnt_f == total_rows \
-        and abs(got_f - exact_f) <= math.ulp(exact_f)
-
+    finals = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
+    ok = _check(total_rows, finals)
     ms_i = [e[0].elapsed_time(e[1]) for e in events]
     ms_f = [e[1].elapsed_time(e[2]) for e in events]
-    avg_i, avg_f = sum(ms_i) / len(ms_i), sum(ms_f) / len(ms_f)
-    bytes_per_launch = rows * 8  # algorithmic: 8 B/row, one launch scans `rows` rows
-    dom_name, dom_ms = ("ma::sum_kernel<double>", avg_f) if avg_f >= avg_i else ("ma::sum_kernel<int64>", avg_i)
-    achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
+    kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i)},
+               "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f)}}
 
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc.exists():
-        try:
-            key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
-            traffic = json.loads(pmc.read_text()).get(key)
-        except Exception:
-            traffic = None
-
+    rc = 0 if ok else 1
     if rank == 0:
-        value = total_rows * 2 * args.steps / elapsed / 1e9
-        out = {
-            "metric": "Grows/sec + achieved HBM GB/s, 1B-row i64/f64 sum",
-            "value": value,
-            "unit": "Grows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "i64+f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{rows}-row IntegerArray<i64> sum + {rows}-row FloatArray<f64> sum per GPU, null-free, "
-                            f"HBM-resident (BASELINE configs[1])",
-                "rows_per_gpu_per_column": rows,
-                "columns": ["i64", "f64"],
-                "parallelism": f"row-chunk x{world}" + ((" + gloo all-gather of scalars (REHEARSAL: ranks share a GPU)" if rehearsal
-                                                          else " + RCCL all-gather of scalars") if distributed else ""),
-                "exchange": "side stream, overlapped with the next step's scans" if overlap else "scan stream",
-                "variant": args.variant,
-                "blocks_per_cu": args.blocks_per_cu or "auto",
-            },
-            "hbm_gbps": total_rows * 2 * 8 * args.steps / elapsed / 1e9,
-            "parity_ok": bool(ok),
-            # avg = sum / valid count from the same scan (the reference has no mean kernel; its "avg" benches average
-            # timings): derived here from the job's finals; the wrapping i64 total only means something while it fits
-            "result": {"i64_sum": got_i, "f64_sum": got_f, "f64_ulps_from_exact": abs(got_f - exact_f) / math.ulp(exact_f),
-                       "rows": cnt_i, "i64_avg": (got_i / cnt_i) if expect < (1 << 63) and cnt_i else None,
-                       "f64_avg": (got_f / cnt_f) if cnt_f else None},
-            "kernels": {
-                "sum_i64": {"avg_ms": avg_i, "min_ms": min(ms_i), "gbps": bytes_per_launch / (avg_i * 1e-3) / 1e9,
-                            "grows_per_s": rows / (avg_i * 1e-3) / 1e9},
-                "sum_f64": {"avg_ms": avg_f, "min_ms": min(ms_f), "gbps": bytes_per_launch / (avg_f * 1e-3) / 1e9,
-                            "grows_per_s": rows / (avg_f * 1e-3) / 1e9},
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom_name,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this "
-                                  "command (tools/collect_profiles.sh), FETCH_SIZE doubled per the gfx950 correction"
-                                  if traffic is not None else None,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
+        if not distributed:
+            parallelism, exchange = "row-chunk x1", "none (one GPU): device fold on the scan stream"
+        elif rehearsal:
+            parallelism = f"row-chunk x{world}, one process per rank (REHEARSAL: ranks share a GPU)"
+            exchange = "gloo all-gather of the records over host memory + device fold"
+        else:
+            parallelism = f"row-chunk x{world}, one process per GPU"
+            exchange = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold, on the scan stream"
+                        if comm is not None else
+                        "RCCL all-gather (torch.distributed) + device fold, " +
+                        ("side stream, overlapped with the next step's scans" if overlap else "on the scan stream"))
+            if comm_note:
+                exchange += f" [{comm_note}]"
+        out = _result_line(args, world, total_rows * 2 * args.steps, elapsed, kernels, ok, finals, parallelism, exchange,
+                           {"rccl_ranks": world if (distributed and not rehearsal) else 0,
+                            "launch": "torch.distributed.run" if world > 1 else "single process"})
+        if world == 1:
             del col_i, col_f
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+            if not args.no_other_configs:
+                try:
+                    ctx.set_async(False)
+                    out["other_configs"] = gpu_other_configs(ctx, args.other_rows or rows, args.other_reps)
+                    parities = [v for v in _walk(out["other_configs"], "parity")]
+                    out["other_configs"]["parity_ok"] = all(parities)
+                    if not all(parities):
+                        rc = 1
+                except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+                    out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+                    rc = 1
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
+        _emit(result_fd, out)
         if not ok:
-            print(f"PARITY FAILURE: i64 {got_i} vs {expect}, f64 {got_f} vs {exact_f}", file=sys.stderr)
+            print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
 
+    if comm is not None:
+        comm.close()
     if ctx_side is not ctx:
         ctx_side.close()
     ctx.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    return 0 if ok else 1
+    return rc
+
+
+def _walk(d, key):
+    for k, v in d.items():
+        if k == key:
+            yield v
+        elif isinstance(v, dict):
+            yield from _walk(v, key)
+
+
+OPS = {"add": 0, "subtract": 1, "multiply": 2}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU per column")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 29, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3-5 (N = 1 only)")
+    ap.add_argument("--other-rows", type=int, default=0, help="rows of the configs 3-5 leg (default: --rows)")
+    ap.add_argument("--other-reps", type=int, default=10)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--exchange", default="native", choices=["native", "torch", "host"],
+                    help="native = RCCL inside libminarrow_hip (ma_group_* in one process, ma_comm_* under a launcher); torch = "
+                         "torch.distributed's all-gather (launcher mode); host = host fold of pinned records (one process)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
+                         "GPU(s) and the 64-byte records cross host memory; never a reported number")
+    ap.add_argument("--overlap", action="store_true",
+                    help="torch exchange only: run each step's scalar exchange on a side stream, overlapped with the next "
+                         "step's scans (off by default: at N = 1 it costs the scan more than it saves, 876 vs 889 Grows/s)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
+    ap.add_argument("--force-group", action="store_true",
+                    help="take the one-process group path even with --gpus 1 (exercises ncclCommInitAll on a 1-GPU box)")
+    args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout. RCCL prints a version banner and gloo its connection messages to the
+    # process's stdout (fd 1) from native code, on every rank, and torch.distributed.run merges all ranks' stdout: keep
+    # the real stdout aside for the result line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes here
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and world != args.gpus:
+        print(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if (world == 1 and args.gpus > 1) or args.force_group:
+        return run_group(args, result_fd)
+    return run_ranks(args, result_fd)
 
 
 if __name__ == "__main__":

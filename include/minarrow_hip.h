@@ -22,8 +22,16 @@
  *  - Synchronous by default: a call returns after its result is available to the host. With
  *    ma_ctx_set_async(ctx,1) calls only enqueue work on the context's stream; scalar outputs must then be
  *    device-reachable memory and errors detected on the device are reported by ma_ctx_synchronize().
- *  - Thread safety: a ctx may be shared between host threads (calls serialise on an internal lock);
- *    independent ctxs are fully independent. No hidden global scratch.
+ *  - Thread safety: a ctx may be shared between host threads (the reference's kernels are re-entrant,
+ *    src/kernels/arithmetic/mod.rs:29-31). A synchronous call that finds the context busy in another thread runs on
+ *    one of the context's internal lanes (own stream + reduction scratch, up to MINARROW_HIP_LANES = 4 per context,
+ *    created on demand), so threads overlap instead of queueing behind each other's wait. Calls in async mode, during
+ *    capture, or on a caller-owned stream (ma_ctx_create_on_stream) serialise on the context's one stream — ordering
+ *    is the contract there. Independent ctxs are fully independent. No hidden global scratch.
+ *  - Environment (read once): MINARROW_HIP_DEVICES ("2,3": the library's ordinal i is HIP device
+ *    list[i]), MINARROW_HIP_MIN_ROWS (ma_min_device_rows), MINARROW_HIP_STAGING_TILE (bytes, ma_ctx_set_staging_tile's
+ *    default), MINARROW_HIP_LANES, MINARROW_HIP_GROUP_EXCHANGE ("rccl"), MINARROW_HIP_PINNED_POOL_BYTES,
+ *    MINARROW_HIP_DEV_POOL_BYTES (block-cache limits).
  *
  * Status codes mirror KernelError (src/enums/error.rs:157-187) as far as the numeric kernels can raise them.
  */
@@ -72,8 +80,13 @@ enum { MA_LOGICAL_AND = 0, MA_LOGICAL_OR = 1, MA_LOGICAL_XOR = 2 };
  * ---------------------------------------------------------------------------------------------- */
 
 int32_t ma_abi_version(void);
-/* Number of visible HIP devices (0 when there is none; never initialises a device context). */
+/* Number of devices the library may use: the visible HIP devices, or the entries of MINARROW_HIP_DEVICES (0 when there
+ * is none; never initialises a device context). Device ordinals of this ABI index that list. */
 int32_t ma_device_count(void);
+/* Column length below which a host wrapper should keep the reference's CPU kernels (MINARROW_HIP_MIN_ROWS, default
+ * 65536): a synchronous GPU call costs ~17 us whatever the size, the reference's 1000-row scalar sum 85 ns
+ * (src/lib.rs:58). Advice for the host shim only — the library itself has no CPU path and accepts any length. */
+int64_t ma_min_device_rows(void);
 /* Thread-local description of the last non-OK status returned on this thread. Never NULL. */
 const char* ma_last_error_string(void);
 const char* ma_status_name(ma_status s);
@@ -123,9 +136,14 @@ ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
  * built on raw hipHostMalloc would be 50x slower than malloc for large columns): ma_free_pinned parks them,
  * ma_alloc64_pinned reuses them. ma_pinned_pool_trim(keep) releases cached blocks down to `keep` bytes and makes that the
  * new cache limit (default 2 GiB; 0 = no caching). Thread safe. */
+/* Contract of ma_free_pinned (and ma_dev_free): every piece of work that touches the block — kernels an ASYNC context
+ * still has in flight, copies on other streams — must have completed first; a parked block is handed out again at
+ * once, where hipHostFree used to wait. Freeing a block twice is refused (MA_ERR_INVALID_ARGUMENT).
+ * ma_pinned_pool_set_limit changes the cache limit without releasing anything (undoes a trim's lowering). */
 ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr);
 ma_status ma_free_pinned(void* ptr);
 ma_status ma_pinned_pool_trim(size_t keep_bytes);
+ma_status ma_pinned_pool_set_limit(size_t limit_bytes);
 /* Pins an EXISTING host allocation in place (hipHostRegister, portable + mapped) — for a host that cannot change the
  * allocator of buffers it already owns: a Vec64<T> from the stock vec64 crate (Cargo.toml:54), a foreign buffer behind
  * SharedBuffer::from_owner (src/structs/shared_buffer/mod.rs:187-206), an mmap. From then on the range classifies as
@@ -143,9 +161,15 @@ ma_status ma_host_unregister(void* ptr);
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
 ma_status ma_dev_pool_trim(ma_ctx* ctx, size_t keep_bytes);
+/* Cache limit of the context's device without releasing anything. Every device allocation the library makes for
+ * itself (scratch, staging rings, context state) releases the parked blocks and retries when HBM is full. */
+ma_status ma_dev_pool_set_limit(ma_ctx* ctx, size_t limit_bytes);
 ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t bytes);
+/* Device-to-device copy by the runtime's copy path (hipMemcpyAsync on the context's stream; follows the sync / async
+ * mode). bench.py times it next to the read+write kernels as the same-process reference rate. */
+ma_status ma_dev_copy(ma_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 /* 0 = pageable host, 1 = pinned/registered host, 2 = device, 3 = managed. */
 int32_t ma_pointer_kind(const void* ptr);
 
@@ -707,24 +731,90 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
 /* ------------------------------------------------------------------------------------------------
  * Row-chunk reductions over several GPUs driven from ONE process — the reference's Rayon path
  * (`slice.par_chunks(1 << 20).map(simd_sum).sum()`, benches/benchmark_parallel_simd.rs:81-98) for a host such as the
- * Rust library itself. A group owns one context per listed device ordinal (an ordinal may repeat). Member i scans
- * chunk i (resident on, or reachable from, its device) concurrently with the others; the per-member
- * {sum | hi, lo, count} records are folded on the host in member order (wrapping add; double-double for floats,
- * so the f64 total stays within 1 ULP). Split rows with 64-row-aligned boundaries so that a chunk's validity
- * window starts on a word (any bit offset works, aligned ones are free). Between processes the same exchange is one
- * RCCL all-gather (bench.py, minarrow_amd/parallel.py).
+ * Rust library itself. A group owns one context per listed device ordinal. Member i scans chunk i (resident on, or
+ * reachable from, its device) concurrently with the others and writes {sum | hi, lo, count} into its 64-byte record of
+ * the reduction's `column` (0 .. MA_GROUP_MAX_COLUMNS-1: several reductions — the columns of a SuperTable, or an i64
+ * and an f64 column as in the reference's bench — share ONE exchange). Split rows with 64-row-aligned boundaries so
+ * that a chunk's validity window starts on a word (any bit offset works, aligned ones are free).
+ *
+ * The exchange that replaces Rayon's `.sum()` of the partials:
+ *   MA_GROUP_EXCHANGE_RCCL   ncclCommInitAll over the members' devices (which must be distinct); ma_group_exchange
+ *                            enqueues ONE grouped ncclAllGather of the members' record blocks over xGMI on the members'
+ *                            streams, then on every device the member-ordered fold (wrapping adds; error-free two-sum
+ *                            for the (hi, lo) pairs): all GPUs end up with bit-identical finals, the f64 total within
+ *                            1 ULP of the exactly rounded sum. This is an all-reduce; ncclAllReduce itself is not used
+ *                            for the float pairs because its sum rounds at every hop.
+ *   (default)                the kernels write their records into pinned host memory and the host folds the G x 64
+ *                            bytes in member order after the streams drain: no collective is needed inside one process.
+ *   MA_GROUP_EXCHANGE_FALLBACK_HOST  with MA_GROUP_EXCHANGE_RCCL: use the host fold when RCCL cannot be initialised
+ *                            (library missing, members sharing a device); ma_group_exchange_note() then says why.
+ * ma_group_create() = ma_group_create_ex() with flags 0, or RCCL|FALLBACK_HOST when the environment variable
+ * MINARROW_HIP_GROUP_EXCHANGE is "rccl". librccl.so.1 is opened on first use, never at library load.
+ *
+ * ma_group_enqueue_sum_* and ma_group_exchange only ENQUEUE (steps may be issued back to back without waiting; a
+ * later step overwrites the records of an earlier one in stream order); ma_group_synchronize waits for every member
+ * and makes ma_group_result valid: out_int_* from the *_i64 reduction of that column, out_f64_* from its *_f64 reduction
+ * (any may be NULL). ma_group_member_result reads the finals GPU `member` holds (identical on all members).
+ * ma_group_sum_i64 / _f64 are the synchronous one-call forms on column 0. The member contexts (ma_group_ctx: use them
+ * to allocate and fill each device's chunk) stay in async mode for the life of the group.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ma_group ma_group;
+#define MA_GROUP_MAX_COLUMNS 16
+enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2 };
 ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
+ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group);
 void ma_group_destroy(ma_group* group);
 int32_t ma_group_size(ma_group* group);
 ma_ctx* ma_group_ctx(ma_group* group, int32_t index);
+/* 1 = RCCL all-gather + device fold, 0 = host fold. */
+int32_t ma_group_exchange_kind(ma_group* group);
+const char* ma_group_exchange_note(ma_group* group);
+ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
+                                   const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                   const size_t* chunk_mask_offsets);
+ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double* const* chunk_data,
+                                   const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                   const size_t* chunk_mask_offsets);
+ma_status ma_group_exchange(ma_group* group);
+ma_status ma_group_synchronize(ma_group* group);
+ma_status ma_group_result(ma_group* group, int32_t column, int64_t* out_int_sum, uint64_t* out_int_count,
+                          double* out_f64_sum, uint64_t* out_f64_count);
+ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column, int64_t* out_int_sum,
+                                 uint64_t* out_int_count, double* out_f64_sum, uint64_t* out_f64_count);
 ma_status ma_group_sum_i64(ma_group* group, const int64_t* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, int64_t* out_sum,
                            uint64_t* out_valid_count);
 ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_sum,
                            uint64_t* out_valid_count);
+
+/* ------------------------------------------------------------------------------------------------
+ * The same exchange between PROCESSES (one process per GPU — e.g. one Rust worker per device, or ranks started by a
+ * launcher): an RCCL communicator bound to a context. Rank 0 calls ma_comm_unique_id and hands the 128 bytes to the
+ * other ranks by the host's own means (a file, a socket, MPI, torch.distributed's store); every rank then calls
+ * ma_comm_create (collective: it returns once all n_ranks ranks have joined). Collectives are enqueued on the
+ * context's stream and follow its sync / async mode; buffers must be device-reachable.
+ *   ma_comm_sum_exchange  local_records = slots_per_rank x n_columns records of 8 x u64 ([0] integer sum, [1] integer
+ *       valid count, [2] f64 hi bits, [3] f64 lo bits, [4] float valid count — what ma_<t>_sum / ma_<t>_sum_dd write when
+ *       pointed at them); ONE ncclAllGather into `gathered` (n_ranks x that), then column c is folded over (rank, slot)
+ *       in that order into out_finals[4c .. 4c+3] = [integer sum, integer count, f64 sum bits, float count] — the
+ *       job's finals, bit-identical on every rank (ma_fold_sum_records' rule). slots_per_rank > 1 serves a rank that
+ *       holds several batches of a SuperTable (src/structs/chunked/super_table.rs:78-83): the fold is in batch order.
+ *   ma_comm_all_gather / ma_comm_all_reduce_sum_i64  the bare collectives (wrapping integer sum).
+ * ma_rccl_version: ncclGetVersion's code (e.g. 22707), 0 when RCCL cannot be loaded.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ma_comm ma_comm;
+#define MA_COMM_ID_BYTES 128
+int32_t ma_rccl_version(void);
+ma_status ma_comm_unique_id(uint8_t* out_id);
+ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, ma_comm** out_comm);
+void ma_comm_destroy(ma_comm* comm);
+int32_t ma_comm_rank(ma_comm* comm);
+int32_t ma_comm_size(ma_comm* comm);
+ma_status ma_comm_all_gather(ma_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
+ma_status ma_comm_all_reduce_sum_i64(ma_comm* comm, const int64_t* send, int64_t* recv, size_t count);
+ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
+                               uint64_t* gathered, uint64_t* out_finals);
 
 #ifdef __cplusplus
 } /* extern "C" */

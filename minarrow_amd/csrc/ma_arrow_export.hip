@@ -145,7 +145,7 @@ ma_status plan_column(const ArrowArray* lhs, const ArrowSchema* ls, const ArrowA
 }
 
 // lhs[c] (op) rhs[c] for n_cols column pairs: ONE pinned slab, every kernel enqueued back to back (the context is
-// switched to async for the duration), ONE synchronise, then the owned ArrowArray / ArrowSchema pairs are filled in.
+// enqueue-only for the duration: ma::NoSync), ONE synchronise, then the owned ArrowArray / ArrowSchema pairs are filled in.
 // null_count follows create_arrow_export (arrow_c_ffi.rs:1750): 0 without a validity buffer, -1 (unknown) with one.
 ma_status export_columns(ma_ctx* ctx, int32_t op, size_t n_cols, const ArrowArray* const* lhs, const ArrowSchema* const* ls,
                          const ArrowArray* const* rhs, const ArrowSchema* const* rs, const char* const* names,
@@ -160,20 +160,21 @@ ma_status export_columns(ma_ctx* ctx, int32_t op, size_t n_cols, const ArrowArra
         delete slab;
         return st;
     }
-    bool was_async;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        was_async = ctx->async;
-    }
-    (void)ma_ctx_set_async(ctx, 1);
     std::vector<int32_t> has_validity(n_cols, 0);
-    for (size_t c = 0; c < n_cols && st == MA_OK; ++c)
-        st = ma_apply_arrow(ctx, op, lhs[c], ls[c], rhs[c], rs[c], (char*)slab->base + plan[c].values_off,
-                            (uint8_t*)slab->base + plan[c].validity_off, &has_validity[c]);
-    // everything enqueued so far must drain before the buffers are handed out (or freed); a dense integer division by
-    // zero recorded by any column surfaces here
-    ma_status sync = ma_ctx_synchronize(ctx);
-    (void)ma_ctx_set_async(ctx, was_async ? 1 : 0);
+    ma_status sync = MA_OK;
+    {
+        // One lane for the whole sequence (the per-column calls re-use it), enqueue-only without touching the context's
+        // user-visible mode: other threads sharing the context keep their synchronous semantics meanwhile.
+        MA_ENTER(ctx);
+        NoSync enqueue_only;
+        for (size_t c = 0; c < n_cols && st == MA_OK; ++c)
+            st = ma_apply_arrow(ctx, op, lhs[c], ls[c], rhs[c], rs[c], (char*)slab->base + plan[c].values_off,
+                                (uint8_t*)slab->base + plan[c].validity_off, &has_validity[c]);
+        // everything enqueued so far must drain before the buffers are handed out (or freed); a dense integer division
+        // by zero recorded by any column surfaces here
+        (void)hipSetDevice(ctx->device);
+        sync = sync_and_check(ctx);
+    }
     if (st == MA_OK) st = sync;
     if (st != MA_OK) {
         (void)ma_free_pinned(slab->base);

@@ -573,7 +573,7 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     MA_REQUIRE(aligned_elem(c.lhs) && aligned_elem(c.rhs) && aligned_elem(c.acc) && aligned_elem(c.out),
                MA_ERR_INVALID_ARGUMENT, "a data pointer is not aligned to its element size");
 
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     const bool int_div = kInt && !c.fma &&
                          (c.op == MA_OP_DIVIDE || c.op == MA_OP_REMAINDER || c.op == MA_OP_FLOORDIV);
@@ -635,9 +635,9 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     }
     MA_TRY(enqueue_binary<T>(ctx, a, c.fma, masked, true));
 
-    if (may_latch && (ctx->async && !scope.staged())) ctx->pending_flags = true;
+    if (may_latch && (is_async(ctx) && !scope.staged())) ctx->pending_flags = true;
     MA_TRY(end_call(ctx, scope));
-    if (may_latch && (!ctx->async || scope.staged())) return check_divide_latch(ctx, c.op);
+    if (may_latch && (!is_async(ctx) || scope.staged())) return check_divide_latch(ctx, c.op);
     return MA_OK;
 }
 

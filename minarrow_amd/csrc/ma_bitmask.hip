@@ -332,7 +332,7 @@ static ma_status words_op(ma_ctx* ctx, int op, const uint8_t* lhs, size_t lo, co
     MA_REQUIRE(!binary || rhs != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL rhs bitmap");
     lo -= lo % round;
     ro -= ro % round;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     BitArgs a{};
@@ -349,7 +349,7 @@ static ma_status words_op(ma_ctx* ctx, int op, const uint8_t* lhs, size_t lo, co
 
 static ma_status fill_bits(ma_ctx* ctx, uint8_t* out_bits, size_t len, bool value) {
     // Bitmask::new_set_all(len, value) — src/structs/bitmask.rs:94-105
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "a constant bitmap fill");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
@@ -367,7 +367,7 @@ static ma_status fill_bits(ma_ctx* ctx, uint8_t* out_bits, size_t len, bool valu
 
 static ma_status scan_op(ma_ctx* ctx, const uint8_t* lhs, size_t lo, const uint8_t* rhs, size_t ro, size_t len,
                          BitScan* out) {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     BitArgs a{};
@@ -529,7 +529,7 @@ ma_status ma_merge_bitmasks_to_new(ma_ctx* ctx, const uint8_t* lhs_bits, const u
         if (n == 0) return MA_OK;                                                                                \
         MA_REQUIRE(data != nullptr && out_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");               \
         MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "misaligned data pointer");       \
-        std::lock_guard<std::mutex> lock(ctx->mu);                                                               \
+        MA_ENTER(ctx);                                                               \
         MA_HIP(hipSetDevice(ctx->device));                                                                       \
         CallScope scope(ctx);                                                                                    \
         const void* d = nullptr;                                                                                 \

@@ -39,6 +39,8 @@ struct ResultSlot {
 };
 
 void set_error(const char* fmt, ...);
+// hipMalloc on `device` (already current) that releases the device's parked-block cache and retries once when HBM is full.
+hipError_t device_malloc(int device, void** out, size_t bytes);
 ma_status hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 }  // namespace ma
@@ -54,6 +56,9 @@ ma_status hip_fail(hipError_t e, const char* what, const char* file, int line);
         ma_status _s = (expr);            \
         if (_s != MA_OK) return _s;       \
     } while (0)
+
+#define MA_ENTER(ctx) ::ma::Enter _ma_enter(ctx)
+#define MA_ENTER_PRIMARY(ctx) ::ma::Enter _ma_enter(ctx, true)
 
 #define MA_REQUIRE(cond, status, ...)     \
     do {                                  \
@@ -87,6 +92,15 @@ struct ma_ctx {
     size_t scratch_bytes = 0;          //   (one user at a time: callers hold `mu` and order their use on `stream`)
     void* pipe = nullptr;              // staging ring of the tiled host-operand path (ma_pipeline.hip), made on first use
     size_t staging_tile_bytes = (size_t)32 << 20;  // bytes of one operand per tile; 0 = stage whole operands
+    // Lanes: a synchronous call holds its context for the whole call (enqueue + wait). So that host threads sharing
+    // one context do not serialise on that wait (the reference's kernels are re-entrant: src/kernels/arithmetic/mod.rs:
+    // 29-31), a call that finds the context busy runs on a LANE instead: an internal context of the same device with its
+    // own stream and reduction scratch, created on demand (ma::Enter, ma_ctx.hip). Only for synchronous calls on a
+    // context that owns its stream: async / capturing / borrowed-stream contexts promise ordering on ONE stream.
+    ma_ctx* parent = nullptr;          // set on a lane
+    std::vector<ma_ctx*> lanes;        // owned; guarded by lanes_mu
+    std::mutex lanes_mu;
+    int max_lanes = 4;                 // the context itself included (MINARROW_HIP_LANES)
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
@@ -96,6 +110,32 @@ struct ma_ctx {
 
 namespace ma {
 
+// Entry-point guard. `Enter e(ctx)` locks the context for the duration of the call — or, when another thread holds it
+// and the context may fan out (see ma_ctx::lanes), a free lane — and re-points `ctx` at whichever was locked. A call
+// made by a thread that already holds (a lane of) the same context — an entry point composed of others — re-uses
+// that lane without locking. primary_only: the call is tied to the context's own stream (synchronize, capture,
+// timers, collectives).
+class Enter {
+  public:
+    explicit Enter(ma_ctx*& ctx, bool primary_only = false);
+    ~Enter();
+    Enter(const Enter&) = delete;
+    Enter& operator=(const Enter&) = delete;
+
+  private:
+    ma_ctx* locked_ = nullptr;
+};
+// While one is alive on a thread, the entry points that thread calls only enqueue (as in async mode) — the composed
+// entry point synchronises once at its end. Never changes the context's user-visible mode.
+struct NoSync {
+    NoSync();
+    ~NoSync();
+};
+bool nosync_active();
+inline bool is_async(const ma_ctx* ctx) { return ctx->async || nosync_active(); }
+// Waits for the context's stream and turns a latched device condition (dense integer divide by zero) into its status.
+ma_status sync_and_check(ma_ctx* ctx);
+
 enum PtrKind : int32_t { kPageable = 0, kPinned = 1, kDevice = 2, kManaged = 3 };
 PtrKind pointer_kind(const void* p);
 // Which operands of a large elementwise call go through the staging ring (ma_pipeline.hip): pageable host memory
@@ -103,7 +143,7 @@ PtrKind pointer_kind(const void* p);
 // fill both directions of the link where a kernel reading and writing over it does not (a (+) scalar at 2^28 rows:
 // 45.8 vs 49.6 ms, profiles/r01_pcie_tiled.json). An async context keeps pinned operands in place: the call must
 // return before the work is done.
-inline bool crosses_in_tiles(const ma_ctx* ctx, PtrKind k) { return k == kPageable || (k == kPinned && !ctx->async); }
+inline bool crosses_in_tiles(const ma_ctx* ctx, PtrKind k) { return k == kPageable || (k == kPinned && !is_async(ctx)); }
 
 // Makes every buffer of one ABI call device-reachable. Pageable host inputs are copied into temporary
 // device buffers; pageable host outputs get a temporary that is copied back by finish(). Using any
@@ -141,6 +181,7 @@ class CallScope {
     ma_ctx* ctx_;
     std::vector<Temp> temps_;
     std::vector<void*> slabs_;
+    bool finished_ = false;  // finish() ran to completion: nothing in flight touches the slabs any more
     char* slab_cur_ = nullptr;
     size_t slab_left_ = 0, slab_next_ = (size_t)1 << 20;
 };
@@ -183,6 +224,15 @@ void pipe_destroy(ma_ctx* ctx);
 // `bytes` of device scratch owned by the context (256-byte aligned). Valid until the next ctx_scratch call on this
 // context; the caller holds ctx->mu and enqueues every use on ctx->stream, so successive users are stream-ordered.
 ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out);
+
+// A reduction record as it is exchanged between GPUs: 8 x u64 (64 bytes) — [0] integer sum, [1] integer valid count,
+// [2] f64 hi bits, [3] f64 lo bits, [4] float valid count, [5..7] unused.
+constexpr size_t kRecordWords = 8;
+// Enqueues the ordered fold of gathered records on ctx->stream (ma_reduce_batch.hip): column c = records at
+// rec + c * kRecordWords + r * stride_words for r in [0, n_records); out = 4 x u64 per column. Device-reachable buffers;
+// the caller holds ctx->mu.
+ma_status enqueue_fold_columns(ma_ctx* ctx, const uint64_t* rec, size_t n_records, size_t stride_words, size_t n_columns,
+                               uint64_t* out);
 
 // Completes a call: in sync mode waits for the stream. Returns MA_ERR_DEVICE on failure.
 ma_status end_call(ma_ctx* ctx, CallScope& scope);

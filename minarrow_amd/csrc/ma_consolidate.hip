@@ -248,7 +248,7 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     MA_REQUIRE(out_data != nullptr, MA_ERR_INVALID_ARGUMENT, "out_data is NULL");
     MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
 
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
@@ -372,7 +372,7 @@ extern "C" ma_status ma_consolidate_table_arena(ma_ctx* ctx, size_t n_cols, size
             MA_REQUIRE(((uintptr_t)p % elem_sizes[c]) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu batch %zu is misaligned", c, b);
         }
 
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
@@ -487,7 +487,7 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     MA_REQUIRE(out_bits != nullptr, MA_ERR_INVALID_ARGUMENT, "out_bits is NULL");
     MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
 
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);

@@ -1,7 +1,9 @@
 // Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
 // C ABI: include/minarrow_hip.h.
 #include <atomic>
+#include <cstdlib>
 #include <map>
+#include <unordered_set>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -21,6 +23,7 @@ namespace {
 struct PinnedPool {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> parked;   // rounded size -> free blocks of that size
+    std::unordered_set<void*> parked_set;          // the same blocks by address: a second free of one is refused
     std::unordered_map<void*, size_t> live;        // blocks handed out by the pool -> their rounded size
     size_t cached_bytes = 0;
     size_t limit_bytes = (size_t)2 << 30;
@@ -32,8 +35,20 @@ size_t pool_size_of(size_t bytes) {  // bytes >= kPoolMinBytes
     const size_t step = top >> 3;
     return ((bytes + step - 1) / step) * step;
 }
+// MINARROW_HIP_PINNED_POOL_BYTES / MINARROW_HIP_DEV_POOL_BYTES: cache limits, read once (0 = no caching).
+size_t env_bytes(const char* name, size_t fallback) {
+    const char* v = getenv(name);
+    if (!v || !*v) return fallback;
+    char* end = nullptr;
+    unsigned long long x = strtoull(v, &end, 10);
+    return end && *end == '\0' ? (size_t)x : fallback;
+}
 PinnedPool& pinned_pool() {
-    static PinnedPool* pool = new PinnedPool();  // intentionally leaked: frees may arrive during process teardown
+    static PinnedPool* pool = [] {  // intentionally leaked: frees may arrive during process teardown
+        PinnedPool* p = new PinnedPool();
+        p->limit_bytes = env_bytes("MINARROW_HIP_PINNED_POOL_BYTES", p->limit_bytes);
+        return p;
+    }();
     return *pool;
 }
 // The same cache for device blocks, one per device: hipFree synchronises the WHOLE device (~160 us, and every other
@@ -42,17 +57,49 @@ constexpr int kMaxPooledDevices = 64;
 PinnedPool& device_pool(int device) {
     static PinnedPool* pools = [] {
         PinnedPool* p = new PinnedPool[kMaxPooledDevices];
-        for (int i = 0; i < kMaxPooledDevices; ++i) p[i].limit_bytes = (size_t)16 << 30;
+        const size_t limit = env_bytes("MINARROW_HIP_DEV_POOL_BYTES", (size_t)16 << 30);
+        for (int i = 0; i < kMaxPooledDevices; ++i) p[i].limit_bytes = limit;
         return p;
     }();
     return pools[device];
+}
+
+// Releases every parked block of `device` back to the runtime (the device must be current). Returns the bytes freed.
+size_t dev_pool_flush(int device) {
+    if (device < 0 || device >= kMaxPooledDevices) return 0;
+    PinnedPool& pool = device_pool(device);
+    std::vector<void*> victims;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> plock(pool.mu);
+        for (auto& kv : pool.parked) {
+            victims.insert(victims.end(), kv.second.begin(), kv.second.end());
+            kv.second.clear();
+        }
+        bytes = pool.cached_bytes;
+        pool.cached_bytes = 0;
+        pool.parked_set.clear();
+    }
+    for (void* v : victims) (void)hipFree(v);
+    return bytes;
+}
+
+// hipMalloc that, when HBM is full of parked blocks, releases them and tries once more. Every internal device
+// allocation goes through here (scratch, staging rings, context state), not only ma_dev_alloc.
+hipError_t dev_malloc_retry(int device, void** out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        if (dev_pool_flush(device) > 0) e = hipMalloc(out, bytes);
+    }
+    return e;
 }
 
 // hipMalloc / hipFree through the device's block cache (the caller has made the device current and, for a free, has
 // made sure nothing in flight still touches the block).
 hipError_t dev_block_alloc(int device, size_t bytes, void** out) {
     *out = nullptr;
-    if (bytes < kPoolMinBytes || device < 0 || device >= kMaxPooledDevices) return hipMalloc(out, bytes == 0 ? 64 : bytes);
+    if (bytes < kPoolMinBytes || device < 0 || device >= kMaxPooledDevices) return dev_malloc_retry(device, out, bytes == 0 ? 64 : bytes);
     PinnedPool& pool = device_pool(device);
     const size_t rounded = pool_size_of(bytes);
     {
@@ -61,26 +108,13 @@ hipError_t dev_block_alloc(int device, size_t bytes, void** out) {
         if (it != pool.parked.end() && !it->second.empty()) {
             *out = it->second.back();
             it->second.pop_back();
+            pool.parked_set.erase(*out);
             pool.cached_bytes -= rounded;
             pool.live.emplace(*out, rounded);
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(out, rounded);
-    if (e == hipErrorOutOfMemory) {  // HBM is full of parked blocks: release them and try once more
-        (void)hipGetLastError();
-        std::vector<void*> victims;
-        {
-            std::lock_guard<std::mutex> plock(pool.mu);
-            for (auto& kv : pool.parked) {
-                victims.insert(victims.end(), kv.second.begin(), kv.second.end());
-                kv.second.clear();
-            }
-            pool.cached_bytes = 0;
-        }
-        for (void* v : victims) (void)hipFree(v);
-        e = hipMalloc(out, rounded);
-    }
+    hipError_t e = dev_malloc_retry(device, out, rounded);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> plock(pool.mu);
     pool.live.emplace(*out, rounded);
@@ -91,12 +125,14 @@ hipError_t dev_block_free(int device, void* ptr) {
     if (device >= 0 && device < kMaxPooledDevices) {
         PinnedPool& pool = device_pool(device);
         std::lock_guard<std::mutex> plock(pool.mu);
+        if (pool.parked_set.count(ptr)) return hipErrorInvalidValue;  // already parked: a double free
         auto it = pool.live.find(ptr);
         if (it != pool.live.end()) {
             const size_t rounded = it->second;
             pool.live.erase(it);
             if (pool.cached_bytes + rounded <= pool.limit_bytes) {
                 pool.parked[rounded].push_back(ptr);
+                pool.parked_set.insert(ptr);
                 pool.cached_bytes += rounded;
                 return hipSuccess;
             }
@@ -104,7 +140,24 @@ hipError_t dev_block_free(int device, void* ptr) {
     }
     return hipFree(ptr);
 }
+
+// Takes parked blocks out of `pool` until at most keep_bytes stay, largest first.
+std::vector<void*> pool_take_victims(PinnedPool& pool, size_t keep_bytes) {
+    std::vector<void*> victims;
+    std::lock_guard<std::mutex> plock(pool.mu);
+    pool.limit_bytes = keep_bytes;
+    for (auto it = pool.parked.rbegin(); it != pool.parked.rend() && pool.cached_bytes > keep_bytes; ++it)
+        while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
+            victims.push_back(it->second.back());
+            pool.parked_set.erase(it->second.back());
+            it->second.pop_back();
+            pool.cached_bytes -= it->first;
+        }
+    return victims;
+}
 }  // namespace
+
+hipError_t device_malloc(int device, void** out, size_t bytes) { return dev_malloc_retry(device, out, bytes); }
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -181,7 +234,11 @@ CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
 }
 
 CallScope::~CallScope() {
-    for (void* slab : slabs_) (void)dev_block_free(ctx_->device, slab);  // staged calls end synchronised: safe to park
+    // A parked slab can be handed to another context at once. finish() leaves the stream drained; an early error return
+    // (a later operand failing to stage, a validation failure after kernels were enqueued) does not: wait here, so that
+    // nothing in flight still reads or writes the slabs and the caller gets its "synchronous" call back quiescent.
+    if (!slabs_.empty() && !finished_) (void)hipStreamSynchronize(ctx_->stream);
+    for (void* slab : slabs_) (void)dev_block_free(ctx_->device, slab);
     if (--t_scope_depth == 0 || !temps_.empty()) forget_ranges();
 }
 
@@ -274,7 +331,7 @@ ma_status CallScope::out_mask(uint8_t* bits, size_t len_bits, uint64_t** out_wor
 }
 
 ma_status CallScope::finish() {
-    bool need_sync = !ctx_->async || !temps_.empty();
+    bool need_sync = !is_async(ctx_) || !temps_.empty();
     bool any_out = false;
     for (auto& t : temps_) {
         if (t.host_dst) {
@@ -283,7 +340,10 @@ ma_status CallScope::finish() {
         }
     }
     (void)any_out;
-    if (need_sync) MA_HIP(hipStreamSynchronize(ctx_->stream));
+    if (need_sync) {
+        MA_HIP(hipStreamSynchronize(ctx_->stream));
+        finished_ = true;
+    }
     return MA_OK;
 }
 
@@ -299,7 +359,7 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
         }
         size_t want = bytes + bytes / 2;
         want = (want + 4095) & ~(size_t)4095;
-        MA_HIP(hipMalloc(&ctx->scratch, want));
+        MA_HIP(dev_malloc_retry(ctx->device, &ctx->scratch, want));
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
@@ -309,6 +369,99 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
 ma_status end_call(ma_ctx* ctx, CallScope& scope) {
     (void)ctx;
     return scope.finish();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Entry-point guard: the context, or a lane of it (ma_common.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Held {
+    ma_ctx* root;
+    ma_ctx* lane;
+};
+constexpr int kMaxHeld = 8;
+thread_local Held t_held[kMaxHeld];
+thread_local int t_n_held = 0;
+thread_local int t_nosync = 0;
+}  // namespace
+
+NoSync::NoSync() { ++t_nosync; }
+NoSync::~NoSync() { --t_nosync; }
+bool nosync_active() { return t_nosync > 0; }
+
+ma_status make_lane(ma_ctx* root, ma_ctx** out);  // defined with the context constructor below
+
+Enter::Enter(ma_ctx*& ctx, bool primary_only) {
+    if (ctx == nullptr) return;  // the entry point reports the NULL itself
+    ma_ctx* root = ctx->parent ? ctx->parent : ctx;
+    for (int i = 0; i < t_n_held; ++i)
+        if (t_held[i].root == root) {  // a composed entry point calling its parts: same lane, no second lock
+            ctx = t_held[i].lane;
+            return;
+        }
+    ma_ctx* lane = root;
+    if (!root->mu.try_lock()) {
+        // Busy in another thread. Ordering on the context's one stream is part of the contract for async, capturing and
+        // borrowed-stream contexts (and for calls tied to that stream): wait. Otherwise run beside it on a lane.
+        const bool may_fan_out = !primary_only && !root->async && !root->capturing && root->owns_stream && root->max_lanes > 1;
+        lane = nullptr;
+        if (may_fan_out) {
+            std::lock_guard<std::mutex> ll(root->lanes_mu);
+            for (ma_ctx* x : root->lanes)
+                if (x->mu.try_lock()) {
+                    lane = x;
+                    break;
+                }
+            if (!lane && (int)root->lanes.size() + 1 < root->max_lanes) {
+                ma_ctx* fresh = nullptr;
+                if (make_lane(root, &fresh) == MA_OK) {
+                    fresh->mu.lock();
+                    root->lanes.push_back(fresh);
+                    lane = fresh;
+                }
+            }
+        }
+        if (!lane) {
+            root->mu.lock();
+            lane = root;
+        } else {  // tuning knobs follow the context (plain ints; a concurrent setter is the caller's race, as before)
+            lane->variant = root->variant;
+            lane->blocks_per_cu = root->blocks_per_cu;
+            lane->grid_override = root->grid_override;
+            lane->staging_tile_bytes = root->staging_tile_bytes;
+        }
+    }
+    locked_ = lane;
+    ctx = lane;
+    if (t_n_held < kMaxHeld) t_held[t_n_held++] = {root, lane};
+}
+
+Enter::~Enter() {
+    if (!locked_) return;
+    for (int i = t_n_held - 1; i >= 0; --i)
+        if (t_held[i].lane == locked_) {
+            for (int j = i; j + 1 < t_n_held; ++j) t_held[j] = t_held[j + 1];
+            --t_n_held;
+            break;
+        }
+    locked_->mu.unlock();
+}
+
+ma_status sync_and_check(ma_ctx* ctx) {
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_flags) {
+        ctx->pending_flags = false;
+        uint32_t flags = 0;
+        MA_HIP(hipMemcpy(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost));
+        if (flags) {
+            MA_HIP(hipMemset(ctx->dev_flags, 0, sizeof(flags)));
+            if (flags & 1u) {
+                set_error("integer division by zero in a dense kernel enqueued before this synchronize");
+                return MA_ERR_DIVIDE_BY_ZERO;
+            }
+        }
+    }
+    return MA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -351,12 +504,12 @@ static ma_status launch_fill(ma_ctx* ctx, T* dst, size_t n, F f) {
     MA_REQUIRE(dst != nullptr, MA_ERR_INVALID_ARGUMENT, "dst is NULL");
     MA_REQUIRE(pointer_kind(dst) != kPageable, MA_ERR_INVALID_ARGUMENT,
                "synthetic generators need a device-reachable destination");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     int grid = grid_for(ctx, (n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((fill_kernel<T, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, dst, n, f);
     MA_HIP(hipGetLastError());
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 
@@ -395,13 +548,48 @@ extern "C" {
 
 int32_t ma_abi_version(void) { return MA_ABI_VERSION; }
 
-int32_t ma_device_count(void) {
+static int physical_device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     return n;
+}
+
+// MINARROW_HIP_DEVICES = "2,3,5": the library's device ordinal i is HIP device list[i] (a per-library
+// HIP_VISIBLE_DEVICES that leaves the rest of the process alone). Unset or empty: the identity over all devices.
+static const std::vector<int>& device_map() {
+    static const std::vector<int>* map = [] {
+        auto* m = new std::vector<int>();
+        const int n = physical_device_count();
+        const char* v = getenv("MINARROW_HIP_DEVICES");
+        if (v && *v) {
+            const char* p = v;
+            while (*p) {
+                char* end = nullptr;
+                long d = strtol(p, &end, 10);
+                if (end == p) break;
+                if (d >= 0 && d < n) m->push_back((int)d);
+                p = (*end == ',') ? end + 1 : end;
+                if (*end != ',' && *end != '\0') break;
+            }
+        }
+        if (m->empty())
+            for (int i = 0; i < n; ++i) m->push_back(i);
+        return m;
+    }();
+    return *map;
+}
+
+int32_t ma_device_count(void) { return physical_device_count() > 0 ? (int32_t)device_map().size() : 0; }
+
+int64_t ma_min_device_rows(void) {
+    // MINARROW_HIP_MIN_ROWS: the column length below which a host wrapper should keep its CPU kernels — a GPU call costs
+    // ~17 us synchronously whatever the size (profiles/r01_launch_bound.json), the reference's scalar sum of 1000 rows
+    // 85 ns (src/lib.rs:58). The library itself never computes on the CPU; this is advice the host shim reads.
+    static const int64_t rows = (int64_t)env_bytes("MINARROW_HIP_MIN_ROWS", (size_t)1 << 16);
+    return rows;
 }
 
 const char* ma_last_error_string(void) { return g_err; }
@@ -419,7 +607,7 @@ const char* ma_status_name(ma_status s) {
     }
 }
 
-static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_ctx** out_ctx) {
+static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_ctx** out_ctx, bool map_ordinal = true) {
     MA_REQUIRE(out_ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
     *out_ctx = nullptr;
     int n = ma_device_count();
@@ -427,7 +615,10 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         set_error("no HIP device is visible; libminarrow_hip has no CPU fallback");
         return MA_ERR_NO_DEVICE;
     }
-    MA_REQUIRE(device >= 0 && device < n, MA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range [0,%d)", device, n);
+    if (map_ordinal) {
+        MA_REQUIRE(device >= 0 && device < n, MA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range [0,%d)", device, n);
+        device = device_map()[(size_t)device];  // MINARROW_HIP_DEVICES
+    }
     MA_HIP(hipSetDevice(device));
     ma_ctx* c = new ma_ctx();
     c->device = device;
@@ -454,8 +645,8 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         ma_ctx_destroy(c);
         return s;
     };
-    if ((e = hipMalloc((void**)&c->partials, sizeof(Partial) * kMaxGrid)) != hipSuccess) return fail(e, "hipMalloc(partials)");
-    if ((e = hipMalloc((void**)&c->ticket, 256)) != hipSuccess) return fail(e, "hipMalloc(ticket)");
+    if ((e = device_malloc(device, (void**)&c->partials, sizeof(Partial) * kMaxGrid)) != hipSuccess) return fail(e, "hipMalloc(partials)");
+    if ((e = device_malloc(device, (void**)&c->ticket, 256)) != hipSuccess) return fail(e, "hipMalloc(ticket)");
     if ((e = hipMemset(c->ticket, 0, 256)) != hipSuccess) return fail(e, "hipMemset(ticket)");
     c->dev_flags = c->ticket + 16;  // same zeroed allocation, a different 64-B line
     if ((e = hipHostMalloc((void**)&c->result, sizeof(ResultSlot) * 4, hipHostMallocDefault)) != hipSuccess)
@@ -463,9 +654,33 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
     memset(c->result, 0, sizeof(ResultSlot) * 4);
     if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
+    // Environment surface (read at context creation): staging tile of host-resident operands and
+    // how many lanes concurrent synchronous calls may fan out over.
+    c->staging_tile_bytes = env_bytes("MINARROW_HIP_STAGING_TILE", c->staging_tile_bytes);
+    if (c->staging_tile_bytes != 0 && c->staging_tile_bytes < ((size_t)1 << 16)) c->staging_tile_bytes = (size_t)1 << 16;
+    const size_t lanes = env_bytes("MINARROW_HIP_LANES", (size_t)c->max_lanes);
+    c->max_lanes = lanes < 1 ? 1 : (lanes > 16 ? 16 : (int)lanes);
     *out_ctx = c;
     return MA_OK;
 }
+
+}  // extern "C"
+
+namespace ma {
+ma_status make_lane(ma_ctx* root, ma_ctx** out) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    ma_status st = ctx_create_impl(root->device, nullptr, false, out, false);  // root->device is already a HIP ordinal
+    if (st == MA_OK) {
+        (*out)->parent = root;
+        (*out)->max_lanes = 1;
+    }
+    (void)hipSetDevice(prev);
+    return st;
+}
+}  // namespace ma
+
+extern "C" {
 
 ma_status ma_ctx_create(int32_t device_ordinal, ma_ctx** out_ctx) {
     return ctx_create_impl(device_ordinal, nullptr, false, out_ctx);
@@ -477,6 +692,8 @@ ma_status ma_ctx_create_on_stream(int32_t device_ordinal, void* hip_stream, ma_c
 
 void ma_ctx_destroy(ma_ctx* ctx) {
     if (!ctx) return;
+    for (ma_ctx* lane : ctx->lanes) ma_ctx_destroy(lane);
+    ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partials) (void)hipFree(ctx->partials);
@@ -492,28 +709,15 @@ void ma_ctx_destroy(ma_ctx* ctx) {
 
 ma_status ma_ctx_synchronize(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_ctx_synchronize");
     MA_HIP(hipSetDevice(ctx->device));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->pending_flags) {
-        ctx->pending_flags = false;
-        uint32_t flags = 0;
-        MA_HIP(hipMemcpy(&flags, ctx->dev_flags, sizeof(flags), hipMemcpyDeviceToHost));
-        if (flags) {
-            MA_HIP(hipMemset(ctx->dev_flags, 0, sizeof(flags)));
-            if (flags & 1u) {
-                set_error("integer division by zero in a dense kernel enqueued before this synchronize");
-                return MA_ERR_DIVIDE_BY_ZERO;
-            }
-        }
-    }
-    return MA_OK;
+    return sync_and_check(ctx);
 }
 
 ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     if (ctx->capturing) {  // takes effect when the capture ends
         ctx->async_before_capture = enabled != 0;
         return MA_OK;
@@ -537,7 +741,7 @@ extern "C" {
 
 ma_status ma_ctx_capture_begin(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_REQUIRE(!ctx->capturing, MA_ERR_INVALID_ARGUMENT, "a capture is already in progress on this context");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -553,7 +757,7 @@ ma_status ma_ctx_capture_begin(ma_ctx* ctx) {
 ma_status ma_ctx_capture_end(ma_ctx* ctx, ma_graph** out_graph) {
     MA_REQUIRE(ctx != nullptr && out_graph != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_graph is NULL");
     *out_graph = nullptr;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_REQUIRE(ctx->capturing, MA_ERR_INVALID_ARGUMENT, "no capture in progress on this context");
     MA_HIP(hipSetDevice(ctx->device));
     ctx->capturing = false;
@@ -582,16 +786,12 @@ ma_status ma_graph_launch(ma_ctx* ctx, ma_graph* graph) {
     MA_REQUIRE(ctx != nullptr && graph != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or graph is NULL");
     MA_REQUIRE(graph->device == ctx->device, MA_ERR_INVALID_ARGUMENT, "the graph was recorded on device %d, this context is on %d",
                graph->device, ctx->device);
-    bool wait = false;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        MA_NO_CAPTURE(ctx, "ma_graph_launch");
-        MA_HIP(hipSetDevice(ctx->device));
-        MA_HIP(hipGraphLaunch(graph->exec, ctx->stream));
-        if (graph->may_latch) ctx->pending_flags = true;
-        wait = !ctx->async;
-    }
-    return wait ? ma_ctx_synchronize(ctx) : MA_OK;
+    MA_ENTER_PRIMARY(ctx);
+    MA_NO_CAPTURE(ctx, "ma_graph_launch");
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipGraphLaunch(graph->exec, ctx->stream));
+    if (graph->may_latch) ctx->pending_flags = true;
+    return is_async(ctx) ? MA_OK : sync_and_check(ctx);
 }
 
 ma_status ma_graph_node_count(const ma_graph* graph, size_t* out_nodes) {
@@ -616,7 +816,7 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 64, MA_ERR_INVALID_ARGUMENT, "blocks_per_cu %d out of range",
                blocks_per_cu);
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     ctx->blocks_per_cu = blocks_per_cu;
     return MA_OK;
 }
@@ -624,21 +824,21 @@ ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
 ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(workgroups >= 0, MA_ERR_INVALID_ARGUMENT, "workgroups must be >= 0");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     ctx->grid_override = workgroups;
     return MA_OK;
 }
 
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     ctx->variant = variant;
     return MA_OK;
 }
 
 ma_status ma_ctx_timer_start(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_ctx_timer_start");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
@@ -647,7 +847,7 @@ ma_status ma_ctx_timer_start(ma_ctx* ctx) {
 
 ma_status ma_ctx_timer_stop(ma_ctx* ctx) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_ctx_timer_stop");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -656,7 +856,7 @@ ma_status ma_ctx_timer_stop(ma_ctx* ctx) {
 
 ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms) {
     MA_REQUIRE(ctx != nullptr && out_ms != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_ms is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_ctx_timer_elapsed_ms");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipEventSynchronize(ctx->ev_stop));
@@ -689,6 +889,7 @@ ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr) {
         if (it != pool.parked.end() && !it->second.empty()) {
             p = it->second.back();
             it->second.pop_back();
+            pool.parked_set.erase(p);
             pool.cached_bytes -= rounded;
             pool.live.emplace(p, rounded);
             *out_ptr = p;
@@ -707,12 +908,15 @@ ma_status ma_free_pinned(void* ptr) {
     PinnedPool& pool = pinned_pool();
     {
         std::lock_guard<std::mutex> lock(pool.mu);
+        MA_REQUIRE(pool.parked_set.count(ptr) == 0, MA_ERR_INVALID_ARGUMENT,
+                   "ma_free_pinned(%p): the block is already free (double free)", ptr);
         auto it = pool.live.find(ptr);
         if (it != pool.live.end()) {
             const size_t rounded = it->second;
             pool.live.erase(it);
             if (pool.cached_bytes + rounded <= pool.limit_bytes) {
                 pool.parked[rounded].push_back(ptr);
+                pool.parked_set.insert(ptr);
                 pool.cached_bytes += rounded;
                 return MA_OK;
             }
@@ -724,19 +928,19 @@ ma_status ma_free_pinned(void* ptr) {
 }
 
 ma_status ma_pinned_pool_trim(size_t keep_bytes) {
-    PinnedPool& pool = pinned_pool();
-    std::vector<void*> victims;
-    {
-        std::lock_guard<std::mutex> lock(pool.mu);
-        pool.limit_bytes = keep_bytes;
-        for (auto it = pool.parked.rbegin(); it != pool.parked.rend() && pool.cached_bytes > keep_bytes; ++it)  // largest first
-            while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
-                victims.push_back(it->second.back());
-                it->second.pop_back();
-                pool.cached_bytes -= it->first;
-            }
+    hipError_t first = hipSuccess;
+    for (void* v : pool_take_victims(pinned_pool(), keep_bytes)) {
+        hipError_t e = hipHostFree(v);
+        if (e != hipSuccess && first == hipSuccess) first = e;
     }
-    for (void* v : victims) MA_HIP(hipHostFree(v));
+    MA_HIP(first);
+    return MA_OK;
+}
+
+ma_status ma_pinned_pool_set_limit(size_t limit_bytes) {
+    PinnedPool& pool = pinned_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    pool.limit_bytes = limit_bytes;
     return MA_OK;
 }
 
@@ -760,7 +964,7 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;
     MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "device allocation of %zu bytes is too large", bytes);
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_dev_alloc");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(dev_block_alloc(ctx->device, bytes, out_dev_ptr));
@@ -770,32 +974,36 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (!dev_ptr) return MA_OK;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_dev_free");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipStreamSynchronize(ctx->stream));  // nothing enqueued through this context still touches the block
-    MA_HIP(dev_block_free(ctx->device, dev_ptr));
+    hipError_t fe = dev_block_free(ctx->device, dev_ptr);
+    MA_REQUIRE(fe != hipErrorInvalidValue, MA_ERR_INVALID_ARGUMENT, "ma_dev_free(%p): the block is already free (double free)", dev_ptr);
+    MA_HIP(fe);
     return MA_OK;
 }
 
 ma_status ma_dev_pool_trim(ma_ctx* ctx, size_t keep_bytes) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(ctx->device >= 0 && ctx->device < kMaxPooledDevices, MA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
-    PinnedPool& pool = device_pool(ctx->device);
-    std::vector<void*> victims;
-    {
-        std::lock_guard<std::mutex> plock(pool.mu);
-        pool.limit_bytes = keep_bytes;
-        for (auto it = pool.parked.rbegin(); it != pool.parked.rend() && pool.cached_bytes > keep_bytes; ++it)
-            while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
-                victims.push_back(it->second.back());
-                it->second.pop_back();
-                pool.cached_bytes -= it->first;
-            }
+    hipError_t first = hipSuccess;
+    for (void* v : pool_take_victims(device_pool(ctx->device), keep_bytes)) {
+        hipError_t e = hipFree(v);
+        if (e != hipSuccess && first == hipSuccess) first = e;
     }
-    for (void* v : victims) MA_HIP(hipFree(v));
+    MA_HIP(first);
+    return MA_OK;
+}
+
+ma_status ma_dev_pool_set_limit(ma_ctx* ctx, size_t limit_bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(ctx->device >= 0 && ctx->device < kMaxPooledDevices, MA_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    PinnedPool& pool = device_pool(ctx->device);
+    std::lock_guard<std::mutex> lock(pool.mu);
+    pool.limit_bytes = limit_bytes;
     return MA_OK;
 }
 
@@ -803,7 +1011,7 @@ ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (bytes == 0) return MA_OK;
     MA_REQUIRE(dst_dev && src_host, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_dev_upload");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -815,7 +1023,7 @@ ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (bytes == 0) return MA_OK;
     MA_REQUIRE(dst_host && src_dev, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_dev_download");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -827,10 +1035,21 @@ ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t b
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     if (bytes == 0) return MA_OK;
     MA_REQUIRE(dst_dev != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, ctx->stream));
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_dev_copy(ma_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (bytes == 0) return MA_OK;
+    MA_REQUIRE(dst_dev && src_dev, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_ENTER_PRIMARY(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 
@@ -869,14 +1088,14 @@ ma_status ma_synth_validity(ma_ctx* ctx, uint8_t* dst_bits, size_t n_bits, uint6
     MA_REQUIRE(((uintptr_t)dst_bits & 7) == 0, MA_ERR_INVALID_ARGUMENT, "validity bitmap must be 8-byte aligned");
     MA_REQUIRE(pointer_kind(dst_bits) != kPageable, MA_ERR_INVALID_ARGUMENT,
                "synthetic generators need a device-reachable destination");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     size_t n_words = (n_bits + 63) / 64;
     int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(validity_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (uint64_t*)dst_bits, n_bits, seed,
                        first_index, null_every);
     MA_HIP(hipGetLastError());
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 

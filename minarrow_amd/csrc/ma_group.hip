@@ -1,62 +1,208 @@
 // Single-process, multi-GPU row-chunk reduction: what the reference's Rayon path
 // (`slice.par_chunks(1 << 20).map(simd_sum).sum()`, benches/benchmark_parallel_simd.rs:81-98) becomes for a host
 // that drives all GPUs of a node from one process (e.g. the Rust library itself). One ma_ctx per device; every
-// device scans its own row chunk concurrently (async launches on independent streams) and writes {sum | hi, lo,
-// count} into a pinned record; the host folds the G records in device order (wrapping add; double-double for floats,
-// so the f64 total stays within 1 ULP). G x 24 bytes: no collective is needed inside one process. The multi-PROCESS
-// form of the same exchange is one RCCL all-gather (minarrow_amd/parallel.py, bench.py).
+// device scans its own row chunk concurrently (enqueue-only launches on independent streams) and writes
+// {sum | hi, lo, count} into its 64-byte record of the reduction's column. The records are then exchanged:
+//
+//   RCCL  (MA_GROUP_EXCHANGE_RCCL)  ncclCommInitAll over the group's devices; ONE grouped ncclAllGather of the
+//         members' record blocks over xGMI, enqueued on the members' streams, followed on every device by the
+//         member-ordered fold kernel (wrapping adds; error-free two-sum for the double-double pairs): every GPU ends
+//         up holding bit-identical finals — an all-reduce whose f64 result stays within 1 ULP, which ncclAllReduce's
+//         own rounding sum cannot give. Nothing but the finals ever reaches the host.
+//   host  (default)  the kernels write their records straight into pinned host memory and the host folds the
+//         G x 64 bytes after the streams drain — no collective is needed inside one process.
+//
+// The multi-PROCESS form of the same exchange is ma_comm_sum_exchange (ma_rccl.hip).
+#include <cstdlib>
 #include <vector>
 
-#include "ma_common.hpp"
+#include "ma_rccl.hpp"
 
 struct ma_group {
     std::vector<ma_ctx*> ctxs;
-    uint64_t* records = nullptr;  // pinned, 4 x u64 per member
+    std::mutex mu;
+    bool use_rccl = false;
+    std::vector<ncclComm_t> comms;
+    // RCCL: per member a device block of kColumns records (`local`), a device block of G x kColumns gathered records
+    // and a pinned host block of kColumns x 4 finals the fold kernel writes. host: `local[i]` points into `host_records`.
+    std::vector<uint64_t*> local, gathered, finals;
+    uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
+    uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
+    char note[256] = "";
 };
 
 using namespace ma;
 
 namespace {
 
-inline void two_sum_acc(double& hi, double& lo, double h, double l) {
-    double t = hi + h;
-    double bp = t - hi;
-    double e = (hi - (t - bp)) + (h - bp);
-    hi = t;
-    lo += e + l;
+constexpr int kColumns = MA_GROUP_MAX_COLUMNS;
+constexpr size_t kBlockWords = (size_t)kColumns * kRecordWords;
+
+struct HostFoldDD {
+    uint64_t isum = 0, icnt = 0, fcnt = 0;
+    double hi = 0.0, lo = 0.0;
+    void add(const uint64_t* p) {
+        isum += p[0];
+        icnt += p[1];
+        double h, l;
+        memcpy(&h, &p[2], 8);
+        memcpy(&l, &p[3], 8);
+        const double t = hi + h;
+        const double bp = t - hi;
+        const double e = (hi - (t - bp)) + (h - bp);
+        hi = t;
+        lo += e + l;
+        fcnt += p[4];
+    }
+    double total() const {
+        const bool finite = (hi - hi == 0.0) && (lo - lo == 0.0);
+        return finite ? hi + lo : hi;
+    }
+};
+
+// Frees the exchange's buffers and communicators (either kind); the members stay.
+void release_exchange(ma_group* g) {
+    for (size_t i = 0; i < g->ctxs.size(); ++i) {
+        (void)hipSetDevice(g->ctxs[i]->device);
+        (void)hipStreamSynchronize(g->ctxs[i]->stream);
+    }
+    if (g->use_rccl || !g->comms.empty()) {
+        const RcclApi* api = rccl();
+        for (ncclComm_t c : g->comms)
+            if (c && api) (void)api->CommDestroy(c);
+        for (size_t i = 0; i < g->ctxs.size(); ++i) {
+            (void)hipSetDevice(g->ctxs[i]->device);
+            if (i < g->local.size() && g->local[i]) (void)hipFree(g->local[i]);
+            if (i < g->gathered.size() && g->gathered[i]) (void)hipFree(g->gathered[i]);
+        }
+        if (g->host_finals) (void)hipHostFree(g->host_finals);
+    } else {
+        if (g->host_records) (void)hipHostFree(g->host_records);
+        free(g->host_finals);
+    }
+    g->host_records = g->host_finals = nullptr;
+    g->comms.clear();
+    g->local.clear();
+    g->gathered.clear();
+    g->finals.clear();
+    g->use_rccl = false;
+}
+
+void destroy_members(ma_group* g) {
+    release_exchange(g);
+    for (ma_ctx* c : g->ctxs) ma_ctx_destroy(c);
+    g->ctxs.clear();
+}
+
+// RCCL exchange set-up. Returns MA_OK with g->use_rccl set, or a status + the thread's error string.
+ma_status setup_rccl(ma_group* g) {
+    const size_t n = g->ctxs.size();
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j)
+            MA_REQUIRE(g->ctxs[i]->device != g->ctxs[j]->device, MA_ERR_UNSUPPORTED,
+                       "an RCCL communicator needs distinct devices (members %zu and %zu share device %d)", i, j,
+                       g->ctxs[i]->device);
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    std::vector<int> devs(n);
+    for (size_t i = 0; i < n; ++i) devs[i] = g->ctxs[i]->device;
+    g->comms.assign(n, nullptr);  // non-empty from here on: release_exchange frees the RCCL-side resources
+    MA_NCCL(api, CommInitAll(g->comms.data(), (int)n, devs.data()));
+    g->use_rccl = true;
+    g->local.assign(n, nullptr);
+    g->gathered.assign(n, nullptr);
+    g->finals.assign(n, nullptr);
+    MA_HIP(hipHostMalloc((void**)&g->host_finals, n * kColumns * 4 * 8, hipHostMallocPortable | hipHostMallocMapped));
+    memset(g->host_finals, 0, n * kColumns * 4 * 8);
+    for (size_t i = 0; i < n; ++i) {
+        MA_HIP(hipSetDevice(devs[i]));
+        MA_HIP(device_malloc(devs[i], (void**)&g->local[i], kBlockWords * 8));
+        MA_HIP(device_malloc(devs[i], (void**)&g->gathered[i], n * kBlockWords * 8));
+        MA_HIP(hipMemset(g->local[i], 0, kBlockWords * 8));
+        MA_HIP(hipMemset(g->gathered[i], 0, n * kBlockWords * 8));
+        g->finals[i] = g->host_finals + i * kColumns * 4;
+    }
+    return MA_OK;
+}
+
+ma_status setup_host(ma_group* g) {
+    const size_t n = g->ctxs.size();
+    MA_HIP(hipHostMalloc((void**)&g->host_records, n * kBlockWords * 8, hipHostMallocPortable | hipHostMallocMapped));
+    memset(g->host_records, 0, n * kBlockWords * 8);
+    g->host_finals = (uint64_t*)calloc((size_t)kColumns * 4, 8);
+    MA_REQUIRE(g->host_finals != nullptr, MA_ERR_DEVICE, "out of host memory");
+    g->local.assign(n, nullptr);
+    for (size_t i = 0; i < n; ++i) g->local[i] = g->host_records + i * kBlockWords;
+    return MA_OK;
 }
 
 template <typename Launch>
-ma_status group_run(ma_group* g, const size_t* lens, Launch launch) {
+ma_status enqueue_members(ma_group* g, int32_t column, Launch launch) {
+    MA_REQUIRE(g != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
+    std::lock_guard<std::mutex> lock(g->mu);
+    for (size_t i = 0; i < g->ctxs.size(); ++i) {
+        uint64_t* rec = g->local[i] + (size_t)column * kRecordWords;
+        MA_TRY(launch(i, rec));  // enqueue only (the members are in async mode): all devices run concurrently
+    }
+    return MA_OK;
+}
+
+ma_status exchange_locked(ma_group* g) {
+    if (!g->use_rccl) return MA_OK;  // host exchange: the records are already in host memory once the streams drain
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
     const size_t n = g->ctxs.size();
-    std::vector<int> was_async(n);
-    ma_status st = MA_OK;
-    for (size_t i = 0; i < n; ++i) MA_NO_CAPTURE(g->ctxs[i], "a group reduction");
+    MA_NCCL(api, GroupStart());
     for (size_t i = 0; i < n; ++i) {
-        {
-            std::lock_guard<std::mutex> lock(g->ctxs[i]->mu);
-            was_async[i] = g->ctxs[i]->async ? 1 : 0;
+        ncclResult_t r = api->AllGather(g->local[i], g->gathered[i], kBlockWords * 8, ncclChar, g->comms[i], g->ctxs[i]->stream);
+        if (r != ncclSuccess) {
+            (void)api->GroupEnd();
+            return rccl_fail(r, "AllGather", __FILE__, __LINE__);
         }
-        (void)ma_ctx_set_async(g->ctxs[i], 1);
     }
-    for (size_t i = 0; i < n && st == MA_OK; ++i) {
-        uint64_t* rec = g->records + 4 * i;
-        rec[0] = rec[1] = rec[2] = 0;
-        if (lens[i]) st = launch(i, rec);  // enqueue only: all devices run concurrently
-    }
+    MA_NCCL(api, GroupEnd());
     for (size_t i = 0; i < n; ++i) {
-        ma_status s = ma_ctx_synchronize(g->ctxs[i]);
-        if (st == MA_OK) st = s;
-        (void)ma_ctx_set_async(g->ctxs[i], was_async[i]);
+        ma_ctx* c = g->ctxs[i];
+        std::lock_guard<std::mutex> lock(c->mu);
+        MA_HIP(hipSetDevice(c->device));
+        MA_TRY(enqueue_fold_columns(c, g->gathered[i], n, kBlockWords, kColumns, g->finals[i]));
     }
-    return st;
+    return MA_OK;
+}
+
+ma_status synchronize_locked(ma_group* g) {
+    ma_status st = MA_OK;
+    for (ma_ctx* c : g->ctxs) {
+        ma_status s = ma_ctx_synchronize(c);
+        if (st == MA_OK) st = s;
+    }
+    MA_TRY(st);
+    if (!g->use_rccl) {
+        for (int col = 0; col < kColumns; ++col) {
+            HostFoldDD f;
+            for (size_t i = 0; i < g->ctxs.size(); ++i) f.add(g->local[i] + (size_t)col * kRecordWords);
+            uint64_t* out = g->host_finals + (size_t)col * 4;
+            const double total = f.total();
+            out[0] = f.isum;
+            out[1] = f.icnt;
+            memcpy(&out[2], &total, 8);
+            out[3] = f.fcnt;
+        }
+    }
+    return MA_OK;
+}
+
+const uint64_t* finals_of(const ma_group* g, size_t member, int32_t column) {
+    const uint64_t* base = g->use_rccl ? g->finals[member] : g->host_finals;
+    return base + (size_t)column * 4;
 }
 
 }  // namespace
 
 extern "C" {
 
-ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group) {
+ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group) {
     MA_REQUIRE(out_group != nullptr, MA_ERR_INVALID_ARGUMENT, "out_group is NULL");
     *out_group = nullptr;
     MA_REQUIRE(device_ordinals != nullptr && n_members > 0 && n_members <= 1024, MA_ERR_INVALID_ARGUMENT,
@@ -65,28 +211,45 @@ ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_
     for (int32_t i = 0; i < n_members; ++i) {
         ma_ctx* c = nullptr;
         ma_status st = ma_ctx_create(device_ordinals[i], &c);
+        if (st == MA_OK) st = ma_ctx_set_async(c, 1);  // members only ever enqueue; the group synchronises them
         if (st != MA_OK) {
-            for (ma_ctx* x : g->ctxs) ma_ctx_destroy(x);
+            if (c) ma_ctx_destroy(c);
+            destroy_members(g);
             delete g;
             return st;
         }
         g->ctxs.push_back(c);
     }
-    hipError_t e = hipHostMalloc((void**)&g->records, sizeof(uint64_t) * 4 * (size_t)n_members,
-                                 hipHostMallocPortable | hipHostMallocMapped);
-    if (e != hipSuccess) {
-        for (ma_ctx* x : g->ctxs) ma_ctx_destroy(x);
+    ma_status st = MA_OK;
+    if (flags & MA_GROUP_EXCHANGE_RCCL) {
+        st = setup_rccl(g);
+        if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
+            snprintf(g->note, sizeof(g->note), "host fold instead of RCCL: %s", ma_last_error_string());
+            release_exchange(g);  // whatever the attempt allocated; the members stay
+            st = setup_host(g);
+        }
+    } else {
+        st = setup_host(g);
+    }
+    if (st != MA_OK) {
+        destroy_members(g);
         delete g;
-        return hip_fail(e, "hipHostMalloc(group records)", __FILE__, __LINE__);
+        return st;
     }
     *out_group = g;
     return MA_OK;
 }
 
+ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group) {
+    // MINARROW_HIP_GROUP_EXCHANGE=rccl makes RCCL the default exchange (with the host fold as its fallback).
+    const char* env = getenv("MINARROW_HIP_GROUP_EXCHANGE");
+    const uint32_t flags = (env && strcmp(env, "rccl") == 0) ? (MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST) : 0u;
+    return ma_group_create_ex(device_ordinals, n_members, flags, out_group);
+}
+
 void ma_group_destroy(ma_group* group) {
     if (!group) return;
-    for (ma_ctx* c : group->ctxs) ma_ctx_destroy(c);
-    if (group->records) (void)hipHostFree(group->records);
+    destroy_members(group);
     delete group;
 }
 
@@ -97,47 +260,76 @@ ma_ctx* ma_group_ctx(ma_group* group, int32_t index) {
     return group->ctxs[(size_t)index];
 }
 
+int32_t ma_group_exchange_kind(ma_group* group) { return group && group->use_rccl ? 1 : 0; }
+const char* ma_group_exchange_note(ma_group* group) { return group ? group->note : ""; }
+
+ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
+                                   const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                   const size_t* chunk_mask_offsets) {
+    MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
+    return enqueue_members(group, column, [&](size_t i, uint64_t* rec) {
+        return ma_i64_sum(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
+                          chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (int64_t*)&rec[0], &rec[1]);
+    });
+}
+
+ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double* const* chunk_data,
+                                   const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                   const size_t* chunk_mask_offsets) {
+    MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
+    return enqueue_members(group, column, [&](size_t i, uint64_t* rec) {
+        return ma_f64_sum_dd(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
+                             chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (double*)&rec[2], (double*)&rec[3], &rec[4]);
+    });
+}
+
+ma_status ma_group_exchange(ma_group* group) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::mutex> lock(group->mu);
+    return exchange_locked(group);
+}
+
+ma_status ma_group_synchronize(ma_group* group) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::mutex> lock(group->mu);
+    return synchronize_locked(group);
+}
+
+ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column, int64_t* out_int_sum,
+                                 uint64_t* out_int_count, double* out_f64_sum, uint64_t* out_f64_count) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
+    MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
+    std::lock_guard<std::mutex> lock(group->mu);
+    const uint64_t* f = finals_of(group, (size_t)member, column);
+    if (out_int_sum) *out_int_sum = (int64_t)f[0];
+    if (out_int_count) *out_int_count = f[1];
+    if (out_f64_sum) memcpy(out_f64_sum, &f[2], 8);
+    if (out_f64_count) *out_f64_count = f[3];
+    return MA_OK;
+}
+
+ma_status ma_group_result(ma_group* group, int32_t column, int64_t* out_int_sum, uint64_t* out_int_count,
+                          double* out_f64_sum, uint64_t* out_f64_count) {
+    return ma_group_member_result(group, 0, column, out_int_sum, out_int_count, out_f64_sum, out_f64_count);
+}
+
 ma_status ma_group_sum_i64(ma_group* group, const int64_t* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, int64_t* out_sum,
                            uint64_t* out_valid_count) {
-    MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    ma_status st = group_run(group, chunk_lens, [&](size_t i, uint64_t* rec) {
-        return ma_i64_sum(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
-                          chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (int64_t*)&rec[0], &rec[2]);
-    });
-    MA_TRY(st);
-    uint64_t sum = 0, cnt = 0;
-    for (size_t i = 0; i < group->ctxs.size(); ++i) {
-        sum += group->records[4 * i];
-        cnt += group->records[4 * i + 2];
-    }
-    if (out_sum) *out_sum = (int64_t)sum;
-    if (out_valid_count) *out_valid_count = cnt;
-    return MA_OK;
+    MA_TRY(ma_group_enqueue_sum_i64(group, 0, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets));
+    MA_TRY(ma_group_exchange(group));
+    MA_TRY(ma_group_synchronize(group));
+    return ma_group_result(group, 0, out_sum, out_valid_count, nullptr, nullptr);
 }
 
 ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_sum,
                            uint64_t* out_valid_count) {
-    MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    ma_status st = group_run(group, chunk_lens, [&](size_t i, uint64_t* rec) {
-        return ma_f64_sum_dd(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
-                             chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (double*)&rec[0], (double*)&rec[1], &rec[2]);
-    });
-    MA_TRY(st);
-    double hi = 0.0, lo = 0.0;
-    uint64_t cnt = 0;
-    for (size_t i = 0; i < group->ctxs.size(); ++i) {
-        double h, l;
-        memcpy(&h, &group->records[4 * i], 8);
-        memcpy(&l, &group->records[4 * i + 1], 8);
-        two_sum_acc(hi, lo, h, l);
-        cnt += group->records[4 * i + 2];
-    }
-    const bool finite = (hi - hi == 0.0) && (lo - lo == 0.0);
-    if (out_sum) *out_sum = finite ? hi + lo : hi;
-    if (out_valid_count) *out_valid_count = cnt;
-    return MA_OK;
+    MA_TRY(ma_group_enqueue_sum_f64(group, 0, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets));
+    MA_TRY(ma_group_exchange(group));
+    MA_TRY(ma_group_synchronize(group));
+    return ma_group_result(group, 0, nullptr, nullptr, out_sum, out_valid_count);
 }
 
 }  // extern "C"

@@ -58,7 +58,7 @@ ma_status pipe_acquire(ma_ctx* ctx, size_t buf_bytes, Pipe** out) {
         MA_HIP(hipStreamSynchronize(ctx->stream));  // an earlier call's kernels may still read the old ring
         pipe_free_buffers(p);
         for (int s = 0; s < kSlots; ++s)
-            for (int i = 0; i < kMaxPipeOperands; ++i) MA_HIP(hipMalloc(&p->buf[s][i], buf_bytes));
+            for (int i = 0; i < kMaxPipeOperands; ++i) MA_HIP(device_malloc(ctx->device, &p->buf[s][i], buf_bytes));
         p->buf_bytes = buf_bytes;
     }
     *out = p;
@@ -224,7 +224,7 @@ extern "C" ma_status ma_ctx_set_staging_tile(ma_ctx* ctx, size_t tile_bytes) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(tile_bytes == 0 || tile_bytes >= ((size_t)1 << 16), MA_ERR_INVALID_ARGUMENT,
                "staging tile must be 0 (whole-operand staging) or at least 64 KiB");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     ctx->staging_tile_bytes = tile_bytes;
     return MA_OK;
 }

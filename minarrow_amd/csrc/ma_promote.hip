@@ -150,7 +150,7 @@ static ma_status promote_impl(ma_ctx* ctx, int kind, const LT* lhs, size_t lhs_l
     MA_REQUIRE(!masked || out_mask_bits, MA_ERR_INVALID_ARGUMENT, "a masked call needs an output bitmap");
     MA_REQUIRE(((uintptr_t)lhs % sizeof(LT)) == 0 && ((uintptr_t)rhs % sizeof(RT)) == 0 && ((uintptr_t)out % sizeof(OT)) == 0,
                MA_ERR_INVALID_ARGUMENT, "a data pointer is not aligned to its element size");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     PromoteArgs<LT, RT, OT> a{};

@@ -1,0 +1,198 @@
+// RCCL loader and the multi-PROCESS communicator of the C ABI (ma_comm_*): one process per GPU, the per-rank
+// reduction records {sum | hi, lo, count} exchanged with one all-gather over xGMI and folded in rank order on every
+// rank. Replaces the combine step of the reference's Rayon reduction (`par_chunks(1 << 20).map(simd_sum).sum()`,
+// benches/benchmark_parallel_simd.rs:81-98) for a row-chunk partition over the GPUs of a node. The single-process
+// form (one host thread driving every GPU) is ma_group_* (ma_group.hip).
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "ma_rccl.hpp"
+
+namespace ma {
+
+namespace {
+std::once_flag g_rccl_once;
+RcclApi g_rccl;
+bool g_rccl_ok = false;
+char g_rccl_err[256] = "";
+
+void load_rccl() {
+    // A name already loaded into the process (PyTorch's bundled build has the same SONAME) resolves to that copy.
+    static const char* kNames[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* name : kNames) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            g_rccl.path = name;
+            break;
+        }
+    }
+    if (!h) {
+        snprintf(g_rccl_err, sizeof(g_rccl_err), "cannot open librccl.so.1: %s", dlerror());
+        return;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) -> void* {
+        void* p = dlsym(h, name);
+        if (!p) {
+            ok = false;
+            snprintf(g_rccl_err, sizeof(g_rccl_err), "librccl has no symbol %s", name);
+        }
+        return p;
+    };
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))sym("ncclGetVersion");
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl_ok = ok;
+}
+}  // namespace
+
+const RcclApi* rccl() {
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl_ok) {
+        set_error("RCCL is not available: %s", g_rccl_err);
+        return nullptr;
+    }
+    return &g_rccl;
+}
+
+ma_status rccl_fail(ncclResult_t r, const char* what, const char* file, int line) {
+    const RcclApi* api = g_rccl_ok ? &g_rccl : nullptr;
+    set_error("RCCL error %d (%s) in %s at %s:%d", (int)r, api ? api->GetErrorString(r) : "?", what, file, line);
+    (void)hipGetLastError();
+    return MA_ERR_DEVICE;
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+struct ma_comm {
+    ma_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+extern "C" {
+
+int32_t ma_rccl_version(void) {
+    const RcclApi* api = rccl();
+    int v = 0;
+    if (!api || api->GetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
+
+ma_status ma_comm_unique_id(uint8_t* out_id) {
+    MA_REQUIRE(out_id != nullptr, MA_ERR_INVALID_ARGUMENT, "out_id is NULL");
+    static_assert(MA_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ma_comm ids carry an ncclUniqueId");
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    MA_NCCL(api, GetUniqueId(&id));
+    memcpy(out_id, id.internal, MA_COMM_ID_BYTES);
+    return MA_OK;
+}
+
+ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, ma_comm** out_comm) {
+    MA_REQUIRE(out_comm != nullptr, MA_ERR_INVALID_ARGUMENT, "out_comm is NULL");
+    *out_comm = nullptr;
+    MA_REQUIRE(ctx != nullptr && id != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or id is NULL");
+    MA_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, MA_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, n_ranks);
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "ma_comm_create");
+    MA_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, MA_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    MA_NCCL(api, CommInitRank(&comm, n_ranks, uid, rank));
+    ma_comm* c = new ma_comm();
+    c->ctx = ctx;
+    c->comm = comm;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    *out_comm = c;
+    return MA_OK;
+}
+
+void ma_comm_destroy(ma_comm* comm) {
+    if (!comm) return;
+    if (comm->comm) {
+        (void)hipSetDevice(comm->ctx->device);
+        (void)hipStreamSynchronize(comm->ctx->stream);
+        const RcclApi* api = rccl();
+        if (api) (void)api->CommDestroy(comm->comm);
+    }
+    delete comm;
+}
+
+int32_t ma_comm_rank(ma_comm* comm) { return comm ? comm->rank : -1; }
+int32_t ma_comm_size(ma_comm* comm) { return comm ? comm->n_ranks : 0; }
+
+ma_status ma_comm_all_gather(ma_comm* comm, const void* send, void* recv, size_t bytes_per_rank) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    if (bytes_per_rank == 0) return MA_OK;
+    MA_REQUIRE(send != nullptr && recv != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_REQUIRE(pointer_kind(send) != kPageable && pointer_kind(recv) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "collectives need device-reachable buffers");
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    ma_ctx* ctx = comm->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "a collective");
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_NCCL(api, AllGather(send, recv, bytes_per_rank, ncclChar, comm->comm, ctx->stream));
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_comm_all_reduce_sum_i64(ma_comm* comm, const int64_t* send, int64_t* recv, size_t count) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    if (count == 0) return MA_OK;
+    MA_REQUIRE(send != nullptr && recv != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_REQUIRE(pointer_kind(send) != kPageable && pointer_kind(recv) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "collectives need device-reachable buffers");
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    ma_ctx* ctx = comm->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "a collective");
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_NCCL(api, AllReduce(send, recv, count, ncclInt64, ncclSum, comm->comm, ctx->stream));  // wrapping, like the scans
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
+                               uint64_t* gathered, uint64_t* out_finals) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_REQUIRE(local_records && gathered && out_finals, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_REQUIRE(slots_per_rank >= 1 && n_columns >= 1, MA_ERR_INVALID_ARGUMENT, "nothing to exchange");
+    MA_REQUIRE(pointer_kind(local_records) != kPageable && pointer_kind(gathered) != kPageable &&
+                   pointer_kind(out_finals) != kPageable,
+               MA_ERR_INVALID_ARGUMENT, "collectives need device-reachable buffers");
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    ma_ctx* ctx = comm->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_NO_CAPTURE(ctx, "a collective");
+    MA_HIP(hipSetDevice(ctx->device));
+    const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
+    MA_NCCL(api, AllGather(local_records, gathered, per_rank_words * 8, ncclChar, comm->comm, ctx->stream));
+    // column c is folded over (rank, slot) in that order: records c, c + n_columns, ...
+    MA_TRY(enqueue_fold_columns(ctx, gathered, (size_t)comm->n_ranks * slots_per_rank, n_columns * kRecordWords, n_columns,
+                                out_finals));
+    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
+}  // extern "C"

@@ -432,7 +432,7 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     MA_REQUIRE(n == 0 || data != nullptr, MA_ERR_INVALID_ARGUMENT, "data is NULL");
     MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "data pointer %p is not aligned to its element size",
                (const void*)data);
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
 
     // The reference gates on the cached null count / all_true_mask before touching a mask
@@ -497,7 +497,7 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     auto route = [&](void* user) -> bool { return user != nullptr && pointer_kind(user) != kPageable; };
     const bool direct_a = route(out_a), direct_b = route(out_b), direct_c = route(out_cnt), direct_m = route(out_mean);
     const bool any_slot = (out_a && !direct_a) || (out_b && !direct_b) || (out_cnt && !direct_c) || (out_mean && !direct_m);
-    MA_REQUIRE(!(ctx->async && any_slot), MA_ERR_INVALID_ARGUMENT,
+    MA_REQUIRE(!(is_async(ctx) && any_slot), MA_ERR_INVALID_ARGUMENT,
                "async mode needs device-reachable (pinned or device) output pointers");
     a.out_a = out_a ? (direct_a ? (uint64_t*)out_a : &slot->a) : nullptr;
     a.out_b = out_b ? (direct_b ? (uint64_t*)out_b : &slot->b) : nullptr;
@@ -508,7 +508,7 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     a.is_signed = is_signed ? 1 : 0;
     MA_TRY(enqueue_sum<T>(ctx, a, masked));
     MA_TRY(end_call(ctx, scope));
-    if (!ctx->async) {
+    if (!is_async(ctx)) {
         if (out_a && !direct_a) memcpy(out_a, &slot->a, 8);
         if (out_b && !direct_b) memcpy(out_b, &slot->b, 8);
         if (out_cnt && !direct_c) *out_cnt = slot->cnt;

@@ -219,7 +219,7 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
         MA_REQUIRE(col_lens[i] == 0 || col_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu data is NULL", i);
         MA_REQUIRE(((uintptr_t)col_data[i] % elem) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu is misaligned", i);
     }
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
@@ -276,8 +276,11 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
 // out = 4 x u64: [0] integer sum, [1] integer count, [2] f64 sum bits, [3] float count.
 // ------------------------------------------------------------------------------------------------
 namespace ma {
+// blockIdx.x = column: its records start kRecordWords further on, its finals 4 words further on.
 __global__ void fold_records_kernel(const uint64_t* __restrict__ rec, size_t n, size_t stride, uint64_t* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    rec += (size_t)blockIdx.x * kRecordWords;
+    out += (size_t)blockIdx.x * 4;
     uint64_t isum = 0, icnt = 0, fcnt = 0;
     double hi = 0.0, lo = 0.0;
     for (size_t r = 0; r < n; ++r) {
@@ -298,6 +301,14 @@ __global__ void fold_records_kernel(const uint64_t* __restrict__ rec, size_t n, 
     out[2] = (uint64_t)__double_as_longlong(total);
     out[3] = fcnt;
 }
+
+ma_status enqueue_fold_columns(ma_ctx* ctx, const uint64_t* rec, size_t n_records, size_t stride_words, size_t n_columns,
+                               uint64_t* out) {
+    if (n_columns == 0) return MA_OK;
+    hipLaunchKernelGGL(fold_records_kernel, dim3((unsigned)n_columns), dim3(64), 0, ctx->stream, rec, n_records, stride_words, out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
 }  // namespace ma
 
 extern "C" ma_status ma_fold_sum_records(ma_ctx* ctx, const uint64_t* records, size_t n_records, size_t stride_words,
@@ -306,15 +317,13 @@ extern "C" ma_status ma_fold_sum_records(ma_ctx* ctx, const uint64_t* records, s
     MA_REQUIRE(records != nullptr && out4 != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
     MA_REQUIRE(stride_words >= 5, MA_ERR_INVALID_ARGUMENT, "a record has 5 words; stride_words = %zu", stride_words);
     MA_REQUIRE(((uintptr_t)records & 7) == 0 && ((uintptr_t)out4 & 7) == 0, MA_ERR_INVALID_ARGUMENT, "misaligned buffer");
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     const void* r = nullptr;
     void* o = nullptr;
     MA_TRY(scope.in(records, n_records * stride_words * 8, &r));
     MA_TRY(scope.out(out4, 32, &o));
-    hipLaunchKernelGGL(fold_records_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)r, n_records, stride_words,
-                       (uint64_t*)o);
-    MA_HIP(hipGetLastError());
+    MA_TRY(enqueue_fold_columns(ctx, (const uint64_t*)r, n_records, stride_words, 1, (uint64_t*)o));
     return end_call(ctx, scope);
 }

@@ -23,7 +23,9 @@ ma_status grow_dev(void** p, size_t* cap, size_t need) {
     if (*p) MA_HIP(hipFree(*p));
     *p = nullptr;
     size_t bytes = need + need / 2 + 4096;
-    MA_HIP(hipMalloc(p, bytes));
+    int dev = 0;
+    MA_HIP(hipGetDevice(&dev));
+    MA_HIP(device_malloc(dev, p, bytes));
     *cap = bytes;
     return MA_OK;
 }
@@ -87,7 +89,7 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
     void* d_mask = nullptr;
     size_t mask_cap = 0;
     uint64_t* record = nullptr;  // pinned: [0] sum / hi, [1] lo, [2] count — written by the batch's kernel
-    bool pending = false, was_async = false;
+    bool pending = false;
     double hi = 0.0, lo = 0.0;
     uint64_t isum = 0, count = 0, rows = 0, batches = 0;
 
@@ -109,18 +111,16 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
         if (d_values) (void)hipFree(d_values);
         if (d_mask) (void)hipFree(d_mask);
         if (record) (void)hipHostFree(record);
-        (void)ma_ctx_set_async(ctx, was_async ? 1 : 0);
     };
 
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        MA_NO_CAPTURE(ctx, "ma_sum_arrow_stream");
-        was_async = ctx->async;
-    }
+    // One lane of the context for the whole stream (the per-batch reductions re-use it); they only enqueue (ma::NoSync)
+    // — the context's user-visible mode is never touched, so other threads sharing it are unaffected.
+    MA_ENTER(ctx);
+    NoSync enqueue_only;
+    MA_NO_CAPTURE(ctx, "ma_sum_arrow_stream");
     MA_HIP(hipSetDevice(ctx->device));
     hipError_t he = hipHostMalloc((void**)&record, 64, hipHostMallocPortable | hipHostMallocMapped);
     if (he != hipSuccess) return hip_fail(he, "hipHostMalloc(record)", __FILE__, __LINE__);
-    (void)ma_ctx_set_async(ctx, 1);
 
     for (;;) {
         struct ArrowArray batch;

@@ -172,7 +172,7 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     constexpr int U = 4;
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * U * kWaves;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "route_super_array_broadcast (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);

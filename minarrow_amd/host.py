@@ -250,6 +250,13 @@ class Context:
             buf.upload(arr)
         return buf
 
+    def dev_copy(self, dst, src, nbytes: int) -> None:
+        """Device-to-device copy through the runtime (hipMemcpyAsync on the context's stream)."""
+        ffi.check(self.lib.ma_dev_copy(self.handle, addr_of(dst), addr_of(src), int(nbytes)))
+
+    def dev_memset(self, dst, byte_value: int, nbytes: int) -> None:
+        ffi.check(self.lib.ma_dev_memset(self.handle, addr_of(dst), int(byte_value), int(nbytes)))
+
     # -- synthetic inputs ------------------------------------------------------------------------
     def synth_iota(self, tag: str, dst, n: int, start: int = 0) -> None:
         fn = getattr(self.lib, f"ma_synth_iota_{tag}")
@@ -544,6 +551,124 @@ class Context:
         ffi.check(self.lib.ma_sum_arrow_stream(self.handle, int(stream_ptr), int(column), C.addressof(f), C.addressof(i),
                                                C.addressof(c), C.addressof(r), C.addressof(b)))
         return f.value, i.value, int(c.value), int(r.value), int(b.value)
+
+
+class Group:
+    """One process driving several GPUs (ma_group_*): member i scans chunk i on device i, one exchange ends the
+    reduction. exchange = "rccl" (ncclCommInitAll + grouped all-gather + device fold), "rccl-or-host", or "host"."""
+
+    MAX_COLUMNS = 16
+
+    def __init__(self, devices, exchange: str = "host"):
+        self.lib = ffi.load_library()
+        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3}[exchange]
+        n = len(devices)
+        devs = (C.c_int32 * n)(*[int(d) for d in devices])
+        h = C.c_void_p()
+        ffi.check(self.lib.ma_group_create_ex(C.cast(devs, C.c_void_p), n, flags, C.byref(h)))
+        self.handle = h.value
+        self.size = n
+        self.devices = [int(d) for d in devices]
+
+    @property
+    def exchange_kind(self) -> str:
+        return "rccl" if self.lib.ma_group_exchange_kind(self.handle) == 1 else "host"
+
+    @property
+    def exchange_note(self) -> str:
+        s = self.lib.ma_group_exchange_note(self.handle)
+        return s.decode() if s else ""
+
+    def member_ctx(self, i: int) -> "Context":
+        """A non-owning Context over member i's ma_ctx (allocate / fill that device's chunk through it)."""
+        c = Context.__new__(Context)
+        c.lib = self.lib
+        c.handle = self.lib.ma_group_ctx(self.handle, int(i))
+        c.device = self.devices[i]
+        c.close = lambda: None  # the group owns it
+        return c
+
+    def _tables(self, chunks, lens, masks, mask_offsets):
+        k = self.size
+        assert len(chunks) == k and len(lens) == k
+        data = (C.c_void_p * k)(*[addr_of(c) or None for c in chunks])
+        ln = (C.c_size_t * k)(*[int(n) for n in lens])
+        m = (C.c_void_p * k)(*[addr_of(x) or None for x in masks]) if masks is not None else None
+        o = (C.c_size_t * k)(*[int(x) for x in mask_offsets]) if mask_offsets is not None else None
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        return cast(data), cast(ln), cast(m), cast(o), (data, ln, m, o)
+
+    def enqueue_sum(self, tag: str, column: int, chunks, lens, masks=None, mask_offsets=None) -> None:
+        d, l, m, o, keep = self._tables(chunks, lens, masks, mask_offsets)
+        ffi.check(getattr(self.lib, f"ma_group_enqueue_sum_{tag}")(self.handle, int(column), d, l, m, o))
+
+    def exchange(self) -> None:
+        ffi.check(self.lib.ma_group_exchange(self.handle))
+
+    def synchronize(self) -> None:
+        ffi.check(self.lib.ma_group_synchronize(self.handle))
+
+    def result(self, column: int = 0, member: int = 0):
+        """(int sum, int count, f64 sum, f64 count) of `column` as GPU `member` holds them (after synchronize)."""
+        i, ic, f, fc = C.c_int64(), C.c_uint64(), C.c_double(), C.c_uint64()
+        ffi.check(self.lib.ma_group_member_result(self.handle, int(member), int(column), C.addressof(i), C.addressof(ic),
+                                                  C.addressof(f), C.addressof(fc)))
+        return int(i.value), int(ic.value), float(f.value), int(fc.value)
+
+    def sum(self, tag: str, chunks, lens, masks=None, mask_offsets=None):
+        """Synchronous one-call form: (sum, valid count)."""
+        d, l, m, o, keep = self._tables(chunks, lens, masks, mask_offsets)
+        cnt = C.c_uint64()
+        out = C.c_int64() if tag == "i64" else C.c_double()
+        ffi.check(getattr(self.lib, f"ma_group_sum_{tag}")(self.handle, d, l, m, o, C.addressof(out), C.addressof(cnt)))
+        return out.value, int(cnt.value)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.ma_group_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Comm:
+    """One rank of a multi-process RCCL communicator bound to a Context (ma_comm_*)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        ffi.check(ffi.load_library().ma_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", unique_id: bytes, rank: int, n_ranks: int):
+        assert len(unique_id) == self.ID_BYTES
+        self.ctx, self.lib = ctx, ctx.lib
+        buf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        ffi.check(self.lib.ma_comm_create(ctx.handle, C.cast(buf, C.c_void_p), int(rank), int(n_ranks), C.byref(h)))
+        self.handle = h.value
+        self.rank, self.size = int(rank), int(n_ranks)
+
+    def all_gather(self, send, recv, bytes_per_rank: int) -> None:
+        ffi.check(self.lib.ma_comm_all_gather(self.handle, addr_of(send), addr_of(recv), int(bytes_per_rank)))
+
+    def all_reduce_sum_i64(self, send, recv, count: int) -> None:
+        ffi.check(self.lib.ma_comm_all_reduce_sum_i64(self.handle, addr_of(send), addr_of(recv), int(count)))
+
+    def sum_exchange(self, local_records, slots_per_rank: int, n_columns: int, gathered, out_finals) -> None:
+        ffi.check(self.lib.ma_comm_sum_exchange(self.handle, addr_of(local_records), int(slots_per_rank), int(n_columns),
+                                                addr_of(gathered), addr_of(out_finals)))
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.ma_comm_destroy(self.handle)
+            self.handle = None
 
 
 def arena_layout(elem_sizes, has_nulls, n_rows: int):

@@ -1,6 +1,9 @@
-"""Single-process multi-GPU group API (ma_group_*): row chunks on several contexts, folded on the host. The GPU
-boxes of the test pool have one device, so the members share device 0 (independent contexts and streams); the
-partition + fold logic is the same for 8 devices."""
+"""Single-process multi-GPU group API (ma_group_*) and the multi-process communicator (ma_comm_*).
+
+Host exchange: members may share a device (independent contexts and streams), so the partition + fold logic is
+covered with 1, 3 and 8 members on the pool's one-GPU boxes. RCCL exchange: needs distinct devices — the test takes
+min(device_count, 8) of them (one on this pool: ncclCommInitAll, the grouped all-gather and the device fold all run, with
+one rank; on an 8-GPU node the same test covers 8)."""
 import ctypes as C
 import math
 
@@ -83,3 +86,115 @@ def test_device_fold_of_records_equals_the_host_fold(ctx):
         drec, dout = ctx.to_device(rec), ctx.alloc(32)
         ctx.fold_sum_records(drec, world, 8, dout)
         np.testing.assert_array_equal(dout.download(np.uint64, 4), out)
+
+
+def _chunk_tables(ctxs, ints, flts, bits, chunks):
+    """Uploads chunk i to member i's device; returns the per-member buffers."""
+    di = [c.to_device(ints[a:b], 64) for c, (a, b) in zip(ctxs, chunks)]
+    df = [c.to_device(flts[a:b], 64) for c, (a, b) in zip(ctxs, chunks)]
+    dm = [c.to_device(bits, 16) for c in ctxs]  # every device holds the un-windowed validity buffer
+    return di, df, dm
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "host"])
+def test_group_over_distinct_devices(oracle, exchange):
+    """One member per visible GPU (up to 8). With exchange = "rccl": ncclCommInitAll + grouped all-gather + device fold —
+    every member must hold the same finals."""
+    from minarrow_amd.host import Group
+
+    n_dev = min(ffi.device_count(), 8)
+    assert n_dev >= 1
+    n = 3_000_017
+    rng = np.random.default_rng(11)
+    ints = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+    flts = rng.standard_normal(n) * 1e12
+    bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
+    with Group(list(range(n_dev)), exchange=exchange) as g:
+        assert g.exchange_kind == exchange and g.exchange_note == ""
+        ctxs = [g.member_ctx(i) for i in range(n_dev)]
+        chunks = row_chunks(n, n_dev)
+        di, df, dm = _chunk_tables(ctxs, ints, flts, bits, chunks)
+        lens = [b - a for a, b in chunks]
+        offs = [a for a, _ in chunks]
+        # several steps enqueued back to back, two columns sharing one exchange, one synchronize
+        for _ in range(3):
+            g.enqueue_sum("i64", 0, di, lens)
+            g.enqueue_sum("f64", 0, df, lens)
+            g.enqueue_sum("i64", 5, di, lens, dm, offs)
+            g.enqueue_sum("f64", 5, df, lens, dm, offs)
+            g.exchange()
+        g.synchronize()
+        valid = np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+        for m in range(n_dev):
+            isum, icnt, fsum, fcnt = g.result(0, m)
+            assert (isum, icnt) == (oracle.sum_scalar(ints), n)
+            exact = math.fsum(flts.tolist())
+            assert fcnt == n and abs(fsum - exact) <= math.ulp(exact)
+            isum, icnt, fsum, fcnt = g.result(5, m)
+            assert (isum, icnt) == oracle.masked_sum(ints, bits, 0)
+            exact = math.fsum(flts[valid].tolist())
+            assert fcnt == int(valid.sum()) and abs(fsum - exact) <= math.ulp(exact)
+            assert g.result(0, m) == g.result(0, 0) and g.result(5, m) == g.result(5, 0)
+        # the synchronous one-call forms
+        assert g.sum("i64", di, lens) == (oracle.sum_scalar(ints), n)
+        f, c = g.sum("f64", df, lens, dm, offs)
+        assert c == int(valid.sum()) and abs(f - exact) <= math.ulp(exact)
+        for b in di + df + dm:
+            b.free()
+
+
+def test_group_rccl_needs_distinct_devices_and_can_fall_back():
+    from minarrow_amd.host import Group
+
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        Group([0, 0], exchange="rccl")
+    assert e.value.status == ffi.MA_ERR_UNSUPPORTED and "distinct devices" in e.value.message
+    with Group([0, 0], exchange="rccl-or-host") as g:
+        assert g.exchange_kind == "host" and "distinct devices" in g.exchange_note
+        ctx0 = g.member_ctx(0)
+        a = np.arange(1000, dtype=np.int64)
+        d = ctx0.to_device(a, 64)
+        assert g.sum("i64", [d, d.offset(4000)], [500, 500]) == (int(a.sum()), 1000)
+        d.free()
+
+
+def test_comm_one_rank(ctx, oracle):
+    """ma_comm_*: ncclGetUniqueId + ncclCommInitRank with one rank on this box's GPU, the bare collectives and the
+    record exchange (all-gather + ordered fold)."""
+    from minarrow_amd.host import Comm
+
+    lib = ffi.load_library()
+    assert lib.ma_rccl_version() >= 20000
+    comm = Comm(ctx, Comm.unique_id(), 0, 1)
+    try:
+        assert (lib.ma_comm_rank(comm.handle), lib.ma_comm_size(comm.handle)) == (0, 1)
+        src = np.arange(256, dtype=np.int64) - 77
+        d_src, d_dst = ctx.to_device(src), ctx.alloc(src.nbytes)
+        comm.all_gather(d_src, d_dst, src.nbytes)
+        np.testing.assert_array_equal(d_dst.download(np.int64, src.size), src)
+        ctx.dev_memset(d_dst, 0, src.nbytes)
+        comm.all_reduce_sum_i64(d_src, d_dst, src.size)
+        np.testing.assert_array_equal(d_dst.download(np.int64, src.size), src)
+        # two slots x three columns of records: the kernels write them, the exchange folds column c over the slots
+        n = 100_003
+        rng = np.random.default_rng(3)
+        ints = rng.integers(-(1 << 60), 1 << 60, size=n, dtype=np.int64)
+        flts = rng.standard_normal(n) * 1e6
+        di, df = ctx.to_device(ints, 64), ctx.to_device(flts, 64)
+        slots, cols = 2, 3
+        local, gathered, finals = ctx.alloc(slots * cols * 64), ctx.alloc(slots * cols * 64), ctx.alloc(cols * 32)
+        ctx.dev_memset(local, 0, slots * cols * 64)
+        half = (n // 2 // 64) * 64
+        for slot, (a, b) in enumerate(((0, half), (half, n))):
+            r = local.ptr + 64 * (slot * cols + 1)  # column 1
+            ctx.sum_into("i64", di.offset(a * 8), b - a, out_sum=r, out_count=r + 8)
+            ctx.sum_into("f64", df.offset(a * 8), b - a, out_sum=r + 16, dd_lo=r + 24, out_count=r + 32)
+        comm.sum_exchange(local, slots, cols, gathered, finals)
+        f = finals.download(np.uint64, cols * 4).reshape(cols, 4)
+        assert int(f[1][0]) == oracle.sum_scalar(ints) & ((1 << 64) - 1) and int(f[1][1]) == n and int(f[1][3]) == n
+        exact = math.fsum(flts.tolist())
+        assert abs(float(f[1][2:3].view(np.float64)[0]) - exact) <= math.ulp(exact)
+        assert not f[0].any() and not f[2].any()  # untouched columns fold to zero
+        np.testing.assert_array_equal(gathered.download(np.uint64, slots * cols * 8), local.download(np.uint64, slots * cols * 8))
+    finally:
+        comm.close()
