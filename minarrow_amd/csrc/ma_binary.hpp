@@ -177,6 +177,10 @@ struct BinArgs {
     const uint64_t* words;  // input validity (8-byte aligned base) or nullptr
     size_t bit_off;         // bit index of row 0 relative to `words`
     size_t last_word;       // last word index holding a window bit
+    const uint64_t* words2; // optional SECOND input validity, combined with the first per row: apply_datetime's AND
+    size_t bit_off2;        //   (merge_bitmasks_to_new, dispatch.rs:336-341) or the chunk pair's OR (Bitmask::union,
+    size_t last_word2;      //   broadcast/super_array.rs:224) — fused here instead of a merged temporary
+    int combine_and;        // 1: words & words2, 0: words | words2
     uint64_t* out_words;    // output validity words (data-dependent validity only) or nullptr
     uint32_t* flags;        // device latch: bit 0 = integer divide by zero seen in a dense kernel
     int op;                 // row kernel: runtime ArithmeticOperator
@@ -214,13 +218,20 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
         }
-        uint64_t aw = 0;
-        if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
+        RunWords<MASKED ? WPT : 1> aw;
+        if constexpr (MASKED) {
+            aw.load(a.words, a.bit_off + row0, a.last_word, lane);
+            if (a.words2) {  // wave-uniform
+                RunWords<WPT> bw;
+                bw.load(a.words2, a.bit_off2 + row0, a.last_word2, lane);
+                aw.combine(bw, a.combine_and != 0);
+            }
+        }
         V* __restrict__ o = (V*)(a.out + row0) + lane;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             unsigned bits = ~0u;
-            if constexpr (MASKED) bits = lane_bits<R>(aw, u, lane);
+            if constexpr (MASKED) bits = aw.template bits<R>(u, lane);
             unsigned out_bits = bits;
             V r;
 #pragma unroll
@@ -270,13 +281,13 @@ __global__ __launch_bounds__(kBlock) void fma_vec_kernel(BinArgs<T> a) {
         for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) vc[u] = load16u<V, true>(c + (size_t)u * 64);
-        uint64_t aw = 0;
-        if constexpr (MASKED) aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
+        RunWords<MASKED ? WPT : 1> aw;
+        if constexpr (MASKED) aw.load(a.words, a.bit_off + row0, a.last_word, lane);
         V* __restrict__ o = (V*)(a.out + row0) + lane;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             unsigned bits = ~0u;
-            if constexpr (MASKED) bits = lane_bits<R>(aw, u, lane);
+            if constexpr (MASKED) bits = aw.template bits<R>(u, lane);
             V r;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -313,7 +324,13 @@ __global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t
         bool valid = in_range;
         bool dz = false;
         if (in_range) {
-            if constexpr (MASKED) valid = row_bit(a.words, a.bit_off + row) != 0;
+            if constexpr (MASKED) {
+                valid = row_bit(a.words, a.bit_off + row) != 0;
+                if (a.words2) {
+                    const bool v2 = row_bit(a.words2, a.bit_off2 + row) != 0;
+                    valid = a.combine_and ? (valid && v2) : (valid || v2);
+                }
+            }
             T v;
             if constexpr (FMA) {
                 v = Elem<T>::fma3(a.lhs[row], a.rhs[row], a.acc[row]);
@@ -342,6 +359,9 @@ __global__ __launch_bounds__(kBlock) void binary_row_kernel(BinArgs<T> a, size_t
 
 // Output validity = input validity window re-based to bit 0 (bits >= n zero). Defined in ma_bitmask.hip.
 ma_status launch_mask_copy(ma_ctx* ctx, const uint64_t* words, size_t bit_off, size_t n, uint64_t* out_words);
+// Output validity = (window 1) AND / OR (window 2), re-based to bit 0 (bits >= n zero). Defined in ma_bitmask.hip.
+ma_status launch_mask_combine(ma_ctx* ctx, const uint64_t* w1, size_t off1, const uint64_t* w2, size_t off2, size_t n,
+                              bool is_and, uint64_t* out_words);
 
 // ------------------------------------------------------------------------------------------------
 // Host dispatch
@@ -360,35 +380,25 @@ struct BinaryCall {
     T scalar = T();
     const uint8_t* mask_bits = nullptr;
     size_t mask_bit_offset = 0;
+    const uint8_t* mask2_bits = nullptr;  // optional second validity, combined per row with the first (AND / OR)
+    size_t mask2_bit_offset = 0;
+    bool combine_and = true;
     T* out = nullptr;
     uint8_t* out_mask_bits = nullptr;
 };
 
-// Largest unroll a type can use: the masked kernels need R * UNROLL validity words <= 64 per wave run (a wave loads its
-// run's words with one lane each); dense kernels have no such limit.
+// Unroll of the vec kernel: 8 or 4 sixteen-byte accesses per operand per lane. Masked kernels read R * UNROLL validity
+// words per wave run (RunWords: up to 128, i.e. 1-byte types at 8 — two wave instructions).
 template <typename T>
 constexpr int clamp_unroll(int unroll, bool masked) {
-    constexpr int R = 16 / (int)sizeof(T);
-    if (!masked) return unroll == 8 ? 8 : 4;
-    if (R * 4 > 64) return 2;
-    if (unroll == 8 && R * 8 > 64) return 4;    // 1-byte types: 16 rows per lane x 4 = 64 validity words per run
+    (void)masked;
     return unroll == 8 ? 8 : 4;
 }
 
 template <typename T, int OP, int KIND, bool MASKED>
 static void launch_vec(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll) {
-    constexpr int R = 16 / (int)sizeof(T);
-    if constexpr (MASKED && R * 4 > 64) {
-        hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    } else {
-        if (unroll == 8) {
-            if constexpr (!MASKED || R * 8 <= 64) {
-                hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-                return;
-            }
-        }
-        hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    }
+    if (unroll == 8) hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
 template <typename T, int OP, bool MASKED>
@@ -421,6 +431,7 @@ ma_status enqueue_binary(ma_ctx* ctx, BinArgs<T> a, bool fma, bool masked, bool 
     constexpr bool kInt = std::is_integral<T>::value;
     const size_t n = a.n;
     if (masked) a.last_word = (a.bit_off + n - 1) >> 6;
+    if (masked && a.words2) a.last_word2 = (a.bit_off2 + n - 1) >> 6;
     const bool int_div = kInt && !fma &&
                          (a.op == MA_OP_DIVIDE || a.op == MA_OP_REMAINDER || a.op == MA_OP_FLOORDIV);
     const bool ballot = masked && int_div;  // output validity depends on the data: the kernels write out_words themselves
@@ -465,7 +476,10 @@ ma_status enqueue_binary(ma_ctx* ctx, BinArgs<T> a, bool fma, bool masked, bool 
     a.ballot_mask = ballot ? 1 : 0;
     const size_t tail_start = head + n_tiles * tile_rows;  // ballot mode: head == 0 and this is a multiple of 64
 
-    if (masked && !ballot && copy_mask) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+    if (masked && !ballot && copy_mask) {
+        if (a.words2) MA_TRY(launch_mask_combine(ctx, a.words, a.bit_off, a.words2, a.bit_off2, n, a.combine_and != 0, a.out_words));
+        else MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+    }
     if (n_tiles) {
         int grid = grid_for(ctx, n_tiles, bpc);
         if (fma) {
@@ -539,6 +553,11 @@ struct TileCall {
             a.words = t.base.words + (bit >> 6);
             a.bit_off = bit & 63;
             a.out_words = t.base.out_words + (row0 >> 6);
+            if (t.base.words2) {
+                const size_t bit2 = t.base.bit_off2 + row0;
+                a.words2 = t.base.words2 + (bit2 >> 6);
+                a.bit_off2 = bit2 & 63;
+            }
         }
         return enqueue_binary<T>(t.ctx, a, t.fma, t.masked, false);
     }
@@ -603,8 +622,13 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
         if (any) {
             if (masked) {
                 MA_TRY(scope.in_mask(c.mask_bits, c.mask_bit_offset, n, &a.words, &a.bit_off));
+                if (c.mask2_bits) MA_TRY(scope.in_mask(c.mask2_bits, c.mask2_bit_offset, n, &a.words2, &a.bit_off2));
+                a.combine_and = c.combine_and ? 1 : 0;
                 MA_TRY(scope.out_mask(c.out_mask_bits, n, &a.out_words));
-                if (!int_div) MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+                if (!int_div) {
+                    if (a.words2) MA_TRY(launch_mask_combine(ctx, a.words, a.bit_off, a.words2, a.bit_off2, n, c.combine_and, a.out_words));
+                    else MA_TRY(launch_mask_copy(ctx, a.words, a.bit_off, n, a.out_words));
+                }
             }
             TileCall<T> call{ctx, a, c.fma, masked};
             MA_TRY(run_tiled(ctx, n, tile_rows, ops, 4, &TileCall<T>::run, &call));
@@ -631,6 +655,8 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
     a.out = (T*)po;
     if (masked) {
         MA_TRY(scope.in_mask(c.mask_bits, c.mask_bit_offset, n, &a.words, &a.bit_off));
+        if (c.mask2_bits) MA_TRY(scope.in_mask(c.mask2_bits, c.mask2_bit_offset, n, &a.words2, &a.bit_off2));
+        a.combine_and = c.combine_and ? 1 : 0;
         MA_TRY(scope.out_mask(c.out_mask_bits, n, &a.out_words));
     }
     MA_TRY(enqueue_binary<T>(ctx, a, c.fma, masked, true));
@@ -672,6 +698,21 @@ ma_status binary_impl(ma_ctx* ctx, const BinaryCall<T>& c) {
         c.op = op; c.kind = ::ma::kSA; c.rhs = rhs; c.rhs_len = rhs_len; c.scalar = scalar;                           \
         c.mask_bits = mask_bits; c.mask_bit_offset = mask_bit_offset; c.out = out; c.out_mask_bits = out_mask_bits;   \
         return ::ma::binary_impl<T>(ctx, c);                                                                          \
+    }
+
+// apply_datetime's shape (dispatch.rs:309-372): both operands carry their own validity, the kernel combines them per
+// row in registers instead of materialising merge_bitmasks_to_new's result. Internal (ma_datetime.hip), not exported.
+#define MA_DEFINE_APPLY_TWO_MASKS(TAG, T)                                                                             \
+    namespace ma {                                                                                                    \
+    ma_status apply_int_two_masks_##TAG(ma_ctx* ctx, const T* lhs, size_t lhs_len, const T* rhs, size_t rhs_len,      \
+                                        int32_t op, const uint8_t* mask1, size_t off1, const uint8_t* mask2,          \
+                                        size_t off2, bool combine_and, T* out, uint8_t* out_mask_bits) {             \
+        BinaryCall<T> c;                                                                                              \
+        c.op = op; c.kind = kAA; c.lhs = lhs; c.lhs_len = lhs_len; c.rhs = rhs; c.rhs_len = rhs_len;                  \
+        c.mask_bits = mask1; c.mask_bit_offset = off1; c.mask2_bits = mask2; c.mask2_bit_offset = off2;               \
+        c.combine_and = combine_and; c.out = out; c.out_mask_bits = out_mask_bits;                                    \
+        return binary_impl<T>(ctx, c);                                                                                \
+    }                                                                                                                 \
     }
 
 #define MA_DEFINE_APPLY_FMA(TAG, T)                                                                                   \

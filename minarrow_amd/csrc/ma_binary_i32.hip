@@ -2,3 +2,4 @@
 #include "ma_binary.hpp"
 
 MA_DEFINE_APPLY(int, i32, int32_t)
+MA_DEFINE_APPLY_TWO_MASKS(i32, int32_t)

@@ -2,3 +2,4 @@
 #include "ma_binary.hpp"
 
 MA_DEFINE_APPLY(int, u32, uint32_t)
+MA_DEFINE_APPLY_TWO_MASKS(u32, uint32_t)

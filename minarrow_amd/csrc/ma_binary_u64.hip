@@ -2,3 +2,4 @@
 #include "ma_binary.hpp"
 
 MA_DEFINE_APPLY(int, u64, uint64_t)
+MA_DEFINE_APPLY_TWO_MASKS(u64, uint64_t)

@@ -321,6 +321,17 @@ static ma_status launch_words(ma_ctx* ctx, const BitArgs& a) {
     return MA_OK;
 }
 
+// Output validity of an op with two input validities (ma_binary.hpp): (window 1) AND / OR (window 2), re-based to bit 0.
+ma_status launch_mask_combine(ma_ctx* ctx, const uint64_t* w1, size_t off1, const uint64_t* w2, size_t off2, size_t n,
+                              bool is_and, uint64_t* out_words) {
+    if (n == 0) return MA_OK;
+    BitArgs a{};
+    fill_window(a, w1, off1, w2, off2, n);
+    a.out = out_words;
+    a.op = is_and ? kBitAnd : kBitOr;
+    return launch_words(ctx, a);
+}
+
 // One entry for every word-producing op. `lhs_round` / `rhs_round`: the reference addresses these windows at
 // byte (8) or word (64) granularity; the offset is rounded DOWN accordingly so results match it bit for bit.
 static ma_status words_op(ma_ctx* ctx, int op, const uint8_t* lhs, size_t lo, const uint8_t* rhs, size_t ro, size_t len,

@@ -646,8 +646,9 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         return s;
     };
     if ((e = device_malloc(device, (void**)&c->partials, sizeof(Partial) * kMaxGrid)) != hipSuccess) return fail(e, "hipMalloc(partials)");
-    if ((e = device_malloc(device, (void**)&c->ticket, 256)) != hipSuccess) return fail(e, "hipMalloc(ticket)");
-    if ((e = hipMemset(c->ticket, 0, 256)) != hipSuccess) return fail(e, "hipMemset(ticket)");
+    // one zeroed block: [0] reduction ticket, [64 B] dev_flags, [128 B] bitmask scan accumulator, [256 B ...] 8 ticket shards
+    if ((e = device_malloc(device, (void**)&c->ticket, 1024)) != hipSuccess) return fail(e, "hipMalloc(ticket)");
+    if ((e = hipMemset(c->ticket, 0, 1024)) != hipSuccess) return fail(e, "hipMemset(ticket)");
     c->dev_flags = c->ticket + 16;  // same zeroed allocation, a different 64-B line
     if ((e = hipHostMalloc((void**)&c->result, sizeof(ResultSlot) * 4, hipHostMallocDefault)) != hipSuccess)
         return fail(e, "hipHostMalloc(result)");

@@ -2,9 +2,23 @@
 // "All other ops delegate directly to the integer kernels": the result validity is merge_bitmasks_to_new(lhs mask,
 // rhs mask, len) (per-row AND from bit 0 — the reference does NOT window the masks by the view offset, only the data:
 // dispatch.rs:321-324), then the masked or dense integer kernel runs on data[off .. off+len].
+// Here the merge is fused: the integer kernel reads BOTH validity bitmaps and ANDs them in registers (BinArgs::words2,
+// ma_binary.hpp); the output validity is one word-wise AND launch (data-dependent validity — Div/Rem/FloorDiv — comes
+// out of the kernel itself). No merged temporary, no allocation.
 #include "ma_common.hpp"
 
 using namespace ma;
+
+namespace ma {
+#define MA_DECLARE_TWO_MASKS(TAG, T)                                                                                \
+    ma_status apply_int_two_masks_##TAG(ma_ctx* ctx, const T* lhs, size_t lhs_len, const T* rhs, size_t rhs_len,    \
+                                        int32_t op, const uint8_t* mask1, size_t off1, const uint8_t* mask2,        \
+                                        size_t off2, bool combine_and, T* out, uint8_t* out_mask_bits);
+MA_DECLARE_TWO_MASKS(i32, int32_t)
+MA_DECLARE_TWO_MASKS(u32, uint32_t)
+MA_DECLARE_TWO_MASKS(i64, int64_t)
+MA_DECLARE_TWO_MASKS(u64, uint64_t)
+}  // namespace ma
 
 #define MA_DEFINE_DATETIME(TAG, T)                                                                                    \
     extern "C" ma_status ma_apply_datetime_##TAG(ma_ctx* ctx, const T* lhs_data, size_t lhs_offset, size_t lhs_len,    \
@@ -24,14 +38,11 @@ using namespace ma;
         MA_REQUIRE(out_mask_bits != nullptr || lhs_len == 0, MA_ERR_INVALID_ARGUMENT,                                  \
                    "an input carries nulls but out_mask_bits is NULL");                                               \
         if (lhs_len == 0) return MA_OK;                                                                               \
-        void* merged = nullptr;                                                                                       \
-        MA_TRY(ma_dev_alloc(ctx, ((lhs_len + 63) / 64) * 8 + 8, &merged));                                             \
-        int32_t some = 0;                                                                                             \
-        ma_status st = ma_merge_bitmasks_to_new(ctx, lhs_mask_bits, rhs_mask_bits, lhs_len, (uint8_t*)merged, &some);  \
-        if (st == MA_OK)                                                                                              \
-            st = ma_apply_int_##TAG(ctx, l, lhs_len, r, rhs_len, op, (const uint8_t*)merged, 0, out, out_mask_bits);   \
-        ma_status fr = ma_dev_free(ctx, merged);                                                                      \
-        return st != MA_OK ? st : fr;                                                                                 \
+        if (lhs_mask_bits && rhs_mask_bits)                                                                           \
+            return apply_int_two_masks_##TAG(ctx, l, lhs_len, r, rhs_len, op, lhs_mask_bits, 0, rhs_mask_bits, 0,      \
+                                             true, out, out_mask_bits);                                               \
+        return ma_apply_int_##TAG(ctx, l, lhs_len, r, rhs_len, op, lhs_mask_bits ? lhs_mask_bits : rhs_mask_bits, 0,   \
+                                  out, out_mask_bits);                                                                \
     }
 
 MA_DEFINE_DATETIME(i32, int32_t)

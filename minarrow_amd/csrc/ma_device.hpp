@@ -104,6 +104,11 @@ __device__ __forceinline__ uint64_t load_agent(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Agent-scope relaxed store: write-through to device scope (global_store ... sc1), dropped from this XCD's L2.
+__device__ __forceinline__ void store_agent(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Validity words for one wave's contiguous run of rows.
 //
@@ -126,6 +131,51 @@ __device__ __forceinline__ uint64_t load_run_words(const uint64_t* __restrict__ 
     }
     return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
 }
+
+// The same for runs of up to 128 words (1-byte types at 8 loads per lane: 16 rows x 8 x 64 lanes = 128 validity
+// words): lane k holds run-words k and 64 + k, fetched by two wave instructions. word(i) hands every lane run-word i
+// when i is wave-uniform, or each lane its own word when it is not.
+template <int WPT>
+struct RunWords {
+    static_assert(WPT >= 1 && WPT <= 128, "a wave covers at most 128 validity words per run");
+    static constexpr int N = (WPT + 63) / 64;
+    uint64_t w[N];
+
+    __device__ __forceinline__ void load(const uint64_t* __restrict__ words, size_t bit0, size_t last_word, unsigned lane) {
+        const size_t w0 = bit0 >> 6;
+        const unsigned sh = (unsigned)(bit0 & 63);
+        uint64_t raw[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const size_t idx = w0 + (size_t)(64 * j) + lane;
+            raw[j] = ((unsigned)(64 * j) + lane <= (unsigned)WPT && idx <= last_word) ? words[idx] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            uint64_t nx = (uint64_t)__shfl_down((unsigned long long)raw[j], 1, 64);
+            if (j + 1 < N) {
+                const uint64_t first_of_next = (uint64_t)__shfl((unsigned long long)raw[j + 1 < N ? j + 1 : j], 0, 64);
+                if (lane == 63) nx = first_of_next;
+            } else if (WPT == 64 * N) {
+                // every lane of the last register holds a run word; the very last one fetches its funnel partner itself
+                if (lane == 63) nx = (sh && w0 + (size_t)(64 * N) <= last_word) ? words[w0 + (size_t)(64 * N)] : 0;
+            }
+            w[j] = sh ? ((raw[j] >> sh) | (nx << (64 - sh))) : raw[j];
+        }
+    }
+    // this lane's R validity bits for load step u (u is a compile-time constant after unrolling)
+    template <int R>
+    __device__ __forceinline__ unsigned bits(int u, unsigned lane) const {
+        constexpr int LPW = 64 / R;
+        const int idx = u * R + (int)(lane / LPW);
+        const uint64_t word = (uint64_t)__shfl((unsigned long long)w[(u * R) >> 6], idx & 63, 64);
+        return (unsigned)(word >> ((lane % LPW) * R)) & ((1u << R) - 1u);
+    }
+    __device__ __forceinline__ void combine(const RunWords& o, bool is_and) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) w[j] = is_and ? (w[j] & o.w[j]) : (w[j] | o.w[j]);
+    }
+};
 
 // The R validity bits of this lane's rows for load step `u` of the run (R rows per lane per 16-byte load).
 template <int R>

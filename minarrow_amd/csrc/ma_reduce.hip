@@ -47,7 +47,15 @@ struct SumArgs {
     int interleave;         // dense only: 1 = n_tiles counts 1-KiB pieces dealt to ALL waves of the grid in turn
     int mode;               // 0: out_a = final value (int, or rounded double); 1: out_a/out_b = double-double
     int is_signed;          // integer mean: interpret the 64-bit sum as signed
+    int fenced;             // 1: round-1 publish (release / acquire fences) instead of sc1 stores (A/B only)
 };
+
+// Arrival counters inside the context's zeroed scratch block (ma_ctx.hip): word 0 is the top ticket; the shards sit on
+// their own 64-byte lines further on.
+constexpr unsigned kTicketShards = 8;
+constexpr unsigned kTicketShardWord0 = 64;   // 256 bytes in
+constexpr unsigned kTicketShardStride = 16;  // 64 bytes
+constexpr unsigned kShardFrom = 96;          // grids up to this size arrive on the one ticket
 
 template <typename T, int UNROLL, bool MASKED, bool NT, bool IL = false, int PACE = 0>
 __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
@@ -181,16 +189,43 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         Partial p;
         s.to_partial(p);
         p.cnt = c;
-        p.pad = 0;
-        a.partials[blockIdx.x] = p;
-        // Publish: release at agent scope, drain, then take a ticket (MI355X guide, Guideline 16).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = ticket == gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int last;
+        if (a.fenced) {
+            // Round-1 form, kept for A/B (ctx variant bit 8): plain partial -> agent-scope release -> ticket -> acquire.
+            p.pad = 0;
+            a.partials[blockIdx.x] = p;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = ticket == gridDim.x - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            // Publish with write-through (sc1) stores, drain them, THEN arrive: one lane of the workgroup signals for all
+            // of its stores, the consumer is the workgroup whose add came last and reads every partial with sc1 loads
+            // (MI355X guide, workgroup hand-off table, first row). No release / acquire fence: each costs ~1.7 us, and
+            // both sat on the last workgroup's critical path — most of a mid-size column's fixed overhead.
+            uint64_t* q = (uint64_t*)&a.partials[blockIdx.x];
+            store_agent(q, p.a);
+            store_agent(q + 1, p.b);
+            store_agent(q + 2, p.cnt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (gridDim.x <= kShardFrom) {
+                last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            } else {
+                // Hundreds of arrivals on one word serialise at ~12 ns each: eight counters (workgroups b and b + 8 share
+                // an XCD, so a shard's arrivals stay on one L2), the last arrival of each shard arrives at the top.
+                const unsigned sh = blockIdx.x & (kTicketShards - 1);
+                const unsigned members = (gridDim.x - sh + kTicketShards - 1) / kTicketShards;
+                unsigned int* shard = a.ticket + kTicketShardWord0 + sh * kTicketShardStride;
+                last = 0;
+                if (__hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                    __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                    last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kTicketShards - 1;
+                }
+            }
         }
         is_last = last;
     }
@@ -248,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         }
         if (a.out_cnt) *a.out_cnt = c;
         if (a.out_mean) *a.out_mean = c ? as_double / (double)c : __longlong_as_double(0x7ff8000000000000ll);
-        *a.ticket = 0;  // ready for the next launch on this stream
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
     }
 }
 
@@ -306,7 +341,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         case 4: unroll = (R * 16 < 64 && !masked) ? 16 : 8; break;
         default: break;
     }
-    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean ? 1 : 2);
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean ? 1 : 2);
     const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
     // Rows in front of the first 16-byte boundary.
     size_t head = 0;
@@ -321,6 +356,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
     // tiled mapping stays the default.
     a.interleave = (!masked && nt && unroll == 8 && (variant & 16) != 0) ? 1 : 0;
+    a.fenced = (variant & 256) ? 1 : 0;
     // Load pacing (pace_loads): idle cycles between a wave's consecutive loads. Swept per type at 10^9 rows
     // (profiles/r01_sweep_sum_pace.txt): dense i64 1.117 -> 1.099 ms at 24 cycles, f64 1.106 -> 1.095 at 20, i32 0.586 ->
     // 0.583 at 16, f32 0.591 -> 0.566 at 16-32; the masked kernels, which already spend cycles on validity words between
@@ -332,6 +368,11 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         const int dense_default = std::is_same<T, float>::value ? 24 : std::is_same<T, double>::value ? 20 : (R == 2 ? 24 : 16);
         a.pace = sel >= 0 ? sel : (masked ? 0 : dense_default);
     }
+    // Mid-size columns (up to ~24 tiles per CU: 2^24 8-byte rows — the chunk sizes the reference actually runs at,
+    // src/structs/chunked/super_array.rs:51-59): the lean shape's one workgroup per CU leaves the memory pipeline
+    // half empty during the ramp and the tail of so short a scan; three per CU are 3-6 % faster there, and lose 3 %
+    // from 2^26 rows on (profiles/r02_sweep_mid.jsonl).
+    if (lean && ctx->blocks_per_cu <= 0 && a.n_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
     size_t work = a.n_tiles;
     if (a.interleave) {
         a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces

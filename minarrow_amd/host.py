@@ -7,6 +7,7 @@ Buffers may be numpy arrays (pageable host memory: the library stages them), `De
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Tuple
 
 import numpy as np
@@ -62,6 +63,9 @@ class DeviceBuffer:
         p = C.c_void_p()
         ffi.check(ctx.lib.ma_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = int(p.value)
+        live = getattr(ctx, "_buffers", None)
+        if live is not None:
+            live.add(self)  # Context.close() returns whatever is still outstanding
 
     def offset(self, nbytes: int) -> int:
         return self.ptr + int(nbytes)
@@ -106,6 +110,7 @@ class PinnedBuffer:
         dt = np.dtype(dtype)
         count = self.nbytes // dt.itemsize if count is None else int(count)
         buf = (C.c_uint8 * (count * dt.itemsize)).from_address(self.ptr)
+        buf._owner = self  # the array's base chain now holds the PinnedBuffer: no recycling under a live view
         return np.frombuffer(buf, dtype=dt, count=count)
 
     def free(self) -> None:
@@ -180,10 +185,13 @@ class Context:
             ffi.check(self.lib.ma_ctx_create_on_stream(int(device), int(stream), C.byref(h)))
         self.handle = h.value
         self.device = int(device)
+        self._buffers = weakref.WeakSet()
 
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self) -> None:
         if self.handle:
+            for buf in list(getattr(self, "_buffers", ())):  # device blocks that outlived their users
+                buf.free()
             self.lib.ma_ctx_destroy(self.handle)
             self.handle = None
 

@@ -245,6 +245,41 @@ def test_ref_datetime(ctx, gpu, oracle):
     np.testing.assert_array_equal(out, np.where(want_valid, a[loff:loff + n] * b[roff:roff + n], 0))
 
 
+@pytest.mark.parametrize("tag", ["i32", "u32", "i64", "u64"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097, 32768 + 5, (1 << 18) + 77])
+def test_datetime_two_masks_fused_matches_merge_then_apply(ctx, oracle, tag, n):
+    """apply_datetime with BOTH operands masked: the kernel ANDs the two validities in registers (no merged
+    temporary). Must equal the reference's two-step form — merge_bitmasks_to_new, then apply_int with the merged
+    mask (dispatch.rs:336-365) — for every op, incl. the data-dependent validity of Div / Rem / FloorDiv, on
+    device-resident and on host operands."""
+    rng = np.random.default_rng(n * 7 + len(tag))
+    dt = NP[tag]
+    info = np.iinfo(dt)
+    a = rng.integers(max(info.min, -(1 << 40)), min(info.max, 1 << 40), size=n).astype(dt)
+    b = rng.integers(0, 9, size=n).astype(dt)  # zeros included: they null rows of the division ops
+    m1 = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    m2 = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    merged = oracle.merge_bitmasks(m1, m2, n)
+    da, db, dm1, dm2 = ctx.to_device(a, 64), ctx.to_device(b, 64), ctx.to_device(m1, 16), ctx.to_device(m2, 16)
+    dout, dom = ctx.alloc(n * a.itemsize + 64), ctx.alloc(mask_bytes(n) + 16)
+    for op in ("add", "subtract", "multiply", "divide", "remainder", "floordiv"):
+        st, want, want_mask, _ = oracle.apply_int(a, b, op, merged, n)
+        assert st == 0
+        want_valid = unpack(want_mask, n)
+        # device-resident
+        assert ctx.apply_datetime(tag, da, 0, n, dm1, db, 0, n, dm2, OPS[op], dout, dom)
+        np.testing.assert_array_equal(dout.download(dt, n), want[:n])
+        np.testing.assert_array_equal(unpack(dom.download(np.uint8, mask_bytes(n)), n), want_valid)
+        # host operands (staged)
+        out = np.zeros(n, dtype=dt)
+        om = np.zeros(mask_bytes(n) + 8, dtype=np.uint8)
+        assert ctx.apply_datetime(tag, a, 0, n, m1, b, 0, n, m2, OPS[op], out, om)
+        np.testing.assert_array_equal(out, want[:n])
+        np.testing.assert_array_equal(unpack(om, n), want_valid)
+    for buf in (da, db, dm1, dm2, dout, dom):
+        buf.free()
+
+
 def test_ref_int_power_short_vs_long(gpu):
     """test_int_dense_power_short_vs_long_input_simd — mod.rs:507-537"""
     g = ARITH["int_power_short_vs_long"]

@@ -34,6 +34,54 @@ def test_many_threads_one_shared_context(ctx):
     assert not errors, errors
 
 
+def test_threads_sharing_one_context_overlap():
+    """SURVEY §8(b) Threading: a shared context must not serialise its callers. Four threads each make synchronous
+    sums of their own 2^20-row column through ONE context; the context's lanes let the calls overlap, so the wall time
+    must be well under the same calls made one after the other (measured 0.42x on MI355X, tools/bench_lanes.py; 1.03x
+    with MINARROW_HIP_LANES=1). Results are checked on every call."""
+    import time
+
+    from minarrow_amd.host import Context
+
+    ctx = Context(0)
+    n, T, reps = 1 << 20, 4, 400
+    bufs = []
+    for i in range(T):
+        b = ctx.alloc(n * 8)
+        ctx.synth_iota("i64", b, n, i)
+        bufs.append(b)
+    want = [n * (n - 1) // 2 + i * n for i in range(T)]
+    errors = []
+
+    def work(i, count):
+        try:
+            for _ in range(count):
+                assert ctx.sum("i64", bufs[i], n) == (want[i], n)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def concurrent(count):
+        ts = [threading.Thread(target=work, args=(i, count)) for i in range(T)]
+        t0 = time.perf_counter()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        return time.perf_counter() - t0
+
+    concurrent(20)  # the lanes exist from here on
+    best_ratio = 10.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(T):
+            work(i, reps)
+        serial = time.perf_counter() - t0
+        best_ratio = min(best_ratio, concurrent(reps) / serial)
+    for b in bufs:
+        b.free()
+    ctx.close()
+    assert not errors, errors
+    assert best_ratio < 0.75, f"concurrent / serial = {best_ratio:.2f}: the shared context serialises its callers"
+
+
 def test_one_context_per_thread():
     from minarrow_amd.host import Context
 

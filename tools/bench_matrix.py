@@ -7,8 +7,12 @@ stream, inputs resident in HBM. `--bytes` is the size of one operand column (def
 """
 import argparse
 import json
+import os
 import sys
 from pathlib import Path
+
+if os.environ.get("MA_IMPORT_TORCH"):  # run on PyTorch's bundled HIP runtime (what bench.py runs on) instead of /opt/rocm's
+    import torch  # noqa: F401
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
@@ -27,6 +31,7 @@ def main():
     from minarrow_amd.host import Context
 
     ctx = Context(0)
+    print(json.dumps({"hip_runtime": [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1]}), flush=True)
     B = args.bytes
     a, b, c, o = (ctx.alloc(B + 256) for _ in range(4))
     n_bits_max = B  # one validity bit per row of the narrowest type
@@ -35,10 +40,19 @@ def main():
     ctx.synth_validity(mask, n_bits_max, seed=7, null_every=10)
     slot = ctx.alloc(256)
 
+    copy_gbps = [None]
+
     def emit(family, tag, variant, ms, nbytes, rows):
         gbps = nbytes / ms / 1e6
-        print(json.dumps({"family": family, "type": tag, "variant": variant, "ms": round(ms, 4), "gbps": round(gbps, 1),
-                          "frac_of_8TBps": round(gbps / PEAK, 3), "grows_per_s": round(rows / ms / 1e6, 1)}), flush=True)
+        # a rate above the HBM spec means the byte accounting is wrong (aliased operands, a short-circuiting kernel)
+        assert gbps <= PEAK, f"{family} {tag} {variant}: {gbps:.0f} GB/s is above the {PEAK:.0f} GB/s peak: fix the byte count"
+        line = {"family": family, "type": tag, "variant": variant, "ms": round(ms, 4), "gbps": round(gbps, 1),
+                "frac_of_8TBps": round(gbps / PEAK, 3), "grows_per_s": round(rows / ms / 1e6, 1)}
+        if copy_gbps[0] and family not in ("sum", "mean", "sum_columns", "copy"):
+            # kernels with a store stream: the same-process, same-buffers copy rate is the reference (the write rate of
+            # a buffer depends on where the driver placed it: profiles/r02_probe_alloc_*.txt)
+            line["frac_of_copy"] = round(gbps / copy_gbps[0], 3)
+        print(json.dumps(line), flush=True)
 
     def timed(fn, sync=False):
         fn()
@@ -52,6 +66,14 @@ def main():
 
     def want(name):
         return not args.only or any(k in name for k in args.only.split(","))
+
+    # the reference rate of this process and these buffers: a plain 16-byte-per-lane copy a -> o
+    ctx.set_async(True)
+    ms = timed(lambda: ctx.consolidate_column(8, [a], [B // 8], o))
+    ctx.set_async(False)
+    ctx.synchronize()
+    emit("copy", "8-byte", "copy kernel a -> o (reference for frac_of_copy)", ms, 2 * B, B // 8)
+    copy_gbps[0] = 2 * B / ms / 1e6
 
     def fill(tag):
         """a = 1, 2, 3, ...; b = 3, 4, 5, ... in the widest generator that tiles the type (narrow types reinterpret)."""
@@ -149,9 +171,13 @@ def main():
         # a, b as bitmaps of `bits` bits (already random-ish)
         ctx.synth_iota("i64", a, B // 8, 0x0102030405060708)
         ctx.synth_iota("i64", b, B // 8, 0x0301070503010703)
-        for name in ("and_masks", "or_masks", "xor_masks", "in_mask", "eq_mask"):
+        for name in ("and_masks", "or_masks", "xor_masks", "eq_mask"):
             ms = timed(lambda: ctx.mask_words_op(name, a, 0, b, 0, bits, o))
             emit("bitmask", "u64 words", name, ms, 3 * bits / 8, bits)
+        # in_mask: rhs holds both values here, so the result is all-true: one scan of rhs + one constant fill of out
+        # (ma_in_mask, simd.rs:327-398) — 2 streams, not 3
+        ms = timed(lambda: ctx.mask_words_op("in_mask", a, 0, b, 0, bits, o))
+        emit("bitmask", "u64 words", "in_mask (rhs has both values: scan + fill)", ms, 2 * bits / 8, bits)
         ms = timed(lambda: ctx.mask_words_op("and_masks", a, 8, b, 24, bits - 64, o))
         emit("bitmask", "u64 words", "and_masks, byte offsets 1 and 3", ms, 3 * bits / 8, bits)
         ms = timed(lambda: ctx.mask_unary_op("not_mask", a, 0, bits, o))
@@ -160,8 +186,9 @@ def main():
         emit("bitmask", "u64 words", "bitmask_slice (bit offset 13)", ms, 2 * bits / 8, bits)
         ms = timed(lambda: ctx.popcount_mask(a, 0, bits))
         emit("bitmask", "u64 words", "popcount_mask", ms, bits / 8, bits)
-        ms = timed(lambda: ctx.mask_all("all_eq", a, 0, a, 0, bits))
-        emit("bitmask", "u64 words", "all_eq (no early exit possible)", ms, 2 * bits / 8, bits)
+        ctx.dev_copy(c, a, bits // 8)  # equal contents in a DISTINCT buffer: no early exit, and two real streams
+        ms = timed(lambda: ctx.mask_all("all_eq", a, 0, c, 0, bits))
+        emit("bitmask", "u64 words", "all_eq (equal contents, distinct buffers)", ms, 2 * bits / 8, bits)
         ms = timed(lambda: ctx.merge_bitmasks(a, b, bits, o))
         emit("bitmask", "u64 words", "merge_bitmasks_to_new", ms, 3 * bits / 8, bits)
         for tag in ("u8", "u16", "u32", "u64"):

@@ -4,8 +4,12 @@
 resident; columns up to ~256 MiB are MALL/L2-resident across repetitions, so rates above 8 TB/s there are cache
 rates, not HBM."""
 import json
+import os
 import sys
 from pathlib import Path
+
+if os.environ.get("MA_IMPORT_TORCH"):  # A/B: the process then runs on PyTorch's bundled HIP runtime instead of /opt/rocm's
+    import torch  # noqa: F401
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from minarrow_amd.host import Context  # noqa: E402
@@ -31,7 +35,7 @@ def main():
     ctx.synth_iota("f64", b, top, 1)
     ctx.synth_validity(mask, top, seed=1, null_every=10)
     ctx.set_async(True)
-    for e in range(10, 31, 2):
+    for e in range(int(os.environ.get("MA_SWEEP_MIN", "10")), 31, 2):
         n = 1 << e
         reps = 200 if e <= 22 else (50 if e <= 26 else 10)
         row = {"rows": n, "bytes_per_operand": n * 8}
@@ -49,6 +53,7 @@ def main():
     ctx.set_async(False)
     ctx.synchronize()
     ctx.close()
+    print(json.dumps({"hip_runtime": [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1]}), flush=True)
 
 
 if __name__ == "__main__":
