@@ -247,6 +247,9 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     if (total == 0) return MA_OK;
     MA_REQUIRE(out_data != nullptr, MA_ERR_INVALID_ARGUMENT, "out_data is NULL");
     MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
+    // every argument check comes BEFORE the first enqueue: a failure past that point would return with kernels in flight
+    MA_REQUIRE(!has_mask || ((uintptr_t)out_mask & 7) == 0, MA_ERR_INVALID_ARGUMENT,
+               "output bitmap must be 8-byte aligned (got %p)", (const void*)out_mask);
 
     MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
@@ -255,6 +258,8 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     std::vector<ChunkDesc> desc(n_chunks);
     void* po = nullptr;
     MA_TRY(scope.out(out_data, total * elem_size, &po));
+    uint64_t* ow = nullptr;
+    if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &ow));
     const size_t tile_rows = elem_size == 1 ? tile_rows_of<uint8_t>() : elem_size == 2 ? tile_rows_of<uint16_t>()
                            : elem_size == 4 ? tile_rows_of<uint32_t>() : tile_rows_of<uint64_t>();
     size_t row = 0, n_tiles = 0;
@@ -295,8 +300,6 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     }
     MA_HIP(hipGetLastError());
     if (has_mask) {
-        uint64_t* ow = nullptr;
-        MA_TRY(scope.out_mask(out_mask, total, &ow));
         launch_concat_mask(ctx, d, n_chunks, total, ow);
         MA_HIP(hipGetLastError());
     }
@@ -519,13 +522,12 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     MA_HIP(hipMemcpyAsync(dd, data_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
     if (has_mask) MA_HIP(hipMemcpyAsync(md, mask_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
-    uint64_t* ow = nullptr;
+    uint64_t *ow = nullptr, *mw = nullptr;  // both outputs are validated before the first launch
     MA_TRY(scope.out_mask(out_bits, total, &ow));
+    if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &mw));
     launch_concat_mask(ctx, dd, n_chunks, total, ow);
     MA_HIP(hipGetLastError());
     if (has_mask) {
-        uint64_t* mw = nullptr;
-        MA_TRY(scope.out_mask(out_mask, total, &mw));
         launch_concat_mask(ctx, md, n_chunks, total, mw);
         MA_HIP(hipGetLastError());
     }

@@ -577,6 +577,7 @@ class Group:
         self.handle = h.value
         self.size = n
         self.devices = [int(d) for d in devices]
+        self._members = []
 
     @property
     def exchange_kind(self) -> str:
@@ -594,6 +595,8 @@ class Group:
         c.handle = self.lib.ma_group_ctx(self.handle, int(i))
         c.device = self.devices[i]
         c.close = lambda: None  # the group owns it
+        c._buffers = weakref.WeakSet()
+        self._members.append(c)
         return c
 
     def _tables(self, chunks, lens, masks, mask_offsets):
@@ -633,6 +636,10 @@ class Group:
 
     def close(self) -> None:
         if self.handle:
+            for c in self._members:  # buffers still alive on a member's device go first; the views die with the group
+                for buf in list(c._buffers):
+                    buf.free()
+                c.handle = None
             self.lib.ma_group_destroy(self.handle)
             self.handle = None
 

@@ -303,3 +303,52 @@ def test_device_blocks_are_recycled(ctx):
     ffi.check(lib.ma_dev_pool_trim(ctx.handle, 16 << 30))
     small = ctx.alloc(4096)
     small.free()
+
+
+def test_double_free_of_a_parked_block_is_refused(ctx):
+    """A block that sits in the pinned / device cache must not be freed again: round 1 would have handed the same
+    memory out twice (pinned) or hipFree'd a block still listed as parked. Now MA_ERR_INVALID_ARGUMENT, and the block
+    stays usable for the next allocation."""
+    import ctypes as C
+
+    lib = ctx.lib
+    p = C.c_void_p()
+    ffi.check(lib.ma_alloc64_pinned(3 << 20, C.byref(p)))
+    ffi.check(lib.ma_free_pinned(p.value))
+    assert lib.ma_free_pinned(p.value) == ffi.MA_ERR_INVALID_ARGUMENT
+    assert b"double free" in lib.ma_last_error_string()
+    q = C.c_void_p()
+    ffi.check(lib.ma_alloc64_pinned(3 << 20, C.byref(q)))
+    assert q.value == p.value  # the parked block, once
+    ffi.check(lib.ma_free_pinned(q.value))
+    d = C.c_void_p()
+    ffi.check(lib.ma_dev_alloc(ctx.handle, 5 << 20, C.byref(d)))
+    ffi.check(lib.ma_dev_free(ctx.handle, d.value))
+    assert lib.ma_dev_free(ctx.handle, d.value) == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+def test_pool_limits_can_be_restored_after_a_trim(ctx):
+    """trim(keep) lowers the cache limit for good; *_pool_set_limit raises it again without releasing anything."""
+    import ctypes as C
+
+    lib = ctx.lib
+    ffi.check(lib.ma_dev_pool_trim(ctx.handle, 0))
+    a = ctx.alloc(6 << 20)
+    first = a.ptr
+    a.free()  # limit 0: released to the runtime
+    ffi.check(lib.ma_dev_pool_set_limit(ctx.handle, 16 << 30))
+    b = ctx.alloc(6 << 20)
+    second = b.ptr
+    b.free()  # parked again
+    c = ctx.alloc(6 << 20)
+    assert c.ptr == second
+    c.free()
+    ffi.check(lib.ma_pinned_pool_trim(0))
+    ffi.check(lib.ma_pinned_pool_set_limit(2 << 30))
+    p, q = C.c_void_p(), C.c_void_p()
+    ffi.check(lib.ma_alloc64_pinned(2 << 20, C.byref(p)))
+    ffi.check(lib.ma_free_pinned(p.value))
+    ffi.check(lib.ma_alloc64_pinned(2 << 20, C.byref(q)))
+    assert q.value == p.value
+    ffi.check(lib.ma_free_pinned(q.value))
+    del first

@@ -57,12 +57,16 @@ def main():
     def timed(fn, sync=False):
         fn()
         fn()
-        ctx.synchronize()
-        ctx.timer_start()
-        for _ in range(args.reps):
-            fn()
-        ctx.timer_stop()
-        return ctx.timer_elapsed_ms() / args.reps
+        best = None
+        for _ in range(2):  # best of two rounds: a single stalled launch (seen once: 8 ms instead of 0.9) must not be a row
+            ctx.synchronize()
+            ctx.timer_start()
+            for _ in range(args.reps):
+                fn()
+            ctx.timer_stop()
+            ms = ctx.timer_elapsed_ms() / args.reps
+            best = ms if best is None else min(best, ms)
+        return best
 
     def want(name):
         return not args.only or any(k in name for k in args.only.split(","))
