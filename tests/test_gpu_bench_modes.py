@@ -1,0 +1,67 @@
+"""bench.py is what the driver runs: its launch modes and its configs-3-5 leg are exercised end to end at a small size
+(2^24 rows), through the same code paths as the 10^9-row run. One JSON line on stdout, parity checked inside."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+SMALL = ["--rows", str(1 << 24), "--steps", "3", "--warmup", "1"]
+
+
+def run(cmd, extra_env=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]  # the contract: ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_with_other_configs_and_cpu_baseline():
+    out = run([sys.executable, "bench.py", *SMALL, "--cpu-rows", str(1 << 22), "--cpu-seconds", "1", "--other-reps", "2"])
+    assert out["parity_ok"] and out["n_gpus"] == 1 and out["unit"] == "Grows/s" and out["scaling"] == "weak"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    assert 0 < out["roofline"]["frac"] <= 1.0
+    oc = out["other_configs"]
+    assert oc["parity_ok"] is True and oc["rows"] == 1 << 24
+    for key in ("add_array_array", "multiply_array_array", "add_array_scalar", "multiply_array_scalar"):
+        k = oc["config3_f64_elementwise"][key]
+        assert k["parity"] is True and k["frac_of_peak"] <= 1.0 and k["frac_of_copy"] > 0
+    assert oc["config4_i64_sum_10pct_nulls"]["parity"] is True
+    assert 0.09 < oc["config4_i64_sum_10pct_nulls"]["null_fraction"] < 0.11
+    for tag in ("i64", "f64"):
+        for leg in ("reduce_per_batch", "consolidate", "reduce_consolidated"):
+            assert oc["config5_supertable_8_batches"][tag][leg]["parity"] is True
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_one_process_group_mode_with_rccl():
+    """`bench.py --gpus N` started directly = one process over N GPUs through ma_group_* (--force-group takes that path
+    with the GPUs this box has: one on the test pool, where ncclCommInitAll runs with one rank)."""
+    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline"])
+    assert out["parity_ok"] and out["config"]["launch"] == "single process"
+    assert out["config"]["rccl_ranks"] == 1 and "RCCL all-gather (ncclCommInitAll" in out["config"]["exchange"]
+    host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host"])
+    assert host["parity_ok"] and host["config"]["rccl_ranks"] == 0 and "host fold" in host["config"]["exchange"]
+    assert host["result"]["i64_sum"] == out["result"]["i64_sum"] and host["result"]["f64_sum"] == out["result"]["f64_sum"]
+
+
+@pytest.mark.parametrize("exchange, extra", [("native", []), ("torch", []), ("torch", ["--overlap"])])
+def test_launcher_mode_one_rank(exchange, extra):
+    """One process per GPU under torch.distributed.run: the library's own communicator (ma_comm_*), torch's all-gather,
+    and torch's all-gather on a side stream (--overlap)."""
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+               "--no-other-configs", "--exchange", exchange, *extra])
+    assert out["parity_ok"] and out["n_gpus"] == 1
+    want = "ma_comm_*" if exchange == "native" else "torch.distributed"
+    assert want in out["config"]["exchange"]
+    if extra:
+        assert "side stream" in out["config"]["exchange"]
