@@ -391,6 +391,29 @@ def _emit(result_fd, out):
     os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
+class _Deadline:
+    """The multi-GPU legs that follow the headline contain collectives; should one ever hang (a rank lost, a fabric
+    fault), the headline line must still reach the driver: after `seconds` the line is printed without them and the
+    process ends with the headline's own exit code."""
+
+    def __init__(self, seconds, result_fd, out, rc):
+        import threading
+
+        def fire():
+            if out is not None:
+                late = dict(out)
+                late["other_configs"] = {"error": f"the multi-GPU configs 3-5 leg did not finish within {seconds:.0f} s"}
+                _emit(result_fd, late)
+            os._exit(rc)
+
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallelism, exchange, extra_config=None):
     rows = args.rows
     got_i, cnt_i, got_f, cnt_f = finals
@@ -467,6 +490,99 @@ def _check(total_rows, finals):
         and abs(got_f - exact_f) <= math.ulp(exact_f)
 
 
+def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
+    """BASELINE configs 3 and 4 of the multi-GPU kind, one process over N GPUs (after and outside the timed headline):
+    config 4 = a 10^9-row i64 column with 10 % nulls, row-chunk partitioned over the N GPUs (strong scaling: N x fewer rows
+    per GPU), masked scans + ONE exchange per step; config 5 = a SuperTable of N batches of `rows` rows (one per GPU),
+    columns i64 + f64 with 10 % nulls, per-column reduce of BOTH columns with ONE exchange per step — a batch-sharded
+    table consolidates logically, no column bytes move. Parity: the job's finals against the sum of the
+    members' own synchronous scans of their chunks (checksum of checksums; f64 within 1 ULP-scale of the ordered fold)."""
+    import numpy as np
+
+    from minarrow_amd.parallel import fold_dd, row_chunks
+
+    world = len(ctxs)
+    M64 = (1 << 64) - 1
+    res = {}
+
+    def timed_steps(step):
+        for _ in range(2):
+            step()
+        group.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        group.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    # ---- config 4: 10^9 rows over N GPUs
+    n = min(1_000_000_000, rows * world)
+    chunks = row_chunks(n, world)
+    lens = [hi - lo for lo, hi in chunks]
+    masks = []
+    for r, c in enumerate(ctxs):
+        lo, hi = chunks[r]
+        c.synth_iota("i64", cols_i[r], lens[r], lo)  # the chunk's slice of the global iota column
+        m = c.alloc(lens[r] // 8 + 128)
+        c.synth_validity(m, lens[r], seed=0xC0FFEE, first_index=lo, null_every=10)
+        masks.append(m)
+    zeros = [0] * world
+    ms = timed_steps(lambda: (group.enqueue_sum("i64", 2, cols_i, lens, masks, zeros), group.exchange()))
+    total, cnt, _, _ = group.result(2)
+    part_s = part_c = 0
+    for r, c in enumerate(ctxs):  # each member's own scan of its chunk, one at a time
+        c.set_async(False)
+        s_r, c_r = c.sum("i64", cols_i[r], lens[r], mask=masks[r])
+        c.set_async(True)
+        part_s, part_c = (part_s + s_r) & M64, part_c + c_r
+    ok = (total & M64) == part_s and cnt == part_c and 0.09 < 1 - cnt / n < 0.11
+    res["config4_i64_sum_10pct_nulls_row_chunks"] = {
+        "n_gpus": world, "rows_total": n, "ms_per_step": ms, "grows_per_s": n / ms / 1e6, "gbps": 8.125 * n / ms / 1e6,
+        "frac_of_peak_per_gpu": 8.125 * n / ms / 1e6 / world / HBM_PEAK_GBPS, "valid_count": cnt, "parity": bool(ok)}
+    for m in masks:
+        m.free()
+
+    # ---- config 5: SuperTable of N batches of `rows` rows, one per GPU; columns i64 + f64, 10 % nulls
+    lens = [rows] * world
+    masks = []
+    for r, c in enumerate(ctxs):
+        c.synth_iota("i64", cols_i[r], rows, r)  # v[i] = i + batch (benches/consolidate.rs:37-58 pattern)
+        c.synth_iota("f64", cols_f[r], rows, r)
+        m = c.alloc(rows // 8 + 128)
+        c.synth_validity(m, rows, seed=0xABC + r, null_every=10)
+        masks.append(m)
+
+    def table_step():
+        group.enqueue_sum("i64", 3, cols_i, lens, masks, zeros)
+        group.enqueue_sum("f64", 4, cols_f, lens, masks, zeros)
+        group.exchange()
+
+    ms = timed_steps(table_step)
+    isum, icnt, _, _ = group.result(3)
+    _, _, fsum, fcnt = group.result(4)
+    part_s = part_c = 0
+    pairs = []
+    for r, c in enumerate(ctxs):
+        c.set_async(False)
+        s_r, c_r = c.sum("i64", cols_i[r], rows, mask=masks[r])
+        hi, lo, fc = c.sum_dd("f64", cols_f[r], rows, mask=masks[r])
+        c.set_async(True)
+        part_s, part_c = (part_s + s_r) & M64, part_c + c_r
+        pairs.append((hi, lo))
+        ok = ok and fc == c_r
+    want_f = fold_dd(pairs)
+    ok5 = (isum & M64) == part_s and icnt == part_c == fcnt and fsum == want_f
+    res["config5_supertable_one_batch_per_gpu"] = {
+        "n_gpus": world, "batches": world, "rows_per_batch": rows, "columns": ["i64", "f64"], "ms_per_step": ms,
+        "grows_per_s": 2 * rows * world / ms / 1e6, "gbps": 2 * 8.125 * rows * world / ms / 1e6,
+        "frac_of_peak_per_gpu": 2 * 8.125 * rows / ms / 1e6 / HBM_PEAK_GBPS, "valid_count": icnt, "parity": bool(ok5),
+        "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
+    for m in masks:
+        m.free()
+    res["parity_ok"] = bool(ok and ok5)
+    return res
+
+
 def run_group(args, result_fd) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher: ONE process drives the N GPUs through the C ABI's group
     API (one context per device, enqueue-only scans, one grouped RCCL all-gather + device fold per step) — the shape a
@@ -525,13 +641,115 @@ def run_group(args, result_fd) -> int:
                         if group.exchange_kind == "rccl" else "host fold of pinned records") +
                        (f" [{group.exchange_note}]" if group.exchange_note else ""),
                        {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process"})
+    rc = 0 if ok else 1
+    if not args.no_other_configs:
+        guard = _Deadline(args.other_seconds, result_fd, out, rc)
+        try:
+            out["other_configs"] = group_other_configs(group, ctxs, cols_i, cols_f, rows, args.other_reps)
+            if not out["other_configs"]["parity_ok"]:
+                rc = 1
+        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+            out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+            rc = 1
+        guard.cancel()
     _emit(result_fd, out)
     if not ok:
         print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
     for b in cols_i + cols_f + [slot]:
         b.free()
     group.close()
-    return 0 if ok else 1
+    return rc
+
+
+def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, reps: int, rank: int, world: int):
+    """The same two multi-GPU legs as group_other_configs with one process per GPU: every rank scans its chunk / its batch,
+    ONE exchange per step (the library's communicator when there is one, torch.distributed's all-gather otherwise)."""
+    from minarrow_amd.parallel import ScalarExchange, fold_dd, row_chunks
+
+    M64 = (1 << 64) - 1
+    stream = torch.cuda.current_stream(dev)
+
+    def exchange(ex):
+        if comm is not None:
+            comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+            ex._folded_on_device = True
+        else:
+            ex.exchange()
+            ex.fold_on_device(ctx)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed_steps(step):
+        for _ in range(2):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(obj):
+        objs = [None] * world
+        dist.all_gather_object(objs, obj)
+        return objs
+
+    res = {}
+    # ---- config 4
+    n = min(1_000_000_000, rows * world)
+    lo, hi = row_chunks(n, world)[rank]
+    mine = hi - lo
+    ctx.synth_iota("i64", col_i, mine, lo)
+    mask = torch.zeros(mine // 8 + 128, dtype=torch.uint8, device=dev)
+    ctx.synth_validity(mask, mine, seed=0xC0FFEE, first_index=lo, null_every=10)
+    ex = ScalarExchange(dev)
+
+    def step4():
+        ctx.sum_into("i64", col_i, mine, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1), mask=mask)
+        exchange(ex)
+
+    ms = timed_steps(step4)
+    total, cnt, _, _ = ex.results()
+    ctx.set_async(False)
+    own = ctx.sum("i64", col_i, mine, mask=mask)
+    ctx.set_async(True)
+    parts = gather(own)
+    ok = (total & M64) == (sum(p[0] for p in parts) & M64) and cnt == sum(p[1] for p in parts) and 0.09 < 1 - cnt / n < 0.11
+    res["config4_i64_sum_10pct_nulls_row_chunks"] = {
+        "n_gpus": world, "rows_total": n, "ms_per_step": ms, "grows_per_s": n / ms / 1e6, "gbps": 8.125 * n / ms / 1e6,
+        "frac_of_peak_per_gpu": 8.125 * n / ms / 1e6 / world / HBM_PEAK_GBPS, "valid_count": cnt, "parity": bool(ok)}
+    # ---- config 5: one batch of `rows` rows per rank, columns i64 + f64
+    ctx.synth_iota("i64", col_i, rows, rank)
+    ctx.synth_iota("f64", col_f, rows, rank)
+    mask = torch.zeros(rows // 8 + 128, dtype=torch.uint8, device=dev)
+    ctx.synth_validity(mask, rows, seed=0xABC + rank, null_every=10)
+    ex2 = ScalarExchange(dev, n_columns=2)
+
+    def step5():
+        ctx.sum_into("i64", col_i, rows, out_sum=ex2.slot_ptr(0, 0), out_count=ex2.slot_ptr(1, 0), mask=mask)
+        ctx.sum_into("f64", col_f, rows, out_sum=ex2.slot_ptr(2, 1), dd_lo=ex2.slot_ptr(3, 1), out_count=ex2.slot_ptr(4, 1), mask=mask)
+        exchange(ex2)
+
+    ms = timed_steps(step5)
+    (isum, icnt, _, _), (_, _, fsum, fcnt) = ex2.column_results()
+    ctx.set_async(False)
+    own_i = ctx.sum("i64", col_i, rows, mask=mask)
+    own_f = ctx.sum_dd("f64", col_f, rows, mask=mask)
+    ctx.set_async(True)
+    parts = gather((own_i, own_f))
+    want_f = fold_dd([(p[1][0], p[1][1]) for p in parts])
+    ok5 = (isum & M64) == (sum(p[0][0] for p in parts) & M64) and icnt == sum(p[0][1] for p in parts) == fcnt and fsum == want_f
+    res["config5_supertable_one_batch_per_gpu"] = {
+        "n_gpus": world, "batches": world, "rows_per_batch": rows, "columns": ["i64", "f64"], "ms_per_step": ms,
+        "grows_per_s": 2 * rows * world / ms / 1e6, "gbps": 2 * 8.125 * rows * world / ms / 1e6,
+        "frac_of_peak_per_gpu": 2 * 8.125 * rows / ms / 1e6 / HBM_PEAK_GBPS, "valid_count": icnt, "parity": bool(ok5),
+        "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
+    res["parity_ok"] = bool(ok and ok5)
+    return res
 
 
 def run_ranks(args, result_fd) -> int:
@@ -669,6 +887,7 @@ def run_ranks(args, result_fd) -> int:
                "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f)}}
 
     rc = 0 if ok else 1
+    out = None
     if rank == 0:
         if not distributed:
             parallelism, exchange = "row-chunk x1", "none (one GPU): device fold on the scan stream"
@@ -686,7 +905,20 @@ def run_ranks(args, result_fd) -> int:
         out = _result_line(args, world, total_rows * 2 * args.steps, elapsed, kernels, ok, finals, parallelism, exchange,
                            {"rccl_ranks": world if (distributed and not rehearsal) else 0,
                             "launch": "torch.distributed.run" if world > 1 else "single process"})
-        if world == 1:
+    if distributed and not rehearsal and not args.no_other_configs:
+        guard = _Deadline(args.other_seconds, result_fd, out, rc)  # every rank: none may outlive a hung collective
+        try:  # every rank takes part (collectives inside); rank 0 prints
+            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows, args.other_reps, rank, world)
+            if not multi["parity_ok"]:
+                rc = 1
+        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+            multi = {"error": f"{type(e).__name__}: {e}"}
+            rc = 1
+        guard.cancel()
+        if rank == 0:
+            out["other_configs"] = multi
+    if rank == 0:
+        if world == 1 and not distributed:
             del col_i, col_f
             torch.cuda.empty_cache()
             if not args.no_other_configs:
@@ -740,6 +972,8 @@ def main() -> int:
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3-5 (N = 1 only)")
     ap.add_argument("--other-rows", type=int, default=0, help="rows of the configs 3-5 leg (default: --rows)")
     ap.add_argument("--other-reps", type=int, default=10)
+    ap.add_argument("--other-seconds", type=float, default=180.0,
+                    help="N > 1: time limit of the configs 3-5 leg; past it the headline line is printed without it")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "host"],

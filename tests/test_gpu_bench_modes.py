@@ -45,10 +45,15 @@ def test_single_gpu_line_with_other_configs_and_cpu_baseline():
 def test_one_process_group_mode_with_rccl():
     """`bench.py --gpus N` started directly = one process over N GPUs through ma_group_* (--force-group takes that path
     with the GPUs this box has: one on the test pool, where ncclCommInitAll runs with one rank)."""
-    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline"])
+    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--other-reps", "2"])
     assert out["parity_ok"] and out["config"]["launch"] == "single process"
     assert out["config"]["rccl_ranks"] == 1 and "RCCL all-gather (ncclCommInitAll" in out["config"]["exchange"]
-    host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host"])
+    oc = out["other_configs"]  # the multi-GPU legs of configs 4 and 5 (one GPU here)
+    assert oc["parity_ok"] is True
+    assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
+    assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["rows_total"] == 1 << 24
+    host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host",
+                "--no-other-configs"])
     assert host["parity_ok"] and host["config"]["rccl_ranks"] == 0 and "host fold" in host["config"]["exchange"]
     assert host["result"]["i64_sum"] == out["result"]["i64_sum"] and host["result"]["f64_sum"] == out["result"]["f64_sum"]
 
@@ -59,8 +64,11 @@ def test_launcher_mode_one_rank(exchange, extra):
     and torch's all-gather on a side stream (--overlap)."""
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
-               "--no-other-configs", "--exchange", exchange, *extra])
+               "--other-reps", "2", "--exchange", exchange, *extra])
     assert out["parity_ok"] and out["n_gpus"] == 1
+    oc = out["other_configs"]  # configs 4 and 5 through the same exchange
+    assert oc["parity_ok"] is True, oc
+    assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
     want = "ma_comm_*" if exchange == "native" else "torch.distributed"
     assert want in out["config"]["exchange"]
     if extra:
