@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -72,7 +73,7 @@ struct ma_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    bool async = false;
+    std::atomic<bool> async{false};      // read without the lock by ma::Enter (may a busy context fan out?)
     int num_cus = 0;
     int blocks_per_cu = 0;  // 0 = each kernel's own default
     int variant = 0;
@@ -86,7 +87,7 @@ struct ma_ctx {
     hipEvent_t ev_start = nullptr;
     hipEvent_t ev_stop = nullptr;
     bool pending_flags = false;        // async mode: dev_flags must be inspected at the next synchronize
-    bool capturing = false;            // between ma_ctx_capture_begin / _end: calls are recorded into a hipGraph
+    std::atomic<bool> capturing{false};  // between ma_ctx_capture_begin / _end: calls are recorded into a hipGraph
     bool async_before_capture = false;
     void* scratch = nullptr;           // grow-only device scratch for descriptor tables / per-segment partials
     size_t scratch_bytes = 0;          //   (one user at a time: callers hold `mu` and order their use on `stream`)

@@ -22,7 +22,7 @@ void load_rccl() {
     static const char* kNames[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* name : kNames) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) {
             g_rccl.path = name;
             break;
@@ -108,7 +108,7 @@ ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n
     MA_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, MA_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, n_ranks);
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_comm_create");
     MA_HIP(hipSetDevice(ctx->device));
     ncclUniqueId uid;
@@ -147,11 +147,11 @@ ma_status ma_comm_all_gather(ma_comm* comm, const void* send, void* recv, size_t
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     ma_ctx* ctx = comm->ctx;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);  // collectives are tied to the context's own stream
     MA_NO_CAPTURE(ctx, "a collective");
     MA_HIP(hipSetDevice(ctx->device));
     MA_NCCL(api, AllGather(send, recv, bytes_per_rank, ncclChar, comm->comm, ctx->stream));
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 
@@ -164,11 +164,11 @@ ma_status ma_comm_all_reduce_sum_i64(ma_comm* comm, const int64_t* send, int64_t
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     ma_ctx* ctx = comm->ctx;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);  // collectives are tied to the context's own stream
     MA_NO_CAPTURE(ctx, "a collective");
     MA_HIP(hipSetDevice(ctx->device));
     MA_NCCL(api, AllReduce(send, recv, count, ncclInt64, ncclSum, comm->comm, ctx->stream));  // wrapping, like the scans
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 
@@ -183,7 +183,7 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     ma_ctx* ctx = comm->ctx;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    MA_ENTER_PRIMARY(ctx);  // collectives are tied to the context's own stream
     MA_NO_CAPTURE(ctx, "a collective");
     MA_HIP(hipSetDevice(ctx->device));
     const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
@@ -191,7 +191,7 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
     // column c is folded over (rank, slot) in that order: records c, c + n_columns, ...
     MA_TRY(enqueue_fold_columns(ctx, gathered, (size_t)comm->n_ranks * slots_per_rank, n_columns * kRecordWords, n_columns,
                                 out_finals));
-    if (!ctx->async) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
 

@@ -198,3 +198,39 @@ def test_comm_one_rank(ctx, oracle):
         np.testing.assert_array_equal(gathered.download(np.uint64, slots * cols * 8), local.download(np.uint64, slots * cols * 8))
     finally:
         comm.close()
+
+
+def test_group_one_billion_rows_with_nulls_partitioned_eight_ways(ctx):
+    """BASELINE config 4 at full size through the group API: a 10^9-row i64 column with 10 % nulls, row-chunk
+    partitioned over 8 members (sharing this box's GPU; host exchange) — the job's finals must equal the single-call
+    scan of the whole column, and the f64 twin must stay within 1 ULP of it (size-independent property: a checksum of
+    checksums over the partition)."""
+    from minarrow_amd.host import Group
+
+    n, members = 1_000_000_000, 8
+    data, fdata = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    mask = ctx.alloc(n // 8 + 128)
+    ctx.synth_iota("i64", data, n, 0)
+    ctx.synth_iota("f64", fdata, n, 0)
+    ctx.synth_validity(mask, n, seed=0xC0FFEE, null_every=10)
+    whole_i = ctx.sum("i64", data, n, mask=mask)
+    whole_f = ctx.sum("f64", fdata, n, mask=mask)
+    chunks = row_chunks(n, members)
+    lens = [b - a for a, b in chunks]
+    assert all(a % 64 == 0 for a, _ in chunks)
+    with Group([0] * members, exchange="host") as g:
+        pi = [data.ptr + a * 8 for a, _ in chunks]
+        pf = [fdata.ptr + a * 8 for a, _ in chunks]
+        pm = [mask.ptr] * members
+        offs = [a for a, _ in chunks]
+        for _ in range(2):  # two steps back to back, one synchronize
+            g.enqueue_sum("i64", 0, pi, lens, pm, offs)
+            g.enqueue_sum("f64", 0, pf, lens, pm, offs)
+            g.exchange()
+        g.synchronize()
+        isum, icnt, fsum, fcnt = g.result(0)
+        assert (isum, icnt) == whole_i
+        assert fcnt == whole_f[1] and abs(fsum - whole_f[0]) <= math.ulp(whole_f[0])
+        assert 0.0999 < 1 - icnt / n < 0.1001
+    for b in (data, fdata, mask):
+        b.free()
