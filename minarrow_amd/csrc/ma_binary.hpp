@@ -241,10 +241,12 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
                 bool dzk = false;
                 T v = Elem<T>::template apply<OP>(x, y, dzk);
                 dz |= dzk;
-                if constexpr (MASKED) v = ((bits >> k) & 1u) ? v : (T)0;  // null slots hold 0 (simd.rs:315)
+                // null slots hold 0 (simd.rs:315); 1- and 2-byte vectors are masked as a whole below
+                if constexpr (MASKED && sizeof(T) > 2) v = ((bits >> k) & 1u) ? v : (T)0;
                 if constexpr (DATA_VALIDITY) out_bits &= ~((dzk ? 1u : 0u) << k);  // m & !div_zero (simd.rs:319-326)
                 r[k] = v;
             }
+            if constexpr (MASKED && sizeof(T) <= 2) r = zero_null_slots<V, (int)sizeof(T)>(r, bits);
             store16<V, NTS>(o + (size_t)u * 64, r);
             if constexpr (DATA_VALIDITY) {
                 // head == 0 here (host dispatch), so a step's 64*R rows are exactly R output validity words.

@@ -102,6 +102,7 @@ struct ma_ctx {
     std::vector<ma_ctx*> lanes;        // owned; guarded by lanes_mu
     std::mutex lanes_mu;
     int max_lanes = 4;                 // the context itself included (MINARROW_HIP_LANES)
+    bool fenced_reduce = false;        // MINARROW_HIP_FENCED_REDUCE=1: the round-1 release/acquire publish in the sum kernels
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.

@@ -429,6 +429,7 @@ Enter::Enter(ma_ctx*& ctx, bool primary_only) {
             lane->blocks_per_cu = root->blocks_per_cu;
             lane->grid_override = root->grid_override;
             lane->staging_tile_bytes = root->staging_tile_bytes;
+            lane->fenced_reduce = root->fenced_reduce;
         }
     }
     locked_ = lane;
@@ -661,6 +662,7 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
     if (c->staging_tile_bytes != 0 && c->staging_tile_bytes < ((size_t)1 << 16)) c->staging_tile_bytes = (size_t)1 << 16;
     const size_t lanes = env_bytes("MINARROW_HIP_LANES", (size_t)c->max_lanes);
     c->max_lanes = lanes < 1 ? 1 : (lanes > 16 ? 16 : (int)lanes);
+    c->fenced_reduce = env_bytes("MINARROW_HIP_FENCED_REDUCE", 0) != 0;
     *out_ctx = c;
     return MA_OK;
 }

@@ -197,6 +197,25 @@ __device__ __forceinline__ uint64_t pack_lane_bits(unsigned bits, unsigned lane)
     return v;
 }
 
+// Zeroes the null slots of a 16-byte vector of 1- or 2-byte elements: the lane's R validity bits are spread into byte /
+// halfword masks with one multiply per 32-bit word (bit i of a nibble -> byte i: n * 0x00204081 puts b0..b3 at bits
+// 0, 8, 16, 24 with no carries; x 0xFF fills the bytes) instead of a test + select per element — 16 VALU operations per
+// vector where the per-element form needs 48.
+typedef unsigned int U32x4 __attribute__((ext_vector_type(4)));
+template <typename V, int ELEM_BYTES>
+__device__ __forceinline__ V zero_null_slots(V v, unsigned bits) {
+    static_assert(ELEM_BYTES == 1 || ELEM_BYTES == 2, "wider elements select per element");
+    U32x4 w = __builtin_bit_cast(U32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned m;
+        if constexpr (ELEM_BYTES == 1) m = ((((bits >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+        else m = ((((bits >> (2 * i)) & 0x3u) * 0x8001u) & 0x00010001u) * 0xFFFFu;
+        w[i] &= m;
+    }
+    return __builtin_bit_cast(V, w);
+}
+
 __device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
     return (unsigned)(((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
 }

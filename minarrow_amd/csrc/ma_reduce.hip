@@ -356,7 +356,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
     // tiled mapping stays the default.
     a.interleave = (!masked && nt && unroll == 8 && (variant & 16) != 0) ? 1 : 0;
-    a.fenced = (variant & 256) ? 1 : 0;
+    a.fenced = ((variant & 256) || ctx->fenced_reduce) ? 1 : 0;
     // Load pacing (pace_loads): idle cycles between a wave's consecutive loads. Swept per type at 10^9 rows
     // (profiles/r01_sweep_sum_pace.txt): dense i64 1.117 -> 1.099 ms at 24 cycles, f64 1.106 -> 1.095 at 20, i32 0.586 ->
     // 0.583 at 16, f32 0.591 -> 0.566 at 16-32; the masked kernels, which already spend cycles on validity words between

@@ -353,3 +353,33 @@ def test_byte_misaligned_mask_pointer(ctx, oracle):
         assert ctx.sum("i64", d, n, mask=m.offset(byte_delta), mask_bit_offset=bit_off) == expect
         view = bits[byte_delta:]  # a numpy view: pageable memory at an odd address
         assert ctx.sum("i64", a, n, mask=view, mask_bit_offset=bit_off) == expect
+
+
+@pytest.mark.parametrize("n", [1, 4097, (1 << 20) + 37, (1 << 24) + 5])
+def test_both_publish_forms_of_the_reduction_agree(ctx, oracle, n):
+    """The single-launch reduction publishes per-workgroup partials with write-through stores + sharded arrival tickets
+    (default) or with agent-scope release / acquire fences (ctx variant bit 8, MINARROW_HIP_FENCED_REDUCE=1): identical
+    results, for grids below and above the sharding threshold, dense and masked."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+    f = rng.standard_normal(n) * 1e3
+    bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+    da, df, dm = ctx.to_device(a, 64), ctx.to_device(f, 64), ctx.to_device(bits, 16)
+    got = {}
+    try:
+        for variant in (0, 256):
+            ctx.set_variant(variant)
+            for grid in (0, 3, 97, 2048):
+                ctx.set_grid(grid)
+                got[(variant, grid)] = (ctx.sum("i64", da, n), ctx.sum("i64", da, n, mask=dm, mask_bit_offset=5),
+                                        ctx.sum_dd("f64", df, n), ctx.sum("f64", df, n, mask=dm))
+    finally:
+        ctx.set_variant(0)
+        ctx.set_grid(0)
+    assert got[(0, 0)][0] == (oracle.sum_scalar(a), n)
+    assert got[(0, 0)][1] == oracle.masked_sum(a, bits, 5)
+    for grid in (0, 3, 97, 2048):
+        assert got[(0, grid)] == got[(256, grid)]          # same grid, same fold order: bit-identical, floats included
+        assert got[(0, grid)][:2] == got[(0, 0)][:2]       # integers: any grid
+    for b in (da, df, dm):
+        b.free()
