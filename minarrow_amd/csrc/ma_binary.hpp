@@ -234,6 +234,21 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
             if constexpr (MASKED) bits = aw.template bits<R>(u, lane);
             unsigned out_bits = bits;
             V r;
+            if constexpr (sizeof(T) == 1 && (OP == MA_OP_ADD || OP == MA_OP_SUBTRACT)) {
+                // 1-byte wrapping add / subtract, four elements per 32-bit operation (carries cut at the byte borders:
+                // the low 7 bits add / subtract freely, the top bit is patched in by XOR) instead of sixteen 16-bit
+                // operations with sub-dword selects per vector.
+                const unsigned splat = (unsigned)(uint8_t)a.scalar * 0x01010101u;
+                const U32x4 ss = {splat, splat, splat, splat};
+                U32x4 x = ss, y = ss;
+                if constexpr (KIND != kSA) x = __builtin_bit_cast(U32x4, va[u]);
+                if constexpr (KIND != kAS) y = __builtin_bit_cast(U32x4, vb[u]);
+                constexpr unsigned H = 0x80808080u, L = 0x7f7f7f7fu;
+                U32x4 z;
+                if constexpr (OP == MA_OP_ADD) z = ((x & L) + (y & L)) ^ ((x ^ y) & H);
+                else z = ((x | H) - (y & L)) ^ ((x ^ ~y) & H);
+                r = __builtin_bit_cast(V, z);
+            } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 T x = KIND == kSA ? a.scalar : (T)va[u][k];
@@ -245,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
                 if constexpr (MASKED && sizeof(T) > 2) v = ((bits >> k) & 1u) ? v : (T)0;
                 if constexpr (DATA_VALIDITY) out_bits &= ~((dzk ? 1u : 0u) << k);  // m & !div_zero (simd.rs:319-326)
                 r[k] = v;
+            }
             }
             if constexpr (MASKED && sizeof(T) <= 2) r = zero_null_slots<V, (int)sizeof(T)>(r, bits);
             store16<V, NTS>(o + (size_t)u * 64, r);
