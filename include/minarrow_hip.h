@@ -30,7 +30,8 @@
  *    is the contract there. Independent ctxs are fully independent. No hidden global scratch.
  *  - Environment (read once): MINARROW_HIP_DEVICES ("2,3": the library's ordinal i is HIP device
  *    list[i]), MINARROW_HIP_MIN_ROWS (ma_min_device_rows), MINARROW_HIP_STAGING_TILE (bytes, ma_ctx_set_staging_tile's
- *    default), MINARROW_HIP_LANES, MINARROW_HIP_GROUP_EXCHANGE ("rccl"), MINARROW_HIP_FENCED_REDUCE, MINARROW_HIP_PINNED_POOL_BYTES,
+ *    default), MINARROW_HIP_LANES, MINARROW_HIP_GROUP_EXCHANGE ("rccl"), MINARROW_HIP_FENCED_REDUCE, MINARROW_HIP_POLL_US,
+ *    MINARROW_HIP_PINNED_POOL_BYTES,
  *    MINARROW_HIP_DEV_POOL_BYTES (block-cache limits).
  *
  * Status codes mirror KernelError (src/enums/error.rs:157-187) as far as the numeric kernels can raise them.

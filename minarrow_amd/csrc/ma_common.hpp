@@ -102,6 +102,8 @@ struct ma_ctx {
     std::vector<ma_ctx*> lanes;        // owned; guarded by lanes_mu
     std::mutex lanes_mu;
     int max_lanes = 4;                 // the context itself included (MINARROW_HIP_LANES)
+    uint64_t result_seq = 0;           // stamps of the polled synchronous reductions (ma_reduce.hip)
+    long poll_us = 60;                 // MINARROW_HIP_POLL_US: how long such a call polls before it blocks (0 = never poll)
     bool fenced_reduce = false;        // MINARROW_HIP_FENCED_REDUCE=1: the round-1 release/acquire publish in the sum kernels
 };
 

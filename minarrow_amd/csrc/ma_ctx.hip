@@ -430,6 +430,7 @@ Enter::Enter(ma_ctx*& ctx, bool primary_only) {
             lane->grid_override = root->grid_override;
             lane->staging_tile_bytes = root->staging_tile_bytes;
             lane->fenced_reduce = root->fenced_reduce;
+            lane->poll_us = root->poll_us;
         }
     }
     locked_ = lane;
@@ -663,6 +664,7 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
     const size_t lanes = env_bytes("MINARROW_HIP_LANES", (size_t)c->max_lanes);
     c->max_lanes = lanes < 1 ? 1 : (lanes > 16 ? 16 : (int)lanes);
     c->fenced_reduce = env_bytes("MINARROW_HIP_FENCED_REDUCE", 0) != 0;
+    c->poll_us = (long)env_bytes("MINARROW_HIP_POLL_US", (size_t)c->poll_us);
     *out_ctx = c;
     return MA_OK;
 }

@@ -21,6 +21,8 @@
 //     rounded sum regardless of order, and bit-reproducible for a fixed grid.
 //   * Wave reduce by shuffles -> 4 LDS slots -> one 32-byte partial per workgroup -> the workgroup that
 //     draws the last ticket folds all partials in index order (agent-scope release/acquire).
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <limits>
 
@@ -48,6 +50,8 @@ struct SumArgs {
     int mode;               // 0: out_a = final value (int, or rounded double); 1: out_a/out_b = double-double
     int is_signed;          // integer mean: interpret the 64-bit sum as signed
     int fenced;             // 1: round-1 publish (release / acquire fences) instead of sc1 stores (A/B only)
+    uint64_t* done_word;    // pinned host word the final thread stamps with done_seq after the results (or nullptr):
+    uint64_t done_seq;      //   a synchronous call polls it instead of paying hipStreamSynchronize's wake-up
 };
 
 // Arrival counters inside the context's zeroed scratch block (ma_ctx.hip): word 0 is the top ticket; the shards sit on
@@ -284,6 +288,9 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         if (a.out_cnt) *a.out_cnt = c;
         if (a.out_mean) *a.out_mean = c ? as_double / (double)c : __longlong_as_double(0x7ff8000000000000ll);
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+        // Last of all: tell a polling host that every result above has landed (system-scope release: the results may sit
+        // in host memory or in device memory the host will read next).
+        if (a.done_word) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -547,8 +554,32 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
     a.out_mean = out_mean ? (direct_m ? out_mean : mean_slot) : nullptr;
     a.mode = mode;
     a.is_signed = is_signed ? 1 : 0;
+    // A synchronous call on resident data does not go through hipStreamSynchronize (whose wake-up costs ~10 us, most
+    // of a small call): the kernel's final thread stamps a pinned word after its results and the host polls that word —
+    // for at most kPollUs, then it falls back to the blocking wait (a multi-millisecond scan must not burn a core).
+    const bool poll = !is_async(ctx) && !scope.staged() && !ctx->capturing && ctx->poll_us > 0;
+    volatile uint64_t* done = (volatile uint64_t*)&slot[2].a;
+    if (poll) {
+        a.done_word = (uint64_t*)done;
+        a.done_seq = ++ctx->result_seq;
+    }
     MA_TRY(enqueue_sum<T>(ctx, a, masked));
-    MA_TRY(end_call(ctx, scope));
+    bool landed = false;
+    if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (*done == a.done_seq) {
+                landed = true;
+                break;
+            }
+            if ((spins & 63) == 63 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->poll_us)
+                break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!landed) MA_TRY(end_call(ctx, scope));
     if (!is_async(ctx)) {
         if (out_a && !direct_a) memcpy(out_a, &slot->a, 8);
         if (out_b && !direct_b) memcpy(out_b, &slot->b, 8);

@@ -39,11 +39,23 @@ def test_threads_sharing_one_context_overlap():
     sums of their own 2^20-row column through ONE context; the context's lanes let the calls overlap, so the wall time
     must be well under the same calls made one after the other (measured 0.42x on MI355X, tools/bench_lanes.py; 1.03x
     with MINARROW_HIP_LANES=1). Results are checked on every call."""
+    import os
     import time
 
     from minarrow_amd.host import Context
 
-    ctx = Context(0)
+    # The blocking wait (hipStreamSynchronize) is what a serialising context would queue its callers behind; the polled
+    # wait of synchronous reductions (MINARROW_HIP_POLL_US) shortens the serial leg by ~30 % and would blur the ratio
+    # this test is about, so this context is created without it (the variable is read at context creation).
+    saved = os.environ.get("MINARROW_HIP_POLL_US")
+    os.environ["MINARROW_HIP_POLL_US"] = "0"
+    try:
+        ctx = Context(0)
+    finally:
+        if saved is None:
+            del os.environ["MINARROW_HIP_POLL_US"]
+        else:
+            os.environ["MINARROW_HIP_POLL_US"] = saved
     n, T, reps = 1 << 20, 4, 400
     bufs = []
     for i in range(T):
