@@ -82,19 +82,44 @@ __device__ __forceinline__ size_t pair_index(size_t tile, int u) {
     return (tile * kWaves + wave) * ((size_t)kVecUnroll * 64) + (size_t)u * 64 + lane;
 }
 
-// `vec`: both windows start on a word (bit offset % 64 == 0) and every pointer is 16-byte aligned at the window's
-// first word, so two words move per lane per access (global_load/store_dwordx4, non-temporal).
+// Word pair of a window that starts at ANY bit: the pair is read with a byte-aligned 16-byte load at the window's first
+// byte; the remaining 1..7 bits are funnelled in registers — x0 from (p.x, p.y), x1 from (p.y, the next pair's first
+// byte), which is the neighbouring lane's p.x (lane 63 of a wave instruction reads that one byte itself).
+__device__ __forceinline__ u64x2 funnel_pair(u64x2 p, unsigned sub, uint64_t next_of_lane63, unsigned lane) {
+    if (sub == 0) return p;  // wave-uniform
+    uint64_t nx = (uint64_t)__shfl_down((unsigned long long)p.x, 1, 64);
+    if (lane == 63) nx = next_of_lane63;
+    u64x2 r;
+    r.x = (p.x >> sub) | (p.y << (64 - sub));
+    r.y = (p.y >> sub) | (nx << (64 - sub));
+    return r;
+}
+
+// `vec`: two words move per lane per access (global_load/store_dwordx4, non-temporal). The windows may start at any
+// bit (round 2; byte-aligned starts only in round 1); the output must sit on a 16-byte boundary.
 template <bool VEC>  // separate instantiations: the word-pair path's registers must not cost the scalar path its occupancy
 __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     size_t first_scalar = 0;
     if constexpr (VEC) {
-        const size_t n_pairs = (n_words - 1) >> 1;  // the last word (trailing-bit mask) always goes through the scalar path
-        // windows start on BYTES here (vec_ok): a byte-shifted pointer is the window, no funnel shift needed
-        const u64x2_u* __restrict__ lp = (const u64x2_u*)((const uint8_t*)a.lw + (a.lo >> 3));
-        const u64x2_u* __restrict__ rp = a.rw ? (const u64x2_u*)((const uint8_t*)a.rw + (a.ro >> 3)) : nullptr;
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned sl = (unsigned)(a.lo & 7), sr = (unsigned)(a.ro & 7);
+        const uint8_t* __restrict__ lb = (const uint8_t*)a.lw + (a.lo >> 3);
+        const uint8_t* __restrict__ rb = a.rw ? (const uint8_t*)a.rw + (a.ro >> 3) : nullptr;
+        const u64x2_u* __restrict__ lp = (const u64x2_u*)lb;
+        const u64x2_u* __restrict__ rp = (const u64x2_u*)rb;
         u64x2* __restrict__ op = (u64x2*)a.out;
+        // Pairs the vector body may touch: the last word (trailing-bit mask) always goes through the scalar path, and a
+        // pair reads 17 bytes (16 + the funnel byte) which must stay inside the words that hold window bits.
+        size_t n_pairs = (n_words - 1) >> 1;
+        auto cap = [&](size_t off_bits, size_t last_word) {
+            const size_t avail = (last_word + 1) * 8, b0 = off_bits >> 3;  // readable bytes; the window's first byte
+            const size_t safe = avail >= b0 + 17 ? (avail - b0 - 17) / 16 + 1 : 0;
+            if (safe < n_pairs) n_pairs = safe;
+        };
+        cap(a.lo, a.l_last);
+        if (rb) cap(a.ro, a.r_last);
         // Tiles of kVecUnroll * kBlock pairs: every lane issues its kVecUnroll loads per operand before the first use.
         const size_t n_tiles = n_pairs / ((size_t)kVecUnroll * kBlock);
         for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -106,25 +131,46 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
                 y[u] = u64x2{0, 0};
                 if (rp) y[u] = __builtin_nontemporal_load(rp + pair_index(t, u));
             }
+            // Lane 63's funnel partner is lane 0's pair of the NEXT access (the wave's run is contiguous); only the last
+            // access needs a byte from beyond the run, fetched along with the rest.
+            uint64_t xt = 0, yt = 0;
+            if (lane == 63) {
+                const size_t after = 16 * (pair_index(t, kVecUnroll - 1) + 1);
+                if (sl) xt = lb[after];
+                if (rp && sr) yt = rb[after];
+            }
 #pragma unroll
             for (int u = 0; u < kVecUnroll; ++u) {
+                const size_t j = pair_index(t, u);
+                const uint64_t xn = u + 1 < kVecUnroll ? (uint64_t)__shfl((unsigned long long)x[u + 1 < kVecUnroll ? u + 1 : u].x, 0, 64) : xt;
+                const uint64_t yn = u + 1 < kVecUnroll ? (uint64_t)__shfl((unsigned long long)y[u + 1 < kVecUnroll ? u + 1 : u].x, 0, 64) : yt;
+                const u64x2 xx = funnel_pair(x[u], sl, xn, lane);
+                u64x2 yy = y[u];
+                if (rp) yy = funnel_pair(y[u], sr, yn, lane);
                 u64x2 r;
-                r.x = bit_op(a.op, x[u].x, y[u].x);
-                r.y = bit_op(a.op, x[u].y, y[u].y);
-                __builtin_nontemporal_store(r, op + pair_index(t, u));
+                r.x = bit_op(a.op, xx.x, yy.x);
+                r.y = bit_op(a.op, xx.y, yy.y);
+                __builtin_nontemporal_store(r, op + j);
             }
         }
-        for (size_t j = n_tiles * ((size_t)kVecUnroll * kBlock) + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_pairs;
-             j += stride) {
-            u64x2 x = __builtin_nontemporal_load(lp + j);
+        // whole waves only: funnel_pair shuffles across the lanes of a wave instruction
+        const size_t done = n_tiles * ((size_t)kVecUnroll * kBlock);
+        const size_t n_vec = done + ((n_pairs - done) / 64) * 64;
+        for (size_t j = done + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_vec; j += stride) {
+            uint64_t xt = 0, yt = 0;
+            if (lane == 63) {
+                if (sl) xt = lb[16 * (j + 1)];
+                if (rp && sr) yt = rb[16 * (j + 1)];
+            }
+            u64x2 x = funnel_pair(__builtin_nontemporal_load(lp + j), sl, xt, lane);
             u64x2 y = {0, 0};
-            if (rp) y = __builtin_nontemporal_load(rp + j);
+            if (rp) y = funnel_pair(__builtin_nontemporal_load(rp + j), sr, yt, lane);
             u64x2 r;
             r.x = bit_op(a.op, x.x, y.x);
             r.y = bit_op(a.op, x.y, y.y);
             __builtin_nontemporal_store(r, op + j);
         }
-        first_scalar = n_pairs << 1;
+        first_scalar = n_vec << 1;
     }
     for (size_t j = first_scalar + (size_t)blockIdx.x * kBlock + threadIdx.x; j < n_words; j += stride) {
         uint64_t x = window_word(a.lw, a.lo, a.l_last, j);
@@ -287,8 +333,8 @@ static void fill_window(BitArgs& a, const uint64_t* lw, size_t lo, const uint64_
 // the reference anyway, bitmask/mod.rs:124-128); inputs are read with byte-aligned 16-byte loads, the output (always
 // re-based to bit 0) must sit on a 16-byte boundary.
 static int vec_ok(const BitArgs& a, bool with_out) {
-    if ((a.lo & 7) || (a.rw && (a.ro & 7))) return 0;
-    if (with_out && ((uintptr_t)a.out & 15)) return 0;
+    if (!with_out && ((a.lo & 7) || (a.rw && (a.ro & 7)))) return 0;  // the scan kernel reads byte-aligned windows only
+    if (with_out && ((uintptr_t)a.out & 15)) return 0;                 // the word kernel funnels any bit offset
     return a.n >= 256 ? 1 : 0;
 }
 

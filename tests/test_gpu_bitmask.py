@@ -161,6 +161,21 @@ def test_not_and_slice_random(g, oracle):
             assert not unpack(sl, nbytes(n) * 8 - n, n).any()  # trailing bits are zero
 
 
+@pytest.mark.parametrize("n", [256, 8191, 64 * 64 * 2 + 1, (1 << 18) + 64, (1 << 22) + 77, 3 * (1 << 21) + 12345])
+def test_slice_at_every_sub_byte_offset_through_the_vector_path(g, n):
+    """bitmask_slice re-bases a window that starts at ANY bit. From 256 bits on the kernel moves word pairs (16-byte
+    accesses) and funnels the 1..7 leftover bits in registers — across lanes within a wave instruction, across the
+    accesses of a wave's run, and into the scalar tail: sizes around each of those seams, every sub-byte offset, checked
+    bit for bit against numpy."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
+    bits = np.unpackbits(a, bitorder="little")
+    for off in (1, 2, 3, 4, 5, 6, 7, 13, 63, 64 + 9, 8 * 5 + 3):
+        sl = g.unary("bitmask_slice", a, off, n)
+        np.testing.assert_array_equal(unpack(sl, n), bits[off:off + n].astype(bool), err_msg=f"n={n} off={off}")
+        assert not unpack(sl, nbytes(n) * 8 - n, n).any()  # trailing bits are zero
+
+
 def test_popcount_and_predicates_random(ctx, oracle):
     rng = np.random.default_rng(3)
     for n in LENS + [10_000_019]:
