@@ -59,12 +59,26 @@ struct Elem<T, false> {
         return (T)acc;
     }
     static __device__ __forceinline__ T div(T a, T b) {
-        if (kSigned && b == (T)-1) return (T)((U)0 - (U)a);  // MIN / -1 wraps to MIN like the SIMD lanes
-        return (T)(a / b);
+        if constexpr (sizeof(T) == 1) {
+            // 8-bit quotients through one reciprocal instead of the ~30-instruction 32-bit division sequence: a * rcp(b)
+            // carries <= 2 ulp (2.4e-7 relative); a non-integer quotient sits >= 1/255 away from the next integer, so
+            // it cannot cross it, and an exact integer quotient is kept on the right side of the truncation by scaling
+            // with 1 + 2^-20. Exhaustively checked over all 65 536 operand pairs of both types
+            // (tests/test_gpu_arith.py::test_8bit_division_exhaustive). MIN / -1 gives 128, which wraps to MIN.
+            const float q = (float)(int)a * __builtin_amdgcn_rcpf((float)(int)b) * 1.00000095367431640625f;
+            return (T)(int)q;  // truncation toward zero
+        } else {
+            if (kSigned && b == (T)-1) return (T)((U)0 - (U)a);  // MIN / -1 wraps to MIN like the SIMD lanes
+            return (T)(a / b);
+        }
     }
     static __device__ __forceinline__ T rem(T a, T b) {
-        if (kSigned && b == (T)-1) return (T)0;
-        return (T)(a % b);
+        if constexpr (sizeof(T) == 1) {
+            return (T)((int)a - (int)div(a, b) * (int)b);  // MIN % -1: -128 - (-128)(-1) wraps to 0
+        } else {
+            if (kSigned && b == (T)-1) return (T)0;
+            return (T)(a % b);
+        }
     }
     template <int OP>
     static __device__ __forceinline__ T apply(T a, T b, bool& dz) {

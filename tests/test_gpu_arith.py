@@ -280,6 +280,39 @@ def test_datetime_two_masks_fused_matches_merge_then_apply(ctx, oracle, tag, n):
         buf.free()
 
 
+@pytest.mark.parametrize("tag", ["i8", "u8"])
+def test_8bit_division_exhaustive(ctx, oracle, tag):
+    """Every operand pair of the 1-byte types (65 536 per type) through Divide / Remainder / FloorDiv, dense (zero
+    divisors excluded: they are the reference's panic) and masked (zero divisors null the row): the kernels compute
+    8-bit quotients through a float reciprocal, which must be exact everywhere, MIN / -1 included."""
+    dt = NP[tag]
+    info = np.iinfo(dt)
+    vals = np.arange(info.min, info.max + 1, dtype=np.int64)
+    a = np.repeat(vals, vals.size).astype(dt)
+    b = np.tile(vals, vals.size).astype(dt)
+    n = a.size
+    nz = b != 0
+    an, bn = np.ascontiguousarray(a[nz]), np.ascontiguousarray(b[nz])
+    da, db = ctx.to_device(an, 64), ctx.to_device(bn, 64)
+    dout = ctx.alloc(an.size + 64)
+    for op in ("divide", "remainder", "floordiv"):
+        st, want, _, _ = oracle.apply_int(an, bn, op)
+        assert st & ~4 == 0  # bit 2: the scalar body's MIN / -1 overflow panic; the value written is the wrapping one
+        ctx.apply(tag, da, db, OPS[op], dout, an.size, an.size)
+        np.testing.assert_array_equal(dout.download(dt, an.size), want[:an.size], err_msg=f"{tag} {op} dense")
+    mask = np.full(mask_bytes(n) + 16, 0xFF, dtype=np.uint8)
+    dA, dB, dm = ctx.to_device(a, 64), ctx.to_device(b, 64), ctx.to_device(mask, 16)
+    dO, dom = ctx.alloc(n + 64), ctx.alloc(mask_bytes(n) + 16)
+    for op in ("divide", "remainder", "floordiv"):
+        st, want, want_mask, _ = oracle.apply_int(a, b, op, mask, n)
+        assert st & ~4 == 0  # bit 2: the scalar body's MIN / -1 overflow panic; the value written is the wrapping one
+        ctx.apply(tag, dA, dB, OPS[op], dO, n, n, mask=dm, out_mask=dom)
+        np.testing.assert_array_equal(dO.download(dt, n), want[:n], err_msg=f"{tag} {op} masked")
+        np.testing.assert_array_equal(unpack(dom.download(np.uint8, mask_bytes(n)), n), unpack(want_mask, n))
+    for buf in (da, db, dout, dA, dB, dm, dO, dom):
+        buf.free()
+
+
 def test_ref_int_power_short_vs_long(gpu):
     """test_int_dense_power_short_vs_long_input_simd — mod.rs:507-537"""
     g = ARITH["int_power_short_vs_long"]

@@ -57,10 +57,41 @@ def worker(seed):
     ctx.close()
 
 
+def shared_worker(ctx, seed):
+    """Round 2: SYNCHRONOUS sums from several threads through ONE context — its lanes (own stream, partials and arrival
+    tickets each) and the polled completion word, on dense and masked windows at random sizes and offsets."""
+    rng = np.random.default_rng(1000 + seed)
+    n_max = 2_000_000
+    a = rng.integers(-(1 << 40), 1 << 40, size=n_max, dtype=np.int64)
+    bits = rng.integers(0, 256, size=n_max // 8 + 64, dtype=np.uint8)
+    valid = np.unpackbits(bits, bitorder="little")[:n_max].astype(bool)
+    d, m = ctx.to_device(a, 64), ctx.to_device(bits, 16)
+    csum = np.concatenate([[0], np.cumsum(a)])
+    msum = np.concatenate([[0], np.cumsum(np.where(valid, a, 0))])
+    mcnt = np.concatenate([[0], np.cumsum(valid)])
+    t_end = time.time() + seconds
+    done = 0
+    while time.time() < t_end and not errors:
+        n = int(rng.integers(1, n_max))
+        off = int(rng.integers(0, n_max - n + 1)) & ~1
+        got = ctx.sum("i64", d.offset(off * 8), n)
+        if got != (int(csum[off + n] - csum[off]), n):
+            errors.append(f"shared ctx seed {seed}: dense n={n} off={off} got {got}")
+        got = ctx.sum("i64", d.offset(off * 8), n, mask=m, mask_bit_offset=off)
+        if got != (int(msum[off + n] - msum[off]), int(mcnt[off + n] - mcnt[off])):
+            errors.append(f"shared ctx seed {seed}: masked n={n} off={off} got {got}")
+        done += 2
+    counts.append(done)
+
+
+shared = Context(0)
 threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+threads += [threading.Thread(target=shared_worker, args=(shared, s)) for s in range(4)]
 [t.start() for t in threads]
 [t.join() for t in threads]
-print(f"{sum(counts)} reductions checked on 4 contexts, {len(errors)} errors")
+shared.close()
+print(f"{sum(counts)} reductions checked on 4 private contexts (async, random grids) + 4 threads sharing one context "
+      f"(synchronous, lanes + polled completion), {len(errors)} errors")
 for e in errors[:10]:
     print(e)
 sys.exit(1 if errors else 0)
