@@ -102,6 +102,8 @@ ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled);
 void* ma_ctx_stream(ma_ctx* ctx);
 int32_t ma_ctx_device(ma_ctx* ctx);
 int32_t ma_ctx_compute_units(ma_ctx* ctx);
+/* Lanes the context has grown so far, itself included (1 until two synchronous calls overlap; at most MINARROW_HIP_LANES). */
+int32_t ma_ctx_lane_count(ma_ctx* ctx);
 /* Launch geometry for the streaming kernels: workgroups per CU (0 = built-in default). */
 ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
 /* Tuning harness: absolute workgroup count for the streaming kernels (0 = built-in default). */

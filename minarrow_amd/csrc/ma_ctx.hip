@@ -816,6 +816,11 @@ void ma_graph_destroy(ma_graph* graph) {
 void* ma_ctx_stream(ma_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int32_t ma_ctx_device(ma_ctx* ctx) { return ctx ? ctx->device : -1; }
 int32_t ma_ctx_compute_units(ma_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+int32_t ma_ctx_lane_count(ma_ctx* ctx) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> ll(ctx->lanes_mu);
+    return 1 + (int32_t)ctx->lanes.size();
+}
 
 ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");

@@ -36,62 +36,69 @@ def test_many_threads_one_shared_context(ctx):
 
 def test_threads_sharing_one_context_overlap():
     """SURVEY §8(b) Threading: a shared context must not serialise its callers. Four threads each make synchronous
-    sums of their own 2^20-row column through ONE context; the context's lanes let the calls overlap, so the wall time
-    must be well under the same calls made one after the other (measured 0.42x on MI355X, tools/bench_lanes.py; 1.03x
-    with MINARROW_HIP_LANES=1). Results are checked on every call."""
+    sums of their own 2^20-row column through ONE context. Deterministic part: the context grows lanes (own stream +
+    reduction scratch) when calls overlap, and a context created with MINARROW_HIP_LANES=1 never does. Timing part: the
+    same four threads finish sooner on the context with lanes than on the one without (0.4-0.7x on MI355X,
+    tools/bench_lanes.py; asserted loosely — the box's CPU quota and the GIL are in this figure too). Results are
+    checked on every call."""
     import os
     import time
 
     from minarrow_amd.host import Context
 
-    # The blocking wait (hipStreamSynchronize) is what a serialising context would queue its callers behind; the polled
-    # wait of synchronous reductions (MINARROW_HIP_POLL_US) shortens the serial leg by ~30 % and would blur the ratio
-    # this test is about, so this context is created without it (the variable is read at context creation).
-    saved = os.environ.get("MINARROW_HIP_POLL_US")
-    os.environ["MINARROW_HIP_POLL_US"] = "0"
-    try:
-        ctx = Context(0)
-    finally:
-        if saved is None:
-            del os.environ["MINARROW_HIP_POLL_US"]
-        else:
-            os.environ["MINARROW_HIP_POLL_US"] = saved
-    n, T, reps = 1 << 20, 4, 400
-    bufs = []
-    for i in range(T):
-        b = ctx.alloc(n * 8)
-        ctx.synth_iota("i64", b, n, i)
-        bufs.append(b)
+    def make(lanes):
+        saved = {k: os.environ.get(k) for k in ("MINARROW_HIP_POLL_US", "MINARROW_HIP_LANES")}
+        # the blocking wait is what a serialising context queues its callers behind; the polled wait of synchronous
+        # reductions would blur the comparison (both variables are read at context creation)
+        os.environ["MINARROW_HIP_POLL_US"] = "0"
+        os.environ["MINARROW_HIP_LANES"] = str(lanes)
+        try:
+            return Context(0)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+
+    n, T, reps = 1 << 20, 4, 300
     want = [n * (n - 1) // 2 + i * n for i in range(T)]
     errors = []
-
-    def work(i, count):
-        try:
-            for _ in range(count):
-                assert ctx.sum("i64", bufs[i], n) == (want[i], n)
-        except Exception as e:  # noqa: BLE001
-            errors.append(repr(e))
-
-    def concurrent(count):
-        ts = [threading.Thread(target=work, args=(i, count)) for i in range(T)]
-        t0 = time.perf_counter()
-        [t.start() for t in ts]
-        [t.join() for t in ts]
-        return time.perf_counter() - t0
-
-    concurrent(20)  # the lanes exist from here on
-    best_ratio = 10.0
-    for _ in range(3):
-        t0 = time.perf_counter()
+    timings = {}
+    for lanes in (4, 1):
+        ctx = make(lanes)
+        bufs = []
         for i in range(T):
-            work(i, reps)
-        serial = time.perf_counter() - t0
-        best_ratio = min(best_ratio, concurrent(reps) / serial)
-    for b in bufs:
-        b.free()
-    ctx.close()
+            b = ctx.alloc(n * 8)
+            ctx.synth_iota("i64", b, n, i)
+            bufs.append(b)
+
+        def work(i, count):
+            try:
+                for _ in range(count):
+                    assert ctx.sum("i64", bufs[i], n) == (want[i], n)
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        def concurrent(count):
+            ts = [threading.Thread(target=work, args=(i, count)) for i in range(T)]
+            t0 = time.perf_counter()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            return time.perf_counter() - t0
+
+        concurrent(30)
+        timings[lanes] = min(concurrent(reps) for _ in range(3))
+        grown = ctx.lib.ma_ctx_lane_count(ctx.handle)
+        if lanes == 1:
+            assert grown == 1
+        else:
+            assert 2 <= grown <= 4, grown  # overlapping calls ran on lanes instead of queueing on the context's lock
+        for b in bufs:
+            b.free()
+        ctx.close()
     assert not errors, errors
-    assert best_ratio < 0.75, f"concurrent / serial = {best_ratio:.2f}: the shared context serialises its callers"
+    assert timings[4] < 0.95 * timings[1], f"with lanes {timings[4]:.4f} s, without {timings[1]:.4f} s"
 
 
 def test_one_context_per_thread():
