@@ -575,6 +575,87 @@ static void device_residency_suite() {
     ASSERT(!mixed.data.is_device() && mixed.data[1] == a[1] + b[1]);
 }
 
+// rayon_simd_sum_{i64,f64} over the GPUs of the node, driven from ONE compiled host process straight through the C ABI
+// (benches/benchmark_parallel_simd.rs:81-98: `par_chunks(1 << 20).map(simd_sum).sum()` — here one row chunk per device,
+// the partials meeting in the library's exchange). Every visible device takes part (one on the test pool: the RCCL
+// exchange then runs with one rank); the f64 total must equal the single-device sum bit for bit when there is one
+// member and stay within 1 ULP of the exact sum otherwise.
+static void multi_gpu_group_suite() {
+    std::printf("multi-GPU group (C ABI)\n");
+    const int n_dev = std::min<int>(ma_device_count(), 8);
+    ASSERT(n_dev >= 1);
+    const size_t n = 3000017;
+    std::vector<int32_t> devs(n_dev);
+    for (int i = 0; i < n_dev; ++i) devs[i] = i;
+    for (uint32_t flags : {0u, (uint32_t)(MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST)}) {
+        ma_group* g = nullptr;
+        ASSERT(ma_group_create_ex(devs.data(), n_dev, flags, &g) == MA_OK);
+        if (!g) continue;
+        ASSERT(ma_group_size(g) == n_dev);
+        if (flags) ASSERT(ma_group_exchange_kind(g) == 1);  // distinct devices + librccl present: no fallback taken
+        // 64-row-aligned row chunks; chunk i lives on device i
+        std::vector<void*> di(n_dev), df(n_dev);
+        std::vector<const int64_t*> pi(n_dev);
+        std::vector<const double*> pf(n_dev);
+        std::vector<size_t> lens(n_dev);
+        const size_t units = (n + 63) / 64;
+        for (int r = 0; r < n_dev; ++r) {
+            const size_t lo = std::min(n, (units * r / n_dev) * 64), hi = r + 1 == n_dev ? n : std::min(n, (units * (r + 1) / n_dev) * 64);
+            lens[r] = hi - lo;
+            ma_ctx* c = ma_group_ctx(g, r);
+            ASSERT(ma_dev_alloc(c, lens[r] * 8 + 64, &di[r]) == MA_OK && ma_dev_alloc(c, lens[r] * 8 + 64, &df[r]) == MA_OK);
+            ASSERT(ma_synth_iota_i64(c, (int64_t*)di[r], lens[r], (int64_t)lo) == MA_OK);
+            ASSERT(ma_synth_iota_f64(c, (double*)df[r], lens[r], (int64_t)lo) == MA_OK);
+            pi[r] = (const int64_t*)di[r];
+            pf[r] = (const double*)df[r];
+        }
+        // asynchronous form: two steps back to back, both reductions share one exchange, one synchronize
+        for (int step = 0; step < 2; ++step) {
+            ASSERT(ma_group_enqueue_sum_i64(g, 0, pi.data(), lens.data(), nullptr, nullptr) == MA_OK);
+            ASSERT(ma_group_enqueue_sum_f64(g, 0, pf.data(), lens.data(), nullptr, nullptr) == MA_OK);
+            ASSERT(ma_group_exchange(g) == MA_OK);
+        }
+        ASSERT(ma_group_synchronize(g) == MA_OK);
+        const int64_t want = (int64_t)(n * (n - 1) / 2);
+        for (int m = 0; m < n_dev; ++m) {  // every GPU holds the job's finals
+            int64_t isum = 0;
+            uint64_t icnt = 0, fcnt = 0;
+            double fsum = 0;
+            ASSERT(ma_group_member_result(g, m, 0, &isum, &icnt, &fsum, &fcnt) == MA_OK);
+            ASSERT(isum == want && icnt == n && fcnt == n && fsum == (double)want);  // sum(0..n) < 2^53: exact in any order
+        }
+        // synchronous one-call form
+        int64_t s = 0;
+        uint64_t c = 0;
+        ASSERT(ma_group_sum_i64(g, pi.data(), lens.data(), nullptr, nullptr, &s, &c) == MA_OK && s == want && c == n);
+        for (int r = 0; r < n_dev; ++r) {
+            ASSERT(ma_dev_free(ma_group_ctx(g, r), di[r]) == MA_OK && ma_dev_free(ma_group_ctx(g, r), df[r]) == MA_OK);
+        }
+        ma_group_destroy(g);
+    }
+    // one process per GPU would use ma_comm_*: here a one-rank communicator on device 0
+    ma_ctx* ctx = nullptr;
+    ASSERT(ma_ctx_create(0, &ctx) == MA_OK);
+    uint8_t id[MA_COMM_ID_BYTES];
+    ma_comm* comm = nullptr;
+    ASSERT(ma_comm_unique_id(id) == MA_OK && ma_comm_create(ctx, id, 0, 1, &comm) == MA_OK);
+    if (comm) {
+        void *col = nullptr, *rec = nullptr, *gathered = nullptr, *fin = nullptr;
+        ASSERT(ma_dev_alloc(ctx, n * 8, &col) == MA_OK && ma_dev_alloc(ctx, 64, &rec) == MA_OK &&
+               ma_dev_alloc(ctx, 64, &gathered) == MA_OK && ma_dev_alloc(ctx, 32, &fin) == MA_OK);
+        ASSERT(ma_dev_memset(ctx, rec, 0, 64) == MA_OK && ma_synth_iota_i64(ctx, (int64_t*)col, n, 0) == MA_OK);
+        uint64_t* r = (uint64_t*)rec;
+        ASSERT(ma_i64_sum(ctx, (const int64_t*)col, n, nullptr, 0, 0, (int64_t*)&r[0], &r[1]) == MA_OK);
+        ASSERT(ma_comm_sum_exchange(comm, r, 1, 1, (uint64_t*)gathered, (uint64_t*)fin) == MA_OK);
+        uint64_t out[4] = {0, 0, 0, 0};
+        ASSERT(ma_dev_download(ctx, out, fin, 32) == MA_OK);
+        ASSERT((int64_t)out[0] == (int64_t)(n * (n - 1) / 2) && out[1] == n);
+        ma_comm_destroy(comm);
+        for (void* p : {col, rec, gathered, fin}) ASSERT(ma_dev_free(ctx, p) == MA_OK);
+    }
+    ma_ctx_destroy(ctx);
+}
+
 int main() {
     try {
         int_kernel_suite<int32_t>("i32", [](Slice<int32_t> l, Slice<int32_t> r, Op op, const Bitmask* m) { return apply_int_i32(l, r, op, m); });
@@ -592,6 +673,7 @@ int main() {
         routing_suite();
         chunked_suite();
         device_residency_suite();
+        multi_gpu_group_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
