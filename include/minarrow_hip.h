@@ -85,7 +85,7 @@ int32_t ma_abi_version(void);
  * is none; never initialises a device context). Device ordinals of this ABI index that list. */
 int32_t ma_device_count(void);
 /* Column length below which a host wrapper should keep the reference's CPU kernels (MINARROW_HIP_MIN_ROWS, default
- * 65536): a synchronous GPU call costs ~17 us whatever the size, the reference's 1000-row scalar sum 85 ns
+ * 65536): a synchronous GPU call costs ~12-14 us whatever the size, the reference's 1000-row scalar sum 85 ns
  * (src/lib.rs:58). Advice for the host shim only — the library itself has no CPU path and accepts any length. */
 int64_t ma_min_device_rows(void);
 /* Thread-local description of the last non-OK status returned on this thread. Never NULL. */

@@ -588,7 +588,7 @@ int32_t ma_device_count(void) { return physical_device_count() > 0 ? (int32_t)de
 
 int64_t ma_min_device_rows(void) {
     // MINARROW_HIP_MIN_ROWS: the column length below which a host wrapper should keep its CPU kernels — a GPU call costs
-    // ~17 us synchronously whatever the size (profiles/r01_launch_bound.json), the reference's scalar sum of 1000 rows
+    // ~12-17 us synchronously whatever the size (profiles/r02_sync_latency_polled.jsonl), the reference's scalar sum of 1000 rows
     // 85 ns (src/lib.rs:58). The library itself never computes on the CPU; this is advice the host shim reads.
     static const int64_t rows = (int64_t)env_bytes("MINARROW_HIP_MIN_ROWS", (size_t)1 << 16);
     return rows;
