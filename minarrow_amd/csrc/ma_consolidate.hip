@@ -182,13 +182,26 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
                 w0 = w1 = ~(uint64_t)0;
             } else {
                 const size_t b = d.bit_off + (row - d.start);
-                const size_t w = b >> 6;
-                const unsigned sh = (unsigned)(b & 63);
-                const uint64_t s0 = d.words[w];
-                const uint64_t s1 = d.words[w + 1];  // row + 64 is inside the chunk: word w + 1 holds window bits
-                const uint64_t s2 = (sh && w + 2 <= d.last_word) ? d.words[w + 2] : 0;
-                w0 = sh ? (s0 >> sh) | (s1 << (64 - sh)) : s0;
-                w1 = sh ? (s1 >> sh) | (s2 << (64 - sh)) : s1;
+                const size_t byte0 = b >> 3;
+                const unsigned sub = (unsigned)(b & 7);
+                if (byte0 + 17 <= (d.last_word + 1) * 8) {
+                    // one byte-aligned 16-byte load + the one byte that holds the last `sub` bits (two accesses, the
+                    // wide one at the full 16-byte rate) instead of three 8-byte loads
+                    typedef u2 u2u __attribute__((aligned(1)));
+                    const uint8_t* base = (const uint8_t*)d.words + byte0;
+                    const u2 pr = *(const u2u*)base;
+                    const uint64_t nx = sub ? (uint64_t)base[16] : 0;
+                    w0 = sub ? (pr.x >> sub) | (pr.y << (64 - sub)) : pr.x;
+                    w1 = sub ? (pr.y >> sub) | (nx << (64 - sub)) : pr.y;
+                } else {
+                    const size_t w = b >> 6;
+                    const unsigned sh = (unsigned)(b & 63);
+                    const uint64_t s0 = d.words[w];
+                    const uint64_t s1 = d.words[w + 1];  // row + 64 is inside the chunk: word w + 1 holds window bits
+                    const uint64_t s2 = (sh && w + 2 <= d.last_word) ? d.words[w + 2] : 0;
+                    w0 = sh ? (s0 >> sh) | (s1 << (64 - sh)) : s0;
+                    w1 = sh ? (s1 >> sh) | (s2 << (64 - sh)) : s1;
+                }
             }
         } else {
             w0 = gather_word<LDS>(tab, c, row, total);
