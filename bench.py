@@ -220,7 +220,12 @@ def gpu_other_configs(ctx, n: int, reps: int):
         e.update(extra)
         return e
 
-    a, b, o = (ctx.alloc(n * 8) for _ in range(3))
+    # The OUTPUT buffer first, through the placement-aware allocator (ma_dev_alloc_output: the fastest-writing of up to three
+    # candidate blocks; the rejected candidates are parked and come back as the inputs below, which read at the same rate
+    # wherever they are — DESIGN.md §3.4).
+    o = ctx.alloc_output(n * 8)
+    res["output_block_write_gbps"] = o.write_gbps
+    a, b = (ctx.alloc(n * 8) for _ in range(2))
     mask_bytes = ((n + 511) // 512) * 64 + 64
     mask, om = ctx.alloc(mask_bytes), ctx.alloc(mask_bytes)
     slot = ctx.alloc(256)

@@ -134,17 +134,21 @@ class Vec64 {
         if (data_ && !owner_) ma_free_pinned(data_);
     }
     static Vec64 with_capacity(size_t n) {
-        if (detail::result_placement() == Placement::Device) return on_device(n, 0);
+        if (detail::result_placement() == Placement::Device) return on_device(n, 0, /*written_by_kernels=*/true);
         Vec64 v;
         v.reserve(n);
         return v;
     }
     // `cap` elements of HBM owned by the returned vector (a window whose owner frees the allocation), length `len`.
     // Padded like the host form so that whole-u64-word bitmap writes stay inside it.
-    static Vec64 on_device(size_t cap, size_t len) {
+    // written_by_kernels: a result column (the `out` the reference allocates with Vec64::with_capacity,
+    // src/kernels/arithmetic/dispatch.rs:88-89) — large ones are picked for their write rate (ma_dev_alloc_output).
+    static Vec64 on_device(size_t cap, size_t len, bool written_by_kernels = false) {
         void* p = nullptr;
         ma_ctx* ctx = Context::global().get();
-        check(ma_dev_alloc(ctx, ((cap * sizeof(T) + 63) / 64) * 64 + 64, &p));
+        const size_t bytes = ((cap * sizeof(T) + 63) / 64) * 64 + 64;
+        if (written_by_kernels) check(ma_dev_alloc_output(ctx, bytes, &p, nullptr));
+        else check(ma_dev_alloc(ctx, bytes, &p));
         Vec64 v = from_shared(std::shared_ptr<void>(p, [ctx](void* q) { (void)ma_dev_free(ctx, q); }), static_cast<T*>(p), len);
         v.cap_ = cap;
         v.device_ = true;

@@ -25,6 +25,7 @@ struct PinnedPool {
     std::map<size_t, std::vector<void*>> parked;   // rounded size -> free blocks of that size
     std::unordered_set<void*> parked_set;          // the same blocks by address: a second free of one is refused
     std::unordered_map<void*, size_t> live;        // blocks handed out by the pool -> their rounded size
+    std::unordered_map<void*, float> write_gbps;   // device pools: measured write rate of a block (ma_dev_alloc_output)
     size_t cached_bytes = 0;
     size_t limit_bytes = (size_t)2 << 30;
 };
@@ -79,6 +80,7 @@ size_t dev_pool_flush(int device) {
         bytes = pool.cached_bytes;
         pool.cached_bytes = 0;
         pool.parked_set.clear();
+        for (void* v : victims) pool.write_gbps.erase(v);
     }
     for (void* v : victims) (void)hipFree(v);
     return bytes;
@@ -137,6 +139,7 @@ hipError_t dev_block_free(int device, void* ptr) {
                 return hipSuccess;
             }
         }
+        pool.write_gbps.erase(ptr);
     }
     return hipFree(ptr);
 }
@@ -150,6 +153,7 @@ std::vector<void*> pool_take_victims(PinnedPool& pool, size_t keep_bytes) {
         while (!it->second.empty() && pool.cached_bytes > keep_bytes) {
             victims.push_back(it->second.back());
             pool.parked_set.erase(it->second.back());
+            pool.write_gbps.erase(it->second.back());
             it->second.pop_back();
             pool.cached_bytes -= it->first;
         }
@@ -967,6 +971,124 @@ ma_status ma_host_register(void* ptr, size_t bytes) {
 ma_status ma_host_unregister(void* ptr) {
     if (!ptr) return MA_OK;
     MA_HIP(hipHostUnregister(ptr));
+    return MA_OK;
+}
+
+}  // extern "C"
+
+namespace ma {
+// The store pattern of the elementwise kernels (a wave owns 8 KiB per step, six workgroups per CU, non-temporal 16-byte
+// stores): the pattern whose rate tells a slow-writing region of HBM from a fast one (a tight 1-MiB
+// front would write 6.3-6.5 TB/s on both and tell nothing).
+typedef unsigned int ProbeVec __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kBlock) void probe_write_kernel(ProbeVec* __restrict__ out, size_t n_tiles) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr size_t WAVE_VECS = 64 * 8, TILE_VECS = WAVE_VECS * kWaves;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        ProbeVec* p = out + t * TILE_VECS + wave * WAVE_VECS + lane;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(ProbeVec{0u, 0u, 0u, 0u}, p + (size_t)u * 64);
+    }
+}
+
+// Write rate of a device block in GB/s, measured with two launches of probe_write_kernel (the second is timed). The
+// block's contents are overwritten with zeros. The caller holds the context.
+static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, float* out_gbps) {
+    const size_t n_tiles = bytes / (16 * 64 * 8 * kWaves);
+    *out_gbps = 0.f;
+    if (n_tiles == 0) return MA_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    MA_HIP(hipEventCreate(&e0));
+    hipError_t e = hipEventCreate(&e1);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+    }
+    const size_t cap = (size_t)ctx->num_cus * 6;
+    const int grid = (int)(n_tiles < cap ? n_tiles : cap);
+    hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+    (void)hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+    (void)hipEventRecord(e1, ctx->stream);
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return hip_fail(e, "write-rate probe", __FILE__, __LINE__);
+    if (ms > 0.f) *out_gbps = (float)((double)n_tiles * 16 * 64 * 8 * kWaves / (ms * 1e-3) / 1e9);
+    return MA_OK;
+}
+}  // namespace ma
+
+extern "C" {
+
+ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, float* out_write_gbps) {
+    MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
+    *out_dev_ptr = nullptr;
+    if (out_write_gbps) *out_write_gbps = 0.f;
+    MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "device allocation of %zu bytes is too large", bytes);
+    MA_ENTER_PRIMARY(ctx);
+    MA_NO_CAPTURE(ctx, "ma_dev_alloc_output");
+    MA_HIP(hipSetDevice(ctx->device));
+    // Small blocks, or the feature switched off: the plain allocator.
+    static const size_t kMinBytes = env_bytes("MINARROW_HIP_OUTPUT_MIN_BYTES", (size_t)256 << 20);
+    static const size_t kCandidates = env_bytes("MINARROW_HIP_OUTPUT_CANDIDATES", 6);
+    static const float kGoodGbps = (float)env_bytes("MINARROW_HIP_OUTPUT_GOOD_GBPS", 6200);
+    const int dev = ctx->device;
+    if (bytes < kMinBytes || kCandidates <= 1 || dev < 0 || dev >= kMaxPooledDevices) {
+        MA_HIP(dev_block_alloc(dev, bytes, out_dev_ptr));
+        return MA_OK;
+    }
+    PinnedPool& pool = device_pool(dev);
+    // Candidates come from the block cache first (parked blocks of this size class cost nothing to try), then from
+    // the runtime; the search stops at the first block that writes at the fast regions' rate.
+    std::vector<std::pair<void*, float>> tried;
+    void* best = nullptr;
+    float best_rate = -1.f;
+    size_t measured = 0;
+    // parked blocks whose rate is already known cost nothing to consider: only fresh measurements count against the limit
+    while (measured < kCandidates && tried.size() < kCandidates + 8) {
+        void* blk = nullptr;
+        hipError_t e = dev_block_alloc(dev, bytes, &blk);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (tried.empty()) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+            break;  // HBM is full: keep the best of what there is
+        }
+        float rate = 0.f;
+        bool known = false;
+        {
+            std::lock_guard<std::mutex> plock(pool.mu);
+            auto it = pool.write_gbps.find(blk);
+            if (it != pool.write_gbps.end()) {
+                rate = it->second;
+                known = true;
+            }
+        }
+        if (!known) {
+            ma_status st = measure_write_gbps(ctx, blk, bytes, &rate);
+            if (st != MA_OK) {
+                (void)dev_block_free(dev, blk);
+                for (auto& t : tried) (void)dev_block_free(dev, t.first);
+                return st;
+            }
+            std::lock_guard<std::mutex> plock(pool.mu);
+            pool.write_gbps[blk] = rate;
+            ++measured;
+        }
+        tried.emplace_back(blk, rate);
+        if (rate > best_rate) {
+            best_rate = rate;
+            best = blk;
+        }
+        if (rate >= kGoodGbps) break;
+    }
+    // The others go (back) to the block cache: they read as fast as any block and serve as inputs.
+    for (auto& t : tried)
+        if (t.first != best) (void)dev_block_free(dev, t.first);
+    *out_dev_ptr = best;
+    if (out_write_gbps) *out_write_gbps = best_rate;
     return MA_OK;
 }
 

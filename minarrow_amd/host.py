@@ -55,13 +55,20 @@ def addr_of(x) -> int:
 
 
 class DeviceBuffer:
-    """Device-resident bytes owned through ma_dev_alloc / ma_dev_free."""
+    """Device-resident bytes owned through ma_dev_alloc / ma_dev_free. output=True: ma_dev_alloc_output — a block meant
+    to be written by the kernels, picked for its write rate (`write_gbps` holds the measured figure, 0 if none)."""
 
-    def __init__(self, ctx: "Context", nbytes: int):
+    def __init__(self, ctx: "Context", nbytes: int, output: bool = False):
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        self.write_gbps = 0.0
         p = C.c_void_p()
-        ffi.check(ctx.lib.ma_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
+        if output:
+            rate = C.c_float()
+            ffi.check(ctx.lib.ma_dev_alloc_output(ctx.handle, self.nbytes, C.byref(p), C.byref(rate)))
+            self.write_gbps = float(rate.value)
+        else:
+            ffi.check(ctx.lib.ma_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = int(p.value)
         live = getattr(ctx, "_buffers", None)
         if live is not None:
@@ -248,6 +255,10 @@ class Context:
     # -- memory ----------------------------------------------------------------------------------
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def alloc_output(self, nbytes: int) -> DeviceBuffer:
+        """A block the kernels will write (ma_dev_alloc_output): the fastest-writing of a few candidates."""
+        return DeviceBuffer(self, nbytes, output=True)
 
     def to_device(self, arr: np.ndarray, pad_bytes: int = 0) -> DeviceBuffer:
         arr = np.ascontiguousarray(arr)

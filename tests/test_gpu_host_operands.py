@@ -352,3 +352,24 @@ def test_pool_limits_can_be_restored_after_a_trim(ctx):
     assert q.value == p.value
     ffi.check(lib.ma_free_pinned(q.value))
     del first
+
+
+def test_output_allocator_picks_by_measured_write_rate(ctx):
+    """ma_dev_alloc_output: blocks of 256 MiB and more are chosen among a few candidates by their measured write rate
+    (DESIGN.md §3.4); the rejected candidates are parked and handed out by the next allocations; small blocks take the
+    plain path. The block must be usable like any other."""
+    n = 40_000_000  # 320 MB
+    out = ctx.alloc_output(n * 8)
+    assert 1000.0 < out.write_gbps < 8000.0  # measured, and a plausible HBM figure
+    a = ctx.alloc(n * 8)                     # a parked candidate when any was rejected, else a fresh block
+    ctx.synth_iota("i64", a, n, 5)
+    ctx.apply_scalar("i64", "rhs", a, n, 3, 0, out)  # out = a + 3
+    assert ctx.sum("i64", out, n) == (n * (n - 1) // 2 + 8 * n, n)
+    first = out.ptr
+    out.free()
+    again = ctx.alloc_output(n * 8)  # the block cache now holds measured blocks: no probe needed to choose among them
+    assert again.write_gbps >= out.write_gbps * 0.97 or again.ptr == first
+    small = ctx.alloc_output(4096)
+    assert small.write_gbps == 0.0
+    for b in (a, again, small):
+        b.free()

@@ -33,7 +33,9 @@ def main():
     ctx = Context(0)
     print(json.dumps({"hip_runtime": [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1]}), flush=True)
     B = args.bytes
-    a, b, c, o = (ctx.alloc(B + 256) for _ in range(4))
+    o = ctx.alloc_output(B + 256)  # the buffer every kernel writes: picked for its write rate (ma_dev_alloc_output)
+    a, b, c = (ctx.alloc(B + 256) for _ in range(3))
+    print(json.dumps({"output_block_write_gbps": round(o.write_gbps, 1)}), flush=True)
     n_bits_max = B  # one validity bit per row of the narrowest type
     mask = ctx.alloc(n_bits_max // 8 + 64)
     omask = ctx.alloc(n_bits_max // 8 + 64)
