@@ -166,12 +166,14 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
  * `Vec64::with_capacity(len)`, src/kernels/arithmetic/dispatch.rs:88-89), a consolidated column. On MI355X the write
  * rate of a region of HBM is a property of where the driver placed it: ~three quarters of the regions write at 5.4-5.8
  * TB/s under the kernels' store pattern, the rest at 6.3-6.8, while all of them read at 7.1-7.3. For
- * blocks of 256 MiB and more (MINARROW_HIP_OUTPUT_MIN_BYTES) this entry point tries up to 6 candidate blocks
- * (MINARROW_HIP_OUTPUT_CANDIDATES; 1 = off; parked blocks of the size class first, then fresh ones — up to six times the
- * block's size is held while the search runs), measures each one's write
- * rate once with two launches of the store pattern (~1.3 ms per 8 GB; remembered for as long as the library owns the
- * block), stops at the first that reaches 6200 GB/s (MINARROW_HIP_OUTPUT_GOOD_GBPS), returns the fastest and parks the
- * others in the block cache, where ma_dev_alloc picks them up as inputs. The block's contents are undefined (the probe
+ * blocks of 256 MiB and more (MINARROW_HIP_OUTPUT_MIN_BYTES) this entry point tries 6 candidate blocks
+ * (MINARROW_HIP_OUTPUT_CANDIDATES; 1 = off; parked blocks of the size class first, then fresh ones), and up to 6 more
+ * while the best is still below the good rate — so up to twelve times the block's size is held while the search runs,
+ * less when HBM is short (the search then settles for what it has). Each candidate's write rate is measured once with
+ * three launches of the store pattern (~1.3 ms each per 8 GB; the rate is remembered for as long as the library owns
+ * the block); the search stops at the first block that reaches 6200 GB/s (MINARROW_HIP_OUTPUT_GOOD_GBPS), returns the
+ * fastest and parks the others in the block cache, where ma_dev_alloc picks them up as inputs. The probe tells the two
+ * classes apart but is no promise: on boxes where every candidate was a slow region the best block wrote at 5.8 TB/s. The block's contents are undefined (the probe
  * writes zeros). out_write_gbps (may be NULL) receives the chosen block's measured rate, 0 when nothing was measured.
  * Free with ma_dev_free. */
 ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, float* out_write_gbps);

@@ -991,30 +991,33 @@ __global__ __launch_bounds__(kBlock) void probe_write_kernel(ProbeVec* __restric
     }
 }
 
-// Write rate of a device block in GB/s, measured with two launches of probe_write_kernel (the second is timed). The
-// block's contents are overwritten with zeros. The caller holds the context.
+// Write rate of a device block in GB/s: three launches of probe_write_kernel, the faster of the last two counts (one
+// 1.3-ms sample is at the mercy of whatever else the device was finishing). The block's contents are overwritten with
+// zeros. The caller holds the context.
 static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, float* out_gbps) {
     const size_t n_tiles = bytes / (16 * 64 * 8 * kWaves);
     *out_gbps = 0.f;
     if (n_tiles == 0) return MA_OK;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    MA_HIP(hipEventCreate(&e0));
-    hipError_t e = hipEventCreate(&e1);
-    if (e != hipSuccess) {
-        (void)hipEventDestroy(e0);
-        return hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
-    }
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
     const size_t cap = (size_t)ctx->num_cus * 6;
     const int grid = (int)(n_tiles < cap ? n_tiles : cap);
-    hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
-    (void)hipEventRecord(e0, ctx->stream);
-    hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
-    (void)hipEventRecord(e1, ctx->stream);
-    e = hipEventSynchronize(e1);
     float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+        for (int i = 0; i < 3; ++i) {
+            (void)hipEventRecord(ev[i], ctx->stream);
+            if (i < 2) hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+        }
+        e = hipEventSynchronize(ev[2]);
+        float m1 = 0.f, m2 = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&m1, ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&m2, ev[1], ev[2]);
+        ms = m1 < m2 ? m1 : m2;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
     if (e != hipSuccess) return hip_fail(e, "write-rate probe", __FILE__, __LINE__);
     if (ms > 0.f) *out_gbps = (float)((double)n_tiles * 16 * 64 * 8 * kWaves / (ms * 1e-3) / 1e9);
     return MA_OK;
@@ -1047,8 +1050,11 @@ ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, flo
     void* best = nullptr;
     float best_rate = -1.f;
     size_t measured = 0;
-    // parked blocks whose rate is already known cost nothing to consider: only fresh measurements count against the limit
-    while (measured < kCandidates && tried.size() < kCandidates + 8) {
+    // Parked blocks whose rate is already known cost nothing to consider: only fresh measurements count against the
+    // limit. Most regions are slow ones (about three in four on the boxes measured): while nothing has reached the good
+    // rate the search goes on once more, to twice the limit.
+    while (measured < 2 * kCandidates && tried.size() < 2 * kCandidates + 8) {
+        if (measured >= kCandidates && best_rate >= 0.97f * kGoodGbps) break;
         void* blk = nullptr;
         hipError_t e = dev_block_alloc(dev, bytes, &blk);
         if (e != hipSuccess) {
