@@ -795,6 +795,19 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
                                    const size_t* chunk_mask_offsets);
 ma_status ma_group_exchange(ma_group* group);
 ma_status ma_group_synchronize(ma_group* group);
+/* route_super_array_broadcast (src/kernels/broadcast/super_array.rs:180-251; its chunk loop carries "// TODO:
+ * Parallelise", :193) over the GPUs of a group: chunk pair i is computed by member i % ma_group_size(group), on whose
+ * device its buffers must be resident (or in host memory); the pairs of one member run as one launch, the members
+ * concurrently, nothing crosses between GPUs and the result stays chunked where its inputs are. Arguments and rules as
+ * ma_route_super_array_broadcast, except member_mask_overrides: NULL, or one pointer per MEMBER (the override bitmap as
+ * resident on that member's device; an entry may be NULL). ENQUEUES only: ma_group_synchronize waits and reports a dense
+ * integer division by zero (MA_ERR_DIVIDE_BY_ZERO); out_has_mask is filled before the call returns. */
+ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_code, int32_t op, size_t n_chunks,
+                                               const void* const* lhs_data, const size_t* lhs_lens,
+                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                               const size_t* rhs_lens, const uint8_t* const* rhs_masks,
+                                               const uint8_t* const* member_mask_overrides, void* const* out_data,
+                                               uint8_t* const* out_masks, int32_t* out_has_mask);
 ma_status ma_group_result(ma_group* group, int32_t column, int64_t* out_int_sum, uint64_t* out_int_count,
                           double* out_f64_sum, uint64_t* out_f64_count);
 ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column, int64_t* out_int_sum,

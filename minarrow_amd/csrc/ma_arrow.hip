@@ -239,6 +239,19 @@ ma_status ma_apply_arrow(ma_ctx* ctx, int32_t op, const struct ArrowArray* lhs, 
 
 }  // extern "C"
 
+namespace ma {
+// the two-mask integer kernels (ma_binary_{i32,u32,i64,u64}.hip): validity = mask1 (&|) mask2, formed in registers
+#define MA_DECL_TWO_MASKS(TAG, T)                                                                                    \
+    ma_status apply_int_two_masks_##TAG(ma_ctx* ctx, const T* lhs, size_t lhs_len, const T* rhs, size_t rhs_len,    \
+                                        int32_t op, const uint8_t* mask1, size_t off1, const uint8_t* mask2,         \
+                                        size_t off2, bool combine_and, T* out, uint8_t* out_mask_bits);
+MA_DECL_TWO_MASKS(i32, int32_t)
+MA_DECL_TWO_MASKS(u32, uint32_t)
+MA_DECL_TWO_MASKS(i64, int64_t)
+MA_DECL_TWO_MASKS(u64, uint64_t)
+#undef MA_DECL_TWO_MASKS
+}  // namespace ma
+
 // ------------------------------------------------------------------------------------------------
 // route_super_array_broadcast — src/kernels/broadcast/super_array.rs:180-251.
 // SuperArray (op) SuperArray, chunk by chunk. The reference's loop is sequential with a literal
@@ -279,42 +292,30 @@ extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_
                                              null_mask_override, out_data, out_masks, out_has_mask);
         }
     }
+    // Only reached by masked integer Div / Rem / FloorDiv. Both chunks carrying nulls: lhs.union(rhs) (Bitmask::union, OR)
+    // is formed in registers by the two-mask kernels — no merged bitmap, no allocation, nothing to wait for.
     for (size_t i = 0; i < n_chunks; ++i) {
         const size_t n = lhs_lens[i];
-        const uint8_t* lm = lhs_masks ? lhs_masks[i] : nullptr;
-        const uint8_t* rm = rhs_masks ? rhs_masks[i] : nullptr;
-        const uint8_t* mask = nullptr;
+        const uint8_t* lm = null_mask_override ? null_mask_override : (lhs_masks ? lhs_masks[i] : nullptr);
+        const uint8_t* rm = null_mask_override ? nullptr : (rhs_masks ? rhs_masks[i] : nullptr);
         uint8_t* om = out_masks ? out_masks[i] : nullptr;
-        void* union_tmp = nullptr;
-        if (null_mask_override) {
-            mask = null_mask_override;
-        } else if (lm && rm) {
-            MA_TRY(ma_dev_alloc(ctx, ((n + 63) / 64) * 8 + 8, &union_tmp));
-            ma_status s = n ? ma_or_masks(ctx, lm, 0, rm, 0, n, (uint8_t*)union_tmp) : MA_OK;  // Bitmask::union
-            if (s != MA_OK) {
-                (void)ma_dev_free(ctx, union_tmp);
-                return s;
-            }
-            mask = (const uint8_t*)union_tmp;
-        } else {
-            mask = lm ? lm : rm;
-        }
-        if (out_has_mask) out_has_mask[i] = mask ? 1 : 0;
+        if (out_has_mask) out_has_mask[i] = (lm || rm) ? 1 : 0;
         ma_status st;
-        switch (format_code) {
-            case 'i': st = ma_apply_int_i32(ctx, (const int32_t*)lhs_data[i], n, (const int32_t*)rhs_data[i], n, op, mask, 0, (int32_t*)out_data[i], om); break;
-            case 'I': st = ma_apply_int_u32(ctx, (const uint32_t*)lhs_data[i], n, (const uint32_t*)rhs_data[i], n, op, mask, 0, (uint32_t*)out_data[i], om); break;
-            case 'l': st = ma_apply_int_i64(ctx, (const int64_t*)lhs_data[i], n, (const int64_t*)rhs_data[i], n, op, mask, 0, (int64_t*)out_data[i], om); break;
-            case 'L': st = ma_apply_int_u64(ctx, (const uint64_t*)lhs_data[i], n, (const uint64_t*)rhs_data[i], n, op, mask, 0, (uint64_t*)out_data[i], om); break;
-            case 'f': st = ma_apply_float_f32(ctx, (const float*)lhs_data[i], n, (const float*)rhs_data[i], n, op, mask, 0, (float*)out_data[i], om); break;
-            case 'g': st = ma_apply_float_f64(ctx, (const double*)lhs_data[i], n, (const double*)rhs_data[i], n, op, mask, 0, (double*)out_data[i], om); break;
-            default:
-                set_error("unsupported element format '%c'", (char)format_code);
-                st = MA_ERR_UNSUPPORTED;
-        }
-        if (union_tmp) {
-            ma_status fr = ma_dev_free(ctx, union_tmp);  // synchronises the stream first
-            if (st == MA_OK) st = fr;
+        if (lm && rm) {
+            switch (format_code) {
+                case 'i': st = ma::apply_int_two_masks_i32(ctx, (const int32_t*)lhs_data[i], n, (const int32_t*)rhs_data[i], n, op, lm, 0, rm, 0, false, (int32_t*)out_data[i], om); break;
+                case 'I': st = ma::apply_int_two_masks_u32(ctx, (const uint32_t*)lhs_data[i], n, (const uint32_t*)rhs_data[i], n, op, lm, 0, rm, 0, false, (uint32_t*)out_data[i], om); break;
+                case 'l': st = ma::apply_int_two_masks_i64(ctx, (const int64_t*)lhs_data[i], n, (const int64_t*)rhs_data[i], n, op, lm, 0, rm, 0, false, (int64_t*)out_data[i], om); break;
+                default: st = ma::apply_int_two_masks_u64(ctx, (const uint64_t*)lhs_data[i], n, (const uint64_t*)rhs_data[i], n, op, lm, 0, rm, 0, false, (uint64_t*)out_data[i], om); break;
+            }
+        } else {
+            const uint8_t* mask = lm ? lm : rm;
+            switch (format_code) {
+                case 'i': st = ma_apply_int_i32(ctx, (const int32_t*)lhs_data[i], n, (const int32_t*)rhs_data[i], n, op, mask, 0, (int32_t*)out_data[i], om); break;
+                case 'I': st = ma_apply_int_u32(ctx, (const uint32_t*)lhs_data[i], n, (const uint32_t*)rhs_data[i], n, op, mask, 0, (uint32_t*)out_data[i], om); break;
+                case 'l': st = ma_apply_int_i64(ctx, (const int64_t*)lhs_data[i], n, (const int64_t*)rhs_data[i], n, op, mask, 0, (int64_t*)out_data[i], om); break;
+                default: st = ma_apply_int_u64(ctx, (const uint64_t*)lhs_data[i], n, (const uint64_t*)rhs_data[i], n, op, mask, 0, (uint64_t*)out_data[i], om); break;
+            }
         }
         if (st != MA_OK) return st;
     }

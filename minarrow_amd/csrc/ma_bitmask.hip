@@ -414,10 +414,12 @@ static ma_status fill_bits(ma_ctx* ctx, uint8_t* out_bits, size_t len, bool valu
     MA_TRY(scope.out_mask(out_bits, len, &ow));
     const size_t n_words = (len + 63) >> 6;
     MA_HIP(hipMemsetAsync(ow, value ? 0xFF : 0, n_words * 8, ctx->stream));
-    if (value && (len & 63)) {
-        uint64_t last = (((uint64_t)1) << (len & 63)) - 1;
-        MA_HIP(hipMemcpyAsync(ow + n_words - 1, &last, 8, hipMemcpyHostToDevice, ctx->stream));
-        MA_HIP(hipStreamSynchronize(ctx->stream));  // `last` lives on this stack frame
+    if (value && (len & 63)) {  // trailing bits of the last word are zero: whole bytes, the partial byte, the zero bytes
+        uint8_t* last = (uint8_t*)(ow + n_words - 1);
+        const size_t tail = len & 63, whole = tail >> 3;
+        if (tail & 7) MA_HIP(hipMemsetAsync(last + whole, (1 << (tail & 7)) - 1, 1, ctx->stream));
+        const size_t first_zero = whole + ((tail & 7) ? 1 : 0);
+        if (first_zero < 8) MA_HIP(hipMemsetAsync(last + first_zero, 0, 8 - first_zero, ctx->stream));
     }
     return end_call(ctx, scope);
 }

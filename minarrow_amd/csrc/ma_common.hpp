@@ -105,6 +105,13 @@ struct ma_ctx {
     uint64_t result_seq = 0;           // stamps of the polled synchronous reductions (ma_reduce.hip)
     long poll_us = 60;                 // MINARROW_HIP_POLL_US: how long such a call polls before it blocks (0 = never poll)
     bool fenced_reduce = false;        // MINARROW_HIP_FENCED_REDUCE=1: the round-1 release/acquire publish in the sum kernels
+    // Two pinned staging buffers for small host tables on their way to the device (ma::upload_table): descriptor
+    // tables live in the caller's frame, and a pageable source would force a stream drain per call.
+    void* table_stage[2] = {nullptr, nullptr};
+    size_t table_stage_bytes[2] = {0, 0};
+    hipEvent_t table_ev[2] = {nullptr, nullptr};
+    bool table_busy[2] = {false, false};
+    int table_next = 0;
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
@@ -228,6 +235,11 @@ void pipe_destroy(ma_ctx* ctx);
 // `bytes` of device scratch owned by the context (256-byte aligned). Valid until the next ctx_scratch call on this
 // context; the caller holds ctx->mu and enqueues every use on ctx->stream, so successive users are stream-ordered.
 ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out);
+// Enqueues the copy of a small host table (descriptors living in the caller's frame) to `dev_dst` on ctx->stream
+// WITHOUT waiting for the stream: the bytes are taken into one of the context's two pinned staging buffers before the
+// call returns. (A buffer is re-used only after the copy issued from it two uploads ago has left it.) The caller holds
+// the context.
+ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst);
 
 // A reduction record as it is exchanged between GPUs: 8 x u64 (64 bytes) — [0] integer sum, [1] integer valid count,
 // [2] f64 hi bits, [3] f64 lo bits, [4] float valid count, [5..7] unused.

@@ -307,10 +307,9 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
         if (d.len) n_tiles += d.len > d.head ? (d.len - d.head + tile_rows - 1) / tile_rows : 1;
         row += chunk_lens[i];
     }
-    void* ddesc = nullptr;  // descriptor table -> device scratch (it lives in this frame: wait for the copy)
+    void* ddesc = nullptr;  // descriptor table -> device scratch, through the context's pinned staging (no stream drain)
     MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks, &ddesc));
-    MA_HIP(hipMemcpyAsync(ddesc, desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_TRY(upload_table(ctx, desc.data(), sizeof(ChunkDesc) * n_chunks, ddesc));
 
     const ChunkDesc* d = (const ChunkDesc*)ddesc;
     switch (elem_size) {
@@ -458,8 +457,7 @@ extern "C" ma_status ma_consolidate_table_arena(ma_ctx* ctx, size_t n_cols, size
     }
     void* ddesc = nullptr;
     MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * desc.size(), &ddesc));
-    MA_HIP(hipMemcpyAsync(ddesc, desc.data(), sizeof(ChunkDesc) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));  // `desc` lives in this frame: the copy must leave it before we continue
+    MA_TRY(upload_table(ctx, desc.data(), sizeof(ChunkDesc) * desc.size(), ddesc));
     const ChunkDesc* d = (const ChunkDesc*)ddesc;
     for (int g = 0; g < 4; ++g) {
         if (!groups[g].n_tiles) continue;
@@ -535,14 +533,13 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
         if (has_mask) mask_desc[i] = m;
         row += chunk_lens[i];
     }
-    // both descriptor tables in one scratch region (they live in this frame: wait for the copies)
+    // both descriptor tables in one scratch region
     void* tables = nullptr;
     MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks * 2, &tables));
     ChunkDesc* dd = (ChunkDesc*)tables;
     ChunkDesc* md = dd + n_chunks;
-    MA_HIP(hipMemcpyAsync(dd, data_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
-    if (has_mask) MA_HIP(hipMemcpyAsync(md, mask_desc.data(), sizeof(ChunkDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_TRY(upload_table(ctx, data_desc.data(), sizeof(ChunkDesc) * n_chunks, dd));
+    if (has_mask) MA_TRY(upload_table(ctx, mask_desc.data(), sizeof(ChunkDesc) * n_chunks, md));
     uint64_t *ow = nullptr, *mw = nullptr;  // both outputs are validated before the first launch
     MA_TRY(scope.out_mask(out_bits, total, &ow));
     if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &mw));

@@ -370,6 +370,30 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
     return MA_OK;
 }
 
+ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst) {
+    if (bytes == 0) return MA_OK;
+    const int k = ctx->table_next;
+    ctx->table_next ^= 1;
+    if (!ctx->table_ev[k]) MA_HIP(hipEventCreateWithFlags(&ctx->table_ev[k], hipEventDisableTiming));
+    if (ctx->table_busy[k]) {
+        MA_HIP(hipEventSynchronize(ctx->table_ev[k]));
+        ctx->table_busy[k] = false;
+    }
+    if (bytes > ctx->table_stage_bytes[k]) {
+        if (ctx->table_stage[k]) MA_HIP(hipHostFree(ctx->table_stage[k]));
+        ctx->table_stage[k] = nullptr;
+        ctx->table_stage_bytes[k] = 0;
+        const size_t want = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
+        MA_HIP(hipHostMalloc(&ctx->table_stage[k], want, hipHostMallocPortable));
+        ctx->table_stage_bytes[k] = want;
+    }
+    memcpy(ctx->table_stage[k], src, bytes);
+    MA_HIP(hipMemcpyAsync(dev_dst, ctx->table_stage[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipEventRecord(ctx->table_ev[k], ctx->stream));
+    ctx->table_busy[k] = true;
+    return MA_OK;
+}
+
 ma_status end_call(ma_ctx* ctx, CallScope& scope) {
     (void)ctx;
     return scope.finish();
@@ -708,6 +732,10 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->table_stage[k]) (void)hipHostFree(ctx->table_stage[k]);
+        if (ctx->table_ev[k]) (void)hipEventDestroy(ctx->table_ev[k]);
+    }
     ma::pipe_destroy(ctx);
     if (ctx->result) (void)hipHostFree(ctx->result);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);

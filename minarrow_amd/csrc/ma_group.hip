@@ -283,6 +283,70 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
     });
 }
 
+// route_super_array_broadcast over the GPUs of a group — src/kernels/broadcast/super_array.rs:180-251, whose chunk loop
+// is sequential ("// TODO: Parallelise", :193). Chunk pair i belongs to member i % G: the pairs of one member run as ONE
+// launch on its device (ma_route_super_array_broadcast), all members concurrently; no bytes cross between GPUs and the
+// result stays chunked where its inputs are ("output stays sharded").
+ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_code, int32_t op, size_t n_chunks,
+                                               const void* const* lhs_data, const size_t* lhs_lens,
+                                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                               const size_t* rhs_lens, const uint8_t* const* rhs_masks,
+                                               const uint8_t* const* member_mask_overrides, void* const* out_data,
+                                               uint8_t* const* out_masks, int32_t* out_has_mask) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(n_chunks == 0 || (lhs_data && lhs_lens && rhs_data && rhs_lens && out_data), MA_ERR_INVALID_ARGUMENT,
+               "NULL chunk table");
+    for (size_t i = 0; i < n_chunks; ++i)  // the whole SuperArray is checked before any member starts
+        if (lhs_lens[i] != rhs_lens[i]) {
+            set_error("Super Array broadcasting error - Chunk %zu: LHS %zu RHS %zu", i, lhs_lens[i], rhs_lens[i]);
+            return MA_ERR_LENGTH_MISMATCH;
+        }
+    std::lock_guard<std::mutex> lock(group->mu);
+    const size_t G = group->ctxs.size();
+    // A device-resident chunk must live on its member's GPU: the kernels address it directly.
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (lhs_lens[i] == 0) continue;
+        const int want = group->ctxs[i % G]->device;
+        const void* ptrs[3] = {lhs_data[i], rhs_data[i], out_data[i]};
+        for (const void* p : ptrs) {
+            hipPointerAttribute_t attr;
+            if (p == nullptr || hipPointerGetAttributes(&attr, p) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;  // pageable host memory (staged by the member) or NULL (reported by the member's call)
+            }
+            MA_REQUIRE(attr.type != hipMemoryTypeDevice || attr.device == want, MA_ERR_INVALID_ARGUMENT,
+                       "chunk %zu belongs to member %zu (device %d) but one of its buffers is resident on device %d", i, i % G,
+                       want, attr.device);
+        }
+    }
+    std::vector<const void*> l, r;
+    std::vector<void*> o;
+    std::vector<const uint8_t*> lm, rm;
+    std::vector<uint8_t*> om;
+    std::vector<size_t> ll, rl;
+    std::vector<int32_t> has;
+    for (size_t m = 0; m < G && m < n_chunks; ++m) {
+        l.clear(); r.clear(); o.clear(); lm.clear(); rm.clear(); om.clear(); ll.clear(); rl.clear();
+        for (size_t i = m; i < n_chunks; i += G) {
+            l.push_back(lhs_data[i]);
+            r.push_back(rhs_data[i]);
+            o.push_back(out_data[i]);
+            ll.push_back(lhs_lens[i]);
+            rl.push_back(rhs_lens[i]);
+            lm.push_back(lhs_masks ? lhs_masks[i] : nullptr);
+            rm.push_back(rhs_masks ? rhs_masks[i] : nullptr);
+            om.push_back(out_masks ? out_masks[i] : nullptr);
+        }
+        has.assign(l.size(), 0);
+        MA_TRY(ma_route_super_array_broadcast(group->ctxs[m], format_code, op, l.size(), l.data(), ll.data(), lm.data(), r.data(),
+                                              rl.data(), rm.data(), member_mask_overrides ? member_mask_overrides[m] : nullptr,
+                                              o.data(), om.data(), has.data()));
+        if (out_has_mask)
+            for (size_t j = 0; j < has.size(); ++j) out_has_mask[m + j * G] = has[j];
+    }
+    return MA_OK;
+}
+
 ma_status ma_group_exchange(ma_group* group) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     std::lock_guard<std::mutex> lock(group->mu);

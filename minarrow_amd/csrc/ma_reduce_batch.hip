@@ -251,8 +251,7 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     const size_t bytes = desc_bytes + sizeof(Partial) * (n_segs ? n_segs : 1);
     void* scratch = nullptr;
     MA_TRY(ctx_scratch(ctx, bytes, &scratch));
-    MA_HIP(hipMemcpyAsync(scratch, desc.data(), sizeof(ColDesc) * n_cols, hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));  // `desc` is pageable: the copy must leave it before we continue
+    MA_TRY(upload_table(ctx, desc.data(), sizeof(ColDesc) * n_cols, scratch));
     const ColDesc* d = (const ColDesc*)scratch;
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     switch (format_code) {

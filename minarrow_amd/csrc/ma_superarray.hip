@@ -220,8 +220,7 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     if (n_tiles == 0) return MA_OK;
     void* ddesc = nullptr;
     MA_TRY(ctx_scratch(ctx, sizeof(PairDesc) * n_chunks, &ddesc));
-    MA_HIP(hipMemcpyAsync(ddesc, descs.data(), sizeof(PairDesc) * n_chunks, hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));  // `descs` is pageable: the copy must leave it before we continue
+    MA_TRY(upload_table(ctx, descs.data(), sizeof(PairDesc) * n_chunks, ddesc));
     const PairDesc* dd = (const PairDesc*)ddesc;
     if (any_mask) {
         int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
@@ -236,6 +235,10 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     }
     MA_TRY(end_call(ctx, scope));
     const bool int_div = std::is_integral<T>::value && (op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV);
+    if (int_div && is_async(ctx) && !scope.staged()) {
+        ctx->pending_flags = true;  // like the dense kernels of an async context: reported by the next synchronize
+        return MA_OK;
+    }
     if (int_div) {
         uint32_t f = 0;
         MA_HIP(hipMemcpyAsync(&f, ctx->dev_flags, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));

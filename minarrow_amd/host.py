@@ -624,6 +624,24 @@ class Group:
         d, l, m, o, keep = self._tables(chunks, lens, masks, mask_offsets)
         ffi.check(getattr(self.lib, f"ma_group_enqueue_sum_{tag}")(self.handle, int(column), d, l, m, o))
 
+    def route_super_array_broadcast(self, fmt: str, op: int, lhs_chunks, rhs_chunks, lens_l, lens_r, out_chunks,
+                                    lhs_masks=None, rhs_masks=None, out_masks=None, member_overrides=None):
+        """SuperArray (op) SuperArray over the group's GPUs (ma_group_route_super_array_broadcast): chunk pair i runs on
+        member i % size, where its buffers live. Enqueues only — call synchronize(). Returns the "has validity" flags."""
+        k = len(lhs_chunks)
+
+        def table(items, n=k):
+            return C.cast((C.c_void_p * n)(*[addr_of(x) or None for x in items]), C.c_void_p) if items is not None else None
+
+        ll = (C.c_size_t * k)(*[int(n) for n in lens_l])
+        lr = (C.c_size_t * k)(*[int(n) for n in lens_r])
+        has = (C.c_int32 * k)()
+        ffi.check(self.lib.ma_group_route_super_array_broadcast(
+            self.handle, ord(fmt), int(op), k, table(lhs_chunks), C.cast(ll, C.c_void_p), table(lhs_masks),
+            table(rhs_chunks), C.cast(lr, C.c_void_p), table(rhs_masks), table(member_overrides, self.size),
+            table(out_chunks), table(out_masks), C.cast(has, C.c_void_p)))
+        return [bool(x) for x in has]
+
     def exchange(self) -> None:
         ffi.check(self.lib.ma_group_exchange(self.handle))
 

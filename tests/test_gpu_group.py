@@ -234,3 +234,63 @@ def test_group_one_billion_rows_with_nulls_partitioned_eight_ways(ctx):
         assert 0.0999 < 1 - icnt / n < 0.1001
     for b in (data, fdata, mask):
         b.free()
+
+
+@pytest.mark.parametrize("members,exchange", [(1, "rccl-or-host"), (3, "host"), (8, "host")])
+def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange):
+    """ma_group_route_super_array_broadcast: chunk pair i runs on member i % G (here every member drives device 0 — the
+    partition, the per-member tables and the scatter of the validity flags are what is under test; on a multi-GPU node
+    the same code places member m on device m). Mixed mask presence, odd lengths, an empty chunk, more chunks than
+    members; compared chunk by chunk with the oracle. A dense integer division by zero on one member is reported by
+    synchronize(); a chunk resident on the wrong device is refused."""
+    from minarrow_amd.host import Group
+
+    rng = np.random.default_rng(100 + members)
+    lens = [5, 64, 1000, 4097, 70_001, 0, 129, 8192, 33, 100_003, 1]
+    k = len(lens)
+    with Group([0] * members, exchange) as g:
+        ctxs = [g.member_ctx(m) for m in range(members)]
+        own = lambda i: ctxs[i % members]  # noqa: E731
+        for fmt, dt in (("l", np.int64), ("g", np.float64), ("i", np.int32)):
+            lhs = [rng.integers(1, 100, size=n).astype(dt) for n in lens]
+            rhs = [rng.integers(1, 100, size=n).astype(dt) for n in lens]
+            lm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 2 == 0 else None for i, n in enumerate(lens)]
+            rm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 3 != 1 else None for i, n in enumerate(lens)]
+            up = lambda xs: [own(i).to_device(x, 64) if x is not None else None for i, x in enumerate(xs)]  # noqa: E731
+            dl, dr, dlm, drm = up(lhs), up(rhs), up(lm), up(rm)
+            outs = [own(i).alloc(max(n, 1) * np.dtype(dt).itemsize + 64) for i, n in enumerate(lens)]
+            oms = [own(i).alloc(((n + 63) // 64) * 8 + 8) for i, n in enumerate(lens)]
+            for op, name in ((0, "add"), (2, "multiply"), (3, "divide")):
+                has = g.route_super_array_broadcast(fmt, op, dl, dr, lens, lens, outs, dlm, drm, oms)
+                g.synchronize()
+                for i, n in enumerate(lens):
+                    if lm[i] is not None and rm[i] is not None:
+                        common = oracle.bitmask_union(oracle.pad_bits(lm[i], n), oracle.pad_bits(rm[i], n), n)
+                    else:
+                        common = lm[i] if lm[i] is not None else rm[i]
+                    assert has[i] == (common is not None), (fmt, name, i)
+                    if n == 0:
+                        continue
+                    if common is None:
+                        fn = oracle.apply_float if np.dtype(dt).kind == "f" else oracle.apply_int
+                        st, want, _, _ = fn(oracle.aligned_copy(lhs[i]), oracle.aligned_copy(rhs[i]), name)
+                        np.testing.assert_array_equal(outs[i].download(dt, n), want, err_msg=f"{fmt} {name} chunk {i}")
+                    else:
+                        body = oracle.float_body if np.dtype(dt).kind == "f" else oracle.int_body
+                        st, want, want_mask = body("masked_std", lhs[i], rhs[i], name, mask=oracle.pad_bits(common, n))
+                        nb = ((n + 63) // 64) * 8
+                        np.testing.assert_array_equal(outs[i].download(dt, n), want, err_msg=f"{fmt} {name} chunk {i}")
+                        np.testing.assert_array_equal(oms[i].download(np.uint8, nb), want_mask[:nb], err_msg=f"{fmt} {name} chunk {i} validity")
+        # length mismatch in ANY chunk is reported before a member starts
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.route_super_array_broadcast("i", 0, dl, dr, lens, lens[:-1] + [2], outs)
+        assert e.value.status == ffi.MA_ERR_LENGTH_MISMATCH and "Chunk 10" in e.value.message
+        # dense integer division by zero on one member: latched there, reported by the group's synchronize
+        z = rhs[4].copy()
+        z[17] = 0
+        dz = own(4).to_device(z, 64)
+        g.route_super_array_broadcast("i", 3, dl[:5], dr[:4] + [dz], lens[:5], lens[:5], outs[:5])
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.synchronize()
+        assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+        g.synchronize()  # the latch is cleared by the report

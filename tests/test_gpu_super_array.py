@@ -135,3 +135,31 @@ def test_many_small_chunks_one_launch(ctx, oracle):
     with pytest.raises(ffi.MinarrowHipError) as e:
         ctx.route_super_array_broadcast("l", 3, lhs, rhs2, lens, lens, outs)
     assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+
+
+@pytest.mark.parametrize("fmt,dt", [("l", np.int64), ("i", np.int32), ("I", np.uint32), ("L", np.uint64)])
+def test_masked_integer_division_with_zero_divisors(ctx, oracle, fmt, dt):
+    """Masked integer Div / Rem / FloorDiv go chunk by chunk (validity depends on the data: a zero divisor clears its
+    bit, simd.rs:319-326). Chunks carrying nulls on both sides use lhs.union(rhs) formed inside the kernel."""
+    rng = np.random.default_rng(31)
+    lens = [1, 63, 64, 65, 1000, 4097, 70_001]
+    hi = 100 if np.dtype(dt).kind == "u" else 50
+    lo = 0 if np.dtype(dt).kind == "u" else -50
+    lhs = [rng.integers(lo, hi, size=n).astype(dt) for n in lens]
+    rhs = [rng.integers(0, 4, size=n).astype(dt) for n in lens]  # a quarter of the divisors are zero
+    lm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 3 != 1 else None for i, n in enumerate(lens)]
+    rm = [rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8) if i % 3 != 2 else None for i, n in enumerate(lens)]
+    d = lambda xs: [ctx.to_device(x, 64) if x is not None else None for x in xs]  # noqa: E731
+    outs = [ctx.alloc(n * np.dtype(dt).itemsize + 64) for n in lens]
+    oms = [ctx.alloc(nbytes(n) + 8) for n in lens]
+    for op, name in ((3, "divide"), (4, "remainder"), (6, "floordiv")):
+        has = ctx.route_super_array_broadcast(fmt, op, d(lhs), d(rhs), lens, lens, outs, d(lm), d(rm), oms)
+        assert has == [True] * len(lens)
+        for i, n in enumerate(lens):
+            if lm[i] is not None and rm[i] is not None:
+                common = oracle.bitmask_union(oracle.pad_bits(lm[i], n), oracle.pad_bits(rm[i], n), n)
+            else:
+                common = lm[i] if lm[i] is not None else rm[i]
+            st, want, want_mask = oracle.int_body("masked_std", lhs[i], rhs[i], name, mask=oracle.pad_bits(common, n))
+            np.testing.assert_array_equal(outs[i].download(dt, n), want, err_msg=f"{name} chunk {i}")
+            np.testing.assert_array_equal(oms[i].download(np.uint8, nbytes(n)), want_mask[:nbytes(n)], err_msg=f"{name} chunk {i} validity")
