@@ -496,7 +496,8 @@ def _check(total_rows, finals):
 
 
 def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
-    """BASELINE configs 3 and 4 of the multi-GPU kind, one process over N GPUs (after and outside the timed headline):
+    """BASELINE configs 3, 4 and 5 of the multi-GPU kind, one process over N GPUs (after and outside the timed headline):
+    config 3 = a SuperArray of N chunk pairs, one per GPU, added chunk by chunk with no exchange;
     config 4 = a 10^9-row i64 column with 10 % nulls, row-chunk partitioned over the N GPUs (strong scaling: N x fewer rows
     per GPU), masked scans + ONE exchange per step; config 5 = a SuperTable of N batches of `rows` rows (one per GPU),
     columns i64 + f64 with 10 % nulls, per-column reduce of BOTH columns with ONE exchange per step — a batch-sharded
@@ -519,6 +520,33 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
             step()
         group.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
+
+    # ---- config 3: a SuperArray of N chunks of `rows` rows, one per GPU: out_i = a_i + b_i (i64; b = the f64 column's bit
+    # patterns), fanned out by ma_group_route_super_array_broadcast — one launch per GPU, no exchange, output stays chunked.
+    # Parity: linearity of the wrapping sum, sum(out) == sum(a) + sum(b) mod 2^64 over all GPUs, plus sampled windows.
+    lens = [rows] * world
+    outs = [c.alloc_output(rows * 8) for c in ctxs]
+    ms = timed_steps(lambda: group.route_super_array_broadcast("l", 0, cols_i, cols_f, lens, lens, outs))
+    sums = []
+    for col in (cols_i, cols_f, outs):
+        group.enqueue_sum("i64", 5, col, lens)
+        group.exchange()
+        group.synchronize()
+        sums.append(group.result(5)[0] & M64)
+    ok3 = sums[2] == (sums[0] + sums[1]) & M64
+    for r in (0, world - 1):
+        for start in (0, rows // 2 + 13, max(rows - 4096, 0)):
+            k = min(4096, rows - start)
+            a = cols_i[r].download(np.int64, k, start * 8)
+            b = cols_f[r].download(np.int64, k, start * 8)
+            ok3 = ok3 and bool(np.array_equal(outs[r].download(np.int64, k, start * 8), a + b))
+    res["config3_i64_add_one_chunk_per_gpu"] = {
+        "n_gpus": world, "rows_per_chunk": rows, "ms_per_step": ms, "grows_per_s": rows * world / ms / 1e6,
+        "gbps": 24.0 * rows * world / ms / 1e6, "frac_of_peak_per_gpu": 24.0 * rows / ms / 1e6 / HBM_PEAK_GBPS,
+        "output_block_write_gbps": [round(getattr(o, "write_gbps", 0.0) or 0.0, 1) for o in outs], "parity": bool(ok3),
+        "note": "route_super_array_broadcast over the group: chunk i on GPU i, no exchange, the result stays chunked"}
+    for o in outs:
+        o.free()
 
     # ---- config 4: 10^9 rows over N GPUs
     n = min(1_000_000_000, rows * world)
@@ -584,7 +612,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
         "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
     for m in masks:
         m.free()
-    res["parity_ok"] = bool(ok and ok5)
+    res["parity_ok"] = bool(ok3 and ok and ok5)
     return res
 
 
@@ -704,6 +732,19 @@ def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, re
         return objs
 
     res = {}
+    # ---- config 3: every rank adds its own chunk pair (i64; b = the f64 column's bit patterns); no exchange at all
+    out3 = ctx.alloc_output(rows * 8)
+    ms = timed_steps(lambda: ctx.apply("i64", col_i, col_f, 0, out3, rows, rows))
+    ctx.set_async(False)
+    s_a, s_b, s_o = (ctx.sum("i64", x, rows)[0] & M64 for x in (col_i, col_f, out3))
+    ctx.set_async(True)
+    ok3 = all(gather(s_o == (s_a + s_b) & M64))
+    res["config3_i64_add_one_chunk_per_gpu"] = {
+        "n_gpus": world, "rows_per_chunk": rows, "ms_per_step": ms, "grows_per_s": rows * world / ms / 1e6,
+        "gbps": 24.0 * rows * world / ms / 1e6, "frac_of_peak_per_gpu": 24.0 * rows / ms / 1e6 / HBM_PEAK_GBPS,
+        "output_block_write_gbps": round(getattr(out3, "write_gbps", 0.0) or 0.0, 1), "parity": bool(ok3),
+        "note": "one chunk pair per rank, no exchange, the result stays chunked"}
+    out3.free()
     # ---- config 4
     n = min(1_000_000_000, rows * world)
     lo, hi = row_chunks(n, world)[rank]
@@ -753,7 +794,7 @@ def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, re
         "grows_per_s": 2 * rows * world / ms / 1e6, "gbps": 2 * 8.125 * rows * world / ms / 1e6,
         "frac_of_peak_per_gpu": 2 * 8.125 * rows / ms / 1e6 / HBM_PEAK_GBPS, "valid_count": icnt, "parity": bool(ok5),
         "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
-    res["parity_ok"] = bool(ok and ok5)
+    res["parity_ok"] = bool(ok3 and ok and ok5)
     return res
 
 

@@ -51,6 +51,7 @@ def test_one_process_group_mode_with_rccl():
     oc = out["other_configs"]  # the multi-GPU legs of configs 4 and 5 (one GPU here)
     assert oc["parity_ok"] is True
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
+    assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True  # chunk fan-out over the group, no exchange
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["rows_total"] == 1 << 24
     host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host",
                 "--no-other-configs"])
@@ -66,7 +67,8 @@ def test_launcher_mode_one_rank(exchange, extra):
                "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
                "--other-reps", "2", "--exchange", exchange, *extra])
     assert out["parity_ok"] and out["n_gpus"] == 1
-    oc = out["other_configs"]  # configs 4 and 5 through the same exchange
+    oc = out["other_configs"]  # configs 4 and 5 through the same exchange; config 3 needs none
+    assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True
     assert oc["parity_ok"] is True, oc
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
     want = "ma_comm_*" if exchange == "native" else "torch.distributed"
