@@ -164,12 +164,11 @@ __global__ __launch_bounds__(kBlock) void batched_mask_kernel(const PairDesc* __
     }
 }
 
-template <typename T>
-static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
-                              const uint8_t* const* lhs_masks, const void* const* rhs_data,
-                              const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
-                              uint8_t* const* out_masks, int32_t* out_has_mask) {
-    constexpr int U = 4;
+template <typename T, int U>
+static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
+                                const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                                const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
+                                uint8_t* const* out_masks, int32_t* out_has_mask) {
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * U * kWaves;
     MA_ENTER(ctx);
@@ -251,6 +250,25 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
         }
     }
     return MA_OK;
+}
+
+// Rows per wave step: 8 x 16 bytes per lane (the single-array kernels' shape) for chunks long enough to fill such tiles,
+// 4 x 16 bytes when the chunks are short (RechunkStrategy::Auto's 8192-row chunks: fewer ragged tiles). variant bit 16
+// forces 4, bit 32 forces 8 (tuning).
+template <typename T>
+static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
+                              const uint8_t* const* lhs_masks, const void* const* rhs_data,
+                              const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
+                              uint8_t* const* out_masks, int32_t* out_has_mask) {
+    size_t total = 0;
+    for (size_t i = 0; i < n_chunks; ++i) total += lens[i];
+    constexpr size_t kWideTileRows = (size_t)64 * (16 / sizeof(T)) * 8 * kWaves;
+    bool wide = n_chunks && total / n_chunks >= 16 * kWideTileRows;
+    if (ctx->variant & 16) wide = false;
+    if (ctx->variant & 32) wide = true;
+    if (wide)
+        return batched_impl_u<T, 8>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+    return batched_impl_u<T, 4>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
 }
 
 }  // namespace ma

@@ -7,6 +7,7 @@ stream, inputs resident in HBM. `--bytes` is the size of one operand column (def
 """
 import argparse
 import json
+import time
 import os
 import sys
 from pathlib import Path
@@ -201,6 +202,50 @@ def main():
             n = B // SIZE[tag]
             ms = timed(lambda: ctx.simd_eq_mask(tag, a, n, 0x7, 0x3, o))
             emit("simd_eq_mask", tag, "(data & 7) == 3", ms, B + n / 8, n)
+
+    # ---- SuperArray (op) SuperArray: all chunk pairs in one launch ----
+    if want("super_array"):
+        for tag, fmt in (("f64", "g"), ("i32", "i")):
+            n = fill(tag)
+            sz = SIZE[tag]
+            ctx.set_async(True)
+            for k, label in ((8, "chunks"), (min(n // 8192, 60000), "chunks (RechunkStrategy::Auto)")):
+                per = (n // k) // 64 * 64 if k == 8 else 8192
+                lens = [per] * k
+                lhs = [a.ptr + i * per * sz for i in range(k)]
+                rhs = [b.ptr + i * per * sz for i in range(k)]
+                outs = [o.ptr + i * per * sz for i in range(k)]
+                lms = [mask.ptr + i * (per // 8) for i in range(k)]
+                oms = [omask.ptr + i * (per // 8) for i in range(k)]
+                rows = per * k
+                # the pointer tables are built once, as a host holding a SuperArray would: the timed call is the C entry point
+                import ctypes as C
+                tab = lambda xs: C.cast((C.c_void_p * k)(*xs), C.c_void_p)  # noqa: E731
+                t_l, t_r, t_o, t_lm, t_om = tab(lhs), tab(rhs), tab(outs), tab(lms), tab(oms)
+                t_n = C.cast((C.c_size_t * k)(*lens), C.c_void_p)
+                fn = ctx.lib.ma_route_super_array_broadcast
+
+                def call(masked):
+                    st = fn(ctx.handle, ord(fmt), OP["add"], k, t_l, t_n, t_lm if masked else None, t_r, t_n,
+                            t_lm if masked else None, None, t_o, t_om if masked else None, None)
+                    assert st == 0, st
+
+                for variant, vname in ((0, ""), (16, " [4 x 16 B per lane]"), (32, " [8 x 16 B per lane]")):
+                    ctx.set_variant(variant)
+                    ms = timed(lambda: call(False))
+                    emit("route_super_array_broadcast", tag, f"add dense, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz, rows)
+                    ms = timed(lambda: call(True))
+                    emit("route_super_array_broadcast", tag, f"add, nulls on both sides, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz + 3 * rows / 8, rows)
+                ctx.set_variant(0)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    call(True)
+                host_ms = (time.perf_counter() - t0) / 3 * 1e3  # async context: the call returns when everything is enqueued
+                ctx.synchronize()
+                print(json.dumps({"family": "route_super_array_broadcast", "type": tag, "variant": f"host time per call, {k} masked chunk pairs",
+                                  "host_ms": round(host_ms, 3), "host_us_per_chunk": round(host_ms * 1e3 / k, 3)}), flush=True)
+            ctx.set_async(False)
+            ctx.synchronize()
 
     # ---- consolidate ----
     if want("consolidate"):
