@@ -74,7 +74,10 @@ __device__ __forceinline__ unsigned pair_row_valid(const PairDesc& d, size_t row
     return any ? v : 1u;
 }
 
-template <typename T, int UNROLL>
+// FUSE_MASK: the wave that computes a run of rows also writes the run's words of the chunk's output bitmap (the common
+// mask it has in registers anyway) — possible when every masked chunk's `out` starts on a 16-byte boundary (head == 0),
+// so that runs start on validity-word boundaries; otherwise batched_mask_kernel assembles the bitmaps in a second launch.
+template <typename T, int UNROLL, bool FUSE_MASK>
 __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const PairDesc* __restrict__ descs, int n_chunks,
                                                                 size_t n_tiles, int op, uint32_t* flags) {
     typedef typename Vec16<T>::type V;
@@ -101,23 +104,36 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const PairDesc* 
                 out[i] = v;
             }
         }
-        if (r0 >= d.len) continue;
-        if (r1 - r0 == TILE_ROWS) {  // stores 16-byte aligned by construction; inputs on any element phase (load16u)
-            const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
-            const V* __restrict__ p = (const V*)(lhs + w0) + lane;
-            const V* __restrict__ q = (const V*)(rhs + w0) + lane;
-            V* __restrict__ o = (V*)(out + w0) + lane;
+        const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;  // this wave's run of the tile
+        if (w0 >= r1) continue;
+        // Stores are 16-byte aligned by construction; inputs may sit on any element phase (load16u). A ragged last tile
+        // runs the same vector body over its whole vectors (loads and stores guarded per vector) and finishes the < R
+        // rows that remain one by one; whole runs take the unguarded body.
+        const size_t run_rows = r1 - w0 < WAVE_ROWS ? r1 - w0 : WAVE_ROWS;
+        const V* __restrict__ p = (const V*)(lhs + w0) + lane;
+        const V* __restrict__ q = (const V*)(rhs + w0) + lane;
+        V* __restrict__ o = (V*)(out + w0) + lane;
+        uint64_t aw = ~(uint64_t)0;
+        if (masked) {
+            aw = 0;
+            if (d.lw) aw |= load_run_words<WPT>(d.lw, d.lo + w0, d.l_last, lane);
+            if (d.rw) aw |= load_run_words<WPT>(d.rw, d.ro + w0, d.r_last, lane);
+            if (FUSE_MASK && lane < (unsigned)WPT) {  // lane k holds run word k = word w0 / 64 + k of the chunk's bitmap
+                const size_t j = (w0 >> 6) + lane;
+                const size_t first = j << 6;
+                if (first < d.len) {
+                    uint64_t w = aw;
+                    if (d.len - first < 64) w &= (((uint64_t)1) << (d.len - first)) - 1;
+                    d.ow[j] = w;
+                }
+            }
+        }
+        if (run_rows == WAVE_ROWS) {
             V va[UNROLL], vb[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
-            uint64_t aw = ~(uint64_t)0;
-            if (masked) {
-                aw = 0;
-                if (d.lw) aw |= load_run_words<WPT>(d.lw, d.lo + w0, d.l_last, lane);
-                if (d.rw) aw |= load_run_words<WPT>(d.rw, d.ro + w0, d.r_last, lane);
-            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 unsigned bits = ~0u;
@@ -132,7 +148,26 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const PairDesc* 
                 store16<V, true>(o + (size_t)u * 64, r);
             }
         } else {
-            for (size_t i = r0 + threadIdx.x; i < r1; i += kBlock) {
+            const unsigned n_vec = (unsigned)(run_rows / R);
+            for (int u = 0; u < UNROLL; ++u) {
+                unsigned bits = ~0u;
+                if (masked) bits = lane_bits<R>(aw, u, lane);  // wave-wide shuffle: outside the per-lane guard
+                if ((unsigned)u * 64 + lane < n_vec) {
+                    const V a = load16u<V, true>(p + (size_t)u * 64);
+                    const V b = load16u<V, true>(q + (size_t)u * 64);
+                    V r;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        T v = Elem<T>::apply_rt(op, (T)a[k], (T)b[k], dz);
+                        v = ((bits >> k) & 1u) ? v : (T)0;
+                        r[k] = v;
+                    }
+                    store16<V, true>(o + (size_t)u * 64, r);
+                }
+            }
+            const size_t tail0 = w0 + (size_t)n_vec * R;
+            if (tail0 + lane < w0 + run_rows) {
+                const size_t i = tail0 + lane;
                 T v = Elem<T>::apply_rt(op, lhs[i], rhs[i], dz);
                 if (masked) v = pair_row_valid(d, i) ? v : (T)0;
                 out[i] = v;
@@ -177,7 +212,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     CallScope scope(ctx);
     std::vector<PairDesc> descs(n_chunks);
     size_t n_tiles = 0, n_words = 0;
-    bool any_mask = false;
+    bool any_mask = false, masked_head = false;
     for (size_t i = 0; i < n_chunks; ++i) {
         PairDesc& d = descs[i];
         memset(&d, 0, sizeof(d));
@@ -213,6 +248,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
         }
         const uintptr_t mis = (uintptr_t)d.out & 15;
         d.head = mis ? (unsigned)((16 - mis) / sizeof(T)) : 0;
+        if (d.head && (lm || rm)) masked_head = true;
         n_tiles += n > d.head ? (n - d.head + TILE_ROWS - 1) / TILE_ROWS : 1;
         n_words += (n + 63) >> 6;
     }
@@ -221,15 +257,20 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     MA_TRY(ctx_scratch(ctx, sizeof(PairDesc) * n_chunks, &ddesc));
     MA_TRY(upload_table(ctx, descs.data(), sizeof(PairDesc) * n_chunks, ddesc));
     const PairDesc* dd = (const PairDesc*)ddesc;
-    if (any_mask) {
+    const bool fuse = any_mask && !masked_head && !(ctx->variant & 64);  // variant bit 64: always the separate bitmap launch
+    if (any_mask && !fuse) {
         int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
         hipLaunchKernelGGL(batched_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks, n_words);
         MA_HIP(hipGetLastError());
     }
     {
         int grid = grid_for(ctx, n_tiles, 6);
-        hipLaunchKernelGGL((batched_binary_kernel<T, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks, n_tiles,
-                           op, ctx->dev_flags);
+        if (fuse)
+            hipLaunchKernelGGL((batched_binary_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks,
+                               n_tiles, op, ctx->dev_flags);
+        else
+            hipLaunchKernelGGL((batched_binary_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, dd, (int)n_chunks,
+                               n_tiles, op, ctx->dev_flags);
         MA_HIP(hipGetLastError());
     }
     MA_TRY(end_call(ctx, scope));

@@ -72,18 +72,26 @@ def test_mask_union_rule_and_many_chunks(ctx, oracle, fmt, dt):
     np.testing.assert_array_equal(outs[3].download(dt, n), want)
 
 
-def test_many_small_chunks_one_launch(ctx, oracle):
+@pytest.mark.parametrize("aligned", [False, True])
+def test_many_small_chunks_one_launch(ctx, oracle, aligned):
     """RechunkStrategy::Auto = 8192 rows (src/structs/chunked/super_array.rs:51-59): thousands of chunk pairs, odd
-    lengths, mixed mask presence, run as one batched launch; compared chunk by chunk with the oracle."""
+    lengths, mixed mask presence, run as one batched launch; compared chunk by chunk with the oracle. aligned: every
+    chunk's output starts on a 16-byte boundary (the kernel then writes the output bitmaps itself); otherwise chunks are
+    packed back to back, half of them start mid-vector, and the bitmaps come from the second launch."""
     rng = np.random.default_rng(12)
     k = 700
     lens = [int(x) for x in rng.integers(0, 9000, size=k)]
     lens[:4] = [8192, 8192, 1, 0]
-    total = sum(lens)
+    starts = []
+    pos = 0
+    for n in lens:
+        starts.append(pos)
+        pos += n + (n & 1 if aligned else 0)
+    total = pos
     a = rng.integers(-1000, 1000, size=total).astype(np.int64)
     b = rng.integers(1, 1000, size=total).astype(np.int64)
     da, db, do = ctx.to_device(a, 64), ctx.to_device(b, 64), ctx.alloc(total * 8 + 64)
-    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    offs = np.array(starts + [total], dtype=np.int64)
     # per-chunk bitmaps live in one device arena, each starting on an 8-byte boundary
     lm_host, rm_host, m_offs, pos = [], [], [], 0
     for i, n in enumerate(lens):

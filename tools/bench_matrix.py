@@ -230,7 +230,7 @@ def main():
                             t_lm if masked else None, None, t_o, t_om if masked else None, None)
                     assert st == 0, st
 
-                for variant, vname in ((0, ""), (16, " [4 x 16 B per lane]"), (32, " [8 x 16 B per lane]")):
+                for variant, vname in ((0, ""), (64, " [output bitmaps by a second launch]")):
                     ctx.set_variant(variant)
                     ms = timed(lambda: call(False))
                     emit("route_super_array_broadcast", tag, f"add dense, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz, rows)
