@@ -628,6 +628,29 @@ static void multi_gpu_group_suite() {
         int64_t s = 0;
         uint64_t c = 0;
         ASSERT(ma_group_sum_i64(g, pi.data(), lens.data(), nullptr, nullptr, &s, &c) == MA_OK && s == want && c == n);
+        // SuperArray (+) SuperArray over the group (route_super_array_broadcast, super_array.rs:180-251): chunk i on
+        // device i, no exchange; checked through the linearity of the wrapping sum: sum(a + a) == 2 sum(a)
+        {
+            std::vector<void*> dout(n_dev);
+            std::vector<const void*> lhs(n_dev);
+            std::vector<const int64_t*> po(n_dev);
+            std::vector<int32_t> has(n_dev, 7);
+            for (int r = 0; r < n_dev; ++r) {
+                ASSERT(ma_dev_alloc(ma_group_ctx(g, r), lens[r] * 8 + 64, &dout[r]) == MA_OK);
+                lhs[r] = di[r];
+                po[r] = (const int64_t*)dout[r];
+            }
+            ASSERT(ma_group_route_super_array_broadcast(g, 'l', MA_OP_ADD, (size_t)n_dev, lhs.data(), lens.data(), nullptr, lhs.data(),
+                                                        lens.data(), nullptr, nullptr, dout.data(), nullptr, has.data()) == MA_OK);
+            ASSERT(ma_group_synchronize(g) == MA_OK);
+            for (int r = 0; r < n_dev; ++r) ASSERT(has[r] == 0);
+            ASSERT(ma_group_sum_i64(g, po.data(), lens.data(), nullptr, nullptr, &s, &c) == MA_OK && s == 2 * want && c == n);
+            std::vector<size_t> bad(lens);
+            bad[n_dev - 1] += 1;  // "Super Array broadcasting error": reported before any member starts
+            ASSERT(ma_group_route_super_array_broadcast(g, 'l', MA_OP_ADD, (size_t)n_dev, lhs.data(), lens.data(), nullptr, lhs.data(),
+                                                        bad.data(), nullptr, nullptr, dout.data(), nullptr, nullptr) == MA_ERR_LENGTH_MISMATCH);
+            for (int r = 0; r < n_dev; ++r) ASSERT(ma_dev_free(ma_group_ctx(g, r), dout[r]) == MA_OK);
+        }
         for (int r = 0; r < n_dev; ++r) {
             ASSERT(ma_dev_free(ma_group_ctx(g, r), di[r]) == MA_OK && ma_dev_free(ma_group_ctx(g, r), df[r]) == MA_OK);
         }
