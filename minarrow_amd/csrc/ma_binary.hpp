@@ -140,6 +140,58 @@ struct Elem<double, true> {
     static __device__ __forceinline__ double fma3(double a, double b, double c) { return fma(a, b, c); }
 };
 
+// ln and exp for the f32 Power path, evaluated in f64 to ~2^-45 relative — far inside the half-ULP of the f32 value they
+// are rounded to, at a third of the instructions of the 1-ULP f64 routines (atanh series to s^15 on [1/sqrt2, sqrt2),
+// Taylor to r^11 on |r| <= ln2/2). Against the f64-libm formulation they replace: 1 result in 2 x 10^8 differs, by 1 ULP.
+__device__ __forceinline__ double pow_f32_ln(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752) {
+        m += m;
+        e -= 1;
+    }
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);  // 2^-24.4 on gfx950 (tools/probe_rcp_f64.hip); one Newton step: 2^-48.7
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double s = f * r;  // ln m = 2 atanh(s)
+    const double z = s * s;
+    double p = 1.0 / 15;
+    p = fma(p, z, 1.0 / 13);
+    p = fma(p, z, 1.0 / 11);
+    p = fma(p, z, 1.0 / 9);
+    p = fma(p, z, 1.0 / 7);
+    p = fma(p, z, 1.0 / 5);
+    p = fma(p, z, 1.0 / 3);
+    p = p * z;
+    const double two_s = s + s;
+    double res = fma((double)e, 0.6931471805599453, fma(two_s, p, two_s));
+    if (x == __builtin_inf()) res = x;
+    if (x == 0.0) res = -__builtin_inf();
+    if (!(x >= 0.0)) res = __builtin_nan("");  // negative or NaN
+    return res;
+}
+__device__ __forceinline__ double pow_f32_exp(double y) {
+    const double yc = fmin(fmax(y, -150.0), 150.0);  // far beyond the f32 range on both sides
+    const double k = __builtin_rint(yc * 1.4426950408889634);
+    double r = fma(-k, 0.6931471803691238, yc);  // ln2 split: the high part's product with |k| < 2^10 is exact
+    r = fma(-k, 1.9082149292705877e-10, r);
+    double p = 1.0 / 39916800.0;
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double res = __builtin_amdgcn_ldexp(p, (int)k);
+    return y != y ? y : res;
+}
+
 template <>
 struct Elem<float, true> {
     template <int OP>
@@ -152,11 +204,12 @@ struct Elem<float, true> {
         // (rhs * lhs.ln()).exp() — std.rs:153. The reference's ln/exp are the host libm's logf/expf, which are
         // correctly rounded in all but a handful of cases; evaluating both through f64 and rounding at the same
         // three points (ln, product, exp) reproduces those bits instead of adding a second set of libm errors
-        // that the exp() would amplify by |b ln a|.
+        // that the exp() would amplify by |b ln a|. The f64 evaluations only need to be good to the f32 rounding:
+        // pow_f32_ln / pow_f32_exp above.
         if constexpr (OP == MA_OP_POWER) {
-            float l = (float)log((double)a);
+            float l = (float)pow_f32_ln((double)a);
             float y = b * l;
-            return (float)exp((double)y);
+            return (float)pow_f32_exp((double)y);
         }
         if constexpr (OP == MA_OP_FLOORDIV) return floorf(a / b);
         return 0.0f;
