@@ -1,6 +1,9 @@
 // Bitmask kernels for gfx950 — src/kernels/bitmask/{mod,std,simd,dispatch}.rs.
 // A bitmap window is (bits, bit offset, bit length) = BitmaskVT (src/aliases.rs:172). One u64 word = 64 rows
 // = one wave64, so these are plain word-wise kernels: one thread per output word, coalesced 8-byte accesses.
+#include <atomic>
+#include <chrono>
+
 #include "ma_device.hpp"
 
 namespace ma {
@@ -185,8 +188,19 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
 // Scalar facts about one or two windows, accumulated into 4 device words:
 //   acc[0] += popcount(x)            acc[1] |= any bit set in x
 //   acc[2] |= any bit clear in x     acc[3] |= any bit where x != y
+// Epilogue (round 2): a workgroup adds its four words to the accumulator with agent-scope atomics, waits until they have
+// been performed, and takes a ticket; the workgroup whose ticket is the last reads the totals (sc1 loads), writes them to
+// the PINNED host slot, zeroes accumulator and ticket for the next launch and stamps the completion word the host polls
+// — no memset before, no copy after, no hipStreamSynchronize wake-up on the small-bitmap path (null counts).
+struct ScanOut {
+    unsigned long long* acc;    // device: 4 totals + the ticket word behind them
+    unsigned long long* host;   // pinned: where the four totals go
+    uint64_t* done_word;        // pinned: stamped with done_seq after the totals
+    uint64_t done_seq;
+};
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned long long* acc) {
+__global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so) {
+    unsigned long long* acc = so.acc;
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned long long pop = 0, any_set = 0, any_clear = 0, any_diff = 0;
@@ -242,12 +256,41 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, unsigned lo
         any_clear |= __shfl_down(any_clear, off, 64);
         any_diff |= __shfl_down(any_diff, off, 64);
     }
+    __shared__ unsigned long long part[kWaves][4];
     if ((threadIdx.x & 63) == 0) {
-        if (pop) atomicAdd(&acc[0], pop);
-        if (any_set) atomicOr(&acc[1], 1ull);
-        if (any_clear) atomicOr(&acc[2], 1ull);
-        if (any_diff) atomicOr(&acc[3], 1ull);
+        unsigned long long* q = part[threadIdx.x >> 6];
+        q[0] = pop;
+        q[1] = any_set;
+        q[2] = any_clear;
+        q[3] = any_diff;
     }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    pop = any_set = any_clear = any_diff = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        pop += part[w][0];
+        any_set |= part[w][1];
+        any_clear |= part[w][2];
+        any_diff |= part[w][3];
+    }
+    if (pop) __hip_atomic_fetch_add(&acc[0], pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any_set) __hip_atomic_fetch_or(&acc[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any_clear) __hip_atomic_fetch_or(&acc[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any_diff) __hip_atomic_fetch_or(&acc[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed, not merely issued, before this workgroup arrives
+    unsigned int* ticket = (unsigned int*)&acc[4];
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+    const uint64_t t0 = load_agent((const uint64_t*)&acc[0]), t1 = load_agent((const uint64_t*)&acc[1]);
+    const uint64_t t2 = load_agent((const uint64_t*)&acc[2]), t3 = load_agent((const uint64_t*)&acc[3]);
+    so.host[0] = t0;
+    so.host[1] = t1;
+    so.host[2] = t2;
+    so.host[3] = t3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_agent((uint64_t*)&acc[i], 0);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(so.done_word, so.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // simd_eq_mask_u{8,16,32,64} — bit j = ((data[j] & field_mask) == target).
@@ -338,20 +381,42 @@ static int vec_ok(const BitArgs& a, bool with_out) {
     return a.n >= 256 ? 1 : 0;
 }
 
-static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out) {
+static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out, bool staged) {
     MA_NO_CAPTURE(ctx, "a bitmap scan that returns its result to the host");
-    unsigned long long* acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 inside the 256-byte scratch line set
-    MA_HIP(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    ScanOut so;
+    so.acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 + the scan's ticket: byte 128 of the zeroed scratch block
+    ResultSlot* slot = ctx->result;
+    so.host = (unsigned long long*)&slot[3];  // one 32-byte slot
+    volatile uint64_t* done = (volatile uint64_t*)&slot[2].b;
+    so.done_word = (uint64_t*)done;
+    so.done_seq = ++ctx->result_seq;
     const size_t n_words = (a.n + 63) >> 6;
     const int vec = vec_ok(a, false);
     // vec: read-only stream like the sums (2 workgroups per CU, 8 x 16 bytes per lane in flight)
     int grid = vec ? grid_for(ctx, n_words / 2 / ((size_t)kVecUnroll * kBlock) + 1, 2)
                    : grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
-    if (vec) hipLaunchKernelGGL(bit_scan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
-    else hipLaunchKernelGGL(bit_scan_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, acc);
+    if (vec) hipLaunchKernelGGL(bit_scan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, so);
+    else hipLaunchKernelGGL(bit_scan_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, so);
     MA_HIP(hipGetLastError());
-    MA_HIP(hipMemcpyAsync(out, acc, sizeof(BitScan), hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    // The result always comes back to the host: poll the completion word for a while (a small bitmap — a null count —
+    // is done in a few microseconds; hipStreamSynchronize's wake-up alone costs ~10), then block.
+    bool landed = false;
+    if (!staged && ctx->poll_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (*done == so.done_seq) {
+                landed = true;
+                break;
+            }
+            if ((spins & 63) == 63 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->poll_us)
+                break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!landed) MA_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, (const void*)so.host, sizeof(BitScan));
     return MA_OK;
 }
 
@@ -435,7 +500,7 @@ static ma_status scan_op(ma_ctx* ctx, const uint8_t* lhs, size_t lo, const uint8
     MA_TRY(scope.in_mask(lhs, lo, len, &lw, &lo2));
     if (rhs) MA_TRY(scope.in_mask(rhs, ro, len, &rw, &ro2));
     fill_window(a, lw, lo2, rw, ro2, len);
-    MA_TRY(scan_windows(ctx, a, out));
+    MA_TRY(scan_windows(ctx, a, out, scope.staged()));
     return MA_OK;
 }
 

@@ -326,3 +326,36 @@ def test_bitmask_struct_vectors(ctx, oracle):
     c = k["concatenate"]
     assert ctx.consolidate_boolean_column([(dev(c["m1"]), 0, 5), (dev(c["m2"]), 0, 4)], out) is False
     assert unpack(out.download(np.uint8, 8), 9).tolist() == c["expect"]
+
+
+def test_scans_back_to_back_leave_no_state_behind(ctx):
+    """The scan kernels keep their accumulator and ticket on the device between launches (the last workgroup to arrive
+    zeroes both): thousands of scans of different sizes, grids and answers in a row, from two threads sharing the
+    context (lanes have their own scratch), must each return their own result."""
+    import threading
+
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (1, 63, 64, 1000, 65_537, 1 << 20, (1 << 23) + 5):
+        bits = rng.integers(0, 256, size=n // 8 + 16, dtype=np.uint8)
+        want = int(np.unpackbits(bits, bitorder="little")[:n].sum())
+        ones = np.full(n // 8 + 16, 0xFF, dtype=np.uint8)
+        cases.append((n, ctx.to_device(bits, 16), want, ctx.to_device(ones, 16)))
+    errors = []
+
+    def work(seed):
+        try:
+            order = np.random.default_rng(seed).integers(0, len(cases), size=1500)
+            for k in order:
+                n, dbits, want, dones = cases[int(k)]
+                assert ctx.popcount_mask(dbits, 0, n) == want
+                assert ctx.all_true_mask(dones, n) is True
+                assert ctx.all_false_mask(dones, n) is False
+                assert ctx.popcount_mask(dones, 0, n) == n
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in (1, 2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[:3]
