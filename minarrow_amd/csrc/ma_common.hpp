@@ -146,6 +146,9 @@ bool nosync_active();
 inline bool is_async(const ma_ctx* ctx) { return ctx->async || nosync_active(); }
 // Waits for the context's stream and turns a latched device condition (dense integer divide by zero) into its status.
 ma_status sync_and_check(ma_ctx* ctx);
+// Waits for everything enqueued on the context's stream: polls a stream-written completion word first (small calls),
+// then blocks (ma_ctx.hip).
+ma_status stream_wait(ma_ctx* ctx);
 
 enum PtrKind : int32_t { kPageable = 0, kPinned = 1, kDevice = 2, kManaged = 3 };
 PtrKind pointer_kind(const void* p);

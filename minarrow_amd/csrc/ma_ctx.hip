@@ -1,6 +1,7 @@
 // Context, memory and error plumbing of libminarrow_hip.so, plus the synthetic-input generators.
 // C ABI: include/minarrow_hip.h.
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <unordered_set>
@@ -334,6 +335,34 @@ ma_status CallScope::out_mask(uint8_t* bits, size_t len_bits, uint64_t** out_wor
     return MA_OK;
 }
 
+// The wait at the end of a synchronous call. hipStreamSynchronize's wake-up costs ~10 us — most of a small call — so the
+// stream is first asked to stamp a pinned word when it has finished everything before (hipStreamWriteValue64: a
+// command-processor write, no kernel) and the host polls that word for up to poll_us; a long call falls through to the
+// blocking wait, and so does a faulted one (whose stamp never comes), which then reports its error.
+ma_status stream_wait(ma_ctx* ctx) {
+    if (ctx->poll_us > 0 && !ctx->capturing && ctx->result && !(ctx->variant & 128)) {
+        volatile uint64_t* done = (volatile uint64_t*)&ctx->result[2].cnt;
+        const uint64_t seq = ++ctx->result_seq;
+        if (hipStreamWriteValue64(ctx->stream, (void*)done, seq, 0) == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (*done == seq) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    return MA_OK;
+                }
+                if ((spins & 63) == 63 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= ctx->poll_us)
+                    break;
+                __builtin_ia32_pause();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    return MA_OK;
+}
+
 ma_status CallScope::finish() {
     bool need_sync = !is_async(ctx_) || !temps_.empty();
     bool any_out = false;
@@ -345,7 +374,7 @@ ma_status CallScope::finish() {
     }
     (void)any_out;
     if (need_sync) {
-        MA_HIP(hipStreamSynchronize(ctx_->stream));
+        MA_TRY(stream_wait(ctx_));
         finished_ = true;
     }
     return MA_OK;
