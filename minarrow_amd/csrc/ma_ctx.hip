@@ -507,7 +507,7 @@ Enter::~Enter() {
 }
 
 ma_status sync_and_check(ma_ctx* ctx) {
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_TRY(stream_wait(ctx));
     if (ctx->pending_flags) {
         ctx->pending_flags = false;
         uint32_t flags = 0;
