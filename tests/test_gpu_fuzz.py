@@ -344,15 +344,20 @@ def test_consolidate_boolean(ctx, lens, with_masks, seed):
 @settings(**COMMON)
 @given(fmt=st.sampled_from(["i", "l", "f", "g"]), op=st.sampled_from([0, 1, 2]),
        lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
-       mask_mode=st.sampled_from(["none", "mixed", "override"]), seed=st.integers(0, 2**31))
-def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed):
+       mask_mode=st.sampled_from(["none", "mixed", "override"]), seed=st.integers(0, 2**31),
+       variant=st.sampled_from([0, 32, 64, 96]), out_off=st.integers(0, 3))
+def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed, variant, out_off):
+    """variant: 32 = the 8 x 16-byte tile also for short chunks, 64 = output bitmaps by the second launch instead of the
+    computing wave; out_off: outputs start out_off elements past a 16-byte boundary (a masked chunk off the boundary
+    sends the whole call to the second-launch path)."""
     rng = np.random.default_rng(seed)
     dt = np.dtype({"i": np.int32, "l": np.int64, "f": np.float32, "g": np.float64}[fmt])
     k = len(lens)
     L = [rand_values(rng, dt, n, small=True) for n in lens]
     R = [rand_values(rng, dt, n, small=True) for n in lens]
     dL, dR = [ctx.to_device(x, 64) for x in L], [ctx.to_device(x, 64) for x in R]
-    dO = [ctx.alloc(n * dt.itemsize + 64) for n in lens]
+    bO = [ctx.alloc(n * dt.itemsize + 128) for n in lens]
+    dO = [b.ptr + (out_off if i % 2 else 0) * dt.itemsize for i, b in enumerate(bO)]
     dOM = [ctx.alloc(n // 8 + 64) for n in lens]
     lm = rm = [None] * k
     override = None
@@ -365,7 +370,11 @@ def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed):
     dlm = [ctx.to_device(m, 16) if m is not None else None for m in lm]
     drm = [ctx.to_device(m, 16) if m is not None else None for m in rm]
     dov = ctx.to_device(override, 16) if override is not None else None
-    has = ctx.route_super_array_broadcast(fmt, op, dL, dR, lens, lens, dO, dlm, drm, dOM, dov)
+    ctx.set_variant(variant)
+    try:
+        has = ctx.route_super_array_broadcast(fmt, op, dL, dR, lens, lens, dO, dlm, drm, dOM, dov)
+    finally:
+        ctx.set_variant(0)
     for i, n in enumerate(lens):
         if override is not None:
             valid = unpack(override, 0, n)
@@ -384,9 +393,12 @@ def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed):
         with np.errstate(all="ignore"):
             res = [L[i] + R[i], L[i] - R[i], L[i] * R[i]][op].astype(dt)
         want = np.where(valid, res, dt.type(0))
-        np.testing.assert_array_equal(dO[i].download(dt, n).view(np.uint8), want.view(np.uint8))
+        got = bO[i].download(dt, n, (out_off if i % 2 else 0) * dt.itemsize)
+        np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
         if want_has:
-            np.testing.assert_array_equal(unpack(dOM[i].download(np.uint8, ((n + 63) // 64) * 8), 0, n), valid)
+            bits = dOM[i].download(np.uint8, ((n + 63) // 64) * 8)
+            np.testing.assert_array_equal(unpack(bits, 0, n), valid)
+            assert not unpack(bits, n, ((n + 63) // 64) * 64 - n).any()  # trailing bits of the last word are zero
 
 
 # ---- host-resident operands through the tiled staging pipeline (ma_pipeline.hip) -------------------------------------
