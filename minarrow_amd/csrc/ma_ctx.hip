@@ -568,7 +568,7 @@ static ma_status launch_fill(ma_ctx* ctx, T* dst, size_t n, F f) {
     int grid = grid_for(ctx, (n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((fill_kernel<T, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, dst, n, f);
     MA_HIP(hipGetLastError());
-    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
@@ -1210,7 +1210,7 @@ ma_status ma_dev_upload(ma_ctx* ctx, void* dst_dev, const void* src_host, size_t
     MA_NO_CAPTURE(ctx, "ma_dev_upload");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
@@ -1222,7 +1222,7 @@ ma_status ma_dev_download(ma_ctx* ctx, void* dst_host, const void* src_dev, size
     MA_NO_CAPTURE(ctx, "ma_dev_download");
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
+    MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
@@ -1233,7 +1233,7 @@ ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t b
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, ctx->stream));
-    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
@@ -1244,7 +1244,7 @@ ma_status ma_dev_copy(ma_ctx* ctx, void* dst_dev, const void* src_dev, size_t by
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     MA_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
@@ -1290,7 +1290,7 @@ ma_status ma_synth_validity(ma_ctx* ctx, uint8_t* dst_bits, size_t n_bits, uint6
     hipLaunchKernelGGL(validity_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (uint64_t*)dst_bits, n_bits, seed,
                        first_index, null_every);
     MA_HIP(hipGetLastError());
-    if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (!is_async(ctx)) MA_TRY(stream_wait(ctx));
     return MA_OK;
 }
 
