@@ -66,6 +66,7 @@ def shared_worker(ctx, seed):
     bits = rng.integers(0, 256, size=n_max // 8 + 64, dtype=np.uint8)
     valid = np.unpackbits(bits, bitorder="little")[:n_max].astype(bool)
     d, m = ctx.to_device(a, 64), ctx.to_device(bits, 16)
+    out = ctx.alloc(20000 * 8 + 64)
     csum = np.concatenate([[0], np.cumsum(a)])
     msum = np.concatenate([[0], np.cumsum(np.where(valid, a, 0))])
     mcnt = np.concatenate([[0], np.cumsum(valid)])
@@ -81,6 +82,20 @@ def shared_worker(ctx, seed):
         if got != (int(msum[off + n] - msum[off]), int(mcnt[off + n] - mcnt[off])):
             errors.append(f"shared ctx seed {seed}: masked n={n} off={off} got {got}")
         done += 2
+        # bitmap scans (ticketed epilogue, device accumulator zeroed by the last workgroup) and a synchronous elementwise
+        # call followed by a download (both end in the stream-stamped, polled wait)
+        nb = int(rng.integers(1, n_max))
+        lo = off & ~63  # popcount addresses its window by whole words (bitmask/simd.rs): keep the offset on one
+        hi = lo + min(nb, n_max - lo)
+        got = ctx.popcount_mask(m, lo, hi - lo)
+        if got != int(mcnt[hi] - mcnt[lo]):
+            errors.append(f"shared ctx seed {seed}: popcount bits [{lo},{hi}) got {got} want {int(mcnt[hi] - mcnt[lo])}")
+        k = int(rng.integers(1, 20000))
+        ctx.apply("i64", d.offset(off * 8), d.offset(off * 8), 0, out, min(k, n), min(k, n))
+        res = out.download(np.int64, min(k, n))
+        if not np.array_equal(res, a[off:off + min(k, n)] * 2):
+            errors.append(f"shared ctx seed {seed}: a + a n={min(k, n)} off={off} mismatch")
+        done += 2
     counts.append(done)
 
 
@@ -91,7 +106,7 @@ threads += [threading.Thread(target=shared_worker, args=(shared, s)) for s in ra
 [t.join() for t in threads]
 shared.close()
 print(f"{sum(counts)} reductions checked on 4 private contexts (async, random grids) + 4 threads sharing one context "
-      f"(synchronous, lanes + polled completion), {len(errors)} errors")
+      f"(synchronous sums, bitmap scans, elementwise + download: lanes + polled completion), {len(errors)} errors")
 for e in errors[:10]:
     print(e)
 sys.exit(1 if errors else 0)
