@@ -243,6 +243,11 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out);
 // call returns. (A buffer is re-used only after the copy issued from it two uploads ago has left it.) The caller holds
 // the context.
 ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst);
+// The same in two steps for tables large enough that the extra copy shows (100 000 chunk descriptors): table_begin hands
+// out the pinned staging buffer to BUILD the table in, table_commit enqueues its copy. Nothing else may stage a table on
+// this context in between; a begin without a commit is harmless.
+ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host);
+ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_dst);
 
 // A reduction record as it is exchanged between GPUs: 8 x u64 (64 bytes) — [0] integer sum, [1] integer valid count,
 // [2] f64 hi bits, [3] f64 lo bits, [4] float valid count, [5..7] unused.

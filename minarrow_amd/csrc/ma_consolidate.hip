@@ -276,7 +276,8 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    std::vector<ChunkDesc> desc(n_chunks);
+    ChunkDesc* desc = nullptr;  // built in the context's pinned staging buffer (ma::table_begin / table_commit)
+    MA_TRY(table_begin(ctx, sizeof(ChunkDesc) * n_chunks, (void**)&desc));
     void* po = nullptr;
     MA_TRY(scope.out(out_data, total * elem_size, &po));
     uint64_t* ow = nullptr;
@@ -309,7 +310,7 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     }
     void* ddesc = nullptr;  // descriptor table -> device scratch, through the context's pinned staging (no stream drain)
     MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks, &ddesc));
-    MA_TRY(upload_table(ctx, desc.data(), sizeof(ChunkDesc) * n_chunks, ddesc));
+    MA_TRY(table_commit(ctx, desc, sizeof(ChunkDesc) * n_chunks, ddesc));
 
     const ChunkDesc* d = (const ChunkDesc*)ddesc;
     switch (elem_size) {

@@ -185,22 +185,36 @@ ma_status hip_fail(hipError_t e, const char* what, const char* file, int line) {
 // a hipFree by the host) and handed out again as host memory, which a kernel must never be pointed at.
 namespace {
 constexpr int kRanges = 8;
-thread_local uintptr_t t_lo[kRanges] = {0}, t_hi[kRanges] = {0};
-thread_local unsigned t_next_slot = 0;
-thread_local int t_scope_depth = 0;
+// One thread-local object (one TLS lookup per call in a shared library, not one per variable); the range that matched
+// last is tried first — a chunked column's pointers arrive in runs from the same few allocations.
+struct RangeCache {
+    uintptr_t lo[kRanges] = {0}, hi[kRanges] = {0};
+    unsigned next_slot = 0;
+    unsigned last_hit = 0;
+    int scope_depth = 0;
+};
+thread_local RangeCache t_ranges;
 
 void forget_ranges() {
-    for (int i = 0; i < kRanges; ++i) t_lo[i] = t_hi[i] = 0;
-    t_next_slot = 0;
+    RangeCache& c = t_ranges;
+    for (int i = 0; i < kRanges; ++i) c.lo[i] = c.hi[i] = 0;
+    c.next_slot = 0;
+    c.last_hit = 0;
 }
 }  // namespace
 
 PtrKind pointer_kind(const void* p) {
-    const bool remember = t_scope_depth > 0;
+    RangeCache& c = t_ranges;
+    const bool remember = c.scope_depth > 0;
     const uintptr_t addr = (uintptr_t)p;
-    if (remember)
-        for (int i = 0; i < kRanges; ++i)
-            if (addr >= t_lo[i] && addr < t_hi[i]) return kDevice;
+    if (remember) {
+        if (addr >= c.lo[c.last_hit] && addr < c.hi[c.last_hit]) return kDevice;
+        for (unsigned i = 0; i < (unsigned)kRanges; ++i)
+            if (addr >= c.lo[i] && addr < c.hi[i]) {
+                c.last_hit = i;
+                return kDevice;
+            }
+    }
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
@@ -213,9 +227,10 @@ PtrKind pointer_kind(const void* p) {
             size_t size = 0;
             if (remember) {
                 if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size) {
-                    t_lo[t_next_slot] = (uintptr_t)base;
-                    t_hi[t_next_slot] = (uintptr_t)base + size;
-                    t_next_slot = (t_next_slot + 1) % kRanges;
+                    c.lo[c.next_slot] = (uintptr_t)base;
+                    c.hi[c.next_slot] = (uintptr_t)base + size;
+                    c.last_hit = c.next_slot;
+                    c.next_slot = (c.next_slot + 1) % kRanges;
                 } else {
                     (void)hipGetLastError();
                 }
@@ -235,7 +250,7 @@ PtrKind pointer_kind(const void* p) {
 }
 
 CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
-    if (t_scope_depth++ == 0) forget_ranges();
+    if (t_ranges.scope_depth++ == 0) forget_ranges();
 }
 
 CallScope::~CallScope() {
@@ -244,7 +259,7 @@ CallScope::~CallScope() {
     // nothing in flight still reads or writes the slabs and the caller gets its "synchronous" call back quiescent.
     if (!slabs_.empty() && !finished_) (void)hipStreamSynchronize(ctx_->stream);
     for (void* slab : slabs_) (void)dev_block_free(ctx_->device, slab);
-    if (--t_scope_depth == 0 || !temps_.empty()) forget_ranges();
+    if (--t_ranges.scope_depth == 0 || !temps_.empty()) forget_ranges();
 }
 
 ma_status CallScope::carve(size_t bytes, void** out) {
@@ -399,10 +414,10 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
     return MA_OK;
 }
 
-ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst) {
+ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host) {
+    *out_host = nullptr;
     if (bytes == 0) return MA_OK;
     const int k = ctx->table_next;
-    ctx->table_next ^= 1;
     if (!ctx->table_ev[k]) MA_HIP(hipEventCreateWithFlags(&ctx->table_ev[k], hipEventDisableTiming));
     if (ctx->table_busy[k]) {
         MA_HIP(hipEventSynchronize(ctx->table_ev[k]));
@@ -416,11 +431,27 @@ ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst
         MA_HIP(hipHostMalloc(&ctx->table_stage[k], want, hipHostMallocPortable));
         ctx->table_stage_bytes[k] = want;
     }
-    memcpy(ctx->table_stage[k], src, bytes);
-    MA_HIP(hipMemcpyAsync(dev_dst, ctx->table_stage[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out_host = ctx->table_stage[k];
+    return MA_OK;
+}
+
+ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_dst) {
+    if (bytes == 0) return MA_OK;
+    const int k = ctx->table_next;
+    MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit without table_begin");
+    ctx->table_next ^= 1;
+    MA_HIP(hipMemcpyAsync(dev_dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipEventRecord(ctx->table_ev[k], ctx->stream));
     ctx->table_busy[k] = true;
     return MA_OK;
+}
+
+ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst) {
+    if (bytes == 0) return MA_OK;
+    void* host = nullptr;
+    MA_TRY(table_begin(ctx, bytes, &host));
+    memcpy(host, src, bytes);
+    return table_commit(ctx, host, bytes, dev_dst);
 }
 
 ma_status end_call(ma_ctx* ctx, CallScope& scope) {

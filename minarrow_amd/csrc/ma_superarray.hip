@@ -210,7 +210,8 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     MA_NO_CAPTURE(ctx, "route_super_array_broadcast (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    std::vector<PairDesc> descs(n_chunks);
+    PairDesc* descs = nullptr;  // built in the context's pinned staging buffer: no second copy of a multi-megabyte table
+    MA_TRY(table_begin(ctx, sizeof(PairDesc) * n_chunks, (void**)&descs));
     size_t n_tiles = 0, n_words = 0;
     bool any_mask = false, masked_head = false;
     for (size_t i = 0; i < n_chunks; ++i) {
@@ -255,7 +256,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     if (n_tiles == 0) return MA_OK;
     void* ddesc = nullptr;
     MA_TRY(ctx_scratch(ctx, sizeof(PairDesc) * n_chunks, &ddesc));
-    MA_TRY(upload_table(ctx, descs.data(), sizeof(PairDesc) * n_chunks, ddesc));
+    MA_TRY(table_commit(ctx, descs, sizeof(PairDesc) * n_chunks, ddesc));
     const PairDesc* dd = (const PairDesc*)ddesc;
     const bool fuse = any_mask && !masked_head && !(ctx->variant & 64);  // variant bit 64: always the separate bitmap launch
     if (any_mask && !fuse) {
