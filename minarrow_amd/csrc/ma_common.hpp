@@ -159,6 +159,22 @@ PtrKind pointer_kind(const void* p);
 // return before the work is done.
 inline bool crosses_in_tiles(const ma_ctx* ctx, PtrKind k) { return k == kPageable || (k == kPinned && !is_async(ctx)); }
 
+// The device allocation a pointer was found in during this call (pointer_kind's per-call range cache): lets a loop over
+// thousands of chunk pointers test "same allocation as the previous one" with two compares. Only valid while the
+// CallScope of the call is alive.
+bool known_device_range(const void* p, uintptr_t* lo, uintptr_t* hi);
+struct DeviceRange {
+    uintptr_t lo = 1, hi = 0;  // empty
+    bool holds(const void* p) const { return (uintptr_t)p >= lo && (uintptr_t)p < hi; }
+    void learn(const void* p) {
+        uintptr_t l, h;
+        if (known_device_range(p, &l, &h)) {
+            lo = l;
+            hi = h;
+        }
+    }
+};
+
 // Makes every buffer of one ABI call device-reachable. Pageable host inputs are copied into temporary
 // device buffers; pageable host outputs get a temporary that is copied back by finish(). Using any
 // temporary forces the call to be synchronous.

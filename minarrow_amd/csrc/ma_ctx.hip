@@ -249,6 +249,18 @@ PtrKind pointer_kind(const void* p) {
     }
 }
 
+bool known_device_range(const void* p, uintptr_t* lo, uintptr_t* hi) {
+    RangeCache& c = t_ranges;
+    const uintptr_t addr = (uintptr_t)p;
+    for (int i = 0; i < kRanges; ++i)
+        if (addr >= c.lo[i] && addr < c.hi[i]) {
+            *lo = c.lo[i];
+            *hi = c.hi[i];
+            return true;
+        }
+    return false;
+}
+
 CallScope::CallScope(ma_ctx* ctx) : ctx_(ctx) {
     if (t_ranges.scope_depth++ == 0) forget_ranges();
 }

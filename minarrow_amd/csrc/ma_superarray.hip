@@ -214,6 +214,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     MA_TRY(table_begin(ctx, sizeof(PairDesc) * n_chunks, (void**)&descs));
     size_t n_tiles = 0, n_words = 0;
     bool any_mask = false, masked_head = false;
+    DeviceRange lhs_role, rhs_role, out_role, lm_role, rm_role, om_role;
     for (size_t i = 0; i < n_chunks; ++i) {
         PairDesc& d = descs[i];
         memset(&d, 0, sizeof(d));
@@ -226,25 +227,63 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
         if (out_has_mask) out_has_mask[i] = (lm || rm) ? 1 : 0;
         if (n == 0) continue;
         MA_REQUIRE(lhs_data[i] && rhs_data[i] && out_data[i], MA_ERR_INVALID_ARGUMENT, "chunk %zu: NULL buffer", i);
-        const void* p = nullptr;
-        MA_TRY(scope.in(lhs_data[i], n * sizeof(T), &p));
-        d.lhs = p;
-        MA_TRY(scope.in(rhs_data[i], n * sizeof(T), &p));
-        d.rhs = p;
-        void* po = nullptr;
-        MA_TRY(scope.out(out_data[i], n * sizeof(T), &po));
-        d.out = po;
+        // A chunked column's pointers run through a few allocations: each operand role remembers the device range its
+        // last pointer fell into, so the common case is two compares per pointer (no classification call — six of those
+        // per chunk pair were most of the 38 ns a pair cost the host, as long as the kernel itself at 60 000 pairs).
+        if (lhs_role.holds(lhs_data[i])) {
+            d.lhs = lhs_data[i];
+        } else {
+            const void* p = nullptr;
+            MA_TRY(scope.in(lhs_data[i], n * sizeof(T), &p));
+            d.lhs = p;
+            lhs_role.learn(lhs_data[i]);
+        }
+        if (rhs_role.holds(rhs_data[i])) {
+            d.rhs = rhs_data[i];
+        } else {
+            const void* p = nullptr;
+            MA_TRY(scope.in(rhs_data[i], n * sizeof(T), &p));
+            d.rhs = p;
+            rhs_role.learn(rhs_data[i]);
+        }
+        if (out_role.holds(out_data[i])) {
+            d.out = out_data[i];
+        } else {
+            void* po = nullptr;
+            MA_TRY(scope.out(out_data[i], n * sizeof(T), &po));
+            d.out = po;
+            out_role.learn(out_data[i]);
+        }
         if (lm) {
-            MA_TRY(scope.in_mask(lm, 0, n, &d.lw, &d.lo));
+            if (lm_role.holds(lm)) {
+                const uintptr_t addr = (uintptr_t)lm, base = addr & ~(uintptr_t)7;  // CallScope::in_mask's re-basing
+                d.lw = (const uint64_t*)base;
+                d.lo = (size_t)(addr - base) * 8;
+            } else {
+                MA_TRY(scope.in_mask(lm, 0, n, &d.lw, &d.lo));
+                lm_role.learn(lm);
+            }
             d.l_last = (d.lo + n - 1) >> 6;
         }
         if (rm) {
-            MA_TRY(scope.in_mask(rm, 0, n, &d.rw, &d.ro));
+            if (rm_role.holds(rm)) {
+                const uintptr_t addr = (uintptr_t)rm, base = addr & ~(uintptr_t)7;
+                d.rw = (const uint64_t*)base;
+                d.ro = (size_t)(addr - base) * 8;
+            } else {
+                MA_TRY(scope.in_mask(rm, 0, n, &d.rw, &d.ro));
+                rm_role.learn(rm);
+            }
             d.r_last = (d.ro + n - 1) >> 6;
         }
         if (lm || rm) {
             MA_REQUIRE(out_masks && out_masks[i], MA_ERR_INVALID_ARGUMENT, "chunk %zu carries nulls but has no output bitmap", i);
-            MA_TRY(scope.out_mask(out_masks[i], n, &d.ow));
+            if (om_role.holds(out_masks[i]) && ((uintptr_t)out_masks[i] & 7) == 0) {
+                d.ow = (uint64_t*)out_masks[i];
+            } else {
+                MA_TRY(scope.out_mask(out_masks[i], n, &d.ow));
+                om_role.learn(out_masks[i]);
+            }
             any_mask = true;
         }
         const uintptr_t mis = (uintptr_t)d.out & 15;
