@@ -285,19 +285,32 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     const size_t tile_rows = elem_size == 1 ? tile_rows_of<uint8_t>() : elem_size == 2 ? tile_rows_of<uint16_t>()
                            : elem_size == 4 ? tile_rows_of<uint32_t>() : tile_rows_of<uint64_t>();
     size_t row = 0, n_tiles = 0;
+    DeviceRange data_role, mask_role;
     for (size_t i = 0; i < n_chunks; ++i) {
         ChunkDesc& d = desc[i];
-        const void* p = nullptr;
-        MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
-        d.data = p;
+        if (data_role.holds(chunk_data[i])) {  // same device allocation as the previous chunk: no classification call
+            d.data = chunk_data[i];
+        } else {
+            const void* p = nullptr;
+            MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
+            d.data = p;
+            if (chunk_lens[i]) data_role.learn(chunk_data[i]);
+        }
         d.start = row;
         d.len = chunk_lens[i];
         d.words = nullptr;
         d.bit_off = 0;
         d.last_word = 0;
         if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
-            MA_TRY(scope.in_mask(chunk_masks[i], chunk_mask_offsets ? chunk_mask_offsets[i] : 0, chunk_lens[i], &d.words,
-                                 &d.bit_off));
+            const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
+            if (mask_role.holds(chunk_masks[i])) {
+                const uintptr_t addr = (uintptr_t)chunk_masks[i], base = addr & ~(uintptr_t)7;  // CallScope::in_mask's re-basing
+                d.words = (const uint64_t*)base;
+                d.bit_off = mo + (size_t)(addr - base) * 8;
+            } else {
+                MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &d.words, &d.bit_off));
+                mask_role.learn(chunk_masks[i]);
+            }
             d.last_word = (d.bit_off + d.len - 1) >> 6;
         }
         // copy tiles of this chunk
