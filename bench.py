@@ -430,7 +430,7 @@ def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallel
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc.exists():
+    if pmc.exists() and rows == 1_000_000_000:  # the counters were collected on the full-size workload only
         try:
             key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
             traffic = json.loads(pmc.read_text()).get(key)
