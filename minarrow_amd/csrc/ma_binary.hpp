@@ -210,14 +210,9 @@ __device__ __forceinline__ double pow_f32_ln(double x) {
     p = fma(p, z, 1.0 / 3);
     p = p * z;
     const double two_s = s + s;
-    double res = fma((double)e, 0.6931471805599453, fma(two_s, p, two_s));
-    if (x == __builtin_inf()) res = x;
-    if (x == 0.0) res = -__builtin_inf();
-    if (!(x >= 0.0)) res = __builtin_nan("");  // negative or NaN
-    return res;
+    return fma((double)e, 0.6931471805599453, fma(two_s, p, two_s));  // x = 0, inf, negative, NaN: the caller's business
 }
-__device__ __forceinline__ double pow_f32_exp(double y) {
-    const double yc = fmin(fmax(y, -150.0), 150.0);  // far beyond the f32 range on both sides
+__device__ __forceinline__ double pow_f32_exp(double yc) {  // |yc| <= 150 (clamped by the caller), not NaN
     const double k = __builtin_rint(yc * 1.4426950408889634);
     double r = fma(-k, 0.6931471803691238, yc);  // ln2 split: the high part's product with |k| < 2^10 is exact
     r = fma(-k, 1.9082149292705877e-10, r);
@@ -233,8 +228,7 @@ __device__ __forceinline__ double pow_f32_exp(double y) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double res = __builtin_amdgcn_ldexp(p, (int)k);
-    return y != y ? y : res;
+    return __builtin_amdgcn_ldexp(p, (int)k);
 }
 
 template <>
@@ -252,9 +246,15 @@ struct Elem<float, true> {
         // that the exp() would amplify by |b ln a|. The f64 evaluations only need to be good to the f32 rounding:
         // pow_f32_ln / pow_f32_exp above.
         if constexpr (OP == MA_OP_POWER) {
+            // the special operands are sorted out in f32 (one-register compares and selects)
             float l = (float)pow_f32_ln((double)a);
-            float y = b * l;
-            return (float)pow_f32_exp((double)y);
+            l = a == __builtin_inff() ? a : l;
+            l = a == 0.0f ? -__builtin_inff() : l;
+            l = a >= 0.0f ? l : __builtin_nanf("");  // negative or NaN
+            const float y = b * l;
+            const float yc = __builtin_fminf(__builtin_fmaxf(y, -150.0f), 150.0f);  // far beyond the f32 range; NaN -> -150
+            const float r = (float)pow_f32_exp((double)yc);
+            return y != y ? y : r;
         }
         if constexpr (OP == MA_OP_FLOORDIV) return floorf(a / b);
         return 0.0f;
