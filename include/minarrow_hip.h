@@ -808,6 +808,18 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
                                                const size_t* rhs_lens, const uint8_t* const* rhs_masks,
                                                const uint8_t* const* member_mask_overrides, void* const* out_data,
                                                uint8_t* const* out_masks, int32_t* out_has_mask);
+/* SuperTable::consolidate (src/structs/chunked/super_table.rs:657-743, src/traits/consolidate.rs:80-207) for a column
+ * whose batches live on different GPUs: chunk i is device memory of member i % ma_group_size(group); the consolidated
+ * column (and its validity, present iff some chunk has one; chunks without contribute all-valid rows) is written to
+ * out_data / out_mask, device memory of member dest_member. Owners push their chunks into place with peer copies over
+ * xGMI on their own streams, concurrently; validity is gathered on byte boundaries and joined at bit granularity on the
+ * destination. Arguments otherwise as ma_consolidate_column. ENQUEUES only: the destination member's stream is ordered
+ * behind the copies, ma_group_synchronize waits for everything. A batch-sharded table needs this only when one
+ * contiguous column is explicitly asked for — its per-column reduce moves no bytes (ma_group_enqueue_sum_*). */
+ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size_t elem_size, size_t n_chunks,
+                                      const void* const* chunk_data, const size_t* chunk_lens,
+                                      const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, void* out_data,
+                                      uint8_t* out_mask, int32_t* out_has_mask);
 ma_status ma_group_result(ma_group* group, int32_t column, int64_t* out_int_sum, uint64_t* out_int_count,
                           double* out_f64_sum, uint64_t* out_f64_count);
 ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column, int64_t* out_int_sum,

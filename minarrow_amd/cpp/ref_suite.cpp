@@ -651,6 +651,25 @@ static void multi_gpu_group_suite() {
                                                         bad.data(), nullptr, nullptr, dout.data(), nullptr, nullptr) == MA_ERR_LENGTH_MISMATCH);
             for (int r = 0; r < n_dev; ++r) ASSERT(ma_dev_free(ma_group_ctx(g, r), dout[r]) == MA_OK);
         }
+        // SuperTable::consolidate of the sharded column onto member 0 (peer copies; super_table.rs:657-743): the chunks are
+        // slices of one iota column, so the consolidated column is 0, 1, 2, ... again
+        {
+            ma_ctx* c0 = ma_group_ctx(g, 0);
+            void* whole = nullptr;
+            ASSERT(ma_dev_alloc(c0, n * 8 + 64, &whole) == MA_OK);
+            std::vector<const void*> chunks(n_dev);
+            for (int r = 0; r < n_dev; ++r) chunks[r] = di[r];
+            int32_t has = 7;
+            ASSERT(ma_group_consolidate_column(g, 0, 8, (size_t)n_dev, chunks.data(), lens.data(), nullptr, nullptr, whole, nullptr,
+                                               &has) == MA_OK);
+            ASSERT(ma_group_synchronize(g) == MA_OK && has == 0);
+            std::vector<int64_t> host(n);
+            ASSERT(ma_dev_download(c0, host.data(), whole, n * 8) == MA_OK);
+            bool iota = true;
+            for (size_t j = 0; j < n; ++j) iota = iota && host[j] == (int64_t)j;
+            ASSERT(iota);
+            ASSERT(ma_dev_free(c0, whole) == MA_OK);
+        }
         for (int r = 0; r < n_dev; ++r) {
             ASSERT(ma_dev_free(ma_group_ctx(g, r), di[r]) == MA_OK && ma_dev_free(ma_group_ctx(g, r), df[r]) == MA_OK);
         }

@@ -28,6 +28,10 @@ struct ma_group {
     std::vector<uint64_t*> local, gathered, finals;
     uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
     uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
+    // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
+    // gathered into before the bit-granular join (re-used across calls in stream order)
+    std::vector<void*> mask_stage;
+    std::vector<size_t> mask_stage_bytes;
     char note[256] = "";
 };
 
@@ -89,7 +93,14 @@ void release_exchange(ma_group* g) {
 }
 
 void destroy_members(ma_group* g) {
-    release_exchange(g);
+    release_exchange(g);  // drains every member's stream first
+    for (size_t i = 0; i < g->mask_stage.size() && i < g->ctxs.size(); ++i)
+        if (g->mask_stage[i]) {
+            (void)hipSetDevice(g->ctxs[i]->device);
+            (void)hipFree(g->mask_stage[i]);
+        }
+    g->mask_stage.clear();
+    g->mask_stage_bytes.clear();
     for (ma_ctx* c : g->ctxs) ma_ctx_destroy(c);
     g->ctxs.clear();
 }
@@ -345,6 +356,145 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
             for (size_t j = 0; j < has.size(); ++j) out_has_mask[m + j * G] = has[j];
     }
     return MA_OK;
+}
+
+// SuperTable::consolidate for a column whose batches live on different GPUs (src/structs/chunked/super_table.rs:657-743,
+// src/traits/consolidate.rs:80-207): chunk i is resident on member i % G, the consolidated column lands on
+// `dest_member`'s device. Every owner pushes its chunks into place with peer copies on ITS stream (all xGMI links into
+// the destination run concurrently); validity bytes are gathered into a staging arena on the destination and joined at
+// bit granularity there (ma_consolidate_boolean_column: chunks without a bitmap contribute all-valid bits). The
+// destination's stream ends up ordered behind every copy; owners wait for the destination's earlier work before they
+// overwrite `out_data`. Enqueue-only. SURVEY.md 8(e): "do it only when a contiguous result is explicitly requested" —
+// the per-column reduce of a batch-sharded table needs no bytes moved (ma_group_enqueue_sum_*).
+ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size_t elem_size, size_t n_chunks,
+                                      const void* const* chunk_data, const size_t* chunk_lens,
+                                      const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, void* out_data,
+                                      uint8_t* out_mask, int32_t* out_has_mask) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, MA_ERR_UNSUPPORTED,
+               "element size %zu is not supported (1, 2, 4 or 8 bytes)", elem_size);
+    MA_REQUIRE(n_chunks > 0, MA_ERR_INVALID_ARGUMENT, "consolidate() called on empty SuperTable");
+    MA_REQUIRE(chunk_data != nullptr && chunk_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
+    std::lock_guard<std::mutex> lock(group->mu);
+    const size_t G = group->ctxs.size();
+    MA_REQUIRE(dest_member >= 0 && (size_t)dest_member < G, MA_ERR_INVALID_ARGUMENT, "member %d out of range", dest_member);
+    ma_ctx* dest = group->ctxs[(size_t)dest_member];
+    bool has_mask = false;
+    size_t total = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        MA_REQUIRE(chunk_lens[i] == 0 || chunk_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "chunk %zu data is NULL", i);
+        if (chunk_masks && chunk_masks[i] && chunk_lens[i]) has_mask = true;
+        total += chunk_lens[i];
+    }
+    if (out_has_mask) *out_has_mask = has_mask ? 1 : 0;
+    if (total == 0) return MA_OK;
+    MA_REQUIRE(out_data != nullptr, MA_ERR_INVALID_ARGUMENT, "out_data is NULL");
+    MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
+    MA_REQUIRE(!has_mask || ((uintptr_t)out_mask & 7) == 0, MA_ERR_INVALID_ARGUMENT,
+               "output bitmap must be 8-byte aligned (got %p)", (const void*)out_mask);
+    auto device_of = [](const void* p) -> int {  // -1: not device memory
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        return attr.type == hipMemoryTypeDevice ? attr.device : -1;
+    };
+    MA_REQUIRE(device_of(out_data) == dest->device, MA_ERR_INVALID_ARGUMENT,
+               "out_data must be device memory of member %d (device %d)", dest_member, dest->device);
+    MA_REQUIRE(!has_mask || device_of(out_mask) == dest->device, MA_ERR_INVALID_ARGUMENT,
+               "out_mask must be device memory of member %d (device %d)", dest_member, dest->device);
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (!chunk_lens[i]) continue;
+        const int want = group->ctxs[i % G]->device;
+        MA_REQUIRE(device_of(chunk_data[i]) == want, MA_ERR_INVALID_ARGUMENT,
+                   "chunk %zu belongs to member %zu: its data must be device memory of device %d", i, i % G, want);
+        MA_REQUIRE(!(chunk_masks && chunk_masks[i]) || device_of(chunk_masks[i]) == want, MA_ERR_INVALID_ARGUMENT,
+                   "chunk %zu belongs to member %zu: its bitmap must be device memory of device %d", i, i % G, want);
+    }
+    // validity staging arena on the destination: one 8-byte aligned slot per chunk
+    std::vector<size_t> slot_off(n_chunks, 0), slot_bit(n_chunks, 0);
+    size_t stage_bytes = 0;
+    if (has_mask) {
+        for (size_t i = 0; i < n_chunks; ++i) {
+            const size_t mo = (chunk_masks && chunk_masks[i] && chunk_mask_offsets) ? chunk_mask_offsets[i] : 0;
+            slot_bit[i] = mo & 7;
+            slot_off[i] = stage_bytes;
+            stage_bytes += (((slot_bit[i] + chunk_lens[i] + 7) >> 3) + 15) & ~(size_t)7;  // bytes + a spare word
+        }
+        if (group->mask_stage.size() < G) {
+            group->mask_stage.resize(G, nullptr);
+            group->mask_stage_bytes.resize(G, 0);
+        }
+        if (stage_bytes > group->mask_stage_bytes[(size_t)dest_member]) {
+            MA_HIP(hipSetDevice(dest->device));
+            if (group->mask_stage[(size_t)dest_member]) {
+                MA_HIP(hipStreamSynchronize(dest->stream));  // an earlier join may still read the old arena
+                MA_HIP(hipFree(group->mask_stage[(size_t)dest_member]));
+                group->mask_stage[(size_t)dest_member] = nullptr;
+                group->mask_stage_bytes[(size_t)dest_member] = 0;
+            }
+            const size_t want = stage_bytes + stage_bytes / 2 + 4096;
+            MA_HIP(device_malloc(dest->device, &group->mask_stage[(size_t)dest_member], want));
+            group->mask_stage_bytes[(size_t)dest_member] = want;
+        }
+    }
+    uint8_t* stage = has_mask ? (uint8_t*)group->mask_stage[(size_t)dest_member] : nullptr;
+
+    // Owners start after the destination's earlier work (which may still use out_data or the arena).
+    MA_HIP(hipSetDevice(dest->device));
+    hipEvent_t ready = nullptr;
+    MA_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ready, dest->stream);
+    std::vector<hipEvent_t> done(G, nullptr);
+    size_t row = 0;
+    for (size_t i = 0; i < n_chunks && e == hipSuccess; ++i) {
+        const size_t n = chunk_lens[i];
+        if (n) {
+            ma_ctx* owner = group->ctxs[i % G];
+            e = hipSetDevice(owner->device);
+            if (e == hipSuccess && !done[i % G]) {  // first use of this owner in the call
+                e = hipEventCreateWithFlags(&done[i % G], hipEventDisableTiming);
+                if (e == hipSuccess && owner != dest) e = hipStreamWaitEvent(owner->stream, ready, 0);
+            }
+            if (e == hipSuccess)
+                e = hipMemcpyPeerAsync((char*)out_data + row * elem_size, dest->device, chunk_data[i], owner->device, n * elem_size,
+                                       owner->stream);
+            if (e == hipSuccess && has_mask) {
+                uint8_t* slot = stage + slot_off[i];
+                const size_t nbytes = (slot_bit[i] + n + 7) >> 3;
+                if (chunk_masks && chunk_masks[i]) {
+                    const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
+                    e = hipMemcpyPeerAsync(slot, dest->device, chunk_masks[i] + (mo >> 3), owner->device, nbytes, owner->stream);
+                } else {  // no bitmap: all rows valid (consolidate.rs:80-105); the arena is the destination's to fill
+                    e = hipSetDevice(dest->device);
+                    if (e == hipSuccess) e = hipMemsetAsync(slot, 0xFF, nbytes, dest->stream);
+                }
+            }
+        }
+        row += n;
+    }
+    // The destination continues once every owner's copies have landed.
+    for (size_t m = 0; m < G && e == hipSuccess; ++m) {
+        if (!done[m]) continue;
+        e = hipSetDevice(group->ctxs[m]->device);
+        if (e == hipSuccess) e = hipEventRecord(done[m], group->ctxs[m]->stream);
+        if (e == hipSuccess && group->ctxs[m] != dest) {
+            e = hipSetDevice(dest->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(dest->stream, done[m], 0);
+        }
+    }
+    for (hipEvent_t ev : done)
+        if (ev) (void)hipEventDestroy(ev);  // released once the recorded work has completed
+    (void)hipEventDestroy(ready);
+    if (e != hipSuccess) return hip_fail(e, "ma_group_consolidate_column", __FILE__, __LINE__);
+    if (!has_mask) return MA_OK;
+    // bit-granular join of the staged validity windows on the destination
+    std::vector<const uint8_t*> bits(n_chunks);
+    for (size_t i = 0; i < n_chunks; ++i) bits[i] = stage + slot_off[i];
+    MA_HIP(hipSetDevice(dest->device));
+    return ma_consolidate_boolean_column(dest, n_chunks, bits.data(), slot_bit.data(), chunk_lens, nullptr, nullptr, out_mask,
+                                         nullptr, nullptr);
 }
 
 ma_status ma_group_exchange(ma_group* group) {

@@ -642,6 +642,23 @@ class Group:
             table(out_chunks), table(out_masks), C.cast(has, C.c_void_p)))
         return [bool(x) for x in has]
 
+    def consolidate_column(self, dest_member: int, elem_size: int, chunks, lens, out_data, masks=None, mask_offsets=None,
+                           out_mask=None) -> bool:
+        """SuperTable::consolidate for a column sharded over the group (ma_group_consolidate_column): chunk i lives on
+        member i % size, the result on member dest_member. Enqueues only. Returns True when out_mask will be written."""
+        k = len(chunks)
+        data_arr = (C.c_void_p * k)(*[addr_of(c) or None for c in chunks])
+        len_arr = (C.c_size_t * k)(*[int(n) for n in lens])
+        mask_arr = (C.c_void_p * k)(*[addr_of(m) or None for m in masks]) if masks is not None else None
+        off_arr = (C.c_size_t * k)(*[int(o) for o in mask_offsets]) if mask_offsets is not None else None
+        has = C.c_int32()
+        ffi.check(self.lib.ma_group_consolidate_column(
+            self.handle, int(dest_member), int(elem_size), k, C.cast(data_arr, C.c_void_p), C.cast(len_arr, C.c_void_p),
+            C.cast(mask_arr, C.c_void_p) if mask_arr is not None else None,
+            C.cast(off_arr, C.c_void_p) if off_arr is not None else None, addr_of(out_data), addr_of(out_mask),
+            C.addressof(has)))
+        return bool(has.value)
+
     def exchange(self) -> None:
         ffi.check(self.lib.ma_group_exchange(self.handle))
 

@@ -294,3 +294,57 @@ def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange):
             g.synchronize()
         assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
         g.synchronize()  # the latch is cleared by the report
+
+
+@pytest.mark.parametrize("members,dest", [(1, 0), (3, 1), (8, 7)])
+def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, dest):
+    """ma_group_consolidate_column: chunk i on member i % G, the consolidated column (+ validity joined at bit
+    granularity, chunks without a bitmap = all valid) on member `dest`. With every member on device 0 the peer copies
+    are same-device copies; what is under test is the placement arithmetic, the staging of the validity windows (byte
+    offsets, bit remainders), the stream ordering between the members and the join — against the single-context
+    ma_consolidate_column on the same chunks, which is itself checked against the oracle and the reference's vectors."""
+    from minarrow_amd.host import Group
+
+    rng = np.random.default_rng(500 + members)
+    for dt, lens in ((np.int64, [5, 64, 1000, 0, 4097, 70_001, 129, 1, 8192, 33]), (np.int32, [100_003, 63, 65, 7]), (np.uint8, [3, 1000, 17, 4096, 9])):
+        dt = np.dtype(dt)
+        k, total = len(lens), sum(lens)
+        data = [rng.integers(0, 100, size=n).astype(dt) for n in lens]
+        offs = [int(o) for o in rng.integers(0, 50, size=k)]
+        masks = [rng.integers(0, 256, size=(o + n) // 8 + 16, dtype=np.uint8) if i % 3 != 1 else None
+                 for i, (n, o) in enumerate(zip(lens, offs))]
+        nb = ((total + 63) // 64) * 8
+        # single-context answer
+        want_out, want_mask = ctx.alloc(total * dt.itemsize + 64), ctx.alloc(nb + 8)
+        d1 = [ctx.to_device(x, 64) for x in data]
+        m1 = [ctx.to_device(m, 16) if m is not None else None for m in masks]
+        for with_masks in (False, True):
+            has1 = ctx.consolidate_column(dt.itemsize, d1, lens, want_out, m1 if with_masks else None, offs if with_masks else None,
+                                          want_mask if with_masks else None)
+            with Group([0] * members, "host") as g:
+                own = [g.member_ctx(m) for m in range(members)]
+                dd = [own[i % members].to_device(x, 64) for i, x in enumerate(data)]
+                dm = [own[i % members].to_device(m, 16) if m is not None else None for i, m in enumerate(masks)]
+                out = own[dest].alloc(total * dt.itemsize + 64)
+                om = own[dest].alloc(nb + 8)
+                for _ in range(2):  # twice: the staging arena is re-used in stream order
+                    has = g.consolidate_column(dest, dt.itemsize, dd, lens, out, dm if with_masks else None,
+                                               offs if with_masks else None, om if with_masks else None)
+                g.synchronize()
+                assert has == has1 == with_masks
+                np.testing.assert_array_equal(out.download(dt, total), want_out.download(dt, total))
+                if with_masks:
+                    np.testing.assert_array_equal(om.download(np.uint8, nb), want_mask.download(np.uint8, nb))
+                if with_masks and members > 1:  # a chunk on the wrong member's context is refused only across devices: skip here
+                    pass
+        for b in d1 + [m for m in m1 if m is not None] + [want_out, want_mask]:
+            b.free()
+    with Group([0], "host") as g:
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.consolidate_column(0, 8, [], [], None)
+        assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "empty SuperTable" in e.value.message
+        host = np.zeros(16, dtype=np.int64)
+        o = g.member_ctx(0).alloc(256)
+        with pytest.raises(ffi.MinarrowHipError) as e:  # chunks must be device memory of their member
+            g.consolidate_column(0, 8, [host], [16], o)
+        assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
