@@ -610,6 +610,36 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
         "grows_per_s": 2 * rows * world / ms / 1e6, "gbps": 2 * 8.125 * rows * world / ms / 1e6,
         "frac_of_peak_per_gpu": 2 * 8.125 * rows / ms / 1e6 / HBM_PEAK_GBPS, "valid_count": icnt, "parity": bool(ok5),
         "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
+    # ---- config 5, physically: the i64 column's N batches gathered onto GPU 0 (peer copies over xGMI on the owners' streams,
+    # validity joined at bit granularity) — what a host asks for only when it needs one contiguous column. Its own
+    # try: a failure here is reported in its entry and leaves the other legs standing.
+    try:
+        c0 = ctxs[0]
+        whole = c0.alloc_output(rows * world * 8)
+        wmask = c0.alloc(rows * world // 8 + 128)
+        steps = max(1, min(reps, 3))
+        for _ in range(1):
+            group.consolidate_column(0, 8, cols_i, lens, whole, masks, zeros, wmask)
+        group.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            group.consolidate_column(0, 8, cols_i, lens, whole, masks, zeros, wmask)
+        group.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        c0.set_async(False)
+        s_w, c_w = c0.sum("i64", whole, rows * world, mask=wmask)
+        c0.set_async(True)
+        ok_g = (s_w & M64) == part_s and c_w == part_c  # the consolidated column reduces to the per-batch totals
+        moved = 8.125 * rows * world
+        res["config5_physical_consolidate_onto_gpu0"] = {
+            "n_gpus": world, "rows_total": rows * world, "ms_per_step": ms, "gbps_into_gpu0": moved / ms / 1e6,
+            "bytes_over_xgmi": 8.125 * rows * (world - 1), "parity": bool(ok_g),
+            "note": "ma_group_consolidate_column: hipMemcpyPeerAsync per batch on its owner's stream + bit-granular validity join"}
+        ok5 = ok5 and ok_g
+        whole.free()
+        wmask.free()
+    except Exception as e:  # noqa: BLE001
+        res["config5_physical_consolidate_onto_gpu0"] = {"error": f"{type(e).__name__}: {e}"}
     for m in masks:
         m.free()
     res["parity_ok"] = bool(ok3 and ok and ok5)

@@ -52,6 +52,7 @@ def test_one_process_group_mode_with_rccl():
     assert oc["parity_ok"] is True
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True  # chunk fan-out over the group, no exchange
+    assert oc["config5_physical_consolidate_onto_gpu0"]["parity"] is True  # the gather onto one member
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["rows_total"] == 1 << 24
     host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host",
                 "--no-other-configs"])
