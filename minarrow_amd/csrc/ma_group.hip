@@ -64,6 +64,37 @@ struct HostFoldDD {
     }
 };
 
+// Which device a pointer's memory is resident on (-1: pageable / pinned host memory, or NULL). A chunked column's
+// thousands of pointers run through a handful of allocations: each allocation is asked about once per call.
+class DeviceLookup {
+  public:
+    int device_of(const void* p) {
+        const uintptr_t a = (uintptr_t)p;
+        for (const Seen& r : seen_)
+            if (a >= r.lo && a < r.hi) return r.device;
+        hipPointerAttribute_t attr;
+        if (p == nullptr || hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        if (attr.type != hipMemoryTypeDevice) return -1;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size)
+            seen_.push_back({(uintptr_t)base, (uintptr_t)base + size, attr.device});
+        else
+            (void)hipGetLastError();
+        return attr.device;
+    }
+
+  private:
+    struct Seen {
+        uintptr_t lo, hi;
+        int device;
+    };
+    std::vector<Seen> seen_;
+};
+
 // Frees the exchange's buffers and communicators (either kind); the members stay.
 void release_exchange(ma_group* g) {
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
@@ -314,20 +345,19 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
         }
     std::lock_guard<std::mutex> lock(group->mu);
     const size_t G = group->ctxs.size();
-    // A device-resident chunk must live on its member's GPU: the kernels address it directly.
+    // A device-resident chunk must live on its member's GPU: the kernels address it directly. A SuperArray's thousands
+    // of chunk pointers run through a handful of allocations: each allocation is asked about once.
+    DeviceLookup lookup;
+    auto device_of = [&](const void* p) { return lookup.device_of(p); };
     for (size_t i = 0; i < n_chunks; ++i) {
         if (lhs_lens[i] == 0) continue;
         const int want = group->ctxs[i % G]->device;
         const void* ptrs[3] = {lhs_data[i], rhs_data[i], out_data[i]};
         for (const void* p : ptrs) {
-            hipPointerAttribute_t attr;
-            if (p == nullptr || hipPointerGetAttributes(&attr, p) != hipSuccess) {
-                (void)hipGetLastError();
-                continue;  // pageable host memory (staged by the member) or NULL (reported by the member's call)
-            }
-            MA_REQUIRE(attr.type != hipMemoryTypeDevice || attr.device == want, MA_ERR_INVALID_ARGUMENT,
+            const int dev = device_of(p);
+            MA_REQUIRE(dev < 0 || dev == want, MA_ERR_INVALID_ARGUMENT,
                        "chunk %zu belongs to member %zu (device %d) but one of its buffers is resident on device %d", i, i % G,
-                       want, attr.device);
+                       want, dev);
         }
     }
     std::vector<const void*> l, r;
@@ -392,14 +422,8 @@ ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size
     MA_REQUIRE(!has_mask || out_mask != nullptr, MA_ERR_INVALID_ARGUMENT, "a chunk carries nulls but out_mask is NULL");
     MA_REQUIRE(!has_mask || ((uintptr_t)out_mask & 7) == 0, MA_ERR_INVALID_ARGUMENT,
                "output bitmap must be 8-byte aligned (got %p)", (const void*)out_mask);
-    auto device_of = [](const void* p) -> int {  // -1: not device memory
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return -1;
-        }
-        return attr.type == hipMemoryTypeDevice ? attr.device : -1;
-    };
+    DeviceLookup lookup;
+    auto device_of = [&](const void* p) { return lookup.device_of(p); };
     MA_REQUIRE(device_of(out_data) == dest->device, MA_ERR_INVALID_ARGUMENT,
                "out_data must be device memory of member %d (device %d)", dest_member, dest->device);
     MA_REQUIRE(!has_mask || device_of(out_mask) == dest->device, MA_ERR_INVALID_ARGUMENT,
