@@ -99,11 +99,22 @@ def shared_worker(ctx, seed):
     counts.append(done)
 
 
+def heartbeat():  # a long silent run looks hung to the GPU pool's watchdog: say something every 30 s
+    t0 = time.time()
+    while time.time() - t0 < seconds + 30 and not stop_heartbeat.is_set():
+        stop_heartbeat.wait(30)
+        print(f"[{time.time() - t0:5.0f} s] running, {len(errors)} errors so far", flush=True)
+
+
+stop_heartbeat = threading.Event()
+hb = threading.Thread(target=heartbeat, daemon=True)
+hb.start()
 shared = Context(0)
 threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
 threads += [threading.Thread(target=shared_worker, args=(shared, s)) for s in range(4)]
 [t.start() for t in threads]
 [t.join() for t in threads]
+stop_heartbeat.set()
 shared.close()
 print(f"{sum(counts)} reductions checked on 4 private contexts (async, random grids) + 4 threads sharing one context "
       f"(synchronous sums, bitmap scans, elementwise + download: lanes + polled completion), {len(errors)} errors")
