@@ -4,11 +4,14 @@ column sums (configs[1]: "1B-row i64 and f64 sum/avg, null-free, 1 MI355X vs SIM
 
 A step = one pass of the hot path over one batch: ma_i64_sum over a 10^9-row IntegerArray<i64> column plus
 ma_f64_sum_dd over a 10^9-row FloatArray<f64> column (the two loops of benches/benchmark_parallel_simd.rs:99-125),
-both already resident in HBM. With N GPUs every rank owns its own 10^9-row chunk of a N x 10^9-row column
-(row-chunk partition, weak scaling) and the step ends with the exchange of the per-rank scalars over RCCL
-(all-gather of one 64-byte record per rank) and their rank-ordered fold on the GPU (ma_fold_sum_records: wrapping
-integer adds, error-free two-sum for the double-double pairs, so the f64 result stays within 1 ULP and every rank
-holds bit-identical finals).
+both already resident in HBM. With N GPUs the SAME 10^9-row columns are partitioned over the GPUs into 64-row-aligned
+row chunks (minarrow_amd.parallel.row_chunks — the reference's `slice.par_chunks(..)` over ONE slice,
+benches/benchmark_parallel_simd.rs:39,81-98): strong scaling, the form BASELINE's metric names ("1B-row i64/f64 sum at
+1/2/4/8 MI355X"); `--scaling weak` gives every GPU its own 10^9-row chunk of an N x 10^9-row column instead. Either way
+the step ends with the exchange of the per-rank scalars over RCCL (all-gather of one 64-byte record per rank) and their
+rank-ordered fold on the GPU (ma_fold_sum_records: wrapping integer adds, error-free two-sum for the double-double
+pairs, so the f64 result stays within 1 ULP and every rank holds bit-identical finals). At N > 1 the line also carries
+`n1_same_process` (the whole 10^9-row job on GPU 0 alone, same process, same steps) and `efficiency_vs_n1`.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus N ...            # ONE process drives N GPUs through ma_group_* (RCCL exchange, no torch)
@@ -419,30 +422,53 @@ class _Deadline:
         self.timer.cancel()
 
 
-def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallelism, exchange, extra_config=None):
-    rows = args.rows
+def _split(args, world):
+    """(scaling label, total rows per column, [(lo, hi)] per rank). strong: --rows rows in total, 64-row-aligned row
+    chunks; weak: --rows rows per GPU."""
+    from minarrow_amd.parallel import row_chunks
+
+    scaling = args.scaling or "strong"
+    if scaling == "strong":
+        return scaling, args.rows, row_chunks(args.rows, world)
+    return scaling, args.rows * world, [(r * args.rows, (r + 1) * args.rows) for r in range(world)]
+
+
+def _result_line(args, world, scaling, total_rows, rows_gpu0, elapsed, kernels, ok, finals, parallelism, exchange, extra_config=None):
+    """`kernels` were timed on GPU 0, whose launches scan `rows_gpu0` rows (the largest chunk of the partition)."""
     got_i, cnt_i, got_f, cnt_f = finals
-    total_rows = rows * world
+    value_rows = total_rows * 2 * args.steps
     exact_f = float(total_rows * (total_rows - 1) // 2)
     avg_i, avg_f = kernels["sum_i64"]["avg_ms"], kernels["sum_f64"]["avg_ms"]
-    bytes_per_launch = rows * 8  # algorithmic: 8 B/row, one launch scans `rows` rows
+    bytes_per_launch = rows_gpu0 * 8  # algorithmic: 8 B/row (SURVEY.md §8(d)), one launch scans GPU 0's chunk
     dom_name, dom_ms = ("ma::sum_kernel<double>", avg_f) if avg_f >= avg_i else ("ma::sum_kernel<int64>", avg_i)
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc.exists() and rows == 1_000_000_000:  # the counters were collected on the full-size workload only
+    if pmc.exists() and rows_gpu0 == 1_000_000_000:  # the counters were collected on the full-size workload only
         try:
             key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
             traffic = json.loads(pmc.read_text()).get(key)
         except Exception:
             traffic = None
     for kname, kk in kernels.items():
+        kk["rows_per_launch"] = rows_gpu0
         kk["gbps"] = bytes_per_launch / (kk["avg_ms"] * 1e-3) / 1e9
-        kk["grows_per_s"] = rows / (kk["avg_ms"] * 1e-3) / 1e9
+        kk["grows_per_s"] = rows_gpu0 / (kk["avg_ms"] * 1e-3) / 1e9
+    if world == 1:
+        workload = (f"{total_rows}-row IntegerArray<i64> sum + {total_rows}-row FloatArray<f64> sum, null-free, "
+                    f"HBM-resident (BASELINE configs[1])")
+    elif scaling == "strong":
+        workload = (f"{total_rows}-row IntegerArray<i64> sum + {total_rows}-row FloatArray<f64> sum, null-free, HBM-resident "
+                    f"(BASELINE configs[1]), each column PARTITIONED over {world} GPUs into 64-row-aligned row chunks of "
+                    f"<= {rows_gpu0} rows (par_chunks over one slice, benches/benchmark_parallel_simd.rs:81-88) + one "
+                    f"64-byte-record exchange per step")
+    else:
+        workload = (f"{args.rows}-row IntegerArray<i64> sum + {args.rows}-row FloatArray<f64> sum per GPU "
+                    f"({total_rows} rows per column over {world} GPUs), null-free, HBM-resident (BASELINE configs[1], weak form)")
     config = {
-        "workload": f"{rows}-row IntegerArray<i64> sum + {rows}-row FloatArray<f64> sum per GPU, null-free, "
-                    f"HBM-resident (BASELINE configs[1])",
-        "rows_per_gpu_per_column": rows,
+        "workload": workload,
+        "rows_total_per_column": total_rows,
+        "rows_per_gpu_per_column": rows_gpu0,
         "columns": ["i64", "f64"],
         "parallelism": parallelism,
         "exchange": exchange,
@@ -459,7 +485,7 @@ def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallel
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "i64+f64",
         "data": "synthetic",
@@ -485,6 +511,45 @@ def _result_line(args, world, value_rows, elapsed, kernels, ok, finals, parallel
                               if traffic is not None else None,
         },
     }
+
+
+def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
+    """The whole `total_rows`-row job on ONE GPU inside the same process, after the timed region (strong scaling at N > 1):
+    the columns are generated on this context's device, the same step (i64 scan + f64 scan + record fold) is timed over
+    the same number of steps with the wall clock, and the line gets `n1_same_process` + `efficiency_vs_n1` =
+    value(N) / (N x value(1))."""
+    cols = []
+    try:
+        col_i, col_f, rec, fin = ctx.alloc(total_rows * 8), ctx.alloc(total_rows * 8), ctx.alloc(64), ctx.alloc(64)
+        cols = [col_i, col_f, rec, fin]
+        ctx.set_async(True)
+        ctx.synth_iota("i64", col_i, total_rows, 0)
+        ctx.synth_iota("f64", col_f, total_rows, 0)
+        ctx.dev_memset(rec, 0, 64)
+
+        def step():
+            ctx.sum_into("i64", col_i, total_rows, out_sum=rec.ptr, out_count=rec.ptr + 8)
+            ctx.sum_into("f64", col_f, total_rows, out_sum=rec.ptr + 16, dd_lo=rec.ptr + 24, out_count=rec.ptr + 32)
+            ctx.fold_sum_records(rec.ptr, 1, 8, fin.ptr)
+
+        for _ in range(max(1, warmup)):
+            step()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        v1 = total_rows * 2 * steps / el / 1e9
+        line["n1_same_process"] = {"value": v1, "unit": "Grows/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+                                   "rows_per_column": total_rows, "gpu": 0}
+        line["efficiency_vs_n1"] = line["value"] / (line["n_gpus"] * v1)
+    except Exception as e:  # noqa: BLE001 — never at the expense of the headline
+        line["n1_same_process"] = {"error": f"{type(e).__name__}: {e}"}
+        line["efficiency_vs_n1"] = None
+    finally:
+        for b in cols:
+            b.free()
 
 
 def _check(total_rows, finals):
@@ -657,18 +722,20 @@ def run_group(args, result_fd) -> int:
     if n_dev < args.gpus:
         print(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible", file=sys.stderr)
         return 2
-    rows, world = args.rows, args.gpus
-    group = Group(list(range(world)), exchange="host" if args.exchange == "host" else "rccl-or-host")
+    world = args.gpus
+    scaling, total_rows, chunks = _split(args, world)
+    lens = [hi - lo for lo, hi in chunks]
+    group = Group(list(range(world)), exchange="host" if args.exchange == "host" else "rccl-or-host",
+                  issue="caller" if args.group_issue == "caller" else "threads")
     ctxs = [group.member_ctx(i) for i in range(world)]
     for c in ctxs:
         c.set_variant(args.variant)
         c.set_blocks_per_cu(args.blocks_per_cu)
-    cols_i = [c.alloc(rows * 8) for c in ctxs]
-    cols_f = [c.alloc(rows * 8) for c in ctxs]
-    for r, c in enumerate(ctxs):  # member r owns global rows [r*rows, (r+1)*rows); generation is enqueue-only too
-        c.synth_iota("i64", cols_i[r], rows, r * rows)
-        c.synth_iota("f64", cols_f[r], rows, r * rows)
-    lens = [rows] * world
+    cols_i = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
+    cols_f = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
+    for r, c in enumerate(ctxs):  # member r owns global rows [lo, hi) of the column; generation is enqueue-only too
+        c.synth_iota("i64", cols_i[r], lens[r], chunks[r][0])
+        c.synth_iota("f64", cols_f[r], lens[r], chunks[r][0])
 
     def step():
         group.enqueue_sum("i64", 0, cols_i, lens)
@@ -680,37 +747,51 @@ def run_group(args, result_fd) -> int:
     for _ in range(args.warmup):
         step()
     group.synchronize()
+    host_issue = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_issue = time.perf_counter() - t0  # the calling thread's time inside the enqueue calls (the GPUs are still busy)
     group.synchronize()
     elapsed = time.perf_counter() - t0
 
     finals = group.result(0)
-    total_rows = rows * world
     ok = _check(total_rows, finals) and all(group.result(0, m) == finals for m in range(world))
     # Kernel durations (outside the timed region): HIP events on member 0's stream around 5 launches of each scan.
     c0 = ctxs[0]
     slot = c0.alloc(64)
     kernels = {}
     for name, tag, col in (("sum_i64", "i64", cols_i[0]), ("sum_f64", "f64", cols_f[0])):
-        fn = (lambda: c0.sum_into("i64", col, rows, out_sum=slot.ptr, out_count=slot.ptr + 8)) if tag == "i64" else \
-            (lambda: c0.sum_into("f64", col, rows, out_sum=slot.ptr, dd_lo=slot.ptr + 8, out_count=slot.ptr + 16))
+        fn = (lambda: c0.sum_into("i64", col, lens[0], out_sum=slot.ptr, out_count=slot.ptr + 8)) if tag == "i64" else \
+            (lambda: c0.sum_into("f64", col, lens[0], out_sum=slot.ptr, dd_lo=slot.ptr + 8, out_count=slot.ptr + 16))
         ms = _timed(c0, fn, 5, 1)
         kernels[name] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
-    out = _result_line(args, world, total_rows * 2 * args.steps, elapsed, kernels, ok, finals,
-                       f"row-chunk x{world}, ONE process (ma_group_*)",
-                       ("RCCL all-gather (ncclCommInitAll, grouped) + device fold, on the scan streams"
+    out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
+                       f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
+                       ("RCCL all-gather (ncclCommInitAll; one call per member issue thread) + device fold, on the scan streams"
                         if group.exchange_kind == "rccl" else "host fold of pinned records") +
                        (f" [{group.exchange_note}]" if group.exchange_note else ""),
-                       {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process"})
+                       {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process",
+                        "host_issue_us_per_step": host_issue / args.steps * 1e6})
     rc = 0 if ok else 1
+    for b in cols_i + cols_f + [slot]:
+        b.free()
+    if (scaling == "strong" and world > 1) or args.force_group:
+        _n1_same_process(c0, total_rows, args.steps, args.warmup, out)
     if not args.no_other_configs:
         guard = _Deadline(args.other_seconds, result_fd, out, rc)
         try:
+            rows = args.other_rows or args.rows
+            cols_i = [c.alloc(rows * 8) for c in ctxs]
+            cols_f = [c.alloc(rows * 8) for c in ctxs]
+            for r, c in enumerate(ctxs):
+                c.synth_iota("i64", cols_i[r], rows, r * rows)
+                c.synth_iota("f64", cols_f[r], rows, r * rows)
             out["other_configs"] = group_other_configs(group, ctxs, cols_i, cols_f, rows, args.other_reps)
             if not out["other_configs"]["parity_ok"]:
                 rc = 1
+            for b in cols_i + cols_f:
+                b.free()
         except Exception as e:  # noqa: BLE001 — the headline line must still be printed
             out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
             rc = 1
@@ -718,13 +799,12 @@ def run_group(args, result_fd) -> int:
     _emit(result_fd, out)
     if not ok:
         print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
-    for b in cols_i + cols_f + [slot]:
-        b.free()
     group.close()
     return rc
 
 
-def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, reps: int, rank: int, world: int):
+def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, reps: int, rank: int, world: int,
+                        comm_stream=None):
     """The same two multi-GPU legs as group_other_configs with one process per GPU: every rank scans its chunk / its batch,
     ONE exchange per step (the library's communicator when there is one, torch.distributed's all-gather otherwise)."""
     from minarrow_amd.parallel import ScalarExchange, fold_dd, row_chunks
@@ -733,7 +813,13 @@ def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, re
     stream = torch.cuda.current_stream(dev)
 
     def exchange(ex):
-        if comm is not None:
+        if comm is not None and comm_stream is not None:  # the communicator's context enqueues on its own (side) stream
+            comm_stream.wait_stream(stream)
+            with torch.cuda.stream(comm_stream):
+                comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+            stream.wait_stream(comm_stream)
+            ex._folded_on_device = True
+        elif comm is not None:
             comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
             ex._folded_on_device = True
         else:
@@ -855,19 +941,31 @@ def run_ranks(args, result_fd) -> int:
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    rows = args.rows
+    scaling, total_rows, chunks = _split(args, world)
+    lo, hi = chunks[rank]
+    rows = hi - lo  # this rank's row chunk of each column
     stream = torch.cuda.current_stream(dev)
     ctx = Context(device_index, stream=stream.cuda_stream)
     ctx.set_variant(args.variant)
     ctx.set_blocks_per_cu(args.blocks_per_cu)
 
     # Columns resident in HBM before anything is timed (construction excluded, as in
-    # benches/benchmark_parallel_simd.rs:103-106). Rank r owns global rows [r*rows, (r+1)*rows).
-    col_i = torch.empty(rows, dtype=torch.int64, device=dev)
-    col_f = torch.empty(rows, dtype=torch.float64, device=dev)
-    ctx.synth_iota("i64", col_i, rows, rank * rows)
-    ctx.synth_iota("f64", col_f, rows, rank * rows)
+    # benches/benchmark_parallel_simd.rs:103-106). Rank r owns global rows [lo, hi) of each column.
+    col_i = torch.empty(max(rows, 8), dtype=torch.int64, device=dev)
+    col_f = torch.empty(max(rows, 8), dtype=torch.float64, device=dev)
+    ctx.synth_iota("i64", col_i, rows, lo)
+    ctx.synth_iota("f64", col_f, rows, lo)
 
+    # Per-rank record the kernels write into: [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits,
+    # [4] f64 count (minarrow_amd/parallel.py). Overlap: the exchange + fold of step k run on a side stream while the
+    # main stream already scans step k + 1 (two record sets in flight; a step's scans wait for the exchange that last
+    # used their record set). Default at N > 1: the partitioned column leaves each GPU 0.14 ms of scan per column, and
+    # an all-gather's latency is a fifth of that. With the native communicator the side stream is the communicator's
+    # context; with torch's exchange it is the stream torch.distributed's collective is issued under.
+    overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and not rehearsal and world > 1)
+    side = torch.cuda.Stream(dev) if overlap else stream
+    ctx_side = Context(device_index, stream=side.cuda_stream) if overlap else ctx
+    ctx_side.set_async(True)
     # The exchange. Native: the library's own RCCL communicator (ma_comm_*: ncclCommInitRank from an id rank 0 made and
     # torch.distributed's store carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up
     # on every rank (or --exchange torch) the same records go through torch.distributed's all-gather instead.
@@ -876,7 +974,7 @@ def run_ranks(args, result_fd) -> int:
         try:
             ids = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            comm = Comm(ctx, ids[0], rank, world)
+            comm = Comm(ctx_side, ids[0], rank, world)
         except Exception as e:  # noqa: BLE001 — any failure means the torch path
             comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
         flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
@@ -886,13 +984,6 @@ def run_ranks(args, result_fd) -> int:
             comm = None
             comm_note = "native communicator unavailable on another rank"
 
-    # Per-rank record the kernels write into: [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits,
-    # [4] f64 count (minarrow_amd/parallel.py). --overlap: the exchange + fold of step k run on a side stream while
-    # the main stream already scans step k + 1 (torch exchange only).
-    overlap = args.overlap and comm is None
-    side = torch.cuda.Stream(dev) if overlap else stream
-    ctx_side = Context(device_index, stream=side.cuda_stream) if overlap else ctx
-    ctx_side.set_async(True)
     exs = [ScalarExchange(dev) for _ in range(2 if overlap else 1)]
     scanned = [torch.cuda.Event() for _ in exs]
     exchanged = [torch.cuda.Event() for _ in exs]
@@ -914,17 +1005,21 @@ def run_ranks(args, result_fd) -> int:
         ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if ev:
             ev[2].record(stream)
-        if comm is not None:
-            comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
-            ex._folded_on_device = True
-        elif overlap:
+        if overlap:
             scanned[k].record(stream)
             with torch.cuda.stream(side):
                 side.wait_event(scanned[k])
-                ex.exchange()
-                ex.fold_on_device(ctx_side)
+                if comm is not None:  # bound to ctx_side: all-gather + fold are enqueued on the side stream
+                    comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
+                    ex._folded_on_device = True
+                else:
+                    ex.exchange()
+                    ex.fold_on_device(ctx_side)
                 exchanged[k].record(side)
             in_use[k] = True
+        elif comm is not None:
+            comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
+            ex._folded_on_device = True
         else:
             ex.exchange()  # N > 1: one all-gather of 64 bytes per rank; N = 1: nothing to exchange
             ex.fold_on_device(ctx)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
@@ -954,7 +1049,6 @@ def run_ranks(args, result_fd) -> int:
     torch.cuda.synchronize(dev)
 
     # ---- verify the job's answer (outside the timed region) ------------------------------------------
-    total_rows = rows * world
     finals = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
     ok = _check(total_rows, finals)
     ms_i = [e[0].elapsed_time(e[1]) for e in events]
@@ -972,19 +1066,31 @@ def run_ranks(args, result_fd) -> int:
             exchange = "gloo all-gather of the records over host memory + device fold"
         else:
             parallelism = f"row-chunk x{world}, one process per GPU"
-            exchange = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold, on the scan stream"
+            exchange = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
+                        ("" if overlap else ", on the scan stream")
                         if comm is not None else
-                        "RCCL all-gather (torch.distributed) + device fold, " +
-                        ("side stream, overlapped with the next step's scans" if overlap else "on the scan stream"))
+                        "RCCL all-gather (torch.distributed) + device fold" + ("" if overlap else ", on the scan stream"))
             if comm_note:
                 exchange += f" [{comm_note}]"
-        out = _result_line(args, world, total_rows * 2 * args.steps, elapsed, kernels, ok, finals, parallelism, exchange,
+        if overlap:
+            exchange += "; exchange of step k on a side stream, overlapped with the scans of step k + 1"
+        out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exchange,
                            {"rccl_ranks": world if (distributed and not rehearsal) else 0,
                             "launch": "torch.distributed.run" if world > 1 else "single process"})
+        if (scaling == "strong" and world > 1) or args.force_dist:
+            _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
     if distributed and not rehearsal and not args.no_other_configs:
         guard = _Deadline(args.other_seconds, result_fd, out, rc)  # every rank: none may outlive a hung collective
         try:  # every rank takes part (collectives inside); rank 0 prints
-            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows, args.other_reps, rank, world)
+            orows = args.other_rows or args.rows  # these legs are per-GPU sized (one chunk / batch of `orows` rows per GPU)
+            del col_i, col_f
+            torch.cuda.empty_cache()
+            col_i = torch.empty(orows, dtype=torch.int64, device=dev)
+            col_f = torch.empty(orows, dtype=torch.float64, device=dev)
+            ctx.synth_iota("i64", col_i, orows, rank * orows)
+            ctx.synth_iota("f64", col_f, orows, rank * orows)
+            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, orows, args.other_reps, rank, world,
+                                        comm_stream=side if overlap else None)
             if not multi["parity_ok"]:
                 rc = 1
         except Exception as e:  # noqa: BLE001 — the headline line must still be printed
@@ -1000,7 +1106,7 @@ def run_ranks(args, result_fd) -> int:
             if not args.no_other_configs:
                 try:
                     ctx.set_async(False)
-                    out["other_configs"] = gpu_other_configs(ctx, args.other_rows or rows, args.other_reps)
+                    out["other_configs"] = gpu_other_configs(ctx, args.other_rows or args.rows, args.other_reps)
                     parities = [v for v in _walk(out["other_configs"], "parity")]
                     out["other_configs"]["parity_ok"] = all(parities)
                     if not all(parities):
@@ -1041,7 +1147,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU per column")
+    ap.add_argument("--rows", type=int, default=1_000_000_000,
+                    help="rows per column: in total with --scaling strong (the default), per GPU with --scaling weak")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the --rows-row columns are partitioned over the GPUs into row chunks — the "
+                         "metric as BASELINE names it; weak = every GPU scans its own --rows rows")
+    ap.add_argument("--group-issue", default="threads", choices=["threads", "caller"],
+                    help="one-process mode: per-member issue threads (default) or the calling thread issues for every GPU")
     ap.add_argument("--cpu-rows", type=int, default=1 << 29, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1058,9 +1170,10 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
-    ap.add_argument("--overlap", action="store_true",
-                    help="torch exchange only: run each step's scalar exchange on a side stream, overlapped with the next "
-                         "step's scans (off by default: at N = 1 it costs the scan more than it saves, 876 vs 889 Grows/s)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
+                    help="one process per GPU: run each step's scalar exchange on a side stream, overlapped with the next "
+                         "step's scans. auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
+                         "it costs the scan more than it saves there, 876 vs 889 Grows/s)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",

@@ -46,7 +46,10 @@
 extern "C" {
 #endif
 
-#define MA_ABI_VERSION 1
+/* 2 (round 3): + ma_ctx_hip_device, ma_pointer_device, ma_group_issue_kind, ma_group_peer_access; ma_ctx_device now
+ * returns the LIBRARY ordinal (round-trip safe through ma_ctx_create); group calls are issued by per-member threads.
+ * A binding compares ma_abi_version() with the MA_ABI_VERSION it was generated from. */
+#define MA_ABI_VERSION 2
 
 typedef struct ma_ctx ma_ctx;
 typedef int32_t ma_status;
@@ -100,7 +103,10 @@ void ma_ctx_destroy(ma_ctx* ctx);
 ma_status ma_ctx_synchronize(ma_ctx* ctx);
 ma_status ma_ctx_set_async(ma_ctx* ctx, int32_t enabled);
 void* ma_ctx_stream(ma_ctx* ctx);
+/* The context's device as the LIBRARY ordinal (an index into the MINARROW_HIP_DEVICES list — the number ma_ctx_create and
+ * ma_group_create take, so it round-trips), and as the HIP runtime's own ordinal (what hipSetDevice takes). */
 int32_t ma_ctx_device(ma_ctx* ctx);
+int32_t ma_ctx_hip_device(ma_ctx* ctx);
 int32_t ma_ctx_compute_units(ma_ctx* ctx);
 /* Lanes the context has grown so far, itself included (1 until two synchronous calls overlap; at most MINARROW_HIP_LANES). */
 int32_t ma_ctx_lane_count(ma_ctx* ctx);
@@ -190,6 +196,9 @@ ma_status ma_dev_memset(ma_ctx* ctx, void* dst_dev, int32_t byte_value, size_t b
 ma_status ma_dev_copy(ma_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 /* 0 = pageable host, 1 = pinned/registered host, 2 = device, 3 = managed. */
 int32_t ma_pointer_kind(const void* ptr);
+/* The HIP ordinal of the device whose memory `ptr` points into; -1 for host memory (pageable or pinned), NULL and
+ * pointers the runtime does not know. The residency rule of the ma_group_* calls is stated in terms of it. */
+int32_t ma_pointer_device(const void* ptr);
 
 /* ------------------------------------------------------------------------------------------------
  * Synthetic inputs generated in place on the device (patterns of
@@ -775,10 +784,23 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  * (any may be NULL). ma_group_member_result reads the finals GPU `member` holds (identical on all members).
  * ma_group_sum_i64 / _f64 are the synchronous one-call forms on column 0. The member contexts (ma_group_ctx: use them
  * to allocate and fill each device's chunk) stay in async mode for the life of the group.
+ *
+ * Who issues: every member has a persistent issue thread (the reference's Rayon pool issues from all cores,
+ * benches/benchmark_parallel_simd.rs:83-87). A group call validates on the calling thread, the members' threads enqueue
+ * their own launches concurrently (own device, own stream, own RCCL rank — no ncclGroup needed), and the call returns
+ * when every member has enqueued: host time per call is ONE member's launches plus a hand-off, not the sum over the
+ * members. MA_GROUP_ISSUE_CALLER (or MINARROW_HIP_GROUP_ISSUE=caller) keeps everything on the calling thread.
+ *
+ * Residency: chunk i is dereferenced by member i's kernels, so its data and validity must be resident on that member's
+ * device (ma_pointer_device(ptr) == ma_ctx_hip_device(ma_group_ctx(group, i))) or be host memory; a pointer into
+ * another GPU's memory is MA_ERR_INVALID_ARGUMENT before anything is enqueued. Peer capability between the members'
+ * devices is probed (hipDeviceCanAccessPeer) and enabled once at creation — ma_group_peer_access, summarised in
+ * ma_group_exchange_note — and ma_group_consolidate_column returns MA_ERR_UNSUPPORTED for an owner -> destination pair
+ * without it.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ma_group ma_group;
 #define MA_GROUP_MAX_COLUMNS 16
-enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2 };
+enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2, MA_GROUP_ISSUE_CALLER = 4 };
 ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
 ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group);
 void ma_group_destroy(ma_group* group);
@@ -786,7 +808,18 @@ int32_t ma_group_size(ma_group* group);
 ma_ctx* ma_group_ctx(ma_group* group, int32_t index);
 /* 1 = RCCL all-gather + device fold, 0 = host fold. */
 int32_t ma_group_exchange_kind(ma_group* group);
+/* Why the exchange is not the one asked for (if so), the peer-access summary, who issues. Never NULL. */
 const char* ma_group_exchange_note(ma_group* group);
+/* 1 = one issue thread per member, 0 = the calling thread issues for every member. */
+int32_t ma_group_issue_kind(ma_group* group);
+/* 1 when member from_member's device can address member to_member's device memory (same device, or peer access probed
+ * and enabled at creation), 0 when not, -1 for a bad argument. */
+int32_t ma_group_peer_access(ma_group* group, int32_t from_member, int32_t to_member);
+/* TESTING ONLY. Makes the residency and peer checks treat `member` as if its device were HIP device `hip_device`, with
+ * (peer_capable != 0) or without peer access between it and every other member; nothing is launched differently. Lets a
+ * one-GPU box exercise the refusals a multi-GPU node produces (a chunk resident on the wrong GPU, an owner without a
+ * link to the destination). */
+ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable);
 ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets);

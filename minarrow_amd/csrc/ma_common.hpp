@@ -70,7 +70,8 @@ ma_status hip_fail(hipError_t e, const char* what, const char* file, int line);
     } while (0)
 
 struct ma_ctx {
-    int device = 0;
+    int device = 0;    // HIP runtime ordinal (hipSetDevice)
+    int ordinal = 0;   // library ordinal: index into the MINARROW_HIP_DEVICES list (what ma_ctx_create took)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::atomic<bool> async{false};      // read without the lock by ma::Enter (may a busy context fan out?)

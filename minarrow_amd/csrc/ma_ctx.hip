@@ -717,13 +717,27 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         set_error("no HIP device is visible; libminarrow_hip has no CPU fallback");
         return MA_ERR_NO_DEVICE;
     }
+    int ordinal = device;
     if (map_ordinal) {
         MA_REQUIRE(device >= 0 && device < n, MA_ERR_INVALID_ARGUMENT, "device ordinal %d out of range [0,%d)", device, n);
         device = device_map()[(size_t)device];  // MINARROW_HIP_DEVICES
+    } else {
+        ordinal = -1;  // a lane: inherits its root's ordinal (make_lane)
+    }
+    if (borrow && stream != nullptr) {
+        // a borrowed stream belongs to whatever device it was made on: it must be the one the ordinal names
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess)
+            MA_REQUIRE((int)sdev == device, MA_ERR_INVALID_ARGUMENT,
+                       "the stream lives on HIP device %d but device ordinal %d is HIP device %d (MINARROW_HIP_DEVICES remaps "
+                       "ordinals)", (int)sdev, ordinal, device);
+        else
+            (void)hipGetLastError();
     }
     MA_HIP(hipSetDevice(device));
     ma_ctx* c = new ma_ctx();
     c->device = device;
+    c->ordinal = ordinal;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -778,6 +792,7 @@ ma_status make_lane(ma_ctx* root, ma_ctx** out) {
     ma_status st = ctx_create_impl(root->device, nullptr, false, out, false);  // root->device is already a HIP ordinal
     if (st == MA_OK) {
         (*out)->parent = root;
+        (*out)->ordinal = root->ordinal;
         (*out)->max_lanes = 1;
     }
     (void)hipSetDevice(prev);
@@ -918,7 +933,8 @@ void ma_graph_destroy(ma_graph* graph) {
 }
 
 void* ma_ctx_stream(ma_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-int32_t ma_ctx_device(ma_ctx* ctx) { return ctx ? ctx->device : -1; }
+int32_t ma_ctx_device(ma_ctx* ctx) { return ctx ? ctx->ordinal : -1; }
+int32_t ma_ctx_hip_device(ma_ctx* ctx) { return ctx ? ctx->device : -1; }
 int32_t ma_ctx_compute_units(ma_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
 int32_t ma_ctx_lane_count(ma_ctx* ctx) {
     if (!ctx) return 0;
@@ -1294,6 +1310,16 @@ ma_status ma_dev_copy(ma_ctx* ctx, void* dst_dev, const void* src_dev, size_t by
 int32_t ma_pointer_kind(const void* ptr) {
     if (ma_device_count() <= 0) return kPageable;
     return (int32_t)pointer_kind(ptr);
+}
+
+int32_t ma_pointer_device(const void* ptr) {
+    if (ptr == nullptr || ma_device_count() <= 0) return -1;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return attr.type == hipMemoryTypeDevice ? attr.device : -1;
 }
 
 // ---- synthetic inputs -------------------------------------------------------------------------

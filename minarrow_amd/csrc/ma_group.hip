@@ -13,7 +13,25 @@
 //         G x 64 bytes after the streams drain — no collective is needed inside one process.
 //
 // The multi-PROCESS form of the same exchange is ma_comm_sum_exchange (ma_rccl.hip).
+//
+// Who issues. The reference's Rayon pool issues from all cores (benches/benchmark_parallel_simd.rs:83-87). One host
+// thread issuing for 8 GPUs is launch-bound below ~0.25 ms per step (3 launches x 8 members x ~6-8 us each) — exactly the
+// step a 10^9-row column partitioned over 8 GPUs has (0.14 ms of scan per GPU per column). Every member therefore has a
+// persistent ISSUE THREAD (round 3): a group entry point validates its arguments on the calling thread, hands one job to
+// all members' threads, each thread enqueues its member's launches (its own hipSetDevice, its own stream, its own RCCL
+// communicator — the "one thread per device" form RCCL supports without ncclGroupStart/End), and the call returns when
+// every member has ENQUEUED — so the semantics of round 2 hold (work is on the streams when the call returns, launch
+// errors are returned by the call) while the host cost per call is that of ONE member's launches plus a hand-off.
+// Threads spin for ~200 us after a job (a stepping host never pays a wake-up) and then sleep on a condition variable.
+// MA_GROUP_ISSUE_CALLER / MINARROW_HIP_GROUP_ISSUE=caller keeps the round-2 form (the calling thread loops over the
+// members; the all-gathers inside one ncclGroupStart/End) for A/B measurements and as a fallback.
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <functional>
+#include <map>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "ma_rccl.hpp"
@@ -21,6 +39,28 @@
 struct ma_group {
     std::vector<ma_ctx*> ctxs;
     std::mutex mu;
+    // ---- per-member issue threads (see the header comment). One job at a time, posted under `mu`.
+    bool threads = false;
+    std::vector<std::thread> workers;
+    const std::function<ma_status(size_t)>* job = nullptr;
+    std::atomic<uint64_t> job_seq{0};
+    struct alignas(64) Slot {
+        std::atomic<uint64_t> done{0};
+        ma_status status = MA_OK;
+        std::string message;
+    };
+    std::vector<Slot> slots;
+    std::mutex sleep_mu;
+    std::condition_variable work_cv, done_cv;
+    std::atomic<int> sleepers{0};
+    std::atomic<int> caller_waiting{0};
+    std::atomic<bool> stop{false};
+    // peer[i * G + j]: member i's device can address member j's device memory (same device, or hipDeviceCanAccessPeer and
+    // enabled at creation). Probed once; ma_group_consolidate_column refuses pairs that are not.
+    std::vector<uint8_t> peer;
+    // The HIP device a member's chunks must be resident on: its context's device (ma_group_test_set_member_device
+    // overrides it so that the refusal paths can be exercised on a one-GPU box).
+    std::vector<int> home;
     bool use_rccl = false;
     std::vector<ncclComm_t> comms;
     // RCCL: per member a device block of kColumns records (`local`), a device block of G x kColumns gathered records
@@ -32,7 +72,7 @@ struct ma_group {
     // gathered into before the bit-granular join (re-used across calls in stream order)
     std::vector<void*> mask_stage;
     std::vector<size_t> mask_stage_bytes;
-    char note[256] = "";
+    char note[512] = "";
 };
 
 using namespace ma;
@@ -95,6 +135,8 @@ class DeviceLookup {
     std::vector<Seen> seen_;
 };
 
+void stop_workers(ma_group* g);
+
 // Frees the exchange's buffers and communicators (either kind); the members stay.
 void release_exchange(ma_group* g) {
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
@@ -124,6 +166,7 @@ void release_exchange(ma_group* g) {
 }
 
 void destroy_members(ma_group* g) {
+    stop_workers(g);
     release_exchange(g);  // drains every member's stream first
     for (size_t i = 0; i < g->mask_stage.size() && i < g->ctxs.size(); ++i)
         if (g->mask_stage[i]) {
@@ -178,16 +221,124 @@ ma_status setup_host(ma_group* g) {
     return MA_OK;
 }
 
-template <typename Launch>
-ma_status enqueue_members(ma_group* g, int32_t column, Launch launch) {
+// ---- issue threads ------------------------------------------------------------------------------------------------
+
+void worker_main(ma_group* g, size_t i) {
+    (void)hipSetDevice(g->ctxs[i]->device);
+    uint64_t seen = 0;
+    for (;;) {
+        // wait for job `seen + 1`: spin for ~200 us (a stepping host never pays a wake-up), then sleep
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (g->job_seq.load(std::memory_order_acquire) == seen && !g->stop.load(std::memory_order_acquire)) {
+            __builtin_ia32_pause();
+            if ((++spins & 255) == 0 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= 200) {
+                std::unique_lock<std::mutex> lock(g->sleep_mu);
+                g->sleepers.fetch_add(1);
+                g->work_cv.wait(lock, [&] { return g->job_seq.load() != seen || g->stop.load(); });
+                g->sleepers.fetch_sub(1);
+            }
+        }
+        if (g->job_seq.load(std::memory_order_acquire) == seen) return;  // stop, nothing posted
+        ++seen;
+        ma_group::Slot& slot = g->slots[i];
+        slot.status = (*g->job)(i);
+        if (slot.status != MA_OK) slot.message = ma_last_error_string();
+        slot.done.store(seen, std::memory_order_release);
+        if (g->caller_waiting.load() != 0) {
+            { std::lock_guard<std::mutex> lock(g->sleep_mu); }
+            g->done_cv.notify_all();
+        }
+    }
+}
+
+void start_workers(ma_group* g) {
+    const size_t n = g->ctxs.size();
+    g->slots = std::vector<ma_group::Slot>(n);
+    g->workers.reserve(n);
+    for (size_t i = 0; i < n; ++i) g->workers.emplace_back(worker_main, g, i);
+    g->threads = true;
+}
+
+void stop_workers(ma_group* g) {
+    if (!g->threads) return;
+    g->stop.store(true, std::memory_order_release);
+    { std::lock_guard<std::mutex> lock(g->sleep_mu); }
+    g->work_cv.notify_all();
+    for (std::thread& t : g->workers)
+        if (t.joinable()) t.join();
+    g->workers.clear();
+    g->threads = false;
+}
+
+// Runs fn(member) for every member — on the members' issue threads, concurrently, or in a loop on the calling thread — and
+// returns once all have returned: the first failing member's status, its message in the CALLER's error string.
+// The caller holds g->mu (one job at a time; two calling threads post their collectives in one order to all members).
+ma_status run_on_members(ma_group* g, const std::function<ma_status(size_t)>& fn) {
+    const size_t n = g->ctxs.size();
+    if (!g->threads) {
+        for (size_t i = 0; i < n; ++i) MA_TRY(fn(i));
+        return MA_OK;
+    }
+    g->job = &fn;
+    const uint64_t seq = g->job_seq.fetch_add(1, std::memory_order_acq_rel) + 1;
+    if (g->sleepers.load() != 0) {
+        { std::lock_guard<std::mutex> lock(g->sleep_mu); }
+        g->work_cv.notify_all();
+    }
+    auto all_done = [&] {
+        for (size_t i = 0; i < n; ++i)
+            if (g->slots[i].done.load(std::memory_order_acquire) != seq) return false;
+        return true;
+    };
+    // launches take microseconds, a synchronise takes milliseconds: spin briefly, then block
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (!all_done()) {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= 100) {
+            std::unique_lock<std::mutex> lock(g->sleep_mu);
+            g->caller_waiting.store(1);
+            g->done_cv.wait(lock, all_done);
+            g->caller_waiting.store(0);
+        }
+    }
+    g->job = nullptr;
+    for (size_t i = 0; i < n; ++i)
+        if (g->slots[i].status != MA_OK) {
+            set_error("%s", g->slots[i].message.c_str());
+            return g->slots[i].status;
+        }
+    return MA_OK;
+}
+
+// A chunk handed to member `member` must be resident on that member's device, or be host memory the device can
+// address: the kernels dereference it directly, and on a multi-GPU node a pointer into another GPU's HBM is a memory
+// fault, not a status. (one row chunk per GPU.)
+ma_status require_resident(ma_group* g, DeviceLookup& lookup, size_t member, const void* p, const char* what, size_t chunk) {
+    if (p == nullptr) return MA_OK;
+    const int want = g->home[member];
+    const int dev = lookup.device_of(p);
+    MA_REQUIRE(dev < 0 || dev == want, MA_ERR_INVALID_ARGUMENT,
+               "chunk %zu belongs to member %zu (device %d) but its %s is resident on device %d", chunk, member, want, what, dev);
+    return MA_OK;
+}
+
+ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* chunk_data, const size_t* chunk_lens,
+                              const uint8_t* const* chunk_masks, const std::function<ma_status(size_t, uint64_t*)>& launch) {
     MA_REQUIRE(g != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
     std::lock_guard<std::mutex> lock(g->mu);
+    DeviceLookup lookup;
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
-        uint64_t* rec = g->local[i] + (size_t)column * kRecordWords;
-        MA_TRY(launch(i, rec));  // enqueue only (the members are in async mode): all devices run concurrently
+        if (chunk_lens[i] == 0) continue;
+        MA_TRY(require_resident(g, lookup, i, chunk_data[i], "data", i));
+        if (chunk_masks) MA_TRY(require_resident(g, lookup, i, chunk_masks[i], "validity bitmap", i));
     }
-    return MA_OK;
+    // enqueue only (the members are in async mode): all devices run concurrently
+    return run_on_members(g, [&](size_t i) { return launch(i, g->local[i] + (size_t)column * kRecordWords); });
 }
 
 ma_status exchange_locked(ma_group* g) {
@@ -195,6 +346,18 @@ ma_status exchange_locked(ma_group* g) {
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     const size_t n = g->ctxs.size();
+    auto fold = [g, n](size_t i) -> ma_status {
+        ma_ctx* c = g->ctxs[i];
+        std::lock_guard<std::mutex> lock(c->mu);
+        MA_HIP(hipSetDevice(c->device));
+        return enqueue_fold_columns(c, g->gathered[i], n, kBlockWords, kColumns, g->finals[i]);
+    };
+    if (g->threads)  // one thread per device: each issues its own rank's all-gather, no ncclGroup needed
+        return run_on_members(g, [&](size_t i) -> ma_status {
+            MA_HIP(hipSetDevice(g->ctxs[i]->device));
+            MA_NCCL(api, AllGather(g->local[i], g->gathered[i], kBlockWords * 8, ncclChar, g->comms[i], g->ctxs[i]->stream));
+            return fold(i);
+        });
     MA_NCCL(api, GroupStart());
     for (size_t i = 0; i < n; ++i) {
         ncclResult_t r = api->AllGather(g->local[i], g->gathered[i], kBlockWords * 8, ncclChar, g->comms[i], g->ctxs[i]->stream);
@@ -204,22 +367,24 @@ ma_status exchange_locked(ma_group* g) {
         }
     }
     MA_NCCL(api, GroupEnd());
-    for (size_t i = 0; i < n; ++i) {
-        ma_ctx* c = g->ctxs[i];
-        std::lock_guard<std::mutex> lock(c->mu);
-        MA_HIP(hipSetDevice(c->device));
-        MA_TRY(enqueue_fold_columns(c, g->gathered[i], n, kBlockWords, kColumns, g->finals[i]));
-    }
+    for (size_t i = 0; i < n; ++i) MA_TRY(fold(i));
     return MA_OK;
 }
 
 ma_status synchronize_locked(ma_group* g) {
-    ma_status st = MA_OK;
-    for (ma_ctx* c : g->ctxs) {
-        ma_status s = ma_ctx_synchronize(c);
-        if (st == MA_OK) st = s;
-    }
-    MA_TRY(st);
+    // every member is waited for even when one reports (a latched division by zero is cleared by its report)
+    std::vector<ma_status> st(g->ctxs.size(), MA_OK);
+    std::vector<std::string> msg(g->ctxs.size());
+    (void)run_on_members(g, [&](size_t i) -> ma_status {
+        st[i] = ma_ctx_synchronize(g->ctxs[i]);
+        if (st[i] != MA_OK) msg[i] = ma_last_error_string();
+        return MA_OK;
+    });
+    for (size_t i = 0; i < st.size(); ++i)
+        if (st[i] != MA_OK) {
+            set_error("%s", msg[i].c_str());
+            return st[i];
+        }
     if (!g->use_rccl) {
         for (int col = 0; col < kColumns; ++col) {
             HostFoldDD f;
@@ -233,6 +398,47 @@ ma_status synchronize_locked(ma_group* g) {
         }
     }
     return MA_OK;
+}
+
+// Peer capability between the members' devices, probed (and enabled) once. Returns how many ordered pairs of DISTINCT
+// devices there are and how many of them are peer-capable; the pairs that are not are listed in `missing`.
+void probe_peers(ma_group* g, int* out_pairs, int* out_capable, std::string* missing) {
+    const size_t n = g->ctxs.size();
+    g->peer.assign(n * n, 0);
+    std::map<std::pair<int, int>, uint8_t> answered;
+    int pairs = 0, capable = 0;
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            const int di = g->ctxs[i]->device, dj = g->ctxs[j]->device;
+            if (di == dj) {
+                g->peer[i * n + j] = 1;
+                continue;
+            }
+            auto it = answered.find({di, dj});  // several members may share a device
+            if (it != answered.end()) {
+                g->peer[i * n + j] = it->second;
+                continue;
+            }
+            ++pairs;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, di, dj) != hipSuccess) {
+                (void)hipGetLastError();
+                can = 0;
+            }
+            if (can) {
+                hipError_t e = hipSetDevice(di);
+                if (e == hipSuccess) e = hipDeviceEnablePeerAccess(dj, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+                (void)hipGetLastError();
+                can = e == hipSuccess ? 1 : 0;
+            }
+            g->peer[i * n + j] = (uint8_t)can;
+            answered[{di, dj}] = (uint8_t)can;
+            if (can) ++capable;
+            else if (missing->size() < 160) *missing += (missing->empty() ? "" : ",") + std::to_string(di) + "->" + std::to_string(dj);
+        }
+    *out_pairs = pairs;
+    *out_capable = capable;
 }
 
 const uint64_t* finals_of(const ma_group* g, size_t member, int32_t column) {
@@ -262,11 +468,17 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
         }
         g->ctxs.push_back(c);
     }
+    for (ma_ctx* c : g->ctxs) g->home.push_back(c->device);
+    // Peer capability first (RCCL enables the same pairs itself and tolerates "already enabled").
+    int pairs = 0, capable = 0;
+    std::string missing;
+    probe_peers(g, &pairs, &capable, &missing);
     ma_status st = MA_OK;
+    char why[256] = "";
     if (flags & MA_GROUP_EXCHANGE_RCCL) {
         st = setup_rccl(g);
         if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
-            snprintf(g->note, sizeof(g->note), "host fold instead of RCCL: %s", ma_last_error_string());
+            snprintf(why, sizeof(why), "host fold instead of RCCL: %s", ma_last_error_string());
             release_exchange(g);  // whatever the attempt allocated; the members stay
             st = setup_host(g);
         }
@@ -278,6 +490,23 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
         delete g;
         return st;
     }
+    // Issue threads unless the caller (flag) or the environment asks for the calling-thread loop.
+    const char* issue = getenv("MINARROW_HIP_GROUP_ISSUE");
+    bool threads = (flags & MA_GROUP_ISSUE_CALLER) == 0;
+    if (issue && strcmp(issue, "caller") == 0) threads = false;
+    if (issue && strcmp(issue, "threads") == 0) threads = true;
+    if (threads) start_workers(g);
+    // the note: why the exchange is what it is (if it is not what was asked for), then the peer matrix
+    char peers[320];
+    if (pairs == 0)
+        snprintf(peers, sizeof(peers), "peer access: n/a (one device)");
+    else if (capable == pairs)
+        snprintf(peers, sizeof(peers), "peer access: %d/%d ordered device pairs", capable, pairs);
+    else
+        snprintf(peers, sizeof(peers), "peer access: %d/%d ordered device pairs (not peer-capable: %s)", capable, pairs,
+                 missing.c_str());
+    snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s", why, why[0] ? "; " : "", peers,
+             g->threads ? "one thread per member" : "calling thread");
     *out_group = g;
     return MA_OK;
 }
@@ -303,13 +532,34 @@ ma_ctx* ma_group_ctx(ma_group* group, int32_t index) {
 }
 
 int32_t ma_group_exchange_kind(ma_group* group) { return group && group->use_rccl ? 1 : 0; }
+int32_t ma_group_issue_kind(ma_group* group) { return group && group->threads ? 1 : 0; }
+int32_t ma_group_peer_access(ma_group* group, int32_t from_member, int32_t to_member) {
+    if (!group) return -1;
+    const size_t G = group->ctxs.size();
+    if (from_member < 0 || to_member < 0 || (size_t)from_member >= G || (size_t)to_member >= G) return -1;
+    return group->peer[(size_t)from_member * G + (size_t)to_member] ? 1 : 0;
+}
 const char* ma_group_exchange_note(ma_group* group) { return group ? group->note : ""; }
+
+ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::mutex> lock(group->mu);
+    const size_t G = group->ctxs.size();
+    MA_REQUIRE(member >= 0 && (size_t)member < G, MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
+    group->home[(size_t)member] = hip_device;
+    for (size_t j = 0; j < G; ++j) {
+        if (j == (size_t)member) continue;
+        const uint8_t can = peer_capable ? 1 : 0;
+        group->peer[(size_t)member * G + j] = group->peer[j * G + (size_t)member] = can;
+    }
+    return MA_OK;
+}
 
 ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets) {
     MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    return enqueue_members(group, column, [&](size_t i, uint64_t* rec) {
+    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, uint64_t* rec) {
         return ma_i64_sum(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
                           chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (int64_t*)&rec[0], &rec[1]);
     });
@@ -319,7 +569,7 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets) {
     MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    return enqueue_members(group, column, [&](size_t i, uint64_t* rec) {
+    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, uint64_t* rec) {
         return ma_f64_sum_dd(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
                              chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (double*)&rec[2], (double*)&rec[3], &rec[4]);
     });
@@ -351,8 +601,9 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
     auto device_of = [&](const void* p) { return lookup.device_of(p); };
     for (size_t i = 0; i < n_chunks; ++i) {
         if (lhs_lens[i] == 0) continue;
-        const int want = group->ctxs[i % G]->device;
-        const void* ptrs[3] = {lhs_data[i], rhs_data[i], out_data[i]};
+        const int want = group->home[i % G];
+        const void* ptrs[6] = {lhs_data[i], rhs_data[i], out_data[i], lhs_masks ? lhs_masks[i] : nullptr,
+                               rhs_masks ? rhs_masks[i] : nullptr, out_masks ? out_masks[i] : nullptr};
         for (const void* p : ptrs) {
             const int dev = device_of(p);
             MA_REQUIRE(dev < 0 || dev == want, MA_ERR_INVALID_ARGUMENT,
@@ -360,14 +611,18 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
                        want, dev);
         }
     }
-    std::vector<const void*> l, r;
-    std::vector<void*> o;
-    std::vector<const uint8_t*> lm, rm;
-    std::vector<uint8_t*> om;
-    std::vector<size_t> ll, rl;
-    std::vector<int32_t> has;
-    for (size_t m = 0; m < G && m < n_chunks; ++m) {
-        l.clear(); r.clear(); o.clear(); lm.clear(); rm.clear(); om.clear(); ll.clear(); rl.clear();
+    // every member gathers its own chunk pairs (i, i + G, ...) and issues its ONE launch — descriptor table included —
+    // on its own thread: the table of a RechunkStrategy-sized column (10^5 pairs) is built G-way parallel
+    return run_on_members(group, [&](size_t m) -> ma_status {
+        if (m >= n_chunks) return MA_OK;
+        std::vector<const void*> l, r;
+        std::vector<void*> o;
+        std::vector<const uint8_t*> lm, rm;
+        std::vector<uint8_t*> om;
+        std::vector<size_t> ll, rl;
+        const size_t mine = (n_chunks - m + G - 1) / G;
+        l.reserve(mine); r.reserve(mine); o.reserve(mine); lm.reserve(mine); rm.reserve(mine); om.reserve(mine);
+        ll.reserve(mine); rl.reserve(mine);
         for (size_t i = m; i < n_chunks; i += G) {
             l.push_back(lhs_data[i]);
             r.push_back(rhs_data[i]);
@@ -378,14 +633,14 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
             rm.push_back(rhs_masks ? rhs_masks[i] : nullptr);
             om.push_back(out_masks ? out_masks[i] : nullptr);
         }
-        has.assign(l.size(), 0);
+        std::vector<int32_t> has(l.size(), 0);
         MA_TRY(ma_route_super_array_broadcast(group->ctxs[m], format_code, op, l.size(), l.data(), ll.data(), lm.data(), r.data(),
                                               rl.data(), rm.data(), member_mask_overrides ? member_mask_overrides[m] : nullptr,
                                               o.data(), om.data(), has.data()));
         if (out_has_mask)
             for (size_t j = 0; j < has.size(); ++j) out_has_mask[m + j * G] = has[j];
-    }
-    return MA_OK;
+        return MA_OK;
+    });
 }
 
 // SuperTable::consolidate for a column whose batches live on different GPUs (src/structs/chunked/super_table.rs:657-743,
@@ -424,17 +679,24 @@ ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size
                "output bitmap must be 8-byte aligned (got %p)", (const void*)out_mask);
     DeviceLookup lookup;
     auto device_of = [&](const void* p) { return lookup.device_of(p); };
-    MA_REQUIRE(device_of(out_data) == dest->device, MA_ERR_INVALID_ARGUMENT,
-               "out_data must be device memory of member %d (device %d)", dest_member, dest->device);
-    MA_REQUIRE(!has_mask || device_of(out_mask) == dest->device, MA_ERR_INVALID_ARGUMENT,
-               "out_mask must be device memory of member %d (device %d)", dest_member, dest->device);
+    const int dest_home = group->home[(size_t)dest_member];
+    MA_REQUIRE(device_of(out_data) == dest_home, MA_ERR_INVALID_ARGUMENT,
+               "out_data must be device memory of member %d (device %d)", dest_member, dest_home);
+    MA_REQUIRE(!has_mask || device_of(out_mask) == dest_home, MA_ERR_INVALID_ARGUMENT,
+               "out_mask must be device memory of member %d (device %d)", dest_member, dest_home);
     for (size_t i = 0; i < n_chunks; ++i) {
         if (!chunk_lens[i]) continue;
-        const int want = group->ctxs[i % G]->device;
+        const int want = group->home[i % G];
         MA_REQUIRE(device_of(chunk_data[i]) == want, MA_ERR_INVALID_ARGUMENT,
                    "chunk %zu belongs to member %zu: its data must be device memory of device %d", i, i % G, want);
         MA_REQUIRE(!(chunk_masks && chunk_masks[i]) || device_of(chunk_masks[i]) == want, MA_ERR_INVALID_ARGUMENT,
                    "chunk %zu belongs to member %zu: its bitmap must be device memory of device %d", i, i % G, want);
+        // the copy is a peer write from the owner into the destination's HBM over xGMI: refused — not left to whatever the
+        // runtime does without a link (a staged copy through the host at PCIe rate, or a fault) — when the pair has none
+        MA_REQUIRE(group->peer[(i % G) * G + (size_t)dest_member] != 0, MA_ERR_UNSUPPORTED,
+                   "chunk %zu: device %d (member %zu) has no peer access to device %d (member %d): consolidate this column "
+                   "on a member whose device the owners can reach, or gather through the host",
+                   i, want, i % G, dest_home, dest_member);
     }
     // validity staging arena on the destination: one 8-byte aligned slot per chunk
     std::vector<size_t> slot_off(n_chunks, 0), slot_bit(n_chunks, 0);

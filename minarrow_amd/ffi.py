@@ -77,6 +77,11 @@ def parse_header(path: Path = HEADER_PATH):
     return protos
 
 
+def header_abi_version(path: Path = HEADER_PATH) -> int:
+    """MA_ABI_VERSION as the header states it: what a binding generated from this header expects ma_abi_version() to be."""
+    return int(re.search(r"^#define\s+MA_ABI_VERSION\s+(\d+)", path.read_text(), flags=re.M).group(1))
+
+
 def _to_ctype(tname: str):
     t = tname.replace("const", " ").replace("struct", " ")
     t = " ".join(t.split())
@@ -102,6 +107,10 @@ def load_library() -> C.CDLL:
             f"or `make -C minarrow_amd/csrc`. There is no CPU fallback."
         )
     lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    lib.ma_abi_version.restype = C.c_int32
+    if lib.ma_abi_version() != header_abi_version():
+        raise LibraryNotBuilt(f"{LIB_PATH} has ABI version {lib.ma_abi_version()}, include/minarrow_hip.h declares "
+                              f"{header_abi_version()}: rebuild it (make -C minarrow_amd/csrc)")
     for name, (ret, args) in parse_header().items():
         fn = getattr(lib, name)
         if ret.replace(" ", "") == "constchar*":

@@ -253,6 +253,11 @@ class Context:
         return Graph(self, g.value)
 
     # -- memory ----------------------------------------------------------------------------------
+    @property
+    def hip_device(self) -> int:
+        """The HIP runtime's ordinal of this context's device (`device` is the library ordinal: MINARROW_HIP_DEVICES)."""
+        return int(self.lib.ma_ctx_hip_device(self.handle))
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
@@ -578,9 +583,9 @@ class Group:
 
     MAX_COLUMNS = 16
 
-    def __init__(self, devices, exchange: str = "host"):
+    def __init__(self, devices, exchange: str = "host", issue: str = "threads"):
         self.lib = ffi.load_library()
-        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3}[exchange]
+        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3}[exchange] | {"threads": 0, "caller": 4}[issue]
         n = len(devices)
         devs = (C.c_int32 * n)(*[int(d) for d in devices])
         h = C.c_void_p()
@@ -598,6 +603,18 @@ class Group:
     def exchange_note(self) -> str:
         s = self.lib.ma_group_exchange_note(self.handle)
         return s.decode() if s else ""
+
+    @property
+    def issue_kind(self) -> str:
+        """"threads": every member's launches are enqueued by its own issue thread; "caller": by the calling thread."""
+        return "threads" if self.lib.ma_group_issue_kind(self.handle) == 1 else "caller"
+
+    def test_set_member_device(self, member: int, hip_device: int, peer_capable: bool = True) -> None:
+        """TESTING ONLY (ma_group_test_set_member_device): the checks treat `member` as living on `hip_device`."""
+        ffi.check(self.lib.ma_group_test_set_member_device(self.handle, int(member), int(hip_device), 1 if peer_capable else 0))
+
+    def peer_access(self, from_member: int, to_member: int) -> bool:
+        return self.lib.ma_group_peer_access(self.handle, int(from_member), int(to_member)) == 1
 
     def member_ctx(self, i: int) -> "Context":
         """A non-owning Context over member i's ma_ctx (allocate / fill that device's chunk through it)."""

@@ -25,7 +25,8 @@ def run(cmd, extra_env=None, timeout=600):
 
 def test_single_gpu_line_with_other_configs_and_cpu_baseline():
     out = run([sys.executable, "bench.py", *SMALL, "--cpu-rows", str(1 << 22), "--cpu-seconds", "1", "--other-reps", "2"])
-    assert out["parity_ok"] and out["n_gpus"] == 1 and out["unit"] == "Grows/s" and out["scaling"] == "weak"
+    assert out["parity_ok"] and out["n_gpus"] == 1 and out["unit"] == "Grows/s" and out["scaling"] == "strong"
+    assert out["config"]["rows_total_per_column"] == out["config"]["rows_per_gpu_per_column"] == 1 << 24
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
     assert 0 < out["roofline"]["frac"] <= 1.0
     oc = out["other_configs"]
@@ -47,6 +48,10 @@ def test_one_process_group_mode_with_rccl():
     with the GPUs this box has: one on the test pool, where ncclCommInitAll runs with one rank)."""
     out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--other-reps", "2"])
     assert out["parity_ok"] and out["config"]["launch"] == "single process"
+    # the N > 1 headline is the PARTITIONED column (strong scaling, the default); the same job on GPU 0 alone rides along
+    assert out["scaling"] == "strong" and out["config"]["rows_total_per_column"] == 1 << 24
+    assert "issue: threads" in out["config"]["parallelism"] and out["config"]["host_issue_us_per_step"] > 0
+    assert out["n1_same_process"]["value"] > 0 and 0.2 < out["efficiency_vs_n1"] < 2.0
     assert out["config"]["rccl_ranks"] == 1 and "RCCL all-gather (ncclCommInitAll" in out["config"]["exchange"]
     oc = out["other_configs"]  # the multi-GPU legs of configs 4 and 5 (one GPU here)
     assert oc["parity_ok"] is True
@@ -58,16 +63,20 @@ def test_one_process_group_mode_with_rccl():
                 "--no-other-configs"])
     assert host["parity_ok"] and host["config"]["rccl_ranks"] == 0 and "host fold" in host["config"]["exchange"]
     assert host["result"]["i64_sum"] == out["result"]["i64_sum"] and host["result"]["f64_sum"] == out["result"]["f64_sum"]
+    weak = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--scaling", "weak",
+                "--group-issue", "caller", "--no-other-configs"])
+    assert weak["parity_ok"] and weak["scaling"] == "weak" and "issue: caller" in weak["config"]["parallelism"]
 
 
-@pytest.mark.parametrize("exchange, extra", [("native", []), ("torch", []), ("torch", ["--overlap"])])
+@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("torch", []), ("torch", ["--overlap"])])
 def test_launcher_mode_one_rank(exchange, extra):
     """One process per GPU under torch.distributed.run: the library's own communicator (ma_comm_*), torch's all-gather,
     and torch's all-gather on a side stream (--overlap)."""
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
                "--other-reps", "2", "--exchange", exchange, *extra])
-    assert out["parity_ok"] and out["n_gpus"] == 1
+    assert out["parity_ok"] and out["n_gpus"] == 1 and out["scaling"] == "strong"
+    assert out["n1_same_process"]["value"] > 0 and out["efficiency_vs_n1"] > 0
     oc = out["other_configs"]  # configs 4 and 5 through the same exchange; config 3 needs none
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True
     assert oc["parity_ok"] is True, oc

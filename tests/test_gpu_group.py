@@ -96,10 +96,18 @@ def _chunk_tables(ctxs, ints, flts, bits, chunks):
     return di, df, dm
 
 
+def _device_lists(members):
+    """The member -> device maps the group tests run over: every member on device 0 (partition logic on a one-GPU box)
+    and one member per visible GPU, up to 8 (the cross-device paths — on this pool's one-GPU boxes that is [0])."""
+    distinct = list(range(min(ffi.device_count(), 8)))
+    return [[0] * members] + ([distinct] if distinct != [0] * members else [])
+
+
+@pytest.mark.parametrize("issue", ["threads", "caller"])
 @pytest.mark.parametrize("exchange", ["rccl", "host"])
-def test_group_over_distinct_devices(oracle, exchange):
-    """One member per visible GPU (up to 8). With exchange = "rccl": ncclCommInitAll + grouped all-gather + device fold —
-    every member must hold the same finals."""
+def test_group_over_distinct_devices(oracle, exchange, issue):
+    """One member per visible GPU (up to 8). With exchange = "rccl": ncclCommInitAll + all-gather (one per member issue
+    thread, or grouped on the calling thread) + device fold — every member must hold the same finals."""
     from minarrow_amd.host import Group
 
     n_dev = min(ffi.device_count(), 8)
@@ -109,9 +117,16 @@ def test_group_over_distinct_devices(oracle, exchange):
     ints = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
     flts = rng.standard_normal(n) * 1e12
     bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
-    with Group(list(range(n_dev)), exchange=exchange) as g:
-        assert g.exchange_kind == exchange and g.exchange_note == ""
+    with Group(list(range(n_dev)), exchange=exchange, issue=issue) as g:
+        assert g.exchange_kind == exchange and g.issue_kind == issue
+        note = g.exchange_note
+        assert "instead of RCCL" not in note and "peer access:" in note and ("one thread per member" in note) == (issue == "threads")
+        # peer capability is probed between every pair of members at creation; a member always reaches itself
+        assert all(g.peer_access(i, i) for i in range(n_dev)) and not g.peer_access(0, n_dev) and not g.peer_access(-1, 0)
+        if n_dev > 1:
+            assert f"/{n_dev * (n_dev - 1)} ordered device pairs" in note
         ctxs = [g.member_ctx(i) for i in range(n_dev)]
+        assert len({c.hip_device for c in ctxs}) == n_dev
         chunks = row_chunks(n, n_dev)
         di, df, dm = _chunk_tables(ctxs, ints, flts, bits, chunks)
         lens = [b - a for a, b in chunks]
@@ -236,8 +251,9 @@ def test_group_one_billion_rows_with_nulls_partitioned_eight_ways(ctx):
         b.free()
 
 
-@pytest.mark.parametrize("members,exchange", [(1, "rccl-or-host"), (3, "host"), (8, "host")])
-def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange):
+@pytest.mark.parametrize("members,exchange,distinct", [(1, "rccl-or-host", False), (3, "host", False), (8, "host", False),
+                                                      (8, "rccl-or-host", True)])
+def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange, distinct):
     """ma_group_route_super_array_broadcast: chunk pair i runs on member i % G (here every member drives device 0 — the
     partition, the per-member tables and the scatter of the validity flags are what is under test; on a multi-GPU node
     the same code places member m on device m). Mixed mask presence, odd lengths, an empty chunk, more chunks than
@@ -248,7 +264,11 @@ def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange):
     rng = np.random.default_rng(100 + members)
     lens = [5, 64, 1000, 4097, 70_001, 0, 129, 8192, 33, 100_003, 1]
     k = len(lens)
-    with Group([0] * members, exchange) as g:
+    devices = [0] * members
+    if distinct:  # one member per visible GPU (up to 8): every chunk's buffers live on ITS member's device
+        devices = list(range(min(ffi.device_count(), 8)))
+        members = len(devices)
+    with Group(devices, exchange) as g:
         ctxs = [g.member_ctx(m) for m in range(members)]
         own = lambda i: ctxs[i % members]  # noqa: E731
         for fmt, dt in (("l", np.int64), ("g", np.float64), ("i", np.int32)):
@@ -296,8 +316,8 @@ def test_group_super_array_broadcast_fans_chunks_out(oracle, members, exchange):
         g.synchronize()  # the latch is cleared by the report
 
 
-@pytest.mark.parametrize("members,dest", [(1, 0), (3, 1), (8, 7)])
-def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, dest):
+@pytest.mark.parametrize("members,dest,distinct", [(1, 0, False), (3, 1, False), (8, 7, False), (8, 7, True)])
+def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, dest, distinct):
     """ma_group_consolidate_column: chunk i on member i % G, the consolidated column (+ validity joined at bit
     granularity, chunks without a bitmap = all valid) on member `dest`. With every member on device 0 the peer copies
     are same-device copies; what is under test is the placement arithmetic, the staging of the validity windows (byte
@@ -306,6 +326,11 @@ def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, 
     from minarrow_amd.host import Group
 
     rng = np.random.default_rng(500 + members)
+    devices = [0] * members
+    if distinct:  # one member per visible GPU (up to 8): real peer copies over xGMI into the last member's HBM
+        devices = list(range(min(ffi.device_count(), 8)))
+        members = len(devices)
+        dest = members - 1
     for dt, lens in ((np.int64, [5, 64, 1000, 0, 4097, 70_001, 129, 1, 8192, 33]), (np.int32, [100_003, 63, 65, 7]), (np.uint8, [3, 1000, 17, 4096, 9])):
         dt = np.dtype(dt)
         k, total = len(lens), sum(lens)
@@ -321,7 +346,8 @@ def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, 
         for with_masks in (False, True):
             has1 = ctx.consolidate_column(dt.itemsize, d1, lens, want_out, m1 if with_masks else None, offs if with_masks else None,
                                           want_mask if with_masks else None)
-            with Group([0] * members, "host") as g:
+            with Group(devices, "host") as g:
+                assert all(g.peer_access(m, dest) for m in range(members)), g.exchange_note
                 own = [g.member_ctx(m) for m in range(members)]
                 dd = [own[i % members].to_device(x, 64) for i, x in enumerate(data)]
                 dm = [own[i % members].to_device(m, 16) if m is not None else None for i, m in enumerate(masks)]
@@ -335,8 +361,6 @@ def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, 
                 np.testing.assert_array_equal(out.download(dt, total), want_out.download(dt, total))
                 if with_masks:
                     np.testing.assert_array_equal(om.download(np.uint8, nb), want_mask.download(np.uint8, nb))
-                if with_masks and members > 1:  # a chunk on the wrong member's context is refused only across devices: skip here
-                    pass
         for b in d1 + [m for m in m1 if m is not None] + [want_out, want_mask]:
             b.free()
     with Group([0], "host") as g:
@@ -348,3 +372,67 @@ def test_group_consolidate_column_gathers_onto_one_member(ctx, oracle, members, 
         with pytest.raises(ffi.MinarrowHipError) as e:  # chunks must be device memory of their member
             g.consolidate_column(0, 8, [host], [16], o)
         assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+def test_group_refuses_chunks_resident_on_another_members_device(ctx):
+    """The cross-device guards (one row chunk per GPU): member i's kernels dereference chunk i, so a chunk
+    in another GPU's HBM must come back as MA_ERR_INVALID_ARGUMENT before anything is enqueued — on a multi-GPU node it
+    would otherwise be a memory fault — and ma_group_consolidate_column must refuse an owner without peer access to the
+    destination. With two or more GPUs the real thing is tested; on a one-GPU box ma_group_test_set_member_device makes
+    member 1 LOOK as if it lived on HIP device 7 (nothing launches differently), which drives the same code."""
+    from minarrow_amd.host import Group
+
+    lib = ffi.load_library()
+    a = np.arange(4096, dtype=np.int64)
+    f = a.astype(np.float64)
+    m = np.full(4096 // 8 + 16, 0xFF, dtype=np.uint8)
+    assert lib.ma_pointer_device(None) == -1 and lib.ma_pointer_device(a.ctypes.data) == -1
+    real = ffi.device_count() >= 2
+    for issue in ("threads", "caller"):
+        with Group([0, 1] if real else [0, 0], "host", issue=issue) as g:
+            c0, c1 = g.member_ctx(0), g.member_ctx(1)
+            if not real:
+                g.test_set_member_device(1, 7, peer_capable=False)
+                assert g.peer_access(0, 0) and not g.peer_access(0, 1) and not g.peer_access(1, 0)
+            on0, on0f, on0m = c0.to_device(a, 64), c0.to_device(f, 64), c0.to_device(m, 16)
+            assert lib.ma_pointer_device(on0.ptr) == c0.hip_device == lib.ma_pointer_device(on0.ptr + 8 * 100)
+            good1 = c1.to_device(a, 64) if real else None
+            # sums: chunk 1 handed to member 1 but resident on member 0's device
+            for tag, buf in (("i64", on0), ("f64", on0f)):
+                with pytest.raises(ffi.MinarrowHipError) as e:
+                    g.enqueue_sum(tag, 0, [buf, buf], [4096, 4096])
+                assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "chunk 1 belongs to member 1" in e.value.message
+                assert f"resident on device {c0.hip_device}" in e.value.message
+            # ... or only its validity bitmap is
+            if real:
+                with pytest.raises(ffi.MinarrowHipError) as e:
+                    g.enqueue_sum("i64", 0, [on0, good1], [4096, 4096], [on0m, on0m], [0, 0])
+                assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "validity bitmap" in e.value.message
+            # host memory is reachable from every device: accepted (staged), and so is an empty chunk with any pointer
+            assert g.sum("i64", [on0, a], [4096, 4096]) == (2 * int(a.sum()), 8192)
+            assert g.sum("i64", [on0, on0], [4096, 0]) == (int(a.sum()), 4096)
+            # chunk fan-out: same rule for operands, result and bitmaps
+            out = c0.alloc(4096 * 8 + 64)
+            with pytest.raises(ffi.MinarrowHipError) as e:
+                g.route_super_array_broadcast("l", 0, [on0, on0], [on0, on0], [4096, 4096], [4096, 4096], [out, out])
+            assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "chunk 1" in e.value.message
+            # consolidate: chunk 1 must be resident on member 1 ...
+            whole = c0.alloc(2 * 4096 * 8 + 64)
+            with pytest.raises(ffi.MinarrowHipError) as e:
+                g.consolidate_column(0, 8, [on0, on0], [4096, 4096], whole)
+            assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "chunk 1 belongs to member 1" in e.value.message
+            if not real:
+                # ... and when it is (member 1 is looked at as device 0 again), an owner WITHOUT a link to the destination is
+                # refused with MA_ERR_UNSUPPORTED instead of being left to whatever the runtime does without one
+                g.test_set_member_device(1, c0.hip_device, peer_capable=False)
+                with pytest.raises(ffi.MinarrowHipError) as e:
+                    g.consolidate_column(0, 8, [on0, on0], [4096, 4096], whole)
+                assert e.value.status == ffi.MA_ERR_UNSUPPORTED and "no peer access" in e.value.message
+                g.test_set_member_device(1, c0.hip_device, peer_capable=True)
+                g.consolidate_column(0, 8, [on0, on0], [4096, 4096], whole)
+                g.synchronize()
+                np.testing.assert_array_equal(whole.download(np.int64, 8192), np.concatenate([a, a]))
+            else:
+                g.consolidate_column(0, 8, [on0, good1], [4096, 4096], whole)
+                g.synchronize()
+                np.testing.assert_array_equal(whole.download(np.int64, 8192), np.concatenate([a, a]))
