@@ -458,6 +458,23 @@ ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_ds
     return MA_OK;
 }
 
+ma_status table_commit_mapped(ma_ctx* ctx, const void* host, const void** out_dev_alias, int* out_slot) {
+    const int k = ctx->table_next;
+    MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit_mapped without table_begin");
+    void* alias = nullptr;
+    MA_HIP(hipHostGetDevicePointer(&alias, ctx->table_stage[k], 0));
+    ctx->table_next ^= 1;
+    *out_dev_alias = alias;
+    *out_slot = k;
+    return MA_OK;
+}
+
+ma_status table_release(ma_ctx* ctx, int slot) {
+    MA_HIP(hipEventRecord(ctx->table_ev[slot], ctx->stream));
+    ctx->table_busy[slot] = true;
+    return MA_OK;
+}
+
 ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst) {
     if (bytes == 0) return MA_OK;
     void* host = nullptr;

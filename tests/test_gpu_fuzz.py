@@ -345,10 +345,10 @@ def test_consolidate_boolean(ctx, lens, with_masks, seed):
 @given(fmt=st.sampled_from(["i", "l", "f", "g"]), op=st.sampled_from([0, 1, 2]),
        lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
        mask_mode=st.sampled_from(["none", "mixed", "override"]), seed=st.integers(0, 2**31),
-       variant=st.sampled_from([0, 32, 64, 96]), out_off=st.integers(0, 3))
+       variant=st.sampled_from([0, 32, 64, 96, 256, 256 | 32, 256 | 16]), out_off=st.integers(0, 3))
 def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed, variant, out_off):
     """variant: 32 = the 8 x 16-byte tile also for short chunks, 64 = output bitmaps by the second launch instead of the
-    computing wave; out_off: outputs start out_off elements past a 16-byte boundary (a masked chunk off the boundary
+    computing wave, 256 = the chunk-per-workgroup kernel (RechunkStrategy-sized chunks) with either tile width; out_off: outputs start out_off elements past a 16-byte boundary (a masked chunk off the boundary
     sends the whole call to the second-launch path)."""
     rng = np.random.default_rng(seed)
     dt = np.dtype({"i": np.int32, "l": np.int64, "f": np.float32, "g": np.float64}[fmt])

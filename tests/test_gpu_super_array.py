@@ -73,14 +73,21 @@ def test_mask_union_rule_and_many_chunks(ctx, oracle, fmt, dt):
 
 
 @pytest.mark.parametrize("aligned", [False, True])
-def test_many_small_chunks_one_launch(ctx, oracle, aligned):
+@pytest.mark.parametrize("k,variant,max_len", [(700, 0, 9000), (700, 256, 9000), (700, 256 | 32, 9000), (700, 64, 9000),
+                                               (9500, 0, 300), (9500, 128, 300), (9500, 1024, 300), (9500, 128 | 1024 | 64, 300)])
+def test_many_small_chunks_one_launch(ctx, oracle, aligned, k, variant, max_len):
     """RechunkStrategy::Auto = 8192 rows (src/structs/chunked/super_array.rs:51-59): thousands of chunk pairs, odd
     lengths, mixed mask presence, run as one batched launch; compared chunk by chunk with the oracle. aligned: every
     chunk's output starts on a 16-byte boundary (the kernel then writes the output bitmaps itself); otherwise chunks are
-    packed back to back, half of them start mid-vector, and the bitmaps come from the second launch."""
+    packed back to back, half of them start mid-vector, and the bitmaps come from the second launch.
+    variant: 0 = the library's own choice (700 chunks: the tile-search kernel on an uploaded table; 9500: the
+    chunk-per-workgroup kernel reading its table from pinned host memory — unless a masked chunk's output starts mid-vector,
+    the unaligned case, which keeps the tile form); 256 / 128 force either form, + 32 = 8 x 16-byte tiles; 64 = output
+    bitmaps by the second launch. 9500 chunks go in three SEGMENTS
+    (4096 + 8192 + the rest: one table and one launch each, the host describing segment k + 1 while segment k runs);
+    1024 = the same list as one segment."""
     rng = np.random.default_rng(12)
-    k = 700
-    lens = [int(x) for x in rng.integers(0, 9000, size=k)]
+    lens = [int(x) for x in rng.integers(0, max_len, size=k)]
     lens[:4] = [8192, 8192, 1, 0]
     starts = []
     pos = 0
@@ -115,7 +122,20 @@ def test_many_small_chunks_one_launch(ctx, oracle, aligned):
     rms = [dr.offset(m_offs[i]) if rm_host[i] is not None else None for i in range(k)]
     oms = [dom.offset(m_offs[i]) for i in range(k)]
     for op, name in ((2, "multiply"), (0, "add")):
-        has = ctx.route_super_array_broadcast("l", op, lhs, rhs, lens, lens, outs, lms, rms, oms)
+        ctx.set_variant(variant)
+        try:
+            has = ctx.route_super_array_broadcast("l", op, lhs, rhs, lens, lens, outs, lms, rms, oms)
+            if name == "add":  # and the dense form of the same call: no bitmaps at all
+                dense_out = ctx.alloc(total * 8 + 64)
+                douts = [dense_out.offset(int(offs[i]) * 8) for i in range(k)]
+                assert not any(ctx.route_super_array_broadcast("l", op, lhs, rhs, lens, lens, douts))
+                dense = dense_out.download(np.int64, total)
+                for i, n in enumerate(lens):
+                    sl = slice(int(offs[i]), int(offs[i]) + n)
+                    np.testing.assert_array_equal(dense[sl], a[sl] + b[sl], err_msg=f"dense chunk {i}")
+                dense_out.free()
+        finally:
+            ctx.set_variant(0)
         got = do.download(np.int64, total)
         got_masks = dom.download(np.uint8, pos)
         for i, n in enumerate(lens):
@@ -140,8 +160,12 @@ def test_many_small_chunks_one_launch(ctx, oracle, aligned):
     zero_b[int(offs[5])] = 0
     db2 = ctx.to_device(zero_b, 64)
     rhs2 = [db2.offset(int(offs[i]) * 8) for i in range(k)]
-    with pytest.raises(ffi.MinarrowHipError) as e:
-        ctx.route_super_array_broadcast("l", 3, lhs, rhs2, lens, lens, outs)
+    ctx.set_variant(variant)
+    try:
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            ctx.route_super_array_broadcast("l", 3, lhs, rhs2, lens, lens, outs)
+    finally:
+        ctx.set_variant(0)
     assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
 
 

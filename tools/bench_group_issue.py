@@ -75,6 +75,11 @@ def measure(members: int, issue: str, rows: int, burst: int, bursts: int, device
 
 
 def main():
+    import os
+
+    sys.stdout.flush()
+    result_fd = os.dup(1)  # RCCL prints a banner to fd 1 from native code: keep the real stdout for the JSON
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--members", default="1,2,4,8")
     ap.add_argument("--rows", type=int, default=4096)
@@ -95,8 +100,9 @@ def main():
     summary = {f"{m}_members": {"caller_us": by[(m, "caller")], "threads_us": by[(m, "threads")],
                                 "ratio": by[(m, "caller")] / by[(m, "threads")]}
                for m in sorted({r["members"] for r in res})}
-    print(json.dumps({"tool": "tools/bench_group_issue.py", "what": "host time of one group step (2 scans + exchange) on the calling thread",
-                      "summary": summary, "runs": res}, indent=1))
+    os.write(result_fd, (json.dumps({"tool": "tools/bench_group_issue.py",
+                                     "what": "host time of one group step (2 scans + exchange) on the calling thread",
+                                     "summary": summary, "runs": res}, indent=1) + "\n").encode())
 
 
 if __name__ == "__main__":

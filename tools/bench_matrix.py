@@ -57,12 +57,17 @@ def main():
             line["frac_of_copy"] = round(gbps / copy_gbps[0], 3)
         print(json.dumps(line), flush=True)
 
-    def timed(fn, sync=False):
+    def timed(fn, sync=False, prime=False):
+        """prime: one un-timed call immediately before the start event, so that the GPU is still busy with it while the host
+        prepares the first timed call — the steady state of back-to-back calls on an async context (the host side of a
+        60 000-chunk call is 0.3-0.5 ms; without this a fifth of it sits inside the events as idle GPU time)."""
         fn()
         fn()
         best = None
         for _ in range(2):  # best of two rounds: a single stalled launch (seen once: 8 ms instead of 0.9) must not be a row
             ctx.synchronize()
+            if prime:
+                fn()
             ctx.timer_start()
             for _ in range(args.reps):
                 fn()
@@ -230,11 +235,16 @@ def main():
                             t_lm if masked else None, None, t_o, t_om if masked else None, None)
                     assert st == 0, st
 
-                for variant, vname in ((0, ""), (64, " [output bitmaps by a second launch]")):
+                for variant, vname in ((0, ""), (1024, " [one segment]"), (128, " [tile-search kernel on an uploaded table]"),
+                                       (128 | 64, " [tile-search kernel, output bitmaps by a second launch]"),
+                                       (256 | 16, " [chunk-per-workgroup kernel on a pinned-host table, 4 x 16 B per lane]"),
+                                       (256 | 32, " [chunk-per-workgroup kernel on a pinned-host table, 8 x 16 B per lane]")):
+                    if k < 2048 and variant & (256 | 1024):
+                        continue  # shapes the library never picks for 8 chunks
                     ctx.set_variant(variant)
-                    ms = timed(lambda: call(False))
+                    ms = timed(lambda: call(False), prime=True)
                     emit("route_super_array_broadcast", tag, f"add dense, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz, rows)
-                    ms = timed(lambda: call(True))
+                    ms = timed(lambda: call(True), prime=True)
                     emit("route_super_array_broadcast", tag, f"add, nulls on both sides, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz + 3 * rows / 8, rows)
                 ctx.set_variant(0)
                 host = []
@@ -245,6 +255,26 @@ def main():
                     host.append((time.perf_counter() - t0) * 1e3)
                 host_ms = sorted(host)[2]
                 ctx.synchronize()
+                for variant, vname in ((0, ""), (1024, " [one segment]"), (128, " [tile-search kernel on an uploaded table]"),
+                                       (256 | 16, " [chunk-per-workgroup kernel, 4 x 16 B]"), (256 | 32, " [chunk-per-workgroup kernel, 8 x 16 B]")):
+                    if k < 2048 and variant:
+                        continue
+                    ctx.set_variant(variant)
+                    shot = []
+                    for masked in (False, True):
+                        ts = []
+                        for _ in range(5):  # ONE call on an idle stream, until its results are complete: host + table + kernel
+                            ctx.synchronize()
+                            t0 = time.perf_counter()
+                            call(masked)
+                            ctx.synchronize()
+                            ts.append((time.perf_counter() - t0) * 1e3)
+                        shot.append(round(sorted(ts)[2], 3))
+                    print(json.dumps({"family": "route_super_array_broadcast", "type": tag,
+                                      "variant": f"one call, idle stream to results complete, {k} chunk pairs{vname}",
+                                      "wall_ms_dense": shot[0], "wall_ms_masked": shot[1],
+                                      "copy_equivalent_ms": round(3 * rows * sz / copy_gbps[0] / 1e6, 3)}), flush=True)
+                ctx.set_variant(0)
                 print(json.dumps({"family": "route_super_array_broadcast", "type": tag, "variant": f"host time per call, {k} masked chunk pairs",
                                   "host_ms": round(host_ms, 3), "host_us_per_chunk": round(host_ms * 1e3 / k, 3)}), flush=True)
             ctx.set_async(False)
