@@ -15,9 +15,11 @@
 // paid was (a) the 104-byte-per-chunk table crossing PCIe ON the stream in front of the kernel (6.2 MB = 0.11 ms of a
 // 1.05 ms kernel) and (b) the host building that table (0.48 ms) before anything was enqueued. Hence the compact tables
 // (2.4 MB dense), and long chunk lists go in SEGMENTS of growing size: the GPU starts on the first 4096 chunks while the
-// host describes the next segment. A chunk-per-workgroup kernel that reads its descriptors straight from pinned host
-// memory (no copy at all) exists as well (variant bit 256); it saves the upload but its access front is four times wider
-// (every workgroup walks its own chunk) and the kernel is 4-8 % slower, so the tile kernel stays the default.
+// host describes the next segment. And RechunkStrategy-sized chunk lists take a second kernel, chunk_binary_kernel: a whole
+// chunk per workgroup, no search, its 32-byte descriptors read straight from the pinned staging buffer with wave-uniform
+// loads a chunk ahead of their use — no copy on the stream at all. As a kernel it is 4-8 % slower than the tile kernel
+// (every workgroup walks its own chunk: a four times wider access front), end to end it wins everywhere but dense f64,
+// where the two tie: see batched_impl for the figures.
 #include <vector>
 
 #include "ma_binary.hpp"
@@ -512,10 +514,9 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
                                           (op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV));
 }
 
-// Rows per wave step: 8 x 16 bytes per lane (the single-array kernels' shape) for chunks long enough to fill such tiles,
-// 4 x 16 bytes when the chunks are short (RechunkStrategy::Auto's 8192-row chunks: fewer ragged tiles). variant bit 16
-// forces 4, bit 32 forces 8 (tuning). variant bit 256: the chunk-per-workgroup kernel on a table left in pinned host
-// memory (needs every masked chunk's output on a 16-byte boundary).
+// Picks the form (chunk-per-workgroup kernel on a pinned-host table, or tile-search kernel on an uploaded table) and the
+// rows per wave step: 8 x 16 bytes per lane (the single-array kernels' shape) or 4 x 16 bytes (fewer ragged tiles when
+// chunks are short). variant bit 16 forces 4, bit 32 forces 8 (tuning).
 template <typename T>
 static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
@@ -539,8 +540,24 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     }
     constexpr size_t kWideTileRows = (size_t)64 * (16 / sizeof(T)) * 8 * kWaves;
     const size_t avg = total / n_chunks;
-    const bool by_chunk = (ctx->variant & 256) != 0 && !masked_head && n_chunks < ((size_t)1 << 31);
-    bool wide = by_chunk ? avg >= kWideTileRows : avg >= 16 * kWideTileRows;
+    size_t longest = 0;
+    for (size_t i = 0; i < n_chunks; ++i)
+        if (lens[i] > longest) longest = lens[i];
+    // Which form (profiles/r03_matrix_super_array.jsonl, 60 000 x 8192-row pairs, fraction of the same-process copy / one
+    // call from an idle stream to complete results against the copy-equivalent time):
+    //   chunk-per-workgroup kernel on the pinned-host table   i32 1.03 dense, 1.01 masked / 1.06-1.12 x;  f64 0.97, 0.98 / 1.05-1.11 x
+    //   tile-search kernel on the uploaded table                i32 0.93, 0.94 / 1.18-1.20 x;               f64 1.00, 0.91 / 1.04-1.16 x
+    // Many chunks of a few tiles each take the chunk form: enough chunks to keep every workgroup busy with an even share
+    // (>= 4 per CU), none so long that its workgroup becomes the tail, every masked chunk's output on a 16-byte boundary
+    // (runs must start on validity words). Everything else — a few long chunks above all — is dealt out tile by tile.
+    // variant bit 128 forces the tile form, bit 256 the chunk form (tuning / tests).
+    bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
+    if (ctx->variant & 128) by_chunk = false;
+    if (ctx->variant & 256) by_chunk = true;
+    by_chunk = by_chunk && !masked_head && n_chunks < ((size_t)1 << 31);
+    // 8 x 16 bytes per lane when the tiles that gives are filled: 8-byte types in the chunk form (two 4096-row tiles per
+    // 8192-row chunk; 4-byte types are faster with two 4 x 16-byte tiles), long chunks in the tile form.
+    bool wide = by_chunk ? (sizeof(T) >= 8 && avg >= kWideTileRows) : avg >= 16 * kWideTileRows;
     if (ctx->variant & 16) wide = false;
     if (ctx->variant & 32) wide = true;
     if (wide)
