@@ -13,6 +13,8 @@
 // workgroup tile), so 100 x 10 000-row batches (benches/consolidate.rs:21-58) cost one launch, not 100 memcpys; a second
 // launch assembles the output bitmap word by word from bit-granular pieces of the chunk bitmaps. HBM-bound:
 // 2 x elem_size bytes per row (+ 2/8 for validity).
+#include <vector>
+
 #include "ma_device.hpp"
 
 namespace ma {
@@ -40,51 +42,93 @@ __device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ 
 
 // Copy tiles: every chunk is cut into tiles of TILE_ROWS rows counted from its first 16-byte aligned destination
 // row (tile 0 also takes the `head` rows in front of it). A full tile moves 16 bytes per lane per access (the
-// bandwidth path) whatever the source's byte phase; partial tiles move one row per lane.
+// bandwidth path) whatever the source's byte phase; partial tiles move whole vectors, then single rows.
 template <typename T, int UNROLL>
-__global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
-                                                        size_t n_tiles, T* __restrict__ out) {
+__device__ __forceinline__ void concat_tile(const T* __restrict__ src, T* __restrict__ dst, unsigned head, size_t len,
+                                            size_t lt, unsigned lane, unsigned wave) {
     typedef typename Vec16<T>::type V;
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const size_t r0 = head + lt * TILE_ROWS;  // first row of the aligned part of this tile
+    const size_t r1 = r0 + TILE_ROWS < len ? r0 + TILE_ROWS : len;
+    if (lt == 0) {
+        for (size_t i = threadIdx.x; i < head && i < len; i += kBlock) dst[i] = src[i];
+    }
+    if (r0 >= len) return;
+    if (r1 - r0 == TILE_ROWS) {
+        // Stores are 16-byte aligned by construction of the tiles; the source is read at whatever element-aligned
+        // phase it has with the same global_load_dwordx4 (gfx950 runs with unaligned access mode on under HSA; a
+        // misaligned wave access touches one extra cache line per KiB).
+        typedef V VU __attribute__((aligned(1)));
+        const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
+        const VU* __restrict__ p = (const VU*)(src + w0) + lane;
+        V* __restrict__ q = (V*)(dst + w0) + lane;
+        V v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) store16<V, true>(q + (size_t)u * 64, v[u]);
+    } else {
+        // The chunk's last, partial tile (up to TILE_ROWS - 1 rows — 32 767 for 1-byte columns): whole 16-byte
+        // vectors first (dst + r0 is 16-byte aligned like every tile start), then the few rows left, instead of one
+        // element per lane per trip (128 trips of 1-byte accesses for one workgroup, ~10 % of a 1-byte consolidate).
+        typedef V VU __attribute__((aligned(1)));
+        const size_t n_vec = (r1 - r0) / R;
+        const VU* __restrict__ p = (const VU*)(src + r0);
+        V* __restrict__ q = (V*)(dst + r0);
+        for (size_t v = threadIdx.x; v < n_vec; v += kBlock) store16<V, true>(q + v, __builtin_nontemporal_load(p + v));
+        for (size_t i = r0 + n_vec * R + threadIdx.x; i < r1; i += kBlock) dst[i] = src[i];
+    }
+}
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
+                                                        size_t n_tiles, T* __restrict__ out) {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int c = find_chunk_by_tile(chunks, n_chunks, t);  // workgroup-uniform
         const ChunkDesc d = chunks[c];
-        const size_t lt = t - d.tile0;
-        const T* __restrict__ src = (const T*)d.data;
-        T* __restrict__ dst = out + d.start;
-        const size_t r0 = d.head + lt * TILE_ROWS;  // first row of the aligned part of this tile
-        const size_t r1 = r0 + TILE_ROWS < d.len ? r0 + TILE_ROWS : d.len;
-        if (lt == 0) {
-            for (size_t i = threadIdx.x; i < d.head && i < d.len; i += kBlock) dst[i] = src[i];
+        concat_tile<T, UNROLL>((const T*)d.data, out + d.start, d.head, d.len, t - d.tile0, lane, wave);
+    }
+}
+
+// RechunkStrategy-sized chunk lists (src/structs/chunked/super_array.rs:51-59: 8192 rows by default — a 10^9-row column is
+// 122 000 chunks): a whole chunk per workgroup, no search, and the 32-byte descriptors are read where the host built
+// them — in the pinned staging buffer, with wave-uniform loads issued a chunk ahead of their use — instead of crossing
+// PCIe as a 64-byte-per-chunk table ON the stream in front of the kernel (ma_superarray.hip has the measurements that
+// led here: the copy and the host's table building, not the search, are what the chunked regime pays for).
+struct ConcatChunk {  // 32 bytes
+    const void* data;
+    uint64_t start;  // first output row
+    uint64_t len;
+    uint64_t pad;
+};
+
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(kBlock) void concat_chunk_kernel(const ConcatChunk* __restrict__ cd, int n_chunks,
+                                                              T* __restrict__ out) {
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr size_t TILE_ROWS = (size_t)64 * R * UNROLL * kWaves;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int c = blockIdx.x;
+    if (c >= n_chunks) return;
+    ConcatChunk e = cd[c];
+    while (true) {
+        const int next = c + (int)gridDim.x;
+        ConcatChunk en{};
+        if (next < n_chunks) en = cd[next];  // wave-uniform address: a scalar load, in flight while this chunk streams
+        const size_t len = (size_t)e.len;
+        if (len) {
+            T* dst = out + e.start;
+            const unsigned mis = (unsigned)((uintptr_t)dst & 15);
+            const unsigned head = mis ? (16 - mis) / (unsigned)sizeof(T) : 0;
+            const size_t n_t = len > head ? (len - head + TILE_ROWS - 1) / TILE_ROWS : 1;
+            for (size_t lt = 0; lt < n_t; ++lt) concat_tile<T, UNROLL>((const T*)e.data, dst, head, len, lt, lane, wave);
         }
-        if (r0 >= d.len) continue;
-        if (r1 - r0 == TILE_ROWS) {
-            // Stores are 16-byte aligned by construction of the tiles; the source is read at whatever element-aligned
-            // phase it has with the same global_load_dwordx4 (gfx950 runs with unaligned access mode on under HSA; a
-            // misaligned wave access touches one extra cache line per KiB).
-            typedef V VU __attribute__((aligned(1)));
-            const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
-            const VU* __restrict__ p = (const VU*)(src + w0) + lane;
-            V* __restrict__ q = (V*)(dst + w0) + lane;
-            V v[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) store16<V, true>(q + (size_t)u * 64, v[u]);
-        } else {
-            // The chunk's last, partial tile (up to TILE_ROWS - 1 rows — 32 767 for 1-byte columns): whole 16-byte
-            // vectors first (dst + r0 is 16-byte aligned like every tile start), then the few rows left, instead of one
-            // element per lane per trip (128 trips of 1-byte accesses for one workgroup, ~10 % of a 1-byte consolidate).
-            typedef V VU __attribute__((aligned(1)));
-            const size_t n_vec = (r1 - r0) / R;
-            const VU* __restrict__ p = (const VU*)(src + r0);
-            V* __restrict__ q = (V*)(dst + r0);
-            for (size_t v = threadIdx.x; v < n_vec; v += kBlock) store16<V, true>(q + v, __builtin_nontemporal_load(p + v));
-            for (size_t i = r0 + n_vec * R + threadIdx.x; i < r1; i += kBlock) dst[i] = src[i];
-        }
+        if (next >= n_chunks) break;
+        c = next;
+        e = en;
     }
 }
 
@@ -99,15 +143,15 @@ constexpr int kLdsChunks = 256;
 
 template <bool LDS>
 struct DescTable {
-    const ChunkDesc* g;
-    const MaskDesc* s;
+    const ChunkDesc* g;   // the copy kernel's table (64-byte entries), or nullptr when only ...
+    const MaskDesc* s;    // ... a compact MaskDesc table exists (LDS: staged in shared memory)
     __device__ __forceinline__ MaskDesc get(int i) const {
-        if constexpr (LDS) return s[i];
+        if (LDS || g == nullptr) return s[i];
         const ChunkDesc& c = g[i];
         return MaskDesc{c.start, c.len, c.words, c.bit_off, c.last_word};
     }
     __device__ __forceinline__ size_t start(int i) const {
-        if constexpr (LDS) return s[i].start;
+        if (LDS || g == nullptr) return s[i].start;
         return g[i].start;
     }
     // Index of the chunk that contains output row `row` (row < total).
@@ -156,7 +200,8 @@ __device__ __forceinline__ uint64_t gather_word(const DescTable<LDS>& tab, int c
 // One thread per PAIR of output words (a 16-byte store). When the pair's 128 rows lie inside one chunk — all but
 // the few pairs at chunk joins — the two words are funnel-shifted out of three consecutive source words.
 template <bool LDS>
-__global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
+__global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __restrict__ chunks,
+                                                             const MaskDesc* __restrict__ compact, int n_chunks,
                                                              size_t total, uint64_t* __restrict__ out_words) {
     typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
     __shared__ MaskDesc staged[LDS ? kLdsChunks : 1];
@@ -167,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
         }
         __syncthreads();
     }
-    const DescTable<LDS> tab{chunks, staged};
+    const DescTable<LDS> tab{chunks, LDS ? staged : compact};
     const size_t n_words = (total + 63) >> 6;
     const size_t n_pairs = (n_words + 1) >> 1;
     const size_t stride = (size_t)gridDim.x * kBlock;
@@ -221,13 +266,14 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
     }
 }
 
-static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks, size_t total, uint64_t* ow) {
+static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks, size_t total, uint64_t* ow,
+                               const MaskDesc* compact = nullptr) {
     const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
     const int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
-    if (n_chunks <= (size_t)kLdsChunks)
-        hipLaunchKernelGGL(concat_mask_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
+    if (d != nullptr && n_chunks <= (size_t)kLdsChunks)
+        hipLaunchKernelGGL(concat_mask_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
     else
-        hipLaunchKernelGGL(concat_mask_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, (int)n_chunks, total, ow);
+        hipLaunchKernelGGL(concat_mask_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
 }
 
 template <typename T>
@@ -276,12 +322,84 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    ChunkDesc* desc = nullptr;  // built in the context's pinned staging buffer (ma::table_begin / table_commit)
-    MA_TRY(table_begin(ctx, sizeof(ChunkDesc) * n_chunks, (void**)&desc));
     void* po = nullptr;
     MA_TRY(scope.out(out_data, total * elem_size, &po));
     uint64_t* ow = nullptr;
     if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &ow));
+    // Many chunks of a few tiles each (4- and 8-byte columns): the chunk-per-workgroup kernel on pinned-host descriptors,
+    // the list cut into segments of 4096, 8192, ... 32768 chunks so that the GPU copies segment k while the host describes
+    // segment k + 1. variant bit 128 keeps the tile form, bit 256 forces the chunk form (tuning / tests).
+    {
+        size_t longest = 0;
+        for (size_t i = 0; i < n_chunks; ++i)
+            if (chunk_lens[i] > longest) longest = chunk_lens[i];
+        const size_t avg = total / n_chunks;
+        bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
+        if (ctx->variant & 128) by_chunk = false;
+        if (ctx->variant & 256) by_chunk = true;
+        if (by_chunk && elem_size >= 4) {
+            std::vector<MaskDesc> mdesc;
+            if (has_mask) mdesc.resize(n_chunks);
+            DeviceRange data_role, mask_role;
+            const size_t kFirst = 4096, kMax = 32768;
+            size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
+            while (c0 < n_chunks) {
+                const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
+                ConcatChunk* cd = nullptr;
+                MA_TRY(table_begin(ctx, sizeof(ConcatChunk) * (c1 - c0), (void**)&cd));
+                for (size_t i = c0; i < c1; ++i) {
+                    const void* p = chunk_data[i];
+                    if (!data_role.holds(p)) {
+                        MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
+                        if (chunk_lens[i]) data_role.learn(chunk_data[i]);
+                    }
+                    cd[i - c0] = ConcatChunk{p, (uint64_t)row, (uint64_t)chunk_lens[i], 0};
+                    if (has_mask) {
+                        MaskDesc& m = mdesc[i];
+                        m = MaskDesc{row, chunk_lens[i], nullptr, 0, 0};
+                        if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
+                            const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
+                            if (mask_role.holds(chunk_masks[i])) {
+                                const uintptr_t addr = (uintptr_t)chunk_masks[i], base = addr & ~(uintptr_t)7;
+                                m.words = (const uint64_t*)base;
+                                m.bit_off = mo + (size_t)(addr - base) * 8;
+                            } else {
+                                MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &m.words, &m.bit_off));
+                                mask_role.learn(chunk_masks[i]);
+                            }
+                            m.last_word = (m.bit_off + m.len - 1) >> 6;
+                        }
+                    }
+                    row += chunk_lens[i];
+                }
+                const void* tab = nullptr;
+                int slot = -1;
+                MA_TRY(table_commit_mapped(ctx, cd, &tab, &slot));
+                const int n = (int)(c1 - c0);
+                const int grid = grid_for(ctx, (size_t)n, 6);
+                if (elem_size == 4)  // two 4 x 16-byte tiles per 8192-row chunk (4-byte), two 8 x 16-byte tiles (8-byte)
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint32_t, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                                       (const ConcatChunk*)tab, n, (uint32_t*)po);
+                else
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint64_t, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                                       (const ConcatChunk*)tab, n, (uint64_t*)po);
+                MA_HIP(hipGetLastError());
+                MA_TRY(table_release(ctx, slot));
+                c0 = c1;
+                if (seg < kMax) seg *= 2;
+            }
+            if (has_mask) {  // the validity join searches the whole list by output row: one compact table, uploaded
+                void* dm = nullptr;
+                MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks, &dm));
+                MA_TRY(upload_table(ctx, mdesc.data(), sizeof(MaskDesc) * n_chunks, dm));
+                launch_concat_mask(ctx, nullptr, n_chunks, total, ow, (const MaskDesc*)dm);
+                MA_HIP(hipGetLastError());
+            }
+            return end_call(ctx, scope);
+        }
+    }
+    ChunkDesc* desc = nullptr;  // built in the context's pinned staging buffer (ma::table_begin / table_commit)
+    MA_TRY(table_begin(ctx, sizeof(ChunkDesc) * n_chunks, (void**)&desc));
     const size_t tile_rows = elem_size == 1 ? tile_rows_of<uint8_t>() : elem_size == 2 ? tile_rows_of<uint16_t>()
                            : elem_size == 4 ? tile_rows_of<uint32_t>() : tile_rows_of<uint64_t>();
     size_t row = 0, n_tiles = 0;

@@ -89,12 +89,16 @@ def test_random_chunks(ctx, oracle, dt):
                 np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
 
 
-def test_many_small_chunks(ctx, oracle):
+@pytest.mark.parametrize("k,dt,variant", [(700, np.int32, 0), (700, np.int32, 256), (700, np.float64, 256), (9000, np.int32, 0),
+                                          (9000, np.int64, 0), (9000, np.int64, 1024), (9000, np.int32, 128)])
+def test_many_small_chunks(ctx, oracle, k, dt, variant):
     """700 chunks (more than the validity kernel stages in LDS), ragged lengths incl. empty ones, masks at odd bit
-    offsets on two thirds of them; values and validity vs the oracle; and the Boolean column twin."""
+    offsets on two thirds of them; values and validity vs the oracle; and the Boolean column twin.
+    variant 256 = the chunk-per-workgroup kernel on pinned-host descriptors (what 9000 chunks of a 4- or 8-byte column take by
+    themselves, in three segments: 4096 + 8192... chunks; 1024 = as one segment), 128 = the tile-search kernel."""
     rng = np.random.default_rng(700)
-    lens = [int(x) for x in rng.choice([0, 1, 7, 63, 64, 65, 130, 500, 3000], size=700)]
-    chunks = [rng.integers(0, 1 << 30, size=n).astype(np.int32) for n in lens]
+    lens = [int(x) for x in rng.choice([0, 1, 7, 63, 64, 65, 130, 500, 3000] if k < 5000 else [0, 1, 7, 63, 64, 65, 130, 500], size=k)]
+    chunks = [rng.integers(0, 1 << 30, size=n).astype(dt) for n in lens]
     masks, offs = [], []
     for i, n in enumerate(lens):
         if i % 3 == 0:
@@ -105,9 +109,18 @@ def test_many_small_chunks(ctx, oracle):
             masks.append(rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8))
             offs.append(off)
     want, want_mask = oracle.consolidate_column(chunks, masks, offs)
-    out, mask = run(ctx, chunks, masks, offs)
+    ctx.set_variant(variant)
+    try:
+        out, mask = run(ctx, chunks, masks, offs)
+        dense, no_mask = run(ctx, chunks, None, None)
+    finally:
+        ctx.set_variant(0)
     np.testing.assert_array_equal(out, want)
     np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
+    np.testing.assert_array_equal(dense, want)
+    assert no_mask is None
+    if k > 5000 or variant:
+        return
     bchunks = [(rng.integers(0, 256, size=(n + 200) // 8 + 16, dtype=np.uint8), int(rng.integers(0, 100)), n) for n in lens]
     bmasks = [(m, o) if m is not None else None for m, o in zip(masks, offs)]
     want, want_mask = oracle.consolidate_boolean_column(bchunks, bmasks)

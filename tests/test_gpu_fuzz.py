@@ -171,8 +171,10 @@ def test_simd_eq_mask(ctx, tag, n, elem_off, seed):
 
 @settings(**COMMON)
 @given(elem=st.sampled_from([1, 2, 4, 8]), lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 40_000)), min_size=1, max_size=9),
-       starts=st.lists(st.integers(0, 9), min_size=9, max_size=9), with_masks=st.booleans(), seed=st.integers(0, 2**31))
-def test_consolidate(ctx, elem, lens, starts, with_masks, seed):
+       starts=st.lists(st.integers(0, 9), min_size=9, max_size=9), with_masks=st.booleans(), seed=st.integers(0, 2**31),
+       variant=st.sampled_from([0, 0, 256, 128]))
+def test_consolidate(ctx, elem, lens, starts, with_masks, seed, variant):
+    """variant 256: the chunk-per-workgroup kernel on pinned-host descriptors (4- and 8-byte columns), 128: the tile form."""
     rng = np.random.default_rng(seed)
     dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[elem]
     chunks = [rand_values(rng, dt, n + s) for n, s in zip(lens, starts)]
@@ -195,7 +197,11 @@ def test_consolidate(ctx, elem, lens, starts, with_masks, seed):
                 dmasks.append(ctx.to_device(m, 16))
     out = ctx.alloc(max(total, 1) * elem + 64)
     om = ctx.alloc(total // 8 + 64)
-    has = ctx.consolidate_column(elem, ptrs, lens, out, dmasks, offs, om)
+    ctx.set_variant(variant)
+    try:
+        has = ctx.consolidate_column(elem, ptrs, lens, out, dmasks, offs, om)
+    finally:
+        ctx.set_variant(0)
     want = np.concatenate([c[s:] for c, s in zip(chunks, starts)]) if total else np.zeros(0, dt)
     np.testing.assert_array_equal(out.download(dt, total), want)
     any_mask = with_masks and any(m is not None for m in masks)

@@ -294,6 +294,44 @@ def main():
             emit("consolidate", f"{sz}-byte", "8 chunks, no validity", ms, 2 * sum(lens) * sz, sum(lens))
             ms = timed(lambda: ctx.consolidate_column(sz, chunks, lens, o, masks, offs, omask))
             emit("consolidate", f"{sz}-byte", "8 chunks + validity at odd bit offsets", ms, 2 * sum(lens) * sz + sum(lens) / 4, sum(lens))
+        # RechunkStrategy-sized chunk lists (src/structs/chunked/super_array.rs:51-59): 60 000 chunks of 8192 rows
+        import ctypes as C
+        for sz in (4, 8):
+            k, per = 60000, 8192
+            lens = [per] * k
+            tab = lambda xs: C.cast((C.c_void_p * k)(*xs), C.c_void_p)  # noqa: E731
+            t_c = tab([a.ptr + i * per * sz for i in range(k)])
+            t_m = tab([mask.ptr + i * (per // 8) for i in range(k)])
+            t_n = C.cast((C.c_size_t * k)(*lens), C.c_void_p)
+            t_o = C.cast((C.c_size_t * k)(*([0] * k)), C.c_void_p)
+            fn = ctx.lib.ma_consolidate_column
+            has = C.c_int32()
+
+            def ccall(masked):
+                st = fn(ctx.handle, sz, k, t_c, t_n, t_m if masked else None, t_o if masked else None, o.ptr,
+                        omask.ptr if masked else None, C.addressof(has))
+                assert st == 0, st
+
+            ctx.set_async(True)
+            for masked, name in ((False, "no validity"), (True, "+ validity")):
+                ms = timed(lambda: ccall(masked), prime=True)
+                emit("consolidate", f"{sz}-byte", f"{k} x {per}-row chunks (RechunkStrategy::Auto), {name}", ms,
+                     2 * k * per * sz + (k * per / 4 if masked else 0), k * per)
+                ts = []
+                for _ in range(5):
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    ccall(masked)
+                    t1 = time.perf_counter()
+                    ctx.synchronize()
+                    ts.append(((time.perf_counter() - t0) * 1e3, (t1 - t0) * 1e3))
+                ts.sort()
+                print(json.dumps({"family": "consolidate", "type": f"{sz}-byte",
+                                  "variant": f"one call, idle stream to results complete, {k} chunks, {name}",
+                                  "wall_ms": round(ts[2][0], 3), "host_ms": round(ts[2][1], 3),
+                                  "copy_equivalent_ms": round(2 * k * per * sz / copy_gbps[0] / 1e6, 3)}), flush=True)
+            ctx.set_async(False)
+            ctx.synchronize()
         bits = B * 4
         per = bits // 8
         chunks = [(a.ptr + i * (per // 64 * 8), 3 * i + 1, per - 200) for i in range(8)]
