@@ -892,6 +892,19 @@ ma_status ma_comm_all_reduce_sum_i64(ma_comm* comm, const int64_t* send, int64_t
 ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
                                uint64_t* gathered, uint64_t* out_finals);
 
+/* ------------------------------------------------------------------------------------------------
+ * Testing hooks. Not part of what a binding needs (ma_group_test_set_member_device above is the other one).
+ * ma_test_pow_series evaluates, element by element, the series float Power is built from — the device stand-ins for the
+ * host libm calls of `(rhs * lhs.ln()).exp()` (src/kernels/arithmetic/std.rs:153, simd.rs:570,585):
+ *   which 0: in = f64 x,  out[i] = ln x           as the f64 Power path computes it (pow_f64_ln)
+ *   which 1: in = f32 a,  out[i] = ln a  in f64   as the f32 Power path computes it before rounding to f32 (pow_f32_ln)
+ *   which 2: in = f32 y,  out[i] = exp y in f64   as the f32 Power path computes it before rounding to f32 (pow_f32_exp;
+ *                                                 |y| <= 150)
+ * tests/test_gpu_pow_series.py holds them to tests/golden/pow_series_kat.npz (tools/check_pow_series.py: 265-bit decimal
+ * arithmetic). Buffers may be host or device memory.
+ * ---------------------------------------------------------------------------------------------- */
+ma_status ma_test_pow_series(ma_ctx* ctx, int32_t which, const void* in, double* out, size_t n);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

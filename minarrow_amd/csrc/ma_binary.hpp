@@ -113,8 +113,11 @@ struct Elem<T, false> {
     }
 };
 
-// ln for the f64 Power path: 0.54 ULP against 200-bit arithmetic over 3 x 10^5 samples (glibc's log: 0.51) in a third of
-// the instructions of the library routine. ln x = e ln2 + 2 atanh(s), s = (m - 1) / (m + 1) on m in [1/sqrt2, sqrt2):
+// ln for the f64 Power path: max 0.518 ULP, mean 0.247 ULP, correctly rounded on 99.86 % of 106 931 inputs (subnormals, a
+// cloud around 1, every power of two and its neighbours) against 265-bit decimal arithmetic — glibc's log on the same
+// inputs: 0.608 / 0.247 / 99.67 % — in a third of the instructions of the library routine. Reproduce:
+// tools/check_pow_series.py -> tests/golden/pow_series_kat.npz -> tests/test_gpu_pow_series.py (bounds), tools/
+// pow_series_report.py -> profiles/r03_pow_series_accuracy.json (figures). ln x = e ln2 + 2 atanh(s), s = (m - 1) / (m + 1) on m in [1/sqrt2, sqrt2):
 // the quotient is carried as s_hi + s_lo (the residual f - s_hi (d + d_lo) comes out of one fma), the series runs to
 // s^23, and the one rounding that matters — e ln2_hi + 2 s_hi — is compensated (Fast2Sum).
 __device__ __forceinline__ double pow_f64_ln(double x) {
@@ -187,7 +190,9 @@ struct Elem<double, true> {
 
 // ln and exp for the f32 Power path, evaluated in f64 to ~2^-45 relative — far inside the half-ULP of the f32 value they
 // are rounded to, at a third of the instructions of the 1-ULP f64 routines (atanh series to s^15 on [1/sqrt2, sqrt2),
-// Taylor to r^11 on |r| <= ln2/2). Against the f64-libm formulation they replace: 1 result in 2 x 10^8 differs, by 1 ULP.
+// Taylor to r^11 on |r| <= ln2/2). Rounded to f32, both ARE the correctly rounded logf / expf values on every one of
+// 60 000 + 67 500 test inputs (subnormal to overflow), and f32 Power end to end equals the exact three-rounding formulation
+// RN32(exp(RN32(b * RN32(ln a)))) on all 60 000 test pairs (same fixture, same tests as above).
 __device__ __forceinline__ double pow_f32_ln(double x) {
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);

@@ -450,16 +450,18 @@ def test_float_power_random(gpu, oracle, tag):
         with np.errstate(invalid="ignore"):  # inf - inf on the non-finite entries, which are compared separately
             diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
         if tag == "f32":
-            # ln, product and exp are rounded to f32 at the same three points as the reference and each of the
-            # two transcendental steps is correctly rounded, like the host libm's logf/expf in all but rare
-            # cases: the results are the reference's bits almost everywhere. A 1-ulp ln difference, where it
-            # happens, is amplified by |b ln a|.
-            assert np.mean(diff[finite] == 0) > 0.98
-            assert np.all(diff[finite] <= (2 + 4 * x[finite]) * ulp[finite])
+            # ln, product and exp are rounded to f32 at the same three points as the reference, and the device's two
+            # transcendental steps ARE the correctly rounded ones (tests/test_gpu_pow_series.py: 100 % of 60 000 + 67 500
+            # inputs); the host libm's logf / expf are too in all but rare cases. Where one of them is not, the 1-ULP ln
+            # difference is amplified by |b ln a|.
+            assert np.mean(diff[finite] == 0) > 0.99
+            assert np.all(diff[finite] <= (1 + 2 * x[finite]) * ulp[finite])
         else:
-            # f64: two independent libms (OCML vs glibc), each <= 1 ulp per call; exp amplifies the ln and
-            # product differences by |b ln a|.
-            assert np.all(diff[finite] <= (4 + 2 * x[finite]) * ulp[finite])
+            # f64: the device's ln is within 0.52 ULP of exact, glibc's within 0.61 (same test file): they disagree on <1 % of
+            # inputs, by 1 ULP, which exp amplifies by |b ln a|; the two exp implementations are < 1 ULP each.
+            # (a 1-ULP ln difference moves the rounded product by up to 2 of ITS ulps, each worth up to |b ln a| result ulps)
+            assert np.all(diff[finite] <= (2 + 2 * x[finite]) * ulp[finite])
+            assert np.mean(diff[finite] <= ulp[finite]) > 0.98
         np.testing.assert_array_equal(got[~finite], want[~finite])
     # ln of a negative base is NaN, of zero -inf: same special-case structure as the reference
     got, _ = gpu.apply(tag, [-2.0, 0.0, 0.0, 1.0], [2.0, 2.0, -1.0, 1e30], "power")
