@@ -64,11 +64,23 @@ def cgroup_cpu_quota():
         return None
 
 
+def _mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(rows: int, budget_s: float):
     """Times the oracle's restatement of rayon_simd_sum_{i64,f64} (benches/benchmark_parallel_simd.rs:81-98) on
-    this box's host cores over a bounded sample of the same workload. The GPU boxes expose all host threads but cap
-    the container's CPU time (cgroup cpu.max), so several pool sizes are tried — quota, 4 x quota, every visible
-    thread — and the fastest is reported; best-of-N catches the un-throttled bursts."""
+    this box's host cores — on the metric's own 10^9 rows per column when the host has the memory for one 8-GB column at
+    a time (the reference's bench holds one too, :103-104, :115-116), on a bounded sample otherwise (`rows` says which).
+    The GPU boxes expose all host threads but cap the container's CPU time (cgroup cpu.max), so several pool sizes are
+    tried — quota, 4 x quota, every visible thread — and the fastest is reported; workers are pinned one per CPU of the
+    set the process may run on; best-of-N catches the un-throttled bursts, the median is reported next to it."""
     import numpy as np
 
     from oracle import oracle
@@ -76,17 +88,18 @@ def cpu_baseline(rows: int, budget_s: float):
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = cgroup_cpu_quota()
     candidates = sorted({visible} | ({min(visible, quota), min(visible, 4 * quota)} if quota else set()))
-    results = {}
-    arrays = {}
-    for dtype, name in ((np.int64, "i64"), (np.float64, "f64")):
-        a = np.empty(rows, dtype=dtype)
-        oracle.par_fill_iota(a, 0, min(visible, 4 * quota) if quota else visible)
-        arrays[name] = a
+    avail = _mem_available_bytes()
+    requested = rows
+    if rows <= 0:  # default: the metric's own size when one column (+ headroom) fits the host, else the 2^29-row sample
+        rows = 1_000_000_000 if (avail is not None and avail >= 12 * (1 << 30)) else 1 << 29
+    oracle.set_pool_pinning(True)
+    results = {t: {} for t in candidates}
     expect = rows * (rows - 1) // 2
     per_case = budget_s / (2 * len(candidates))
-    for threads in candidates:
-        detail = {}
-        for name, a in arrays.items():
+    for dtype, name in ((np.int64, "i64"), (np.float64, "f64")):  # one column at a time: half the host memory
+        a = np.empty(rows, dtype=dtype)
+        oracle.par_fill_iota(a, 0, min(visible, 4 * quota) if quota else visible)
+        for threads in candidates:
             got = oracle.par_sum(a, 1 << 20, 4, threads)  # warm-up (cf. benches/hotloop_benchmark_simd.rs:199-200)
             times = []
             t_end = time.perf_counter() + per_case
@@ -98,10 +111,14 @@ def cpu_baseline(rows: int, budget_s: float):
                 assert got == expect, (got, expect)
             else:
                 assert abs(got - float(expect)) <= 64 * math.ulp(float(expect)), (got, expect)
-            detail[name] = {"best_ms": min(times) * 1e3, "median_ms": sorted(times)[len(times) // 2] * 1e3,
-                            "reps": len(times), "grows_per_s": rows / min(times) / 1e9}
-        total_time = (detail["i64"]["best_ms"] + detail["f64"]["best_ms"]) * 1e-3
-        results[threads] = {"value": 2 * rows / total_time / 1e9, **detail}
+            med = sorted(times)[len(times) // 2]
+            results[threads][name] = {"best_ms": min(times) * 1e3, "median_ms": med * 1e3, "reps": len(times),
+                                      "grows_per_s": rows / min(times) / 1e9, "grows_per_s_median": rows / med / 1e9}
+        del a
+    for threads, detail in results.items():
+        total_best = (detail["i64"]["best_ms"] + detail["f64"]["best_ms"]) * 1e-3
+        total_med = (detail["i64"]["median_ms"] + detail["f64"]["median_ms"]) * 1e-3
+        results[threads] = {"value": 2 * rows / total_best / 1e9, "value_median": 2 * rows / total_med / 1e9, **detail}
     best_threads = max(results, key=lambda t: results[t]["value"])
     # BASELINE configs[0], the reference's own CPU-runnable case: the single-thread loops of
     # benches/hotloop_benchmark_std.rs:49-57 (scalar) and hotloop_benchmark_simd.rs:56-114 (4 lanes) over 10^6 rows.
@@ -119,16 +136,20 @@ def cpu_baseline(rows: int, budget_s: float):
     other = cpu_other_configs(oracle, np)
     return {
         "value": results[best_threads]["value"],
+        "value_median": results[best_threads]["value_median"],
         "unit": "Grows/s",
+        "rows": rows,
         # cores = CPUs' worth of time the pool can actually burn: the container's cgroup quota caps a larger pool
         "cores": min(best_threads, quota) if quota else best_threads,
         "pool_threads": best_threads,
         "cgroup_cpu_quota": quota,
         "host_threads_visible": visible,
         "kind": "port",
-        "sample": f"{rows}-row i64 + {rows}-row f64 iota columns, chunks of 2^20 rows, 4-lane accumulators, persistent "
-                  f"pool of {best_threads} threads (tried {candidates}; {visible} host threads visible, cgroup CPU quota "
-                  f"{quota if quota else 'none'}), best of N reps "
+        "sample": f"{rows} rows per column" + (" (the metric's own size)" if rows == 1_000_000_000 else " (bounded sample)") +
+                  f": a {rows}-row i64 and a {rows}-row f64 iota column, one at a time, chunks of 2^20 rows, 4-lane accumulators, "
+                  f"persistent pinned pool of {best_threads} threads (tried {candidates}; {visible} host threads visible, cgroup "
+                  f"CPU quota {quota if quota else 'none'}; host MemAvailable {avail // (1 << 30) if avail else '?'} GiB), "
+                  f"value = best of N reps, value_median = median "
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
         "detail": {str(t): r for t, r in results.items()},
         "config0_1m_rows": config0,
@@ -223,11 +244,16 @@ def gpu_other_configs(ctx, n: int, reps: int):
         e.update(extra)
         return e
 
-    # The OUTPUT buffer first, through the placement-aware allocator (ma_dev_alloc_output: the fastest-writing of up to three
-    # candidate blocks; the rejected candidates are parked and come back as the inputs below, which read at the same rate
-    # wherever they are — DESIGN.md §3.4).
+    # Two OUTPUT buffers. `o_plain` is what a caller who brings its own `out` has (the ABI's normal contract: the reference
+    # allocates `out` per call, src/kernels/arithmetic/dispatch.rs:88-89): the process's first ma_dev_alloc block, wherever
+    # the driver put it. `o` comes from the placement-aware allocator (ma_dev_alloc_output: the fastest-writing of a bounded
+    # number of candidate blocks; the rejected candidates are parked and come back as the inputs below, which read at the
+    # same rate wherever they are — DESIGN.md §3.4). Every read+write figure below is on `o`; the copy and a + b are timed on
+    # BOTH, and what the search cost (wall time outside every timed region, bytes held while it ran) is in the line.
+    o_plain = ctx.alloc(n * 8)
     o = ctx.alloc_output(n * 8)
     res["output_block_write_gbps"] = o.write_gbps
+    res["output_allocator"] = dict(getattr(o, "alloc_stats", {}), bytes_requested=n * 8)
     a, b = (ctx.alloc(n * 8) for _ in range(2))
     mask_bytes = ((n + 511) // 512) * 64 + 64
     mask, om = ctx.alloc(mask_bytes), ctx.alloc(mask_bytes)
@@ -242,6 +268,15 @@ def gpu_other_configs(ctx, n: int, reps: int):
     ms = _timed(ctx, lambda: ctx.dev_copy(o, a, n * 8), reps)
     res["copy_hipMemcpyDtoD"] = entry(ms, 16, n)
     copy_gbps = max(res["copy_kernel_16B_per_lane"]["gbps"], res["copy_hipMemcpyDtoD"]["gbps"])
+    # the same two kernels into the plain block: what the numbers are WITHOUT shopping for memory
+    ms_c = _timed(ctx, lambda: ctx.consolidate_column(8, [a], [n], o_plain), reps)
+    ms_a = _timed(ctx, lambda: ctx.apply("f64", a, b, OPS["add"], o_plain, n, n), reps)
+    res["plain_output_block"] = {
+        "copy_kernel_16B_per_lane": entry(ms_c, 16, n), "add_array_array": entry(ms_a, 24, n),
+        "note": "output = the process's first plain ma_dev_alloc block (no placement search): the figures a caller-provided "
+                "`out` gets on this box"}
+    ctx.synchronize()
+    o_plain.free()
 
     # ---- config 3: f64 add / mul, array (+) array and array (+) scalar (fused broadcast) ---------------------------
     def windows_equal(buf, fn, starts, count=4096):
@@ -1159,7 +1194,8 @@ def main() -> int:
                          "metric as BASELINE names it; weak = every GPU scans its own --rows rows")
     ap.add_argument("--group-issue", default="threads", choices=["threads", "caller"],
                     help="one-process mode: per-member issue threads (default) or the calling thread issues for every GPU")
-    ap.add_argument("--cpu-rows", type=int, default=1 << 29, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows per column of the CPU baseline (0 = 10^9, the metric's size, when the host has the memory; else 2^29)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE configs 3-5 (N = 1 only)")

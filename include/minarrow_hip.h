@@ -87,9 +87,18 @@ int32_t ma_abi_version(void);
 /* Number of devices the library may use: the visible HIP devices, or the entries of MINARROW_HIP_DEVICES (0 when there
  * is none; never initialises a device context). Device ordinals of this ABI index that list. */
 int32_t ma_device_count(void);
-/* Column length below which a host wrapper should keep the reference's CPU kernels (MINARROW_HIP_MIN_ROWS, default
- * 65536): a synchronous GPU call costs ~12-14 us whatever the size, the reference's 1000-row scalar sum 85 ns
- * (src/lib.rs:58). Advice for the host shim only — the library itself has no CPU path and accepts any length. */
+/* Column length below which a host wrapper should keep the reference's CPU kernels, per kind of call — derived from
+ * measurements (INTEGRATION.md §5 has the table and the profiles/ files): a synchronous call on a resident column costs
+ * ~12 us whatever the size, ONE host thread sums 18.8 cache-resident i64 rows per ns (the reference's 1000-row scalar sum:
+ * 85 ns, src/lib.rs:58) and adds two f64 columns at 2-4 rows per ns:
+ *   MA_KIND_REDUCTION     sums / means         262 144 rows  (MINARROW_HIP_MIN_ROWS)
+ *   MA_KIND_ELEMENTWISE   a (+) b, a (+) x      32 768 rows  (MINARROW_HIP_MIN_ROWS_ELEMENTWISE)
+ *   MA_KIND_BITMASK_SCAN  popcount / all_true  2 097 152 bits (MINARROW_HIP_MIN_BITS_SCAN)
+ * ma_min_device_rows() is the reduction figure. For MANY small columns use one ma_sum_columns call (0.24 us per column)
+ * or a replayed hipGraph rather than a call each. Advice for the host shim only — the library itself has no CPU path and
+ * accepts any length. */
+enum { MA_KIND_REDUCTION = 0, MA_KIND_ELEMENTWISE = 1, MA_KIND_BITMASK_SCAN = 2 };
+int64_t ma_min_device_rows_for(int32_t kind);
 int64_t ma_min_device_rows(void);
 /* Thread-local description of the last non-OK status returned on this thread. Never NULL. */
 const char* ma_last_error_string(void);
@@ -174,15 +183,22 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
  * TB/s under the kernels' store pattern, the rest at 6.3-6.8, while all of them read at 7.1-7.3. For
  * blocks of 256 MiB and more (MINARROW_HIP_OUTPUT_MIN_BYTES) this entry point tries 6 candidate blocks
  * (MINARROW_HIP_OUTPUT_CANDIDATES; 1 = off; parked blocks of the size class first, then fresh ones), and up to 6 more
- * while the best is still below the good rate — so up to twelve times the block's size is held while the search runs,
- * less when HBM is short (the search then settles for what it has). Each candidate's write rate is measured once with
- * three launches of the store pattern (~1.3 ms each per 8 GB; the rate is remembered for as long as the library owns
- * the block); the search stops at the first block that reaches 6200 GB/s (MINARROW_HIP_OUTPUT_GOOD_GBPS), returns the
- * fastest and parks the others in the block cache, where ma_dev_alloc picks them up as inputs. The probe tells the two
- * classes apart but is no promise: on boxes where every candidate was a slow region the best block wrote at 5.8 TB/s. The block's contents are undefined (the probe
- * writes zeros). out_write_gbps (may be NULL) receives the chosen block's measured rate, 0 when nothing was measured.
- * Free with ma_dev_free. */
+ * while the best is still below the good rate. Candidates are held while the search runs (a block given back would be the
+ * next one handed out), so the search is BOUNDED: the blocks alive at one time never exceed 25 % of the HBM that is free
+ * when the call starts (MINARROW_HIP_OUTPUT_HOLD_PERCENT), the search stops at that many, and a request two of which do not
+ * fit the bound — a 64-GB consolidated column on a 288-GB device — is served by the plain allocator without measuring
+ * anything. Each candidate's write rate is measured once with three launches of the store pattern (~1.3 ms each per 8 GB;
+ * the rate is remembered for as long as the library owns the block); the search stops at the first block that reaches the
+ * good rate = 0.97 x the device's own write ceiling (the placement-independent tight-front pattern, measured once per device;
+ * MINARROW_HIP_OUTPUT_GOOD_GBPS overrides), returns the fastest and parks the others in the block cache, where ma_dev_alloc
+ * picks them up as inputs. The probe tells the two classes apart but is no promise: on boxes where every candidate was a slow
+ * region the best block wrote at 5.8 TB/s. The block's contents are undefined (the probe writes zeros). out_write_gbps (may
+ * be NULL) receives the chosen block's measured rate, 0 when nothing was measured. Free with ma_dev_free.
+ * ma_dev_alloc_output_stats: what the calling thread's last search cost — wall time, bytes held at its peak, blocks measured /
+ * considered, the good rate it compared against (all 0 when the plain path was taken; any pointer may be NULL). */
 ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, float* out_write_gbps);
+ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak_bytes, int32_t* out_blocks_measured,
+                                    int32_t* out_blocks_considered, float* out_good_gbps);
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
 ma_status ma_dev_pool_trim(ma_ctx* ctx, size_t keep_bytes);
 /* Cache limit of the context's device without releasing anything. Every device allocation the library makes for

@@ -595,10 +595,25 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// Write-only: the whole grid advances as ONE 1-MiB front — one workgroup per CU, one 16-byte store per lane (1 KiB per
+// wave) per step — the pattern that writes 6.3-6.5 TB/s wherever the driver placed the block (the tiled
+// bursts of the read+write kernels write 5.4-5.7 TB/s on three blocks in four). `head` rows in front of the first
+// 16-byte boundary and the < 16 bytes behind the last whole vector go one row per lane.
 template <typename T, typename F>
-__global__ __launch_bounds__(kBlock) void fill_kernel(T* __restrict__ dst, size_t n, F f) {
-    size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = f(i);
+__global__ __launch_bounds__(kBlock) void fill_kernel(T* __restrict__ dst, size_t n, size_t head, F f) {
+    constexpr int R = 16 / (int)sizeof(T);
+    typedef T V __attribute__((ext_vector_type(R)));
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = tid; i < head; i += stride) dst[i] = f(i);
+    const size_t n_vec = (n - head) / R;
+    V* __restrict__ out = (V*)(dst + head);
+    for (size_t v = tid; v < n_vec; v += stride) {
+        V x;
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = f(head + v * R + k);
+        __builtin_nontemporal_store(x, out + v);
+    }
+    for (size_t i = head + n_vec * R + tid; i < n; i += stride) dst[i] = f(i);
 }
 
 __global__ __launch_bounds__(kBlock) void validity_kernel(uint64_t* __restrict__ words, size_t n_bits, uint64_t seed,
@@ -625,8 +640,12 @@ static ma_status launch_fill(ma_ctx* ctx, T* dst, size_t n, F f) {
                "synthetic generators need a device-reachable destination");
     MA_ENTER(ctx);
     MA_HIP(hipSetDevice(ctx->device));
-    int grid = grid_for(ctx, (n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((fill_kernel<T, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, dst, n, f);
+    const uintptr_t mis = (uintptr_t)dst & 15;
+    size_t head = mis ? (16 - mis) / sizeof(T) : 0;
+    if (head > n) head = n;
+    const size_t work = (n * sizeof(T) / 16 + kBlock - 1) / kBlock;
+    const int grid = (int)(work < (size_t)ctx->num_cus ? (work ? work : 1) : (size_t)ctx->num_cus);  // one workgroup per CU
+    hipLaunchKernelGGL((fill_kernel<T, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, dst, n, head, f);
     MA_HIP(hipGetLastError());
     if (!is_async(ctx)) MA_TRY(stream_wait(ctx));
     return MA_OK;
@@ -703,13 +722,26 @@ static const std::vector<int>& device_map() {
 
 int32_t ma_device_count(void) { return physical_device_count() > 0 ? (int32_t)device_map().size() : 0; }
 
-int64_t ma_min_device_rows(void) {
-    // MINARROW_HIP_MIN_ROWS: the column length below which a host wrapper should keep its CPU kernels — a GPU call costs
-    // ~12-17 us synchronously whatever the size (profiles/r02_sync_latency_polled.jsonl), the reference's scalar sum of 1000 rows
-    // 85 ns (src/lib.rs:58). The library itself never computes on the CPU; this is advice the host shim reads.
-    static const int64_t rows = (int64_t)env_bytes("MINARROW_HIP_MIN_ROWS", (size_t)1 << 16);
-    return rows;
+// The column length below which a host wrapper should keep the reference's CPU kernels. Derived from what was measured
+// (INTEGRATION.md §5 has the table): a synchronous call on a resident column costs 11.4-12.1 us up to 65 536 rows and
+// 13-15 us at 2^20 (profiles/r02_sync_latency_stream_stamp.json); ONE host thread sums 18.8 i64 rows per ns while the
+// column is cache-resident (BENCH_r02 cpu_baseline.config0_1m_rows: 10^6 rows in 53 us) and adds two f64 columns at
+// 1.9 rows per ns from DRAM, ~4 from cache (other_configs_single_thread). Crossovers: a sum 12 us x 18.8 = 2.2 x 10^5 rows
+// (-> 2^18); an elementwise a (+) b 12 us x 3 = 3.6 x 10^4 rows (-> 2^15); a bitmap scan (popcount, ~150 bits per ns on the
+// host) 10.5 us x 150 = 1.6 x 10^6 bits (-> 2^21). Many small columns: one ma_sum_columns call (0.24 us per column) or a
+// replayed hipGraph instead of a call each. The library itself never computes on the CPU; this is advice the host reads.
+int64_t ma_min_device_rows_for(int32_t kind) {
+    static const int64_t reduce = (int64_t)env_bytes("MINARROW_HIP_MIN_ROWS", (size_t)1 << 18);
+    static const int64_t elementwise = (int64_t)env_bytes("MINARROW_HIP_MIN_ROWS_ELEMENTWISE", (size_t)1 << 15);
+    static const int64_t scan_bits = (int64_t)env_bytes("MINARROW_HIP_MIN_BITS_SCAN", (size_t)1 << 21);
+    switch (kind) {
+        case MA_KIND_ELEMENTWISE: return elementwise;
+        case MA_KIND_BITMASK_SCAN: return scan_bits;
+        default: return reduce;
+    }
 }
+
+int64_t ma_min_device_rows(void) { return ma_min_device_rows_for(MA_KIND_REDUCTION); }
 
 const char* ma_last_error_string(void) { return g_err; }
 
@@ -1124,10 +1156,19 @@ __global__ __launch_bounds__(kBlock) void probe_write_kernel(ProbeVec* __restric
     }
 }
 
+// The placement-INDEPENDENT write pattern: the whole grid advances as one 1-MiB front — one workgroup per
+// CU, one 1-KiB store per wave per step. 6.3-6.5 TB/s on every block measured, fast or slow: the device's write ceiling,
+// which is what the output allocator calibrates its "good block" threshold against (once per device).
+__global__ __launch_bounds__(kBlock) void front_write_kernel(ProbeVec* __restrict__ out, size_t n_vecs) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_vecs; i += stride)
+        __builtin_nontemporal_store(ProbeVec{0u, 0u, 0u, 0u}, out + i);
+}
+
 // Write rate of a device block in GB/s: three launches of probe_write_kernel, the faster of the last two counts (one
 // 1.3-ms sample is at the mercy of whatever else the device was finishing). The block's contents are overwritten with
 // zeros. The caller holds the context.
-static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, float* out_gbps) {
+static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, float* out_gbps, bool tight_front = false) {
     const size_t n_tiles = bytes / (16 * 64 * 8 * kWaves);
     *out_gbps = 0.f;
     if (n_tiles == 0) return MA_OK;
@@ -1136,12 +1177,19 @@ static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, floa
     for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&ev[i]);
     const size_t cap = (size_t)ctx->num_cus * 6;
     const int grid = (int)(n_tiles < cap ? n_tiles : cap);
+    const size_t n_vecs = n_tiles * 64 * 8 * kWaves;
+    auto launch = [&] {
+        if (tight_front)
+            hipLaunchKernelGGL(front_write_kernel, dim3(ctx->num_cus), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_vecs);
+        else
+            hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+    };
     float ms = 0.f;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+        launch();
         for (int i = 0; i < 3; ++i) {
             (void)hipEventRecord(ev[i], ctx->stream);
-            if (i < 2) hipLaunchKernelGGL(probe_write_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (ProbeVec*)block, n_tiles);
+            if (i < 2) launch();
         }
         e = hipEventSynchronize(ev[2]);
         float m1 = 0.f, m2 = 0.f;
@@ -1159,10 +1207,19 @@ static ma_status measure_write_gbps(ma_ctx* ctx, void* block, size_t bytes, floa
 
 extern "C" {
 
+// What the last ma_dev_alloc_output search on this thread cost (ma_dev_alloc_output_stats).
+static thread_local double t_out_ms = 0.0;
+static thread_local size_t t_out_held = 0;
+static thread_local int32_t t_out_measured = 0, t_out_considered = 0;
+static thread_local float t_out_good = 0.f;
+
 ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, float* out_write_gbps) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;
     if (out_write_gbps) *out_write_gbps = 0.f;
+    t_out_ms = 0.0;
+    t_out_held = 0;
+    t_out_measured = t_out_considered = 0;
     MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "device allocation of %zu bytes is too large", bytes);
     MA_ENTER_PRIMARY(ctx);
     MA_NO_CAPTURE(ctx, "ma_dev_alloc_output");
@@ -1170,30 +1227,71 @@ ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, flo
     // Small blocks, or the feature switched off: the plain allocator.
     static const size_t kMinBytes = env_bytes("MINARROW_HIP_OUTPUT_MIN_BYTES", (size_t)256 << 20);
     static const size_t kCandidates = env_bytes("MINARROW_HIP_OUTPUT_CANDIDATES", 6);
-    static const float kGoodGbps = (float)env_bytes("MINARROW_HIP_OUTPUT_GOOD_GBPS", 6200);
+    static const float kGoodEnv = (float)env_bytes("MINARROW_HIP_OUTPUT_GOOD_GBPS", 0);  // 0 = calibrate (below)
+    static const size_t kHoldPercent = env_bytes("MINARROW_HIP_OUTPUT_HOLD_PERCENT", 25);
     const int dev = ctx->device;
     if (bytes < kMinBytes || kCandidates <= 1 || dev < 0 || dev >= kMaxPooledDevices) {
         MA_HIP(dev_block_alloc(dev, bytes, out_dev_ptr));
         return MA_OK;
     }
+    // The search holds its candidates while it runs — a block given back would be handed out again by the very next
+    // allocation, and nothing new would be explored — so it is BOUNDED: the candidates alive at one time never exceed
+    // MINARROW_HIP_OUTPUT_HOLD_PERCENT (25) of the HBM that is free when the call starts, the search stops when that many
+    // are held, and an output too large for two candidates to fit the bound (a 64-GB consolidated column) takes the plain
+    // path without measuring anything.
+    size_t free_b = 0, total_b = 0;
+    MA_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t rounded = pool_size_of(bytes);
     PinnedPool& pool = device_pool(dev);
+    size_t parked_same = 0;  // parked blocks of this size class are candidates that take no new memory
+    {
+        std::lock_guard<std::mutex> plock(pool.mu);
+        auto it = pool.parked.find(rounded);
+        if (it != pool.parked.end()) parked_same = it->second.size();
+    }
+    const size_t budget = free_b / 100 * kHoldPercent;
+    const size_t max_live = budget / rounded + parked_same;
+    if (max_live < 2) {
+        MA_HIP(dev_block_alloc(dev, bytes, out_dev_ptr));
+        return MA_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     // Candidates come from the block cache first (parked blocks of this size class cost nothing to try), then from
     // the runtime; the search stops at the first block that writes at the fast regions' rate.
     std::vector<std::pair<void*, float>> tried;
     void* best = nullptr;
     float best_rate = -1.f;
     size_t measured = 0;
+    // "Good" = 0.97 of the device's own write ceiling — the rate of the placement-independent tight-front pattern, measured
+    // once per device on the first candidate (6.3-6.5 TB/s on the MI355X boxes seen, so ~6.2 TB/s; fast regions reach
+    // 6.6-6.8 with the kernels' pattern, slow ones 5.4-5.8). MINARROW_HIP_OUTPUT_GOOD_GBPS overrides.
+    static std::mutex cal_mu;
+    static float cal_good[kMaxPooledDevices] = {};
+    float good = kGoodEnv;
     // Parked blocks whose rate is already known cost nothing to consider: only fresh measurements count against the
     // limit. Most regions are slow ones (about three in four on the boxes measured): while nothing has reached the good
     // rate the search goes on once more, to twice the limit.
-    while (measured < 2 * kCandidates && tried.size() < 2 * kCandidates + 8) {
-        if (measured >= kCandidates && best_rate >= 0.97f * kGoodGbps) break;
+    while (measured < 2 * kCandidates && tried.size() < 2 * kCandidates + 8 && tried.size() < max_live) {
+        if (measured >= kCandidates && best_rate >= 0.97f * good) break;
         void* blk = nullptr;
         hipError_t e = dev_block_alloc(dev, bytes, &blk);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             if (tried.empty()) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
             break;  // HBM is full: keep the best of what there is
+        }
+        if (good <= 0.f) {
+            std::lock_guard<std::mutex> cl(cal_mu);
+            if (cal_good[dev] <= 0.f) {
+                float ceiling = 0.f;
+                ma_status st = measure_write_gbps(ctx, blk, bytes, &ceiling, true);
+                if (st != MA_OK) {
+                    (void)dev_block_free(dev, blk);
+                    return st;
+                }
+                cal_good[dev] = ceiling > 0.f ? 0.97f * ceiling : 6200.f;
+            }
+            good = cal_good[dev];
         }
         float rate = 0.f;
         bool known = false;
@@ -1221,13 +1319,28 @@ ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, flo
             best_rate = rate;
             best = blk;
         }
-        if (rate >= kGoodGbps) break;
+        if (rate >= good) break;
     }
     // The others go (back) to the block cache: they read as fast as any block and serve as inputs.
     for (auto& t : tried)
         if (t.first != best) (void)dev_block_free(dev, t.first);
+    t_out_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    t_out_held = tried.size() * rounded;
+    t_out_measured = (int32_t)measured;
+    t_out_considered = (int32_t)tried.size();
+    t_out_good = good;
     *out_dev_ptr = best;
     if (out_write_gbps) *out_write_gbps = best_rate;
+    return MA_OK;
+}
+
+ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak_bytes, int32_t* out_blocks_measured,
+                                    int32_t* out_blocks_considered, float* out_good_gbps) {
+    if (out_search_ms) *out_search_ms = t_out_ms;
+    if (out_held_peak_bytes) *out_held_peak_bytes = t_out_held;
+    if (out_blocks_measured) *out_blocks_measured = t_out_measured;
+    if (out_blocks_considered) *out_blocks_considered = t_out_considered;
+    if (out_good_gbps) *out_good_gbps = t_out_good;
     return MA_OK;
 }
 

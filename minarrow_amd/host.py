@@ -67,6 +67,13 @@ class DeviceBuffer:
             rate = C.c_float()
             ffi.check(ctx.lib.ma_dev_alloc_output(ctx.handle, self.nbytes, C.byref(p), C.byref(rate)))
             self.write_gbps = float(rate.value)
+            ms, held, measured, considered, good = C.c_double(), C.c_size_t(), C.c_int32(), C.c_int32(), C.c_float()
+            ffi.check(ctx.lib.ma_dev_alloc_output_stats(C.addressof(ms), C.addressof(held), C.addressof(measured),
+                                                        C.addressof(considered), C.addressof(good)))
+            # what the placement search cost: wall time, bytes held at its peak, blocks probed / looked at, the threshold
+            self.alloc_stats = {"search_ms": float(ms.value), "candidates_held_bytes": int(held.value),
+                                "blocks_measured": int(measured.value), "blocks_considered": int(considered.value),
+                                "good_gbps": float(good.value)}
         else:
             ffi.check(ctx.lib.ma_dev_alloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = int(p.value)

@@ -20,8 +20,12 @@
  * Build: `make -C oracle` (gcc, -O3 -march=native, -ffp-contract=off so that nothing is fused that the
  * reference does not fuse).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET: pinning of the bench pool */
+#endif
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -228,9 +232,31 @@ static struct {
     int active;      /* workers with index < active take part in the current job */
 } mo_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, NULL, 0, 0, 0};
 
+/* bench.py's cpu_baseline pins the pool: worker k stays on the k-th CPU (mod their number) of the set the process may
+ * run on — its cgroup's cpuset as sched_getaffinity reports it — so that the timed passes are not at the mercy of
+ * migrations between the box's many idle cores (best-of-N 11 ms against a 16 ms median was the symptom). */
+static int mo_pool_pinning = 0;
+MO_API void mo_pool_set_pinning(int on) { mo_pool_pinning = on; }
+static void mo_pin_self(int index) {
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    const int n = CPU_COUNT(&allowed);
+    if (n <= 0) return;
+    int want = index % n, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &allowed) && seen++ == want) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(c, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            return;
+        }
+}
+
 static void* mo_pool_worker(void* index_ptr) {
     const int index = (int)(intptr_t)index_ptr;
     unsigned long seen = 0;
+    if (mo_pool_pinning) mo_pin_self(index + 1); /* the caller is thread 0 */
     for (;;) {
         pthread_mutex_lock(&mo_pool.mu);
         while (mo_pool.generation == seen || index >= mo_pool.active) {

@@ -133,6 +133,11 @@ def par_sum(a: np.ndarray, chunk: int = 1 << 20, lanes: int = 4, threads: int = 
     raise TypeError(a.dtype)
 
 
+def set_pool_pinning(on: bool) -> None:
+    """Pool workers created from now on stay on one CPU each of the set the process may run on (bench.py's cpu_baseline)."""
+    lib().mo_pool_set_pinning(1 if on else 0)
+
+
 def par_fill_iota(a: np.ndarray, start: int = 0, threads: int = 1) -> None:
     lib().mo_par_fill_iota(_p(a), a.size, start, 1 if a.dtype == np.float64 else 0, threads)
 

@@ -99,6 +99,20 @@ def main():
             ctx.synth_iota("i64", b, B // 8, 0x0301070503010703)
         return n
 
+    # ---- write-only kernels: the tight 1-MiB front, on the picked output block AND on a plain one (this
+    # pattern writes at the same rate wherever the driver placed the block) ----
+    if want("fill"):
+        ctx.set_async(True)
+        for name, buf in (("picked output block", o), ("plain block", c)):
+            for tag in ("f64", "i32"):
+                n = B // SIZE[tag]
+                ms = timed(lambda: ctx.synth_iota(tag, buf, n, 1))
+                emit("fill", tag, f"synth_iota into the {name}", ms, B, n)
+            ms = timed(lambda: ctx.dev_memset(buf, 0xFF, B))
+            emit("fill", "bytes", f"constant fill (hipMemsetAsync: constant bitmaps) into the {name}", ms, B, B)
+        ctx.set_async(False)
+        ctx.synchronize()
+
     # ---- reductions ----
     for tag in ("i64", "u64", "f64", "i32", "u32", "f32"):
         if not want("sum"):
