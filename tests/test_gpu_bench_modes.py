@@ -85,3 +85,25 @@ def test_launcher_mode_one_rank(exchange, extra):
     assert want in out["config"]["exchange"]
     if extra:
         assert "side stream" in out["config"]["exchange"]
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_launcher_rehearsal_partitions_the_column_over_several_ranks(ranks):
+    """The N > 1 headline's own code path with more than one rank on a one-GPU box: `--backend gloo` lets the ranks share
+    the visible GPU (RCCL refuses that) and carries the 64-byte records over host memory — never a reported number, but
+    the strong-scaling partition (64-row-aligned row chunks of ONE 2^24 + 5-row column pair, ragged last chunk), the
+    per-rank generation at the chunk's offset, the rank-ordered fold and the same-process N = 1 leg all run for real."""
+    rows = (1 << 24) + 5
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(29650 + ranks), "bench.py", "--rows", str(rows), "--steps", "3", "--warmup", "1",
+               "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline"])
+    assert out["parity_ok"] and out["n_gpus"] == ranks and out["scaling"] == "strong"
+    assert out["config"]["rows_total_per_column"] == rows and out["result"]["rows"] == rows
+    assert out["config"]["rows_per_gpu_per_column"] == ((rows // ranks) // 64) * 64  # rank 0's 64-row-aligned chunk
+    assert out["result"]["i64_sum"] == rows * (rows - 1) // 2 and out["result"]["f64_ulps_from_exact"] <= 1.0
+    assert "REHEARSAL" in out["config"]["parallelism"] and out["config"]["rccl_ranks"] == 0
+    assert out["n1_same_process"]["rows_per_column"] == rows and out["efficiency_vs_n1"] > 0
+    weak = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                "127.0.0.1", "--master-port", str(29660 + ranks), "bench.py", "--rows", str(1 << 22), "--steps", "2", "--warmup", "1",
+                "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline", "--scaling", "weak"])
+    assert weak["parity_ok"] and weak["scaling"] == "weak" and weak["result"]["rows"] == ranks << 22
