@@ -612,7 +612,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     res = {}
 
     def timed_steps(step):
-        for _ in range(2):
+        for _ in range(4):  # first touches of every GPU's buffers, communicator and fold kernel stay outside the clock
             step()
         group.synchronize()
         t0 = time.perf_counter()
@@ -760,7 +760,9 @@ def run_group(args, result_fd) -> int:
     world = args.gpus
     scaling, total_rows, chunks = _split(args, world)
     lens = [hi - lo for lo, hi in chunks]
-    group = Group(list(range(world)), exchange="host" if args.exchange == "host" else "rccl-or-host",
+    overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
+    group = Group(list(range(world)),
+                  exchange="host" if args.exchange == "host" else ("rccl-overlap-or-host" if overlap else "rccl-or-host"),
                   issue="caller" if args.group_issue == "caller" else "threads")
     ctxs = [group.member_ctx(i) for i in range(world)]
     for c in ctxs:
@@ -803,7 +805,8 @@ def run_group(args, result_fd) -> int:
         kernels[name] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
     out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
                        f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
-                       ("RCCL all-gather (ncclCommInitAll; one call per member issue thread) + device fold, on the scan streams"
+                       ("RCCL all-gather (ncclCommInitAll; one call per member issue thread) + device fold, " +
+                        ("on side streams, overlapped with the next step's scans" if overlap else "on the scan streams")
                         if group.exchange_kind == "rccl" else "host fold of pinned records") +
                        (f" [{group.exchange_note}]" if group.exchange_note else ""),
                        {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process",
@@ -995,12 +998,10 @@ def run_ranks(args, result_fd) -> int:
     # [4] f64 count (minarrow_amd/parallel.py). Overlap: the exchange + fold of step k run on a side stream while the
     # main stream already scans step k + 1 (two record sets in flight; a step's scans wait for the exchange that last
     # used their record set). Default at N > 1: the partitioned column leaves each GPU 0.14 ms of scan per column, and
-    # an all-gather's latency is a fifth of that. With the native communicator the side stream is the communicator's
-    # context; with torch's exchange it is the stream torch.distributed's collective is issued under.
+    # an all-gather's latency is a fifth of that. With the native communicator the library does it itself
+    # (ma_comm_sum_exchange_overlapped: its own stream, device-scope events); with torch's exchange the side stream is the
+    # one torch.distributed's collective is issued under.
     overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and not rehearsal and world > 1)
-    side = torch.cuda.Stream(dev) if overlap else stream
-    ctx_side = Context(device_index, stream=side.cuda_stream) if overlap else ctx
-    ctx_side.set_async(True)
     # The exchange. Native: the library's own RCCL communicator (ma_comm_*: ncclCommInitRank from an id rank 0 made and
     # torch.distributed's store carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up
     # on every rank (or --exchange torch) the same records go through torch.distributed's all-gather instead.
@@ -1009,7 +1010,7 @@ def run_ranks(args, result_fd) -> int:
         try:
             ids = [Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            comm = Comm(ctx_side, ids[0], rank, world)
+            comm = Comm(ctx, ids[0], rank, world)
         except Exception as e:  # noqa: BLE001 — any failure means the torch path
             comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
         flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
@@ -1018,6 +1019,10 @@ def run_ranks(args, result_fd) -> int:
             comm.close()
             comm = None
             comm_note = "native communicator unavailable on another rank"
+    torch_overlap = overlap and comm is None
+    side = torch.cuda.Stream(dev) if torch_overlap else stream
+    ctx_side = Context(device_index, stream=side.cuda_stream) if torch_overlap else ctx
+    ctx_side.set_async(True)
 
     exs = [ScalarExchange(dev) for _ in range(2 if overlap else 1)]
     scanned = [torch.cuda.Event() for _ in exs]
@@ -1030,7 +1035,9 @@ def run_ranks(args, result_fd) -> int:
         k = counter[0] % len(exs)
         counter[0] += 1
         ex = exs[k]
-        if overlap and in_use[k]:
+        if overlap and comm is not None:
+            comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
+        elif overlap and in_use[k]:
             stream.wait_event(exchanged[k])
         if ev:
             ev[0].record(stream)
@@ -1040,16 +1047,15 @@ def run_ranks(args, result_fd) -> int:
         ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if ev:
             ev[2].record(stream)
-        if overlap:
+        if overlap and comm is not None:  # all-gather + fold on the communicator's own stream; this one goes on
+            comm.sum_exchange_overlapped(k, ex.local, 1, 1, ex.gathered, ex.final)
+            ex._folded_on_device = True
+        elif overlap:
             scanned[k].record(stream)
             with torch.cuda.stream(side):
                 side.wait_event(scanned[k])
-                if comm is not None:  # bound to ctx_side: all-gather + fold are enqueued on the side stream
-                    comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
-                    ex._folded_on_device = True
-                else:
-                    ex.exchange()
-                    ex.fold_on_device(ctx_side)
+                ex.exchange()
+                ex.fold_on_device(ctx_side)
                 exchanged[k].record(side)
             in_use[k] = True
         elif comm is not None:
@@ -1129,8 +1135,9 @@ def run_ranks(args, result_fd) -> int:
             col_f = torch.empty(orows, dtype=torch.float64, device=dev)
             ctx.synth_iota("i64", col_i, orows, rank * orows)
             ctx.synth_iota("f64", col_f, orows, rank * orows)
-            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, orows, args.other_reps, rank, world,
-                                        comm_stream=side if overlap else None)
+            if comm is not None:
+                comm.synchronize()  # the other legs use the in-stream exchange: nothing of the headline's may be in flight
+            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, orows, args.other_reps, rank, world)
             if not multi["parity_ok"]:
                 rc = 1
         except Exception as e:  # noqa: BLE001 — the headline line must still be printed
@@ -1212,8 +1219,8 @@ def main() -> int:
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
-                    help="one process per GPU: run each step's scalar exchange on a side stream, overlapped with the next "
-                         "step's scans. auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
+                    help="run each step's scalar exchange on a side stream, overlapped with the next "
+                         "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP; torch events with --exchange torch). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
                          "it costs the scan more than it saves there, 876 vs 889 Grows/s)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")

@@ -789,6 +789,12 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  *                            for the float pairs because its sum rounds at every hop.
  *   (default)                the kernels write their records into pinned host memory and the host folds the G x 64
  *                            bytes in member order after the streams drain: no collective is needed inside one process.
+ *   MA_GROUP_EXCHANGE_OVERLAP  with MA_GROUP_EXCHANGE_RCCL: ma_group_exchange issues the all-gather + fold of the record set
+ *                            just filled on a second stream per member, behind that member's scans, and the members'
+ *                            streams go straight on with the next step's scans into a SECOND record set (two steps in
+ *                            flight; a set is re-filled only behind its last exchange). For back-to-back steps whose scans
+ *                            are short against the exchange — a 10^9-row column over 8 GPUs: 0.14 ms per scan. ma_group_result
+ *                            reads the set of the most recent exchange. (The multi-process twin: ma_comm_sum_exchange_overlapped.)
  *   MA_GROUP_EXCHANGE_FALLBACK_HOST  with MA_GROUP_EXCHANGE_RCCL: use the host fold when RCCL cannot be initialised
  *                            (library missing, members sharing a device); ma_group_exchange_note() then says why.
  * ma_group_create() = ma_group_create_ex() with flags 0, or RCCL|FALLBACK_HOST when the environment variable
@@ -816,7 +822,7 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ma_group ma_group;
 #define MA_GROUP_MAX_COLUMNS 16
-enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2, MA_GROUP_ISSUE_CALLER = 4 };
+enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2, MA_GROUP_ISSUE_CALLER = 4, MA_GROUP_EXCHANGE_OVERLAP = 8 };
 ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
 ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group);
 void ma_group_destroy(ma_group* group);
@@ -892,6 +898,13 @@ ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, con
  *       in that order into out_finals[4c .. 4c+3] = [integer sum, integer count, f64 sum bits, float count] — the
  *       job's finals, bit-identical on every rank (ma_fold_sum_records' rule). slots_per_rank > 1 serves a rank that
  *       holds several batches of a SuperTable (src/structs/chunked/super_table.rs:78-83): the fold is in batch order.
+ *   ma_comm_sum_exchange_overlapped  the same exchange on a stream of the communicator's own, behind everything the
+ *       context's stream has been given so far; the context's stream goes on at once — the scans of step k + 1 run while
+ *       step k's records cross the fabric (a partitioned 10^9-row column leaves each of 8 GPUs 0.14 ms of scan per column,
+ *       an all-gather's latency is a fifth of that). Two record sets alternate: `slot` (0 / 1) names the one being
+ *       exchanged; ma_comm_slot_wait(slot) puts the context's stream behind that slot's last exchange — call it before the
+ *       kernels that overwrite the slot's records and before reading its out_finals in stream order;
+ *       ma_comm_synchronize waits for both streams. Always enqueue-only, whatever the context's mode.
  *   ma_comm_all_gather / ma_comm_all_reduce_sum_i64  the bare collectives (wrapping integer sum).
  * ma_rccl_version: ncclGetVersion's code (e.g. 22707), 0 when RCCL cannot be loaded.
  * ---------------------------------------------------------------------------------------------- */
@@ -907,6 +920,10 @@ ma_status ma_comm_all_gather(ma_comm* comm, const void* send, void* recv, size_t
 ma_status ma_comm_all_reduce_sum_i64(ma_comm* comm, const int64_t* send, int64_t* recv, size_t count);
 ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
                                uint64_t* gathered, uint64_t* out_finals);
+ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uint64_t* local_records, size_t slots_per_rank,
+                                          size_t n_columns, uint64_t* gathered, uint64_t* out_finals);
+ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot);
+ma_status ma_comm_synchronize(ma_comm* comm);
 
 /* ------------------------------------------------------------------------------------------------
  * Testing hooks. Not part of what a binding needs (ma_group_test_set_member_device above is the other one).

@@ -66,6 +66,15 @@ struct ma_group {
     // RCCL: per member a device block of kColumns records (`local`), a device block of G x kColumns gathered records
     // and a pinned host block of kColumns x 4 finals the fold kernel writes. host: `local[i]` points into `host_records`.
     std::vector<uint64_t*> local, gathered, finals;
+    // MA_GROUP_EXCHANGE_OVERLAP (RCCL exchange only): a second record set per member ([1]; the vectors above are set 0), an
+    // internal context per member whose stream carries the all-gather + fold of the set just filled while the member's own
+    // stream already scans into the other set, and per member and set one event each way. `cur` = the set being filled.
+    bool overlap = false;
+    int cur = 0, last = 0;  // last = the set of the most recent exchange (what ma_group_result reads)
+    std::vector<uint64_t*> local1, gathered1, finals1;
+    std::vector<ma_ctx*> side;
+    std::vector<hipEvent_t> ev_ready[2], ev_done[2];
+    bool set_used[2] = {false, false};
     uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
     uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
     // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
@@ -76,6 +85,10 @@ struct ma_group {
 };
 
 using namespace ma;
+
+namespace ma {
+ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+}
 
 namespace {
 
@@ -143,6 +156,11 @@ void release_exchange(ma_group* g) {
         (void)hipSetDevice(g->ctxs[i]->device);
         (void)hipStreamSynchronize(g->ctxs[i]->stream);
     }
+    for (size_t i = 0; i < g->side.size(); ++i) {
+        if (!g->side[i]) continue;
+        (void)hipSetDevice(g->ctxs[i]->device);
+        (void)hipStreamSynchronize(g->side[i]->stream);
+    }
     if (g->use_rccl || !g->comms.empty()) {
         const RcclApi* api = rccl();
         for (ncclComm_t c : g->comms)
@@ -151,6 +169,13 @@ void release_exchange(ma_group* g) {
             (void)hipSetDevice(g->ctxs[i]->device);
             if (i < g->local.size() && g->local[i]) (void)hipFree(g->local[i]);
             if (i < g->gathered.size() && g->gathered[i]) (void)hipFree(g->gathered[i]);
+            if (i < g->local1.size() && g->local1[i]) (void)hipFree(g->local1[i]);
+            if (i < g->gathered1.size() && g->gathered1[i]) (void)hipFree(g->gathered1[i]);
+            for (int k = 0; k < 2; ++k) {
+                if (i < g->ev_ready[k].size() && g->ev_ready[k][i]) (void)hipEventDestroy(g->ev_ready[k][i]);
+                if (i < g->ev_done[k].size() && g->ev_done[k][i]) (void)hipEventDestroy(g->ev_done[k][i]);
+            }
+            if (i < g->side.size() && g->side[i]) ma_ctx_destroy(g->side[i]);
         }
         if (g->host_finals) (void)hipHostFree(g->host_finals);
     } else {
@@ -162,6 +187,17 @@ void release_exchange(ma_group* g) {
     g->local.clear();
     g->gathered.clear();
     g->finals.clear();
+    g->local1.clear();
+    g->gathered1.clear();
+    g->finals1.clear();
+    g->side.clear();
+    for (int k = 0; k < 2; ++k) {
+        g->ev_ready[k].clear();
+        g->ev_done[k].clear();
+        g->set_used[k] = false;
+    }
+    g->overlap = false;
+    g->cur = g->last = 0;
     g->use_rccl = false;
 }
 
@@ -180,7 +216,7 @@ void destroy_members(ma_group* g) {
 }
 
 // RCCL exchange set-up. Returns MA_OK with g->use_rccl set, or a status + the thread's error string.
-ma_status setup_rccl(ma_group* g) {
+ma_status setup_rccl(ma_group* g, bool overlap) {
     const size_t n = g->ctxs.size();
     for (size_t i = 0; i < n; ++i)
         for (size_t j = i + 1; j < n; ++j)
@@ -197,8 +233,19 @@ ma_status setup_rccl(ma_group* g) {
     g->local.assign(n, nullptr);
     g->gathered.assign(n, nullptr);
     g->finals.assign(n, nullptr);
-    MA_HIP(hipHostMalloc((void**)&g->host_finals, n * kColumns * 4 * 8, hipHostMallocPortable | hipHostMallocMapped));
-    memset(g->host_finals, 0, n * kColumns * 4 * 8);
+    const size_t sets = overlap ? 2 : 1;
+    MA_HIP(hipHostMalloc((void**)&g->host_finals, sets * n * kColumns * 4 * 8, hipHostMallocPortable | hipHostMallocMapped));
+    memset(g->host_finals, 0, sets * n * kColumns * 4 * 8);
+    if (overlap) {
+        g->local1.assign(n, nullptr);
+        g->gathered1.assign(n, nullptr);
+        g->finals1.assign(n, nullptr);
+        g->side.assign(n, nullptr);
+        for (int k = 0; k < 2; ++k) {
+            g->ev_ready[k].assign(n, nullptr);
+            g->ev_done[k].assign(n, nullptr);
+        }
+    }
     for (size_t i = 0; i < n; ++i) {
         MA_HIP(hipSetDevice(devs[i]));
         MA_HIP(device_malloc(devs[i], (void**)&g->local[i], kBlockWords * 8));
@@ -206,7 +253,20 @@ ma_status setup_rccl(ma_group* g) {
         MA_HIP(hipMemset(g->local[i], 0, kBlockWords * 8));
         MA_HIP(hipMemset(g->gathered[i], 0, n * kBlockWords * 8));
         g->finals[i] = g->host_finals + i * kColumns * 4;
+        if (overlap) {
+            MA_HIP(device_malloc(devs[i], (void**)&g->local1[i], kBlockWords * 8));
+            MA_HIP(device_malloc(devs[i], (void**)&g->gathered1[i], n * kBlockWords * 8));
+            MA_HIP(hipMemset(g->local1[i], 0, kBlockWords * 8));
+            MA_HIP(hipMemset(g->gathered1[i], 0, n * kBlockWords * 8));
+            g->finals1[i] = g->host_finals + (n + i) * kColumns * 4;
+            MA_TRY(make_lane(g->ctxs[i], &g->side[i]));
+            for (int k = 0; k < 2; ++k) {
+                MA_HIP(hipEventCreateWithFlags(&g->ev_ready[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
+                MA_HIP(hipEventCreateWithFlags(&g->ev_done[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
+            }
+        }
     }
+    g->overlap = overlap;
     return MA_OK;
 }
 
@@ -338,7 +398,10 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
         if (chunk_masks) MA_TRY(require_resident(g, lookup, i, chunk_masks[i], "validity bitmap", i));
     }
     // enqueue only (the members are in async mode): all devices run concurrently
-    return run_on_members(g, [&](size_t i) { return launch(i, g->local[i] + (size_t)column * kRecordWords); });
+    return run_on_members(g, [&](size_t i) {
+        uint64_t* set = (g->overlap && g->cur == 1) ? g->local1[i] : g->local[i];
+        return launch(i, set + (size_t)column * kRecordWords);
+    });
 }
 
 ma_status exchange_locked(ma_group* g) {
@@ -346,28 +409,67 @@ ma_status exchange_locked(ma_group* g) {
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     const size_t n = g->ctxs.size();
-    auto fold = [g, n](size_t i) -> ma_status {
-        ma_ctx* c = g->ctxs[i];
+    const int set = g->overlap ? g->cur : 0;
+    auto local = [g, set](size_t i) { return set ? g->local1[i] : g->local[i]; };
+    auto gathered = [g, set](size_t i) { return set ? g->gathered1[i] : g->gathered[i]; };
+    auto finals = [g, set](size_t i) { return set ? g->finals1[i] : g->finals[i]; };
+    // which context issues the exchange of member i: its own (in-stream), or its side context (overlapped: behind the
+    // scans that filled this set — an event — while the member's stream goes on with the other set)
+    auto before = [g, set](size_t i) -> ma_status {
+        if (!g->overlap) return MA_OK;
+        MA_HIP(hipEventRecord(g->ev_ready[set][i], g->ctxs[i]->stream));
+        MA_HIP(hipStreamWaitEvent(g->side[i]->stream, g->ev_ready[set][i], 0));
+        return MA_OK;
+    };
+    auto after = [g, set](size_t i) -> ma_status {
+        if (!g->overlap) return MA_OK;
+        MA_HIP(hipEventRecord(g->ev_done[set][i], g->side[i]->stream));
+        // the member's stream fills the OTHER set next: behind that set's last exchange (long finished, normally)
+        if (g->set_used[set ^ 1]) MA_HIP(hipStreamWaitEvent(g->ctxs[i]->stream, g->ev_done[set ^ 1][i], 0));
+        return MA_OK;
+    };
+    auto fold = [g, n, gathered, finals](size_t i) -> ma_status {
+        ma_ctx* c = g->overlap ? g->side[i] : g->ctxs[i];
         std::lock_guard<std::mutex> lock(c->mu);
         MA_HIP(hipSetDevice(c->device));
-        return enqueue_fold_columns(c, g->gathered[i], n, kBlockWords, kColumns, g->finals[i]);
+        return enqueue_fold_columns(c, gathered(i), n, kBlockWords, kColumns, finals(i));
     };
-    if (g->threads)  // one thread per device: each issues its own rank's all-gather, no ncclGroup needed
-        return run_on_members(g, [&](size_t i) -> ma_status {
+    auto xstream = [g](size_t i) { return g->overlap ? g->side[i]->stream : g->ctxs[i]->stream; };
+    ma_status st = MA_OK;
+    if (g->threads) {  // one thread per device: each issues its own rank's all-gather, no ncclGroup needed
+        st = run_on_members(g, [&](size_t i) -> ma_status {
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
-            MA_NCCL(api, AllGather(g->local[i], g->gathered[i], kBlockWords * 8, ncclChar, g->comms[i], g->ctxs[i]->stream));
-            return fold(i);
+            MA_TRY(before(i));
+            MA_NCCL(api, AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i)));
+            MA_TRY(fold(i));
+            return after(i);
         });
-    MA_NCCL(api, GroupStart());
-    for (size_t i = 0; i < n; ++i) {
-        ncclResult_t r = api->AllGather(g->local[i], g->gathered[i], kBlockWords * 8, ncclChar, g->comms[i], g->ctxs[i]->stream);
-        if (r != ncclSuccess) {
-            (void)api->GroupEnd();
-            return rccl_fail(r, "AllGather", __FILE__, __LINE__);
+    } else {
+        for (size_t i = 0; i < n && st == MA_OK; ++i) {
+            st = hipSetDevice(g->ctxs[i]->device) == hipSuccess ? before(i) : MA_ERR_DEVICE;
+        }
+        MA_TRY(st);
+        MA_NCCL(api, GroupStart());
+        for (size_t i = 0; i < n; ++i) {
+            ncclResult_t r = api->AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i));
+            if (r != ncclSuccess) {
+                (void)api->GroupEnd();
+                return rccl_fail(r, "AllGather", __FILE__, __LINE__);
+            }
+        }
+        MA_NCCL(api, GroupEnd());
+        for (size_t i = 0; i < n; ++i) {
+            MA_TRY(fold(i));
+            MA_HIP(hipSetDevice(g->ctxs[i]->device));
+            MA_TRY(after(i));
         }
     }
-    MA_NCCL(api, GroupEnd());
-    for (size_t i = 0; i < n; ++i) MA_TRY(fold(i));
+    MA_TRY(st);
+    if (g->overlap) {
+        g->set_used[set] = true;
+        g->last = set;
+        g->cur = set ^ 1;
+    }
     return MA_OK;
 }
 
@@ -378,6 +480,10 @@ ma_status synchronize_locked(ma_group* g) {
     (void)run_on_members(g, [&](size_t i) -> ma_status {
         st[i] = ma_ctx_synchronize(g->ctxs[i]);
         if (st[i] != MA_OK) msg[i] = ma_last_error_string();
+        if (g->overlap && st[i] == MA_OK && hipStreamSynchronize(g->side[i]->stream) != hipSuccess) {
+            st[i] = MA_ERR_DEVICE;
+            msg[i] = "the exchange stream of a group member failed";
+        }
         return MA_OK;
     });
     for (size_t i = 0; i < st.size(); ++i)
@@ -442,7 +548,7 @@ void probe_peers(ma_group* g, int* out_pairs, int* out_capable, std::string* mis
 }
 
 const uint64_t* finals_of(const ma_group* g, size_t member, int32_t column) {
-    const uint64_t* base = g->use_rccl ? g->finals[member] : g->host_finals;
+    const uint64_t* base = !g->use_rccl ? g->host_finals : (g->overlap && g->last == 1) ? g->finals1[member] : g->finals[member];
     return base + (size_t)column * 4;
 }
 
@@ -476,7 +582,7 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
     ma_status st = MA_OK;
     char why[256] = "";
     if (flags & MA_GROUP_EXCHANGE_RCCL) {
-        st = setup_rccl(g);
+        st = setup_rccl(g, (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0);
         if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
             snprintf(why, sizeof(why), "host fold instead of RCCL: %s", ma_last_error_string());
             release_exchange(g);  // whatever the attempt allocated; the members stay
@@ -505,8 +611,8 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
     else
         snprintf(peers, sizeof(peers), "peer access: %d/%d ordered device pairs (not peer-capable: %s)", capable, pairs,
                  missing.c_str());
-    snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s", why, why[0] ? "; " : "", peers,
-             g->threads ? "one thread per member" : "calling thread");
+    snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s%s", why, why[0] ? "; " : "", peers,
+             g->threads ? "one thread per member" : "calling thread", g->overlap ? "; exchange overlapped on side streams" : "");
     *out_group = g;
     return MA_OK;
 }

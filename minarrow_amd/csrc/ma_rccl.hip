@@ -79,7 +79,17 @@ struct ma_comm {
     ma_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, n_ranks = 1;
+    // Overlapped exchanges (ma_comm_sum_exchange_overlapped): an internal context with its own stream — the all-gather and
+    // the fold of record set `slot` run there while the context's stream already scans the next step — and per slot one
+    // event each way (no timing, device-scope release: the dependency never leaves the GPU).
+    ma_ctx* side = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
 };
+
+namespace ma {
+ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+}
 
 extern "C" {
 
@@ -126,12 +136,20 @@ ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n
 
 void ma_comm_destroy(ma_comm* comm) {
     if (!comm) return;
+    (void)hipSetDevice(comm->ctx->device);
+    if (comm->side) {
+        (void)hipStreamSynchronize(comm->side->stream);
+        for (int k = 0; k < 2; ++k) {
+            if (comm->ready[k]) (void)hipEventDestroy(comm->ready[k]);
+            if (comm->done[k]) (void)hipEventDestroy(comm->done[k]);
+        }
+    }
     if (comm->comm) {
-        (void)hipSetDevice(comm->ctx->device);
         (void)hipStreamSynchronize(comm->ctx->stream);
         const RcclApi* api = rccl();
         if (api) (void)api->CommDestroy(comm->comm);
     }
+    if (comm->side) ma_ctx_destroy(comm->side);
     delete comm;
 }
 
@@ -193,6 +211,63 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
                                 out_finals));
     if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
+}
+
+ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uint64_t* local_records, size_t slots_per_rank,
+                                          size_t n_columns, uint64_t* gathered, uint64_t* out_finals) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_REQUIRE(slot == 0 || slot == 1, MA_ERR_INVALID_ARGUMENT, "slot must be 0 or 1 (two record sets in flight)");
+    MA_REQUIRE(local_records && gathered && out_finals, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
+    MA_REQUIRE(slots_per_rank >= 1 && n_columns >= 1, MA_ERR_INVALID_ARGUMENT, "nothing to exchange");
+    MA_REQUIRE(pointer_kind(local_records) != kPageable && pointer_kind(gathered) != kPageable &&
+                   pointer_kind(out_finals) != kPageable,
+               MA_ERR_INVALID_ARGUMENT, "collectives need device-reachable buffers");
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    ma_ctx* ctx = comm->ctx;
+    MA_ENTER_PRIMARY(ctx);
+    MA_NO_CAPTURE(ctx, "a collective");
+    MA_HIP(hipSetDevice(ctx->device));
+    if (!comm->side) {
+        MA_TRY(make_lane(ctx, &comm->side));
+        for (int k = 0; k < 2; ++k) {
+            MA_HIP(hipEventCreateWithFlags(&comm->ready[k], hipEventDisableTiming | hipEventReleaseToDevice));
+            MA_HIP(hipEventCreateWithFlags(&comm->done[k], hipEventDisableTiming | hipEventReleaseToDevice));
+        }
+    }
+    ma_ctx* side = comm->side;
+    std::lock_guard<std::mutex> lock(side->mu);
+    // behind everything the context's stream has been given so far (the scans that wrote this slot's records) ...
+    MA_HIP(hipEventRecord(comm->ready[slot], ctx->stream));
+    MA_HIP(hipStreamWaitEvent(side->stream, comm->ready[slot], 0));
+    const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
+    MA_NCCL(api, AllGather(local_records, gathered, per_rank_words * 8, ncclChar, comm->comm, side->stream));
+    MA_TRY(enqueue_fold_columns(side, gathered, (size_t)comm->n_ranks * slots_per_rank, n_columns * kRecordWords, n_columns,
+                                out_finals));
+    // ... and ma_comm_slot_wait(slot) puts the context's stream behind it
+    MA_HIP(hipEventRecord(comm->done[slot], side->stream));
+    comm->used[slot] = true;
+    return MA_OK;
+}
+
+ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_REQUIRE(slot == 0 || slot == 1, MA_ERR_INVALID_ARGUMENT, "slot must be 0 or 1");
+    if (!comm->side || !comm->used[slot]) return MA_OK;
+    ma_ctx* ctx = comm->ctx;
+    MA_ENTER_PRIMARY(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipStreamWaitEvent(ctx->stream, comm->done[slot], 0));
+    return MA_OK;
+}
+
+ma_status ma_comm_synchronize(ma_comm* comm) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    if (comm->side) {
+        MA_HIP(hipSetDevice(comm->ctx->device));
+        MA_HIP(hipStreamSynchronize(comm->side->stream));
+    }
+    return ma_ctx_synchronize(comm->ctx);
 }
 
 }  // extern "C"

@@ -592,7 +592,8 @@ class Group:
 
     def __init__(self, devices, exchange: str = "host", issue: str = "threads"):
         self.lib = ffi.load_library()
-        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3}[exchange] | {"threads": 0, "caller": 4}[issue]
+        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8}[exchange] | \
+            {"threads": 0, "caller": 4}[issue]
         n = len(devices)
         devs = (C.c_int32 * n)(*[int(d) for d in devices])
         h = C.c_void_p()
@@ -749,6 +750,18 @@ class Comm:
     def sum_exchange(self, local_records, slots_per_rank: int, n_columns: int, gathered, out_finals) -> None:
         ffi.check(self.lib.ma_comm_sum_exchange(self.handle, addr_of(local_records), int(slots_per_rank), int(n_columns),
                                                 addr_of(gathered), addr_of(out_finals)))
+
+    def sum_exchange_overlapped(self, slot: int, local_records, slots_per_rank: int, n_columns: int, gathered, out_finals) -> None:
+        """The exchange of record set `slot` (0 / 1) on the communicator's own stream; the context's stream goes on at once."""
+        ffi.check(self.lib.ma_comm_sum_exchange_overlapped(self.handle, int(slot), addr_of(local_records), int(slots_per_rank),
+                                                           int(n_columns), addr_of(gathered), addr_of(out_finals)))
+
+    def slot_wait(self, slot: int) -> None:
+        """Puts the context's stream behind the last overlapped exchange of record set `slot`."""
+        ffi.check(self.lib.ma_comm_slot_wait(self.handle, int(slot)))
+
+    def synchronize(self) -> None:
+        ffi.check(self.lib.ma_comm_synchronize(self.handle))
 
     def close(self) -> None:
         if self.handle:

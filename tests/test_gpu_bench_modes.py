@@ -64,8 +64,10 @@ def test_one_process_group_mode_with_rccl():
     assert host["parity_ok"] and host["config"]["rccl_ranks"] == 0 and "host fold" in host["config"]["exchange"]
     assert host["result"]["i64_sum"] == out["result"]["i64_sum"] and host["result"]["f64_sum"] == out["result"]["f64_sum"]
     weak = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--scaling", "weak",
-                "--group-issue", "caller", "--no-other-configs"])
+                "--group-issue", "caller", "--no-other-configs", "--overlap", "on"])
     assert weak["parity_ok"] and weak["scaling"] == "weak" and "issue: caller" in weak["config"]["parallelism"]
+    assert "on side streams" in weak["config"]["exchange"]
+    assert weak["result"]["i64_sum"] == out["result"]["i64_sum"]
 
 
 @pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("torch", []), ("torch", ["--overlap"])])

@@ -104,7 +104,7 @@ def _device_lists(members):
 
 
 @pytest.mark.parametrize("issue", ["threads", "caller"])
-@pytest.mark.parametrize("exchange", ["rccl", "host"])
+@pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "host"])
 def test_group_over_distinct_devices(oracle, exchange, issue):
     """One member per visible GPU (up to 8). With exchange = "rccl": ncclCommInitAll + all-gather (one per member issue
     thread, or grouped on the calling thread) + device fold — every member must hold the same finals."""
@@ -118,7 +118,8 @@ def test_group_over_distinct_devices(oracle, exchange, issue):
     flts = rng.standard_normal(n) * 1e12
     bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
     with Group(list(range(n_dev)), exchange=exchange, issue=issue) as g:
-        assert g.exchange_kind == exchange and g.issue_kind == issue
+        assert g.exchange_kind == exchange.split("-")[0] and g.issue_kind == issue
+        assert ("overlapped on side streams" in g.exchange_note) == (exchange == "rccl-overlap")
         note = g.exchange_note
         assert "instead of RCCL" not in note and "peer access:" in note and ("one thread per member" in note) == (issue == "threads")
         # peer capability is probed between every pair of members at creation; a member always reaches itself
@@ -131,7 +132,8 @@ def test_group_over_distinct_devices(oracle, exchange, issue):
         di, df, dm = _chunk_tables(ctxs, ints, flts, bits, chunks)
         lens = [b - a for a, b in chunks]
         offs = [a for a, _ in chunks]
-        # several steps enqueued back to back, two columns sharing one exchange, one synchronize
+        # several steps enqueued back to back, two columns sharing one exchange, one synchronize (with "rccl-overlap" the
+        # exchange of step k runs on side streams while step k + 1 scans into the second record set)
         for _ in range(3):
             g.enqueue_sum("i64", 0, di, lens)
             g.enqueue_sum("f64", 0, df, lens)
@@ -211,6 +213,30 @@ def test_comm_one_rank(ctx, oracle):
         assert abs(float(f[1][2:3].view(np.float64)[0]) - exact) <= math.ulp(exact)
         assert not f[0].any() and not f[2].any()  # untouched columns fold to zero
         np.testing.assert_array_equal(gathered.download(np.uint64, slots * cols * 8), local.download(np.uint64, slots * cols * 8))
+        # the overlapped form: two record sets alternate, each exchange runs on the communicator's own stream behind the
+        # scans that filled its set while the context's stream already works on the other set; slot_wait orders the reuse
+        ctx.set_async(True)
+        sets = [(ctx.alloc(64), ctx.alloc(64), ctx.alloc(32)) for _ in range(2)]
+        wants = []
+        for step in range(6):
+            k = step % 2
+            loc, gat, fin = sets[k]
+            a, b = (step * 1000) % 50_000, n - (step * 777) % 40_000
+            comm.slot_wait(k)
+            ctx.sum_into("i64", di.offset(a * 8), b - a, out_sum=loc.ptr, out_count=loc.ptr + 8)
+            ctx.sum_into("f64", df.offset(a * 8), b - a, out_sum=loc.ptr + 16, dd_lo=loc.ptr + 24, out_count=loc.ptr + 32)
+            comm.sum_exchange_overlapped(k, loc, 1, 1, gat, fin)
+            wants.append((k, oracle.sum_scalar(ints[a:b]) & ((1 << 64) - 1), b - a, math.fsum(flts[a:b].tolist())))
+            if step >= 4:  # the last exchange of each set: read back after everything has drained
+                pass
+        comm.synchronize()
+        ctx.set_async(False)
+        for k, want_i, want_n, want_f in wants[-2:]:
+            f = sets[k][2].download(np.uint64, 4)
+            assert int(f[0]) == want_i and int(f[1]) == want_n and int(f[3]) == want_n
+            assert abs(float(f[2:3].view(np.float64)[0]) - want_f) <= math.ulp(want_f)
+        with pytest.raises(ffi.MinarrowHipError):
+            comm.sum_exchange_overlapped(2, sets[0][0], 1, 1, sets[0][1], sets[0][2])
     finally:
         comm.close()
 
