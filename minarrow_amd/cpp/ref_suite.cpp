@@ -587,12 +587,18 @@ static void multi_gpu_group_suite() {
     const size_t n = 3000017;
     std::vector<int32_t> devs(n_dev);
     for (int i = 0; i < n_dev; ++i) devs[i] = i;
-    for (uint32_t flags : {0u, (uint32_t)(MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST)}) {
+    for (uint32_t flags : {0u, (uint32_t)(MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST),
+                           (uint32_t)(MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP),  // exchange of step k on side streams
+                           (uint32_t)MA_GROUP_ISSUE_CALLER}) {                              // round-2 form: the caller issues
         ma_group* g = nullptr;
         ASSERT(ma_group_create_ex(devs.data(), n_dev, flags, &g) == MA_OK);
         if (!g) continue;
         ASSERT(ma_group_size(g) == n_dev);
-        if (flags) ASSERT(ma_group_exchange_kind(g) == 1);  // distinct devices + librccl present: no fallback taken
+        if (flags & MA_GROUP_EXCHANGE_RCCL) ASSERT(ma_group_exchange_kind(g) == 1);  // distinct devices + librccl present: no fallback taken
+        ASSERT(ma_group_issue_kind(g) == ((flags & MA_GROUP_ISSUE_CALLER) ? 0 : 1));
+        for (int a = 0; a < n_dev; ++a)  // probed at creation; a device always reaches itself
+            ASSERT(ma_group_peer_access(g, a, a) == 1 && ma_group_peer_access(g, a, (a + 1) % n_dev) >= 0);
+        ASSERT(std::string(ma_group_exchange_note(g)).find("peer access") != std::string::npos);
         // 64-row-aligned row chunks; chunk i lives on device i
         std::vector<void*> di(n_dev), df(n_dev);
         std::vector<const int64_t*> pi(n_dev);
@@ -608,6 +614,13 @@ static void multi_gpu_group_suite() {
             ASSERT(ma_synth_iota_f64(c, (double*)df[r], lens[r], (int64_t)lo) == MA_OK);
             pi[r] = (const int64_t*)di[r];
             pf[r] = (const double*)df[r];
+            // residency: the chunk lives on ITS member's device (a pointer into another GPU's HBM is refused, not faulted on)
+            ASSERT(ma_pointer_device(di[r]) == ma_ctx_hip_device(c) && ma_ctx_device(c) == devs[r]);
+        }
+        if (n_dev > 1) {  // chunk 1 handed to member 1 but resident on member 0's device
+            std::vector<const int64_t*> wrong(pi);
+            wrong[1] = pi[0];
+            ASSERT(ma_group_enqueue_sum_i64(g, 0, wrong.data(), lens.data(), nullptr, nullptr) == MA_ERR_INVALID_ARGUMENT);
         }
         // asynchronous form: two steps back to back, both reductions share one exchange, one synchronize
         for (int step = 0; step < 2; ++step) {
@@ -692,6 +705,16 @@ static void multi_gpu_group_suite() {
         uint64_t out[4] = {0, 0, 0, 0};
         ASSERT(ma_dev_download(ctx, out, fin, 32) == MA_OK);
         ASSERT((int64_t)out[0] == (int64_t)(n * (n - 1) / 2) && out[1] == n);
+        // the overlapped form: the exchange runs on the communicator's own stream, slot_wait orders the next use of the set
+        ASSERT(ma_ctx_set_async(ctx, 1) == MA_OK);
+        for (int step = 0; step < 4; ++step) {
+            ASSERT(ma_comm_slot_wait(comm, 0) == MA_OK);
+            ASSERT(ma_i64_sum(ctx, (const int64_t*)col, n - (size_t)step, nullptr, 0, 0, (int64_t*)&r[0], &r[1]) == MA_OK);
+            ASSERT(ma_comm_sum_exchange_overlapped(comm, 0, r, 1, 1, (uint64_t*)gathered, (uint64_t*)fin) == MA_OK);
+        }
+        ASSERT(ma_comm_synchronize(comm) == MA_OK && ma_ctx_set_async(ctx, 0) == MA_OK);
+        ASSERT(ma_dev_download(ctx, out, fin, 32) == MA_OK);
+        ASSERT((int64_t)out[0] == (int64_t)((n - 3) * (n - 4) / 2) && out[1] == n - 3);
         ma_comm_destroy(comm);
         for (void* p : {col, rec, gathered, fin}) ASSERT(ma_dev_free(ctx, p) == MA_OK);
     }

@@ -27,6 +27,9 @@ timeout -k 10 200 $L --overlap off > $O/${R}_strong_share_1gpu_ranks_overlap_off
 timeout -k 10 200 $L --overlap on > $O/${R}_strong_share_1gpu_ranks_overlap_on.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --gpus 1 --force-group --no-cpu-baseline --no-other-configs --steps 200 --warmup 10 --rows 125000000 > $O/${R}_strong_share_1gpu_group_threads.json 2>/dev/null || exit 1
 timeout -k 10 200 python3 bench.py --gpus 1 --force-group --group-issue caller --no-cpu-baseline --no-other-configs --steps 200 --warmup 10 --rows 125000000 > $O/${R}_strong_share_1gpu_group_caller.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --gpus 1 --force-group --overlap on --no-cpu-baseline --no-other-configs --steps 200 --warmup 10 --rows 125000000 > $O/${R}_strong_share_1gpu_group_overlap_on.json 2>/dev/null || exit 1
+timeout -k 10 200 $L --overlap on --exchange torch > $O/${R}_strong_share_1gpu_ranks_torch_overlap_on.json 2>/dev/null || exit 1
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-other-configs --steps 200 --warmup 10 --rows 125000000 > $O/${R}_strong_share_1gpu_plain.json 2>/dev/null || exit 1
 step "Power series accuracy"; timeout -k 10 200 python3 tools/pow_series_report.py > $O/${R}_pow_series_accuracy.json 2>/dev/null || exit 1
 step "kernel trace of the chunked regime (60 000 x 8192-row chunk pairs): kernel durations apart from table delivery"
 timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -- python3 tools/bench_matrix.py --only super_array,consolidate --reps 3 > /dev/null 2>&1 || exit 1
