@@ -229,6 +229,8 @@ def main():
             sz = SIZE[tag]
             ctx.set_async(True)
             for k, label in ((8, "chunks"), (min(n // 8192, 60000), "chunks (RechunkStrategy::Auto)")):
+                if k == 8 and os.environ.get("MA_MATRIX_ONLY_SMALL_CHUNKS"):
+                    continue  # for a kernel trace of the chunked regime alone (tools/collect_profiles.sh)
                 per = (n // k) // 64 * 64 if k == 8 else 8192
                 lens = [per] * k
                 lhs = [a.ptr + i * per * sz for i in range(k)]
@@ -297,6 +299,8 @@ def main():
     # ---- consolidate ----
     if want("consolidate"):
         for sz in (1, 2, 4, 8):
+            if os.environ.get("MA_MATRIX_ONLY_SMALL_CHUNKS"):
+                break
             n = (B // 2) // sz  # in + out fit the two buffers
             k = 8
             per = n // k
