@@ -38,7 +38,7 @@
 
 struct ma_group {
     std::vector<ma_ctx*> ctxs;
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: the one-call forms (ma_group_sum_*) hold it across enqueue + exchange + synchronize
     // ---- per-member issue threads (see the header comment). One job at a time, posted under `mu`.
     bool threads = false;
     std::vector<std::thread> workers;
@@ -290,7 +290,7 @@ void worker_main(ma_group* g, size_t i) {
         // wait for job `seen + 1`: spin for ~200 us (a stepping host never pays a wake-up), then sleep
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
-        while (g->job_seq.load(std::memory_order_acquire) == seen && !g->stop.load(std::memory_order_acquire)) {
+        while (g->job_seq.load() == seen && !g->stop.load()) {
             __builtin_ia32_pause();
             if ((++spins & 255) == 0 &&
                 std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= 200) {
@@ -300,12 +300,15 @@ void worker_main(ma_group* g, size_t i) {
                 g->sleepers.fetch_sub(1);
             }
         }
-        if (g->job_seq.load(std::memory_order_acquire) == seen) return;  // stop, nothing posted
+        if (g->job_seq.load() == seen) return;  // stop, nothing posted
         ++seen;
         ma_group::Slot& slot = g->slots[i];
         slot.status = (*g->job)(i);
         if (slot.status != MA_OK) slot.message = ma_last_error_string();
-        slot.done.store(seen, std::memory_order_release);
+        // seq_cst on purpose (here and in run_on_members): "publish done, then look whether the caller sleeps" against the
+        // caller's "announce sleeping, then look at done" is a store-load pattern on both sides; with a release store the
+        // load may pass it and both could miss each other — a caller asleep for good
+        slot.done.store(seen);
         if (g->caller_waiting.load() != 0) {
             { std::lock_guard<std::mutex> lock(g->sleep_mu); }
             g->done_cv.notify_all();
@@ -323,7 +326,7 @@ void start_workers(ma_group* g) {
 
 void stop_workers(ma_group* g) {
     if (!g->threads) return;
-    g->stop.store(true, std::memory_order_release);
+    g->stop.store(true);
     { std::lock_guard<std::mutex> lock(g->sleep_mu); }
     g->work_cv.notify_all();
     for (std::thread& t : g->workers)
@@ -342,14 +345,14 @@ ma_status run_on_members(ma_group* g, const std::function<ma_status(size_t)>& fn
         return MA_OK;
     }
     g->job = &fn;
-    const uint64_t seq = g->job_seq.fetch_add(1, std::memory_order_acq_rel) + 1;
+    const uint64_t seq = g->job_seq.fetch_add(1) + 1;
     if (g->sleepers.load() != 0) {
         { std::lock_guard<std::mutex> lock(g->sleep_mu); }
         g->work_cv.notify_all();
     }
     auto all_done = [&] {
         for (size_t i = 0; i < n; ++i)
-            if (g->slots[i].done.load(std::memory_order_acquire) != seq) return false;
+            if (g->slots[i].done.load() != seq) return false;
         return true;
     };
     // launches take microseconds, a synchronise takes milliseconds: spin briefly, then block
@@ -390,7 +393,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
                               const uint8_t* const* chunk_masks, const std::function<ma_status(size_t, uint64_t*)>& launch) {
     MA_REQUIRE(g != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
-    std::lock_guard<std::mutex> lock(g->mu);
+    std::lock_guard<std::recursive_mutex> lock(g->mu);
     DeviceLookup lookup;
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
         if (chunk_lens[i] == 0) continue;
@@ -649,7 +652,7 @@ const char* ma_group_exchange_note(ma_group* group) { return group ? group->note
 
 ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     const size_t G = group->ctxs.size();
     MA_REQUIRE(member >= 0 && (size_t)member < G, MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     group->home[(size_t)member] = hip_device;
@@ -699,7 +702,7 @@ ma_status ma_group_route_super_array_broadcast(ma_group* group, int32_t format_c
             set_error("Super Array broadcasting error - Chunk %zu: LHS %zu RHS %zu", i, lhs_lens[i], rhs_lens[i]);
             return MA_ERR_LENGTH_MISMATCH;
         }
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     const size_t G = group->ctxs.size();
     // A device-resident chunk must live on its member's GPU: the kernels address it directly. A SuperArray's thousands
     // of chunk pointers run through a handful of allocations: each allocation is asked about once.
@@ -766,7 +769,7 @@ ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size
                "element size %zu is not supported (1, 2, 4 or 8 bytes)", elem_size);
     MA_REQUIRE(n_chunks > 0, MA_ERR_INVALID_ARGUMENT, "consolidate() called on empty SuperTable");
     MA_REQUIRE(chunk_data != nullptr && chunk_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     const size_t G = group->ctxs.size();
     MA_REQUIRE(dest_member >= 0 && (size_t)dest_member < G, MA_ERR_INVALID_ARGUMENT, "member %d out of range", dest_member);
     ma_ctx* dest = group->ctxs[(size_t)dest_member];
@@ -891,13 +894,13 @@ ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size
 
 ma_status ma_group_exchange(ma_group* group) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     return exchange_locked(group);
 }
 
 ma_status ma_group_synchronize(ma_group* group) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     return synchronize_locked(group);
 }
 
@@ -906,7 +909,7 @@ ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
-    std::lock_guard<std::mutex> lock(group->mu);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     const uint64_t* f = finals_of(group, (size_t)member, column);
     if (out_int_sum) *out_int_sum = (int64_t)f[0];
     if (out_int_count) *out_int_count = f[1];
@@ -923,6 +926,9 @@ ma_status ma_group_result(ma_group* group, int32_t column, int64_t* out_int_sum,
 ma_status ma_group_sum_i64(ma_group* group, const int64_t* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, int64_t* out_sum,
                            uint64_t* out_valid_count) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    // one critical section: two calling threads share column 0's records, and the result must be THIS call's
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_TRY(ma_group_enqueue_sum_i64(group, 0, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets));
     MA_TRY(ma_group_exchange(group));
     MA_TRY(ma_group_synchronize(group));
@@ -932,6 +938,8 @@ ma_status ma_group_sum_i64(ma_group* group, const int64_t* const* chunk_data, co
 ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, const size_t* chunk_lens,
                            const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_sum,
                            uint64_t* out_valid_count) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_TRY(ma_group_enqueue_sum_f64(group, 0, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets));
     MA_TRY(ma_group_exchange(group));
     MA_TRY(ma_group_synchronize(group));

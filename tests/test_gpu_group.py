@@ -462,3 +462,47 @@ def test_group_refuses_chunks_resident_on_another_members_device(ctx):
                 g.consolidate_column(0, 8, [on0, good1], [4096, 4096], whole)
                 g.synchronize()
                 np.testing.assert_array_equal(whole.download(np.int64, 8192), np.concatenate([a, a]))
+
+
+def test_group_issue_thread_handshake_spinning_and_sleeping():
+    """The hand-off between a calling thread and the members' issue threads (ma_group.hip: one job posted to all, workers
+    spin 200 us then sleep on a condition variable, the caller spins 100 us then sleeps): thousands of tiny group calls
+    from TWO calling threads with pauses on either side of both thresholds, so that jobs find workers spinning, about to
+    sleep and asleep, and callers wait both ways. Every call's result is checked; a lost wake-up is a hang (the join
+    timeout), a mixed-up job a wrong sum."""
+    import threading
+    import time
+
+    from minarrow_amd.host import Group
+
+    rng = np.random.default_rng(5)
+    data = rng.integers(-(1 << 40), 1 << 40, size=64 * 1024, dtype=np.int64)
+    errors, done = [], []
+    with Group([0] * 8, "host") as g:
+        ctxs = [g.member_ctx(i) for i in range(8)]
+        bufs = [c.to_device(data, 64) for c in ctxs]
+        pre = np.concatenate([[0], np.cumsum(data)])
+
+        def caller(seed):
+            r = np.random.default_rng(seed)
+            t_end = time.time() + 6.0
+            k = 0
+            while time.time() < t_end and not errors:
+                lens = [int(x) for x in r.integers(0, 4096, size=8)]
+                offs = [int(x) & ~1 for x in r.integers(0, data.size - 4096, size=8)]
+                got = g.sum("i64", [b.offset(o * 8) for b, o in zip(bufs, offs)], lens)
+                want = sum(int(pre[o + n] - pre[o]) for o, n in zip(offs, lens))
+                if got != (want, sum(lens)):
+                    errors.append((seed, k, got, want))
+                k += 1
+                pause = r.choice([0.0, 0.0, 0.00005, 0.00015, 0.0003, 0.002])
+                if pause:
+                    time.sleep(float(pause))
+            done.append(k)
+
+        threads = [threading.Thread(target=caller, args=(s,)) for s in (1, 2)]
+        [t.start() for t in threads]
+        [t.join(timeout=120) for t in threads]
+        assert not any(t.is_alive() for t in threads), "a group call never returned (lost wake-up?)"
+    assert not errors, errors[:3]
+    assert sum(done) > 500, done
