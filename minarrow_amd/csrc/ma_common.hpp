@@ -106,12 +106,13 @@ struct ma_ctx {
     uint64_t result_seq = 0;           // stamps of the polled synchronous reductions (ma_reduce.hip)
     long poll_us = 60;                 // MINARROW_HIP_POLL_US: how long such a call polls before it blocks (0 = never poll)
     bool fenced_reduce = false;        // MINARROW_HIP_FENCED_REDUCE=1: the round-1 release/acquire publish in the sum kernels
-    // Two pinned staging buffers for small host tables on their way to the device (ma::upload_table): descriptor
+    // Pinned staging buffers (kTableSlots, used in turn) for small host tables on their way to the device (ma::upload_table): descriptor
     // tables live in the caller's frame, and a pageable source would force a stream drain per call.
-    void* table_stage[2] = {nullptr, nullptr};
-    size_t table_stage_bytes[2] = {0, 0};
-    hipEvent_t table_ev[2] = {nullptr, nullptr};
-    bool table_busy[2] = {false, false};
+    static constexpr int kTableSlots = 4;  // a segmented chunk list (4 segments for 60 000 chunks) never waits for its own kernels
+    void* table_stage[kTableSlots] = {};
+    size_t table_stage_bytes[kTableSlots] = {};
+    hipEvent_t table_ev[kTableSlots] = {};
+    bool table_busy[kTableSlots] = {};
     int table_next = 0;
 };
 
@@ -256,8 +257,8 @@ void pipe_destroy(ma_ctx* ctx);
 // context; the caller holds ctx->mu and enqueues every use on ctx->stream, so successive users are stream-ordered.
 ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out);
 // Enqueues the copy of a small host table (descriptors living in the caller's frame) to `dev_dst` on ctx->stream
-// WITHOUT waiting for the stream: the bytes are taken into one of the context's two pinned staging buffers before the
-// call returns. (A buffer is re-used only after the copy issued from it two uploads ago has left it.) The caller holds
+// WITHOUT waiting for the stream: the bytes are taken into one of the context's pinned staging buffers (four, used in turn) before the
+// call returns. (A buffer is re-used only after the copy — or the kernel that read it in place — issued from it four uploads ago has finished.) The caller holds
 // the context.
 ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst);
 // The same in two steps for tables large enough that the extra copy shows (100 000 chunk descriptors): table_begin hands

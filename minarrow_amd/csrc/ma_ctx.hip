@@ -451,7 +451,7 @@ ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_ds
     if (bytes == 0) return MA_OK;
     const int k = ctx->table_next;
     MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit without table_begin");
-    ctx->table_next ^= 1;
+    ctx->table_next = (ctx->table_next + 1) % ma_ctx::kTableSlots;
     MA_HIP(hipMemcpyAsync(dev_dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipEventRecord(ctx->table_ev[k], ctx->stream));
     ctx->table_busy[k] = true;
@@ -463,7 +463,7 @@ ma_status table_commit_mapped(ma_ctx* ctx, const void* host, const void** out_de
     MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit_mapped without table_begin");
     void* alias = nullptr;
     MA_HIP(hipHostGetDevicePointer(&alias, ctx->table_stage[k], 0));
-    ctx->table_next ^= 1;
+    ctx->table_next = (ctx->table_next + 1) % ma_ctx::kTableSlots;
     *out_dev_alias = alias;
     *out_slot = k;
     return MA_OK;
@@ -868,7 +868,7 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < ma_ctx::kTableSlots; ++k) {
         if (ctx->table_stage[k]) (void)hipHostFree(ctx->table_stage[k]);
         if (ctx->table_ev[k]) (void)hipEventDestroy(ctx->table_ev[k]);
     }
