@@ -1,0 +1,155 @@
+// minarrow_hip_parallel.hpp — the reference's `parallel_proc` path as a typed C++17 mirror over the C ABI's group API.
+//
+// The only place the reference parallelises the hot path is its bench harness:
+//     fn rayon_simd_sum_i64(slice: &[i64]) -> i64 { slice.par_chunks(1 << 20).map(simd_sum_i64::<4>).sum() }
+// (benches/benchmark_parallel_simd.rs:81-98: Rayon workers on all cores, per-chunk partials, one `.sum()`). With the
+// column resident in HBM the chunks are one per GPU — 64-row-aligned, so that a validity word never straddles two devices
+// — every member of a `Group` scans its chunk on its own device (issued by its own thread, like a Rayon worker), and the
+// `.sum()` of the partials is ONE exchange of 64-byte records (RCCL all-gather + rank-ordered fold inside the library, or the
+// host fold of pinned records): wrapping adds for integers, error-free double-double folding for floats, so the f64 result
+// stays within 1 ULP of the exactly rounded sum whatever the number of GPUs.
+//
+//     ma::Group g({0, 1, 2, 3, 4, 5, 6, 7});
+//     auto col = g.scatter(host_ptr, n);              // ShardedColumn<int64_t>: chunk i in member i's HBM
+//     int64_t s = g.rayon_simd_sum_i64(col);           // == the reference's rayon_simd_sum_i64(&host[..n])
+//
+// Header-only; needs minarrow_hip.hpp (KernelError, check). Nothing here computes on the CPU.
+#pragma once
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "minarrow_hip.hpp"
+
+namespace ma {
+
+// Row ranges [lo, hi) of an n-row column for `parts` GPUs; interior boundaries are multiples of 64 rows (the 6-line rule
+// of minarrow_amd/parallel.py::row_chunks: what `par_chunks` becomes when a chunk must start on a validity word).
+inline std::vector<std::pair<size_t, size_t>> row_chunks(size_t n, size_t parts) {
+    std::vector<std::pair<size_t, size_t>> out;
+    const size_t units = (n + 63) / 64;
+    size_t lo = 0;
+    for (size_t r = 0; r < parts; ++r) {
+        size_t hi = r + 1 == parts ? n : std::min(n, (units * (r + 1) / parts) * 64);
+        if (hi < lo) hi = lo;
+        out.emplace_back(lo, hi);
+        lo = hi;
+    }
+    return out;
+}
+
+// A column whose row chunks live on the members of a group: chunk i is device memory of member i (freed with the column).
+template <typename T>
+struct ShardedColumn {
+    std::vector<std::shared_ptr<void>> owners;  // data (and validity) allocations, one or two per member
+    std::vector<const T*> chunks;
+    std::vector<size_t> lens;
+    std::vector<const uint8_t*> masks;          // empty: no validity. Else one bitmap per member, bit 0 = the chunk's row 0
+    std::vector<size_t> mask_offsets;
+    size_t rows = 0;
+    bool has_mask() const { return !masks.empty(); }
+};
+
+class Group {
+  public:
+    // flags: MA_GROUP_EXCHANGE_* / MA_GROUP_ISSUE_CALLER (minarrow_hip.h). The default asks for the RCCL exchange and
+    // accepts the host fold where RCCL cannot be set up (ma_group_exchange_note says why).
+    explicit Group(const std::vector<int32_t>& devices,
+                   uint32_t flags = MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST) {
+        check(ma_group_create_ex(devices.data(), (int32_t)devices.size(), flags, &g_));
+    }
+    ~Group() { ma_group_destroy(g_); }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    ma_group* get() const { return g_; }
+    size_t size() const { return (size_t)ma_group_size(g_); }
+    ma_ctx* ctx(size_t member) const { return ma_group_ctx(g_, (int32_t)member); }
+    bool rccl() const { return ma_group_exchange_kind(g_) == 1; }
+    bool issue_threads() const { return ma_group_issue_kind(g_) == 1; }
+    bool peer_access(size_t from, size_t to) const { return ma_group_peer_access(g_, (int32_t)from, (int32_t)to) == 1; }
+    std::string note() const { return ma_group_exchange_note(g_); }
+
+    // Uploads chunk i of the host column (and of its validity, if any: `mask_bits` is the Arrow bitmap of the WHOLE column,
+    // bit i = row i) into member i's HBM. Chunk boundaries are multiples of 64 rows = 8 bytes of bitmap, so every member's
+    // bitmap copy starts on a byte and its bit offset is 0.
+    template <typename T>
+    ShardedColumn<T> scatter(const T* host, size_t n, const uint8_t* mask_bits = nullptr) const {
+        ShardedColumn<T> col;
+        col.rows = n;
+        const auto chunks = row_chunks(n, size());
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            const size_t lo = chunks[i].first, len = chunks[i].second - chunks[i].first;
+            ma_ctx* c = ctx(i);
+            void* p = nullptr;
+            check(ma_dev_alloc(c, len * sizeof(T) + 64, &p));
+            col.owners.emplace_back(p, [c](void* q) { (void)ma_dev_free(c, q); });
+            if (len) check(ma_dev_upload(c, p, host + lo, len * sizeof(T)));
+            col.chunks.push_back(static_cast<const T*>(p));
+            col.lens.push_back(len);
+            if (mask_bits) {
+                const size_t nbytes = (len + 7) / 8;
+                void* m = nullptr;
+                check(ma_dev_alloc(c, ((nbytes + 7) / 8) * 8 + 64, &m));  // whole u64 words readable, like the reference
+                col.owners.emplace_back(m, [c](void* q) { (void)ma_dev_free(c, q); });
+                check(ma_dev_memset(c, m, 0, ((nbytes + 7) / 8) * 8 + 64));
+                if (nbytes) check(ma_dev_upload(c, m, mask_bits + lo / 8, nbytes));
+                col.masks.push_back(static_cast<const uint8_t*>(m));
+                col.mask_offsets.push_back(0);
+            }
+        }
+        return col;
+    }
+
+    // rayon_simd_sum_i64 — benches/benchmark_parallel_simd.rs:81-88. Wrapping sum of the valid rows (all rows without a
+    // bitmap); *valid_count receives their number. A chunk on the wrong member's device is KernelError::InvalidArguments.
+    int64_t rayon_simd_sum_i64(const ShardedColumn<int64_t>& col, uint64_t* valid_count = nullptr) const {
+        require_shape(col.chunks.size());
+        int64_t s = 0;
+        uint64_t c = 0;
+        check(ma_group_sum_i64(g_, col.chunks.data(), col.lens.data(), col.has_mask() ? col.masks.data() : nullptr,
+                               col.has_mask() ? col.mask_offsets.data() : nullptr, &s, &c));
+        if (valid_count) *valid_count = c;
+        return s;
+    }
+    // rayon_simd_sum_f64 — :91-98. Within 1 ULP of the exactly rounded sum, bit-reproducible for a given group size.
+    double rayon_simd_sum_f64(const ShardedColumn<double>& col, uint64_t* valid_count = nullptr) const {
+        require_shape(col.chunks.size());
+        double s = 0;
+        uint64_t c = 0;
+        check(ma_group_sum_f64(g_, col.chunks.data(), col.lens.data(), col.has_mask() ? col.masks.data() : nullptr,
+                               col.has_mask() ? col.mask_offsets.data() : nullptr, &s, &c));
+        if (valid_count) *valid_count = c;
+        return s;
+    }
+    // Both columns of the reference's bench in ONE step — two scans per GPU, one exchange — enqueue-only: call wait().
+    // `column` (0 .. MA_GROUP_MAX_COLUMNS-1) names the record set the results are read from.
+    void enqueue_sums(int32_t column, const ShardedColumn<int64_t>& ints, const ShardedColumn<double>& floats) const {
+        require_shape(ints.chunks.size());
+        require_shape(floats.chunks.size());
+        check(ma_group_enqueue_sum_i64(g_, column, ints.chunks.data(), ints.lens.data(), ints.has_mask() ? ints.masks.data() : nullptr,
+                                       ints.has_mask() ? ints.mask_offsets.data() : nullptr));
+        check(ma_group_enqueue_sum_f64(g_, column, floats.chunks.data(), floats.lens.data(),
+                                       floats.has_mask() ? floats.masks.data() : nullptr,
+                                       floats.has_mask() ? floats.mask_offsets.data() : nullptr));
+        check(ma_group_exchange(g_));
+    }
+    void wait() const { check(ma_group_synchronize(g_)); }
+    std::pair<int64_t, double> sums(int32_t column) const {
+        int64_t i = 0;
+        double f = 0;
+        check(ma_group_result(g_, column, &i, nullptr, &f, nullptr));
+        return {i, f};
+    }
+
+  private:
+    void require_shape(size_t n_chunks) const {
+        if (n_chunks != size())
+            throw KernelError(KernelError::InvalidArguments, "a sharded column needs one chunk per group member");
+    }
+    ma_group* g_ = nullptr;
+};
+
+}  // namespace ma

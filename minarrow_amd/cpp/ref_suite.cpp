@@ -15,6 +15,7 @@
 
 #include "minarrow_hip.hpp"
 #include "minarrow_hip_routing.hpp"
+#include "minarrow_hip_parallel.hpp"
 
 using namespace ma;
 using Op = ArithmeticOperator;
@@ -575,6 +576,64 @@ static void device_residency_suite() {
     ASSERT(!mixed.data.is_device() && mixed.data[1] == a[1] + b[1]);
 }
 
+// The typed mirror of the Rayon path (include/minarrow_hip_parallel.hpp): rayon_simd_sum_{i64,f64} over a column
+// scattered across the node's GPUs (benches/benchmark_parallel_simd.rs:81-98), dense and Bitmask-gated, against the
+// closed forms of the bench's own inputs (:103,:115: v[i] = i) and a host loop for the gated case.
+static void parallel_mirror_suite() {
+    std::printf("parallel mirror (ma::Group, ShardedColumn)\n");
+    const int n_dev = std::min<int>(ma_device_count(), 8);
+    std::vector<int32_t> devs(n_dev);
+    for (int i = 0; i < n_dev; ++i) devs[i] = i;
+    const size_t n = 2000003;
+    std::vector<int64_t> hi(n);
+    std::vector<double> hf(n);
+    std::vector<uint8_t> bits((n + 7) / 8 + 8, 0);
+    int64_t want_masked = 0;
+    uint64_t want_valid = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hi[i] = (int64_t)i;
+        hf[i] = (double)i;
+        if ((i * 2654435761u >> 7) % 10 != 0) {  // ~10 % nulls
+            bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+            want_masked += (int64_t)i;
+            ++want_valid;
+        }
+    }
+    for (uint32_t flags : {(uint32_t)(MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_FALLBACK_HOST), 0u}) {
+        ma::Group g(devs, flags);
+        ASSERT(g.size() == (size_t)n_dev && g.issue_threads());
+        auto chunks = ma::row_chunks(n, g.size());
+        ASSERT(chunks.front().first == 0 && chunks.back().second == n);
+        for (size_t i = 1; i < chunks.size(); ++i) ASSERT(chunks[i].first == chunks[i - 1].second && chunks[i].first % 64 == 0);
+        auto ci = g.scatter(hi.data(), n);
+        auto cf = g.scatter(hf.data(), n);
+        uint64_t valid = 0;
+        const int64_t want = (int64_t)(n * (n - 1) / 2);
+        ASSERT(g.rayon_simd_sum_i64(ci, &valid) == want && valid == n);
+        ASSERT(g.rayon_simd_sum_f64(cf, &valid) == (double)want && valid == n);  // < 2^53: exact in any order
+        auto mi = g.scatter(hi.data(), n, bits.data());
+        auto mf = g.scatter(hf.data(), n, bits.data());
+        ASSERT(g.rayon_simd_sum_i64(mi, &valid) == want_masked && valid == want_valid);
+        ASSERT(g.rayon_simd_sum_f64(mf, &valid) == (double)want_masked && valid == want_valid);
+        // the bench's step: both columns, one exchange, enqueue-only, several steps back to back
+        for (int step = 0; step < 3; ++step) g.enqueue_sums(1, ci, cf);
+        g.wait();
+        auto both = g.sums(1);
+        ASSERT(both.first == want && both.second == (double)want);
+        // a column with the wrong number of chunks is refused on the host
+        ma::ShardedColumn<int64_t> bad = ci;
+        bad.chunks.push_back(ci.chunks[0]);
+        bad.lens.push_back(1);
+        bool threw = false;
+        try {
+            (void)g.rayon_simd_sum_i64(bad);
+        } catch (const ma::KernelError&) {
+            threw = true;
+        }
+        ASSERT(threw);
+    }
+}
+
 // rayon_simd_sum_{i64,f64} over the GPUs of the node, driven from ONE compiled host process straight through the C ABI
 // (benches/benchmark_parallel_simd.rs:81-98: `par_chunks(1 << 20).map(simd_sum).sum()` — here one row chunk per device,
 // the partials meeting in the library's exchange). Every visible device takes part (one on the test pool: the RCCL
@@ -739,6 +798,7 @@ int main() {
         chunked_suite();
         device_residency_suite();
         multi_gpu_group_suite();
+        parallel_mirror_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
