@@ -1,0 +1,106 @@
+// ubench_fill.hip — why does the generators' tight-front fill (fill_kernel: 5.77 TB/s) fall short of the bare front with a
+// constant (front_write_kernel / hipMemsetAsync: 6.3-6.6 TB/s)? Same grid (one workgroup per CU), same 16-byte stores,
+// same front; what differs is WHAT is stored and how the value is made:
+//   const      one constant vector
+//   iota64     {i, i + 1} as int64 (cheap: two integer adds)
+//   iotaf64    {(double)i, (double)(i + 1)}
+//   hash       splitmix-style hash of the index (every bit toggles from one store to the next)
+//   const2     constant vector, but computed through the same index arithmetic as iota (volatile-free, kept live)
+// each with nt and plain stores, on two separately allocated 4-GiB blocks.
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench_fill.hip -o /tmp/ubench_fill && /tmp/ubench_fill
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x)                                                             \
+    do {                                                                  \
+        hipError_t e = (x);                                               \
+        if (e != hipSuccess) {                                            \
+            fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e)); \
+            exit(1);                                                      \
+        }                                                                 \
+    } while (0)
+
+typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned long long mix(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void fill(u2* __restrict__ out, size_t n_vecs, unsigned long long seed) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n_vecs; v += stride) {
+        u2 x;
+        if (MODE == 0) x = u2{0x3FF8000000000000ull, 0x4004000000000000ull};
+        if (MODE == 1) x = u2{seed + 2 * v, seed + 2 * v + 1};
+        if (MODE == 2) {
+            const double a = (double)(long long)(seed + 2 * v), b = (double)(long long)(seed + 2 * v + 1);
+            x = u2{(unsigned long long)__double_as_longlong(a), (unsigned long long)__double_as_longlong(b)};
+        }
+        if (MODE == 3) x = u2{mix(seed + 2 * v), mix(seed + 2 * v + 1)};
+        if (MODE == 4) x = u2{(seed + 2 * v) * 0 + 0x3FF8000000000000ull, (seed + 2 * v + 1) * 0 + 0x4004000000000000ull};
+        if (NT) __builtin_nontemporal_store(x, out + v);
+        else out[v] = x;
+    }
+}
+
+template <int MODE, bool NT>
+static float run(u2* buf, size_t n_vecs, int cus, hipStream_t s) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int round = 0; round < 4; ++round) {
+        hipLaunchKernelGGL((fill<MODE, NT>), dim3(cus), dim3(256), 0, s, buf, n_vecs, 12345ull);
+        CK(hipEventRecord(a, s));
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((fill<MODE, NT>), dim3(cus), dim3(256), 0, s, buf, n_vecs, 12345ull + r);
+        CK(hipEventRecord(b, s));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (ms / 5 < best) best = ms / 5;
+    }
+    return best;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const size_t bytes = (size_t)4 << 30, n_vecs = bytes / 16;
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    u2* bufs[2];
+    for (auto& b : bufs) CK(hipMalloc(&b, bytes));
+    const char* names[5] = {"const", "iota64", "iotaf64", "hash", "const_via_index"};
+    printf("%-18s %-6s %10s %10s\n", "value", "store", "buf0 GB/s", "buf1 GB/s");
+    float r[5][2][2];
+    for (int b = 0; b < 2; ++b) {
+        r[0][0][b] = run<0, true>(bufs[b], n_vecs, cus, s);  r[0][1][b] = run<0, false>(bufs[b], n_vecs, cus, s);
+        r[1][0][b] = run<1, true>(bufs[b], n_vecs, cus, s);  r[1][1][b] = run<1, false>(bufs[b], n_vecs, cus, s);
+        r[2][0][b] = run<2, true>(bufs[b], n_vecs, cus, s);  r[2][1][b] = run<2, false>(bufs[b], n_vecs, cus, s);
+        r[3][0][b] = run<3, true>(bufs[b], n_vecs, cus, s);  r[3][1][b] = run<3, false>(bufs[b], n_vecs, cus, s);
+        r[4][0][b] = run<4, true>(bufs[b], n_vecs, cus, s);  r[4][1][b] = run<4, false>(bufs[b], n_vecs, cus, s);
+    }
+    for (int m = 0; m < 5; ++m)
+        for (int st = 0; st < 2; ++st)
+            printf("%-18s %-6s %10.0f %10.0f\n", names[m], st == 0 ? "nt" : "plain", bytes / r[m][st][0] / 1e6, bytes / r[m][st][1] / 1e6);
+    // the runtime's fill for reference
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    CK(hipMemsetAsync(bufs[0], 0xFF, bytes, s));
+    CK(hipEventRecord(a, s));
+    for (int k = 0; k < 5; ++k) CK(hipMemsetAsync(bufs[0], 0xA5, bytes, s));
+    CK(hipEventRecord(b, s));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    printf("%-18s %-6s %10.0f\n", "hipMemsetAsync", "-", bytes / (ms / 5) / 1e6);
+    return 0;
+}
