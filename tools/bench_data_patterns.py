@@ -4,8 +4,12 @@
 benchmark_parallel_simd.rs:103,115), a constant column and SplitMix64 bits (SURVEY.md 8(d)'s secondary distribution).
     python tools/bench_data_patterns.py > profiles/r03_data_patterns.json"""
 import json
+import os
 import sys
 from pathlib import Path
+
+if os.environ.get("MA_IMPORT_TORCH"):  # A/B: PyTorch's bundled HIP runtime instead of /opt/rocm's
+    import torch  # noqa: F401
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from minarrow_amd.host import Context  # noqa: E402
