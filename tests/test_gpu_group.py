@@ -6,6 +6,7 @@ min(device_count, 8) of them (one on this pool: ncclCommInitAll, the grouped all
 one rank; on an 8-GPU node the same test covers 8)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -485,7 +486,7 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
 
         def caller(seed):
             r = np.random.default_rng(seed)
-            t_end = time.time() + 6.0
+            t_end = time.time() + float(os.environ.get("MA_STRESS_SECONDS", "6"))
             k = 0
             while time.time() < t_end and not errors:
                 lens = [int(x) for x in r.integers(0, 4096, size=8)]
@@ -502,7 +503,8 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
 
         threads = [threading.Thread(target=caller, args=(s,)) for s in (1, 2)]
         [t.start() for t in threads]
-        [t.join(timeout=120) for t in threads]
+        [t.join(timeout=120 + float(os.environ.get("MA_STRESS_SECONDS", "6"))) for t in threads]
         assert not any(t.is_alive() for t in threads), "a group call never returned (lost wake-up?)"
     assert not errors, errors[:3]
     assert sum(done) > 500, done
+    print(f"{sum(done)} group calls from two threads checked, 0 errors")

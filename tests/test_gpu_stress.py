@@ -10,6 +10,7 @@ the L2s), dense and Bitmask-gated, i64 and f64, both publish forms (fence-free a
 single result checked: against prefix sums computed on the host (exact: the f64 data are integers, so the double-double sum
 has one right answer), a sample of them against the CPU oracle as well. A stale partial read by the folding workgroup shows
 up as a wrong sum; a lost arrival as a launch that never completes (the test's timeout)."""
+import os
 import threading
 import time
 
@@ -18,7 +19,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SECONDS = 12.0
+SECONDS = float(os.environ.get("MA_STRESS_SECONDS", "12"))  # a longer soak: MA_STRESS_SECONDS=300 pytest -s tests/test_gpu_stress.py
 N_MAX = 3_000_000
 
 
