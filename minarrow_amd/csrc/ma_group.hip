@@ -428,7 +428,16 @@ ma_status exchange_locked(ma_group* g) {
         if (!g->overlap) return MA_OK;
         MA_HIP(hipEventRecord(g->ev_done[set][i], g->side[i]->stream));
         // the member's stream fills the OTHER set next: behind that set's last exchange (long finished, normally)
-        if (g->set_used[set ^ 1]) MA_HIP(hipStreamWaitEvent(g->ctxs[i]->stream, g->ev_done[set ^ 1][i], 0));
+        if (g->set_used[set ^ 1]) {
+            const hipError_t q = hipEventQuery(g->ev_done[set ^ 1][i]);  // finished already: no barrier packet on the stream
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                MA_HIP(hipStreamWaitEvent(g->ctxs[i]->stream, g->ev_done[set ^ 1][i], 0));
+            } else if (q != hipSuccess) {
+                (void)hipGetLastError();
+                return hip_fail(q, "hipEventQuery(exchange done)", __FILE__, __LINE__);
+            }
+        }
         return MA_OK;
     };
     auto fold = [g, n, gathered, finals](size_t i) -> ma_status {

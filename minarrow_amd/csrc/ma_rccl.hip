@@ -257,6 +257,15 @@ ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) {
     ma_ctx* ctx = comm->ctx;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
+    // Two steps ago, normally long finished: then the host's look at the event is the whole wait, and the stream is spared a
+    // barrier packet per step (each costs it a few us: the in-order queue stalls on it even when the event has fired).
+    const hipError_t q = hipEventQuery(comm->done[slot]);
+    if (q == hipSuccess) return MA_OK;
+    if (q != hipErrorNotReady) {
+        (void)hipGetLastError();
+        return hip_fail(q, "hipEventQuery(exchange done)", __FILE__, __LINE__);
+    }
+    (void)hipGetLastError();
     MA_HIP(hipStreamWaitEvent(ctx->stream, comm->done[slot], 0));
     return MA_OK;
 }
