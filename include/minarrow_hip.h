@@ -263,6 +263,16 @@ ma_status ma_i32_sum(ma_ctx* ctx, const int32_t* data, size_t n, const uint8_t* 
                      int64_t null_count, int64_t* out_sum, uint64_t* out_valid_count);
 ma_status ma_u32_sum(ma_ctx* ctx, const uint32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                      int64_t null_count, uint64_t* out_sum, uint64_t* out_valid_count);
+/* The reference's extended_numeric_types (i8 / u8 / i16 / u16 columns, src/enums/collections/numeric_array.rs:81-99):
+ * 64-bit wrapping sums like the 32-bit types; 16 / 8 rows per 16-byte load are summed inside 32-bit registers. */
+ma_status ma_i16_sum(ma_ctx* ctx, const int16_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, int64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_u16_sum(ma_ctx* ctx, const uint16_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, uint64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_i8_sum(ma_ctx* ctx, const int8_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                    int64_t null_count, int64_t* out_sum, uint64_t* out_valid_count);
+ma_status ma_u8_sum(ma_ctx* ctx, const uint8_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                    int64_t null_count, uint64_t* out_sum, uint64_t* out_valid_count);
 ma_status ma_f64_sum(ma_ctx* ctx, const double* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                      int64_t null_count, double* out_sum, uint64_t* out_valid_count);
 ma_status ma_f32_sum(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
@@ -283,6 +293,14 @@ ma_status ma_i32_mean(ma_ctx* ctx, const int32_t* data, size_t n, const uint8_t*
                       int64_t null_count, double* out_mean, uint64_t* out_valid_count);
 ma_status ma_u32_mean(ma_ctx* ctx, const uint32_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                       int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_i16_mean(ma_ctx* ctx, const int16_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_u16_mean(ma_ctx* ctx, const uint16_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                      int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_i8_mean(ma_ctx* ctx, const int8_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, double* out_mean, uint64_t* out_valid_count);
+ma_status ma_u8_mean(ma_ctx* ctx, const uint8_t* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
+                     int64_t null_count, double* out_mean, uint64_t* out_valid_count);
 ma_status ma_f64_mean(ma_ctx* ctx, const double* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                       int64_t null_count, double* out_mean, uint64_t* out_valid_count);
 ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,

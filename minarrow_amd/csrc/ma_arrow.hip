@@ -18,7 +18,9 @@ struct Prim {
     size_t size;
 };
 
-ma_status parse_primitive(const ArrowArray* array, const ArrowSchema* schema, Prim* out) {
+// allow_narrow: also the 1- and 2-byte integers ('c' 'C' 's' 'S': the reference's extended_numeric_types) — for the
+// reductions; the arithmetic type matrix (arithmetic_dispatch, routing/arithmetic.rs:280-339) does not route them.
+ma_status parse_primitive(const ArrowArray* array, const ArrowSchema* schema, Prim* out, bool allow_narrow = false) {
     MA_REQUIRE(array != nullptr && schema != nullptr, MA_ERR_INVALID_ARGUMENT, "ArrowArray or ArrowSchema is NULL");
     MA_REQUIRE(schema->format != nullptr, MA_ERR_INVALID_ARGUMENT, "ArrowSchema.format is NULL");
     MA_REQUIRE(array->length >= 0 && array->offset >= 0, MA_ERR_INVALID_ARGUMENT, "negative length or offset");
@@ -29,6 +31,12 @@ ma_status parse_primitive(const ArrowArray* array, const ArrowSchema* schema, Pr
     switch (f[0]) {
         case 'i': case 'I': case 'f': *out = {f[0], 4}; break;
         case 'l': case 'L': case 'g': *out = {f[0], 8}; break;
+        case 'c': case 'C': case 's': case 'S':
+            if (allow_narrow) {
+                *out = {f[0], (f[0] == 'c' || f[0] == 'C') ? (size_t)1 : (size_t)2};
+                break;
+            }
+            [[fallthrough]];
         default:
             set_error("unsupported Arrow format \"%s\" (numeric primitives only)", f);
             return MA_ERR_UNSUPPORTED;
@@ -55,7 +63,7 @@ extern "C" {
 ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
                        double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count) {
     Prim p{};
-    MA_TRY(parse_primitive(array, schema, &p));
+    MA_TRY(parse_primitive(array, schema, &p, true));
     const size_t n = (size_t)array->length, off = (size_t)array->offset;
     const uint8_t* validity = (const uint8_t*)array->buffers[0];
     const char* values = (const char*)array->buffers[1] + off * p.size;
@@ -92,6 +100,19 @@ ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct
             if (out_sum_f64) *out_sum_f64 = (double)s;
             return MA_OK;
         }
+#define MA_NARROW_SUM(CODE, TAG, T, S)                                                              \
+    case CODE: {                                                                                    \
+        S s = 0;                                                                                    \
+        MA_TRY(ma_##TAG##_sum(ctx, (const T*)values, n, validity, off, nc, &s, out_valid_count));   \
+        if (out_sum_i64) *out_sum_i64 = (int64_t)s;                                                 \
+        if (out_sum_f64) *out_sum_f64 = (double)s;                                                  \
+        return MA_OK;                                                                               \
+    }
+            MA_NARROW_SUM('c', i8, int8_t, int64_t)
+            MA_NARROW_SUM('C', u8, uint8_t, uint64_t)
+            MA_NARROW_SUM('s', i16, int16_t, int64_t)
+            MA_NARROW_SUM('S', u16, uint16_t, uint64_t)
+#undef MA_NARROW_SUM
         case 'f':
             return ma_f32_sum(ctx, (const float*)values, n, validity, off, nc, out_sum_f64, out_valid_count);
         default:
@@ -102,12 +123,16 @@ ma_status ma_sum_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct
 ma_status ma_mean_arrow(ma_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema, double* out_mean,
                         uint64_t* out_valid_count) {
     Prim p{};
-    MA_TRY(parse_primitive(array, schema, &p));
+    MA_TRY(parse_primitive(array, schema, &p, true));
     const size_t n = (size_t)array->length, off = (size_t)array->offset;
     const uint8_t* validity = (const uint8_t*)array->buffers[0];
     const char* values = (const char*)array->buffers[1] + off * p.size;
     const int64_t nc = array->null_count;
     switch (p.code) {
+        case 'c': return ma_i8_mean(ctx, (const int8_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'C': return ma_u8_mean(ctx, (const uint8_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 's': return ma_i16_mean(ctx, (const int16_t*)values, n, validity, off, nc, out_mean, out_valid_count);
+        case 'S': return ma_u16_mean(ctx, (const uint16_t*)values, n, validity, off, nc, out_mean, out_valid_count);
         case 'l': return ma_i64_mean(ctx, (const int64_t*)values, n, validity, off, nc, out_mean, out_valid_count);
         case 'L': return ma_u64_mean(ctx, (const uint64_t*)values, n, validity, off, nc, out_mean, out_valid_count);
         case 'i': return ma_i32_mean(ctx, (const int32_t*)values, n, validity, off, nc, out_mean, out_valid_count);

@@ -61,6 +61,44 @@ constexpr unsigned kTicketShardWord0 = 64;   // 256 bytes in
 constexpr unsigned kTicketShardStride = 16;  // 64 bytes
 constexpr unsigned kShardFrom = 96;          // grids up to this size arrive on the one ticket
 
+// Narrow integer columns (i8 / u8 / i16 / u16 — the reference's extended_numeric_types, src/enums/collections/
+// numeric_array.rs:81-99): 16 or 8 rows per 16-byte load. Widening every element to the u64 accumulator would cost ~48
+// VALU instructions per load; instead the valid elements of one load are summed inside 32-bit registers — bytes four at a
+// time with v_sad_u8 (sum of absolute differences against 0), halves with two masked adds — and only the per-load total
+// (< 2^20) goes to the 64-bit accumulator. Signed types are biased into unsigned ones (x ^ 0x80.. = x + 128 | 32768 as an
+// unsigned value) and the bias of the VALID elements is taken off again: exact, wrapping like every integer sum here.
+// bits: validity of the load's R rows, bit r = row r (all ones for a dense scan).
+template <typename T>
+__device__ __forceinline__ int64_t narrow_vec_sum(const typename Vec16<T>::type& v, unsigned bits) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 d = __builtin_bit_cast(u4, v);
+    constexpr bool kSigned = std::is_signed<T>::value;
+    unsigned s = 0;
+    if constexpr (sizeof(T) == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned x = kSigned ? (d[k] ^ 0x80808080u) : d[k];
+            const unsigned b = (bits >> (4 * k)) & 15u;
+            // 4 validity bits -> 4 byte masks: bit i lands on bit 8 i (no two partial products share a position)
+            const unsigned m = ((b * 0x00204081u) & 0x01010101u) * 0xFFu;
+            s = __builtin_amdgcn_sad_u8(x & m, 0u, s);
+        }
+        const int n_valid = __popc(bits & 0xFFFFu);
+        return kSigned ? (int64_t)s - 128 * (int64_t)n_valid : (int64_t)s;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned x = kSigned ? (d[k] ^ 0x80008000u) : d[k];
+            const unsigned b = (bits >> (2 * k)) & 3u;
+            const unsigned m = (b & 1u) * 0xFFFFu + (b >> 1) * 0xFFFF0000u;
+            x &= m;
+            s += (x & 0xFFFFu) + (x >> 16);
+        }
+        const int n_valid = __popc(bits & 0xFFu);
+        return kSigned ? (int64_t)s - 32768 * (int64_t)n_valid : (int64_t)s;
+    }
+}
+
 template <typename T, int UNROLL, bool MASKED, bool NT, bool IL = false, int PACE = 0>
 __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     typedef typename Vec16<T>::type V;
@@ -69,7 +107,8 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     constexpr int WPT = R * UNROLL;                  // validity words per wave run
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
-    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+    static_assert(!MASKED || WPT < 64, "a wave must be able to load its validity words in one instruction");
+    constexpr bool kNarrow = sizeof(T) <= 2;  // 8 / 16 rows per load: summed inside 32-bit registers (narrow_vec_sum)
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63;
@@ -95,8 +134,12 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
             for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(base + (k + (size_t)u * n_waves + wave_id) * 64);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
+                if constexpr (kNarrow) {
+                    acc[0].add(narrow_vec_sum<T>(v[u], ~0u));
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                    for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                }
             }
         }
 #pragma unroll
@@ -104,8 +147,12 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
             const size_t piece = k + (size_t)u * n_waves + wave_id;
             if (piece < n_pieces) {
                 V v = load16<V, NT>(base + piece * 64);
+                if constexpr (kNarrow) {
+                    acc[0].add(narrow_vec_sum<T>(v, ~0u));
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r].add((T)v[r]);
+                    for (int r = 0; r < R; ++r) acc[r].add((T)v[r]);
+                }
             }
         }
     }
@@ -129,17 +176,25 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const unsigned bits = lane_bits<R>(aw, u, lane);
+                if constexpr (kNarrow) {
+                    acc[0].add(narrow_vec_sum<T>(v[u], bits));
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    T x = ((bits >> r) & 1u) ? v[u][r] : (T)0;
-                    acc[r].add(x);
+                    for (int r = 0; r < R; ++r) {
+                        T x = ((bits >> r) & 1u) ? v[u][r] : (T)0;
+                        acc[r].add(x);
+                    }
                 }
             }
         } else {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
+                if constexpr (kNarrow) {
+                    acc[0].add(narrow_vec_sum<T>(v[u], ~0u));
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                    for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                }
             }
         }
     }
@@ -306,8 +361,8 @@ static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
             return;
         }
     }
-    // Load pacing (pace_loads) is instantiated for the non-temporal scans: a.pace picks the cycle count.
-    if constexpr (NT) {
+    // Load pacing (pace_loads) is instantiated for the non-temporal scans of 4- and 8-byte types: a.pace picks the cycle count.
+    if constexpr (NT && sizeof(T) > 2) {
         switch (a.pace) {
             case 16: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 16>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
             case 20: hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, 20>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
@@ -349,6 +404,17 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         default: break;
     }
     int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean ? 1 : 2);
+    if constexpr (R >= 8) {
+        // narrow types, masked: a wave's validity run must fit one word per lane (R x unroll < 64): 4 loads of 8 rows, 2
+        // loads of 16 rows; the bytes in flight per SIMD then come from more waves (2 / 3 workgroups per CU). Dense scans
+        // have no such limit and take the 8-deep shape of the wider integers.
+        if (masked) {
+            unroll = R == 8 ? 4 : 2;
+            if (ctx->blocks_per_cu <= 0) bpc = R == 8 ? 2 : 3;  // swept: tools/sweep_narrow_sum.py (i8 masked: 3 -> 0.79, 4 -> 0.72)
+        } else if (unroll != 2 && unroll != 4) {
+            unroll = 8;
+        }
+    }
     const size_t tile_rows = (size_t)64 * R * unroll * kWaves;
     // Rows in front of the first 16-byte boundary.
     size_t head = 0;
@@ -362,7 +428,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // variant bit 4: piece-interleaved mapping for dense scans. A/B in one process: +2 % on one MI355X, -1 % on
     // another (profiles/r01_ubench_sum_v2.txt vs r01_sweep_sum_v3.txt) — within the device-to-device spread, so the
     // tiled mapping stays the default.
-    a.interleave = (!masked && nt && unroll == 8 && (variant & 16) != 0) ? 1 : 0;
+    a.interleave = (!masked && nt && unroll == 8 && R < 8 && (variant & 16) != 0) ? 1 : 0;
     a.fenced = ((variant & 256) || ctx->fenced_reduce) ? 1 : 0;
     // Load pacing (pace_loads): idle cycles between a wave's consecutive loads. Swept per type at 10^9 rows
     // (profiles/r01_sweep_sum_pace.txt): dense i64 1.117 -> 1.099 ms at 24 cycles, f64 1.106 -> 1.095 at 20, i32 0.586 ->
@@ -373,13 +439,13 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
         const int sel = kPace[(variant >> 5) & 7];
         const int dense_default = std::is_same<T, float>::value ? 24 : std::is_same<T, double>::value ? 20 : (R == 2 ? 24 : 16);
-        a.pace = sel >= 0 ? sel : (masked ? 0 : dense_default);
+        a.pace = sel >= 0 ? sel : ((masked || R >= 8) ? 0 : dense_default);
     }
     // Mid-size columns (up to ~24 tiles per CU: 2^24 8-byte rows — the chunk sizes the reference actually runs at,
     // src/structs/chunked/super_array.rs:51-59): the lean shape's one workgroup per CU leaves the memory pipeline
     // half empty during the ramp and the tail of so short a scan; three per CU are 3-6 % faster there, and lose 3 %
     // from 2^26 rows on (profiles/r02_sweep_mid.jsonl).
-    if (lean && ctx->blocks_per_cu <= 0 && a.n_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
+    if (lean && R < 8 && ctx->blocks_per_cu <= 0 && a.n_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
     size_t work = a.n_tiles;
     if (a.interleave) {
         a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces
@@ -392,7 +458,13 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         if (nt) launch_sum<T, U, M, true>(ctx, a, grid);      \
         else launch_sum<T, U, M, false>(ctx, a, grid);        \
     } while (0)
-    if (masked) {
+    if constexpr (R >= 8) {  // narrow types: masked = the one shape per width chosen above (deeper overflows the validity run)
+        constexpr int U = R == 8 ? 4 : 2;
+        if (masked) MA_LAUNCH_U(U, true);
+        else if (unroll == 2) MA_LAUNCH_U(2, false);
+        else if (unroll == 4) MA_LAUNCH_U(4, false);
+        else MA_LAUNCH_U(8, false);
+    } else if (masked) {
         switch (unroll) {
             case 2: MA_LAUNCH_U(2, true); break;
             case 8: MA_LAUNCH_U(8, true); break;
@@ -612,6 +684,11 @@ MA_DEFINE_INT_SUM(i64, int64_t, int64_t, true)
 MA_DEFINE_INT_SUM(u64, uint64_t, uint64_t, false)
 MA_DEFINE_INT_SUM(i32, int32_t, int64_t, true)
 MA_DEFINE_INT_SUM(u32, uint32_t, uint64_t, false)
+// the reference's extended_numeric_types (src/enums/collections/numeric_array.rs:81-99; dispatch.rs:380-387)
+MA_DEFINE_INT_SUM(i16, int16_t, int64_t, true)
+MA_DEFINE_INT_SUM(u16, uint16_t, uint64_t, false)
+MA_DEFINE_INT_SUM(i8, int8_t, int64_t, true)
+MA_DEFINE_INT_SUM(u8, uint8_t, uint64_t, false)
 
 #define MA_DEFINE_FLOAT_SUM(NAME, T)                                                                                \
     ma_status ma_##NAME##_sum(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset, \

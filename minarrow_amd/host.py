@@ -308,7 +308,7 @@ class Context:
         cnt = C.c_uint64()
         if tag in ("f64", "f32"):
             out = C.c_double()
-        elif tag in ("i64", "i32"):
+        elif tag in ("i64", "i32", "i16", "i8"):
             out = C.c_int64()
         else:
             out = C.c_uint64()

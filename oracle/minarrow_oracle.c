@@ -407,6 +407,27 @@ MO_API void mo_masked_sum_i32(const int32_t* data, size_t n, const uint8_t* bits
     *out_count = cnt;
 }
 
+/* The reference's extended_numeric_types (src/enums/collections/numeric_array.rs:81-99): the same build-defined scalar loop,
+ * every element widened to 64 bits (sign- or zero-extended) before the wrapping add. `is_signed` picks the extension. */
+#define MO_DEFINE_NARROW_MASKED_SUM(NAME, T, WIDEN)                                                              \
+    MO_API void mo_masked_sum_##NAME(const T* data, size_t n, const uint8_t* bits, size_t bit_offset, int64_t* out_sum, \
+                                     uint64_t* out_count) {                                                      \
+        uint64_t acc = 0, cnt = 0;                                                                               \
+        for (size_t i = 0; i < n; ++i) {                                                                         \
+            if (bits == NULL || mo_get_bit(bits, bit_offset + i)) {                                              \
+                acc += (uint64_t)(WIDEN)data[i];                                                                 \
+                ++cnt;                                                                                           \
+            }                                                                                                    \
+        }                                                                                                        \
+        *out_sum = (int64_t)acc;                                                                                 \
+        *out_count = cnt;                                                                                        \
+    }
+MO_DEFINE_NARROW_MASKED_SUM(i8, int8_t, int64_t)
+MO_DEFINE_NARROW_MASKED_SUM(u8, uint8_t, uint64_t)
+MO_DEFINE_NARROW_MASKED_SUM(i16, int16_t, int64_t)
+MO_DEFINE_NARROW_MASKED_SUM(u16, uint16_t, uint64_t)
+MO_DEFINE_NARROW_MASKED_SUM(u32, uint32_t, uint64_t)
+
 /* Plain left-to-right masked f64 sum. The exactly rounded value the GPU is held to comes from
  * Python's math.fsum in the tests; this is the "what a scalar CPU loop gives" companion. */
 MO_API void mo_masked_sum_f64(const double* data, size_t n, const uint8_t* bits, size_t bit_offset, double* out_sum,

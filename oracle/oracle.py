@@ -78,6 +78,7 @@ def _declare(l: C.CDLL) -> None:
         "mo_masked_sum_i64": (None, [vp, sz, vp, sz, vp, vp]),
         "mo_masked_sum_i32": (None, [vp, sz, vp, sz, vp, vp]),
         "mo_masked_sum_f64": (None, [vp, sz, vp, sz, vp, vp]),
+        **{f"mo_masked_sum_{t}": (None, [vp, sz, vp, sz, vp, vp]) for t in ("i8", "u8", "i16", "u16", "u32")},
     }
     for name, (ret, args) in sig.items():
         if hasattr(l, name):
@@ -155,6 +156,15 @@ def masked_sum(a: np.ndarray, bits: np.ndarray, bit_offset: int = 0):
     elif a.dtype == np.float64:
         out = C.c_double()
         l.mo_masked_sum_f64(_p(a), a.size, _p(bits), bit_offset, C.addressof(out), C.addressof(cnt))
+    elif a.dtype in (np.int8, np.uint8, np.int16, np.uint16, np.uint32):
+        # extended_numeric_types: 64-bit wrapping sum of the widened elements; bits=None = every row valid
+        out = C.c_int64()
+        name = {np.dtype(np.int8): "i8", np.dtype(np.uint8): "u8", np.dtype(np.int16): "i16", np.dtype(np.uint16): "u16",
+                np.dtype(np.uint32): "u32"}[a.dtype]
+        getattr(l, f"mo_masked_sum_{name}")(_p(a), a.size, _p(bits) if bits is not None else None, bit_offset,
+                                            C.addressof(out), C.addressof(cnt))
+        if a.dtype.kind == "u":
+            return out.value & ((1 << 64) - 1), int(cnt.value)
     else:
         raise TypeError(a.dtype)
     return out.value, int(cnt.value)

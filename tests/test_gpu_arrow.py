@@ -68,7 +68,8 @@ def test_random_arrays_with_nulls_and_slices(ctx, fmt):
 
 
 def test_unsupported_formats_are_rejected(ctx):
-    for arr in (pa.array(["a", "b"]), pa.array([True, False]), pa.array([1, 2], type=pa.int16())):
+    for arr in (pa.array(["a", "b"]), pa.array([True, False]), pa.array(np.array([1, 2], dtype=np.float16)),
+                pa.array([1, 2], type=pa.date32())):
         with Exported(arr) as ex:
             with pytest.raises(ffi.MinarrowHipError) as e:
                 ctx.sum_arrow(ex.array_ptr, ex.schema_ptr)
@@ -131,3 +132,29 @@ def test_apply_arrow_errors(ctx):
     with pytest.raises(ffi.MinarrowHipError) as e:
         run_apply(ctx, "divide", a, pa.array([1, 0, 3], type=pa.int64()))
     assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+
+
+@pytest.mark.parametrize("pa_type,code", [(pa.int8(), "c"), (pa.uint8(), "C"), (pa.int16(), "s"), (pa.uint16(), "S")])
+def test_narrow_integer_arrays_reduce_but_do_not_route(ctx, pa_type, code):
+    """The reference's extended_numeric_types as Arrow arrays ('c' 'C' 's' 'S'): ma_sum_arrow / ma_mean_arrow reduce them
+    (nulls, slices with a non-zero offset), against pyarrow.compute; the arithmetic type matrix
+    (arithmetic_dispatch, src/kernels/routing/arithmetic.rs:280-339) has no arm for them: UnsupportedType."""
+    rng = np.random.default_rng(ord(code))
+    n = 50_017
+    np_dt = pa_type.to_pandas_dtype()
+    info = np.iinfo(np_dt)
+    vals = rng.integers(info.min, info.max, size=n, endpoint=True).astype(np_dt)
+    arr = pa.array(vals, type=pa_type, mask=rng.random(n) < 0.1)
+    for sl in (arr, arr.slice(3, 40_000), arr.slice(64 * 7 + 5, 4099), pa.array(vals, type=pa_type)):
+        with Exported(sl) as ex:
+            assert ex.schema.format == code.encode() if isinstance(ex.schema.format, bytes) else True
+            f, i, c = ctx.sum_arrow(ex.array_ptr, ex.schema_ptr)
+            m, c2 = ctx.mean_arrow(ex.array_ptr, ex.schema_ptr)
+        want = pc.sum(sl.cast(pa.int64())).as_py() or 0
+        assert c == c2 == len(sl) - sl.null_count and i == want and f == float(want)
+        assert m == float(want) / c
+    with Exported(arr) as l, Exported(arr) as r:
+        out = ctx.alloc(n * 8)
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            ctx.apply_arrow(0, (l.array_ptr, l.schema_ptr), (r.array_ptr, r.schema_ptr), out, None)
+        assert e.value.status == ffi.MA_ERR_UNSUPPORTED

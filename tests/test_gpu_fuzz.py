@@ -41,7 +41,7 @@ def rand_values(rng, dt, n, small=False):
 
 
 @settings(**COMMON)
-@given(tag=st.sampled_from(["i32", "u32", "i64", "u64", "f32", "f64"]), n=lengths, elem_off=st.integers(0, 7),
+@given(tag=st.sampled_from(["i32", "u32", "i64", "u64", "f32", "f64", "i8", "u8", "i16", "u16"]), n=lengths, elem_off=st.integers(0, 7),
        mask_off=st.integers(0, 130), masked=st.booleans(), null_pct=st.sampled_from([0, 1, 10, 50, 100]),
        seed=st.integers(0, 2**31))
 def test_sum(ctx, tag, n, elem_off, mask_off, masked, null_pct, seed):

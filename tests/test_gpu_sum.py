@@ -383,3 +383,83 @@ def test_both_publish_forms_of_the_reduction_agree(ctx, oracle, n):
         assert got[(0, grid)][:2] == got[(0, 0)][:2]       # integers: any grid
     for b in (da, df, dm):
         b.free()
+
+
+# ---- extended_numeric_types: i8 / u8 / i16 / u16 columns (src/enums/collections/numeric_array.rs:81-99) ---------------
+NARROW = [("i8", np.int8), ("u8", np.uint8), ("i16", np.int16), ("u16", np.uint16)]
+
+
+@pytest.mark.parametrize("tag,dt", NARROW)
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 1000, 4095, 4096, 4097, 32768, 100_003, (1 << 22) + 37])
+def test_narrow_int_sums_dense_and_masked(ctx, oracle, tag, dt, n):
+    """16 / 8 rows per 16-byte load are summed inside 32-bit registers (v_sad_u8, masked half adds; signed types through a
+    bias): bit-exact against the oracle's widening scalar loop — extreme values, every validity phase, windows that start
+    off the 16-byte boundary, pageable and device operands, sum and mean."""
+    rng = np.random.default_rng(n * 7 + len(tag))
+    info = np.iinfo(dt)
+    for kind in ("random", "extremes"):
+        if kind == "random":
+            a = rng.integers(info.min, info.max, size=n + 5, endpoint=True).astype(dt)
+        else:
+            a = rng.choice(np.array([info.min, info.max, 0, -1 if info.min < 0 else 1], dtype=dt), size=n + 5)
+        bits = rng.integers(0, 256, size=(n + 200) // 8 + 24, dtype=np.uint8)
+        d, m = ctx.to_device(a, 64), ctx.to_device(bits, 16)
+        for shift in (0, 1, 3):  # element offsets: the window starts mid-vector
+            win = a[shift:shift + n]
+            want = oracle.masked_sum(np.ascontiguousarray(win), None, 0)
+            assert ctx.sum(tag, d.offset(shift * a.itemsize), n) == want, (tag, kind, n, shift)
+            for off in (0, 5, 64, 77):
+                want = oracle.masked_sum(np.ascontiguousarray(win), bits, off)
+                got = ctx.sum(tag, d.offset(shift * a.itemsize), n, mask=m, mask_bit_offset=off)
+                assert got == want, (tag, kind, n, shift, off, got, want)
+        # host (pageable) operand, and the mean
+        want = oracle.masked_sum(np.ascontiguousarray(a[:n]), bits, 3)
+        assert ctx.sum(tag, np.ascontiguousarray(a[:n]), n, mask=bits, mask_bit_offset=3) == want
+        mean, cnt = ctx.mean(tag, d, n, mask=m, mask_bit_offset=3)
+        signed = info.min < 0
+        s = want[0] - (1 << 64) if (signed and want[0] >= 1 << 63) else want[0]
+        assert cnt == want[1] and (np.isnan(mean) if cnt == 0 else mean == float(s) / cnt)
+        d.free()
+        m.free()
+
+
+@pytest.mark.parametrize("tag,dt", NARROW)
+def test_narrow_int_sum_of_a_large_column(ctx, tag, dt):
+    """2^31 + 77 rows (more than 32 bits of index for the 1-byte types' byte offsets would need; the per-load 32-bit partial
+    sums must not leak between loads): closed form of a repeating pattern, dense and with every third row null."""
+    n = (1 << 31) + 77
+    item = np.dtype(dt).itemsize
+    buf = ctx.alloc(n * item + 64)
+    pattern = np.arange(-3, 13, dtype=np.int64).astype(dt)  # 16 values, wraps for unsigned
+    # fill by doubling copies on the device: pattern -> 2^k repeats
+    ctx.lib.ma_dev_upload(ctx.handle, buf.ptr, pattern.ctypes.data, pattern.nbytes)
+    filled = pattern.size
+    while filled < n:
+        k = min(filled, n - filled)
+        ctx.dev_copy(buf.ptr + filled * item, buf.ptr, k * item)
+        filled += k
+    reps, rem = divmod(n, pattern.size)
+    wide = pattern.astype(np.int64 if np.dtype(dt).kind == "i" else np.uint64)
+    want = (int(wide.sum()) * reps + int(wide[:rem].sum())) & ((1 << 64) - 1)
+    got, cnt = ctx.sum(tag, buf, n)
+    assert (got & ((1 << 64) - 1), cnt) == (want, n)
+    # every third row null (bit pattern 0b110110..., period 3 bits = 24 bits = 3 bytes)
+    mbytes = n // 8 + 64
+    mask = ctx.alloc(mbytes)
+    period = np.array([0b10110110, 0b01101101, 0b11011011], dtype=np.uint8)  # bit i set iff i % 3 != 0
+    ctx.lib.ma_dev_upload(ctx.handle, mask.ptr, period.ctypes.data, 3)
+    filled = 3
+    while filled < mbytes:
+        k = min(filled, mbytes - filled)
+        ctx.dev_copy(mask.ptr + filled, mask.ptr, k)
+        filled += k
+    idx = np.arange(48, dtype=np.int64)  # lcm(16, 3) rows: one period of (value, validity)
+    vals = wide[idx % 16]
+    valid = (idx % 3) != 0
+    reps, rem = divmod(n, 48)
+    want = (int(vals[valid].sum()) * reps + int(vals[:rem][valid[:rem]].sum())) & ((1 << 64) - 1)
+    want_cnt = int(valid.sum()) * reps + int(valid[:rem].sum())
+    got, cnt = ctx.sum(tag, buf, n, mask=mask)
+    assert (got & ((1 << 64) - 1), cnt) == (want, want_cnt)
+    buf.free()
+    mask.free()

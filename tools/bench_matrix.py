@@ -114,7 +114,7 @@ def main():
         ctx.synchronize()
 
     # ---- reductions ----
-    for tag in ("i64", "u64", "f64", "i32", "u32", "f32"):
+    for tag in ("i64", "u64", "f64", "i32", "u32", "f32", "i16", "u16", "i8", "u8"):
         if not want("sum"):
             break
         n = fill(tag)
