@@ -309,7 +309,7 @@ ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* m
 /* Per-column {sum, valid count} of n_cols columns of ONE element type in two launches, whatever n_cols is — the
  * per-column reduce of a wide Table or of the chunks of a SuperTable (BASELINE config 5). A launch costs ~4 us on
  * MI355X, so the column-at-a-time loop of the reference (one pass per Array, benches/hotloop_benchmark_std.rs:109-127)
- * is launch-bound for many small columns. format_code as in Arrow ('i','I','l','L','f','g'); column i =
+ * is launch-bound for many small columns. format_code as in Arrow ('c','C','s','S','i','I','l','L','f','g'); column i =
  * (col_data[i], col_lens[i]) with optional validity col_masks[i] whose row 0 is bit col_mask_offsets[i] (both
  * tables may be NULL). Outputs are arrays of n_cols entries, any may be NULL: integer formats write the wrapping
  * 64-bit sum to out_sums_i64 and its conversion to out_sums_f64; float formats write out_sums_f64 only (within 1 ULP

@@ -220,4 +220,42 @@ __device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
     return (unsigned)(((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
 }
 
+// Narrow integer columns (i8 / u8 / i16 / u16 — the reference's extended_numeric_types, src/enums/collections/
+// numeric_array.rs:81-99): 16 or 8 rows per 16-byte load. Widening every element to the u64 accumulator would cost ~48
+// VALU instructions per load; instead the valid elements of one load are summed inside 32-bit registers — bytes four at a
+// time with v_sad_u8 (sum of absolute differences against 0), halves with two masked adds — and only the per-load total
+// (< 2^20) goes to the 64-bit accumulator. Signed types are biased into unsigned ones (x ^ 0x80.. = x + 128 | 32768 as an
+// unsigned value) and the bias of the VALID elements is taken off again: exact, wrapping like every integer sum here.
+// bits: validity of the load's R rows, bit r = row r (all ones for a dense scan).
+template <typename T>
+__device__ __forceinline__ int64_t narrow_vec_sum(const typename Vec16<T>::type& v, unsigned bits) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 d = __builtin_bit_cast(u4, v);
+    constexpr bool kSigned = std::is_signed<T>::value;
+    unsigned s = 0;
+    if constexpr (sizeof(T) == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned x = kSigned ? (d[k] ^ 0x80808080u) : d[k];
+            const unsigned b = (bits >> (4 * k)) & 15u;
+            // 4 validity bits -> 4 byte masks: bit i lands on bit 8 i (no two partial products share a position)
+            const unsigned m = ((b * 0x00204081u) & 0x01010101u) * 0xFFu;
+            s = __builtin_amdgcn_sad_u8(x & m, 0u, s);
+        }
+        const int n_valid = __popc(bits & 0xFFFFu);
+        return kSigned ? (int64_t)s - 128 * (int64_t)n_valid : (int64_t)s;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned x = kSigned ? (d[k] ^ 0x80008000u) : d[k];
+            const unsigned b = (bits >> (2 * k)) & 3u;
+            const unsigned m = (b & 1u) * 0xFFFFu + (b >> 1) * 0xFFFF0000u;
+            x &= m;
+            s += (x & 0xFFFFu) + (x >> 16);
+        }
+        const int n_valid = __popc(bits & 0xFFu);
+        return kSigned ? (int64_t)s - 32768 * (int64_t)n_valid : (int64_t)s;
+    }
+}
+
 }  // namespace ma

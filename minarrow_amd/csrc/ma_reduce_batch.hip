@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);
     constexpr int WPT = R * UNROLL;
+    constexpr bool kNarrow = sizeof(T) <= 2;  // 8 / 16 rows per load, summed inside 32-bit registers (narrow_vec_sum)
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
     static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
@@ -85,14 +86,22 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const unsigned bits = lane_bits<R>(aw, u, lane);
+                    if constexpr (kNarrow) {
+                        acc[0].add(narrow_vec_sum<T>(v[u], bits));
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r].add(((bits >> r) & 1u) ? (T)v[u][r] : (T)0);
+                        for (int r = 0; r < R; ++r) acc[r].add(((bits >> r) & 1u) ? (T)v[u][r] : (T)0);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
+                    if constexpr (kNarrow) {
+                        acc[0].add(narrow_vec_sum<T>(v[u], ~0u));
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                        for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
+                    }
                 }
             }
         }
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __re
 template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, size_t n_cols, size_t n_segs, Partial* partials, bool is_signed,
                            double* of, uint64_t* oi, uint64_t* oc) {
-    constexpr int UNROLL = sizeof(T) == 8 ? 8 : 4;
+    constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
     const int grid1 = grid_for(ctx, n_segs, 2);
     hipLaunchKernelGGL((column_segments_kernel<T, UNROLL>), dim3(grid1), dim3(kBlock), 0, ctx->stream, d, (int)n_cols,
                        n_segs, partials);
@@ -206,6 +215,8 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     size_t elem = 0;
     switch (format_code) {
+        case 'c': case 'C': elem = 1; break;
+        case 's': case 'S': elem = 2; break;
         case 'i': case 'I': case 'f': elem = 4; break;
         case 'l': case 'L': case 'g': elem = 8; break;
         default:
@@ -255,6 +266,10 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     const ColDesc* d = (const ColDesc*)scratch;
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     switch (format_code) {
+        case 'c': launch_columns<int8_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 's': launch_columns<int16_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
         case 'i': launch_columns<int32_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
         case 'I': launch_columns<uint32_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
         case 'l': launch_columns<int64_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;

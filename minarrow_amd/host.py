@@ -357,7 +357,7 @@ class Context:
         cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
         ffi.check(self.lib.ma_sum_columns(self.handle, ord(fmt), k, cast(data_arr), cast(len_arr), cast(mask_arr),
                                           cast(off_arr), addr_of(f), addr_of(i), addr_of(c)))
-        return f, (i if fmt in "iIlL" else None), c
+        return f, (i if fmt in "cCsSiIlL" else None), c
 
     def fold_sum_records(self, records, n_records: int, stride_words: int, out4) -> None:
         """Device-side, rank-ordered fold of gathered reduction records (ma_fold_sum_records)."""

@@ -215,12 +215,13 @@ def test_consolidate(ctx, elem, lens, starts, with_masks, seed, variant):
 
 
 @settings(**COMMON)
-@given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g"]),
+@given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g", "c", "C", "s", "S"]),
        lens=st.lists(st.one_of(st.sampled_from(EDGES), st.integers(0, 150_000)), min_size=1, max_size=12),
        starts=st.lists(st.integers(0, 5), min_size=12, max_size=12), with_masks=st.booleans(), seed=st.integers(0, 2**31))
 def test_sum_columns(ctx, fmt, lens, starts, with_masks, seed):
     rng = np.random.default_rng(seed)
-    dt = np.dtype({"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64}[fmt])
+    dt = np.dtype({"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64,
+                   "c": np.int8, "C": np.uint8, "s": np.int16, "S": np.uint16}[fmt])
     cols = [rand_values(rng, dt, n + s) for n, s in zip(lens, starts)]
     devs = [ctx.to_device(c, 64) for c in cols]
     ptrs = [d.ptr + s * dt.itemsize for d, s in zip(devs, starts)]
