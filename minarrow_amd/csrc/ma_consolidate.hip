@@ -100,14 +100,24 @@ __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restr
 // led here: the copy and the host's table building, not the search, are what the chunked regime pays for).
 struct ConcatChunk {  // 32 bytes
     const void* data;
-    uint64_t start;  // first output row
-    uint64_t len;
-    uint64_t pad;
+    uint64_t start;       // first output row
+    uint64_t len_bit;     // rows (low 58 bits) | bit index of row 0 inside words[0] (high 6 bits)
+    const uint64_t* words;  // the word of the chunk's bitmap that holds its row 0, or nullptr = all rows valid / no validity
 };
+constexpr uint64_t kConcatLenMask = (((uint64_t)1) << 58) - 1;
+// The validity fields ride in the SAME 32-byte entry: a second table (16 bytes per chunk) doubled the number of reads
+// that cross PCIe per chunk, and at 8192-row chunks of a 4-byte column — 18 us of rows per chunk per workgroup, 1536
+// workgroups — the request rate, not the bytes, became the limit (kernel trace: +14 % with the second table, +1.5 % on an
+// 8-byte column whose chunks take twice as long).
 
-template <typename T, int UNROLL>
+// MASK: the workgroup that copies chunk c also writes the output validity words that lie wholly inside the chunk's rows
+// (for 8192-row chunks on 64-row boundaries: all 128 of them, by one pass of two waves) — one funnel shift of an unaligned
+// 8-byte load each, no search. Words that hold a join of two chunks (a chunk starting in the middle of a word) are left to
+// concat_mask_joins_kernel; the column's last, partial word belongs to the chunk it begins in.
+template <typename T, int UNROLL, bool MASK>
 __global__ __launch_bounds__(kBlock) void concat_chunk_kernel(const ConcatChunk* __restrict__ cd, int n_chunks,
-                                                              T* __restrict__ out) {
+                                                              T* __restrict__ out, uint64_t* __restrict__ out_words,
+                                                              size_t total) {
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * UNROLL * kWaves;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,13 +128,60 @@ __global__ __launch_bounds__(kBlock) void concat_chunk_kernel(const ConcatChunk*
         const int next = c + (int)gridDim.x;
         ConcatChunk en{};
         if (next < n_chunks) en = cd[next];  // wave-uniform address: a scalar load, in flight while this chunk streams
-        const size_t len = (size_t)e.len;
+        const size_t len = (size_t)(e.len_bit & kConcatLenMask);
+        struct {
+            const uint64_t* words;
+            size_t bit_off;
+        } m{e.words, (size_t)(e.len_bit >> 58)};
         if (len) {
             T* dst = out + e.start;
             const unsigned mis = (unsigned)((uintptr_t)dst & 15);
             const unsigned head = mis ? (16 - mis) / (unsigned)sizeof(T) : 0;
             const size_t n_t = len > head ? (len - head + TILE_ROWS - 1) / TILE_ROWS : 1;
+            // validity words of this chunk: thread t takes word w0 + t (+ kBlock, ...). The first word's loads are issued
+            // BEFORE the data tiles and consumed after them, so that their latency hides behind the chunk's rows instead of
+            // following them (measured: +11 % on a 4-byte column of 8192-row chunks when the words were loaded afterwards)
+            const size_t start = (size_t)e.start, end = start + len;
+            const size_t w0 = (start + 63) >> 6, w1 = end >> 6;
+            const bool tail = end == total && (end & 63) != 0 && w0 <= w1;  // the partial last word begins in this chunk
+            const size_t n_w = MASK ? (w1 > w0 ? w1 - w0 : 0) + (tail ? 1 : 0) : 0;
+            const size_t last_word = ((size_t)m.bit_off + len - 1) >> 6;
+            auto fetch = [&](size_t t, uint64_t& lo, uint64_t& hi, unsigned& sh) {
+                const size_t row = (w0 + t) << 6;
+                const size_t b = (size_t)m.bit_off + (row - start);
+                if (end - row >= 64) {
+                    // bits b .. b + 63 are window bits: bytes b/8 .. b/8 + 7, and (b % 8 != 0) byte b/8 + 8, hold them
+                    typedef uint64_t u64u __attribute__((aligned(1)));
+                    const uint8_t* base = (const uint8_t*)m.words + (b >> 3);
+                    sh = (unsigned)(b & 7);
+                    lo = *(const u64u*)base;
+                    hi = sh ? (uint64_t)base[8] : 0;
+                } else {
+                    const size_t wi = b >> 6;
+                    sh = (unsigned)(b & 63);
+                    lo = m.words[wi];
+                    hi = (sh && wi + 1 <= last_word) ? m.words[wi + 1] : 0;
+                }
+            };
+            uint64_t lo0 = 0, hi0 = 0;
+            unsigned sh0 = 0;
+            const bool mine = MASK && threadIdx.x < n_w && m.words != nullptr;
+            if (mine) fetch(threadIdx.x, lo0, hi0, sh0);
             for (size_t lt = 0; lt < n_t; ++lt) concat_tile<T, UNROLL>((const T*)e.data, dst, head, len, lt, lane, wave);
+            if constexpr (MASK) {
+                for (size_t t = threadIdx.x; t < n_w; t += kBlock) {
+                    const size_t w = w0 + t, avail = end - (w << 6);
+                    uint64_t v = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
+                    if (m.words != nullptr) {
+                        uint64_t lo = lo0, hi = hi0;
+                        unsigned sh = sh0;
+                        if (t != threadIdx.x) fetch(t, lo, hi, sh);
+                        v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                    }
+                    if (avail < 64) v &= (((uint64_t)1) << avail) - 1;  // bits >= total stay zero
+                    __builtin_nontemporal_store(v, out_words + w);
+                }
+            }
         }
         if (next >= n_chunks) break;
         c = next;
@@ -276,6 +333,30 @@ static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks,
         hipLaunchKernelGGL(concat_mask_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
 }
 
+// The words concat_chunk_kernel<MASK> leaves out: those a chunk STARTS in the middle of. One thread per chunk; the first
+// non-empty chunk that starts inside a word owns it and gathers it from the chunks either side (gather_word). Launched
+// only when the host saw such a start (chunk lengths that are not multiples of 64 rows).
+__global__ __launch_bounds__(kBlock) void concat_mask_joins_kernel(const MaskDesc* __restrict__ compact, int n_chunks,
+                                                                   size_t total, uint64_t* __restrict__ out_words) {
+    const DescTable<false> tab{nullptr, compact};
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)n_chunks; i += stride) {
+        const int c = (int)i;
+        const size_t start = compact[c].start;
+        if (compact[c].len == 0 || (start & 63) == 0) continue;
+        const size_t row = start & ~(size_t)63;
+        int first = c;  // the chunk that holds the word's first row
+        bool owner = true;
+        for (int k = c - 1; k >= 0; --k) {
+            if (compact[k].len == 0) continue;
+            if (compact[k].start > row) owner = false;  // an earlier chunk starts inside this word too: it (or one before it) owns
+            else first = k;
+            break;
+        }
+        if (owner) out_words[row >> 6] = gather_word<false>(tab, first, row, total);
+    }
+}
+
 template <typename T>
 static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t n_tiles, void* out) {
     int grid = grid_for(ctx, n_tiles, 6);  // store stream in the mix: more workgroups (profiles/r01_sweep_grid.json)
@@ -338,8 +419,18 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
         if (ctx->variant & 128) by_chunk = false;
         if (ctx->variant & 256) by_chunk = true;
         if (by_chunk && elem_size >= 4) {
+            // validity: the words inside a chunk are written by the chunk's workgroup; only when some chunk starts in the
+            // middle of a word (lengths that are not multiples of 64) is there a join pass, and only then a whole-list table
+            bool has_join = false;
+            if (has_mask) {
+                size_t r = 0;
+                for (size_t i = 0; i < n_chunks && !has_join; ++i) {
+                    has_join = chunk_lens[i] != 0 && (r & 63) != 0;
+                    r += chunk_lens[i];
+                }
+            }
             std::vector<MaskDesc> mdesc;
-            if (has_mask) mdesc.resize(n_chunks);
+            if (has_join) mdesc.resize(n_chunks);
             DeviceRange data_role, mask_role;
             const size_t kFirst = 4096, kMax = 32768;
             size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
@@ -353,23 +444,30 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
                         MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
                         if (chunk_lens[i]) data_role.learn(chunk_data[i]);
                     }
-                    cd[i - c0] = ConcatChunk{p, (uint64_t)row, (uint64_t)chunk_lens[i], 0};
+                    MA_REQUIRE(chunk_lens[i] <= kConcatLenMask, MA_ERR_INVALID_ARGUMENT, "chunk %zu is too long", i);
+                    const uint64_t* words = nullptr;
+                    size_t bit_off = 0;
                     if (has_mask) {
-                        MaskDesc& m = mdesc[i];
-                        m = MaskDesc{row, chunk_lens[i], nullptr, 0, 0};
                         if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
                             const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
                             if (mask_role.holds(chunk_masks[i])) {
                                 const uintptr_t addr = (uintptr_t)chunk_masks[i], base = addr & ~(uintptr_t)7;
-                                m.words = (const uint64_t*)base;
-                                m.bit_off = mo + (size_t)(addr - base) * 8;
+                                words = (const uint64_t*)base;
+                                bit_off = mo + (size_t)(addr - base) * 8;
                             } else {
-                                MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &m.words, &m.bit_off));
+                                MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &words, &bit_off));
                                 mask_role.learn(chunk_masks[i]);
                             }
-                            m.last_word = (m.bit_off + m.len - 1) >> 6;
                         }
+                        if (words) {  // to the word that holds row 0: six bits of offset are left
+                            words += bit_off >> 6;
+                            bit_off &= 63;
+                        }
+                        if (has_join)
+                            mdesc[i] = MaskDesc{row, chunk_lens[i], words, bit_off,
+                                                words ? (bit_off + chunk_lens[i] - 1) >> 6 : 0};
                     }
+                    cd[i - c0] = ConcatChunk{p, (uint64_t)row, (uint64_t)chunk_lens[i] | ((uint64_t)bit_off << 58), words};
                     row += chunk_lens[i];
                 }
                 const void* tab = nullptr;
@@ -377,22 +475,32 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
                 MA_TRY(table_commit_mapped(ctx, cd, &tab, &slot));
                 const int n = (int)(c1 - c0);
                 const int grid = grid_for(ctx, (size_t)n, 6);
-                if (elem_size == 4)  // two 4 x 16-byte tiles per 8192-row chunk (4-byte), two 8 x 16-byte tiles (8-byte)
-                    hipLaunchKernelGGL((concat_chunk_kernel<uint32_t, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                                       (const ConcatChunk*)tab, n, (uint32_t*)po);
+                const ConcatChunk* tcd = (const ConcatChunk*)tab;
+                // two 4 x 16-byte tiles per 8192-row chunk (4-byte), two 8 x 16-byte tiles (8-byte)
+                if (elem_size == 4 && has_mask)
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint32_t, 4, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd,
+                                       n, (uint32_t*)po, ow, total);
+                else if (elem_size == 4)
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint32_t, 4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd,
+                                       n, (uint32_t*)po, ow, total);
+                else if (has_mask)
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint64_t, 8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd,
+                                       n, (uint64_t*)po, ow, total);
                 else
-                    hipLaunchKernelGGL((concat_chunk_kernel<uint64_t, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                                       (const ConcatChunk*)tab, n, (uint64_t*)po);
+                    hipLaunchKernelGGL((concat_chunk_kernel<uint64_t, 8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd,
+                                       n, (uint64_t*)po, ow, total);
                 MA_HIP(hipGetLastError());
                 MA_TRY(table_release(ctx, slot));
                 c0 = c1;
                 if (seg < kMax) seg *= 2;
             }
-            if (has_mask) {  // the validity join searches the whole list by output row: one compact table, uploaded
+            if (has_join) {  // the join pass walks the list either side of a chunk: one compact table, uploaded
                 void* dm = nullptr;
                 MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks, &dm));
                 MA_TRY(upload_table(ctx, mdesc.data(), sizeof(MaskDesc) * n_chunks, dm));
-                launch_concat_mask(ctx, nullptr, n_chunks, total, ow, (const MaskDesc*)dm);
+                const int grid = grid_for(ctx, (n_chunks + kBlock - 1) / kBlock, 8);
+                hipLaunchKernelGGL(concat_mask_joins_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MaskDesc*)dm,
+                                   (int)n_chunks, total, ow);
                 MA_HIP(hipGetLastError());
             }
             return end_call(ctx, scope);

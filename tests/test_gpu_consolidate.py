@@ -28,10 +28,11 @@ def run(ctx, chunks, masks=None, offs=None, device=True):
         d_masks = [ctx.to_device(m, 16) if m is not None else None for m in masks] if masks is not None else None
         out = ctx.alloc(max(total, 1) * dt.itemsize + 64)
         om = ctx.alloc(nbytes(total) + 8)
+        ctx.dev_memset(om, 0xA5, nbytes(total) + 8)  # a validity word no kernel writes would show
         has = ctx.consolidate_column(dt.itemsize, d_chunks, [c.size for c in chunks], out, d_masks, offs, om)
         return out.download(dt, total), (om.download(np.uint8, nbytes(total)) if has else None)
     out = np.zeros(total, dtype=dt)
-    om = np.zeros(nbytes(total) + 8, dtype=np.uint8)
+    om = np.full(nbytes(total) + 8, 0xA5, dtype=np.uint8)
     has = ctx.consolidate_column(dt.itemsize, chunks, [c.size for c in chunks], out, masks, offs, om)
     return out, (om[:nbytes(total)] if has else None)
 
@@ -127,6 +128,50 @@ def test_many_small_chunks(ctx, oracle, k, dt, variant):
     got, got_mask = run_bool(ctx, bchunks, bmasks)
     np.testing.assert_array_equal(got, want)
     np.testing.assert_array_equal(got_mask, want_mask)
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.float64])
+@pytest.mark.parametrize("shape", ["aligned", "aligned_tail", "few_joins", "tail_in_join", "tiny_runs"])
+@pytest.mark.parametrize("variant", [256, 256 + 1024])  # the chunk form forced; in segments | as one segment
+def test_chunk_form_validity_words(ctx, oracle, dt, shape, variant):
+    """The chunk-per-workgroup consolidate writes a chunk's validity words from the chunk's own workgroup and leaves only
+    the words a chunk STARTS inside to a join pass (launched only when there is such a word). Shapes: every chunk a
+    multiple of 64 rows (RechunkStrategy::Auto's 8192 among them: no join pass at all); the same with a ragged last chunk
+    (the partial last word belongs to the chunk it begins in); a few ragged chunks among aligned ones; a last word that is
+    itself a join; and runs of chunks shorter than a word, empty ones included (several starts inside one word: one owner).
+    Bitmaps at odd bit offsets on two thirds of the chunks; the output bitmap is poisoned beforehand."""
+    rng = np.random.default_rng(len(shape) * 7 + variant)
+    k = 9000 if shape in ("aligned_tail", "few_joins") else 5000  # 9000: three segments unless variant 1024
+    lens = [int(x) for x in rng.choice([0, 64, 128, 640, 8192], size=k, p=[0.1, 0.3, 0.3, 0.25, 0.05])]
+    if shape == "aligned_tail":
+        lens[-1] = 8192 + 37
+    elif shape == "few_joins":
+        for i in rng.choice(k, size=40, replace=False):
+            lens[int(i)] = int(rng.choice([1, 63, 65, 100, 8191]))
+    elif shape == "tail_in_join":
+        lens[-3:] = [64 + 5, 0, 11]
+    elif shape == "tiny_runs":
+        for i in range(100, 400):
+            lens[i] = int(rng.choice([0, 0, 1, 2, 5, 17, 63]))
+        lens[-1] = 3
+    chunks = [rng.integers(0, 1 << 30, size=n).astype(dt) for n in lens]
+    masks, offs = [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0:
+            masks.append(None)
+            offs.append(0)
+        else:
+            off = int(rng.integers(0, 100))
+            masks.append(rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8))
+            offs.append(off)
+    want, want_mask = oracle.consolidate_column(chunks, masks, offs)
+    ctx.set_variant(variant)
+    try:
+        out, mask = run(ctx, chunks, masks, offs)
+    finally:
+        ctx.set_variant(0)
+    np.testing.assert_array_equal(out, want)
+    np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
 
 
 def test_config5_shape_consolidate_then_reduce(ctx):
