@@ -756,6 +756,21 @@ ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32
                                          const uint8_t* null_mask_override, void* const* out_data,
                                          uint8_t* const* out_masks, int32_t* out_has_mask);
 
+/* broadcast_superarray_to_scalar / broadcast_scalar_to_superarray — src/kernels/broadcast/super_array.rs:87-116 and
+ * src/kernels/broadcast/scalar.rs:214-243 (their SuperArrayView twins: super_array.rs:120-148, scalar.rs:247-276; routed
+ * from broadcast/mod.rs:232-251): every chunk (op) the scalar, or the scalar (op) every chunk when scalar_is_lhs != 0.
+ * The reference maps broadcast_value over the chunks, one array kernel call with a length-1 operand each; here ALL chunks
+ * go in one launch (segments for very long lists) with the scalar as a kernel argument. `scalar` points at ONE host
+ * element of the type format_code names ('i','I','l','L','f','g'; cast mixed-type scalars first, as the C++ mirror does).
+ * chunk_masks: the reference passes None for every chunk (array.rs:183: the chunks' own validity is not consulted, the
+ * result chunks are dense) = NULL here. A non-NULL entry gates chunk i like the mask argument of ma_apply_* (bit 0 = row
+ * 0): out_masks[i] receives it and out_has_mask[i] says so. Dense integer Div / Rem / FloorDiv by zero ->
+ * MA_ERR_DIVIDE_BY_ZERO; masked ones clear the row's bit instead (simd.rs:319-326) and run chunk by chunk. */
+ma_status ma_broadcast_super_array_scalar(ma_ctx* ctx, int32_t format_code, int32_t op, int32_t scalar_is_lhs,
+                                          const void* scalar, size_t n_chunks, const void* const* chunk_data,
+                                          const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                          void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask);
+
 /* ------------------------------------------------------------------------------------------------
  * Arrow C Stream ingestion — the reference moves chunked tables (SuperTable) through ArrowArrayStream
  * (src/ffi/arrow_c_ffi.rs:160-184 struct, :2104-2260 export / import). Sum and valid count of one column over all

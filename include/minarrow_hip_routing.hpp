@@ -433,6 +433,48 @@ inline SuperArray route_super_array_broadcast(ArithmeticOperator op, const Super
     return out;
 }
 
+// SuperArray (op) Scalar / Scalar (op) SuperArray — src/kernels/broadcast/super_array.rs:87-116, scalar.rs:214-243: the
+// reference maps broadcast_value(chunk, scalar) over the chunks, i.e. broadcast_array_to_scalar per chunk — the scalar as a
+// 1-element array of its own type through the ordinary routing with NO null mask (array.rs:183 passes None: the chunks'
+// own validity is not consulted and the result chunks are dense). When the scalar has the chunks' element type ALL chunks
+// run in one launch (ma_broadcast_super_array_scalar); other combinations go chunk by chunk through the type matrix
+// (Int32 with a float scalar promotes, Int64 with Float64 is UnsupportedType).
+namespace detail {
+inline SuperArray super_array_scalar(ArithmeticOperator op, const SuperArray& sa, const Scalar& scalar, bool scalar_is_lhs) {
+    SuperArray out;
+    const size_t k = sa.n_chunks();
+    if (k == 0) return out;
+    const NumericArray one = scalar_array(scalar);
+    bool one_type = true;
+    for (size_t i = 0; i < k; ++i) one_type = one_type && sa.chunks()[i].type() == one.type();
+    if (!one_type) {
+        for (size_t i = 0; i < k; ++i)
+            out.push(scalar_is_lhs ? broadcast_scalar_to_array(op, scalar, sa.chunks()[i])
+                                   : broadcast_array_to_scalar(op, sa.chunks()[i], scalar));
+        return out;
+    }
+    const NumericType t = one.type();
+    std::vector<const void*> cd(k);
+    std::vector<size_t> cl(k);
+    std::vector<void*> od(k);
+    for (size_t i = 0; i < k; ++i) {
+        cd[i] = chunk_data(sa.chunks()[i]);
+        cl[i] = sa.chunks()[i].len();
+        out.push(make_chunk_of(t, cl[i], false));
+        od[i] = mutable_data(out.chunks()[i]);
+    }
+    check(ma_broadcast_super_array_scalar(Context::global().get(), format_code(t), (int32_t)op, scalar_is_lhs ? 1 : 0,
+                                          chunk_data(one), k, cd.data(), cl.data(), nullptr, od.data(), nullptr, nullptr));
+    return out;
+}
+}  // namespace detail
+inline SuperArray broadcast_superarray_to_scalar(ArithmeticOperator op, const SuperArray& super_array, const Scalar& scalar) {
+    return detail::super_array_scalar(op, super_array, scalar, false);
+}
+inline SuperArray broadcast_scalar_to_superarray(ArithmeticOperator op, const Scalar& scalar, const SuperArray& super_array) {
+    return detail::super_array_scalar(op, super_array, scalar, true);
+}
+
 // Consolidate for a chunked column — src/traits/consolidate.rs:110-207: values concatenated in chunk order; the result
 // has a null mask iff any chunk has one, chunks without one contribute all-valid rows (:80-105).
 inline NumericArray consolidate(const SuperArray& sa) {

@@ -416,6 +416,28 @@ static void chunked_suite() {
         SuperArray z({i32s({1, 1, 1}), i32s({1, 0, 1})});
         ASSERT(panics([&] { (void)route_super_array_broadcast(Op::Divide, a, z); }));
     }
+    {   // test_scalar_to_superarray (scalar.rs:1119-1150), test_scalar_to_superarrayview (:1154-1193: the view's slices are
+        // the chunks), and the SuperArray (op) Scalar direction (super_array.rs:87-116)
+        SuperArray a({i32s({1, 2, 3}), i32s({4, 5, 6})});
+        SuperArray r = broadcast_scalar_to_superarray(Op::Add, Scalar{int32_t(10)}, a);
+        ASSERT(r.n_chunks() == 2 && is_i32(r.chunks()[0], {11, 12, 13}) && is_i32(r.chunks()[1], {14, 15, 16}));
+        SuperArray v({i32s({10, 20, 30}), i32s({40, 50, 60})});
+        r = broadcast_scalar_to_superarray(Op::Multiply, Scalar{int32_t(5)}, v);
+        ASSERT(is_i32(r.chunks()[0], {50, 100, 150}) && is_i32(r.chunks()[1], {200, 250, 300}));
+        r = broadcast_superarray_to_scalar(Op::Subtract, v, Scalar{int32_t(5)});
+        ASSERT(is_i32(r.chunks()[0], {5, 15, 25}) && is_i32(r.chunks()[1], {35, 45, 55}));
+        r = broadcast_scalar_to_superarray(Op::Subtract, Scalar{int32_t(5)}, v);  // not commutative: the side matters
+        ASSERT(is_i32(r.chunks()[0], {-5, -15, -25}) && is_i32(r.chunks()[1], {-35, -45, -55}));
+        // the chunks' own validity is not consulted (array.rs:183 passes None): dense result chunks
+        SuperArray am({i32s_masked({1, 2, 3}, {true, false, false}), i32s({4, 5, 6})});
+        r = broadcast_superarray_to_scalar(Op::Add, am, Scalar{int32_t(1)});
+        ASSERT(is_i32(r.chunks()[0], {2, 3, 4}) && !r.chunks()[0].null_mask().has_value());
+        // a scalar of another type goes chunk by chunk through the type matrix: Int32 with Float64 promotes
+        r = broadcast_superarray_to_scalar(Op::Multiply, a, Scalar{0.5});
+        ASSERT(is_f64(r.chunks()[0], {0.5, 1.0, 1.5}) && is_f64(r.chunks()[1], {2.0, 2.5, 3.0}));
+        // dense integer division by a zero scalar panics (std.rs:53-77)
+        ASSERT(panics([&] { (void)broadcast_superarray_to_scalar(Op::Divide, a, Scalar{int32_t(0)}); }));
+    }
     {   // test_consolidate_arena_integer_and_float / _three_batches / _preserves_name
         SuperTable st;
         st.name = "my_table";

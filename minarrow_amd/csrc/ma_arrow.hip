@@ -346,3 +346,65 @@ extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_
     }
     return MA_OK;
 }
+
+// SuperArray (op) Scalar and Scalar (op) SuperArray: the reference maps `broadcast_value(chunk, scalar)` over the chunks
+// (src/kernels/broadcast/super_array.rs:87-116, scalar.rs:214-243; the views' twins :120-148, :247-276), each of which ends
+// in the array kernels with a length-1 operand (maybe_broadcast_scalar_array). Here all chunks go in one launch (a few for
+// very long lists) with the scalar in a kernel argument; a chunk's result carries the chunk's own validity.
+extern "C" ma_status ma_broadcast_super_array_scalar(ma_ctx* ctx, int32_t format_code, int32_t op, int32_t scalar_is_lhs,
+                                                     const void* scalar, size_t n_chunks, const void* const* chunk_data,
+                                                     const size_t* chunk_lens, const uint8_t* const* chunk_masks,
+                                                     void* const* out_data, uint8_t* const* out_masks,
+                                                     int32_t* out_has_mask) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(scalar != nullptr, MA_ERR_INVALID_ARGUMENT, "scalar is NULL");
+    MA_REQUIRE(n_chunks == 0 || (chunk_data && chunk_lens && out_data), MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
+    MA_REQUIRE(op >= MA_OP_ADD && op <= MA_OP_FLOORDIV, MA_ERR_INVALID_ARGUMENT, "unknown ArithmeticOperator code %d", op);
+    size_t elem = 0;
+    switch (format_code) {
+        case 'i': case 'I': case 'f': elem = 4; break;
+        case 'l': case 'L': case 'g': elem = 8; break;
+        default:
+            set_error("unsupported element format '%c'", (char)format_code);
+            return MA_ERR_UNSUPPORTED;
+    }
+    uint64_t sbits = 0;
+    memcpy(&sbits, scalar, elem);
+    const bool is_int = format_code == 'i' || format_code == 'I' || format_code == 'l' || format_code == 'L';
+    const bool divlike = op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV;
+    bool any_mask = false;
+    for (size_t i = 0; i < n_chunks && !any_mask; ++i) any_mask = chunk_masks && chunk_masks[i] && chunk_lens[i];
+    if (!(is_int && divlike && any_mask)) {
+        const int smode = scalar_is_lhs ? 1 : 2;
+        return route_batched(ctx, format_code, op, n_chunks, scalar_is_lhs ? nullptr : chunk_data, chunk_lens,
+                             scalar_is_lhs ? nullptr : chunk_masks, scalar_is_lhs ? chunk_data : nullptr,
+                             scalar_is_lhs ? chunk_masks : nullptr, nullptr, out_data, out_masks, out_has_mask, smode, sbits);
+    }
+    // masked integer Div / Rem / FloorDiv: the output validity depends on the data (a zero divisor clears the row's bit,
+    // simd.rs:319-326) — chunk by chunk through the scalar forms of the array kernels
+    for (size_t i = 0; i < n_chunks; ++i) {
+        const size_t n = chunk_lens[i];
+        const uint8_t* m = chunk_masks ? chunk_masks[i] : nullptr;
+        uint8_t* om = out_masks ? out_masks[i] : nullptr;
+        if (out_has_mask) out_has_mask[i] = m ? 1 : 0;
+        if (n == 0) continue;
+        const void* d = chunk_data[i];
+        ma_status st;
+#define MA_SCALAR_CHUNK(T, TAG)                                                                                            \
+    {                                                                                                                     \
+        T sv;                                                                                                             \
+        memcpy(&sv, scalar, sizeof(T));                                                                                   \
+        st = scalar_is_lhs ? ma_apply_int_##TAG##_scalar_lhs(ctx, sv, (const T*)d, n, op, m, 0, (T*)out_data[i], om)      \
+                           : ma_apply_int_##TAG##_scalar_rhs(ctx, (const T*)d, n, sv, op, m, 0, (T*)out_data[i], om);     \
+    }
+        switch (format_code) {
+            case 'i': MA_SCALAR_CHUNK(int32_t, i32) break;
+            case 'I': MA_SCALAR_CHUNK(uint32_t, u32) break;
+            case 'l': MA_SCALAR_CHUNK(int64_t, i64) break;
+            default: MA_SCALAR_CHUNK(uint64_t, u64) break;
+        }
+#undef MA_SCALAR_CHUNK
+        if (st != MA_OK) return st;
+    }
+    return MA_OK;
+}

@@ -231,11 +231,12 @@ inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0)
     return (int)(work_items < cap ? work_items : cap);
 }
 
-// All chunk pairs of a SuperArray (op) SuperArray in one launch (ma_superarray.hip).
+// All chunk pairs of a SuperArray (op) SuperArray in one launch (ma_superarray.hip). smode 1 / 2: the left / right operand
+// is the scalar whose bits are the low bytes of `sbits` (that side's tables may be NULL).
 ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks, const void* const* lhs_data,
                         const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
                         const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
-                        uint8_t* const* out_masks, int32_t* out_has_mask);
+                        uint8_t* const* out_masks, int32_t* out_has_mask, int smode = 0, uint64_t sbits = 0);
 
 // Chunk-pipelined staging (ma_pipeline.hip). An entry point whose rows are independent describes its operands and
 // hands over a function that enqueues the kernels of one tile on ctx->stream; run_tiled moves the pageable operands

@@ -121,8 +121,12 @@ __device__ __forceinline__ unsigned pair_row_valid(const PairDesc& d, size_t row
 // (the common mask it has in registers anyway) — possible when every masked chunk's `out` starts on a 16-byte boundary
 // (head == 0), so that runs start on validity-word boundaries; otherwise batched_mask_kernel assembles the bitmaps in a
 // second launch.
+// smode: 0 = array (op) array; 1 = the LEFT operand is the scalar `sval` for every chunk (broadcast_scalar_to_superarray,
+// src/kernels/broadcast/scalar.rs:214-243), 2 = the right one (broadcast_superarray_to_scalar, super_array.rs:87-116) —
+// wave-uniform: the scalar side's loads are skipped, nothing else changes.
 template <typename T, int UNROLL, bool FUSE_MASK>
-__device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, bool& dz, unsigned lane, unsigned wave) {
+__device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, bool& dz, unsigned lane, unsigned wave,
+                                          int smode, T sval) {
     typedef typename Vec16<T>::type V;
     constexpr int R = 16 / (int)sizeof(T);
     constexpr int WPT = R * UNROLL;
@@ -136,11 +140,14 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
     const size_t r1 = r0 + TILE_ROWS < d.len ? r0 + TILE_ROWS : d.len;
     if (lt == 0) {
         for (size_t i = threadIdx.x; i < d.head && i < d.len; i += kBlock) {
-            T v = Elem<T>::apply_rt(op, lhs[i], rhs[i], dz);
+            T v = Elem<T>::apply_rt(op, smode == 1 ? sval : lhs[i], smode == 2 ? sval : rhs[i], dz);
             if (masked) v = pair_row_valid(d, i) ? v : (T)0;
             out[i] = v;
         }
     }
+    V sv;
+#pragma unroll
+    for (int k = 0; k < R; ++k) sv[k] = sval;
     const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;  // this wave's run of the tile
     if (w0 >= r1) return;
     // Stores are 16-byte aligned by construction; inputs may sit on any element phase (load16u). A ragged last tile
@@ -168,9 +175,9 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
     if (run_rows == WAVE_ROWS) {
         V va[UNROLL], vb[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) va[u] = smode == 1 ? sv : load16u<V, true>(p + (size_t)u * 64);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) vb[u] = smode == 2 ? sv : load16u<V, true>(q + (size_t)u * 64);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             unsigned bits = ~0u;
@@ -190,8 +197,8 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
             unsigned bits = ~0u;
             if (masked) bits = lane_bits<R>(aw, u, lane);  // wave-wide shuffle: outside the per-lane guard
             if ((unsigned)u * 64 + lane < n_vec) {
-                const V a = load16u<V, true>(p + (size_t)u * 64);
-                const V b = load16u<V, true>(q + (size_t)u * 64);
+                const V a = smode == 1 ? sv : load16u<V, true>(p + (size_t)u * 64);
+                const V b = smode == 2 ? sv : load16u<V, true>(q + (size_t)u * 64);
                 V r;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -205,7 +212,7 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
         const size_t tail0 = w0 + (size_t)n_vec * R;
         if (tail0 + lane < w0 + run_rows) {
             const size_t i = tail0 + lane;
-            T v = Elem<T>::apply_rt(op, lhs[i], rhs[i], dz);
+            T v = Elem<T>::apply_rt(op, smode == 1 ? sval : lhs[i], smode == 2 ? sval : rhs[i], dz);
             if (masked) v = pair_row_valid(d, i) ? v : (T)0;
             out[i] = v;
         }
@@ -218,16 +225,19 @@ template <typename T, int UNROLL, bool FUSE_MASK>
 __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const ChunkPair* __restrict__ cd,
                                                                 const ChunkMaskDesc* __restrict__ md,
                                                                 const uint64_t* __restrict__ tile0, int n_chunks,
-                                                                size_t n_tiles, int op, uint32_t* flags) {
+                                                                size_t n_tiles, int op, uint32_t* flags, int smode,
+                                                                uint64_t sbits) {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool dz = false;
+    T sval;
+    __builtin_memcpy(&sval, &sbits, sizeof(T));
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int c = find_by_prefix(tile0, n_chunks, t);
         const ChunkPair e = cd[c];
         ChunkMaskDesc m{};
         if (md) m = md[c];
         const PairDesc d = make_pair<T>(e, m);
-        pair_tile<T, UNROLL, FUSE_MASK>(d, t - tile0[c], op, dz, lane, wave);
+        pair_tile<T, UNROLL, FUSE_MASK>(d, t - tile0[c], op, dz, lane, wave, smode, sval);
     }
     if constexpr (std::is_integral<T>::value) {
         // only dense chunks can latch (masked integer division is routed chunk by chunk on the host)
@@ -244,11 +254,13 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const ChunkPair*
 template <typename T, int UNROLL, bool ANY_MASK>
 __global__ __launch_bounds__(kBlock) void chunk_binary_kernel(const ChunkPair* __restrict__ cd,
                                                               const ChunkMaskDesc* __restrict__ md, int n_chunks, int op,
-                                                              uint32_t* flags) {
+                                                              uint32_t* flags, int smode, uint64_t sbits) {
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * UNROLL * kWaves;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool dz = false;
+    T sval;
+    __builtin_memcpy(&sval, &sbits, sizeof(T));
     int c = blockIdx.x;
     if (c >= n_chunks) return;
     ChunkPair e = cd[c];
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void chunk_binary_kernel(const ChunkPair* _
         const PairDesc d = make_pair<T>(e, m);
         if (d.len) {
             const size_t n_t = d.len > d.head ? (d.len - d.head + TILE_ROWS - 1) / TILE_ROWS : 1;
-            for (size_t lt = 0; lt < n_t; ++lt) pair_tile<T, UNROLL, ANY_MASK>(d, lt, op, dz, lane, wave);
+            for (size_t lt = 0; lt < n_t; ++lt) pair_tile<T, UNROLL, ANY_MASK>(d, lt, op, dz, lane, wave, smode, sval);
         }
         if (next >= n_chunks) break;
         c = next;
@@ -308,18 +320,22 @@ struct PairRoles {
 };
 template <typename T>
 static ma_status resolve_pair(CallScope& scope, PairRoles& roles, size_t i, size_t n, const void* lhs, const void* rhs,
-                              void* out, const uint8_t* lm, const uint8_t* rm, uint8_t* om, PairDesc& d) {
+                              void* out, const uint8_t* lm, const uint8_t* rm, uint8_t* om, PairDesc& d, int smode) {
     memset(&d, 0, sizeof(d));
     d.len = n;
     if (n == 0) return MA_OK;
-    MA_REQUIRE(lhs && rhs && out, MA_ERR_INVALID_ARGUMENT, "chunk %zu: NULL buffer", i);
-    if (roles.lhs.holds(lhs)) {
+    MA_REQUIRE((lhs || smode == 1) && (rhs || smode == 2) && out, MA_ERR_INVALID_ARGUMENT, "chunk %zu: NULL buffer", i);
+    if (smode == 1) {
+        d.lhs = nullptr;  // the scalar's side: never dereferenced
+    } else if (roles.lhs.holds(lhs)) {
         d.lhs = lhs;
     } else {
         MA_TRY(scope.in(lhs, n * sizeof(T), &d.lhs));
         roles.lhs.learn(lhs);
     }
-    if (roles.rhs.holds(rhs)) {
+    if (smode == 2) {
+        d.rhs = nullptr;
+    } else if (roles.rhs.holds(rhs)) {
         d.rhs = rhs;
     } else {
         MA_TRY(scope.in(rhs, n * sizeof(T), &d.rhs));
@@ -396,7 +412,7 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
                                  const void* const* lhs_data, const size_t* lens, const uint8_t* const* lhs_masks,
                                  const void* const* rhs_data, const uint8_t* const* rhs_masks, const uint8_t* override_mask,
                                  void* const* out_data, uint8_t* const* out_masks, int32_t* out_has_mask, bool any_mask,
-                                 bool by_chunk, char* dev_tab) {
+                                 bool by_chunk, char* dev_tab, int smode, uint64_t sbits) {
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * U * kWaves;
     const size_t n = c1 - c0;
@@ -419,8 +435,8 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
         const uint8_t* rm = override_mask ? nullptr : (rhs_masks ? rhs_masks[i] : nullptr);
         if (out_has_mask) out_has_mask[i] = (lm || rm) ? 1 : 0;
         PairDesc d;
-        MA_TRY(resolve_pair<T>(scope, roles, i, len, lhs_data[i], rhs_data[i], out_data[i], lm, rm,
-                               out_masks ? out_masks[i] : nullptr, d));
+        MA_TRY(resolve_pair<T>(scope, roles, i, len, lhs_data ? lhs_data[i] : nullptr, rhs_data ? rhs_data[i] : nullptr,
+                               out_data[i], lm, rm, out_masks ? out_masks[i] : nullptr, d, smode));
         cd[k] = ChunkPair{d.lhs, d.rhs, d.out, (uint64_t)len};
         if (md) md[k] = ChunkMaskDesc{len ? d.lw : nullptr, len ? d.rw : nullptr, len ? d.ow : nullptr, (uint32_t)d.lo, (uint32_t)d.ro};
         if (tile0) tile0[k] = n_tiles;
@@ -449,10 +465,10 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
         const int grid = grid_for(ctx, n, 6);
         if (any_mask)
             hipLaunchKernelGGL((chunk_binary_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, (int)n, op,
-                               ctx->dev_flags);
+                               ctx->dev_flags, smode, sbits);
         else
             hipLaunchKernelGGL((chunk_binary_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, (int)n, op,
-                               ctx->dev_flags);
+                               ctx->dev_flags, smode, sbits);
         MA_HIP(hipGetLastError());
         if (slot >= 0) MA_TRY(table_release(ctx, slot));
         return MA_OK;
@@ -471,10 +487,10 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
     const int grid = grid_for(ctx, n_tiles, 6);
     if (fuse)
         hipLaunchKernelGGL((batched_binary_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, dt0, (int)n, n_tiles,
-                           op, ctx->dev_flags);
+                           op, ctx->dev_flags, smode, sbits);
     else
         hipLaunchKernelGGL((batched_binary_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, dt0, (int)n, n_tiles,
-                           op, ctx->dev_flags);
+                           op, ctx->dev_flags, smode, sbits);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -483,7 +499,8 @@ template <typename T, int U>
 static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
                                 const uint8_t* const* lhs_masks, const void* const* rhs_data,
                                 const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
-                                uint8_t* const* out_masks, int32_t* out_has_mask, bool any_mask, bool by_chunk) {
+                                uint8_t* const* out_masks, int32_t* out_has_mask, bool any_mask, bool by_chunk, int smode,
+                                uint64_t sbits) {
     MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "route_super_array_broadcast (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
@@ -505,7 +522,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     while (c0 < n_chunks) {
         const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
         MA_TRY((batched_segment<T, U>(ctx, scope, roles, op, c0, c1, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask,
-                                      out_data, out_masks, out_has_mask, any_mask, by_chunk, dev_tab + dev_off)));
+                                      out_data, out_masks, out_has_mask, any_mask, by_chunk, dev_tab + dev_off, smode, sbits)));
         dev_off += (kPerChunk * (c1 - c0) + 255) & ~(size_t)255;
         c0 = c1;
         if (seg < kMax) seg *= 2;
@@ -521,7 +538,7 @@ template <typename T>
 static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* const* lhs_data, const size_t* lens,
                               const uint8_t* const* lhs_masks, const void* const* rhs_data,
                               const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
-                              uint8_t* const* out_masks, int32_t* out_has_mask) {
+                              uint8_t* const* out_masks, int32_t* out_has_mask, int smode, uint64_t sbits) {
     size_t total = 0;
     bool any_mask = false, masked_head = false;
     for (size_t i = 0; i < n_chunks; ++i) {
@@ -561,8 +578,8 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     if (ctx->variant & 16) wide = false;
     if (ctx->variant & 32) wide = true;
     if (wide)
-        return batched_impl_u<T, 8>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk);
-    return batched_impl_u<T, 4>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk);
+        return batched_impl_u<T, 8>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk, smode, sbits);
+    return batched_impl_u<T, 4>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk, smode, sbits);
 }
 
 }  // namespace ma
@@ -574,14 +591,14 @@ namespace ma {
 ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks, const void* const* lhs_data,
                         const size_t* lens, const uint8_t* const* lhs_masks, const void* const* rhs_data,
                         const uint8_t* const* rhs_masks, const uint8_t* override_mask, void* const* out_data,
-                        uint8_t* const* out_masks, int32_t* out_has_mask) {
+                        uint8_t* const* out_masks, int32_t* out_has_mask, int smode, uint64_t sbits) {
     switch (format_code) {
-        case 'i': return batched_impl<int32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
-        case 'I': return batched_impl<uint32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
-        case 'l': return batched_impl<int64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
-        case 'L': return batched_impl<uint64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
-        case 'f': return batched_impl<float>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
-        case 'g': return batched_impl<double>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask);
+        case 'i': return batched_impl<int32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
+        case 'I': return batched_impl<uint32_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
+        case 'l': return batched_impl<int64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
+        case 'L': return batched_impl<uint64_t>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
+        case 'f': return batched_impl<float>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
+        case 'g': return batched_impl<double>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, smode, sbits);
         default:
             set_error("unsupported element format '%c'", (char)format_code);
             return MA_ERR_UNSUPPORTED;

@@ -570,6 +570,23 @@ class Context:
             table(out_masks), C.cast(has, C.c_void_p)))
         return [bool(x) for x in has]
 
+    def broadcast_super_array_scalar(self, fmt: str, op: int, scalar, chunks, lens, out_chunks, masks=None, out_masks=None,
+                                     scalar_is_lhs: bool = False):
+        """SuperArray (op) Scalar, or Scalar (op) SuperArray, all chunks in one launch (super_array.rs:87-116,
+        scalar.rs:214-243). `scalar`: a numpy scalar / 1-element array of the chunks' type. Returns the "has validity" flags."""
+        k = len(chunks)
+
+        def table(items):
+            return C.cast((C.c_void_p * k)(*[addr_of(x) or None for x in items]), C.c_void_p) if items is not None else None
+
+        sc = np.ascontiguousarray(np.asarray(scalar).reshape(1))
+        ll = (C.c_size_t * k)(*[int(n) for n in lens])
+        has = (C.c_int32 * k)()
+        ffi.check(self.lib.ma_broadcast_super_array_scalar(
+            self.handle, ord(fmt), int(op), 1 if scalar_is_lhs else 0, addr_of(sc), k, table(chunks), C.cast(ll, C.c_void_p),
+            table(masks), table(out_chunks), table(out_masks), C.cast(has, C.c_void_p)))
+        return [bool(x) for x in has]
+
     def apply_arrow_stream_export(self, op: int, lhs_stream_ptr: int, rhs_stream_ptr: int, out_stream_ptr: int) -> None:
         """SuperTable (op) SuperTable as a stream operator: moves both input ArrowArrayStreams, fills *out_stream."""
         ffi.check(self.lib.ma_apply_arrow_stream_export(self.handle, int(op), int(lhs_stream_ptr), int(rhs_stream_ptr),

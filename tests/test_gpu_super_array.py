@@ -195,3 +195,115 @@ def test_masked_integer_division_with_zero_divisors(ctx, oracle, fmt, dt):
             st, want, want_mask = oracle.int_body("masked_std", lhs[i], rhs[i], name, mask=oracle.pad_bits(common, n))
             np.testing.assert_array_equal(outs[i].download(dt, n), want, err_msg=f"{name} chunk {i}")
             np.testing.assert_array_equal(oms[i].download(np.uint8, nbytes(n)), want_mask[:nbytes(n)], err_msg=f"{name} chunk {i} validity")
+
+
+def test_ref_scalar_to_superarray(ctx):
+    """test_scalar_to_superarray (src/kernels/broadcast/scalar.rs:1119-1150): 10 + [[1,2,3],[4,5,6]]; test_scalar_to_superarrayview
+    (:1154-1193): 5 * the two 3-row slices of [10..60]."""
+    chunks = [np.array([1, 2, 3], dtype=np.int32), np.array([4, 5, 6], dtype=np.int32)]
+    outs = [np.zeros(3, dtype=np.int32) for _ in chunks]
+    assert ctx.broadcast_super_array_scalar("i", 0, np.int32(10), chunks, [3, 3], outs, scalar_is_lhs=True) == [False, False]
+    np.testing.assert_array_equal(outs[0], [11, 12, 13])
+    np.testing.assert_array_equal(outs[1], [14, 15, 16])
+    arr = np.array([10, 20, 30, 40, 50, 60], dtype=np.int32)
+    d = ctx.to_device(arr, 64)
+    do = ctx.alloc(6 * 4 + 64)
+    ctx.broadcast_super_array_scalar("i", 2, np.int32(5), [d, d.offset(12)], [3, 3], [do, do.offset(12)], scalar_is_lhs=True)
+    np.testing.assert_array_equal(do.download(np.int32, 6), [50, 100, 150, 200, 250, 300])
+
+
+@pytest.mark.parametrize("fmt,dt", [("i", np.int32), ("I", np.uint32), ("l", np.int64), ("L", np.uint64), ("f", np.float32),
+                                    ("g", np.float64)])
+@pytest.mark.parametrize("k,variant,max_len", [(40, 0, 70_000), (3000, 256, 600), (3000, 128, 600), (9500, 0, 300)])
+def test_super_array_scalar_both_sides(ctx, oracle, fmt, dt, k, variant, max_len):
+    """SuperArray (op) Scalar and Scalar (op) SuperArray (super_array.rs:87-116, scalar.rs:214-243) in one launch against the
+    oracle's array kernels on (chunk, scalar broadcast to the chunk's length) — what maybe_broadcast_scalar_array makes of
+    the reference's length-1 operand. Ragged chunk lengths packed back to back (outputs start mid-vector), every operator,
+    both sides, both kernel forms; then with validity on two thirds of the chunks (the ABI's optional gating)."""
+    rng = np.random.default_rng(k + variant)
+    dt = np.dtype(dt)
+    lens = [int(x) for x in rng.integers(0, max_len, size=k)]
+    lens[:3] = [8192, 1, 0]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offs[-1])
+    if dt.kind == "f":
+        a = (rng.standard_normal(total) * 10).astype(dt)
+        scalars = [dt.type(2.5), dt.type(-0.75)]
+    else:
+        a = rng.integers(1 if dt.kind == "u" else -1000, 1000, size=total).astype(dt)
+        a[a == 0] = 1  # the column is also the divisor (scalar / chunk): a dense zero there is an error, tested below
+        scalars = [dt.type(7), dt.type(3)]
+    da, do = ctx.to_device(a, 64), ctx.alloc(total * dt.itemsize + 64)
+    chunks = [da.offset(int(offs[i]) * dt.itemsize) for i in range(k)]
+    outs = [do.offset(int(offs[i]) * dt.itemsize) for i in range(k)]
+    fn = oracle.apply_float if dt.kind == "f" else oracle.apply_int
+    names = ["add", "subtract", "multiply", "divide", "remainder", "power", "floordiv"]
+    ops = [0, 1, 2, 3, 4, 6] if dt.kind != "f" else [0, 1, 2, 3, 5]
+    ctx.set_variant(variant)
+    try:
+        for op in ops:
+            for side, s in ((False, scalars[0]), (True, scalars[1])):
+                has = ctx.broadcast_super_array_scalar(fmt, op, s, chunks, lens, outs, scalar_is_lhs=side)
+                assert not any(has)
+                got = do.download(dt, total)
+                full = np.full(total, s, dtype=dt)
+                l, r = (full, a) if side else (a, full)
+                st, want, _, _ = fn(oracle.aligned_copy(l), oracle.aligned_copy(r), names[op])
+                if dt.kind == "f" and op == 5:
+                    ok = np.isclose(got, want, rtol=1e-5 if dt.itemsize == 4 else 1e-12, equal_nan=True)
+                    assert ok.all()
+                else:
+                    np.testing.assert_array_equal(got, want, err_msg=f"op {names[op]} scalar_is_lhs={side}")
+    finally:
+        ctx.set_variant(0)
+    if dt.kind != "f":  # dense integer division by a zero scalar is reported, like a zero in a dense divisor chunk
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            ctx.broadcast_super_array_scalar(fmt, 3, dt.type(0), chunks, lens, outs)
+        assert e.value.status == ffi.MA_ERR_DIVIDE_BY_ZERO
+    # optional validity per chunk: gates like the mask argument of the array kernels, and is copied to the chunk's output bitmap
+    masks_h, m_offs, pos = [], [], 0
+    for i, n in enumerate(lens):
+        nb = ((n + 63) // 64) * 8 + 8
+        masks_h.append(rng.integers(0, 256, size=nb, dtype=np.uint8) if i % 3 != 0 else None)
+        m_offs.append(pos)
+        pos += nb
+    arena = np.zeros(pos + 8, dtype=np.uint8)
+    for i in range(k):
+        if masks_h[i] is not None:
+            arena[m_offs[i]:m_offs[i] + masks_h[i].size] = masks_h[i]
+    dm, dom = ctx.to_device(arena), ctx.alloc(pos + 8)
+    ms = [dm.offset(m_offs[i]) if masks_h[i] is not None else None for i in range(k)]
+    oms = [dom.offset(m_offs[i]) for i in range(k)]
+    # outputs of masked chunks must start on 16-byte boundaries for the chunk form: use per-chunk aligned outputs
+    starts, p = [], 0
+    for n in lens:
+        starts.append(p)
+        p += (n * dt.itemsize + 15) // 16 * 16
+    do2 = ctx.alloc(p + 64)
+    outs2 = [do2.offset(starts[i]) for i in range(k)]
+    body = oracle.float_body if dt.kind == "f" else oracle.int_body
+    ctx.set_variant(variant)
+    try:
+        for op, name, side in ((2, "multiply", False), (1, "subtract", True), (3, "divide", False)):
+            s = scalars[0]
+            has = ctx.broadcast_super_array_scalar(fmt, op, s, chunks, lens, outs2, ms, oms, scalar_is_lhs=side)
+            got_masks = dom.download(np.uint8, pos)
+            for i in list(range(0, min(k, 60))) + list(range(60, k, 97)):
+                n = lens[i]
+                assert has[i] == (masks_h[i] is not None)
+                if n == 0:
+                    continue
+                sl = slice(int(offs[i]), int(offs[i]) + n)
+                got = do2.download(dt, n, starts[i])
+                full = np.full(n, s, dtype=dt)
+                l, r = (full, a[sl]) if side else (a[sl], full)
+                if masks_h[i] is None:
+                    st, want, _, _ = fn(oracle.aligned_copy(l), oracle.aligned_copy(r), name)
+                    np.testing.assert_array_equal(got, want)
+                else:
+                    st, want, want_mask = body("masked_std", l, r, name, mask=oracle.pad_bits(masks_h[i], n))
+                    np.testing.assert_array_equal(got, want, err_msg=f"{name} chunk {i}")
+                    nb = ((n + 63) // 64) * 8
+                    np.testing.assert_array_equal(got_masks[m_offs[i]:m_offs[i] + nb], want_mask[:nb], err_msg=f"{name} chunk {i} validity")
+    finally:
+        ctx.set_variant(0)

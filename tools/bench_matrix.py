@@ -263,6 +263,24 @@ def main():
                     ms = timed(lambda: call(True), prime=True)
                     emit("route_super_array_broadcast", tag, f"add, nulls on both sides, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz + 3 * rows / 8, rows)
                 ctx.set_variant(0)
+                # SuperArray (op) Scalar (super_array.rs:87-116): the same chunks against a scalar, one launch
+                import numpy as _np
+                sc = _np.array([3], dtype={"f64": _np.float64, "i32": _np.int32}[tag])
+                fs = ctx.lib.ma_broadcast_super_array_scalar
+
+                def call_scalar(masked, lhs_side=0):
+                    st = fs(ctx.handle, ord(fmt), OP["mul"], lhs_side, sc.ctypes.data, k, t_l, t_n, t_lm if masked else None,
+                            t_o, t_om if masked else None, None)
+                    assert st == 0, st
+
+                ms = timed(lambda: call_scalar(False), prime=True)
+                emit("broadcast_superarray_to_scalar", tag, f"multiply dense, {k} x {per}-row {label}", ms, 2 * rows * sz, rows)
+                ms = timed(lambda: call_scalar(False, 1), prime=True)
+                emit("broadcast_scalar_to_superarray", tag, f"multiply dense, {k} x {per}-row {label}", ms, 2 * rows * sz, rows)
+                ms = timed(lambda: call_scalar(True), prime=True)
+                emit("broadcast_superarray_to_scalar", tag, f"multiply, chunks with nulls, {k} x {per}-row {label}", ms,
+                     2 * rows * sz + 2 * rows / 8, rows)
+                ctx.set_variant(0)
                 host = []
                 for _ in range(5):  # async context: the call returns when everything is enqueued; idle stream each time
                     ctx.synchronize()
