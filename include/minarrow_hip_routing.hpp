@@ -475,6 +475,63 @@ inline SuperArray broadcast_scalar_to_superarray(ArithmeticOperator op, const Sc
     return detail::super_array_scalar(op, super_array, scalar, true);
 }
 
+// ArrayView (op) SuperArray / SuperArray (op) ArrayView — src/kernels/broadcast/super_array.rs:255-363 (the SuperArrayV twins
+// :367-475 walk the view's slices the same way): the view must be as long as the SuperArray (ShapeError), chunk i meets the
+// view's window [offset_i, offset_i + len_i), each pair goes through broadcast_value = resolve_binary_arithmetic with no
+// null mask (mod.rs:191-198) — dense result chunks. With one element type everywhere the windows become a pointer table
+// and ALL pairs run in one launch (ma_route_super_array_broadcast without validity); otherwise chunk by chunk.
+namespace detail {
+inline SuperArray arrayview_super_array(ArithmeticOperator op, const NumericArrayV& view, const SuperArray& sa, bool view_is_lhs) {
+    if (view.len() != sa.len())
+        throw KernelError(KernelError::Broadcasting,
+                          view_is_lhs ? "ArrayView length (" + std::to_string(view.len()) + ") does not match SuperArray length (" +
+                                            std::to_string(sa.len()) + ")"
+                                      : "SuperArray length (" + std::to_string(sa.len()) + ") does not match ArrayView length (" +
+                                            std::to_string(view.len()) + ")");
+    SuperArray out;
+    const size_t k = sa.n_chunks();
+    if (k == 0) return out;
+    bool one_type = true;
+    for (size_t i = 0; i < k; ++i) one_type = one_type && sa.chunks()[i].type() == view.array.type();
+    if (!one_type) {
+        size_t off = 0;
+        for (size_t i = 0; i < k; ++i) {
+            const NumericArray& c = sa.chunks()[i];
+            const NumericArrayV window(view.array, view.offset + off, c.len());
+            out.push(view_is_lhs ? resolve_binary_arithmetic(op, window, NumericArrayV(c), nullptr)
+                                 : resolve_binary_arithmetic(op, NumericArrayV(c), window, nullptr));
+            off += c.len();
+        }
+        return out;
+    }
+    const NumericType t = view.array.type();
+    const size_t elem = (t == NumericType::Int32 || t == NumericType::UInt32 || t == NumericType::Float32) ? 4 : 8;
+    const char* base = static_cast<const char*>(chunk_data(view.array)) + view.offset * elem;
+    std::vector<const void*> vd(k), cd(k);
+    std::vector<size_t> cl(k);
+    std::vector<void*> od(k);
+    size_t off = 0;
+    for (size_t i = 0; i < k; ++i) {
+        cl[i] = sa.chunks()[i].len();
+        vd[i] = base + off * elem;
+        cd[i] = chunk_data(sa.chunks()[i]);
+        out.push(make_chunk_of(t, cl[i], false));
+        od[i] = mutable_data(out.chunks()[i]);
+        off += cl[i];
+    }
+    check(ma_route_super_array_broadcast(Context::global().get(), format_code(t), (int32_t)op, k,
+                                         view_is_lhs ? vd.data() : cd.data(), cl.data(), nullptr,
+                                         view_is_lhs ? cd.data() : vd.data(), cl.data(), nullptr, nullptr, od.data(), nullptr, nullptr));
+    return out;
+}
+}  // namespace detail
+inline SuperArray broadcast_arrayview_to_superarray(ArithmeticOperator op, const NumericArrayV& array_view, const SuperArray& super_array) {
+    return detail::arrayview_super_array(op, array_view, super_array, true);
+}
+inline SuperArray broadcast_superarray_to_arrayview(ArithmeticOperator op, const SuperArray& super_array, const NumericArrayV& array_view) {
+    return detail::arrayview_super_array(op, array_view, super_array, false);
+}
+
 // Consolidate for a chunked column — src/traits/consolidate.rs:110-207: values concatenated in chunk order; the result
 // has a null mask iff any chunk has one, chunks without one contribute all-valid rows (:80-105).
 inline NumericArray consolidate(const SuperArray& sa) {

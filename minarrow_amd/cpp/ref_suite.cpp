@@ -438,6 +438,21 @@ static void chunked_suite() {
         // dense integer division by a zero scalar panics (std.rs:53-77)
         ASSERT(panics([&] { (void)broadcast_superarray_to_scalar(Op::Divide, a, Scalar{int32_t(0)}); }));
     }
+    {   // ArrayView (op) SuperArray and back (super_array.rs:255-363): the view's windows follow the chunk boundaries
+        SuperArray sa({i32s({1, 2, 3}), i32s({4, 5}), i32s({6})});
+        NumericArrayV view(i32s({0, 10, 20, 30, 40, 50, 60, 70}), 1, 6);  // [10 .. 60]
+        SuperArray r = broadcast_arrayview_to_superarray(Op::Subtract, view, sa);
+        ASSERT(r.n_chunks() == 3 && is_i32(r.chunks()[0], {9, 18, 27}) && is_i32(r.chunks()[1], {36, 45}) && is_i32(r.chunks()[2], {54}));
+        r = broadcast_superarray_to_arrayview(Op::Subtract, sa, view);
+        ASSERT(is_i32(r.chunks()[0], {-9, -18, -27}) && is_i32(r.chunks()[1], {-36, -45}) && is_i32(r.chunks()[2], {-54}));
+        // a Float64 view over Int32 chunks promotes chunk by chunk
+        FloatArray<double> f;
+        f.data = Vec64<double>{0.5, 0.5, 0.5, 0.5, 0.5, 0.5};
+        r = broadcast_superarray_to_arrayview(Op::Multiply, sa, NumericArrayV(NumericArray::from_float64(std::move(f))));
+        ASSERT(is_f64(r.chunks()[0], {0.5, 1.0, 1.5}) && is_f64(r.chunks()[2], {3.0}));
+        ASSERT(kernel_error(KernelError::Broadcasting, "ArrayView length (5) does not match SuperArray length (6)",
+                            [&] { (void)broadcast_arrayview_to_superarray(Op::Add, NumericArrayV(i32s({0, 10, 20, 30, 40, 50}), 1, 5), sa); }));
+    }
     {   // test_consolidate_arena_integer_and_float / _three_batches / _preserves_name
         SuperTable st;
         st.name = "my_table";
