@@ -1072,6 +1072,28 @@ def run_ranks(args, result_fd) -> int:
 
     step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
     fence()
+    if comm is not None:
+        # The library's communicator has only ever run with one rank before a multi-GPU node sees it: the set-up step's
+        # finals are checked on every rank, and if ANY rank's fold is wrong (or MA_BENCH_DISTRUST_NATIVE_COMM asks, for the
+        # test of this branch) all ranks drop to torch.distributed's all-gather before anything is timed.
+        good = _check(total_rows, exs[(counter[0] - 1) % len(exs)].results()) and not os.environ.get("MA_BENCH_DISTRUST_NATIVE_COMM")
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm.synchronize()
+            comm.close()
+            comm = None
+            comm_note = "the library's communicator failed the set-up check on some rank: torch.distributed's exchange instead"
+            torch_overlap = overlap
+            if torch_overlap:
+                side = torch.cuda.Stream(dev)
+                ctx_side = Context(device_index, stream=side.cuda_stream)
+                ctx_side.set_async(True)
+            for ex in exs:
+                ex._folded_on_device = False
+            for _ in exs:  # every record set once through the new exchange
+                step()
+            fence()
     for _ in range(args.warmup):
         step()
     fence()

@@ -89,6 +89,17 @@ def test_launcher_mode_one_rank(exchange, extra):
         assert "side stream" in out["config"]["exchange"]
 
 
+def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(monkeypatch):
+    """bench.py checks the set-up step's finals on every rank before timing anything; a communicator that folds wrongly
+    (forced here) is dropped for torch.distributed's exchange on all ranks, overlap included, and the line says so."""
+    monkeypatch.setenv("MA_BENCH_DISTRUST_NATIVE_COMM", "1")
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+               "--no-other-configs", "--overlap", "on"])
+    assert out["parity_ok"] and "torch.distributed" in out["config"]["exchange"] and "set-up check" in out["config"]["exchange"]
+    assert "side stream" in out["config"]["exchange"]
+
+
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_launcher_rehearsal_partitions_the_column_over_several_ranks(ranks):
     """The N > 1 headline's own code path with more than one rank on a one-GPU box: `--backend gloo` lets the ranks share
