@@ -1070,6 +1070,19 @@ def run_ranks(args, result_fd) -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    hang_guard = None
+    if distributed:  # a collective that never completes must end the job with a reason, not with the driver's timeout
+        import threading
+
+        def hung():
+            print(f"rank {rank}: the headline's exchange did not complete within {args.headline_seconds:.0f} s "
+                  f"(exchange: {'ma_comm_*' if comm is not None else 'torch.distributed'}, overlap: {overlap}); "
+                  "try --exchange torch or --overlap off", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        hang_guard = threading.Timer(args.headline_seconds, hung)
+        hang_guard.daemon = True
+        hang_guard.start()
     step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
     fence()
     if comm is not None:
@@ -1109,6 +1122,8 @@ def run_ranks(args, result_fd) -> int:
     fence()
     elapsed = time.perf_counter() - t0
     ctx.synchronize()
+    if hang_guard is not None:
+        hang_guard.cancel()
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -1240,6 +1255,8 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
+    ap.add_argument("--headline-seconds", type=float, default=300.0,
+                    help="N > 1: give up (exit code 3, reason on stderr) when set-up + warm-up + timed steps take longer")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="run each step's scalar exchange on a side stream, overlapped with the next "
                          "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP; torch events with --exchange torch). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "

@@ -298,28 +298,113 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so)
 // bits of the 64/R lanes that share an output word are OR-ed together with a butterfly (pack_lane_bits); a wave
 // step covers 1 KiB of data and stores R words. Rows past the last full wave tile (and unaligned data) take the
 // one-ballot-per-64-rows path.
+// The R result bits of one 16-byte load. 4- and 8-byte elements compare one by one; 1- and 2-byte elements are compared
+// four / two at a time inside their 32-bit words: y = (word & mask) ^ target has a zero byte exactly where the row
+// matches, ~(((y & 0x7F..) + 0x7F..) | y) & 0x80.. marks the zero bytes (exact per byte: the add cannot carry out of a
+// byte), and one multiply gathers the four marks into a nibble — 10 operations per 4 rows instead of 14.
+template <typename T>
+__device__ __forceinline__ unsigned eq_bits(const typename Vec16<T>::type& x, T field_mask, T target) {
+    constexpr int R = 16 / (int)sizeof(T);
+    unsigned bits = 0;
+    if constexpr (sizeof(T) == 1) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 d = __builtin_bit_cast(u4, x);
+        const unsigned m4 = (unsigned)(uint8_t)field_mask * 0x01010101u, t4 = (unsigned)(uint8_t)target * 0x01010101u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned y = (d[i] & m4) ^ t4;
+            const unsigned z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+            // marks at bits 7, 15, 23, 31 -> bits 0, 8, 16, 24 -> x (1 + 2^7 + 2^14 + 2^21): bits 21..24 hold them in order
+            bits |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
+        }
+    } else if constexpr (sizeof(T) == 2) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 d = __builtin_bit_cast(u4, x);
+        const unsigned m2 = (unsigned)(uint16_t)field_mask * 0x00010001u, t2 = (unsigned)(uint16_t)target * 0x00010001u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned y = (d[i] & m2) ^ t2;
+            const unsigned z = ~(((y & 0x7FFF7FFFu) + 0x7FFF7FFFu) | y) & 0x80008000u;
+            bits |= (((z >> 15) | (z >> 30)) & 3u) << (2 * i);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) bits |= ((T)((T)x[r] & field_mask) == target ? 1u : 0u) << r;
+    }
+    return bits;
+}
+
+// The scan is a read stream with 1/64 .. 1/8 of its bytes written back: it takes the shape of the sums (ma_reduce.hip:
+// eight 16-byte loads in flight per lane, one or two workgroups per CU) rather than that of the read + write kernels —
+// 2^33 bytes of u64 at 4 loads x 8 workgroups per CU: 5.75 TB/s; see launch_eq_mask for the swept figures.
+// The scan is a read stream with 1/64 .. 1/8 of its bytes written back (tools/sweep_eq_mask.py, 2^33 bytes of data,
+// profiles/r03_sweep_eq_mask.jsonl). With the stores compiled out it reads at 6.8-7.5 TB/s like the sums; ANY form of the
+// stores costs 12-20 % of that (the few writes interleave with the read stream in HBM), the round-2 form — eight-byte
+// stores from the 2 .. 16 lanes that hold a finished word, one store instruction per 1-KiB step, 4 loads per lane, 8
+// workgroups per CU — cost 25-35 %: u8 4.88, u16 5.17, u32 5.62, u64 5.75 TB/s. Now (u8 5.65, u16 5.78, u32 5.88, u64 6.16):
+//   * eight 16-byte loads in flight per lane and one or two workgroups per CU, the shape of the sums;
+//   * a wave collects the bits of its eight steps in its own 64 R bytes of LDS — lane l's R bits of step u ARE bits
+//     [(64 u + l) R, +R) of the wave's output, so no butterfly over the lanes is needed — and writes them back as ONE
+//     non-temporal store of 16 bytes per lane, contiguous;
+//   * that store is issued one trip late, behind the next trip's loads (see the loop).
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict__ data, size_t n_tiles, T field_mask,
                                                              T target, uint64_t* __restrict__ out) {
     using V = typename Vec16<T>::type;
+    typedef unsigned long long u2a8 __attribute__((ext_vector_type(2), aligned(8)));
+    typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
     constexpr int R = 16 / (int)sizeof(T);
-    constexpr int LPW = 64 / R;
+    constexpr int STEP_BYTES = 8 * R;                // result bytes of one 1-KiB step (64 R rows)
+    constexpr int WAVE_BYTES = UNROLL * STEP_BYTES;  // 128 (8-byte elements) .. 1024 (1-byte) for UNROLL = 8
+    static_assert(WAVE_BYTES % 16 == 0 && WAVE_BYTES / 16 <= 64, "one 16-byte store per lane");
+    __shared__ __attribute__((aligned(16))) uint8_t staged[2][kWaves][WAVE_BYTES];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const V* __restrict__ vp = (const V*)data;
+    // One trip behind: the words of trip k are stored AFTER the loads of trip k + 1 have been issued. vmcnt counts loads
+    // and stores in issue order, so a store issued in front of a trip's loads has to be acknowledged before the first of
+    // them can be consumed; issued behind them it is never waited for.
+    int par = 0;
+    bool pending = false;
+    size_t pending_step0 = 0;
+    auto flush = [&](int which, size_t at_step0) {
+        if (lane < (unsigned)(WAVE_BYTES / 16)) {
+            const u2 v = *(const u2*)(staged[which][wave] + lane * 16);
+            __builtin_nontemporal_store(v, (u2a8*)((uint8_t*)out + at_step0 * STEP_BYTES + (size_t)lane * 16));  // `out` is 8-byte aligned
+        }
+    };
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const size_t step0 = (t * kWaves + wave) * UNROLL;  // index of this wave's first 1-KiB step
         V x[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) x[u] = load16<V, true>(vp + (step0 + u) * 64 + lane);
+        if (pending) flush(par ^ 1, pending_step0);
+        uint8_t* mine = staged[par][wave];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) bits |= ((T)((T)x[u][r] & field_mask) == target ? 1u : 0u) << r;
-            const uint64_t word = pack_lane_bits<R>(bits, lane);
-            if (lane % LPW == 0) out[(step0 + u) * R + lane / LPW] = word;
+            const unsigned bits = eq_bits<T>(x[u], field_mask, target);
+            if constexpr (R == 16) {
+                ((uint16_t*)mine)[u * 64 + lane] = (uint16_t)bits;
+            } else if constexpr (R == 8) {
+                mine[u * 64 + lane] = (uint8_t)bits;
+            } else {  // 2 or 4 bits per lane: the 8 / R lanes of a byte combine first
+                constexpr int LPB = 8 / R;
+                unsigned b = bits << ((lane % LPB) * R);
+                // neighbours inside a quad: DPP quad_perm [1,0,3,2] (lane ^ 1) and [2,3,0,1] (lane ^ 2) — no LDS round trip
+                b |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, false);
+                if constexpr (LPB == 4) b |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, false);
+                if (lane % LPB == 0) mine[u * STEP_BYTES + lane / LPB] = (uint8_t)b;
+            }
         }
+        // the wave reads back what ITS lanes wrote: LDS operations of one wave complete in order, the fences keep the
+        // compiler from moving the LDS loads of the flush above these stores (two buffers: the next trip writes the other)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pending = true;
+        pending_step0 = step0;
+        par ^= 1;
     }
+    if (pending) flush(par ^ 1, pending_step0);
 }
 
 template <typename T>
@@ -337,18 +422,24 @@ __global__ __launch_bounds__(kBlock) void eq_mask_kernel(const T* __restrict__ d
     }
 }
 
+template <typename T, int UNROLL>
+static size_t launch_eq_mask_vec(ma_ctx* ctx, const T* d, size_t n, T field_mask, T target, uint64_t* ow, int bpc) {
+    constexpr size_t kTileRows = (size_t)64 * (16 / sizeof(T)) * UNROLL * kWaves;
+    if (((uintptr_t)d & 15) != 0 || n < kTileRows) return 0;
+    const size_t n_tiles = n / kTileRows;
+    int grid = grid_for(ctx, n_tiles, bpc);
+    hipLaunchKernelGGL((eq_mask_vec_kernel<T, UNROLL>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_tiles, field_mask, target,
+                       ow);
+    return n_tiles * kTileRows;  // a multiple of 64: the tail starts on a word
+}
+
 template <typename T>
 static void launch_eq_mask(ma_ctx* ctx, const T* d, size_t n, T field_mask, T target, uint64_t* ow) {
-    constexpr int UNROLL = 4;
-    constexpr size_t kTileRows = (size_t)64 * (16 / sizeof(T)) * UNROLL * kWaves;
-    size_t done = 0;
-    if (((uintptr_t)d & 15) == 0 && n >= kTileRows) {
-        const size_t n_tiles = n / kTileRows;
-        int grid = grid_for(ctx, n_tiles, 8);
-        hipLaunchKernelGGL((eq_mask_vec_kernel<T, UNROLL>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, n_tiles,
-                           field_mask, target, ow);
-        done = n_tiles * kTileRows;  // a multiple of 64: the tail starts on a word
-    }
+    // variant bit 2048: 4 loads per lane on 8 workgroups per CU (round 2's shape) for A/B; blocks_per_cu overrides the grid
+    const bool old_shape = (ctx->variant & 2048) != 0;
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (old_shape ? 8 : sizeof(T) <= 2 ? 1 : 2);
+    size_t done = old_shape ? launch_eq_mask_vec<T, 4>(ctx, d, n, field_mask, target, ow, bpc)
+                            : launch_eq_mask_vec<T, 8>(ctx, d, n, field_mask, target, ow, bpc);
     if (done < n) {
         const size_t n_words = ((n - done) + 63) >> 6;
         int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves, 8);

@@ -272,6 +272,36 @@ def test_simd_eq_mask_random(ctx, oracle, tag, dt):
     np.testing.assert_array_equal(unpack(host_out, n), (data[:n] & 0xF) == 0x9)
 
 
+@pytest.mark.parametrize("tag,dt", [("u8", np.uint8), ("u16", np.uint16), ("u32", np.uint32), ("u64", np.uint64)])
+@pytest.mark.parametrize("grid", [0, 1, 3])
+def test_simd_eq_mask_full_range_many_trips(ctx, tag, dt, grid):
+    """Full-range elements (the 1- and 2-byte types compare four / two rows per 32-bit word: top bits, 0x7F / 0x80 / 0xFF
+    bytes and carries between neighbours must not leak), field masks with high bits, and grids of 1 and 3 workgroups so that
+    every wave makes many trips — its result words are staged in LDS and stored one trip late, the last trip after the
+    loop. Both load depths (variant 2048 = 4 loads per lane)."""
+    rng = np.random.default_rng(ord(tag[1]) + grid)
+    info = np.iinfo(dt)
+    n = 20 * 64 * (16 // np.dtype(dt).itemsize) * 8 * 4 + 777  # 20 tiles of the 8-deep shape + a ragged tail
+    data = rng.integers(0, info.max, size=n, dtype=dt, endpoint=True)
+    special = np.array([0, 1, 0x7F, 0x80, 0xFF, info.max, info.max >> 1, (info.max >> 1) + 1], dtype=dt)
+    data[rng.integers(0, n, size=n // 3)] = special[rng.integers(0, special.size, size=n // 3)]
+    dev = ctx.to_device(data, 64)
+    out = ctx.alloc(nbytes(n) + 8)
+    for fm, tg in ((info.max, 0x80), (info.max, info.max), (0x80, 0x80), (info.max ^ 1, 0x7E), (0xFF, 0), (info.max, 0)):
+        fm, tg = dt(fm & info.max), dt(tg & info.max)
+        for variant in (0, 2048):
+            ctx.set_variant(variant)
+            ctx.set_grid(grid)
+            try:
+                ctx.dev_memset(out, 0xA5, nbytes(n) + 8)
+                ctx.simd_eq_mask(tag, dev, n, int(fm), int(tg), out)
+            finally:
+                ctx.set_grid(0)
+                ctx.set_variant(0)
+            got = unpack(out.download(np.uint8, nbytes(n)), n)
+            np.testing.assert_array_equal(got, (data & fm) == tg, err_msg=f"mask {fm:#x} target {tg:#x} variant {variant}")
+
+
 def test_one_billion_bit_masks(ctx):
     """Config-4-sized validity (10^9 bits, ~10 % nulls): popcount == the masked sum's valid count;
     NOT flips exactly; AND with its own NOT is empty (size-independent properties)."""
