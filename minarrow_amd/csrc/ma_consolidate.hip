@@ -272,9 +272,10 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
     const DescTable<LDS> tab{chunks, LDS ? staged : compact};
     const size_t n_words = (total + 63) >> 6;
     const size_t n_pairs = (n_words + 1) >> 1;
-    const size_t stride = (size_t)gridDim.x * kBlock;
     const bool out16 = ((uintptr_t)out_words & 15) == 0;
-    for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < n_pairs; p += stride) {
+
+    // one pair of output words whatever it straddles: the general form
+    auto one_pair = [&](size_t p) {
         const size_t row = p << 7;
         const int c = tab.find(n_chunks, row);
         const MaskDesc d = tab.get(c);
@@ -320,13 +321,74 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
         } else {
             out_words[2 * p] = w0;
         }
+    };
+
+    // A wave takes runs of 64 x kRun consecutive pairs (4 KiB of output). Almost every run lies inside ONE chunk: the chunk
+    // is then looked up once for the wave (not once per 16 bytes — a binary search and a 40-byte descriptor read, both in
+    // LDS, per pair were what kept a bit-granular join at 0.90 of the copy rate), the bit phase is the same for every lane
+    // (pairs are 128 rows apart), and the kRun loads of a lane are in flight together.
+    constexpr int kRun = 4;
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    const size_t n_runs = (n_pairs + 64 * kRun - 1) / (64 * kRun);
+    for (size_t run = wave_id; run < n_runs; run += n_waves) {
+        const size_t p0 = run * 64 * kRun;
+        const size_t row0 = p0 << 7;
+        const size_t row_end = (p0 + 64 * kRun) << 7;  // one past the run's last row, if the run is whole
+        const int c = __builtin_amdgcn_readfirstlane(tab.find(n_chunks, row0));
+        const MaskDesc d = tab.get(c);
+        const size_t b0 = d.bit_off + (row0 - d.start);
+        const bool whole = p0 + 64 * kRun <= n_pairs && 2 * (p0 + 64 * kRun) <= n_words && row_end <= d.start + d.len &&
+                           out16 && (d.words == nullptr || ((b0 + ((size_t)(64 * kRun - 1) << 7)) >> 3) + 17 <= (d.last_word + 1) * 8);
+        if (whole) {  // wave-uniform
+            u2 v[kRun];
+            if (d.words == nullptr) {
+#pragma unroll
+                for (int u = 0; u < kRun; ++u) v[u] = u2{~(uint64_t)0, ~(uint64_t)0};
+            } else {
+                typedef u2 u2u __attribute__((aligned(1)));
+                const unsigned sub = (unsigned)(b0 & 7);  // the same for every pair of the run
+                u2 pr[kRun];
+                uint64_t nx[kRun];
+                uint64_t last_byte = 0;  // lane 63 of the last load needs the one byte behind the run
+#pragma unroll
+                for (int u = 0; u < kRun; ++u) {
+                    const uint8_t* base = (const uint8_t*)d.words + ((b0 + ((size_t)(u * 64 + lane) << 7)) >> 3);
+                    pr[u] = *(const u2u*)base;
+                    if (u == kRun - 1 && sub && lane == 63) last_byte = base[16];
+                }
+                // the byte that holds a pair's last `sub` bits is the first byte of the NEXT pair's load: one lane up, or
+                // lane 0 of the next load (a byte load per pair doubled the number of memory instructions)
+#pragma unroll
+                for (int u = 0; u < kRun; ++u) {
+                    const unsigned mine = (unsigned)pr[u].x & 0xFFu;
+                    unsigned up = (unsigned)__shfl_down((int)mine, 1, 64);
+                    const unsigned wrap = u + 1 < kRun ? (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)pr[u + 1 < kRun ? u + 1 : u].x & 0xFFu))
+                                                       : (unsigned)last_byte;
+                    nx[u] = lane == 63 ? wrap : up;
+                }
+#pragma unroll
+                for (int u = 0; u < kRun; ++u) {
+                    v[u].x = sub ? (pr[u].x >> sub) | (pr[u].y << (64 - sub)) : pr[u].x;
+                    v[u].y = sub ? (pr[u].y >> sub) | (nx[u] << (64 - sub)) : pr[u].y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) *(u2*)(out_words + 2 * (p0 + u * 64 + lane)) = v[u];
+        } else {
+            for (int u = 0; u < kRun; ++u) {
+                const size_t p = p0 + u * 64 + lane;
+                if (p < n_pairs) one_pair(p);
+            }
+        }
     }
 }
 
 static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks, size_t total, uint64_t* ow,
                                const MaskDesc* compact = nullptr) {
     const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
-    const int grid = grid_for(ctx, (n_pairs + kBlock - 1) / kBlock, 8);
+    const int grid = grid_for(ctx, (n_pairs + kBlock * 4 - 1) / (kBlock * 4), 8);  // a wave takes runs of 64 x 4 pairs
     if (d != nullptr && n_chunks <= (size_t)kLdsChunks)
         hipLaunchKernelGGL(concat_mask_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
     else
