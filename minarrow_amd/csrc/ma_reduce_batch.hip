@@ -4,7 +4,7 @@
 // dispatch on MI355X whatever its size (profiles/r01_launch_bound.json), so a 1000-column table of 1000-row columns is
 // launch-bound by three orders of magnitude; here the launch count is independent of the column count.
 //
-//   pass 1  every column is cut into segments of kSegRows rows; one workgroup reduces one segment at a time
+//   pass 1  every column is cut into segments of seg_rows(element size) rows; one workgroup reduces one segment at a time
 //           (16-byte loads, validity words per wave run — the body of ma_reduce.hip's sum_kernel) and stores a
 //           32-byte partial per segment;
 //   pass 2  one wave per column folds that column's partials in index order and writes {sum, count}.
@@ -26,7 +26,10 @@ struct ColDesc {
     size_t seg0;            // index of this column's first segment (prefix sum)
 };
 
-constexpr size_t kSegRows = (size_t)1 << 16;  // rows per segment: 512 KiB of 8-byte values
+// Rows per segment: 65 536 for 4- and 8-byte values (256 / 512 KiB); the 1- and 2-byte types take 524 288 / 262 144 rows
+// (512 KiB): at 65 536 rows a u8 segment is eight tiles and the per-segment work (search, partial, fold) kept the scan at
+// 4.4 TB/s against the single-column kernel's 6.1.
+constexpr size_t seg_rows(size_t elem) { return elem >= 4 ? ((size_t)1 << 16) : ((size_t)1 << 19) / elem; }
 
 __device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_cols, size_t seg) {
     int lo = 0, hi = n_cols - 1;
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
     for (size_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
         const int c = find_col(cols, n_cols, seg);  // workgroup-uniform
         const ColDesc d = cols[c];
+        constexpr size_t kSegRows = seg_rows(sizeof(T));
         const size_t r_begin = (seg - d.seg0) * kSegRows;
         const size_t r_end = r_begin + kSegRows < d.len ? r_begin + kSegRows : d.len;
         const T* __restrict__ data = (const T*)d.data;
@@ -196,7 +200,7 @@ template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, size_t n_cols, size_t n_segs, Partial* partials, bool is_signed,
                            double* of, uint64_t* oi, uint64_t* oc) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
-    const int grid1 = grid_for(ctx, n_segs, 2);
+    const int grid1 = grid_for(ctx, n_segs, sizeof(T) == 1 ? 3 : 2);  // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip)
     hipLaunchKernelGGL((column_segments_kernel<T, UNROLL>), dim3(grid1), dim3(kBlock), 0, ctx->stream, d, (int)n_cols,
                        n_segs, partials);
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
@@ -250,7 +254,7 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
             d.last_word = (d.bit_off + d.len - 1) >> 6;
         }
         d.seg0 = n_segs;
-        n_segs += d.len ? (d.len + kSegRows - 1) / kSegRows : 0;  // an empty column has no segment: its fold is {0, 0}
+        n_segs += d.len ? (d.len + seg_rows(elem) - 1) / seg_rows(elem) : 0;  // an empty column has no segment: its fold is {0, 0}
     }
     void *of = nullptr, *oi = nullptr, *oc = nullptr;
     MA_TRY(scope.out(out_sums_f64, n_cols * 8, &of));

@@ -33,6 +33,8 @@ def make_columns(rng, fmt, lens):
 def test_ragged_columns_match_single_column_sums(ctx, fmt, device):
     rng = np.random.default_rng(ord(fmt))
     lens = [0, 1, 5, 63, 64, 65, 1000, 4095, 4096, 4097, 65_535, 65_536, 65_537, 200_003, 0, 17]
+    if fmt in "cCsS":  # their segments are 524 288 / 262 144 rows (512 KiB)
+        lens += [262_143, 262_145, 524_287, 524_289, 1_100_003]
     cols = make_columns(rng, fmt, lens)
     masks, offs = [], []
     for i, n in enumerate(lens):
