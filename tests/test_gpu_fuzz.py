@@ -408,6 +408,53 @@ def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed, varian
             assert not unpack(bits, n, ((n + 63) // 64) * 64 - n).any()  # trailing bits of the last word are zero
 
 
+@settings(**COMMON)
+@given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g"]), op=st.sampled_from([0, 1, 2]), side=st.booleans(),
+       lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
+       masked=st.booleans(), seed=st.integers(0, 2**31), variant=st.sampled_from([0, 32, 64, 256, 256 | 32]),
+       in_off=st.integers(0, 3), out_off=st.integers(0, 3))
+def test_broadcast_super_array_scalar(ctx, fmt, op, side, lens, masked, seed, variant, in_off, out_off):
+    """SuperArray (op) Scalar / Scalar (op) SuperArray (super_array.rs:87-116, scalar.rs:214-243) in one launch: chunks on
+    any element phase, outputs off the 16-byte boundary on every other chunk, optional validity per chunk, both kernel forms."""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype({"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64}[fmt])
+    k = len(lens)
+    C_ = [rand_values(rng, dt, n + in_off, small=True) for n in lens]
+    s = rand_values(rng, dt, 1, small=True)[0]
+    dC = [ctx.to_device(x, 64) for x in C_]
+    pC = [d.ptr + in_off * dt.itemsize for d in dC]
+    bO = [ctx.alloc(n * dt.itemsize + 128) for n in lens]
+    offs = [(out_off if (i % 2 and not masked) else 0) for i in range(k)]  # masked chunks of the chunk form start on 16 bytes
+    dO = [b.ptr + o * dt.itemsize for b, o in zip(bO, offs)]
+    ms = dms = doms = None
+    if masked:
+        ms = [np.packbits(rng.random(((n + 63) // 64) * 64 + 64) >= 0.3, bitorder="little") if i % 3 != 0 else None for i, n in enumerate(lens)]
+        dms = [ctx.to_device(m, 16) if m is not None else None for m in ms]
+        doms = [ctx.alloc(n // 8 + 64) for n in lens]
+    ctx.set_variant(variant)
+    try:
+        has = ctx.broadcast_super_array_scalar(fmt, op, s, pC, lens, dO, dms, doms, scalar_is_lhs=side)
+    finally:
+        ctx.set_variant(0)
+    for i, n in enumerate(lens):
+        want_has = bool(masked and ms[i] is not None)
+        assert has[i] == want_has
+        if n == 0:
+            continue
+        x = C_[i][in_off:]
+        full = np.full(n, s, dtype=dt)
+        l, r = (full, x) if side else (x, full)
+        with np.errstate(all="ignore"):
+            res = [l + r, l - r, l * r][op].astype(dt)
+        valid = unpack(ms[i], 0, n) if want_has else np.ones(n, bool)
+        want = np.where(valid, res, dt.type(0))
+        got = bO[i].download(dt, n, offs[i] * dt.itemsize)
+        np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+        if want_has:
+            bits = doms[i].download(np.uint8, ((n + 63) // 64) * 8)
+            np.testing.assert_array_equal(unpack(bits, 0, n), valid)
+
+
 # ---- host-resident operands through the tiled staging pipeline (ma_pipeline.hip) -------------------------------------
 TILE = 256 << 10  # bytes per operand per tile while these properties run
 
