@@ -53,32 +53,30 @@ __device__ __forceinline__ void concat_tile(const T* __restrict__ src, T* __rest
     const size_t r0 = head + lt * TILE_ROWS;  // first row of the aligned part of this tile
     const size_t r1 = r0 + TILE_ROWS < len ? r0 + TILE_ROWS : len;
     if (lt == 0) {
-        for (size_t i = threadIdx.x; i < head && i < len; i += kBlock) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < head && i < len; i += kBlock) as_global(dst)[i] = as_global(src)[i];
     }
     if (r0 >= len) return;
     if (r1 - r0 == TILE_ROWS) {
         // Stores are 16-byte aligned by construction of the tiles; the source is read at whatever element-aligned
         // phase it has with the same global_load_dwordx4 (gfx950 runs with unaligned access mode on under HSA; a
         // misaligned wave access touches one extra cache line per KiB).
-        typedef V VU __attribute__((aligned(1)));
         const size_t w0 = r0 + (size_t)wave * WAVE_ROWS;
-        const VU* __restrict__ p = (const VU*)(src + w0) + lane;
+        const V* __restrict__ p = (const V*)(src + w0) + lane;
         V* __restrict__ q = (V*)(dst + w0) + lane;
         V v[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u) v[u] = load16u<V, true>(p + (size_t)u * 64);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) store16<V, true>(q + (size_t)u * 64, v[u]);
     } else {
         // The chunk's last, partial tile (up to TILE_ROWS - 1 rows — 32 767 for 1-byte columns): whole 16-byte
         // vectors first (dst + r0 is 16-byte aligned like every tile start), then the few rows left, instead of one
         // element per lane per trip (128 trips of 1-byte accesses for one workgroup, ~10 % of a 1-byte consolidate).
-        typedef V VU __attribute__((aligned(1)));
         const size_t n_vec = (r1 - r0) / R;
-        const VU* __restrict__ p = (const VU*)(src + r0);
+        const V* __restrict__ p = (const V*)(src + r0);
         V* __restrict__ q = (V*)(dst + r0);
-        for (size_t v = threadIdx.x; v < n_vec; v += kBlock) store16<V, true>(q + v, __builtin_nontemporal_load(p + v));
-        for (size_t i = r0 + n_vec * R + threadIdx.x; i < r1; i += kBlock) dst[i] = src[i];
+        for (size_t v = threadIdx.x; v < n_vec; v += kBlock) store16<V, true>(q + v, load16u<V, true>(p + v));
+        for (size_t i = r0 + n_vec * R + threadIdx.x; i < r1; i += kBlock) as_global(dst)[i] = as_global(src)[i];
     }
 }
 
@@ -152,15 +150,17 @@ __global__ __launch_bounds__(kBlock) void concat_chunk_kernel(const ConcatChunk*
                 if (end - row >= 64) {
                     // bits b .. b + 63 are window bits: bytes b/8 .. b/8 + 7, and (b % 8 != 0) byte b/8 + 8, hold them
                     typedef uint64_t u64u __attribute__((aligned(1)));
-                    const uint8_t* base = (const uint8_t*)m.words + (b >> 3);
+                    typedef const u64u __attribute__((address_space(1)))* GP;  // global, not flat (ma_device.hpp: as_global)
+                    const auto base = as_global((const uint8_t*)m.words + (b >> 3));
                     sh = (unsigned)(b & 7);
-                    lo = *(const u64u*)base;
+                    lo = *(GP)base;
                     hi = sh ? (uint64_t)base[8] : 0;
                 } else {
                     const size_t wi = b >> 6;
                     sh = (unsigned)(b & 63);
-                    lo = m.words[wi];
-                    hi = (sh && wi + 1 <= last_word) ? m.words[wi + 1] : 0;
+                    const auto gw = as_global(m.words);
+                    lo = gw[wi];
+                    hi = (sh && wi + 1 <= last_word) ? gw[wi + 1] : 0;
                 }
             };
             uint64_t lo0 = 0, hi0 = 0;

@@ -68,12 +68,22 @@ __device__ __forceinline__ void pace_loads() {
     if constexpr (CYCLES == 16 || CYCLES == 32) asm volatile("s_nop 15" ::: "memory");
 }
 
+// Every pointer these helpers see is GLOBAL memory (device or pinned host) — never LDS or scratch. Saying so matters when
+// the pointer was itself loaded from memory (a chunk descriptor table): the compiler then knows nothing about its address
+// space and emits FLAT instructions, which count on lgkmcnt as well as vmcnt — every wait for a descriptor prefetch or an
+// LDS access then also waits for the data stream. With the cast the batched kernels' streams are global_load / global_store
+// like those of the kernels whose pointers are kernel arguments.
+template <typename T>
+__device__ __forceinline__ T __attribute__((address_space(1)))* as_global(T* p) {
+    return (T __attribute__((address_space(1)))*)p;
+}
+
 template <typename V, bool NT>
 __device__ __forceinline__ V load16(const V* p) {
     if constexpr (NT) {
-        return __builtin_nontemporal_load(p);
+        return __builtin_nontemporal_load(as_global(p));
     } else {
-        return *p;
+        return *as_global(p);
     }
 }
 
@@ -83,19 +93,20 @@ __device__ __forceinline__ V load16(const V* p) {
 template <typename V, bool NT>
 __device__ __forceinline__ V load16u(const V* p) {
     typedef V VU __attribute__((aligned(1)));
+    typedef const VU __attribute__((address_space(1)))* GP;  // spelled out: a template would drop the typedef's alignment
     if constexpr (NT) {
-        return __builtin_nontemporal_load((const VU*)p);
+        return __builtin_nontemporal_load((GP)p);
     } else {
-        return *(const VU*)p;
+        return *(GP)p;
     }
 }
 
 template <typename V, bool NT>
 __device__ __forceinline__ void store16(V* p, V v) {
     if constexpr (NT) {
-        __builtin_nontemporal_store(v, p);
+        __builtin_nontemporal_store(v, as_global(p));
     } else {
-        *p = v;
+        *as_global(p) = v;
     }
 }
 
@@ -122,12 +133,13 @@ __device__ __forceinline__ uint64_t load_run_words(const uint64_t* __restrict__ 
     static_assert(WPT <= 64, "a wave loads its run's validity words with one lane each");
     const size_t w0 = bit0 >> 6;
     const unsigned sh = (unsigned)(bit0 & 63);
+    const auto gw = as_global(words);
     uint64_t mw = 0;
-    if (lane <= (unsigned)WPT && w0 + lane <= last_word) mw = words[w0 + lane];
+    if (lane <= (unsigned)WPT && w0 + lane <= last_word) mw = gw[w0 + lane];
     uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
     if constexpr (WPT == 64) {
         // all 64 lanes hold a run word; the last one needs word 64 for its funnel shift and fetches it itself
-        if (lane == 63) nx = (sh && w0 + 64 <= last_word) ? words[w0 + 64] : 0;
+        if (lane == 63) nx = (sh && w0 + 64 <= last_word) ? gw[w0 + 64] : 0;
     }
     return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
 }
@@ -217,7 +229,7 @@ __device__ __forceinline__ V zero_null_slots(V v, unsigned bits) {
 }
 
 __device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
-    return (unsigned)(((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
+    return (unsigned)(as_global((const uint8_t*)words)[bit >> 3] >> (bit & 7)) & 1u;
 }
 
 // Narrow integer columns (i8 / u8 / i16 / u16 — the reference's extended_numeric_types, src/enums/collections/

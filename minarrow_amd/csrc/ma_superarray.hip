@@ -132,9 +132,10 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
     constexpr int WPT = R * UNROLL;
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
-    const T* __restrict__ lhs = (const T*)d.lhs;
-    const T* __restrict__ rhs = (const T*)d.rhs;
-    T* __restrict__ out = (T*)d.out;
+    // global, not flat: these pointers come out of a table (see as_global)
+    const auto lhs = as_global((const T*)d.lhs);
+    const auto rhs = as_global((const T*)d.rhs);
+    const auto out = as_global((T*)d.out);
     const bool masked = d.lw != nullptr || d.rw != nullptr;
     const size_t r0 = d.head + lt * TILE_ROWS;
     const size_t r1 = r0 + TILE_ROWS < d.len ? r0 + TILE_ROWS : d.len;
@@ -154,9 +155,9 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
     // runs the same vector body over its whole vectors (loads and stores guarded per vector) and finishes the < R
     // rows that remain one by one; whole runs take the unguarded body.
     const size_t run_rows = r1 - w0 < WAVE_ROWS ? r1 - w0 : WAVE_ROWS;
-    const V* __restrict__ p = (const V*)(lhs + w0) + lane;
-    const V* __restrict__ q = (const V*)(rhs + w0) + lane;
-    V* __restrict__ o = (V*)(out + w0) + lane;
+    const V* __restrict__ p = (const V*)((const T*)d.lhs + w0) + lane;
+    const V* __restrict__ q = (const V*)((const T*)d.rhs + w0) + lane;
+    V* __restrict__ o = (V*)((T*)d.out + w0) + lane;
     uint64_t aw = ~(uint64_t)0;
     if (masked) {
         aw = 0;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
             if (first < d.len) {
                 uint64_t w = aw;
                 if (d.len - first < 64) w &= (((uint64_t)1) << (d.len - first)) - 1;
-                d.ow[j] = w;
+                as_global(d.ow)[j] = w;
             }
         }
     }

@@ -33,7 +33,7 @@ timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-other-configs --steps 
 step "Power series accuracy"; timeout -k 10 200 python3 tools/pow_series_report.py > $O/${R}_pow_series_accuracy.json 2>/dev/null || exit 1
 step "kernel trace of the chunked regime (60 000 x 8192-row chunk pairs): kernel durations apart from table delivery"
 MA_MATRIX_ONLY_SMALL_CHUNKS=1 timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -- python3 tools/bench_matrix.py --only super_array,consolidate --reps 3 > /dev/null 2>&1 || exit 1
-python3 tools/trace_summary.py $O/trace kernel > $O/${R}_super_array_trace.txt; rm -rf $O/trace
+python3 tools/trace_summary.py $O/trace kernel > $O/${R}_super_array_trace_final.txt; rm -rf $O/trace
 step "matrix (on the runtime bench.py runs on)"; MA_IMPORT_TORCH=1 timeout -k 10 600 python3 tools/bench_matrix.py > $O/${R}_matrix.jsonl 2> $O/${R}_matrix.err || exit 1
 step "size sweep"; MA_IMPORT_TORCH=1 timeout -k 10 400 python3 tools/sweep_sizes.py > $O/${R}_sweep_sizes.jsonl 2>/dev/null || exit 1
 step "lanes"; timeout -k 10 200 python3 tools/bench_lanes.py > $O/${R}_lanes.json 2>/dev/null || exit 1
