@@ -84,10 +84,17 @@ template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void concat_kernel(const ChunkDesc* __restrict__ chunks, int n_chunks,
                                                         size_t n_tiles, T* __restrict__ out) {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the previous tile's chunk is remembered (long chunks: the next tile of this workgroup is nearly always in it)
+    size_t t_lo = 1, t_hi = 0;
+    ChunkDesc d{};
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int c = find_chunk_by_tile(chunks, n_chunks, t);  // workgroup-uniform
-        const ChunkDesc d = chunks[c];
-        concat_tile<T, UNROLL>((const T*)d.data, out + d.start, d.head, d.len, t - d.tile0, lane, wave);
+        if (t < t_lo || t >= t_hi) {
+            const int c = find_chunk_by_tile(chunks, n_chunks, t);  // workgroup-uniform
+            d = chunks[c];
+            t_lo = d.tile0;
+            t_hi = c + 1 < n_chunks ? chunks[c + 1].tile0 : n_tiles;
+        }
+        concat_tile<T, UNROLL>((const T*)d.data, out + d.start, d.head, d.len, t - t_lo, lane, wave);
     }
 }
 
