@@ -271,8 +271,12 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
     __shared__ MaskDesc staged[LDS ? kLdsChunks : 1];
     if constexpr (LDS) {
         for (int i = threadIdx.x; i < n_chunks; i += kBlock) {
-            const ChunkDesc& c = chunks[i];
-            staged[i] = MaskDesc{c.start, c.len, c.words, c.bit_off, c.last_word};
+            if (chunks != nullptr) {
+                const ChunkDesc& c = chunks[i];
+                staged[i] = MaskDesc{c.start, c.len, c.words, c.bit_off, c.last_word};
+            } else {
+                staged[i] = compact[i];
+            }
         }
         __syncthreads();
     }
@@ -396,7 +400,7 @@ static void launch_concat_mask(ma_ctx* ctx, const ChunkDesc* d, size_t n_chunks,
                                const MaskDesc* compact = nullptr) {
     const size_t n_pairs = (((total + 63) >> 6) + 1) >> 1;
     const int grid = grid_for(ctx, (n_pairs + kBlock * 4 - 1) / (kBlock * 4), 8);  // a wave takes runs of 64 x 4 pairs
-    if (d != nullptr && n_chunks <= (size_t)kLdsChunks)
+    if (n_chunks <= (size_t)kLdsChunks)
         hipLaunchKernelGGL(concat_mask_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
     else
         hipLaunchKernelGGL(concat_mask_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, compact, (int)n_chunks, total, ow);
@@ -828,21 +832,31 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     MA_NO_CAPTURE(ctx, "consolidation (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    std::vector<ChunkDesc> data_desc(n_chunks), mask_desc(has_mask ? n_chunks : 0);
+    // Compact 40-byte descriptors (a Boolean column rechunked at 8192 rows is 122 000 chunks per 10^9 rows: the call is
+    // host- and table-bound, not data-bound); a chunked column's bitmaps run through a few allocations, so each operand
+    // role remembers the device range its last pointer fell into (two compares instead of a classification call).
+    std::vector<MaskDesc> data_desc(n_chunks), mask_desc(has_mask ? n_chunks : 0);
+    DeviceRange data_role, mask_role;
+    auto describe = [&](DeviceRange& role, const uint8_t* bits, size_t off, size_t len, MaskDesc& d) -> ma_status {
+        if (role.holds(bits)) {
+            const uintptr_t addr = (uintptr_t)bits, base = addr & ~(uintptr_t)7;  // CallScope::in_mask's re-basing
+            d.words = (const uint64_t*)base;
+            d.bit_off = off + (size_t)(addr - base) * 8;
+        } else {
+            MA_TRY(scope.in_mask(bits, off, len, &d.words, &d.bit_off));
+            role.learn(bits);
+        }
+        d.last_word = (d.bit_off + len - 1) >> 6;
+        return MA_OK;
+    };
     size_t row = 0;
     for (size_t i = 0; i < n_chunks; ++i) {
-        ChunkDesc d{};
-        d.start = row;
-        d.len = chunk_lens[i];
-        ChunkDesc m = d;
+        MaskDesc d{row, chunk_lens[i], nullptr, 0, 0};
+        MaskDesc m = d;
         if (d.len) {
-            MA_TRY(scope.in_mask(chunk_bits[i], chunk_bit_offsets ? chunk_bit_offsets[i] : 0, d.len, &d.words, &d.bit_off));
-            d.last_word = (d.bit_off + d.len - 1) >> 6;
-            if (has_mask && chunk_masks[i]) {
-                MA_TRY(scope.in_mask(chunk_masks[i], chunk_mask_offsets ? chunk_mask_offsets[i] : 0, m.len, &m.words,
-                                     &m.bit_off));
-                m.last_word = (m.bit_off + m.len - 1) >> 6;
-            }
+            MA_TRY(describe(data_role, chunk_bits[i], chunk_bit_offsets ? chunk_bit_offsets[i] : 0, d.len, d));
+            if (has_mask && chunk_masks[i])
+                MA_TRY(describe(mask_role, chunk_masks[i], chunk_mask_offsets ? chunk_mask_offsets[i] : 0, m.len, m));
         }
         data_desc[i] = d;
         if (has_mask) mask_desc[i] = m;
@@ -850,18 +864,18 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     }
     // both descriptor tables in one scratch region
     void* tables = nullptr;
-    MA_TRY(ctx_scratch(ctx, sizeof(ChunkDesc) * n_chunks * 2, &tables));
-    ChunkDesc* dd = (ChunkDesc*)tables;
-    ChunkDesc* md = dd + n_chunks;
-    MA_TRY(upload_table(ctx, data_desc.data(), sizeof(ChunkDesc) * n_chunks, dd));
-    if (has_mask) MA_TRY(upload_table(ctx, mask_desc.data(), sizeof(ChunkDesc) * n_chunks, md));
+    MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks * 2, &tables));
+    MaskDesc* dd = (MaskDesc*)tables;
+    MaskDesc* md = dd + n_chunks;
+    MA_TRY(upload_table(ctx, data_desc.data(), sizeof(MaskDesc) * n_chunks, dd));
+    if (has_mask) MA_TRY(upload_table(ctx, mask_desc.data(), sizeof(MaskDesc) * n_chunks, md));
     uint64_t *ow = nullptr, *mw = nullptr;  // both outputs are validated before the first launch
     MA_TRY(scope.out_mask(out_bits, total, &ow));
     if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &mw));
-    launch_concat_mask(ctx, dd, n_chunks, total, ow);
+    launch_concat_mask(ctx, nullptr, n_chunks, total, ow, dd);
     MA_HIP(hipGetLastError());
     if (has_mask) {
-        launch_concat_mask(ctx, md, n_chunks, total, mw);
+        launch_concat_mask(ctx, nullptr, n_chunks, total, mw, md);
         MA_HIP(hipGetLastError());
     }
     return end_call(ctx, scope);
