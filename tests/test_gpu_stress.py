@@ -115,7 +115,13 @@ def test_sharded_ticket_handoff_under_uneven_load(oracle):
     threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
     bg.start()
     [t.start() for t in threads]
-    [t.join(timeout=SECONDS + 120) for t in threads]
+    deadline = time.time() + SECONDS + 120
+    while any(t.is_alive() for t in threads) and time.time() < deadline:
+        threads[0].join(timeout=60)  # a soak (MA_STRESS_SECONDS >> 60) says it is alive once a minute (visible with -s)
+        if SECONDS > 60:
+            print(f"[stress] {int(time.time() - (deadline - SECONDS - 120))} s, no errors so far" if not errors else f"[stress] errors: {errors[:2]}",
+                  flush=True)
+    [t.join(timeout=1) for t in threads]
     stop.set()
     bg.join(timeout=60)
     assert not any(t.is_alive() for t in threads) and not bg.is_alive(), "a launch never completed (lost arrival?)"
