@@ -43,7 +43,8 @@ __device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_col
 
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* __restrict__ cols, int n_cols,
-                                                                 size_t n_segs, Partial* __restrict__ partials) {
+                                                                 size_t n_segs, Partial* __restrict__ partials,
+                                                                 int one_segment_each) {
     typedef typename Vec16<T>::type V;
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);
@@ -56,7 +57,9 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
     __shared__ Partial lds[kWaves];
 
     for (size_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
-        const int c = find_col(cols, n_cols, seg);  // workgroup-uniform
+        // workgroup-uniform. A chunked column handed over chunk by chunk (8192-row "columns") has one segment per column:
+        // segment s IS column s, and the search — 16 dependent loads in front of 64 KiB of rows — is skipped
+        const int c = one_segment_each ? (int)seg : find_col(cols, n_cols, seg);
         const ColDesc d = cols[c];
         constexpr size_t kSegRows = seg_rows(sizeof(T));
         const size_t r_begin = (seg - d.seg0) * kSegRows;
@@ -200,9 +203,12 @@ template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, size_t n_cols, size_t n_segs, Partial* partials, bool is_signed,
                            double* of, uint64_t* oi, uint64_t* oc) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
-    const int grid1 = grid_for(ctx, n_segs, sizeof(T) == 1 ? 3 : 2);  // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip)
+    // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip). Short columns (a segment or less each): a
+    // workgroup's time per segment is latency (descriptor, partial, barrier), not bandwidth — eight workgroups per CU overlap it
+    const bool short_cols = n_segs <= n_cols;
+    const int grid1 = grid_for(ctx, n_segs, short_cols ? 8 : sizeof(T) == 1 ? 3 : 2);
     hipLaunchKernelGGL((column_segments_kernel<T, UNROLL>), dim3(grid1), dim3(kBlock), 0, ctx->stream, d, (int)n_cols,
-                       n_segs, partials);
+                       n_segs, partials, (n_segs == n_cols) ? 1 : 0);
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
     hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
                        (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc);
@@ -240,17 +246,33 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     CallScope scope(ctx);
     std::vector<ColDesc> desc(n_cols);
     size_t n_segs = 0;
+    // the chunks of a chunked column (one "column" each: 122 000 per 10^9 rows at RechunkStrategy::Auto) run through a few
+    // allocations: each role remembers the device range of its last pointer — two compares instead of a classification
+    DeviceRange data_role, mask_role;
     for (size_t i = 0; i < n_cols; ++i) {
         ColDesc& d = desc[i];
-        const void* p = nullptr;
-        MA_TRY(scope.in(col_data[i], col_lens[i] * elem, &p));
-        d.data = p;
+        if (data_role.holds(col_data[i])) {
+            d.data = col_data[i];
+        } else {
+            const void* p = nullptr;
+            MA_TRY(scope.in(col_data[i], col_lens[i] * elem, &p));
+            d.data = p;
+            if (col_lens[i]) data_role.learn(col_data[i]);
+        }
         d.len = col_lens[i];
         d.words = nullptr;
         d.bit_off = 0;
         d.last_word = 0;
         if (col_masks && col_masks[i] && d.len) {
-            MA_TRY(scope.in_mask(col_masks[i], col_mask_offsets ? col_mask_offsets[i] : 0, d.len, &d.words, &d.bit_off));
+            const size_t mo = col_mask_offsets ? col_mask_offsets[i] : 0;
+            if (mask_role.holds(col_masks[i])) {
+                const uintptr_t addr = (uintptr_t)col_masks[i], base = addr & ~(uintptr_t)7;  // CallScope::in_mask's re-basing
+                d.words = (const uint64_t*)base;
+                d.bit_off = mo + (size_t)(addr - base) * 8;
+            } else {
+                MA_TRY(scope.in_mask(col_masks[i], mo, d.len, &d.words, &d.bit_off));
+                mask_role.learn(col_masks[i]);
+            }
             d.last_word = (d.bit_off + d.len - 1) >> 6;
         }
         d.seg0 = n_segs;

@@ -131,19 +131,21 @@ def main():
     # ---- per-column sums of many columns in two launches (ma_sum_columns): results into device slots, enqueue-only ----
     if want("sum_columns"):
         import ctypes as C
-        res = ctx.alloc(3 * 8 * 4096)
+        res = ctx.alloc(3 * 8 * 65536)
         ctx.set_async(True)
         for tag, fmt in (("i64", "l"), ("f64", "g"), ("i32", "i"), ("u8", "C")):
             n = fill(tag)
-            for k in (8, 1000):
-                per = (n // k) // 64 * 64
+            for k in (8, 1000, 60000):  # 60000: one column per RechunkStrategy::Auto chunk (8192 rows) of a chunked column
+                per = (n // k) // 64 * 64 if k < 60000 else 8192
+                if k == 60000 and tag == "u8":
+                    continue
                 ptrs = C.cast((C.c_void_p * k)(*[a.ptr + i * per * SIZE[tag] for i in range(k)]), C.c_void_p)
                 lens = C.cast((C.c_size_t * k)(*([per] * k)), C.c_void_p)
                 mks = C.cast((C.c_void_p * k)(*[mask.ptr + i * (per // 8) for i in range(k)]), C.c_void_p)
 
                 def call(masked):
                     st = ctx.lib.ma_sum_columns(ctx.handle, ord(fmt), k, ptrs, lens, mks if masked else None, None, res.ptr,
-                                                res.ptr + 8 * 4096 if tag != "f64" else None, res.ptr + 16 * 4096)
+                                                res.ptr + 8 * 65536 if tag != "f64" else None, res.ptr + 16 * 65536)
                     assert st == 0, st
 
                 ms = timed(lambda: call(False))
