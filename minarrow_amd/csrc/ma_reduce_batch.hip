@@ -244,7 +244,8 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    std::vector<ColDesc> desc(n_cols);
+    ColDesc* desc = nullptr;  // built in the context's pinned staging buffer: no second copy of a 60 000-entry table
+    MA_TRY(table_begin(ctx, sizeof(ColDesc) * n_cols, (void**)&desc));
     size_t n_segs = 0;
     // the chunks of a chunked column (one "column" each: 122 000 per 10^9 rows at RechunkStrategy::Auto) run through a few
     // allocations: each role remembers the device range of its last pointer — two compares instead of a classification
@@ -288,7 +289,7 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     const size_t bytes = desc_bytes + sizeof(Partial) * (n_segs ? n_segs : 1);
     void* scratch = nullptr;
     MA_TRY(ctx_scratch(ctx, bytes, &scratch));
-    MA_TRY(upload_table(ctx, desc.data(), sizeof(ColDesc) * n_cols, scratch));
+    MA_TRY(table_commit(ctx, desc, sizeof(ColDesc) * n_cols, scratch));
     const ColDesc* d = (const ColDesc*)scratch;
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     switch (format_code) {
