@@ -26,6 +26,16 @@ struct ColDesc {
     size_t seg0;            // index of this column's first segment (prefix sum)
 };
 
+// Columns of a segment or less each: 32 bytes, read where the host built them (pinned staging buffer, wave-uniform loads a
+// column ahead of their use) — column c IS partial c, nothing to search, no table copy on the stream in front of the kernel
+// (2.9 MB = 0.1 ms of a 0.7-ms call for 60 000 columns).
+struct ShortCol {
+    const void* data;
+    size_t len;
+    const uint64_t* words;  // validity words (8-byte aligned base) or nullptr = dense
+    size_t bit_off;
+};
+
 // Rows per segment: 65 536 for 4- and 8-byte values (256 / 512 KiB); the 1- and 2-byte types take 524 288 / 262 144 rows
 // (512 KiB): at 65 536 rows a u8 segment is eight tiles and the per-segment work (search, partial, fold) kept the scan at
 // 4.4 TB/s against the single-column kernel's 6.1.
@@ -41,26 +51,47 @@ __device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_col
     return lo;
 }
 
-template <typename T, int UNROLL>
-__global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* __restrict__ cols, int n_cols,
-                                                                 size_t n_segs, Partial* __restrict__ partials,
-                                                                 int one_segment_each) {
+// PER_WAVE: a WAVE (not a workgroup) takes a segment and writes its partial itself — no barrier, no LDS merge, four segments
+// in flight per workgroup. For columns of a segment or less each (a chunked column handed over chunk by chunk: 8192-row
+// "columns"), where a workgroup's time per segment was latency — descriptor, barriers, partial — rather than bandwidth.
+template <typename T, int UNROLL, bool PER_WAVE>
+__global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __restrict__ table, int n_cols,
+                                                                 size_t n_segs, Partial* __restrict__ partials) {
     typedef typename Vec16<T>::type V;
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);
     constexpr int WPT = R * UNROLL;
     constexpr bool kNarrow = sizeof(T) <= 2;  // 8 / 16 rows per load, summed inside 32-bit registers (narrow_vec_sum)
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
-    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    constexpr size_t TILE_ROWS = PER_WAVE ? WAVE_ROWS : WAVE_ROWS * kWaves;  // rows per trip of the unit that owns the segment
     static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ Partial lds[kWaves];
+    const unsigned unit_tid = PER_WAVE ? lane : tid;        // index inside the owning unit ...
+    constexpr unsigned kUnit = PER_WAVE ? 64u : (unsigned)kBlock;  // ... and its size
+    __shared__ Partial lds[PER_WAVE ? 1 : kWaves];
 
-    for (size_t seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
-        // workgroup-uniform. A chunked column handed over chunk by chunk (8192-row "columns") has one segment per column:
-        // segment s IS column s, and the search — 16 dependent loads in front of 64 KiB of rows — is skipped
-        const int c = one_segment_each ? (int)seg : find_col(cols, n_cols, seg);
-        const ColDesc d = cols[c];
+    const size_t seg_first = PER_WAVE ? (size_t)blockIdx.x * kWaves + wave : (size_t)blockIdx.x;
+    const size_t seg_stride = PER_WAVE ? (size_t)gridDim.x * kWaves : (size_t)gridDim.x;
+    const ColDesc* __restrict__ cols = (const ColDesc*)table;
+    const ShortCol* __restrict__ shorts = (const ShortCol*)table;
+    ShortCol e{}, e_next{};
+    if constexpr (PER_WAVE) {
+        if (seg_first < n_segs) e = shorts[__builtin_amdgcn_readfirstlane((int)seg_first)];
+    }
+    for (size_t seg = seg_first; seg < n_segs; seg += seg_stride) {
+        ColDesc d;
+        if constexpr (PER_WAVE) {  // segment s = column s: the descriptor was fetched during the previous column's rows
+            if (seg + seg_stride < n_segs) e_next = shorts[__builtin_amdgcn_readfirstlane((int)(seg + seg_stride))];
+            d.data = e.data;
+            d.len = e.len;
+            d.words = e.len ? e.words : nullptr;
+            d.bit_off = e.bit_off;
+            d.last_word = e.len ? (e.bit_off + e.len - 1) >> 6 : 0;
+            d.seg0 = seg;
+            e = e_next;
+        } else {
+            d = cols[find_col(cols, n_cols, seg)];  // workgroup-uniform
+        }
         constexpr size_t kSegRows = seg_rows(sizeof(T));
         const size_t r_begin = (seg - d.seg0) * kSegRows;
         const size_t r_end = r_begin + kSegRows < d.len ? r_begin + kSegRows : d.len;
@@ -82,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
         const size_t body0 = r_begin + head;
         const size_t n_tiles = (r_end - body0) / TILE_ROWS;
         for (size_t t = 0; t < n_tiles; ++t) {
-            const size_t row0 = body0 + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+            const size_t row0 = body0 + t * TILE_ROWS + (PER_WAVE ? 0 : (size_t)wave * WAVE_ROWS);
             const V* __restrict__ p = (const V*)(data + row0) + lane;
             V v[UNROLL];
 #pragma unroll
@@ -114,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
         }
         const size_t tail0 = body0 + n_tiles * TILE_ROWS;
         const size_t n_ragged = head + (r_end - tail0);
-        for (size_t i = tid; i < n_ragged; i += kBlock) {
+        for (size_t i = unit_tid; i < n_ragged; i += kUnit) {
             const size_t row = i < head ? r_begin + i : tail0 + (i - head);
             T x = data[row];
             if (masked) {
@@ -124,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
             }
             acc[0].add(x);
         }
-        if (!masked && tid == 0) cnt = r_end - r_begin;
+        if (!masked && unit_tid == 0) cnt = r_end - r_begin;
 
 #pragma unroll
         for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
@@ -132,6 +163,16 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const ColDesc* 
         for (int off = 32; off > 0; off >>= 1) {
             acc[0].shfl_down_merge(off);
             cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+        }
+        if constexpr (PER_WAVE) {
+            if (lane == 0) {
+                Partial p;
+                acc[0].to_partial(p);
+                p.cnt = cnt;
+                p.pad = 0;
+                partials[seg] = p;
+            }
+            continue;
         }
         __syncthreads();  // lds[] of the previous segment has been consumed
         if (lane == 0) {
@@ -164,14 +205,14 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __restrict__ cols, int n_cols, size_t n_segs,
                                                              const Partial* __restrict__ partials, int is_signed,
                                                              double* __restrict__ out_f64, uint64_t* __restrict__ out_i64,
-                                                             uint64_t* __restrict__ out_cnt) {
+                                                             uint64_t* __restrict__ out_cnt, int partial_per_column) {
     typedef typename AccOf<T>::type Acc;
     const unsigned lane = threadIdx.x & 63;
     const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
     for (size_t c = wave_id; c < (size_t)n_cols; c += n_waves) {
-        const size_t s0 = cols[c].seg0;
-        const size_t s1 = c + 1 < (size_t)n_cols ? cols[c + 1].seg0 : n_segs;
+        const size_t s0 = partial_per_column ? c : cols[c].seg0;
+        const size_t s1 = partial_per_column ? c + 1 : (c + 1 < (size_t)n_cols ? cols[c + 1].seg0 : n_segs);
         Acc tot;
         tot.init();
         uint64_t cnt = 0;
@@ -199,19 +240,25 @@ __global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __re
     }
 }
 
+// short_table != nullptr: every column is a segment or less — a wave per column on the ShortCol table (read in place),
+// partial c = column c; otherwise a workgroup per segment on the uploaded ColDesc table.
 template <typename T>
-static void launch_columns(ma_ctx* ctx, const ColDesc* d, size_t n_cols, size_t n_segs, Partial* partials, bool is_signed,
-                           double* of, uint64_t* oi, uint64_t* oc) {
+static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_table, size_t n_cols, size_t n_segs,
+                           Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
-    // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip). Short columns (a segment or less each): a
-    // workgroup's time per segment is latency (descriptor, partial, barrier), not bandwidth — eight workgroups per CU overlap it
-    const bool short_cols = n_segs <= n_cols;
-    const int grid1 = grid_for(ctx, n_segs, short_cols ? 8 : sizeof(T) == 1 ? 3 : 2);
-    hipLaunchKernelGGL((column_segments_kernel<T, UNROLL>), dim3(grid1), dim3(kBlock), 0, ctx->stream, d, (int)n_cols,
-                       n_segs, partials, (n_segs == n_cols) ? 1 : 0);
+    if (short_table) {
+        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
+        hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream,
+                           (const void*)short_table, (int)n_cols, n_cols, partials);
+    } else {
+        // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip)
+        const int grid1 = grid_for(ctx, n_segs, sizeof(T) == 1 ? 3 : 2);
+        hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, (const void*)d,
+                           (int)n_cols, n_segs, partials);
+    }
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
     hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
-                       (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc);
+                       (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc, short_table ? 1 : 0);
 }
 
 }  // namespace ma
@@ -244,67 +291,85 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
-    ColDesc* desc = nullptr;  // built in the context's pinned staging buffer: no second copy of a 60 000-entry table
-    MA_TRY(table_begin(ctx, sizeof(ColDesc) * n_cols, (void**)&desc));
+    // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
+    bool all_short = n_cols >= 256;  // below that the table copy is a few microseconds and the segment form is as good
+    for (size_t i = 0; i < n_cols && all_short; ++i) all_short = col_lens[i] <= seg_rows(elem);
+    ColDesc* desc = nullptr;  // either table is built in the context's pinned staging buffer: no second copy of 60 000 entries
+    ShortCol* sdesc = nullptr;
+    if (all_short) MA_TRY(table_begin(ctx, sizeof(ShortCol) * n_cols, (void**)&sdesc));
+    else MA_TRY(table_begin(ctx, sizeof(ColDesc) * n_cols, (void**)&desc));
     size_t n_segs = 0;
     // the chunks of a chunked column (one "column" each: 122 000 per 10^9 rows at RechunkStrategy::Auto) run through a few
     // allocations: each role remembers the device range of its last pointer — two compares instead of a classification
     DeviceRange data_role, mask_role;
     for (size_t i = 0; i < n_cols; ++i) {
-        ColDesc& d = desc[i];
-        if (data_role.holds(col_data[i])) {
-            d.data = col_data[i];
-        } else {
-            const void* p = nullptr;
-            MA_TRY(scope.in(col_data[i], col_lens[i] * elem, &p));
-            d.data = p;
+        const void* data = col_data[i];
+        if (!data_role.holds(data)) {
+            MA_TRY(scope.in(col_data[i], col_lens[i] * elem, &data));
             if (col_lens[i]) data_role.learn(col_data[i]);
         }
-        d.len = col_lens[i];
-        d.words = nullptr;
-        d.bit_off = 0;
-        d.last_word = 0;
-        if (col_masks && col_masks[i] && d.len) {
+        const uint64_t* words = nullptr;
+        size_t bit_off = 0;
+        if (col_masks && col_masks[i] && col_lens[i]) {
             const size_t mo = col_mask_offsets ? col_mask_offsets[i] : 0;
             if (mask_role.holds(col_masks[i])) {
                 const uintptr_t addr = (uintptr_t)col_masks[i], base = addr & ~(uintptr_t)7;  // CallScope::in_mask's re-basing
-                d.words = (const uint64_t*)base;
-                d.bit_off = mo + (size_t)(addr - base) * 8;
+                words = (const uint64_t*)base;
+                bit_off = mo + (size_t)(addr - base) * 8;
             } else {
-                MA_TRY(scope.in_mask(col_masks[i], mo, d.len, &d.words, &d.bit_off));
+                MA_TRY(scope.in_mask(col_masks[i], mo, col_lens[i], &words, &bit_off));
                 mask_role.learn(col_masks[i]);
             }
-            d.last_word = (d.bit_off + d.len - 1) >> 6;
         }
-        d.seg0 = n_segs;
-        n_segs += d.len ? (d.len + seg_rows(elem) - 1) / seg_rows(elem) : 0;  // an empty column has no segment: its fold is {0, 0}
+        if (all_short) {
+            sdesc[i] = ShortCol{data, col_lens[i], words, bit_off};
+        } else {
+            ColDesc& d = desc[i];
+            d.data = data;
+            d.len = col_lens[i];
+            d.words = words;
+            d.bit_off = bit_off;
+            d.last_word = words ? (bit_off + d.len - 1) >> 6 : 0;
+            d.seg0 = n_segs;
+            n_segs += d.len ? (d.len + seg_rows(elem) - 1) / seg_rows(elem) : 0;  // an empty column has no segment: its fold is {0, 0}
+        }
     }
     void *of = nullptr, *oi = nullptr, *oc = nullptr;
     MA_TRY(scope.out(out_sums_f64, n_cols * 8, &of));
     MA_TRY(scope.out(out_sums_i64, n_cols * 8, &oi));
     MA_TRY(scope.out(out_valid_counts, n_cols * 8, &oc));
 
-    // descriptors + partials in one scratch allocation
-    const size_t desc_bytes = ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
-    const size_t bytes = desc_bytes + sizeof(Partial) * (n_segs ? n_segs : 1);
+    // descriptors (segment form) + partials in one scratch allocation
+    const size_t n_partials = all_short ? n_cols : (n_segs ? n_segs : 1);
+    const size_t desc_bytes = all_short ? 0 : ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
     void* scratch = nullptr;
-    MA_TRY(ctx_scratch(ctx, bytes, &scratch));
-    MA_TRY(table_commit(ctx, desc, sizeof(ColDesc) * n_cols, scratch));
-    const ColDesc* d = (const ColDesc*)scratch;
+    MA_TRY(ctx_scratch(ctx, desc_bytes + sizeof(Partial) * n_partials, &scratch));
+    const ColDesc* d = nullptr;
+    const ShortCol* sd = nullptr;
+    int slot = -1;
+    if (all_short) {
+        const void* alias = nullptr;
+        MA_TRY(table_commit_mapped(ctx, sdesc, &alias, &slot));
+        sd = (const ShortCol*)alias;
+    } else {
+        MA_TRY(table_commit(ctx, desc, sizeof(ColDesc) * n_cols, scratch));
+        d = (const ColDesc*)scratch;
+    }
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     switch (format_code) {
-        case 'c': launch_columns<int8_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'C': launch_columns<uint8_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 's': launch_columns<int16_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'S': launch_columns<uint16_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'i': launch_columns<int32_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'I': launch_columns<uint32_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'l': launch_columns<int64_t>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'L': launch_columns<uint64_t>(ctx, d, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'f': launch_columns<float>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        default: launch_columns<double>(ctx, d, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
     }
     MA_HIP(hipGetLastError());
+    if (slot >= 0) MA_TRY(table_release(ctx, slot));
     return end_call(ctx, scope);
 }
 

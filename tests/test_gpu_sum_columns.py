@@ -74,6 +74,45 @@ def test_ragged_columns_match_single_column_sums(ctx, fmt, device):
                 assert (int(s1) - int(i64[k])) % (1 << 64) == 0
 
 
+@pytest.mark.parametrize("fmt", ["l", "g", "i", "f", "C", "s"])
+def test_many_short_columns_take_the_wave_per_column_form(ctx, fmt):
+    """From 256 columns of a segment or less each (a chunked column handed over chunk by chunk) a WAVE sums a column, the
+    32-byte descriptors are read where the host built them and partial c is column c: 3000 columns of ragged lengths incl.
+    empty ones and whole segments, sub-allocated at odd element offsets, validity at odd bit offsets on two thirds."""
+    rng = np.random.default_rng(ord(fmt) + 1)
+    dt = NP[fmt]
+    seg = 65_536 if np.dtype(dt).itemsize >= 4 else (1 << 19) // np.dtype(dt).itemsize
+    lens = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 1000, 4097, 8192, 8191, 20_001], size=3000)]
+    lens[5], lens[17] = seg, seg - 1
+    cols = make_columns(rng, fmt, lens)
+    arena = np.concatenate([np.concatenate([np.zeros(1, c.dtype), c]) for c in cols])
+    starts = np.cumsum([0] + [c.size + 1 for c in cols[:-1]]) + 1
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + int(s) * arena.itemsize for s in starts]
+    masks, offs, d_masks = [], [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0 or n == 0:
+            masks.append(None); offs.append(0); d_masks.append(None)
+        else:
+            off = [0, 3, 64, 77][i % 4]
+            m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+            masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+    f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+    for k, (c, n) in enumerate(zip(cols, lens)):
+        valid = (np.unpackbits(masks[k], bitorder="little")[offs[k]:offs[k] + n].astype(bool)
+                 if masks[k] is not None else np.ones(n, dtype=bool))
+        assert cnt[k] == valid.sum(), k
+        sel = c[valid]
+        if fmt in "fg":
+            exact = math.fsum(sel.astype(np.float64).tolist())
+            assert abs(f[k] - exact) <= math.ulp(exact), (k, n)
+        else:
+            want = int(sel.astype(object).sum()) if n else 0
+            assert (int(i64[k]) - want) % (1 << 64) == 0, (k, n)
+    dense_f, dense_i, dense_c = ctx.sum_columns(fmt, ptrs, lens)
+    np.testing.assert_array_equal(dense_c, np.array(lens, dtype=np.uint64))
+
+
 def test_thousand_small_columns(ctx):
     """1000 columns of 1000 rows (the launch-bound shape): iota data, closed forms."""
     k, n = 1000, 1000
