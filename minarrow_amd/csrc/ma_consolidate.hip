@@ -430,6 +430,67 @@ __global__ __launch_bounds__(kBlock) void concat_mask_joins_kernel(const MaskDes
     }
 }
 
+// Bit-packed columns cut into many short chunks (a Boolean column rechunked at 8192 rows: 122 000 chunks per 10^9 rows): a
+// WAVE writes the output words that lie wholly inside its chunk — no search at all —, concat_mask_joins_kernel the words a
+// chunk starts inside. concat_mask_kernel's run-wise lookup pays a 17-step search of the chunk table per 4 KiB there
+// (131 072 x 8192-bit chunks: 306 us of kernel for 256 MB of traffic).
+__global__ __launch_bounds__(kBlock) void concat_bits_chunk_kernel(const MaskDesc* __restrict__ compact, int n_chunks, size_t total,
+                                                                   uint64_t* __restrict__ out_words) {
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave_id = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    for (size_t ci = wave_id; ci < (size_t)n_chunks; ci += n_waves) {
+        const MaskDesc d = compact[__builtin_amdgcn_readfirstlane((int)ci)];
+        if (d.len == 0) continue;
+        const size_t start = d.start, end = start + d.len;
+        const size_t w0 = (start + 63) >> 6, w1 = end >> 6;
+        const bool tail = end == total && (end & 63) != 0 && w0 <= w1;  // the partial last word begins in this chunk
+        const size_t n_w = (w1 > w0 ? w1 - w0 : 0) + (tail ? 1 : 0);
+        const auto gw = as_global(d.words);
+        for (size_t t = lane; t < n_w; t += 64) {
+            const size_t w = w0 + t, row = w << 6, avail = end - row;
+            uint64_t v = ~(uint64_t)0;  // a chunk without a bitmap is all valid (consolidate.rs:91-96)
+            if (d.words != nullptr) {
+                const size_t b = d.bit_off + (row - start);
+                uint64_t lo, hi;
+                unsigned sh;
+                if (avail >= 64) {  // bits b .. b + 63 are window bits: bytes b/8 .. b/8 + 7 and, off a byte boundary, b/8 + 8
+                    typedef uint64_t u64u __attribute__((aligned(1)));
+                    typedef const u64u __attribute__((address_space(1)))* GP;
+                    const auto base = as_global((const uint8_t*)d.words + (b >> 3));
+                    sh = (unsigned)(b & 7);
+                    lo = *(GP)base;
+                    hi = sh ? (uint64_t)base[8] : 0;
+                } else {
+                    const size_t wi = b >> 6;
+                    sh = (unsigned)(b & 63);
+                    lo = gw[wi];
+                    hi = (sh && wi + 1 <= d.last_word) ? gw[wi + 1] : 0;
+                }
+                v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+            }
+            if (avail < 64) v &= (((uint64_t)1) << avail) - 1;  // bits >= total stay zero
+            __builtin_nontemporal_store(v, out_words + w);
+        }
+    }
+}
+
+// Picks the form for a compact (device-resident) table: many short chunks -> chunk-owned words + the join pass (only when a
+// chunk starts inside a word: `has_join`, decided by the host); otherwise concat_mask_kernel.
+static void launch_concat_bits(ma_ctx* ctx, const MaskDesc* compact, size_t n_chunks, size_t total, uint64_t* ow, bool has_join) {
+    const bool many_short = n_chunks >= 1024 && total / n_chunks <= ((size_t)1 << 20) && n_chunks < ((size_t)1 << 31);
+    if (!many_short || (ctx->variant & 128)) {  // variant bit 128: the searching form (A/B, tests)
+        launch_concat_mask(ctx, nullptr, n_chunks, total, ow, compact);
+        return;
+    }
+    const int grid = grid_for(ctx, (n_chunks + kWaves - 1) / kWaves, 8);
+    hipLaunchKernelGGL(concat_bits_chunk_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, compact, (int)n_chunks, total, ow);
+    if (has_join) {
+        const int gj = grid_for(ctx, (n_chunks + kBlock - 1) / kBlock, 8);
+        hipLaunchKernelGGL(concat_mask_joins_kernel, dim3(gj), dim3(kBlock), 0, ctx->stream, compact, (int)n_chunks, total, ow);
+    }
+}
+
 template <typename T>
 static void launch_concat(ma_ctx* ctx, const ChunkDesc* d, int n_chunks, size_t n_tiles, void* out) {
     int grid = grid_for(ctx, n_tiles, 6);  // store stream in the mix: more workgroups (profiles/r01_sweep_grid.json)
@@ -835,7 +896,9 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     // Compact 40-byte descriptors (a Boolean column rechunked at 8192 rows is 122 000 chunks per 10^9 rows: the call is
     // host- and table-bound, not data-bound); a chunked column's bitmaps run through a few allocations, so each operand
     // role remembers the device range its last pointer fell into (two compares instead of a classification call).
-    std::vector<MaskDesc> data_desc(n_chunks), mask_desc(has_mask ? n_chunks : 0);
+    MaskDesc* data_desc = nullptr;  // both tables are built in the context's pinned staging buffer (no second copy of 5 MB)
+    MA_TRY(table_begin(ctx, sizeof(MaskDesc) * n_chunks * (has_mask ? 2 : 1), (void**)&data_desc));
+    MaskDesc* mask_desc = has_mask ? data_desc + n_chunks : nullptr;
     DeviceRange data_role, mask_role;
     auto describe = [&](DeviceRange& role, const uint8_t* bits, size_t off, size_t len, MaskDesc& d) -> ma_status {
         if (role.holds(bits)) {
@@ -850,9 +913,11 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
         return MA_OK;
     };
     size_t row = 0;
+    bool has_join = false;  // a non-empty chunk that starts inside an output word
     for (size_t i = 0; i < n_chunks; ++i) {
         MaskDesc d{row, chunk_lens[i], nullptr, 0, 0};
         MaskDesc m = d;
+        has_join |= chunk_lens[i] != 0 && (row & 63) != 0;
         if (d.len) {
             MA_TRY(describe(data_role, chunk_bits[i], chunk_bit_offsets ? chunk_bit_offsets[i] : 0, d.len, d));
             if (has_mask && chunk_masks[i])
@@ -867,15 +932,14 @@ extern "C" ma_status ma_consolidate_boolean_column(ma_ctx* ctx, size_t n_chunks,
     MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks * 2, &tables));
     MaskDesc* dd = (MaskDesc*)tables;
     MaskDesc* md = dd + n_chunks;
-    MA_TRY(upload_table(ctx, data_desc.data(), sizeof(MaskDesc) * n_chunks, dd));
-    if (has_mask) MA_TRY(upload_table(ctx, mask_desc.data(), sizeof(MaskDesc) * n_chunks, md));
+    MA_TRY(table_commit(ctx, data_desc, sizeof(MaskDesc) * n_chunks * (has_mask ? 2 : 1), dd));
     uint64_t *ow = nullptr, *mw = nullptr;  // both outputs are validated before the first launch
     MA_TRY(scope.out_mask(out_bits, total, &ow));
     if (has_mask) MA_TRY(scope.out_mask(out_mask, total, &mw));
-    launch_concat_mask(ctx, nullptr, n_chunks, total, ow, dd);
+    launch_concat_bits(ctx, dd, n_chunks, total, ow, has_join);
     MA_HIP(hipGetLastError());
     if (has_mask) {
-        launch_concat_mask(ctx, nullptr, n_chunks, total, mw, md);
+        launch_concat_bits(ctx, md, n_chunks, total, mw, has_join);
         MA_HIP(hipGetLastError());
     }
     return end_call(ctx, scope);

@@ -205,11 +205,54 @@ def run_bool(ctx, chunks, masks=None, device=True):
         d_chunks = [(ctx.to_device(c[0], 16), c[1], c[2]) for c in chunks]
         d_masks = [(ctx.to_device(m[0], 16), m[1]) if m is not None else None for m in masks] if masks is not None else None
         out, om = ctx.alloc(nbytes(total) + 8), ctx.alloc(nbytes(total) + 8)
+        ctx.dev_memset(out, 0xA5, nbytes(total) + 8)  # a word no kernel writes would show
+        ctx.dev_memset(om, 0xA5, nbytes(total) + 8)
         has = ctx.consolidate_boolean_column(d_chunks, out, d_masks, om)
         return out.download(np.uint8, nbytes(total)), (om.download(np.uint8, nbytes(total)) if has else None)
     out, om = np.zeros(nbytes(total) + 8, dtype=np.uint8), np.zeros(nbytes(total) + 8, dtype=np.uint8)
     has = ctx.consolidate_boolean_column(chunks, out, masks, om)
     return out[:nbytes(total)], (om[:nbytes(total)] if has else None)
+
+
+@pytest.mark.parametrize("shape", ["aligned", "aligned_tail", "few_joins", "tail_in_join", "tiny_runs", "ragged"])
+@pytest.mark.parametrize("variant", [0, 128])
+def test_boolean_many_short_chunks(ctx, oracle, shape, variant):
+    """A Boolean column rechunked into thousands of short chunks: from 1024 chunks a wave writes the output words wholly
+    inside its chunk and a join pass the words a chunk starts inside (variant 128 = the searching kernel). Source bits at
+    odd bit offsets, validity on half of the chunks, poisoned outputs; the same shapes as the numeric chunk form's test."""
+    rng = np.random.default_rng(len(shape) * 3 + variant)
+    k = 3000
+    lens = [int(x) for x in rng.choice([0, 64, 128, 640, 8192], size=k, p=[0.1, 0.3, 0.3, 0.25, 0.05])]
+    if shape == "aligned_tail":
+        lens[-1] = 8192 + 37
+    elif shape == "few_joins":
+        for i in rng.choice(k, size=40, replace=False):
+            lens[int(i)] = int(rng.choice([1, 63, 65, 100, 8191]))
+    elif shape == "tail_in_join":
+        lens[-3:] = [64 + 5, 0, 11]
+    elif shape == "tiny_runs":
+        for i in range(100, 400):
+            lens[i] = int(rng.choice([0, 0, 1, 2, 5, 17, 63]))
+        lens[-1] = 3
+    elif shape == "ragged":
+        lens = [int(x) for x in rng.integers(0, 3000, size=k)]
+    chunks, masks = [], []
+    for i, n in enumerate(lens):
+        off = int(rng.integers(0, 130))
+        chunks.append((rng.integers(0, 256, size=(off + n) // 8 + 24, dtype=np.uint8), off, n))
+        if i % 2 == 0:
+            moff = int(rng.integers(0, 130))
+            masks.append((rng.integers(0, 256, size=(moff + n) // 8 + 24, dtype=np.uint8), moff))
+        else:
+            masks.append(None)
+    want, want_mask = oracle.consolidate_boolean_column(chunks, masks)
+    ctx.set_variant(variant)
+    try:
+        got, got_mask = run_bool(ctx, chunks, masks)
+    finally:
+        ctx.set_variant(0)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got_mask, want_mask)
 
 
 def _bits(oracle, bools):

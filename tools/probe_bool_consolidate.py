@@ -41,5 +41,13 @@ for k, per, off, label in ((8, BITS // 8, 3, "8 chunks at bit offset 3"), (BITS 
         assert st == 0, st
 
     ms = timed(call)
+    import time
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        call()
+    host_ms = (time.perf_counter() - t0) / 5 * 1e3  # async context: the call returns when everything is enqueued
+    ctx.synchronize()
     b = 2 * k * per / 8
-    print(json.dumps({"shape": label, "ms": round(ms, 4), "gbps": round(b / ms / 1e6, 1), "of_copy": round(b / ms / 1e6 / copy, 3)}), flush=True)
+    print(json.dumps({"shape": label, "ms": round(ms, 4), "gbps": round(b / ms / 1e6, 1), "of_copy": round(b / ms / 1e6 / copy, 3),
+                      "host_ms_per_call": round(host_ms, 4)}), flush=True)
