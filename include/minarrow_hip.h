@@ -149,7 +149,7 @@ ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
  * ---------------------------------------------------------------------------------------------- */
 
 /* hipHostMalloc-backed, 64-byte aligned, device-mapped. The pointer is valid on the host and in kernels. Blocks of
- * 1 MiB and more are recycled through a size-class cache (sizes rounded up by at most 12.5 %; pinning pages costs ~40 ms
+ * 4 KiB and more (device blocks: 1 MiB and more) are recycled through a size-class cache (sizes rounded up by at most 12.5 %; pinning pages costs ~40 ms
  * per 256 MiB, so a Vec64 allocator
  * built on raw hipHostMalloc would be 50x slower than malloc for large columns): ma_free_pinned parks them,
  * ma_alloc64_pinned reuses them. ma_pinned_pool_trim(keep) releases cached blocks down to `keep` bytes and makes that the

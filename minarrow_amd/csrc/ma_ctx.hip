@@ -31,12 +31,15 @@ struct PinnedPool {
     size_t limit_bytes = (size_t)2 << 30;
 };
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
-size_t pool_size_of(size_t bytes) {  // bytes >= kPoolMinBytes
-    size_t top = kPoolMinBytes;
+size_t pool_size_of(size_t bytes, size_t min_bytes = kPoolMinBytes) {  // bytes >= min_bytes
+    size_t top = min_bytes;
     while ((top << 1) != 0 && (top << 1) <= bytes) top <<= 1;  // largest power of two <= bytes
     const size_t step = top >> 3;
     return ((bytes + step - 1) / step) * step;
 }
+// Pinned HOST blocks are recycled from 4 KiB on: a result slab of an 8192-row record batch is ~130 KiB, and a
+// hipHostMalloc + hipHostFree pair per batch (~250 us) was most of the 366 us a batch cost the stream operator.
+constexpr size_t kPinnedPoolMinBytes = (size_t)4 << 10;
 // MINARROW_HIP_PINNED_POOL_BYTES / MINARROW_HIP_DEV_POOL_BYTES: cache limits, read once (0 = no caching).
 size_t env_bytes(const char* name, size_t fallback) {
     const char* v = getenv(name);
@@ -1054,14 +1057,9 @@ ma_status ma_alloc64_pinned(size_t bytes, void** out_ptr) {
     }
     // hipHostMalloc returns page-aligned memory, which satisfies Vec64's 64-byte contract.
     void* p = nullptr;
-    if (bytes < kPoolMinBytes) {
-        MA_HIP(hipHostMalloc(&p, bytes == 0 ? 64 : bytes, hipHostMallocPortable | hipHostMallocMapped));
-        *out_ptr = p;
-        return MA_OK;
-    }
     MA_REQUIRE(bytes < ((size_t)1 << 46), MA_ERR_INVALID_ARGUMENT, "pinned allocation of %zu bytes is too large", bytes);
     PinnedPool& pool = pinned_pool();
-    const size_t rounded = pool_size_of(bytes);
+    const size_t rounded = pool_size_of(bytes < kPinnedPoolMinBytes ? kPinnedPoolMinBytes : bytes, kPinnedPoolMinBytes);
     {
         std::lock_guard<std::mutex> lock(pool.mu);
         auto it = pool.parked.find(rounded);

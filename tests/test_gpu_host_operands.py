@@ -256,8 +256,9 @@ def test_registering_an_existing_host_buffer(ctx, oracle):
 
 
 def test_pinned_allocator_recycles_large_blocks(ctx):
-    """ma_alloc64_pinned / ma_free_pinned: blocks of 1 MiB and more come back from a size-class cache (pinning pages is
-    the expensive part of a pinned Vec64), small ones do not; ma_pinned_pool_trim empties it."""
+    """ma_alloc64_pinned / ma_free_pinned: blocks come back from a size-class cache (pinning pages is the expensive part
+    of a pinned Vec64; from 4 KiB on since round 3: the result slab of an 8192-row record batch is ~130 KiB);
+    ma_pinned_pool_trim empties it."""
     import ctypes as C
 
     lib = ctx.lib
@@ -276,9 +277,19 @@ def test_pinned_allocator_recycles_large_blocks(ctx):
     ffi.check(lib.ma_pinned_pool_trim(0))       # nothing stays cached ...
     ffi.check(lib.ma_alloc64_pinned(4 << 20, C.byref(p2)))
     ffi.check(lib.ma_free_pinned(p2.value))     # ... and with a zero limit nothing is parked again
-    ffi.check(lib.ma_alloc64_pinned(1000, C.byref(small)))
-    ffi.check(lib.ma_free_pinned(small.value))
     ffi.check(lib.ma_pinned_pool_trim(2 << 30))
+    ffi.check(lib.ma_alloc64_pinned(1000, C.byref(small)))  # the smallest class: 4 KiB
+    first_small = small.value
+    ffi.check(lib.ma_free_pinned(small.value))
+    ffi.check(lib.ma_alloc64_pinned(3000, C.byref(small)))
+    assert small.value == first_small
+    ffi.check(lib.ma_free_pinned(small.value))
+    ffi.check(lib.ma_alloc64_pinned(140_000, C.byref(small)))  # the 144-KiB class (128 KiB + 16 KiB)
+    first_small = small.value
+    ffi.check(lib.ma_free_pinned(small.value))
+    ffi.check(lib.ma_alloc64_pinned(145_000, C.byref(small)))
+    assert small.value == first_small
+    ffi.check(lib.ma_free_pinned(small.value))
 
 
 def test_device_blocks_are_recycled(ctx):
