@@ -50,29 +50,6 @@ struct GatherTile {
     size_t rows = 0;
 };
 
-// n bits of `src` starting at bit `s` (a buffer of `src_bytes` bytes; nullptr = all ones) appended to `dst` at bit `p`;
-// the words of `dst` from bit p on are zero.
-inline void append_bits(uint64_t* dst, size_t p, const uint8_t* src, size_t src_bytes, size_t s, size_t n) {
-    for (size_t i = 0; i < n; i += 64) {
-        const size_t take = n - i < 64 ? n - i : 64;
-        uint64_t w = ~(uint64_t)0;
-        if (src) {
-            const size_t b = (s + i) >> 3;
-            const unsigned sh = (unsigned)((s + i) & 7);
-            uint64_t lo = 0;
-            const size_t avail = src_bytes > b ? src_bytes - b : 0;
-            memcpy(&lo, src + b, avail < 8 ? avail : 8);
-            w = lo >> sh;
-            if (sh && avail > 8) w |= (uint64_t)src[b + 8] << (64 - sh);
-        }
-        if (take < 64) w &= (((uint64_t)1) << take) - 1;
-        const size_t q = p + i, wi = q >> 6;
-        const unsigned ps = (unsigned)(q & 63);
-        dst[wi] |= w << ps;
-        if (ps && take > 64 - ps) dst[wi + 1] |= w >> (64 - ps);
-    }
-}
-
 inline void two_sum_acc(double& hi, double& lo, double h, double l) {
     double t = hi + h;
     double bp = t - hi;

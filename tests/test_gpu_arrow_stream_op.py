@@ -93,3 +93,64 @@ def test_stream_operator_errors_go_through_the_stream_protocol(ctx):
     with pytest.raises(ffi.MinarrowHipError) as e:
         ctx.apply_arrow_stream_export(0, l.ptr, r.ptr, C.addressof(out))  # inputs already moved / released
     assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_small_batches_are_gathered_and_come_back_batch_by_batch(ctx, with_nulls):
+    """Batch pairs under 1 MiB per column are gathered into pinned tiles, a tile is one call of the batch operator, and the
+    results come back as slices (Arrow `offset`) of the tile's result — same batch boundaries, names, types and values as
+    the batch-by-batch form. 1500 ragged pairs (empty ones, sliced ones, every third column-pair without nulls) around two
+    large pairs that take the direct path; more rows than one tile holds."""
+    rng = np.random.default_rng(21)
+    sizes = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 1000, 4097, 8192], size=1500)]
+    sizes[200], sizes[900] = 400_000, 300_000  # 3.2 / 2.4 MB per 8-byte column: the direct path
+    sizes += [8192] * 150                       # > 2^20 rows in all: several tiles
+    L, R = make_batches(rng, [n + 7 for n in sizes], with_nulls), make_batches(rng, [n + 7 for n in sizes], with_nulls, names=("x", "y", "z"))
+    L = [b.slice(7, n) if k % 4 == 0 else b.slice(0, n) for k, (b, n) in enumerate(zip(L, sizes))]
+    R = [b.slice(3, n) if k % 3 == 0 else b.slice(0, n) for k, (b, n) in enumerate(zip(R, sizes))]
+    for op, fn in ((0, pc.add), (2, pc.multiply)):
+        reader = run_operator(ctx, op, L, R)
+        assert reader.schema.names == ["a", "b", "c"]
+        got = list(reader)
+        assert [g.num_rows for g in got] == sizes
+        for g, l, r in zip(got, L, R):
+            for c in range(3):
+                assert g.column(c).equals(fn(l.column(c), r.column(c)))
+        del got, reader
+
+
+def test_gathered_batches_keep_error_positions(ctx):
+    """An error inside a gathered tile is reported at ITS batch, after every batch in front of it: a dense integer division
+    by zero in pair 5 of 12 small pairs (the tile call fails, the held batches are replayed one by one); a row-count
+    mismatch in pair 3; one stream ending first after 4 pairs."""
+    rng = np.random.default_rng(22)
+    mk = lambda vals: pa.RecordBatch.from_pydict({"v": pa.array(vals, type=pa.int64())})  # noqa: E731
+    L = [mk(rng.integers(1, 100, size=500)) for _ in range(12)]
+    R = [mk(rng.integers(1, 100, size=500)) for _ in range(12)]
+    bad = rng.integers(1, 100, size=500)
+    bad[77] = 0
+    R[5] = mk(bad)
+    reader = run_operator(ctx, 3, L, R)  # Divide
+    for k in range(5):
+        b = reader.read_next_batch()
+        assert b.num_rows == 500 and b.column(0).equals(pc.divide(L[k].column(0), R[k].column(0)))
+    with pytest.raises(Exception) as e:
+        reader.read_next_batch()
+    assert "batch 5" in str(e.value)
+    del reader
+    R2 = list(R)
+    R2[5] = R[4]
+    R2[3] = mk(rng.integers(1, 100, size=499))
+    reader = run_operator(ctx, 0, L, R2)
+    for k in range(3):
+        assert reader.read_next_batch().column(0).equals(pc.add(L[k].column(0), R2[k].column(0)))
+    with pytest.raises(Exception) as e:
+        reader.read_next_batch()
+    assert "batch 3" in str(e.value)
+    del reader
+    reader = run_operator(ctx, 0, L[:6], R2[:3] + [R[4]])
+    for k in range(4):
+        assert reader.read_next_batch().num_rows == 500
+    with pytest.raises(Exception) as e:
+        reader.read_next_batch()
+    assert "SuperTable chunk count mismatch: 5 vs 4" in str(e.value)
