@@ -319,6 +319,18 @@ ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const 
                          const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
                          double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts);
 
+/* The sum (and valid count) of ONE column held as a list of chunks — a SuperArray's chunks, one column of the batches of a
+ * SuperTable (src/structs/chunked/super_array.rs, super_table.rs): what the reference's bench computes over one slice with
+ * `par_chunks(..).map(simd_sum).sum()` (benches/benchmark_parallel_simd.rs:81-98), for a column that is already chunked.
+ * Arguments as ma_sum_columns with the chunks in place of the columns; the outputs are single values. Pass 1 is
+ * ma_sum_columns' (122 000 chunks of 8192 rows per 10^9 rows: a wave per chunk on in-place descriptors); pass 2 folds the
+ * partials of ALL chunks — wrapping adds, or error-free double-double merges in a fixed order, so that the f64 total is within
+ * 1 ULP of the exactly rounded sum and reproducible for a given chunk list (a host-side addition of per-chunk rounded sums
+ * is neither). An empty list gives {0, 0}. */
+ma_status ma_sum_chunks(ma_ctx* ctx, int32_t format_code, size_t n_chunks, const void* const* chunk_data,
+                        const size_t* chunk_lens, const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
+                        double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count);
+
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
  * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =
  * stride_words x u64 (>= 5 used): [0] integer sum, [1] integer valid count, [2] f64 hi bits, [3] f64 lo bits (the

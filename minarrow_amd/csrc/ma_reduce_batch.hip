@@ -240,11 +240,95 @@ __global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __re
     }
 }
 
+// ---- the total over ALL partials (ma_sum_chunks: the chunks are one logical column) -----------------------------------
+// Level 1 (many partials): wave w folds the contiguous slice [w * per, (w + 1) * per) in index order per lane, then across
+// lanes, and writes one partial. Level 2: one workgroup folds what is left and writes the result. Slices, lanes and waves
+// are always combined in the same order: the double-double total is reproducible for a given chunk list.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void partial_fold_kernel(const Partial* __restrict__ in, size_t n, size_t per,
+                                                              Partial* __restrict__ out) {
+    typedef typename AccOf<T>::type Acc;
+    const unsigned lane = threadIdx.x & 63;
+    const size_t w = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t s0 = w * per, s1 = s0 + per < n ? s0 + per : n;
+    Acc tot;
+    tot.init();
+    uint64_t cnt = 0;
+    for (size_t s = s0 + lane; s < s1; s += 64) {
+        Acc o;
+        o.from_words(in[s].a, in[s].b);
+        tot.merge(o);
+        cnt += in[s].cnt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot.shfl_down_merge(off);
+        cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+    }
+    if (lane == 0) {
+        Partial p;
+        tot.to_partial(p);
+        p.cnt = cnt;
+        p.pad = 0;
+        out[w] = p;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __restrict__ in, size_t n, int is_signed,
+                                                            double* __restrict__ out_f64, uint64_t* __restrict__ out_i64,
+                                                            uint64_t* __restrict__ out_cnt) {
+    typedef typename AccOf<T>::type Acc;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ Partial lds[kWaves];
+    Acc tot;
+    tot.init();
+    uint64_t cnt = 0;
+    for (size_t s = tid; s < n; s += kBlock) {
+        Acc o;
+        o.from_words(in[s].a, in[s].b);
+        tot.merge(o);
+        cnt += in[s].cnt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tot.shfl_down_merge(off);
+        cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+    }
+    if (lane == 0) {
+        tot.to_partial(lds[wave]);
+        lds[wave].cnt = cnt;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    Acc s;
+    s.from_words(lds[0].a, lds[0].b);
+    uint64_t c = lds[0].cnt;
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+        Acc o;
+        o.from_words(lds[w].a, lds[w].b);
+        s.merge(o);
+        c += lds[w].cnt;
+    }
+    if constexpr (std::is_same<Acc, DDAcc>::value) {
+        s.normalise();
+        if (out_f64) *out_f64 = s.hi;
+    } else {
+        if (out_i64) *out_i64 = s.s;
+        if (out_f64) *out_f64 = is_signed ? (double)(int64_t)s.s : (double)s.s;
+    }
+    if (out_cnt) *out_cnt = c;
+}
+
 // short_table != nullptr: every column is a segment or less — a wave per column on the ShortCol table (read in place),
 // partial c = column c; otherwise a workgroup per segment on the uploaded ColDesc table.
+// total: one {sum, count} over all columns (they are the chunks of ONE logical column) instead of one per column;
+// `partials2` then has room for 4096 partials.
 template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_table, size_t n_cols, size_t n_segs,
-                           Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc) {
+                           Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc, bool total = false,
+                           Partial* partials2 = nullptr) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
     if (short_table) {
         const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
@@ -256,6 +340,21 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, (const void*)d,
                            (int)n_cols, n_segs, partials);
     }
+    if (total) {
+        const Partial* src = partials;
+        size_t n = short_table ? n_cols : n_segs;
+        if (n > 4096) {  // level 1: up to 1024 workgroups x 4 waves, each wave a contiguous slice
+            const size_t waves = 4096;
+            const size_t per = (n + waves - 1) / waves;
+            const size_t used = (n + per - 1) / per;
+            hipLaunchKernelGGL((partial_fold_kernel<T>), dim3((unsigned)((used + kWaves - 1) / kWaves)), dim3(kBlock), 0, ctx->stream,
+                               src, n, per, partials2);
+            src = partials2;
+            n = ((used + kWaves - 1) / kWaves) * kWaves;  // waves past `used` wrote empty partials
+        }
+        hipLaunchKernelGGL((total_fold_kernel<T>), dim3(1), dim3(kBlock), 0, ctx->stream, src, n, is_signed ? 1 : 0, of, oi, oc);
+        return;
+    }
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
     hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
                        (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc, short_table ? 1 : 0);
@@ -265,10 +364,9 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
 
 using namespace ma;
 
-extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
-                                    const size_t* col_lens, const uint8_t* const* col_masks,
-                                    const size_t* col_mask_offsets, double* out_sums_f64, int64_t* out_sums_i64,
-                                    uint64_t* out_valid_counts) {
+static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
+                                  const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
+                                  double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts, bool total) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     size_t elem = 0;
     switch (format_code) {
@@ -280,9 +378,9 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
             set_error("unsupported element format '%c' (numeric primitives only)", (char)format_code);
             return MA_ERR_UNSUPPORTED;
     }
-    if (n_cols == 0) return MA_OK;
+    if (n_cols == 0 && !total) return MA_OK;
     MA_REQUIRE(n_cols < ((size_t)1 << 30), MA_ERR_INVALID_ARGUMENT, "too many columns");
-    MA_REQUIRE(col_data != nullptr && col_lens != nullptr, MA_ERR_INVALID_ARGUMENT, "NULL column table");
+    MA_REQUIRE(n_cols == 0 || (col_data != nullptr && col_lens != nullptr), MA_ERR_INVALID_ARGUMENT, "NULL column table");
     for (size_t i = 0; i < n_cols; ++i) {
         MA_REQUIRE(col_lens[i] == 0 || col_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu data is NULL", i);
         MA_REQUIRE(((uintptr_t)col_data[i] % elem) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu is misaligned", i);
@@ -291,6 +389,20 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
+    if (n_cols == 0) {  // ma_sum_chunks of an empty chunk list: {0, 0}
+        void *zf = nullptr, *zi = nullptr, *zc = nullptr;
+        MA_TRY(scope.out(out_sums_f64, 8, &zf));
+        MA_TRY(scope.out(out_sums_i64, 8, &zi));
+        MA_TRY(scope.out(out_valid_counts, 8, &zc));
+        if (format_code == 'f' || format_code == 'g')
+            hipLaunchKernelGGL((total_fold_kernel<double>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)nullptr, (size_t)0, 1,
+                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc);
+        else
+            hipLaunchKernelGGL((total_fold_kernel<int64_t>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)nullptr, (size_t)0, 1,
+                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc);
+        MA_HIP(hipGetLastError());
+        return end_call(ctx, scope);
+    }
     // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
     bool all_short = n_cols >= 256;  // below that the table copy is a few microseconds and the segment form is as good
     for (size_t i = 0; i < n_cols && all_short; ++i) all_short = col_lens[i] <= seg_rows(elem);
@@ -335,15 +447,16 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
         }
     }
     void *of = nullptr, *oi = nullptr, *oc = nullptr;
-    MA_TRY(scope.out(out_sums_f64, n_cols * 8, &of));
-    MA_TRY(scope.out(out_sums_i64, n_cols * 8, &oi));
-    MA_TRY(scope.out(out_valid_counts, n_cols * 8, &oc));
+    const size_t n_out = total ? 1 : n_cols;
+    MA_TRY(scope.out(out_sums_f64, n_out * 8, &of));
+    MA_TRY(scope.out(out_sums_i64, n_out * 8, &oi));
+    MA_TRY(scope.out(out_valid_counts, n_out * 8, &oc));
 
     // descriptors (segment form) + partials in one scratch allocation
     const size_t n_partials = all_short ? n_cols : (n_segs ? n_segs : 1);
     const size_t desc_bytes = all_short ? 0 : ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
     void* scratch = nullptr;
-    MA_TRY(ctx_scratch(ctx, desc_bytes + sizeof(Partial) * n_partials, &scratch));
+    MA_TRY(ctx_scratch(ctx, desc_bytes + sizeof(Partial) * (n_partials + (total ? 4096 : 0)), &scratch));
     const ColDesc* d = nullptr;
     const ShortCol* sd = nullptr;
     int slot = -1;
@@ -356,21 +469,40 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
         d = (const ColDesc*)scratch;
     }
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
+    Partial* partials2 = partials + n_partials;  // level-1 results of the total fold
     switch (format_code) {
-        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
-        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc); break;
+        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
     }
     MA_HIP(hipGetLastError());
     if (slot >= 0) MA_TRY(table_release(ctx, slot));
     return end_call(ctx, scope);
+}
+
+extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
+                                    const size_t* col_lens, const uint8_t* const* col_masks,
+                                    const size_t* col_mask_offsets, double* out_sums_f64, int64_t* out_sums_i64,
+                                    uint64_t* out_valid_counts) {
+    return sum_columns_impl(ctx, format_code, n_cols, col_data, col_lens, col_masks, col_mask_offsets, out_sums_f64, out_sums_i64,
+                            out_valid_counts, false);
+}
+
+// The sum of ONE column held as a list of chunks (a SuperArray's chunks, one column of a SuperTable's batches): the same two
+// passes, then the partials of ALL chunks folded into one {sum, count} — the double-double fold keeps the f64 total within
+// 1 ULP of the exactly rounded sum, which a host-side addition of per-chunk rounded sums would not.
+extern "C" ma_status ma_sum_chunks(ma_ctx* ctx, int32_t format_code, size_t n_chunks, const void* const* chunk_data,
+                                   const size_t* chunk_lens, const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
+                                   double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count) {
+    return sum_columns_impl(ctx, format_code, n_chunks, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets, out_sum_f64,
+                            out_sum_i64, out_valid_count, true);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -359,6 +359,20 @@ class Context:
                                           cast(off_arr), addr_of(f), addr_of(i), addr_of(c)))
         return f, (i if fmt in "cCsSiIlL" else None), c
 
+    def sum_chunks(self, fmt: str, chunks, lens, masks=None, mask_offsets=None):
+        """(sum as float, sum as wrapped int64 or None for float formats, valid count) of ONE column held as a list of
+        chunks (ma_sum_chunks): f64 within 1 ULP of the exactly rounded sum."""
+        k = len(chunks)
+        data_arr = (C.c_void_p * max(k, 1))(*[addr_of(c) or None for c in chunks])
+        len_arr = (C.c_size_t * max(k, 1))(*[int(n) for n in lens])
+        mask_arr = (C.c_void_p * max(k, 1))(*[addr_of(m) or None for m in masks]) if masks is not None else None
+        off_arr = (C.c_size_t * max(k, 1))(*[int(o) for o in mask_offsets]) if mask_offsets is not None else None
+        f, i, c = C.c_double(), C.c_int64(), C.c_uint64()
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        ffi.check(self.lib.ma_sum_chunks(self.handle, ord(fmt), k, cast(data_arr), cast(len_arr), cast(mask_arr), cast(off_arr),
+                                         C.addressof(f), C.addressof(i), C.addressof(c)))
+        return f.value, (i.value if fmt in "cCsSiIlL" else None), int(c.value)
+
     def fold_sum_records(self, records, n_records: int, stride_words: int, out4) -> None:
         """Device-side, rank-ordered fold of gathered reduction records (ma_fold_sum_records)."""
         ffi.check(self.lib.ma_fold_sum_records(self.handle, addr_of(records), int(n_records), int(stride_words), addr_of(out4)))

@@ -152,3 +152,48 @@ def test_errors(ctx):
     assert e.value.status == ffi.MA_ERR_UNSUPPORTED
     f, i64, cnt = ctx.sum_columns("l", [], [])
     assert len(f) == 0
+
+
+@pytest.mark.parametrize("fmt", ["l", "L", "g", "f", "i", "C", "s"])
+@pytest.mark.parametrize("shape", ["few_long", "many_short", "mixed", "empty"])
+def test_sum_chunks_is_the_sum_of_the_consolidated_column(ctx, fmt, shape):
+    """ma_sum_chunks: ONE {sum, count} over a column held as a chunk list == the single-column sum of the concatenated
+    chunks — bit-exact for integers, within 1 ULP of the exactly rounded sum for floats whatever the number of chunks
+    (7 000 chunks: the two-level fold of the partials), validity at odd bit offsets on two thirds of the chunks."""
+    rng = np.random.default_rng(ord(fmt) * 7 + len(shape))
+    dt = NP[fmt]
+    if shape == "few_long":
+        lens = [200_003, 65_536, 1, 0, 70_001]
+    elif shape == "many_short":
+        lens = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 1000, 8192, 8191], size=7000)]
+    elif shape == "mixed":
+        lens = [int(x) for x in rng.choice([5, 8192, 300_000], size=300, p=[0.3, 0.6, 0.1])]
+    else:
+        lens = []
+    cols = make_columns(rng, fmt, lens)
+    masks, offs, d_cols, d_masks = [], [], [], []
+    for i, n in enumerate(lens):
+        d_cols.append(ctx.to_device(cols[i], 64))
+        if i % 3 == 0 or n == 0:
+            masks.append(None); offs.append(0); d_masks.append(None)
+        else:
+            off = [0, 3, 64, 77][i % 4]
+            m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+            masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+    f, i64, cnt = ctx.sum_chunks(fmt, d_cols, lens, d_masks if lens else None, offs if lens else None)
+    sel = [c[np.unpackbits(m, bitorder="little")[o:o + n].astype(bool)] if m is not None else c
+           for c, m, o, n in zip(cols, masks, offs, lens)]
+    allv = np.concatenate(sel) if sel else np.zeros(0, dtype=dt)
+    assert cnt == allv.size
+    if fmt in "fg":
+        exact = math.fsum(allv.astype(np.float64).tolist())
+        assert abs(f - exact) <= math.ulp(exact) if allv.size else f == 0.0
+        assert i64 is None
+    else:
+        want = int(allv.astype(object).sum()) if allv.size else 0
+        assert (int(i64) - want) % (1 << 64) == 0
+    f2, i2, c2 = ctx.sum_chunks(fmt, d_cols, lens)  # dense
+    assert c2 == sum(lens)
+    if fmt in "fg" and lens:
+        exact = math.fsum(np.concatenate(cols).astype(np.float64).tolist())
+        assert abs(f2 - exact) <= math.ulp(exact)
