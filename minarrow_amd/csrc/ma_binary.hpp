@@ -308,9 +308,18 @@ struct BinArgs {
 // ------------------------------------------------------------------------------------------------
 // vec kernel
 // ------------------------------------------------------------------------------------------------
+// Element k of a loaded 16-byte vector. 1-byte elements are taken out of the dwords by hand: with a <16 x i8> value between
+// the load and its use the optimiser dropped the loads' non-temporal hint (every i8 / u8 kernel read with plain loads).
+template <typename T, typename VL>
+__device__ __forceinline__ T loaded_elem(const VL& v, int k) {
+    if constexpr (sizeof(T) == 1) return (T)(uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+    else return (T)v[k];
+}
+
 template <typename T, int OP, int KIND, bool MASKED, int UNROLL, bool NTS = true>
 __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
     typedef typename Vec16<T>::type V;
+    typedef typename std::conditional<sizeof(T) == 1, MaU4, V>::type VL;  // what a load yields
     constexpr int R = 16 / (int)sizeof(T);
     constexpr int WPT = R * UNROLL;
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
@@ -324,16 +333,16 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
 
     for (size_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
         const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
-        V va[UNROLL], vb[UNROLL];
+        VL va[UNROLL], vb[UNROLL];
         if constexpr (KIND != kSA) {
-            const V* __restrict__ p = (const V*)(a.lhs + row0) + lane;
+            const VL* __restrict__ p = (const VL*)(a.lhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) va[u] = load16u<V, true>(p + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) va[u] = load16u<VL, true>(p + (size_t)u * 64);
         }
         if constexpr (KIND != kAS) {
-            const V* __restrict__ q = (const V*)(a.rhs + row0) + lane;
+            const VL* __restrict__ q = (const VL*)(a.rhs + row0) + lane;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<V, true>(q + (size_t)u * 64);
+            for (int u = 0; u < UNROLL; ++u) vb[u] = load16u<VL, true>(q + (size_t)u * 64);
         }
         RunWords<MASKED ? WPT : 1> aw;
         if constexpr (MASKED) {
@@ -368,8 +377,8 @@ __global__ __launch_bounds__(kBlock) void binary_vec_kernel(BinArgs<T> a) {
             } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                T x = KIND == kSA ? a.scalar : (T)va[u][k];
-                T y = KIND == kAS ? a.scalar : (T)vb[u][k];
+                T x = KIND == kSA ? a.scalar : loaded_elem<T>(va[u], k);
+                T y = KIND == kAS ? a.scalar : loaded_elem<T>(vb[u], k);
                 bool dzk = false;
                 T v = Elem<T>::template apply<OP>(x, y, dzk);
                 dz |= dzk;

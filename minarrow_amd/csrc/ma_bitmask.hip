@@ -302,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so)
 // four / two at a time inside their 32-bit words: y = (word & mask) ^ target has a zero byte exactly where the row
 // matches, ~(((y & 0x7F..) + 0x7F..) | y) & 0x80.. marks the zero bytes (exact per byte: the add cannot carry out of a
 // byte), and one multiply gathers the four marks into a nibble — 10 operations per 4 rows instead of 14.
-template <typename T>
-__device__ __forceinline__ unsigned eq_bits(const typename Vec16<T>::type& x, T field_mask, T target) {
+template <typename T, typename V16>
+__device__ __forceinline__ unsigned eq_bits(const V16& x, T field_mask, T target) {
     constexpr int R = 16 / (int)sizeof(T);
     unsigned bits = 0;
     if constexpr (sizeof(T) == 1) {
@@ -351,6 +351,9 @@ template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict__ data, size_t n_tiles, T field_mask,
                                                              T target, uint64_t* __restrict__ out) {
     using V = typename Vec16<T>::type;
+    // 1- and 2-byte elements stay four dwords from the load to the packed compare (a vector of 1-byte elements loses the
+    // loads' non-temporal hint on its way through the optimiser: ma_device.hpp)
+    typedef typename std::conditional<(sizeof(T) <= 2), MaU4, V>::type VL;
     typedef unsigned long long u2a8 __attribute__((ext_vector_type(2), aligned(8)));
     typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
     constexpr int R = 16 / (int)sizeof(T);
@@ -374,9 +377,9 @@ __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict
     };
     for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const size_t step0 = (t * kWaves + wave) * UNROLL;  // index of this wave's first 1-KiB step
-        V x[UNROLL];
+        VL x[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) x[u] = load16<V, true>(vp + (step0 + u) * 64 + lane);
+        for (int u = 0; u < UNROLL; ++u) x[u] = load16<VL, true>((const VL*)vp + (step0 + u) * 64 + lane);
         if (pending) flush(par ^ 1, pending_step0);
         uint8_t* mine = staged[par][wave];
 #pragma unroll

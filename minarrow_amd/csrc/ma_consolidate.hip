@@ -46,7 +46,7 @@ __device__ __forceinline__ int find_chunk_by_tile(const ChunkDesc* __restrict__ 
 template <typename T, int UNROLL>
 __device__ __forceinline__ void concat_tile(const T* __restrict__ src, T* __restrict__ dst, unsigned head, size_t len,
                                             size_t lt, unsigned lane, unsigned wave) {
-    typedef typename Vec16<T>::type V;
+    typedef MaU4 V;  // a copy moves dwords whatever the element type (and 1-byte vectors lose the loads' nt hint: ma_device.hpp)
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;

@@ -78,12 +78,30 @@ __device__ __forceinline__ T __attribute__((address_space(1)))* as_global(T* p) 
     return (T __attribute__((address_space(1)))*)p;
 }
 
+// The 16 bytes move as four dwords whatever V's element type: a non-temporal load or store of a vector of 1-byte elements
+// loses its `nt` bit when the compiler legalises <16 x i8> (the 1-byte sums read at 6.2 TB/s with plain loads against 6.9
+// for the 2-byte types, whose vectors keep it).
+typedef unsigned int MaU4 __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned int MaU2 __attribute__((ext_vector_type(2), may_alias));
+template <size_t BYTES>
+struct MaDwords;  // the dword vector a load / store of BYTES bytes moves as (16: global_*_dwordx4, 8: dwordx2)
+template <>
+struct MaDwords<16> {
+    typedef MaU4 type;
+};
+template <>
+struct MaDwords<8> {
+    typedef MaU2 type;
+};
+
 template <typename V, bool NT>
 __device__ __forceinline__ V load16(const V* p) {
+    typedef typename MaDwords<sizeof(V)>::type D;
+    typedef const D __attribute__((address_space(1)))* GP;
     if constexpr (NT) {
-        return __builtin_nontemporal_load(as_global(p));
+        return __builtin_bit_cast(V, __builtin_nontemporal_load((GP)p));
     } else {
-        return *as_global(p);
+        return __builtin_bit_cast(V, *(GP)p);
     }
 }
 
@@ -92,21 +110,23 @@ __device__ __forceinline__ V load16(const V* p) {
 // global_load_dwordx4 either way; a misaligned wave access touches one extra cache line per KiB.
 template <typename V, bool NT>
 __device__ __forceinline__ V load16u(const V* p) {
-    typedef V VU __attribute__((aligned(1)));
+    typedef typename MaDwords<sizeof(V)>::type VU __attribute__((aligned(1)));
     typedef const VU __attribute__((address_space(1)))* GP;  // spelled out: a template would drop the typedef's alignment
     if constexpr (NT) {
-        return __builtin_nontemporal_load((GP)p);
+        return __builtin_bit_cast(V, __builtin_nontemporal_load((GP)p));
     } else {
-        return *(GP)p;
+        return __builtin_bit_cast(V, *(GP)p);
     }
 }
 
 template <typename V, bool NT>
 __device__ __forceinline__ void store16(V* p, V v) {
+    typedef typename MaDwords<sizeof(V)>::type D;
+    typedef D __attribute__((address_space(1)))* GP;
     if constexpr (NT) {
-        __builtin_nontemporal_store(v, as_global(p));
+        __builtin_nontemporal_store(__builtin_bit_cast(D, v), (GP)p);
     } else {
-        *as_global(p) = v;
+        *(GP)p = __builtin_bit_cast(D, v);
     }
 }
 
@@ -239,8 +259,9 @@ __device__ __forceinline__ unsigned row_bit(const uint64_t* words, size_t bit) {
 // (< 2^20) goes to the 64-bit accumulator. Signed types are biased into unsigned ones (x ^ 0x80.. = x + 128 | 32768 as an
 // unsigned value) and the bias of the VALID elements is taken off again: exact, wrapping like every integer sum here.
 // bits: validity of the load's R rows, bit r = row r (all ones for a dense scan).
-template <typename T>
-__device__ __forceinline__ int64_t narrow_vec_sum(const typename Vec16<T>::type& v, unsigned bits) {
+template <typename T, typename V16>
+__device__ __forceinline__ int64_t narrow_vec_sum(const V16& v, unsigned bits) {
+    static_assert(sizeof(V16) == 16, "one 16-byte load");
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const u4 d = __builtin_bit_cast(u4, v);
     constexpr bool kSigned = std::is_signed<T>::value;
