@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
 #pragma unroll
                 for (int u = 0; u < kRun; ++u) {
                     const uint8_t* base = (const uint8_t*)d.words + ((b0 + ((size_t)(u * 64 + lane) << 7)) >> 3);
-                    pr[u] = *(const u2u*)base;
+                    pr[u] = __builtin_nontemporal_load((const u2u __attribute__((address_space(1)))*)base);  // a stream: read once
                     if (u == kRun - 1 && sub && lane == 63) last_byte = base[16];
                 }
                 // the byte that holds a pair's last `sub` bits is the first byte of the NEXT pair's load: one lane up, or
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void concat_mask_kernel(const ChunkDesc* __
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kRun; ++u) *(u2*)(out_words + 2 * (p0 + u * 64 + lane)) = v[u];
+            for (int u = 0; u < kRun; ++u) __builtin_nontemporal_store(v[u], (u2 __attribute__((address_space(1)))*)(out_words + 2 * (p0 + u * 64 + lane)));
         } else {
             for (int u = 0; u < kRun; ++u) {
                 const size_t p = p0 + u * 64 + lane;
