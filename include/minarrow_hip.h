@@ -900,6 +900,17 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
                                    const size_t* chunk_mask_offsets);
 ma_status ma_group_exchange(ma_group* group);
 ma_status ma_group_synchronize(ma_group* group);
+/* The sum of ONE column held as many chunks spread over the group's GPUs — a SuperArray, or one column of the batches of a
+ * SuperTable at the reference's own batch sizes (BASELINE config 5 with 8192-row batches: 122 000 chunks per 10^9 rows).
+ * Chunk i belongs to member i % size and must be resident there; every member sums ITS chunks with one ma_sum_chunks
+ * pass into its record of `column` (integer formats: the integer slots; 'f' / 'g': a (hi, lo) pair in the float slots),
+ * all members concurrently. Enqueue-only like ma_group_enqueue_sum_*: ma_group_exchange, ma_group_synchronize, then
+ * ma_group_result(column) holds the total — wrapping, or within 1 ULP of the exactly rounded sum. format_code as
+ * ma_sum_columns. */
+ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t format_code, size_t n_chunks,
+                                      const void* const* chunk_data, const size_t* chunk_lens,
+                                      const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets);
+
 /* route_super_array_broadcast (src/kernels/broadcast/super_array.rs:180-251; its chunk loop carries "// TODO:
  * Parallelise", :193) over the GPUs of a group: chunk pair i is computed by member i % ma_group_size(group), on whose
  * device its buffers must be resident (or in host memory); the pairs of one member run as one launch, the members

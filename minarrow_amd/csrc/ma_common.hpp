@@ -231,6 +231,11 @@ inline int grid_for(const ma_ctx* ctx, size_t work_items, int blocks_per_cu = 0)
     return (int)(work_items < cap ? work_items : cap);
 }
 
+// ma_sum_chunks with the float total as a (hi, lo) pair (ma_reduce_batch.hip); any output may be NULL.
+ma_status sum_chunks_dd(ma_ctx* ctx, int32_t format_code, size_t n_chunks, const void* const* chunk_data, const size_t* chunk_lens,
+                        const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_hi, double* out_lo,
+                        int64_t* out_sum_i64, uint64_t* out_valid_count);
+
 // All chunk pairs of a SuperArray (op) SuperArray in one launch (ma_superarray.hip). smode 1 / 2: the left / right operand
 // is the scalar whose bits are the low bytes of `sbits` (that side's tables may be NULL).
 ma_status route_batched(ma_ctx* ctx, int32_t format_code, int32_t op, size_t n_chunks, const void* const* lhs_data,

@@ -693,6 +693,49 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
     });
 }
 
+// The sum of ONE column held as MANY chunks spread over the group — a SuperArray, or one column of a SuperTable's batches
+// (BASELINE config 5 at the reference's own batch sizes: 122 000 batches of 8192 rows per 10^9 rows, not one per GPU).
+// Chunk i belongs to member i % G (like the fan-out below); every member sums ITS chunks in one ma_sum_chunks pass
+// (a wave per chunk, in-place descriptors) into its record of `column` — integer formats into the integer slots, float
+// formats as a (hi, lo) pair into the float slots —, concurrently on the members' issue threads. ma_group_exchange and
+// ma_group_result then give the job's total as for one chunk per member: wrapping, or within 1 ULP.
+ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t format_code, size_t n_chunks,
+                                      const void* const* chunk_data, const size_t* chunk_lens,
+                                      const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
+    MA_REQUIRE(n_chunks == 0 || (chunk_data && chunk_lens), MA_ERR_INVALID_ARGUMENT, "NULL chunk table");
+    MA_REQUIRE(format_code > 0 && strchr("cCsSiIlLfg", (char)format_code) != nullptr, MA_ERR_UNSUPPORTED,
+               "unsupported element format '%c' (numeric primitives only)", (char)format_code);
+    const bool is_float = format_code == 'f' || format_code == 'g';
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    const size_t G = group->ctxs.size();
+    DeviceLookup lookup;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        if (chunk_lens[i] == 0) continue;
+        MA_TRY(require_resident(group, lookup, i % G, chunk_data[i], "data", i));
+        if (chunk_masks) MA_TRY(require_resident(group, lookup, i % G, chunk_masks[i], "validity bitmap", i));
+    }
+    return run_on_members(group, [&](size_t m) -> ma_status {
+        std::vector<const void*> d;
+        std::vector<size_t> n, o;
+        std::vector<const uint8_t*> k;
+        for (size_t i = m; i < n_chunks; i += G) {
+            d.push_back(chunk_data[i]);
+            n.push_back(chunk_lens[i]);
+            k.push_back(chunk_masks ? chunk_masks[i] : nullptr);
+            o.push_back(chunk_mask_offsets ? chunk_mask_offsets[i] : 0);
+        }
+        uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[m] : group->local[m];
+        uint64_t* rec = set + (size_t)column * kRecordWords;
+        ma_ctx* c = group->ctxs[m];
+        return is_float ? sum_chunks_dd(c, format_code, d.size(), d.data(), n.data(), chunk_masks ? k.data() : nullptr, o.data(),
+                                        (double*)&rec[2], (double*)&rec[3], nullptr, &rec[4])
+                        : sum_chunks_dd(c, format_code, d.size(), d.data(), n.data(), chunk_masks ? k.data() : nullptr, o.data(),
+                                        nullptr, nullptr, (int64_t*)&rec[0], &rec[1]);
+    });
+}
+
 // route_super_array_broadcast over the GPUs of a group — src/kernels/broadcast/super_array.rs:180-251, whose chunk loop
 // is sequential ("// TODO: Parallelise", :193). Chunk pair i belongs to member i % G: the pairs of one member run as ONE
 // launch on its device (ma_route_super_array_broadcast), all members concurrently; no bytes cross between GPUs and the

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void partial_fold_kernel(const Partial* __r
 template <typename T>
 __global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __restrict__ in, size_t n, int is_signed,
                                                             double* __restrict__ out_f64, uint64_t* __restrict__ out_i64,
-                                                            uint64_t* __restrict__ out_cnt) {
+                                                            uint64_t* __restrict__ out_cnt, double* __restrict__ out_lo) {
     typedef typename AccOf<T>::type Acc;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ Partial lds[kWaves];
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __res
     if constexpr (std::is_same<Acc, DDAcc>::value) {
         s.normalise();
         if (out_f64) *out_f64 = s.hi;
+        if (out_lo) *out_lo = s.lo;  // the pair, for a further error-free fold (a group's exchange)
     } else {
         if (out_i64) *out_i64 = s.s;
         if (out_f64) *out_f64 = is_signed ? (double)(int64_t)s.s : (double)s.s;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __res
 template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_table, size_t n_cols, size_t n_segs,
                            Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc, bool total = false,
-                           Partial* partials2 = nullptr) {
+                           Partial* partials2 = nullptr, double* olo = nullptr) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
     if (short_table) {
         const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
@@ -354,7 +355,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
             src = partials2;
             n = ((used + kWaves - 1) / kWaves) * kWaves;  // waves past `used` wrote empty partials
         }
-        hipLaunchKernelGGL((total_fold_kernel<T>), dim3(1), dim3(kBlock), 0, ctx->stream, src, n, is_signed ? 1 : 0, of, oi, oc);
+        hipLaunchKernelGGL((total_fold_kernel<T>), dim3(1), dim3(kBlock), 0, ctx->stream, src, n, is_signed ? 1 : 0, of, oi, oc, olo);
         return;
     }
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
@@ -368,7 +369,8 @@ using namespace ma;
 
 static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
                                   const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
-                                  double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts, bool total) {
+                                  double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts, bool total,
+                                  double* out_lo = nullptr) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     size_t elem = 0;
     switch (format_code) {
@@ -392,16 +394,17 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     MA_HIP(hipSetDevice(ctx->device));
     CallScope scope(ctx);
     if (n_cols == 0) {  // ma_sum_chunks of an empty chunk list: {0, 0}
-        void *zf = nullptr, *zi = nullptr, *zc = nullptr;
+        void *zf = nullptr, *zi = nullptr, *zc = nullptr, *zl = nullptr;
         MA_TRY(scope.out(out_sums_f64, 8, &zf));
         MA_TRY(scope.out(out_sums_i64, 8, &zi));
         MA_TRY(scope.out(out_valid_counts, 8, &zc));
+        MA_TRY(scope.out(out_lo, 8, &zl));
         if (format_code == 'f' || format_code == 'g')
             hipLaunchKernelGGL((total_fold_kernel<double>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)nullptr, (size_t)0, 1,
-                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc);
+                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc, (double*)zl);
         else
             hipLaunchKernelGGL((total_fold_kernel<int64_t>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)nullptr, (size_t)0, 1,
-                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc);
+                               (double*)zf, (uint64_t*)zi, (uint64_t*)zc, (double*)zl);
         MA_HIP(hipGetLastError());
         return end_call(ctx, scope);
     }
@@ -453,6 +456,8 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     MA_TRY(scope.out(out_sums_f64, n_out * 8, &of));
     MA_TRY(scope.out(out_sums_i64, n_out * 8, &oi));
     MA_TRY(scope.out(out_valid_counts, n_out * 8, &oc));
+    void* olo = nullptr;
+    if (total) MA_TRY(scope.out(out_lo, 8, &olo));
 
     // descriptors (segment form) + partials in one scratch allocation
     const size_t n_partials = all_short ? n_cols : (n_segs ? n_segs : 1);
@@ -473,16 +478,16 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     Partial* partials2 = partials + n_partials;  // level-1 results of the total fold
     switch (format_code) {
-        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
-        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2); break;
+        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
     }
     MA_HIP(hipGetLastError());
     if (slot >= 0) MA_TRY(table_release(ctx, slot));
@@ -496,6 +501,16 @@ extern "C" ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_c
     return sum_columns_impl(ctx, format_code, n_cols, col_data, col_lens, col_masks, col_mask_offsets, out_sums_f64, out_sums_i64,
                             out_valid_counts, false);
 }
+
+// ma_sum_chunks with the float total as a (hi, lo) pair: what a group member contributes to the exchange (ma_group.hip).
+namespace ma {
+ma_status sum_chunks_dd(ma_ctx* ctx, int32_t format_code, size_t n_chunks, const void* const* chunk_data, const size_t* chunk_lens,
+                        const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, double* out_hi, double* out_lo,
+                        int64_t* out_sum_i64, uint64_t* out_valid_count) {
+    return sum_columns_impl(ctx, format_code, n_chunks, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets, out_hi, out_sum_i64,
+                            out_valid_count, true, out_lo);
+}
+}  // namespace ma
 
 // The sum of ONE column held as a list of chunks (a SuperArray's chunks, one column of a SuperTable's batches): the same two
 // passes, then the partials of ALL chunks folded into one {sum, count} — the double-double fold keeps the f64 total within

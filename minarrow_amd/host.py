@@ -680,6 +680,18 @@ class Group:
         d, l, m, o, keep = self._tables(chunks, lens, masks, mask_offsets)
         ffi.check(getattr(self.lib, f"ma_group_enqueue_sum_{tag}")(self.handle, int(column), d, l, m, o))
 
+    def enqueue_sum_chunks(self, fmt: str, column: int, chunks, lens, masks=None, mask_offsets=None) -> None:
+        """ONE column held as many chunks, chunk i on member i % size (ma_group_enqueue_sum_chunks). Enqueues only:
+        exchange(), synchronize(), then result(column)."""
+        k = len(chunks)
+        data_arr = (C.c_void_p * max(k, 1))(*[addr_of(c) or None for c in chunks])
+        len_arr = (C.c_size_t * max(k, 1))(*[int(n) for n in lens])
+        mask_arr = (C.c_void_p * max(k, 1))(*[addr_of(m) or None for m in masks]) if masks is not None else None
+        off_arr = (C.c_size_t * max(k, 1))(*[int(o) for o in mask_offsets]) if mask_offsets is not None else None
+        cast = lambda a: C.cast(a, C.c_void_p) if a is not None else None
+        ffi.check(self.lib.ma_group_enqueue_sum_chunks(self.handle, int(column), ord(fmt), k, cast(data_arr), cast(len_arr),
+                                                       cast(mask_arr), cast(off_arr)))
+
     def route_super_array_broadcast(self, fmt: str, op: int, lhs_chunks, rhs_chunks, lens_l, lens_r, out_chunks,
                                     lhs_masks=None, rhs_masks=None, out_masks=None, member_overrides=None):
         """SuperArray (op) SuperArray over the group's GPUs (ma_group_route_super_array_broadcast): chunk pair i runs on

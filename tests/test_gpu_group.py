@@ -508,3 +508,53 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
     assert not errors, errors[:3]
     assert sum(done) > 500, done
     print(f"{sum(done)} group calls from two threads checked, 0 errors")
+
+
+@pytest.mark.parametrize("members,exchange", [(1, "rccl"), (1, "rccl-overlap"), (4, "host"), (8, "host")])
+@pytest.mark.parametrize("issue", ["threads", "caller"])
+def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
+    """ma_group_enqueue_sum_chunks: ONE column held as 3000 chunks (ragged, some empty, validity at odd bit offsets on two
+    thirds), chunk i on member i % size; every member sums its chunks in one pass, one exchange: the total equals the sum
+    over the consolidated column — bit-exact for i64 / i32, within 1 ULP for f64 / f32 — and every member holds the same
+    finals. On a one-GPU box the members share device 0 (host exchange) or the group has one member (RCCL)."""
+    from minarrow_amd.host import Group
+
+    rng = np.random.default_rng(members * 5 + len(exchange))
+    lens = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 1000, 8192, 8191], size=3000)]
+    with Group([0] * members, exchange=exchange, issue=issue) as g:
+        for fmt, dt, col in (("l", np.int64, 0), ("g", np.float64, 0), ("i", np.int32, 3), ("f", np.float32, 3)):
+            if np.dtype(dt).kind == "f":
+                cols = [(rng.standard_normal(n) * 1e6).astype(dt) for n in lens]
+            else:
+                info = np.iinfo(dt)
+                cols = [rng.integers(info.min // 2, info.max // 2, size=n, dtype=dt) for n in lens]
+            masks, offs, d_cols, d_masks = [], [], [], []
+            for i, n in enumerate(lens):
+                d_cols.append(ctx.to_device(cols[i], 64))
+                if i % 3 == 0 or n == 0:
+                    masks.append(None); offs.append(0); d_masks.append(None)
+                else:
+                    off = [0, 3, 64, 77][i % 4]
+                    m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+                    masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+            for masked in (False, True):
+                g.enqueue_sum_chunks(fmt, col, d_cols, lens, d_masks if masked else None, offs if masked else None)
+                g.exchange()
+                g.synchronize()
+                sel = [c[np.unpackbits(m, bitorder="little")[o:o + n].astype(bool)] if (masked and m is not None) else c
+                       for c, m, o, n in zip(cols, masks, offs, lens)]
+                allv = np.concatenate(sel)
+                for m_ in range(members):
+                    isum, icnt, fsum, fcnt = g.result(col, m_)
+                    if np.dtype(dt).kind == "f":
+                        exact = math.fsum(allv.astype(np.float64).tolist())
+                        assert fcnt == allv.size and abs(fsum - exact) <= math.ulp(exact)
+                    else:
+                        assert icnt == allv.size and (isum - int(allv.astype(object).sum())) % (1 << 64) == 0
+            for b in d_cols + [m for m in d_masks if m is not None]:
+                b.free()
+        # an empty chunk list is a zero record on every member
+        g.enqueue_sum_chunks("l", 7, [], [])
+        g.exchange()
+        g.synchronize()
+        assert g.result(7, 0)[:2] == (0, 0)
