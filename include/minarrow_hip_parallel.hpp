@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -134,6 +135,24 @@ class Group {
         check(ma_group_enqueue_sum_f64(g_, column, floats.chunks.data(), floats.lens.data(),
                                        floats.has_mask() ? floats.masks.data() : nullptr,
                                        floats.has_mask() ? floats.mask_offsets.data() : nullptr));
+        check(ma_group_exchange(g_));
+    }
+    // ONE column held as many chunks spread over the group — a SuperArray, or one column of a SuperTable's batches (config 5
+    // at the reference's batch sizes): chunk i lives on member i % size(). Enqueue-only (ma_group_enqueue_sum_chunks + the
+    // exchange): wait(), then sums(column). T: int64_t ('l'), int32_t ('i'), double ('g'), float ('f').
+    template <typename T>
+    void enqueue_sum_chunks(int32_t column, const std::vector<const T*>& chunks, const std::vector<size_t>& lens,
+                            const std::vector<const uint8_t*>* masks = nullptr,
+                            const std::vector<size_t>* mask_offsets = nullptr) const {
+        static_assert(std::is_same<T, int64_t>::value || std::is_same<T, int32_t>::value || std::is_same<T, double>::value ||
+                          std::is_same<T, float>::value,
+                      "i64, i32, f64 or f32 chunks");
+        if (chunks.size() != lens.size() || (masks && masks->size() != chunks.size()))
+            throw KernelError(KernelError::InvalidArguments, "chunk tables of different lengths");
+        const int32_t fmt = std::is_same<T, int64_t>::value ? 'l' : std::is_same<T, int32_t>::value ? 'i' : std::is_same<T, double>::value ? 'g' : 'f';
+        check(ma_group_enqueue_sum_chunks(g_, column, fmt, chunks.size(), reinterpret_cast<const void* const*>(chunks.data()),
+                                          lens.data(), masks ? masks->data() : nullptr,
+                                          mask_offsets ? mask_offsets->data() : nullptr));
         check(ma_group_exchange(g_));
     }
     void wait() const { check(ma_group_synchronize(g_)); }
