@@ -37,6 +37,10 @@ python3 tools/trace_summary.py $O/trace kernel > $O/${R}_super_array_trace_final
 step "matrix (on the runtime bench.py runs on)"; MA_IMPORT_TORCH=1 timeout -k 10 600 python3 tools/bench_matrix.py > $O/${R}_matrix.jsonl 2> $O/${R}_matrix.err || exit 1
 step "size sweep"; MA_IMPORT_TORCH=1 timeout -k 10 400 python3 tools/sweep_sizes.py > $O/${R}_sweep_sizes.jsonl 2>/dev/null || exit 1
 step "lanes"; timeout -k 10 200 python3 tools/bench_lanes.py > $O/${R}_lanes.json 2>/dev/null || exit 1
+step "record-batch streams: ingestion and the stream operator at chunk-sized and large batches"
+for a in "8192 20000" "65536 2000" "262144 500" "1000000 128" "8000000 32"; do timeout -k 10 200 python3 tools/bench_stream_ingest.py $a 2>/dev/null | tail -1; done > $O/${R}_stream_ingest.jsonl
+for a in "8192 5000" "65536 1000" "262144 250" "1000000 64"; do timeout -k 10 200 python3 tools/bench_stream_op.py $a 2>/dev/null | tail -1; done > $O/${R}_stream_op.jsonl
+step "simd_eq_mask shapes"; timeout -k 10 200 python3 tools/sweep_eq_mask.py > $O/${R}_sweep_eq_mask.jsonl 2>/dev/null || exit 1
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write
 ls -la $O
 head -c 1200 $O/${R}_bench.json
