@@ -506,6 +506,120 @@ static size_t tile_rows_of() {
 
 using namespace ma;
 
+// The chunk-per-workgroup form of one column's concatenation (see ma_consolidate_column for when it is chosen): descriptors in
+// the pinned staging buffer, segments of growing size, validity words by the chunk's own workgroup + the join pass.
+// `po` / `ow`: device-reachable destination of the values / of the validity words (nullptr: the column has none).
+static ma_status concat_column_by_chunks(ma_ctx* ctx, CallScope& scope, size_t elem_size, size_t n_chunks,
+                                         const void* const* chunk_data, const size_t* chunk_lens,
+                                         const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets, void* po,
+                                         uint64_t* ow, size_t total) {
+    const bool has_mask = ow != nullptr;
+    // validity: the words inside a chunk are written by the chunk's workgroup; only when some chunk starts in the
+    // middle of a word (lengths that are not multiples of 64) is there a join pass, and only then a whole-list table
+    bool has_join = false;
+    if (has_mask) {
+        size_t r = 0;
+        for (size_t i = 0; i < n_chunks && !has_join; ++i) {
+            has_join = chunk_lens[i] != 0 && (r & 63) != 0;
+            r += chunk_lens[i];
+        }
+    }
+    std::vector<MaskDesc> mdesc;
+    if (has_join) mdesc.resize(n_chunks);
+    DeviceRange data_role, mask_role;
+    const size_t kFirst = 4096, kMax = 32768;
+    size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
+    while (c0 < n_chunks) {
+        const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
+        ConcatChunk* cd = nullptr;
+        MA_TRY(table_begin(ctx, sizeof(ConcatChunk) * (c1 - c0), (void**)&cd));
+        for (size_t i = c0; i < c1; ++i) {
+            const void* p = chunk_data[i];
+            if (!data_role.holds(p)) {
+                MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
+                if (chunk_lens[i]) data_role.learn(chunk_data[i]);
+            }
+            MA_REQUIRE(chunk_lens[i] <= kConcatLenMask, MA_ERR_INVALID_ARGUMENT, "chunk %zu is too long", i);
+            const uint64_t* words = nullptr;
+            size_t bit_off = 0;
+            if (has_mask) {
+                if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
+                    const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
+                    if (mask_role.holds(chunk_masks[i])) {
+                        const uintptr_t addr = (uintptr_t)chunk_masks[i], base = addr & ~(uintptr_t)7;
+                        words = (const uint64_t*)base;
+                        bit_off = mo + (size_t)(addr - base) * 8;
+                    } else {
+                        MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &words, &bit_off));
+                        mask_role.learn(chunk_masks[i]);
+                    }
+                }
+                if (words) {  // to the word that holds row 0: six bits of offset are left
+                    words += bit_off >> 6;
+                    bit_off &= 63;
+                }
+                if (has_join)
+                    mdesc[i] = MaskDesc{row, chunk_lens[i], words, bit_off,
+                                        words ? (bit_off + chunk_lens[i] - 1) >> 6 : 0};
+            }
+            cd[i - c0] = ConcatChunk{p, (uint64_t)row, (uint64_t)chunk_lens[i] | ((uint64_t)bit_off << 58), words};
+            row += chunk_lens[i];
+        }
+        const void* tab = nullptr;
+        int slot = -1;
+        MA_TRY(table_commit_mapped(ctx, cd, &tab, &slot));
+        const int n = (int)(c1 - c0);
+        const int grid = grid_for(ctx, (size_t)n, 6);
+        const ConcatChunk* tcd = (const ConcatChunk*)tab;
+        // two 4 x 16-byte tiles per 8192-row chunk (4-byte), two 8 x 16-byte tiles (8-byte); one tile for the 1- and
+        // 2-byte columns (2 / 4 x 16 bytes per lane)
+#define MA_CONCAT_CHUNKS(T, U)                                                                                              \
+    do {                                                                                                                     \
+if (has_mask)                                                                                                        \
+    hipLaunchKernelGGL((concat_chunk_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd, n, (T*)po, ow, \
+                       total);                                                                                       \
+else                                                                                                                 \
+    hipLaunchKernelGGL((concat_chunk_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd, n, (T*)po, ow, \
+                       total);                                                                                       \
+    } while (0)
+        switch (elem_size) {
+            case 1: MA_CONCAT_CHUNKS(uint8_t, 2); break;
+            case 2: MA_CONCAT_CHUNKS(uint16_t, 4); break;
+            case 4: MA_CONCAT_CHUNKS(uint32_t, 4); break;
+            default: MA_CONCAT_CHUNKS(uint64_t, 8); break;
+        }
+#undef MA_CONCAT_CHUNKS
+        MA_HIP(hipGetLastError());
+        MA_TRY(table_release(ctx, slot));
+        c0 = c1;
+        if (seg < kMax) seg *= 2;
+    }
+    if (has_join) {  // the join pass walks the list either side of a chunk: one compact table, uploaded
+        void* dm = nullptr;
+        MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks, &dm));
+        MA_TRY(upload_table(ctx, mdesc.data(), sizeof(MaskDesc) * n_chunks, dm));
+        const int grid = grid_for(ctx, (n_chunks + kBlock - 1) / kBlock, 8);
+        hipLaunchKernelGGL(concat_mask_joins_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MaskDesc*)dm,
+                           (int)n_chunks, total, ow);
+        MA_HIP(hipGetLastError());
+    }
+    return MA_OK;
+}
+
+// Whether a chunk list takes the chunk-per-workgroup form: enough chunks to keep every workgroup busy with an even share
+// (>= 4 per CU), short on average, none so long that its workgroup becomes the tail. variant bit 128 keeps the tile form,
+// bit 256 forces the chunk form (tuning / tests).
+static bool chunk_form_wanted(const ma_ctx* ctx, size_t n_chunks, const size_t* chunk_lens, size_t total) {
+    size_t longest = 0;
+    for (size_t i = 0; i < n_chunks; ++i)
+        if (chunk_lens[i] > longest) longest = chunk_lens[i];
+    const size_t avg = total / n_chunks;
+    bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
+    if (ctx->variant & 128) by_chunk = false;
+    if (ctx->variant & 256) by_chunk = true;
+    return by_chunk;
+}
+
 extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t n_chunks, const void* const* chunk_data,
                                            const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                            const size_t* chunk_mask_offsets, void* out_data, uint8_t* out_mask,
@@ -545,106 +659,10 @@ extern "C" ma_status ma_consolidate_column(ma_ctx* ctx, size_t elem_size, size_t
     // 60 000 x 8192 rows 0.26 / 0.37 ms against 0.30-0.44 / 0.42 for the tile search — the host's 4.4 ns per chunk is the floor),
     // the list cut into segments of 4096, 8192, ... 32768 chunks so that the GPU copies segment k while the host describes
     // segment k + 1. variant bit 128 keeps the tile form, bit 256 forces the chunk form (tuning / tests).
-    {
-        size_t longest = 0;
-        for (size_t i = 0; i < n_chunks; ++i)
-            if (chunk_lens[i] > longest) longest = chunk_lens[i];
-        const size_t avg = total / n_chunks;
-        bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
-        if (ctx->variant & 128) by_chunk = false;
-        if (ctx->variant & 256) by_chunk = true;
-        if (by_chunk) {
-            // validity: the words inside a chunk are written by the chunk's workgroup; only when some chunk starts in the
-            // middle of a word (lengths that are not multiples of 64) is there a join pass, and only then a whole-list table
-            bool has_join = false;
-            if (has_mask) {
-                size_t r = 0;
-                for (size_t i = 0; i < n_chunks && !has_join; ++i) {
-                    has_join = chunk_lens[i] != 0 && (r & 63) != 0;
-                    r += chunk_lens[i];
-                }
-            }
-            std::vector<MaskDesc> mdesc;
-            if (has_join) mdesc.resize(n_chunks);
-            DeviceRange data_role, mask_role;
-            const size_t kFirst = 4096, kMax = 32768;
-            size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
-            while (c0 < n_chunks) {
-                const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
-                ConcatChunk* cd = nullptr;
-                MA_TRY(table_begin(ctx, sizeof(ConcatChunk) * (c1 - c0), (void**)&cd));
-                for (size_t i = c0; i < c1; ++i) {
-                    const void* p = chunk_data[i];
-                    if (!data_role.holds(p)) {
-                        MA_TRY(scope.in(chunk_data[i], chunk_lens[i] * elem_size, &p));
-                        if (chunk_lens[i]) data_role.learn(chunk_data[i]);
-                    }
-                    MA_REQUIRE(chunk_lens[i] <= kConcatLenMask, MA_ERR_INVALID_ARGUMENT, "chunk %zu is too long", i);
-                    const uint64_t* words = nullptr;
-                    size_t bit_off = 0;
-                    if (has_mask) {
-                        if (chunk_masks && chunk_masks[i] && chunk_lens[i]) {
-                            const size_t mo = chunk_mask_offsets ? chunk_mask_offsets[i] : 0;
-                            if (mask_role.holds(chunk_masks[i])) {
-                                const uintptr_t addr = (uintptr_t)chunk_masks[i], base = addr & ~(uintptr_t)7;
-                                words = (const uint64_t*)base;
-                                bit_off = mo + (size_t)(addr - base) * 8;
-                            } else {
-                                MA_TRY(scope.in_mask(chunk_masks[i], mo, chunk_lens[i], &words, &bit_off));
-                                mask_role.learn(chunk_masks[i]);
-                            }
-                        }
-                        if (words) {  // to the word that holds row 0: six bits of offset are left
-                            words += bit_off >> 6;
-                            bit_off &= 63;
-                        }
-                        if (has_join)
-                            mdesc[i] = MaskDesc{row, chunk_lens[i], words, bit_off,
-                                                words ? (bit_off + chunk_lens[i] - 1) >> 6 : 0};
-                    }
-                    cd[i - c0] = ConcatChunk{p, (uint64_t)row, (uint64_t)chunk_lens[i] | ((uint64_t)bit_off << 58), words};
-                    row += chunk_lens[i];
-                }
-                const void* tab = nullptr;
-                int slot = -1;
-                MA_TRY(table_commit_mapped(ctx, cd, &tab, &slot));
-                const int n = (int)(c1 - c0);
-                const int grid = grid_for(ctx, (size_t)n, 6);
-                const ConcatChunk* tcd = (const ConcatChunk*)tab;
-                // two 4 x 16-byte tiles per 8192-row chunk (4-byte), two 8 x 16-byte tiles (8-byte); one tile for the 1- and
-                // 2-byte columns (2 / 4 x 16 bytes per lane)
-#define MA_CONCAT_CHUNKS(T, U)                                                                                              \
-    do {                                                                                                                     \
-        if (has_mask)                                                                                                        \
-            hipLaunchKernelGGL((concat_chunk_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd, n, (T*)po, ow, \
-                               total);                                                                                       \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((concat_chunk_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, tcd, n, (T*)po, ow, \
-                               total);                                                                                       \
-    } while (0)
-                switch (elem_size) {
-                    case 1: MA_CONCAT_CHUNKS(uint8_t, 2); break;
-                    case 2: MA_CONCAT_CHUNKS(uint16_t, 4); break;
-                    case 4: MA_CONCAT_CHUNKS(uint32_t, 4); break;
-                    default: MA_CONCAT_CHUNKS(uint64_t, 8); break;
-                }
-#undef MA_CONCAT_CHUNKS
-                MA_HIP(hipGetLastError());
-                MA_TRY(table_release(ctx, slot));
-                c0 = c1;
-                if (seg < kMax) seg *= 2;
-            }
-            if (has_join) {  // the join pass walks the list either side of a chunk: one compact table, uploaded
-                void* dm = nullptr;
-                MA_TRY(ctx_scratch(ctx, sizeof(MaskDesc) * n_chunks, &dm));
-                MA_TRY(upload_table(ctx, mdesc.data(), sizeof(MaskDesc) * n_chunks, dm));
-                const int grid = grid_for(ctx, (n_chunks + kBlock - 1) / kBlock, 8);
-                hipLaunchKernelGGL(concat_mask_joins_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const MaskDesc*)dm,
-                                   (int)n_chunks, total, ow);
-                MA_HIP(hipGetLastError());
-            }
-            return end_call(ctx, scope);
-        }
+    if (chunk_form_wanted(ctx, n_chunks, chunk_lens, total)) {
+        MA_TRY(concat_column_by_chunks(ctx, scope, elem_size, n_chunks, chunk_data, chunk_lens, chunk_masks, chunk_mask_offsets, po,
+                                       has_mask ? ow : nullptr, total));
+        return end_call(ctx, scope);
     }
     ChunkDesc* desc = nullptr;  // built in the context's pinned staging buffer (ma::table_begin / table_commit)
     MA_TRY(table_begin(ctx, sizeof(ChunkDesc) * n_chunks, (void**)&desc));
@@ -784,6 +802,17 @@ extern "C" ma_status ma_consolidate_table_arena(ma_ctx* ctx, size_t n_cols, size
     // A pageable arena is staged through a temporary that is copied back whole: give its padding defined (zero) bytes,
     // as Arena::with_capacity pre-fills (arena.rs:125-130). A device-reachable arena keeps whatever its padding held.
     if (pa != arena) MA_HIP(hipMemsetAsync(pa, 0, capacity, ctx->stream));
+    // A SuperTable of many short batches (RechunkStrategy::Auto: 8192 rows): every column takes the chunk-per-workgroup form
+    // of the single-column consolidate (in-place descriptors, segments, validity by the chunk's own workgroup) — cells of one
+    // column are contiguous in the cell tables. 20 000 batches x 4 columns: 0.69 -> see DESIGN.md 3.2b.
+    if (chunk_form_wanted(ctx, n_batches, batch_rows, n_rows)) {
+        for (size_t c = 0; c < n_cols; ++c)
+            MA_TRY(concat_column_by_chunks(ctx, scope, elem_sizes[c], n_batches, cell_data + c * n_batches, batch_rows,
+                                           cell_masks ? cell_masks + c * n_batches : nullptr,
+                                           cell_mask_offsets ? cell_mask_offsets + c * n_batches : nullptr, (char*)pa + data_off[c],
+                                           has_nulls[c] ? (uint64_t*)((char*)pa + mask_off[c]) : nullptr, n_rows));
+        return end_call(ctx, scope);
+    }
     // Descriptor table: first the copy descriptors grouped by element width (one launch per width; `start` counts
     // elements from the arena base — regions are 64-byte aligned, so every data offset is a whole number of elements),
     // then one run of validity descriptors per nullable column (`start` = the batch's first row in the column).

@@ -409,6 +409,33 @@ def test_arena_random_tables_vs_oracle(ctx, oracle, seed, pageable):
     np.testing.assert_array_equal(arena, want)
 
 
+@pytest.mark.parametrize("pageable", [False, True])
+@pytest.mark.parametrize("aligned", [True, False])
+def test_arena_many_short_batches_take_the_chunk_form(ctx, oracle, aligned, pageable):
+    """A SuperTable of 1500 short batches (RechunkStrategy::Auto sizes; here 64 ... 640 rows, or ragged ones incl. empty
+    batches): every column goes through the chunk-per-workgroup form — in-place descriptors, validity words by the chunk's
+    own workgroup, join pass when batches start inside a word. All eight element types, masks on all / some / no batches."""
+    rng = np.random.default_rng(17 + aligned)
+    n_batches = 1500
+    batch_rows = [int(x) for x in (rng.choice([64, 128, 640], size=n_batches) if aligned else rng.choice([0, 1, 63, 65, 200, 777], size=n_batches))]
+    types = [np.int64, np.float64, np.int32, np.float32, np.uint8, np.int16, np.uint64, np.int8]
+    cols = []
+    for k, dt in enumerate(types):
+        chunks = [(rng.integers(0, 120, size=r)).astype(dt) for r in batch_rows]
+        kind = k % 3  # 0: no masks at all, 1: every batch masked, 2: some
+        if kind == 0:
+            cols.append((chunks, None, None))
+            continue
+        offs = [int(rng.integers(0, 70)) for _ in batch_rows]
+        masks = [None if (kind == 2 and rng.random() < 0.5) else rng.integers(0, 256, size=(o + r + 7) // 8 + 16, dtype=np.uint8)
+                 for r, o in zip(batch_rows, offs)]
+        cols.append((chunks, masks, offs))
+    arena, d_off, m_off, used = _arena_call(ctx, cols, batch_rows, pageable=pageable)
+    want, wd, wm, wu = oracle.consolidate_table_arena(cols)
+    assert (d_off, m_off, used) == (wd, wm, wu)
+    np.testing.assert_array_equal(arena, want)
+
+
 def test_arena_bench_shape_and_errors(ctx, oracle):
     """benches/consolidate.rs:34-35: 100 tables x 10 000 rows; the numeric half of its 20-column table."""
     n_batches, rows = 100, 10_000
