@@ -31,3 +31,30 @@ def test_cpp_host_fails_loudly_without_a_gpu():
     build()
     r = subprocess.run([str(BIN)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "no HIP device is visible" in r.stdout
+
+
+def _build_example(tmp_path):
+    exe = tmp_path / "chunked_column"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "chunked_column.c"),
+                    f"-L{ROOT / 'minarrow_amd' / 'lib'}", "-lminarrow_hip", f"-Wl,-rpath,{ROOT / 'minarrow_amd' / 'lib'}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+@pytest.mark.gpu
+def test_c_example_of_the_chunked_regime(tmp_path):
+    """examples/chunked_column.c: a C99 host, the header and the .so — resident sum, the same column as 8192-row chunks
+    (ma_sum_chunks), chunk + scalar for all chunks in one launch, consolidate; every result against its closed form."""
+    exe = _build_example(tmp_path)
+    r = subprocess.run([str(exe), str((1 << 24) + 12345)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
+def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    from minarrow_amd import ffi
+
+    exe = _build_example(tmp_path)
+    if ffi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device is visible" in r.stdout
