@@ -415,6 +415,53 @@ def gpu_other_configs(ctx, n: int, reps: int):
                    "reduce_consolidated": entry(ms_phys, 8.125, total, same)}
     res["config5_supertable_8_batches"] = {"batches": k, "rows_per_batch": rows, **c5}
 
+    # ---- config 5 at the reference's OWN batch size: RechunkStrategy::Auto = 8192 rows (src/structs/chunked/super_array.rs:
+    # 51-59) — the column is ~122 000 chunks per 10^9 rows, not 8. One call each: the total of the chunked column with 10 %
+    # nulls (ma_sum_chunks: a wave per chunk on in-place descriptors, double-double fold of all partials) and its
+    # consolidation incl. validity (chunk-per-workgroup form). The pointer tables are built once, as a host holding a
+    # SuperTable would; parity against the same rows scanned / copied as ONE array.
+    try:
+        import ctypes as C
+
+        per = 8192
+        kc = min(n // per, 122_000)
+        if kc >= 1024:
+            rows_c = kc * per
+            ctx.set_async(False)
+            ctx.synth_iota("i64", a, rows_c, 3)
+            ctx.synth_validity(mask, rows_c, seed=0xC5, first_index=0, null_every=10)
+            tab = lambda xs: C.cast((C.c_void_p * kc)(*xs), C.c_void_p)  # noqa: E731
+            t_d = tab([a.ptr + i * per * 8 for i in range(kc)])
+            t_m = tab([mask.ptr + i * (per // 8) for i in range(kc)])
+            t_n = C.cast((C.c_size_t * kc)(*([per] * kc)), C.c_void_p)
+            has = C.c_int32()
+
+            def sum_chunks():
+                st = ctx.lib.ma_sum_chunks(ctx.handle, ord("l"), kc, t_d, t_n, t_m, None, None, slot.ptr, slot.ptr + 8)
+                assert st == 0, st
+
+            def consolidate_chunks():
+                st = ctx.lib.ma_consolidate_column(ctx.handle, 8, kc, t_d, t_n, t_m, None, o.ptr, om.ptr, C.addressof(has))
+                assert st == 0, st
+
+            ctx.set_async(True)
+            ms_s = _timed(ctx, sum_chunks, reps)
+            ms_k = _timed(ctx, consolidate_chunks, max(2, reps // 2), 1)
+            ctx.set_async(False)
+            ctx.synchronize()
+            got = slot.download(np.int64, 2)
+            one_s, one_c = ctx.sum("i64", a, rows_c, mask=mask)
+            ok_s = (int(got[0]) & M64) == (one_s & M64) and int(got[1]) == one_c
+            join_s, join_c = ctx.sum("i64", o, rows_c, mask=om)
+            ok_k = (join_s & M64) == (one_s & M64) and join_c == one_c and bool(np.array_equal(
+                o.download(np.int64, 4096, (rows_c // 2 - 2048) * 8), a.download(np.int64, 4096, (rows_c // 2 - 2048) * 8)))
+            res["config5_supertable_8192_row_batches"] = {
+                "batches": kc, "rows_per_batch": per,
+                "i64_total_of_the_chunked_column_10pct_nulls": entry(ms_s, 8.125, rows_c, ok_s),
+                "i64_consolidate_with_validity": entry(ms_k, 16.25, rows_c, ok_k)}
+    except Exception as e:  # noqa: BLE001 — an extra leg must not cost the line
+        res["config5_supertable_8192_row_batches"] = {"error": f"{type(e).__name__}: {e}"}
+
     def add_frac(d):
         for v in d.values():
             if isinstance(v, dict):
