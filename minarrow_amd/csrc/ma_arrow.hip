@@ -303,15 +303,22 @@ extern "C" ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_
             return MA_ERR_LENGTH_MISMATCH;
         }
     }
-    // One launch for all chunks (ma_superarray.hip) unless output validity depends on the data: masked integer
-    // Div/Rem/FloorDiv clears the bit of a zero divisor (simd.rs:319-326) and goes chunk by chunk below.
+    // One launch for all chunks (ma_superarray.hip). Masked integer Div/Rem/FloorDiv makes the output validity depend on
+    // the data — a zero divisor clears the row's bit (simd.rs:319-326) — ...
     {
         const bool is_int = format_code == 'i' || format_code == 'I' || format_code == 'l' || format_code == 'L';
         const bool divlike = op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV;
         bool any_mask = null_mask_override != nullptr;
         for (size_t i = 0; i < n_chunks && !any_mask; ++i)
             any_mask = (lhs_masks && lhs_masks[i]) || (rhs_masks && rhs_masks[i]);
-        if (!(is_int && divlike && any_mask)) {
+        // ... which the batched kernels do themselves (the computing wave packs the result bits: pair_tile's DV form) as long
+        // as every masked chunk's output starts on a 16-byte boundary; only otherwise chunk by chunk
+        bool masked_mid_vector = false;
+        if (is_int && divlike && any_mask)
+            for (size_t i = 0; i < n_chunks && !masked_mid_vector; ++i)
+                masked_mid_vector = lhs_lens[i] != 0 && (((uintptr_t)out_data[i]) & 15) != 0 &&
+                                    (null_mask_override || (lhs_masks && lhs_masks[i]) || (rhs_masks && rhs_masks[i]));
+        if (!(is_int && divlike && any_mask && masked_mid_vector)) {
             MA_REQUIRE(op >= MA_OP_ADD && op <= MA_OP_FLOORDIV, MA_ERR_INVALID_ARGUMENT, "unknown ArithmeticOperator code %d", op);
             return route_batched(ctx, format_code, op, n_chunks, lhs_data, lhs_lens, lhs_masks, rhs_data, rhs_masks,
                                              null_mask_override, out_data, out_masks, out_has_mask);
@@ -374,7 +381,11 @@ extern "C" ma_status ma_broadcast_super_array_scalar(ma_ctx* ctx, int32_t format
     const bool divlike = op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV;
     bool any_mask = false;
     for (size_t i = 0; i < n_chunks && !any_mask; ++i) any_mask = chunk_masks && chunk_masks[i] && chunk_lens[i];
-    if (!(is_int && divlike && any_mask)) {
+    bool masked_mid_vector = false;  // a masked chunk whose output starts off a 16-byte boundary (see ma_route_super_array_broadcast)
+    if (is_int && divlike && any_mask)
+        for (size_t i = 0; i < n_chunks && !masked_mid_vector; ++i)
+            masked_mid_vector = chunk_lens[i] != 0 && chunk_masks[i] && (((uintptr_t)out_data[i]) & 15) != 0;
+    if (!(is_int && divlike && any_mask && masked_mid_vector)) {
         const int smode = scalar_is_lhs ? 1 : 2;
         return route_batched(ctx, format_code, op, n_chunks, scalar_is_lhs ? nullptr : chunk_data, chunk_lens,
                              scalar_is_lhs ? nullptr : chunk_masks, scalar_is_lhs ? chunk_data : nullptr,

@@ -124,7 +124,11 @@ __device__ __forceinline__ unsigned pair_row_valid(const PairDesc& d, size_t row
 // smode: 0 = array (op) array; 1 = the LEFT operand is the scalar `sval` for every chunk (broadcast_scalar_to_superarray,
 // src/kernels/broadcast/scalar.rs:214-243), 2 = the right one (broadcast_superarray_to_scalar, super_array.rs:87-116) —
 // wave-uniform: the scalar side's loads are skipped, nothing else changes.
-template <typename T, int UNROLL, bool FUSE_MASK>
+// DV (integer Div / Rem / FloorDiv of a call that carries validity): a masked chunk's OUTPUT validity depends on the data —
+// a zero divisor clears the row's bit instead of raising (m & !div_zero, simd.rs:319-326) — so the computing wave packs the
+// result bits of its rows into the chunk's output words itself (FUSE_MASK is then always on); dense chunks of the same call
+// keep the latch.
+template <typename T, int UNROLL, bool FUSE_MASK, bool DV = false>
 __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, bool& dz, unsigned lane, unsigned wave,
                                           int smode, T sval) {
     typedef typename Vec16<T>::type V;
@@ -163,7 +167,7 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
         aw = 0;
         if (d.lw) aw |= load_run_words<WPT>(d.lw, d.lo + w0, d.l_last, lane);
         if (d.rw) aw |= load_run_words<WPT>(d.rw, d.ro + w0, d.r_last, lane);
-        if (FUSE_MASK && lane < (unsigned)WPT) {  // lane k holds run word k = word w0 / 64 + k of the chunk's bitmap
+        if (FUSE_MASK && !DV && lane < (unsigned)WPT) {  // lane k holds run word k = word w0 / 64 + k of the chunk's bitmap
             const size_t j = (w0 >> 6) + lane;
             const size_t first = j << 6;
             if (first < d.len) {
@@ -184,13 +188,45 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
             unsigned bits = ~0u;
             if (masked) bits = lane_bits<R>(aw, u, lane);
             V r;
+            [[maybe_unused]] unsigned out_bits = bits;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                T v = Elem<T>::apply_rt(op, (T)va[u][k], (T)vb[u][k], dz);
-                v = ((bits >> k) & 1u) ? v : (T)0;
+                T v;
+                if constexpr (DV) {
+                    bool dzk = false;
+                    v = Elem<T>::apply_rt(op, (T)va[u][k], (T)vb[u][k], dzk);
+                    if (masked) out_bits &= ~((dzk ? 1u : 0u) << k);
+                    else dz |= dzk;
+                } else {  // exactly the round-2 form: a per-element flag cost the masked i32 kernels 5-17 %
+                    v = Elem<T>::apply_rt(op, (T)va[u][k], (T)vb[u][k], dz);
+                }
+                v = ((bits >> k) & 1u) ? v : (T)0;  // a zero divisor already gave 0
                 r[k] = v;
             }
             store16<V, true>(o + (size_t)u * 64, r);
+            if constexpr (DV) {
+                if (masked) {  // wave-uniform: the run's 64 R rows of step u are exactly R words of the chunk's output bitmap
+                    constexpr int LPW = 64 / R;
+                    const uint64_t word = pack_lane_bits<R>(out_bits & ((1u << R) - 1u), lane);
+                    if (lane % LPW == 0) as_global(d.ow)[(w0 >> 6) + (size_t)u * R + lane / LPW] = word;
+                }
+            }
+        }
+    } else if (DV && masked) {
+        // the chunk's ragged last run: one row per lane, one ballot per 64 rows (its words hold bits of vector and of tail rows)
+        const size_t end = w0 + run_rows;
+        for (size_t base = w0; base < end; base += 64) {
+            const size_t i = base + lane;
+            bool ok = false;
+            T v = (T)0;
+            if (i < end && pair_row_valid(d, i)) {
+                bool dzk = false;
+                v = Elem<T>::apply_rt(op, smode == 1 ? sval : lhs[i], smode == 2 ? sval : rhs[i], dzk);
+                ok = !dzk;
+            }
+            const unsigned long long word = __ballot(ok);
+            if (i < end) out[i] = v;
+            if (lane == 0) as_global(d.ow)[base >> 6] = word;
         }
     } else {
         const unsigned n_vec = (unsigned)(run_rows / R);
@@ -222,7 +258,7 @@ __device__ __forceinline__ void pair_tile(const PairDesc& d, size_t lt, int op, 
 
 // Tiles dealt round-robin to workgroups (the grid sweeps the chunk list as one contiguous front); each workgroup
 // binary-searches its tile's chunk in the tile prefix array.
-template <typename T, int UNROLL, bool FUSE_MASK>
+template <typename T, int UNROLL, bool FUSE_MASK, bool DV = false>
 __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const ChunkPair* __restrict__ cd,
                                                                 const ChunkMaskDesc* __restrict__ md,
                                                                 const uint64_t* __restrict__ tile0, int n_chunks,
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const ChunkPair*
             t_lo = tile0[c];
             t_hi = c + 1 < n_chunks ? tile0[c + 1] : n_tiles;
         }
-        pair_tile<T, UNROLL, FUSE_MASK>(d, t - t_lo, op, dz, lane, wave, smode, sval);
+        pair_tile<T, UNROLL, FUSE_MASK, DV>(d, t - t_lo, op, dz, lane, wave, smode, sval);
     }
     if constexpr (std::is_integral<T>::value) {
         // only dense chunks can latch (masked integer division is routed chunk by chunk on the host)
@@ -261,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void batched_binary_kernel(const ChunkPair*
 // the descriptor is 32 bytes (+32 when the call carries validity) instead of 104, read with wave-uniform (scalar) loads
 // one chunk ahead of its use: the table that has to cross PCIe before the kernel may start shrinks from 6.2 MB to
 // 1.9 MB for 60 000 dense pairs.
-template <typename T, int UNROLL, bool ANY_MASK>
+template <typename T, int UNROLL, bool ANY_MASK, bool DV = false>
 __global__ __launch_bounds__(kBlock) void chunk_binary_kernel(const ChunkPair* __restrict__ cd,
                                                               const ChunkMaskDesc* __restrict__ md, int n_chunks, int op,
                                                               uint32_t* flags, int smode, uint64_t sbits) {
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void chunk_binary_kernel(const ChunkPair* _
         const PairDesc d = make_pair<T>(e, m);
         if (d.len) {
             const size_t n_t = d.len > d.head ? (d.len - d.head + TILE_ROWS - 1) / TILE_ROWS : 1;
-            for (size_t lt = 0; lt < n_t; ++lt) pair_tile<T, UNROLL, ANY_MASK>(d, lt, op, dz, lane, wave, smode, sval);
+            for (size_t lt = 0; lt < n_t; ++lt) pair_tile<T, UNROLL, ANY_MASK, DV>(d, lt, op, dz, lane, wave, smode, sval);
         }
         if (next >= n_chunks) break;
         c = next;
@@ -425,6 +461,8 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
                                  bool by_chunk, char* dev_tab, int smode, uint64_t sbits) {
     constexpr int R = 16 / (int)sizeof(T);
     constexpr size_t TILE_ROWS = (size_t)64 * R * U * kWaves;
+    // integer Div / Rem / FloorDiv with validity: the output bitmaps depend on the data (pair_tile's DV form)
+    const bool dv = std::is_integral<T>::value && any_mask && (op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV);
     const size_t n = c1 - c0;
     const size_t off_md = sizeof(ChunkPair) * n;
     const size_t off_t0 = off_md + (any_mask ? sizeof(ChunkMaskDesc) * n : 0);
@@ -473,7 +511,16 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
         const ChunkPair* dcd = (const ChunkPair*)tab;
         const ChunkMaskDesc* dmd = any_mask ? (const ChunkMaskDesc*)((const char*)tab + off_md) : nullptr;
         const int grid = grid_for(ctx, n, 6);
-        if (any_mask)
+        bool launched = false;
+        if constexpr (std::is_integral<T>::value) {
+            if (dv) {
+                hipLaunchKernelGGL((chunk_binary_kernel<T, U, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, (int)n,
+                                   op, ctx->dev_flags, smode, sbits);
+                launched = true;
+            }
+        }
+        if (launched) {
+        } else if (any_mask)
             hipLaunchKernelGGL((chunk_binary_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, (int)n, op,
                                ctx->dev_flags, smode, sbits);
         else
@@ -488,14 +535,24 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
     const ChunkMaskDesc* dmd = any_mask ? (const ChunkMaskDesc*)(dev_tab + off_md) : nullptr;
     const uint64_t* dt0 = (const uint64_t*)(dev_tab + off_t0);
     const uint64_t* dw0 = any_mask ? (const uint64_t*)(dev_tab + off_w0) : nullptr;
-    const bool fuse = any_mask && !masked_head && !(ctx->variant & 64);  // variant bit 64: always the separate bitmap launch
+    const bool fuse = any_mask && !masked_head && (dv || !(ctx->variant & 64));  // variant bit 64: always the separate bitmap launch
+    MA_REQUIRE(!dv || fuse, MA_ERR_DEVICE, "internal: data-dependent validity needs every masked chunk's output on a 16-byte boundary");
     if (any_mask && !fuse) {
         int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
         hipLaunchKernelGGL(batched_mask_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, dw0, (int)n, n_words);
         MA_HIP(hipGetLastError());
     }
     const int grid = grid_for(ctx, n_tiles, 6);
-    if (fuse)
+    bool launched = false;
+    if constexpr (std::is_integral<T>::value) {
+        if (dv) {
+            hipLaunchKernelGGL((batched_binary_kernel<T, U, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, dt0, (int)n,
+                               n_tiles, op, ctx->dev_flags, smode, sbits);
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if (fuse)
         hipLaunchKernelGGL((batched_binary_kernel<T, U, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, dt0, (int)n, n_tiles,
                            op, ctx->dev_flags, smode, sbits);
     else

@@ -307,3 +307,132 @@ def test_super_array_scalar_both_sides(ctx, oracle, fmt, dt, k, variant, max_len
                     np.testing.assert_array_equal(got_masks[m_offs[i]:m_offs[i] + nb], want_mask[:nb], err_msg=f"{name} chunk {i} validity")
     finally:
         ctx.set_variant(0)
+
+
+@pytest.mark.parametrize("fmt,dt", [("i", np.int32), ("l", np.int64), ("I", np.uint32), ("L", np.uint64)])
+@pytest.mark.parametrize("k,variant,max_len", [(2500, 0, 9000), (2500, 256, 9000), (2500, 128, 9000), (5000, 0, 600), (5000, 256 | 32, 600)])
+def test_masked_integer_division_over_chunk_lists_in_one_launch(ctx, oracle, fmt, dt, k, variant, max_len):
+    """Masked integer Div / Rem / FloorDiv over thousands of chunk pairs: the output validity depends on the data (a zero
+    divisor clears the row's bit, simd.rs:319-326), and the batched kernels produce it themselves — full runs pack the result
+    bits of their lanes, a chunk's ragged last run goes row by row with one ballot per 64 rows. Ragged lengths, nulls on
+    one or both sides or neither (a dense chunk with a zero divisor would raise: dense chunks get non-zero divisors here),
+    a quarter of the masked chunks' divisors zero; both kernel forms; the scalar forms on both sides; and one call whose
+    masked outputs start mid-vector (the chunk-by-chunk path)."""
+    rng = np.random.default_rng(k + variant + ord(fmt))
+    dt = np.dtype(dt)
+    lens = [int(x) for x in rng.integers(0, max_len, size=k)]
+    lens[:4] = [8192, 4096, 1, 0]
+    lo, hi = (0, 100) if dt.kind == "u" else (-50, 50)
+    lhs = [rng.integers(lo, hi, size=n).astype(dt) for n in lens]
+    mb = lambda n: ((n + 63) // 64) * 8 + 8  # noqa: E731 — bytes of a chunk's bitmap slot
+    lm = [rng.integers(0, 256, size=mb(n), dtype=np.uint8) if i % 3 != 1 else None for i, n in enumerate(lens)]
+    rm = [rng.integers(0, 256, size=mb(n), dtype=np.uint8) if i % 4 == 0 else None for i, n in enumerate(lens)]
+    rhs = [(rng.integers(0, 4, size=n) if (lm[i] is not None or rm[i] is not None) else rng.integers(1, 5, size=n)).astype(dt)
+           for i, n in enumerate(lens)]
+    # every chunk's buffers start on 16-byte boundaries inside shared arenas
+    starts, p = [], 0
+    for n in lens:
+        starts.append(p)
+        p += (n * dt.itemsize + 15) // 16 * 16
+    arena_l, arena_r = np.zeros(p + 64, dtype=np.uint8), np.zeros(p + 64, dtype=np.uint8)
+    m_starts, q = [], 0
+    for n in lens:
+        m_starts.append(q)
+        q += ((n + 63) // 64) * 8 + 8
+    am_l, am_r = np.zeros(q + 8, dtype=np.uint8), np.zeros(q + 8, dtype=np.uint8)
+    for i, n in enumerate(lens):
+        arena_l[starts[i]:starts[i] + n * dt.itemsize] = lhs[i].view(np.uint8)
+        arena_r[starts[i]:starts[i] + n * dt.itemsize] = rhs[i].view(np.uint8)
+        if lm[i] is not None:
+            am_l[m_starts[i]:m_starts[i] + lm[i].size] = lm[i]
+        if rm[i] is not None:
+            am_r[m_starts[i]:m_starts[i] + rm[i].size] = rm[i]
+    dl, dr, do = ctx.to_device(arena_l, 64), ctx.to_device(arena_r, 64), ctx.alloc(p + 128)
+    dml, dmr, dom = ctx.to_device(am_l, 16), ctx.to_device(am_r, 16), ctx.alloc(q + 64)
+    L = [dl.offset(s) for s in starts]
+    R = [dr.offset(s) for s in starts]
+    O = [do.offset(s) for s in starts]
+    LM = [dml.offset(m_starts[i]) if lm[i] is not None else None for i in range(k)]
+    RM = [dmr.offset(m_starts[i]) if rm[i] is not None else None for i in range(k)]
+    OM = [dom.offset(s) for s in m_starts]
+
+    def common(i, n):
+        if lm[i] is not None and rm[i] is not None:
+            return oracle.bitmask_union(oracle.pad_bits(lm[i], n), oracle.pad_bits(rm[i], n), n)
+        return lm[i] if lm[i] is not None else rm[i]
+
+    def check(name, get_l, get_r, has, sample):
+        got, got_masks = do.download(np.uint8, p), dom.download(np.uint8, q)
+        for i in sample:
+            n = lens[i]
+            c = common(i, n)
+            assert has[i] == (c is not None)
+            if n == 0:
+                continue
+            g = got[starts[i]:starts[i] + n * dt.itemsize].view(dt)
+            if c is None:
+                st, want, _, _ = oracle.apply_int(oracle.aligned_copy(get_l(i)), oracle.aligned_copy(get_r(i)), name)
+                np.testing.assert_array_equal(g, want, err_msg=f"{name} dense chunk {i}")
+            else:
+                st, want, want_mask = oracle.int_body("masked_std", get_l(i), get_r(i), name, mask=oracle.pad_bits(c, n))
+                np.testing.assert_array_equal(g, want, err_msg=f"{name} chunk {i}")
+                nb = ((n + 63) // 64) * 8
+                np.testing.assert_array_equal(got_masks[m_starts[i]:m_starts[i] + nb], want_mask[:nb], err_msg=f"{name} chunk {i} validity")
+
+    sample = list(range(0, 40)) + list(range(40, k, 61))
+    ctx.set_variant(variant)
+    try:
+        for op, name in ((3, "divide"), (4, "remainder"), (6, "floordiv")):
+            ctx.dev_memset(dom, 0xA5, q + 64)
+            has = ctx.route_super_array_broadcast(fmt, op, L, R, lens, lens, O, LM, RM, OM)
+            check(name, lambda i: lhs[i], lambda i: rhs[i], has, sample)
+        # chunk / scalar and scalar / chunk with the chunks' own validity (the ABI's optional gating); a zero scalar divisor
+        # nulls every row of a masked chunk
+        for side, s in ((False, dt.type(3)), (True, dt.type(7))):
+            cols = rhs if side else lhs  # scalar / chunk divides by the chunk: the masked chunks' rhs has zeros
+            arena = dr if side else dl
+            cm = [LM[i] if LM[i] is not None else RM[i] for i in range(k)]
+            cm_h = [lm[i] if lm[i] is not None else rm[i] for i in range(k)]
+            C_ = [arena.offset(st_) for st_ in starts]
+            ctx.dev_memset(dom, 0xA5, q + 64)
+            has = ctx.broadcast_super_array_scalar(fmt, 3, s, C_, lens, O, cm, OM, scalar_is_lhs=side)
+            got, got_masks = do.download(np.uint8, p), dom.download(np.uint8, q)
+            for i in sample:
+                n = lens[i]
+                assert has[i] == (cm_h[i] is not None)
+                if n == 0:
+                    continue
+                full = np.full(n, s, dtype=dt)
+                l_, r_ = (full, cols[i]) if side else (cols[i], full)
+                g = got[starts[i]:starts[i] + n * dt.itemsize].view(dt)
+                if cm_h[i] is None:
+                    st, want, _, _ = oracle.apply_int(oracle.aligned_copy(l_), oracle.aligned_copy(r_), "divide")
+                    np.testing.assert_array_equal(g, want)
+                else:
+                    st, want, want_mask = oracle.int_body("masked_std", l_, r_, "divide", mask=oracle.pad_bits(cm_h[i], n))
+                    np.testing.assert_array_equal(g, want, err_msg=f"scalar side={side} chunk {i}")
+                    nb = ((n + 63) // 64) * 8
+                    np.testing.assert_array_equal(got_masks[m_starts[i]:m_starts[i] + nb], want_mask[:nb])
+    finally:
+        ctx.set_variant(0)
+    # masked outputs that start mid-vector: the chunk-by-chunk path, same results
+    few = list(range(0, 12))
+    O2 = [do.offset(starts[i] + dt.itemsize) for i in few]
+    ctx.dev_memset(dom, 0xA5, q + 64)
+    has = ctx.route_super_array_broadcast(fmt, 3, [L[i] for i in few], [R[i] for i in few], [max(lens[i] - 1, 0) for i in few],
+                                          [max(lens[i] - 1, 0) for i in few], O2, [LM[i] for i in few], [RM[i] for i in few], [OM[i] for i in few])
+    got, got_masks = do.download(np.uint8, p), dom.download(np.uint8, q)
+    for j, i in enumerate(few):
+        n = max(lens[i] - 1, 0)
+        c = common(i, lens[i])
+        if n == 0:
+            continue
+        g = got[starts[i] + dt.itemsize:starts[i] + dt.itemsize + n * dt.itemsize].view(dt)
+        if c is None:
+            st, want, _, _ = oracle.apply_int(oracle.aligned_copy(lhs[i][:n]), oracle.aligned_copy(rhs[i][:n]), "divide")
+            np.testing.assert_array_equal(g, want)
+        else:
+            st, want, want_mask = oracle.int_body("masked_std", lhs[i][:n], rhs[i][:n], "divide", mask=oracle.pad_bits(c, n))
+            np.testing.assert_array_equal(g, want, err_msg=f"mid-vector chunk {i}")
+            nb = ((n + 63) // 64) * 8
+            np.testing.assert_array_equal(got_masks[m_starts[i]:m_starts[i] + nb], want_mask[:nb])
