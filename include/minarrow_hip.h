@@ -777,7 +777,8 @@ ma_status ma_route_super_array_broadcast(ma_ctx* ctx, int32_t format_code, int32
  * chunk_masks: the reference passes None for every chunk (array.rs:183: the chunks' own validity is not consulted, the
  * result chunks are dense) = NULL here. A non-NULL entry gates chunk i like the mask argument of ma_apply_* (bit 0 = row
  * 0): out_masks[i] receives it and out_has_mask[i] says so. Dense integer Div / Rem / FloorDiv by zero ->
- * MA_ERR_DIVIDE_BY_ZERO; masked ones clear the row's bit instead (simd.rs:319-326) and run chunk by chunk. */
+ * MA_ERR_DIVIDE_BY_ZERO; masked ones clear the row's bit instead (simd.rs:319-326) — inside the same launch, unless a masked chunk's output starts off a
+ * 16-byte boundary (then chunk by chunk). */
 ma_status ma_broadcast_super_array_scalar(ma_ctx* ctx, int32_t format_code, int32_t op, int32_t scalar_is_lhs,
                                           const void* scalar, size_t n_chunks, const void* const* chunk_data,
                                           const size_t* chunk_lens, const uint8_t* const* chunk_masks,
