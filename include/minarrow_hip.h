@@ -790,7 +790,7 @@ ma_status ma_broadcast_super_array_scalar(ma_ctx* ctx, int32_t format_code, int3
  * record batches of a stream; `column` indexes the children of "+s" (record batch) arrays, or is -1 / 0 for a
  * stream of primitive arrays. Each batch is uploaded at PCIe line rate, released, and its sum kernel runs while
  * the host pulls the next batch from the producer; batches under 4 MiB (a SuperTable rechunked at 8192 rows) are gathered
- * into pinned 8-MiB tiles first — one copy and one sum per tile (39 GB/s at 8192-row batches; 1.5-2.2 batch by batch). The stream is consumed to its end but NOT
+ * into pinned 8-MiB tiles first — one copy and one sum per tile (43-48 GB/s at 8192-row batches; 1.5-2.2 batch by batch). The stream is consumed to its end but NOT
  * released (the caller owns it). Outputs as ma_sum_arrow; *out_rows / *out_batches count what was read.
  * ---------------------------------------------------------------------------------------------- */
 #ifndef ARROW_C_STREAM_INTERFACE

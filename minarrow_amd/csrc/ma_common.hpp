@@ -42,6 +42,10 @@ struct ResultSlot {
 void set_error(const char* fmt, ...);
 // hipMalloc on `device` (already current) that releases the device's parked-block cache and retries once when HBM is full.
 hipError_t device_malloc(int device, void** out, size_t bytes);
+// The same through the device's block cache; the caller has made the device current and, for a free, has made sure that
+// nothing in flight still touches the block.
+hipError_t device_block_alloc(int device, void** out, size_t bytes);
+hipError_t device_block_free(int device, void* ptr);
 ma_status hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 }  // namespace ma

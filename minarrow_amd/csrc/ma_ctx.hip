@@ -166,6 +166,9 @@ std::vector<void*> pool_take_victims(PinnedPool& pool, size_t keep_bytes) {
 }  // namespace
 
 hipError_t device_malloc(int device, void** out, size_t bytes) { return dev_malloc_retry(device, out, bytes); }
+// Through the device's block cache (blocks of 1 MiB and more are parked on free instead of stalling the device in hipFree).
+hipError_t device_block_alloc(int device, void** out, size_t bytes) { return dev_block_alloc(device, bytes, out); }
+hipError_t device_block_free(int device, void* ptr) { return dev_block_free(device, ptr); }
 
 void set_error(const char* fmt, ...) {
     va_list ap;

@@ -18,14 +18,19 @@ using namespace ma;
 
 namespace {
 
+// Device slots come from (and go back to) the device's block cache: a hipMalloc + hipFree pair per stream call would stall
+// every stream of the device in hipFree (~160 us) — as long as a whole short stream takes.
 ma_status grow_dev(void** p, size_t* cap, size_t need) {
     if (need <= *cap) return MA_OK;
-    if (*p) MA_HIP(hipFree(*p));
-    *p = nullptr;
-    size_t bytes = need + need / 2 + 4096;
     int dev = 0;
     MA_HIP(hipGetDevice(&dev));
-    MA_HIP(device_malloc(dev, p, bytes));
+    if (*p) {
+        MA_HIP(hipDeviceSynchronize());  // the old slot may still be read by a kernel in flight
+        MA_HIP(device_block_free(dev, *p));
+    }
+    *p = nullptr;
+    size_t bytes = need + need / 2 + 4096;
+    MA_HIP(device_block_alloc(dev, p, bytes));
     *cap = bytes;
     return MA_OK;
 }
@@ -34,7 +39,7 @@ ma_status grow_dev(void** p, size_t* cap, size_t need) {
 // are gathered: their values are copied into one of two pinned 8-MiB tiles, their validity bits are appended to the tile's
 // bitmap at bit granularity (batches without a bitmap contribute valid bits once any batch of the tile has one), and a
 // full tile goes to the GPU as ONE copy and ONE sum — a copy, two synchronisations and a launch per 64-KiB batch cost
-// 30-44 us each: 1.5-2.2 GB/s for 8192-row batches, 9-11 GB/s for 65 536-row ones; gathered 31-39 and 32-36 GB/s
+// 30-44 us each: 1.5-2.2 GB/s for 8192-row batches, 9-11 GB/s for 65 536-row ones; gathered 43-48 and 36-47 GB/s
 // (tools/bench_stream_ingest.py 8192 20000 / 65536 2000) — the host's memcpy into pinned memory. Batches of 4 MiB and more keep
 // the direct path above (52-54 GB/s).
 constexpr size_t kSmallBatchBytes = (size_t)4 << 20;  // the direct path's ~35 us per batch equal the gather's memcpy here
@@ -133,8 +138,8 @@ extern "C" ma_status ma_sum_arrow_stream(ma_ctx* ctx, struct ArrowArrayStream* s
     int cur = 0;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(ctx->stream);
-        if (d_values) (void)hipFree(d_values);
-        if (d_mask) (void)hipFree(d_mask);
+        if (d_values) (void)device_block_free(ctx->device, d_values);
+        if (d_mask) (void)device_block_free(ctx->device, d_mask);
         if (record) (void)hipHostFree(record);
         for (GatherTile& t : tiles) {
             if (t.values) (void)ma_free_pinned(t.values);
