@@ -164,6 +164,23 @@ __device__ __forceinline__ uint64_t load_run_words(const uint64_t* __restrict__ 
     return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
 }
 
+// In two steps, for kernels that fetch the words of the NEXT run while they work on this one: the raw word of this lane
+// (a load and nothing that waits for it), and the funnel shift across lanes once the value is wanted.
+template <int WPT>
+__device__ __forceinline__ uint64_t load_run_raw(const uint64_t* __restrict__ words, size_t bit0, size_t last_word, unsigned lane) {
+    static_assert(WPT < 64, "lane WPT holds the word the last run-word funnels from");
+    const size_t w0 = bit0 >> 6;
+    const auto gw = as_global(words);
+    uint64_t mw = 0;
+    if (lane <= (unsigned)WPT && w0 + lane <= last_word) mw = gw[w0 + lane];
+    return mw;
+}
+__device__ __forceinline__ uint64_t finish_run_words(uint64_t mw, size_t bit0) {
+    const unsigned sh = (unsigned)(bit0 & 63);
+    const uint64_t nx = (uint64_t)__shfl_down((unsigned long long)mw, 1, 64);
+    return sh ? ((mw >> sh) | (nx << (64 - sh))) : mw;
+}
+
 // The same for runs of up to 128 words (1-byte types at 8 loads per lane: 16 rows x 8 x 64 lanes = 128 validity
 // words): lane k holds run-words k and 64 + k, fetched by two wave instructions. word(i) hands every lane run-word i
 // when i is wave-uniform, or each lane its own word when it is not.

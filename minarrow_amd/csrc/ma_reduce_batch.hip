@@ -202,6 +202,194 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __r
     }
 }
 
+// ---- columns of a segment or less, one WAVE per column, loads a tile ahead ---------------------------------------------------
+// The chunked regime (8192-row "columns": 8 or 16 tiles a wave's worth each). A scan is fastest with ~8 KiB of loads in
+// flight per SIMD from ONE or TWO waves (ma_reduce.hip's launch shape; eight workgroups per CU on this path read at 6.2 TB/s,
+// one at 6.7: tools/probe_sum_chunks.py) — but with so few waves nobody covers for a wave that has drained its loads at a
+// column's end. So every wave keeps the NEXT tile's loads in flight while it accumulates this one, across column boundaries
+// too: the first tile of column c + W is requested before column c is reduced and stored. Descriptors come a column ahead
+// from the pinned table (wave-uniform loads), requested right after a column's result is out so that no cross-lane step
+// waits on PCIe.
+// TOTAL: the columns are chunks of ONE column (ma_sum_chunks) — nothing is reduced per chunk; the wave's accumulators run on
+// and its one partial goes to partials[wave].
+template <typename T, int UNROLL, bool TOTAL>
+__global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __restrict__ table, size_t n_cols_,
+                                                              Partial* __restrict__ partials) {
+    typedef typename std::conditional<(sizeof(T) <= 2), MaU4, typename Vec16<T>::type>::type V;
+    typedef typename AccOf<T>::type Acc;
+    constexpr int R = 16 / (int)sizeof(T);
+    constexpr int WPT = R * UNROLL;
+    constexpr bool kNarrow = sizeof(T) <= 2;
+    constexpr size_t TILE_ROWS = (size_t)64 * R * UNROLL;
+    static_assert(WPT < 64, "a wave must be able to load its validity words in one instruction");
+    const unsigned lane = threadIdx.x & 63;
+    // Wave-uniform by construction, and said so: the column state lives in scalar registers. 32-bit wherever the value allows
+    // (column indices < 2^30, a column is a segment or less): the scalar unit has no 64-bit ordered compare, and uniform
+    // values that took a detour through vector registers ended up in the tiles' registers — with waits for their loads.
+    const unsigned w_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + (threadIdx.x >> 6)));
+    const unsigned n_w = gridDim.x * kWaves;
+    const unsigned n_cols = (unsigned)n_cols_;
+
+    struct Col {
+        const T* data;
+        const uint64_t* words;
+        size_t bit_off, last_word;
+        unsigned len, head, n_tiles;
+    };
+    auto derive = [&](const ShortCol& e) -> Col {
+        Col c;
+        c.data = (const T*)e.data;
+        c.len = (unsigned)e.len;
+        c.words = c.len ? e.words : nullptr;
+        c.bit_off = e.bit_off;
+        c.last_word = c.len ? (e.bit_off + c.len - 1) >> 6 : 0;
+        const unsigned mis = (unsigned)(uintptr_t)c.data & 15u;
+        c.head = (mis && c.len) ? (16u - mis) / (unsigned)sizeof(T) : 0u;
+        if (c.head > c.len) c.head = c.len;
+        c.n_tiles = (c.len - c.head) / (unsigned)TILE_ROWS;
+        return c;
+    };
+    // always a load (the index is clamped instead of the load being skipped): a conditional one ends in register moves that
+    // wait for the value where it was requested — ~2 us of PCIe per column
+    auto fetch = [&](unsigned col) -> ShortCol {
+        const unsigned i = col < n_cols ? col : n_cols - 1;
+        return table[i];
+    };
+    // Requests tile t of column c — ALWAYS nine loads: with nothing to request (`real` false: the wave's last tile, a column
+    // without a full tile) every lane reads the first bytes of `partials` instead, and a dense column's "validity word" comes
+    // from there too. Loads that are issued on some paths only would make the compiler's wait counts assume the shortest
+    // queue (vmcnt counts in order): the wait for THIS tile would then also wait for most of the next one.
+    auto issue = [&](const Col& c, unsigned t, bool real, V (&v)[UNROLL], uint64_t& raw) {
+        const unsigned row0 = c.head + t * (unsigned)TILE_ROWS;
+        const V* __restrict__ p = real ? (const V*)(c.data + row0) + lane : (const V*)partials;
+        const size_t stride = real ? 64 : 0;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, true>(p + (size_t)u * stride);
+        const bool masked = real && c.words != nullptr;
+        // lane l <= WPT holds run word l (the last one only feeds the funnel shift); clamped, not skipped, past the column's
+        // last word — a full tile never needs a word behind it
+        size_t idx = ((c.bit_off + row0) >> 6) + (lane < (unsigned)WPT ? lane : (unsigned)WPT);
+        idx = idx < c.last_word ? idx : c.last_word;
+        raw = as_global(masked ? c.words : (const uint64_t*)partials)[masked ? idx : 0];
+    };
+
+    Acc acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r].init();
+    uint64_t cnt = 0;
+    auto flush = [&](unsigned slot) {  // lanes and slots -> one partial; the accumulators start over
+#pragma unroll
+        for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc[0].shfl_down_merge(off);
+            cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
+        }
+        if (lane == 0) {
+            Partial p;
+            acc[0].to_partial(p);
+            p.cnt = cnt;
+            p.pad = 0;
+            partials[slot] = p;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r].init();
+        cnt = 0;
+    };
+
+    unsigned col = w_id;
+    if (col >= n_cols) {
+        if (TOTAL) flush(w_id);
+        return;
+    }
+    Col c = derive(fetch(col));
+    ShortCol e_next = fetch(col + n_w);
+    unsigned t = 0;
+    bool have = c.n_tiles > 0;
+    // One step: request the tile after (c, t) into (nv, nraw), then consume (cv, craw) = tile (c, t). Two register sets that
+    // swap roles from step to step (a copy from "next" to "current" would wait for the loads it copies).
+    auto step = [&](V (&cv)[UNROLL], uint64_t& craw, V (&nv)[UNROLL], uint64_t& nraw) __attribute__((always_inline)) -> bool {
+        // the tile after this one: the same column's, or the first of this wave's next column
+        const bool col_done = !(have && t + 1 < c.n_tiles);
+        const unsigned col_n = col + n_w;
+        Col cn = c;
+        unsigned tn = t + 1;
+        bool have_n = !col_done;
+        if (col_done && col_n < n_cols) {
+            cn = derive(e_next);
+            tn = 0;
+            have_n = cn.n_tiles > 0;
+        }
+        issue(cn, tn, have_n, nv, nraw);
+
+        if (have) {
+            const unsigned row0 = c.head + t * (unsigned)TILE_ROWS;
+            if (c.words) {
+                const uint64_t aw = finish_run_words(craw, c.bit_off + row0);
+                if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned bits = lane_bits<R>(aw, u, lane);
+                    if constexpr (kNarrow) {
+                        acc[0].add(narrow_vec_sum<T>(cv[u], bits));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r].add(((bits >> r) & 1u) ? (T)cv[u][r] : (T)0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if constexpr (kNarrow) {
+                        acc[0].add(narrow_vec_sum<T>(cv[u], ~0u));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r].add((T)cv[u][r]);
+                    }
+                }
+            }
+        } else {
+            // nothing was requested for real, but the registers were loaded: "use" them, so that on this path too they are
+            // known to have arrived — otherwise every path's next request waits before it overwrites them
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("" ::"v"(cv[u]));
+            asm volatile("" ::"v"(craw));
+        }
+        if (col_done) {
+            // rows in front of the first 16-byte boundary and behind the last full tile
+            const unsigned tail0 = c.head + c.n_tiles * (unsigned)TILE_ROWS;
+            const unsigned n_ragged = c.head + (c.len - tail0);
+            for (unsigned i = lane; i < n_ragged; i += 64) {
+                const unsigned row = i < c.head ? i : tail0 + (i - c.head);
+                T x = c.data[row];
+                if (c.words) {
+                    const unsigned valid = row_bit(c.words, c.bit_off + row);
+                    cnt += valid;
+                    x = valid ? x : (T)0;
+                }
+                acc[0].add(x);
+            }
+            if (!c.words && lane == 0) cnt += c.len;
+            if (!TOTAL) flush(col);
+            if (col_n >= n_cols) return false;
+            col = col_n;
+            e_next = fetch(col + n_w);  // a column ahead, and behind the cross-lane steps of flush()
+            c = cn;
+        }
+        t = tn;
+        have = have_n;
+        return true;
+    };
+    V va[UNROLL], vb[UNROLL];
+    uint64_t raw_a = 0, raw_b = 0;
+    issue(c, 0, have, va, raw_a);
+    for (;;) {
+        if (!step(va, raw_a, vb, raw_b)) break;
+        if (!step(vb, raw_b, va, raw_a)) break;
+    }
+    if (TOTAL) flush(w_id);
+}
+
 // One wave per column: fold the column's partials in index order per lane, then across lanes.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void column_fold_kernel(const ColDesc* __restrict__ cols, int n_cols, size_t n_segs,
@@ -333,8 +521,30 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
                            Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc, bool total = false,
                            Partial* partials2 = nullptr, double* olo = nullptr) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
-    if (short_table) {
-        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
+    size_t n_short_partials = n_cols;  // short form: partial c = column c, or (total) partial w = wave w
+    if (short_table && !(ctx->variant & 4096)) {
+        // one or two waves per SIMD with ~8 KiB of loads each in flight AND a tile requested ahead (column_waves_kernel);
+        // ctx->variant bits 1-3 / blocks_per_cu override the shape for sweeps (tools/probe_sum_chunks.py)
+        // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks.jsonl): two waves per SIMD; 8-byte rows with eight loads
+        // per tile (i64 / f64 6.9 TB/s dense, 6.7 with validity, end to end, against 7.3 for the plain sum of the same
+        // bytes), 4-byte rows with four (6.6 / 6.4). One wave per SIMD can be a few per cent faster still, or 15 % slower,
+        // depending on how much of the tile ahead the compiler's wait counts leave in flight: not the default.
+        constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
+        const int sel = (ctx->variant >> 1) & 7;
+        const bool deep = sizeof(T) >= 4 && (sel == 3 || (sel == 0 && sizeof(T) == 8));
+        const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 2;
+        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, bpc);
+        if (total) n_short_partials = (size_t)grid1 * kWaves;
+        if (deep) {
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+        } else {
+            constexpr int U1 = sizeof(T) == 8 ? 4 : UNROLL;
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+        }
+    } else if (short_table) {  // variant bit 4096: round 3's first shape (eight workgroups per CU, no tile ahead), for A/B
+        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8);
         hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream,
                            (const void*)short_table, (int)n_cols, n_cols, partials);
     } else {
@@ -345,7 +555,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
     }
     if (total) {
         const Partial* src = partials;
-        size_t n = short_table ? n_cols : n_segs;
+        size_t n = short_table ? n_short_partials : n_segs;
         if (n > 4096) {  // level 1: up to 1024 workgroups x 4 waves, each wave a contiguous slice
             const size_t waves = 4096;
             const size_t per = (n + waves - 1) / waves;
@@ -460,7 +670,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     if (total) MA_TRY(scope.out(out_lo, 8, &olo));
 
     // descriptors (segment form) + partials in one scratch allocation
-    const size_t n_partials = all_short ? n_cols : (n_segs ? n_segs : 1);
+    const size_t n_partials = all_short ? n_cols + kWaves : (n_segs ? n_segs : 1);  // + kWaves: a total's partial per WAVE, grid rounded up
     const size_t desc_bytes = all_short ? 0 : ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
     void* scratch = nullptr;
     MA_TRY(ctx_scratch(ctx, desc_bytes + sizeof(Partial) * (n_partials + (total ? 4096 : 0)), &scratch));

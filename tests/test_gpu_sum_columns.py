@@ -197,3 +197,51 @@ def test_sum_chunks_is_the_sum_of_the_consolidated_column(ctx, fmt, shape):
     if fmt in "fg" and lens:
         exact = math.fsum(np.concatenate(cols).astype(np.float64).tolist())
         assert abs(f2 - exact) <= math.ulp(exact)
+
+
+@pytest.mark.parametrize("fmt", ["l", "g", "i", "f", "s", "C"])
+def test_short_columns_with_few_waves_walk_many_columns_each(ctx, fmt):
+    """The wave-per-column kernel keeps the next tile requested while it works on this one, ACROSS column boundaries: with
+    the grid cut to 3 or 1 workgroups every wave walks hundreds of columns (full tiles, no full tile, empty, misaligned,
+    dense next to masked), at both tile depths, per column and as one total — and the first shape of the round (variant
+    bit 4096) must give the same integers / floats within 1 ULP of the exact sum."""
+    rng = np.random.default_rng(ord(fmt) + 99)
+    lens = [int(x) for x in rng.choice([0, 1, 63, 64, 65, 1000, 2048, 4096, 4097, 8192, 8191, 12_345], size=1500)]
+    cols = make_columns(rng, fmt, lens)
+    arena = np.concatenate([np.concatenate([np.zeros(1, c.dtype), c]) for c in cols])
+    starts = np.cumsum([0] + [c.size + 1 for c in cols[:-1]]) + 1
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + int(s) * arena.itemsize for s in starts]
+    masks, offs, d_masks = [], [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0 or n == 0:
+            masks.append(None); offs.append(0); d_masks.append(None)
+        else:
+            off = [0, 3, 64, 77][i % 4]
+            m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+            masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+    valid = [np.unpackbits(m, bitorder="little")[o:o + n].astype(bool) if m is not None else np.ones(n, dtype=bool)
+             for m, o, n in zip(masks, offs, lens)]
+    want_cnt = np.array([v.sum() for v in valid], dtype=np.uint64)
+    sel = [c[v] for c, v in zip(cols, valid)]
+    try:
+        for grid, variant in ((3, 0), (1, 4), (3, 6), (0, 4096), (2, 4096)):
+            ctx.set_grid(grid)
+            ctx.set_variant(variant)
+            f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+            np.testing.assert_array_equal(cnt, want_cnt)
+            tf, ti, tc = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+            assert tc == int(want_cnt.sum())
+            if fmt in "fg":
+                for k, s in enumerate(sel):
+                    exact = math.fsum(s.astype(np.float64).tolist())
+                    assert abs(f[k] - exact) <= math.ulp(exact), (grid, variant, k)
+                exact = math.fsum(np.concatenate(sel).astype(np.float64).tolist())
+                assert abs(tf - exact) <= math.ulp(exact), (grid, variant)
+            else:
+                want = [int(s.astype(object).sum()) if s.size else 0 for s in sel]
+                assert all((int(a) - w) % (1 << 64) == 0 for a, w in zip(i64, want)), (grid, variant)
+                assert (int(ti) - sum(want)) % (1 << 64) == 0, (grid, variant)
+    finally:
+        ctx.set_grid(0)
+        ctx.set_variant(0)

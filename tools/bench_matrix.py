@@ -148,18 +148,18 @@ def main():
                                                 res.ptr + 8 * 65536 if tag != "f64" else None, res.ptr + 16 * 65536)
                     assert st == 0, st
 
-                ms = timed(lambda: call(False))
+                ms = timed(lambda: call(False), prime=k >= 1000)
                 emit("sum_columns", tag, f"{k} columns of {per} rows, dense", ms, k * per * SIZE[tag], k * per)
-                ms = timed(lambda: call(True))
+                ms = timed(lambda: call(True), prime=k >= 1000)
                 emit("sum_columns", tag, f"{k} columns of {per} rows, 10% nulls", ms, k * per * SIZE[tag] + k * per / 8, k * per)
                 if k == 60000:  # the same chunk list as ONE column: a single {sum, count} (ma_sum_chunks)
                     def total(masked):
                         st = ctx.lib.ma_sum_chunks(ctx.handle, ord(fmt), k, ptrs, lens, mks if masked else None, None, res.ptr,
                                                    res.ptr + 8 * 65536 if tag != "f64" else None, res.ptr + 16 * 65536)
                         assert st == 0, st
-                    ms = timed(lambda: total(False))
+                    ms = timed(lambda: total(False), prime=True)
                     emit("sum_chunks", tag, f"one column as {k} chunks of {per} rows, dense", ms, k * per * SIZE[tag], k * per)
-                    ms = timed(lambda: total(True))
+                    ms = timed(lambda: total(True), prime=True)
                     emit("sum_chunks", tag, f"one column as {k} chunks of {per} rows, 10% nulls", ms, k * per * SIZE[tag] + k * per / 8, k * per)
         ctx.set_async(False)
         ctx.synchronize()
