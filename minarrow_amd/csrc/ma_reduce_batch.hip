@@ -41,12 +41,19 @@ struct ShortCol {
 // 4.4 TB/s against the single-column kernel's 6.1.
 constexpr size_t seg_rows(size_t elem) { return elem >= 4 ? ((size_t)1 << 16) : ((size_t)1 << 19) / elem; }
 
-__device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_cols, size_t seg) {
-    int lo = 0, hi = n_cols - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (c[mid].seg0 <= seg) lo = mid;
-        else hi = mid - 1;
+// The column of segment `seg`: the LAST c with cols[c].seg0 <= seg (an empty column shares its seg0 with the next one).
+// 64 probes at a time, one per lane, instead of a bisection: two dependent loads for up to 4096 columns where the bisection
+// made twelve — a workgroup streams nothing while it looks for its next segment.
+__device__ __forceinline__ int find_col(const ColDesc* __restrict__ c, int n_cols, size_t seg, unsigned lane) {
+    int lo = 0, n = n_cols;  // the answer lies in [lo, lo + n); c[lo].seg0 <= seg throughout
+    while (n > 1) {
+        const int step = (n + 63) >> 6;
+        const int idx = lo + (int)lane * step;
+        const bool le = idx < lo + n && c[idx].seg0 <= seg;
+        const int k = __popcll(__ballot(le)) - 1;  // the predicate is monotone over the lanes; lane 0 holds
+        const int end = lo + n;
+        lo += k * step;
+        n = end - lo < step ? end - lo : step;
     }
     return lo;
 }
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __r
             d.seg0 = seg;
             e = e_next;
         } else {
-            d = cols[find_col(cols, n_cols, seg)];  // workgroup-uniform
+            d = cols[__builtin_amdgcn_readfirstlane(find_col(cols, n_cols, seg, lane))];  // workgroup-uniform
         }
         constexpr size_t kSegRows = seg_rows(sizeof(T));
         const size_t r_begin = (seg - d.seg0) * kSegRows;
@@ -512,6 +519,36 @@ __global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __res
     if (out_cnt) *out_cnt = c;
 }
 
+// ---- long columns through the same wave kernel ------------------------------------------------------------------------------
+// Rows per PIECE (64 KiB) when a table of MANY long 1- or 2-byte columns is large enough to keep every wave busy with many
+// pieces: the chunked regime's shape. In-process A/B at 1000 columns of 8.2 segments each (tools/probe_sum_chunks.py
+// 0,4096 0 u8,i16 1000x4294912): u8 6.44 -> 6.76 TB/s dense and 5.09 -> 5.96 with validity, i16 with validity 5.72 -> 6.26
+// (dense 6.84 -> 6.65: stays on segments); i32 / i64 / f64 gain nothing (6.55 either way) and stay on segments, as do few very
+// long columns. The pieces are described ON the device: one thread per piece finds its column and writes a ShortCol;
+// ColDesc::seg0 then counts pieces.
+constexpr size_t piece_rows(size_t elem) { return ((size_t)1 << 16) / elem; }
+constexpr size_t kMinPieces = 16384;  // 8 per wave at two workgroups per CU: below that, segments and workgroups
+
+__global__ __launch_bounds__(kBlock) void expand_pieces_kernel(const ColDesc* __restrict__ cols, int n_cols, size_t n_pieces,
+                                                               size_t rows_per_piece, size_t elem, ShortCol* __restrict__ out) {
+    const size_t s = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_pieces) return;
+    int lo = 0, hi = n_cols - 1;  // the last column whose first piece is <= s (an empty column shares its seg0 with the next)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cols[mid].seg0 <= s) lo = mid;
+        else hi = mid - 1;
+    }
+    const ColDesc d = cols[lo];
+    const size_t off = (s - d.seg0) * rows_per_piece;
+    ShortCol e;
+    e.data = (const char*)d.data + off * elem;
+    e.len = d.len - off < rows_per_piece ? d.len - off : rows_per_piece;
+    e.words = d.words;
+    e.bit_off = d.bit_off + off;
+    out[s] = e;
+}
+
 // short_table != nullptr: every column is a segment or less — a wave per column on the ShortCol table (read in place),
 // partial c = column c; otherwise a workgroup per segment on the uploaded ColDesc table.
 // total: one {sum, count} over all columns (they are the chunks of ONE logical column) instead of one per column;
@@ -519,29 +556,36 @@ __global__ __launch_bounds__(kBlock) void total_fold_kernel(const Partial* __res
 template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_table, size_t n_cols, size_t n_segs,
                            Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc, bool total = false,
-                           Partial* partials2 = nullptr, double* olo = nullptr) {
+                           Partial* partials2 = nullptr, double* olo = nullptr, ShortCol* expand_to = nullptr) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
-    size_t n_short_partials = n_cols;  // short form: partial c = column c, or (total) partial w = wave w
-    if (short_table && !(ctx->variant & 4096)) {
+    size_t n_short = n_cols;  // entries of the short table: columns, or the pieces of long columns (expand_to)
+    if (expand_to) {
+        hipLaunchKernelGGL(expand_pieces_kernel, dim3((unsigned)((n_segs + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, d,
+                           (int)n_cols, n_segs, piece_rows(sizeof(T)), sizeof(T), expand_to);
+        short_table = expand_to;
+        n_short = n_segs;
+    }
+    size_t n_short_partials = n_short;  // short form: partial c = entry c, or (total) partial w = wave w
+    if (short_table && (expand_to || !(ctx->variant & 4096))) {
         // one or two waves per SIMD with ~8 KiB of loads each in flight AND a tile requested ahead (column_waves_kernel);
         // ctx->variant bits 1-3 / blocks_per_cu override the shape for sweeps (tools/probe_sum_chunks.py)
         // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks.jsonl): two waves per SIMD; 8-byte rows with eight loads
-        // per tile (i64 / f64 6.9 TB/s dense, 6.7 with validity, end to end, against 7.3 for the plain sum of the same
-        // bytes), 4-byte rows with four (6.6 / 6.4). One wave per SIMD can be a few per cent faster still, or 15 % slower,
+        // per tile (i64 / f64 6.7-6.9 TB/s dense, 6.5-6.7 with validity, end to end, against 7.3 for the plain sum of the
+        // same bytes), 4-byte rows with four (6.5-6.6 / 6.1-6.4). One wave per SIMD can be a few per cent faster still, or 15 % slower,
         // depending on how much of the tile ahead the compiler's wait counts leave in flight: not the default.
         constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
         const int sel = (ctx->variant >> 1) & 7;
         const bool deep = sizeof(T) >= 4 && (sel == 3 || (sel == 0 && sizeof(T) == 8));
         const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 2;
-        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, bpc);
+        const int grid1 = grid_for(ctx, (n_short + kWaves - 1) / kWaves, bpc);
         if (total) n_short_partials = (size_t)grid1 * kWaves;
         if (deep) {
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
         } else {
             constexpr int U1 = sizeof(T) == 8 ? 4 : UNROLL;
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_cols, partials);
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
         }
     } else if (short_table) {  // variant bit 4096: round 3's first shape (eight workgroups per CU, no tile ahead), for A/B
         const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8);
@@ -549,7 +593,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
                            (const void*)short_table, (int)n_cols, n_cols, partials);
     } else {
         // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip)
-        const int grid1 = grid_for(ctx, n_segs, sizeof(T) == 1 ? 3 : 2);
+        const int grid1 = grid_for(ctx, n_segs, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : sizeof(T) == 1 ? 3 : 2);
         hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, (const void*)d,
                            (int)n_cols, n_segs, partials);
     }
@@ -570,7 +614,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
     }
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
     hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
-                       (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc, short_table ? 1 : 0);
+                       (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc, (short_table && !expand_to) ? 1 : 0);
 }
 
 }  // namespace ma
@@ -621,6 +665,17 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
     bool all_short = n_cols >= 256;  // below that the table copy is a few microseconds and the segment form is as good
     for (size_t i = 0; i < n_cols && all_short; ++i) all_short = col_lens[i] <= seg_rows(elem);
+    // Long columns, enough of them for every wave to take many pieces: described per column, cut into pieces on the device and
+    // summed by the same wave kernel (expand_pieces_kernel). variant bit 4096: segments and workgroups, for A/B.
+    size_t n_pieces = 0, n_long_segs = 0;
+    if (!all_short && elem <= 2 && !(ctx->variant & 4096))
+        for (size_t i = 0; i < n_cols; ++i) {
+            n_pieces += (col_lens[i] + piece_rows(elem) - 1) / piece_rows(elem);
+            n_long_segs += (col_lens[i] + seg_rows(elem) - 1) / seg_rows(elem);
+        }
+    const bool expand = (elem == 1 || (elem == 2 && col_masks != nullptr)) && n_pieces >= kMinPieces &&
+                        n_pieces < ((size_t)1 << 30) && n_long_segs < 32 * n_cols;
+    const size_t rows_per_seg = expand ? piece_rows(elem) : seg_rows(elem);
     ColDesc* desc = nullptr;  // either table is built in the context's pinned staging buffer: no second copy of 60 000 entries
     ShortCol* sdesc = nullptr;
     if (all_short) MA_TRY(table_begin(ctx, sizeof(ShortCol) * n_cols, (void**)&sdesc));
@@ -658,7 +713,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
             d.bit_off = bit_off;
             d.last_word = words ? (bit_off + d.len - 1) >> 6 : 0;
             d.seg0 = n_segs;
-            n_segs += d.len ? (d.len + seg_rows(elem) - 1) / seg_rows(elem) : 0;  // an empty column has no segment: its fold is {0, 0}
+            n_segs += d.len ? (d.len + rows_per_seg - 1) / rows_per_seg : 0;  // an empty column has no segment: its fold is {0, 0}
         }
     }
     void *of = nullptr, *oi = nullptr, *oc = nullptr;
@@ -669,13 +724,15 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     void* olo = nullptr;
     if (total) MA_TRY(scope.out(out_lo, 8, &olo));
 
-    // descriptors (segment form) + partials in one scratch allocation
-    const size_t n_partials = all_short ? n_cols + kWaves : (n_segs ? n_segs : 1);  // + kWaves: a total's partial per WAVE, grid rounded up
-    const size_t desc_bytes = all_short ? 0 : ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
+    // descriptors (segment form) + the pieces' table + partials in one scratch allocation
+    const size_t n_partials = all_short ? n_cols + kWaves : (n_segs ? n_segs : 1) + kWaves;  // + kWaves: a total's partial per WAVE, grid rounded up
+    const size_t col_bytes = all_short ? 0 : ((sizeof(ColDesc) * n_cols + 255) / 256) * 256;
+    const size_t desc_bytes = col_bytes + (expand ? ((sizeof(ShortCol) * n_segs + 255) / 256) * 256 : 0);
     void* scratch = nullptr;
     MA_TRY(ctx_scratch(ctx, desc_bytes + sizeof(Partial) * (n_partials + (total ? 4096 : 0)), &scratch));
     const ColDesc* d = nullptr;
     const ShortCol* sd = nullptr;
+    ShortCol* pieces = expand ? (ShortCol*)((char*)scratch + col_bytes) : nullptr;
     int slot = -1;
     if (all_short) {
         const void* alias = nullptr;
@@ -688,16 +745,16 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     Partial* partials2 = partials + n_partials;  // level-1 results of the total fold
     switch (format_code) {
-        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
-        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo); break;
+        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
     }
     MA_HIP(hipGetLastError());
     if (slot >= 0) MA_TRY(table_release(ctx, slot));

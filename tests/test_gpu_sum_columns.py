@@ -245,3 +245,49 @@ def test_short_columns_with_few_waves_walk_many_columns_each(ctx, fmt):
     finally:
         ctx.set_grid(0)
         ctx.set_variant(0)
+
+
+@pytest.mark.parametrize("fmt", ["s", "S", "C", "c"])
+def test_long_columns_of_a_large_table_are_cut_into_pieces_on_the_device(ctx, fmt):
+    """From 16 384 pieces of 64 KiB a table of many LONG 1- or 2-byte columns is described per column, cut into pieces by a kernel and summed
+    by the wave kernel: 405 ragged columns of 17 000 pieces in all — empty ones, one of a single row, starts off the 16-byte
+    grid, validity at odd bit offsets on a third — per column and as one total, against numpy, and against the segment
+    form (variant bit 4096)."""
+    rng = np.random.default_rng(ord(fmt) + 5)
+    dt = NP[fmt]
+    isz = np.dtype(dt).itemsize
+    piece = 65_536 // isz
+    total_rows = 17_000 * piece
+    lens = [int(x) for x in rng.integers(1, 2 * total_rows // 400, size=400)]
+    lens[3], lens[20], lens[35] = 0, 1, piece  # empty, one row, exactly one piece
+    lens += [0, 7 * piece + 13, 0, 5, piece - 1]
+    info = np.iinfo(dt)
+    arena = rng.integers(info.min, int(info.max) + 1, size=sum(lens) + len(lens), dtype=dt)
+    starts = np.cumsum([0] + [n + 1 for n in lens[:-1]]) + 1  # one element between columns: every phase of the 16-byte grid
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + int(s) * isz for s in starts]
+    masks, offs, d_masks = [], [], []
+    for i, n in enumerate(lens):
+        if i % 3 != 1 or n == 0:
+            masks.append(None); offs.append(0); d_masks.append(None)
+        else:
+            off = [3, 64, 77][i % 3]
+            m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+            masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+    want_sum, want_cnt = [], []
+    for s0, n, m, o in zip(starts, lens, masks, offs):
+        c = arena[int(s0):int(s0) + n].astype(np.int64)
+        v = np.unpackbits(m, bitorder="little")[o:o + n].astype(bool) if m is not None else np.ones(n, dtype=bool)
+        want_sum.append(int(c[v].sum()))
+        want_cnt.append(int(v.sum()))
+    try:
+        for variant in (0, 4096):
+            ctx.set_variant(variant)
+            f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+            np.testing.assert_array_equal(cnt, np.array(want_cnt, dtype=np.uint64))
+            tf, ti, tc = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+            assert tc == sum(want_cnt)
+            assert [int(x) for x in i64] == want_sum, variant
+            assert int(ti) == sum(want_sum)
+    finally:
+        ctx.set_variant(0)

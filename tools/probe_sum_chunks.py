@@ -12,6 +12,8 @@ from minarrow_amd.host import Context  # noqa: E402
 
 ctx = Context(0)
 k, per = 60_000, 8192
+if len(sys.argv) > 4:  # e.g. 1000x536832: the workgroup-per-segment form (columns longer than a segment)
+    k, per = (int(x) for x in sys.argv[4].split("x"))
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "4096", "8192", "12288"])]
 bpcs = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
