@@ -40,6 +40,9 @@ step "lanes"; timeout -k 10 200 python3 tools/bench_lanes.py > $O/${R}_lanes.jso
 step "record-batch streams: ingestion and the stream operator at chunk-sized and large batches"
 for a in "8192 20000" "65536 2000" "262144 500" "1000000 128" "8000000 32"; do timeout -k 10 200 python3 tools/bench_stream_ingest.py $a 2>/dev/null | tail -1; done > $O/${R}_stream_ingest.jsonl
 for a in "8192 5000" "65536 1000" "262144 250" "1000000 64"; do timeout -k 10 200 python3 tools/bench_stream_op.py $a 2>/dev/null | tail -1; done > $O/${R}_stream_op.jsonl
+step "chunk-list sums: the shipped wave kernel against the round's first shape, and pieces against segments"
+timeout -k 10 300 python3 tools/probe_sum_chunks.py 0,4096 0,1,2,3 > $O/${R}_sweep_sum_chunks.jsonl 2>/dev/null || exit 1
+timeout -k 10 200 python3 tools/probe_sum_chunks.py 0,4096 0 u8,i16 1000x4294912 > $O/${R}_sweep_sum_pieces.jsonl 2>/dev/null || exit 1
 step "simd_eq_mask shapes"; timeout -k 10 200 python3 tools/sweep_eq_mask.py > $O/${R}_sweep_eq_mask.jsonl 2>/dev/null || exit 1
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write
 ls -la $O
