@@ -315,7 +315,12 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
     bool have = c.n_tiles > 0;
     // One step: request the tile after (c, t) into (nv, nraw), then consume (cv, craw) = tile (c, t). Two register sets that
     // swap roles from step to step (a copy from "next" to "current" would wait for the loads it copies).
-    auto step = [&](V (&cv)[UNROLL], uint64_t& craw, V (&nv)[UNROLL], uint64_t& nraw) __attribute__((always_inline)) -> bool {
+    // (Both steps of the loop below always run and the loop leaves at its end only: a step after the wave's last column
+    // requests and "uses" nine loads like any other and skips the column's end. With an exit between the steps the exit shared
+    // its branch with the loop's end, and the compiler's wait counts — which follow every path the branches allow, taken or
+    // not — held each step's requests back until most of the tile before them had arrived.)
+    bool finished = false;
+    auto step = [&](V (&cv)[UNROLL], uint64_t& craw, V (&nv)[UNROLL], uint64_t& nraw) __attribute__((always_inline)) {
         // the tile after this one: the same column's, or the first of this wave's next column
         const bool col_done = !(have && t + 1 < c.n_tiles);
         const unsigned col_n = col + n_w;
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
                         for (int r = 0; r < R; ++r) acc[r].add((T)cv[u][r]);
                     }
                 }
+                asm volatile("" ::"v"(craw));  // loaded, not needed: "used" all the same (see below)
             }
         } else {
             // nothing was requested for real, but the registers were loaded: "use" them, so that on this path too they are
@@ -363,37 +369,41 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
             asm volatile("" ::"v"(craw));
         }
         if (col_done) {
-            // rows in front of the first 16-byte boundary and behind the last full tile
-            const unsigned tail0 = c.head + c.n_tiles * (unsigned)TILE_ROWS;
-            const unsigned n_ragged = c.head + (c.len - tail0);
-            for (unsigned i = lane; i < n_ragged; i += 64) {
-                const unsigned row = i < c.head ? i : tail0 + (i - c.head);
-                T x = c.data[row];
-                if (c.words) {
-                    const unsigned valid = row_bit(c.words, c.bit_off + row);
-                    cnt += valid;
-                    x = valid ? x : (T)0;
+            if (!finished) {
+                // rows in front of the first 16-byte boundary and behind the last full tile
+                const unsigned tail0 = c.head + c.n_tiles * (unsigned)TILE_ROWS;
+                const unsigned n_ragged = c.head + (c.len - tail0);
+                for (unsigned i = lane; i < n_ragged; i += 64) {
+                    const unsigned row = i < c.head ? i : tail0 + (i - c.head);
+                    T x = c.data[row];
+                    if (c.words) {
+                        const unsigned valid = row_bit(c.words, c.bit_off + row);
+                        cnt += valid;
+                        x = valid ? x : (T)0;
+                    }
+                    acc[0].add(x);
                 }
-                acc[0].add(x);
+                if (!c.words && lane == 0) cnt += c.len;
+                if (!TOTAL) flush(col);
             }
-            if (!c.words && lane == 0) cnt += c.len;
-            if (!TOTAL) flush(col);
-            if (col_n >= n_cols) return false;
-            col = col_n;
-            e_next = fetch(col + n_w);  // a column ahead, and behind the cross-lane steps of flush()
-            c = cn;
+            if (col_n >= n_cols) {
+                finished = true;
+            } else {
+                col = col_n;
+                e_next = fetch(col + n_w);  // a column ahead, and behind the cross-lane steps of flush()
+                c = cn;
+            }
         }
         t = tn;
         have = have_n;
-        return true;
     };
     V va[UNROLL], vb[UNROLL];
     uint64_t raw_a = 0, raw_b = 0;
     issue(c, 0, have, va, raw_a);
-    for (;;) {
-        if (!step(va, raw_a, vb, raw_b)) break;
-        if (!step(vb, raw_b, va, raw_a)) break;
-    }
+    do {
+        step(va, raw_a, vb, raw_b);
+        step(vb, raw_b, va, raw_a);
+    } while (!finished);
     if (TOTAL) flush(w_id);
 }
 
@@ -556,7 +566,8 @@ __global__ __launch_bounds__(kBlock) void expand_pieces_kernel(const ColDesc* __
 template <typename T>
 static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_table, size_t n_cols, size_t n_segs,
                            Partial* partials, bool is_signed, double* of, uint64_t* oi, uint64_t* oc, bool total = false,
-                           Partial* partials2 = nullptr, double* olo = nullptr, ShortCol* expand_to = nullptr) {
+                           Partial* partials2 = nullptr, double* olo = nullptr, ShortCol* expand_to = nullptr,
+                           bool any_masked = false) {
     constexpr int UNROLL = sizeof(T) == 8 ? 8 : sizeof(T) == 1 ? 2 : 4;  // R * UNROLL <= 32 validity words per wave
     size_t n_short = n_cols;  // entries of the short table: columns, or the pieces of long columns (expand_to)
     if (expand_to) {
@@ -569,14 +580,17 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
     if (short_table && (expand_to || !(ctx->variant & 4096))) {
         // one or two waves per SIMD with ~8 KiB of loads each in flight AND a tile requested ahead (column_waves_kernel);
         // ctx->variant bits 1-3 / blocks_per_cu override the shape for sweeps (tools/probe_sum_chunks.py)
-        // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks.jsonl): two waves per SIMD; 8-byte rows with eight loads
-        // per tile (i64 / f64 6.7-6.9 TB/s dense, 6.5-6.7 with validity, end to end, against 7.3 for the plain sum of the
-        // same bytes), 4-byte rows with four (6.5-6.6 / 6.1-6.4). One wave per SIMD can be a few per cent faster still, or 15 % slower,
-        // depending on how much of the tile ahead the compiler's wait counts leave in flight: not the default.
+        // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks.jsonl): ONE wave per SIMD with eight loads per tile — sixteen
+        // in flight with the tile ahead — for 4- and 8-byte rows: i64 / f64 / i32 6.7-6.8 TB/s dense AND with validity, end to
+        // end, against 7.2-7.3 for the plain sum of the same bytes (two waves per SIMD: 6.4-6.7; the round's first shape, eight
+        // workgroups per CU and no tile ahead: 6.3-6.4, i32 5.9). The 1- and 2-byte types keep their shallower tiles (the
+        // validity words of a tile must fit one load instruction) on two waves per SIMD.
         constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
         const int sel = (ctx->variant >> 1) & 7;
-        const bool deep = sizeof(T) >= 4 && (sel == 3 || (sel == 0 && sizeof(T) == 8));
-        const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 2;
+        const bool deep = sizeof(T) >= 4 && sel != 2;
+        // (f32 with validity — widened to f64, four double-double accumulators per load — is ALU-bound on one wave: 5.2 -> 5.9)
+        const bool two = sizeof(T) < 4 || (std::is_same<T, float>::value && any_masked);
+        const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : two ? 2 : 1;
         const int grid1 = grid_for(ctx, (n_short + kWaves - 1) / kWaves, bpc);
         if (total) n_short_partials = (size_t)grid1 * kWaves;
         if (deep) {
@@ -684,6 +698,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     // the chunks of a chunked column (one "column" each: 122 000 per 10^9 rows at RechunkStrategy::Auto) run through a few
     // allocations: each role remembers the device range of its last pointer — two compares instead of a classification
     DeviceRange data_role, mask_role;
+    bool any_masked = false;
     for (size_t i = 0; i < n_cols; ++i) {
         const void* data = col_data[i];
         if (!data_role.holds(data)) {
@@ -703,6 +718,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
                 mask_role.learn(col_masks[i]);
             }
         }
+        any_masked |= words != nullptr;
         if (all_short) {
             sdesc[i] = ShortCol{data, col_lens[i], words, bit_off};
         } else {
@@ -745,16 +761,16 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     Partial* partials = (Partial*)((char*)scratch + desc_bytes);
     Partial* partials2 = partials + n_partials;  // level-1 results of the total fold
     switch (format_code) {
-        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
-        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces); break;
+        case 'c': launch_columns<int8_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'C': launch_columns<uint8_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 's': launch_columns<int16_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'S': launch_columns<uint16_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'i': launch_columns<int32_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'I': launch_columns<uint32_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'l': launch_columns<int64_t>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'L': launch_columns<uint64_t>(ctx, d, sd, n_cols, n_segs, partials, false, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        case 'f': launch_columns<float>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
+        default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
     }
     MA_HIP(hipGetLastError());
     if (slot >= 0) MA_TRY(table_release(ctx, slot));
