@@ -291,3 +291,24 @@ def test_long_columns_of_a_large_table_are_cut_into_pieces_on_the_device(ctx, fm
             assert int(ti) == sum(want_sum)
     finally:
         ctx.set_variant(0)
+
+
+def test_segment_form_finds_its_column_among_thousands(ctx):
+    """One column longer than a segment sends the whole table through the workgroup-per-segment form, whose column search
+    probes 64 entries at a time: 9000 columns (three rounds of probes), empty ones in runs (they share their first segment
+    with the next column), two long ones at the ends and one in the middle."""
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.choice([0, 0, 1, 5, 64, 300, 1000], size=9000)]
+    lens[0], lens[4500], lens[-1] = 70_000, 200_001, 65_537
+    lens[10:30] = [0] * 20
+    lens[-5:-1] = [0] * 4
+    cols = [rng.integers(-(1 << 40), 1 << 40, size=n, dtype=np.int64) for n in lens]
+    arena = np.concatenate(cols)
+    starts = np.cumsum([0] + lens[:-1])
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + int(s) * 8 for s in starts]
+    f, i64, cnt = ctx.sum_columns("l", ptrs, lens)
+    np.testing.assert_array_equal(cnt, np.array(lens, dtype=np.uint64))
+    np.testing.assert_array_equal(i64, np.array([int(c.sum()) for c in cols], dtype=np.int64))
+    tf, ti, tc = ctx.sum_chunks("l", ptrs, lens)
+    assert tc == sum(lens) and int(ti) == int(arena.sum())
