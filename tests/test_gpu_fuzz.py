@@ -249,6 +249,63 @@ def test_sum_columns(ctx, fmt, lens, starts, with_masks, seed):
             assert (int(i64[k]) - want) % (1 << 64) == 0
 
 
+SHORT = [0, 0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095,
+         4096, 4097, 8191, 8192]
+
+
+@settings(**COMMON)
+@given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g", "c", "C", "s", "S"]), n_cols=st.integers(256, 700),
+       gap=st.integers(0, 3), mask_mode=st.sampled_from(["none", "some", "all"]), grid=st.sampled_from([0, 0, 1, 2, 7]),
+       variant=st.sampled_from([0, 0, 4, 6]), seed=st.integers(0, 2**31))
+def test_sum_short_columns(ctx, fmt, n_cols, gap, mask_mode, grid, variant, seed):
+    """From 256 columns of a segment or less each: a WAVE per column with the next tile requested ahead, across columns
+    (`column_waves_kernel`) — per column (ma_sum_columns) and as one total (ma_sum_chunks), on grids so small that a wave
+    walks hundreds of columns, at both tile depths, every 16-byte phase, validity at any bit offset on none / some / all."""
+    rng = np.random.default_rng(seed)
+    dt = np.dtype({"i": np.int32, "I": np.uint32, "l": np.int64, "L": np.uint64, "f": np.float32, "g": np.float64,
+                   "c": np.int8, "C": np.uint8, "s": np.int16, "S": np.uint16}[fmt])
+    lens = [int(x) for x in rng.choice(SHORT, size=n_cols)]
+    starts, pos = [], int(rng.integers(0, 4))
+    for n in lens:
+        starts.append(pos)
+        pos += n + gap
+    arena = rand_values(rng, dt, pos + 16)
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + s * dt.itemsize for s in starts]
+    mbytes = rng.integers(0, 256, size=sum((n + 7) // 8 + 24 for n in lens) + 64, dtype=np.uint8)
+    dmask = ctx.to_device(mbytes, 16)
+    mptrs, offs, valid, mpos = [], [], [], 0
+    for i, n in enumerate(lens):
+        masked = n > 0 and (mask_mode == "all" or (mask_mode == "some" and i % 3 != 0))
+        off = int(rng.integers(0, 130)) if masked else 0
+        mptrs.append(dmask.ptr + mpos if masked else None)
+        offs.append(off)
+        valid.append(np.unpackbits(mbytes[mpos:mpos + (off + n + 7) // 8 + 1], bitorder="little")[off:off + n].astype(bool)
+                     if masked else np.ones(n, bool))
+        mpos += (n + 7) // 8 + 24
+    sel = [arena[s:s + n][v] for s, n, v in zip(starts, lens, valid)]
+    try:
+        ctx.set_grid(grid)
+        ctx.set_variant(variant)
+        f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, mptrs if mask_mode != "none" else None, offs if mask_mode != "none" else None)
+        tf, ti, tc = ctx.sum_chunks(fmt, ptrs, lens, mptrs if mask_mode != "none" else None, offs if mask_mode != "none" else None)
+    finally:
+        ctx.set_grid(0)
+        ctx.set_variant(0)
+    np.testing.assert_array_equal(cnt, np.array([v.sum() for v in valid], dtype=np.uint64))
+    assert tc == sum(int(v.sum()) for v in valid)
+    if dt.kind == "f":
+        for k, x in enumerate(sel):
+            exact = math.fsum(x.astype(np.float64).tolist())
+            assert abs(f[k] - exact) <= math.ulp(exact), k
+        exact = math.fsum(np.concatenate(sel).astype(np.float64).tolist())
+        assert abs(tf - exact) <= math.ulp(exact)
+    else:
+        want = [int(x.astype(object).sum()) if x.size else 0 for x in sel]
+        assert all((int(a) - w) % (1 << 64) == 0 for a, w in zip(i64, want))
+        assert (int(ti) - sum(want)) % (1 << 64) == 0
+
+
 @settings(**COMMON)
 @given(tag=st.sampled_from(["f32", "f64"]), n=lengths, offs=st.tuples(st.integers(0, 3), st.integers(0, 3), st.integers(0, 3), st.integers(0, 3)),
        masked=st.booleans(), seed=st.integers(0, 2**31))
