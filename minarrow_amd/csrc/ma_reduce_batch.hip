@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __r
 // and its one partial goes to partials[wave].
 template <typename T, int UNROLL, bool TOTAL>
 __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __restrict__ table, size_t n_cols_,
-                                                              Partial* __restrict__ partials) {
+                                                              Partial* __restrict__ partials, int stagger = 1) {
     typedef typename std::conditional<(sizeof(T) <= 2), MaU4, typename Vec16<T>::type>::type V;
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);
@@ -236,12 +236,20 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
     const unsigned w_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + (threadIdx.x >> 6)));
     const unsigned n_w = gridDim.x * kWaves;
     const unsigned n_cols = (unsigned)n_cols_;
+    // Wave w starts every column at tile w mod (tiles of the column) and wraps: the waves advance in step, and without this the
+    // four waves of a CU read the SAME offset of four adjacent chunks at any moment (i64 6.81 -> 7.05 TB/s, with validity 6.65 ->
+    // 6.97, i32 6.48 -> 6.72; the same start for a workgroup's four waves and a different one per workgroup: 6.70 — it is the
+    // waves that share a CU that must differ). variant bit 32768: every wave from tile 0, A/B.
+    auto tile_of = [&](unsigned t, unsigned rot, unsigned n_tiles) -> unsigned {
+        const unsigned r = t + rot;
+        return r >= n_tiles ? r - n_tiles : r;
+    };
 
     struct Col {
         const T* data;
         const uint64_t* words;
         size_t bit_off, last_word;
-        unsigned len, head, n_tiles;
+        unsigned len, head, n_tiles, rot;
     };
     auto derive = [&](const ShortCol& e) -> Col {
         Col c;
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
         c.head = (mis && c.len) ? (16u - mis) / (unsigned)sizeof(T) : 0u;
         if (c.head > c.len) c.head = c.len;
         c.n_tiles = (c.len - c.head) / (unsigned)TILE_ROWS;
+        c.rot = (stagger && c.n_tiles) ? w_id % c.n_tiles : 0u;
         return c;
     };
     // always a load (the index is clamped instead of the load being skipped): a conditional one ends in register moves that
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
     // from there too. Loads that are issued on some paths only would make the compiler's wait counts assume the shortest
     // queue (vmcnt counts in order): the wait for THIS tile would then also wait for most of the next one.
     auto issue = [&](const Col& c, unsigned t, bool real, V (&v)[UNROLL], uint64_t& raw) {
-        const unsigned row0 = c.head + t * (unsigned)TILE_ROWS;
+        const unsigned row0 = c.head + tile_of(t, c.rot, c.n_tiles) * (unsigned)TILE_ROWS;
         const V* __restrict__ p = real ? (const V*)(c.data + row0) + lane : (const V*)partials;
         const size_t stride = real ? 64 : 0;
 #pragma unroll
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
         issue(cn, tn, have_n, nv, nraw);
 
         if (have) {
-            const unsigned row0 = c.head + t * (unsigned)TILE_ROWS;
+            const unsigned row0 = c.head + tile_of(t, c.rot, c.n_tiles) * (unsigned)TILE_ROWS;
             if (c.words) {
                 const uint64_t aw = finish_run_words(craw, c.bit_off + row0);
                 if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
@@ -591,15 +600,16 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         // (f32 with validity — widened to f64, four double-double accumulators per load — is ALU-bound on one wave: 5.2 -> 5.9)
         const bool two = sizeof(T) < 4 || (std::is_same<T, float>::value && any_masked);
         const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : two ? 2 : 1;
+        const int stagger = (ctx->variant & 32768) ? 0 : 1;
         const int grid1 = grid_for(ctx, (n_short + kWaves - 1) / kWaves, bpc);
         if (total) n_short_partials = (size_t)grid1 * kWaves;
         if (deep) {
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
         } else {
             constexpr int U1 = sizeof(T) == 8 ? 4 : UNROLL;
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials);
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
         }
     } else if (short_table) {  // variant bit 4096: round 3's first shape (eight workgroups per CU, no tile ahead), for A/B
         const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8);
