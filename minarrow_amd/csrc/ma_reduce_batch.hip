@@ -589,11 +589,11 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
     if (short_table && (expand_to || !(ctx->variant & 4096))) {
         // one or two waves per SIMD with ~8 KiB of loads each in flight AND a tile requested ahead (column_waves_kernel);
         // ctx->variant bits 1-3 / blocks_per_cu override the shape for sweeps (tools/probe_sum_chunks.py)
-        // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks.jsonl): ONE wave per SIMD with eight loads per tile — sixteen
-        // in flight with the tile ahead — for 4- and 8-byte rows: i64 / f64 / i32 6.7-6.8 TB/s dense AND with validity, end to
-        // end, against 7.2-7.3 for the plain sum of the same bytes (two waves per SIMD: 6.4-6.7; the round's first shape, eight
-        // workgroups per CU and no tile ahead: 6.3-6.4, i32 5.9). The 1- and 2-byte types keep their shallower tiles (the
-        // validity words of a tile must fit one load instruction) on two waves per SIMD.
+        // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks*.jsonl): ONE wave per SIMD with eight loads per tile — sixteen
+        // in flight with the tile ahead — for 4- and 8-byte rows: i64 / f64 / i32 6.8-6.9 TB/s dense, 6.7-6.9 with validity, end
+        // to end, against 7.2-7.3 for the plain sum of the same bytes; 122 000 chunks: 7.1 = 0.97 of the plain sum (two waves per
+        // SIMD: 6.4-6.7; the round's first shape, eight workgroups per CU and no tile ahead: 6.3-6.4, i32 5.8). The 1- and 2-byte
+        // types keep their shallower tiles (the validity words of a tile must fit one load instruction) on two waves per SIMD.
         constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
         const int sel = (ctx->variant >> 1) & 7;
         const bool deep = sizeof(T) >= 4 && sel != 2;
