@@ -256,7 +256,7 @@ SHORT = [0, 0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 
 @settings(**COMMON)
 @given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g", "c", "C", "s", "S"]), n_cols=st.integers(256, 700),
        gap=st.integers(0, 3), mask_mode=st.sampled_from(["none", "some", "all"]), grid=st.sampled_from([0, 0, 1, 2, 7]),
-       variant=st.sampled_from([0, 0, 4, 6]), seed=st.integers(0, 2**31))
+       variant=st.sampled_from([0, 0, 4, 6, 32768]), seed=st.integers(0, 2**31))
 def test_sum_short_columns(ctx, fmt, n_cols, gap, mask_mode, grid, variant, seed):
     """From 256 columns of a segment or less each: a WAVE per column with the next tile requested ahead, across columns
     (`column_waves_kernel`) — per column (ma_sum_columns) and as one total (ma_sum_chunks), on grids so small that a wave

@@ -225,7 +225,7 @@ def test_short_columns_with_few_waves_walk_many_columns_each(ctx, fmt):
     want_cnt = np.array([v.sum() for v in valid], dtype=np.uint64)
     sel = [c[v] for c, v in zip(cols, valid)]
     try:
-        for grid, variant in ((3, 0), (1, 4), (3, 6), (0, 4096), (2, 4096)):
+        for grid, variant in ((3, 0), (1, 4), (3, 6), (2, 32768), (0, 4096), (2, 4096)):  # 32768: every wave from tile 0
             ctx.set_grid(grid)
             ctx.set_variant(variant)
             f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
