@@ -139,9 +139,14 @@ def cpu_baseline(rows: int, budget_s: float):
         "value_median": results[best_threads]["value_median"],
         "unit": "Grows/s",
         "rows": rows,
-        # cores = CPUs' worth of time the pool can actually burn: the container's cgroup quota caps a larger pool
-        "cores": min(best_threads, quota) if quota else best_threads,
+        # cores = the threads that produced `value`: the pool size of the fastest configuration. On a GPU box the container
+        # sees every host thread but may only burn `cgroup_cpu_quota` CPUs' worth of time per period, so a large pool's
+        # best-of-N is an un-throttled burst inside one period; what a quota-bound host SUSTAINS is `value_quota_bound` (the
+        # median of the pool sized to the quota, `cores_quota_bound` threads).
+        "cores": best_threads,
         "pool_threads": best_threads,
+        "value_quota_bound": results[min(candidates)]["value_median"] if quota else results[best_threads]["value_median"],
+        "cores_quota_bound": min(candidates) if quota else best_threads,
         "cgroup_cpu_quota": quota,
         "host_threads_visible": visible,
         "kind": "port",
@@ -244,16 +249,13 @@ def gpu_other_configs(ctx, n: int, reps: int):
         e.update(extra)
         return e
 
-    # Two OUTPUT buffers. `o_plain` is what a caller who brings its own `out` has (the ABI's normal contract: the reference
-    # allocates `out` per call, src/kernels/arithmetic/dispatch.rs:88-89): the process's first ma_dev_alloc block, wherever
-    # the driver put it. `o` comes from the placement-aware allocator (ma_dev_alloc_output: the fastest-writing of a bounded
-    # number of candidate blocks; the rejected candidates are parked and come back as the inputs below, which read at the
-    # same rate wherever they are — DESIGN.md §3.4). Every read+write figure below is on `o`; the copy and a + b are timed on
-    # BOTH, and what the search cost (wall time outside every timed region, bytes held while it ran) is in the line.
-    o_plain = ctx.alloc(n * 8)
-    o = ctx.alloc_output(n * 8)
-    res["output_block_write_gbps"] = o.write_gbps
-    res["output_allocator"] = dict(getattr(o, "alloc_stats", {}), bytes_requested=n * 8)
+    # The OUTPUT buffer is a plain ma_dev_alloc block — what a caller who brings its own `out` has (the ABI's normal contract:
+    # the reference allocates `out` per call, src/kernels/arithmetic/dispatch.rs:88-89), wherever the driver put it. The write
+    # rate of a block depends on that placement, which is why every read+write figure also carries
+    # `frac_of_copy`: the fraction of a plain copy into the SAME block, measured in this process. The placement search of
+    # rounds 2-3 (ma_dev_alloc_output) is opt-in since round 4 and not used here.
+    o = ctx.alloc(n * 8)
+    res["output_block"] = "plain ma_dev_alloc block (no placement search)"
     a, b = (ctx.alloc(n * 8) for _ in range(2))
     mask_bytes = ((n + 511) // 512) * 64 + 64
     mask, om = ctx.alloc(mask_bytes), ctx.alloc(mask_bytes)
@@ -268,15 +270,6 @@ def gpu_other_configs(ctx, n: int, reps: int):
     ms = _timed(ctx, lambda: ctx.dev_copy(o, a, n * 8), reps)
     res["copy_hipMemcpyDtoD"] = entry(ms, 16, n)
     copy_gbps = max(res["copy_kernel_16B_per_lane"]["gbps"], res["copy_hipMemcpyDtoD"]["gbps"])
-    # the same two kernels into the plain block: what the numbers are WITHOUT shopping for memory
-    ms_c = _timed(ctx, lambda: ctx.consolidate_column(8, [a], [n], o_plain), reps)
-    ms_a = _timed(ctx, lambda: ctx.apply("f64", a, b, OPS["add"], o_plain, n, n), reps)
-    res["plain_output_block"] = {
-        "copy_kernel_16B_per_lane": entry(ms_c, 16, n), "add_array_array": entry(ms_a, 24, n),
-        "note": "output = the process's first plain ma_dev_alloc block (no placement search): the figures a caller-provided "
-                "`out` gets on this box"}
-    ctx.synchronize()
-    o_plain.free()
 
     # ---- config 3: f64 add / mul, array (+) array and array (+) scalar (fused broadcast) ---------------------------
     def windows_equal(buf, fn, starts, count=4096):
@@ -523,22 +516,25 @@ def _result_line(args, world, scaling, total_rows, rows_gpu0, elapsed, kernels, 
     got_i, cnt_i, got_f, cnt_f = finals
     value_rows = total_rows * 2 * args.steps
     exact_f = float(total_rows * (total_rows - 1) // 2)
-    avg_i, avg_f = kernels["sum_i64"]["avg_ms"], kernels["sum_f64"]["avg_ms"]
-    bytes_per_launch = rows_gpu0 * 8  # algorithmic: 8 B/row, one launch scans GPU 0's chunk
-    dom_name, dom_ms = ("ma::sum_kernel<double>", avg_f) if avg_f >= avg_i else ("ma::sum_kernel<int64>", avg_i)
+    # one entry per kind of launch in the step: `columns` = how many of the step's two 8-byte columns one launch scans
+    # (1: ma_i64_sum / ma_f64_sum_dd, 2: ma_sum_fused). Algorithmic bytes: 8 B/row x GPU 0's rows x columns.
+    names = {"sum_i64": "ma::sum_kernel<int64>", "sum_f64": "ma::sum_kernel<double>", "sum_fused": "ma::sum_fused_kernel (i64 + f64 in one launch)"}
+    for kname, kk in kernels.items():
+        cols = 2 if kname == "sum_fused" else 1
+        kk["rows_per_launch"] = rows_gpu0 * cols
+        kk["bytes_per_launch"] = rows_gpu0 * 8 * cols
+        kk["gbps"] = kk["bytes_per_launch"] / (kk["avg_ms"] * 1e-3) / 1e9
+        kk["grows_per_s"] = kk["rows_per_launch"] / (kk["avg_ms"] * 1e-3) / 1e9
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])  # the dominant kernel: the launch the step spends most time in
+    dom_name, dom_ms, bytes_per_launch = names.get(dom, dom), kernels[dom]["avg_ms"], kernels[dom]["bytes_per_launch"]
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists() and rows_gpu0 == 1_000_000_000:  # the counters were collected on the full-size workload only
         try:
-            key = "sum_f64_hbm_bytes_per_launch" if avg_f >= avg_i else "sum_i64_hbm_bytes_per_launch"
-            traffic = json.loads(pmc.read_text()).get(key)
+            traffic = json.loads(pmc.read_text()).get(f"{dom}_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    for kname, kk in kernels.items():
-        kk["rows_per_launch"] = rows_gpu0
-        kk["gbps"] = bytes_per_launch / (kk["avg_ms"] * 1e-3) / 1e9
-        kk["grows_per_s"] = rows_gpu0 / (kk["avg_ms"] * 1e-3) / 1e9
     if world == 1:
         workload = (f"{total_rows}-row IntegerArray<i64> sum + {total_rows}-row FloatArray<f64> sum, null-free, "
                     f"HBM-resident (BASELINE configs[1])")
@@ -675,7 +671,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     # patterns), fanned out by ma_group_route_super_array_broadcast — one launch per GPU, no exchange, output stays chunked.
     # Parity: linearity of the wrapping sum, sum(out) == sum(a) + sum(b) mod 2^64 over all GPUs, plus sampled windows.
     lens = [rows] * world
-    outs = [c.alloc_output(rows * 8) for c in ctxs]
+    outs = [c.alloc(rows * 8) for c in ctxs]
     ms = timed_steps(lambda: group.route_super_array_broadcast("l", 0, cols_i, cols_f, lens, lens, outs))
     sums = []
     for col in (cols_i, cols_f, outs):
@@ -693,7 +689,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     res["config3_i64_add_one_chunk_per_gpu"] = {
         "n_gpus": world, "rows_per_chunk": rows, "ms_per_step": ms, "grows_per_s": rows * world / ms / 1e6,
         "gbps": 24.0 * rows * world / ms / 1e6, "frac_of_peak_per_gpu": 24.0 * rows / ms / 1e6 / HBM_PEAK_GBPS,
-        "output_block_write_gbps": [round(getattr(o, "write_gbps", 0.0) or 0.0, 1) for o in outs], "parity": bool(ok3),
+        "parity": bool(ok3),
         "note": "route_super_array_broadcast over the group: chunk i on GPU i, no exchange, the result stays chunked"}
     for o in outs:
         o.free()
@@ -735,9 +731,8 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
         c.synth_validity(m, rows, seed=0xABC + r, null_every=10)
         masks.append(m)
 
-    def table_step():
-        group.enqueue_sum("i64", 3, cols_i, lens, masks, zeros)
-        group.enqueue_sum("f64", 4, cols_f, lens, masks, zeros)
+    def table_step():  # both columns of every member's batch in ONE fused launch, then ONE exchange
+        group.enqueue_sum_table([("l", 3, cols_i, lens, masks, zeros), ("g", 4, cols_f, lens, masks, zeros)])
         group.exchange()
 
     ms = timed_steps(table_step)
@@ -765,7 +760,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     # try: a failure here is reported in its entry and leaves the other legs standing.
     try:
         c0 = ctxs[0]
-        whole = c0.alloc_output(rows * world * 8)
+        whole = c0.alloc(rows * world * 8)
         wmask = c0.alloc(rows * world // 8 + 128)
         steps = max(1, min(reps, 3))
         for _ in range(1):
@@ -824,9 +819,14 @@ def run_group(args, result_fd) -> int:
         c.synth_iota("i64", cols_i[r], lens[r], chunks[r][0])
         c.synth_iota("f64", cols_f[r], lens[r], chunks[r][0])
 
+    fused = args.step != "separate"  # the partitioned step as ONE launch per member (ma_group_enqueue_sum_table)
+
     def step():
-        group.enqueue_sum("i64", 0, cols_i, lens)
-        group.enqueue_sum("f64", 0, cols_f, lens)
+        if fused:
+            group.enqueue_sum_table([("l", 0, cols_i, lens), ("g", 0, cols_f, lens)])
+        else:
+            group.enqueue_sum("i64", 0, cols_i, lens)
+            group.enqueue_sum("f64", 0, cols_f, lens)
         group.exchange()
 
     step()  # set-up, never timed: first use of the communicator and of the fold kernel
@@ -834,6 +834,7 @@ def run_group(args, result_fd) -> int:
     for _ in range(args.warmup):
         step()
     group.synchronize()
+    group.exchange_stats()  # forget the set-up's samples
     host_issue = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -841,28 +842,46 @@ def run_group(args, result_fd) -> int:
     host_issue = time.perf_counter() - t0  # the calling thread's time inside the enqueue calls (the GPUs are still busy)
     group.synchronize()
     elapsed = time.perf_counter() - t0
+    stats = group.exchange_stats()  # all-gather / fold durations on member 0's exchange stream, every 4th exchange
 
     finals = group.result(0)
     ok = _check(total_rows, finals) and all(group.result(0, m) == finals for m in range(world))
-    # Kernel durations (outside the timed region): HIP events on member 0's stream around 5 launches of each scan.
+    # Kernel durations (outside the timed region): HIP events on each member's stream around 5 launches of its scan(s).
     c0 = ctxs[0]
-    slot = c0.alloc(64)
+    slots = [c.alloc(64) for c in ctxs]
+
+    def scan_ms(m, which):
+        c, sl = ctxs[m], slots[m]
+        if which == "fused":
+            fn = lambda: c.sum_fused([("l", cols_i[m], lens[m], sl.ptr), ("g", cols_f[m], lens[m], sl.ptr + 16)])  # noqa: E731
+        elif which == "i64":
+            fn = lambda: c.sum_into("i64", cols_i[m], lens[m], out_sum=sl.ptr, out_count=sl.ptr + 8)  # noqa: E731
+        else:
+            fn = lambda: c.sum_into("f64", cols_f[m], lens[m], out_sum=sl.ptr, dd_lo=sl.ptr + 8, out_count=sl.ptr + 16)  # noqa: E731
+        return _timed(c, fn, 5, 1)
+
     kernels = {}
-    for name, tag, col in (("sum_i64", "i64", cols_i[0]), ("sum_f64", "f64", cols_f[0])):
-        fn = (lambda: c0.sum_into("i64", col, lens[0], out_sum=slot.ptr, out_count=slot.ptr + 8)) if tag == "i64" else \
-            (lambda: c0.sum_into("f64", col, lens[0], out_sum=slot.ptr, dd_lo=slot.ptr + 8, out_count=slot.ptr + 16))
-        ms = _timed(c0, fn, 5, 1)
-        kernels[name] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
+    for which in (("fused",) if fused else ("i64", "f64")):
+        ms = scan_ms(0, which)
+        kernels["sum_" + which] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
+    per_member = [sum(scan_ms(m, w) for w in (("fused",) if fused else ("i64", "f64"))) for m in range(world)]
     out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
                        f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
-                       ("RCCL all-gather (ncclCommInitAll; one call per member issue thread) + device fold, " +
+                       ("RCCL all-gather (ncclCommInitAll; grouped on the calling thread when there is more than one member) + "
+                        "device fold, " +
                         ("on side streams, overlapped with the next step's scans" if overlap else "on the scan streams")
                         if group.exchange_kind == "rccl" else "host fold of pinned records") +
                        (f" [{group.exchange_note}]" if group.exchange_note else ""),
-                       {"rccl_ranks": world if group.exchange_kind == "rccl" else 0, "launch": "single process",
-                        "host_issue_us_per_step": host_issue / args.steps * 1e6})
+                       {"rccl_ranks": stats["rccl_ranks"], "launch": "single process",
+                        "step": "one fused launch per member (ma_group_enqueue_sum_table)" if fused else "two launches per member",
+                        "host": "torch-free", "hip_runtime": _hip_runtime_path(),
+                        "host_issue_us_per_step": host_issue / args.steps * 1e6,
+                        "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
+                        "scan_ms_per_step_min_over_members": min(per_member), "scan_ms_per_step_max_over_members": max(per_member)})
+    for sl in slots:
+        sl.free()
     rc = 0 if ok else 1
-    for b in cols_i + cols_f + [slot]:
+    for b in cols_i + cols_f:
         b.free()
     if (scaling == "strong" and world > 1) or args.force_group:
         _n1_same_process(c0, total_rows, args.steps, args.warmup, out)
@@ -891,119 +910,453 @@ def run_group(args, result_fd) -> int:
     return rc
 
 
-def ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, rows: int, reps: int, rank: int, world: int,
-                        comm_stream=None):
-    """The same two multi-GPU legs as group_other_configs with one process per GPU: every rank scans its chunk / its batch,
-    ONE exchange per step (the library's communicator when there is one, torch.distributed's all-gather otherwise)."""
-    from minarrow_amd.parallel import ScalarExchange, fold_dd, row_chunks
+class Records:
+    """Per-rank reduction records in device memory owned by a library context — the torch-free twin of
+    minarrow_amd.parallel.ScalarExchange. Record layout (8 x u64): [0] integer sum, [1] integer valid count, [2] f64 hi bits,
+    [3] f64 lo bits, [4] float valid count. `local` = this rank's n_columns records, `gathered` = every rank's, `final` =
+    4 x u64 per column written by the rank-ordered device fold."""
 
-    M64 = (1 << 64) - 1
-    stream = torch.cuda.current_stream(dev)
+    RECORD = 8
 
-    def exchange(ex):
-        if comm is not None and comm_stream is not None:  # the communicator's context enqueues on its own (side) stream
-            comm_stream.wait_stream(stream)
-            with torch.cuda.stream(comm_stream):
-                comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
-            stream.wait_stream(comm_stream)
-            ex._folded_on_device = True
-        elif comm is not None:
-            comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
-            ex._folded_on_device = True
+    def __init__(self, ctx, world: int = 1, n_columns: int = 1):
+        self.ctx, self.world, self.n_columns = ctx, int(world), int(n_columns)
+        self.local = ctx.alloc(64 * self.n_columns)
+        ctx.dev_memset(self.local, 0, 64 * self.n_columns)
+        if self.world > 1:
+            self.gathered = ctx.alloc(64 * self.n_columns * self.world)
+            ctx.dev_memset(self.gathered, 0, 64 * self.n_columns * self.world)
         else:
-            ex.exchange()
-            ex.fold_on_device(ctx)
+            self.gathered = self.local  # one rank: the local records ARE the gathered ones
+        self.final = ctx.alloc(32 * self.n_columns)
+        ctx.dev_memset(self.final, 0, 32 * self.n_columns)
 
-    def fence():
-        dist.barrier()
-        torch.cuda.synchronize(dev)
+    def slot_ptr(self, index: int, column: int = 0, slot: int = 0) -> int:
+        assert 0 <= index < self.RECORD and 0 <= column < self.n_columns and slot == 0
+        return self.local.ptr + 8 * (column * self.RECORD + index)
+
+    def fold_on_device(self, ctx) -> None:
+        for c in range(self.n_columns):
+            ctx.fold_sum_records(self.gathered.ptr + 64 * c, self.world, 8 * self.n_columns, self.final.ptr + 32 * c)
+
+    def column_results(self):
+        import numpy as np
+
+        f = self.final.download(np.uint64, 4 * self.n_columns).reshape(self.n_columns, 4)
+        return [(int(r[0]), int(r[1]), float(r[2:3].view(np.float64)[0]), int(r[3])) for r in f]
+
+    def results(self):
+        got = self.column_results()[0]
+        i = got[0] - (1 << 64) if got[0] >= (1 << 63) else got[0]
+        return (i, got[1], got[2], got[3])
+
+    def free(self):
+        for b in {id(x): x for x in (self.local, self.gathered, self.final)}.values():
+            b.free()
+
+
+def ranks_other_configs(env, col_i, col_f, rows: int, reps: int):
+    """The multi-GPU legs of configs 3-5 with one process per GPU: every rank scans its chunk / its batch, ONE exchange per
+    step. `env` carries the run's plumbing — ctx, rank, world, make_ex(n_columns) -> records object, exchange(ex) (all-gather +
+    device fold through whichever exchange the headline used), fence() (barrier + device drain), max_over_ranks(x),
+    gather(obj), alloc(bytes) — so that the torch-hosted and the torch-free run share this function."""
+    from minarrow_amd.parallel import fold_dd, row_chunks
+
+    ctx, rank, world = env.ctx, env.rank, env.world
+    M64 = (1 << 64) - 1
 
     def timed_steps(step):
         for _ in range(2):
             step()
-        fence()
+        env.fence()
         t0 = time.perf_counter()
         for _ in range(reps):
             step()
-        fence()
-        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def gather(obj):
-        objs = [None] * world
-        dist.all_gather_object(objs, obj)
-        return objs
+        env.fence()
+        return env.max_over_ranks((time.perf_counter() - t0) / reps * 1e3)
 
     res = {}
     # ---- config 3: every rank adds its own chunk pair (i64; b = the f64 column's bit patterns); no exchange at all
-    out3 = ctx.alloc_output(rows * 8)
+    out3 = ctx.alloc(rows * 8)
     ms = timed_steps(lambda: ctx.apply("i64", col_i, col_f, 0, out3, rows, rows))
     ctx.set_async(False)
     s_a, s_b, s_o = (ctx.sum("i64", x, rows)[0] & M64 for x in (col_i, col_f, out3))
     ctx.set_async(True)
-    ok3 = all(gather(s_o == (s_a + s_b) & M64))
+    ok3 = all(env.gather(s_o == (s_a + s_b) & M64))
     res["config3_i64_add_one_chunk_per_gpu"] = {
         "n_gpus": world, "rows_per_chunk": rows, "ms_per_step": ms, "grows_per_s": rows * world / ms / 1e6,
         "gbps": 24.0 * rows * world / ms / 1e6, "frac_of_peak_per_gpu": 24.0 * rows / ms / 1e6 / HBM_PEAK_GBPS,
-        "output_block_write_gbps": round(getattr(out3, "write_gbps", 0.0) or 0.0, 1), "parity": bool(ok3),
-        "note": "one chunk pair per rank, no exchange, the result stays chunked"}
+        "parity": bool(ok3), "note": "one chunk pair per rank, no exchange, the result stays chunked"}
     out3.free()
     # ---- config 4
     n = min(1_000_000_000, rows * world)
     lo, hi = row_chunks(n, world)[rank]
     mine = hi - lo
     ctx.synth_iota("i64", col_i, mine, lo)
-    mask = torch.zeros(mine // 8 + 128, dtype=torch.uint8, device=dev)
+    mask = env.alloc(mine // 8 + 128)
     ctx.synth_validity(mask, mine, seed=0xC0FFEE, first_index=lo, null_every=10)
-    ex = ScalarExchange(dev)
+    ex = env.make_ex(1)
 
     def step4():
         ctx.sum_into("i64", col_i, mine, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1), mask=mask)
-        exchange(ex)
+        env.exchange(ex)
 
     ms = timed_steps(step4)
     total, cnt, _, _ = ex.results()
     ctx.set_async(False)
     own = ctx.sum("i64", col_i, mine, mask=mask)
     ctx.set_async(True)
-    parts = gather(own)
+    parts = env.gather(own)
     ok = (total & M64) == (sum(p[0] for p in parts) & M64) and cnt == sum(p[1] for p in parts) and 0.09 < 1 - cnt / n < 0.11
     res["config4_i64_sum_10pct_nulls_row_chunks"] = {
         "n_gpus": world, "rows_total": n, "ms_per_step": ms, "grows_per_s": n / ms / 1e6, "gbps": 8.125 * n / ms / 1e6,
         "frac_of_peak_per_gpu": 8.125 * n / ms / 1e6 / world / HBM_PEAK_GBPS, "valid_count": cnt, "parity": bool(ok)}
-    # ---- config 5: one batch of `rows` rows per rank, columns i64 + f64
+    # ---- config 5: one batch of `rows` rows per rank, columns i64 + f64, BOTH scanned by one fused launch per step
     ctx.synth_iota("i64", col_i, rows, rank)
     ctx.synth_iota("f64", col_f, rows, rank)
-    mask = torch.zeros(rows // 8 + 128, dtype=torch.uint8, device=dev)
-    ctx.synth_validity(mask, rows, seed=0xABC + rank, null_every=10)
-    ex2 = ScalarExchange(dev, n_columns=2)
+    mask5 = env.alloc(rows // 8 + 128)
+    ctx.synth_validity(mask5, rows, seed=0xABC + rank, null_every=10)
+    ex2 = env.make_ex(2)
 
     def step5():
-        ctx.sum_into("i64", col_i, rows, out_sum=ex2.slot_ptr(0, 0), out_count=ex2.slot_ptr(1, 0), mask=mask)
-        ctx.sum_into("f64", col_f, rows, out_sum=ex2.slot_ptr(2, 1), dd_lo=ex2.slot_ptr(3, 1), out_count=ex2.slot_ptr(4, 1), mask=mask)
-        exchange(ex2)
+        ctx.sum_fused([("l", col_i, rows, ex2.slot_ptr(0, 0), mask5), ("g", col_f, rows, ex2.slot_ptr(2, 1), mask5)])
+        env.exchange(ex2)
 
     ms = timed_steps(step5)
     (isum, icnt, _, _), (_, _, fsum, fcnt) = ex2.column_results()
     ctx.set_async(False)
-    own_i = ctx.sum("i64", col_i, rows, mask=mask)
-    own_f = ctx.sum_dd("f64", col_f, rows, mask=mask)
+    own_i = ctx.sum("i64", col_i, rows, mask=mask5)
+    own_f = ctx.sum_dd("f64", col_f, rows, mask=mask5)
     ctx.set_async(True)
-    parts = gather((own_i, own_f))
+    parts = env.gather((own_i, own_f))
     want_f = fold_dd([(p[1][0], p[1][1]) for p in parts])
     ok5 = (isum & M64) == (sum(p[0][0] for p in parts) & M64) and icnt == sum(p[0][1] for p in parts) == fcnt and fsum == want_f
     res["config5_supertable_one_batch_per_gpu"] = {
         "n_gpus": world, "batches": world, "rows_per_batch": rows, "columns": ["i64", "f64"], "ms_per_step": ms,
         "grows_per_s": 2 * rows * world / ms / 1e6, "gbps": 2 * 8.125 * rows * world / ms / 1e6,
         "frac_of_peak_per_gpu": 2 * 8.125 * rows / ms / 1e6 / HBM_PEAK_GBPS, "valid_count": icnt, "parity": bool(ok5),
-        "note": "per-column reduce of both columns with ONE exchange; the batch-sharded table is consolidated logically"}
+        "note": "both columns of the batch in ONE fused launch per rank, ONE exchange; the batch-sharded table is consolidated "
+                "logically"}
     res["parity_ok"] = bool(ok3 and ok and ok5)
     return res
 
 
-def run_ranks(args, result_fd) -> int:
-    """N = 1, or one process per GPU under torch.distributed.run."""
+def _hip_runtime_path():
+    """The libamdhip64 the LIBRARY runs on (a process may map two: PyTorch bundles its own)."""
+    try:
+        from minarrow_amd import ffi
+
+        return ffi.load_library().ma_hip_runtime_path().decode()
+    except Exception:
+        return None
+
+
+def _torch_hosted_leg(args):
+    """The same headline hosted by PyTorch (torch imported first: its bundled HIP runtime, torch tensors, torch's stream —
+    what rounds 1-3 reported), in a child process, as a labelled extra key next to the product's own figure."""
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--torch-hosted", "--gpus", "1", "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--rows", str(args.rows), "--no-other-configs", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.torch_hosted_seconds, cwd=str(ROOT))
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"exit code {r.returncode}: {r.stderr[-300:]}"}
+        child = json.loads(lines[-1])
+        return {"value": child["value"], "unit": child["unit"], "ms_per_step": child["ms_per_step"], "parity_ok": child["parity_ok"],
+                "roofline_frac": child["roofline"]["frac"], "roofline_kernel": child["roofline"]["kernel"],
+                "kernels": {k: {"avg_ms": v["avg_ms"], "gbps": v["gbps"]} for k, v in child["kernels"].items()},
+                "hip_runtime": child["config"].get("hip_runtime"),
+                "note": "`bench.py --torch-hosted` in a child process, started after this process had released its columns and "
+                        "paused (the driver clears released VRAM in the background: profiles/r04_read_rate_states_root_cause.txt)"}
+    except Exception as e:  # noqa: BLE001 — an extra leg must not cost the line
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def run_native(args, result_fd) -> int:
+    """The default: this process is a plain host of libminarrow_hip.so, the way a Rust binary would be — the library is loaded
+    FIRST and runs on /opt/rocm's HIP runtime, columns come from ma_dev_alloc, kernels run on the context's own stream, per-kernel
+    durations come from the library's timing marks (HIP events on that stream). N = 1: no torch at all. Under
+    torch.distributed.run (one process per GPU): torch.distributed's gloo backend carries the rendezvous, the barriers
+    and the max-over-ranks on the CPU side only (torch.cuda is never initialised); the exchange of the per-rank records is
+    the library's own RCCL communicator (ma_comm_*)."""
+    import numpy as np
+
+    from minarrow_amd import ffi
+
+    ffi.load_library()  # before anything else can bring another HIP runtime into the process
+    from minarrow_amd.host import Comm, Context
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or args.force_dist
+    rehearsal = args.backend == "gloo"
+    dist = torch = None
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch  # CPU side only
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+    n_dev = ffi.device_count()
+    device_index = local_rank % max(n_dev, 1) if rehearsal else local_rank
+    ctx = Context(device_index)
+    ctx.set_variant(args.variant)
+    ctx.set_blocks_per_cu(args.blocks_per_cu)
+
+    scaling, total_rows, chunks = _split(args, world)
+    lo, hi = chunks[rank]
+    rows = hi - lo  # this rank's row chunk of each column
+    # Columns resident in HBM before anything is timed (construction excluded, as in
+    # benches/benchmark_parallel_simd.rs:103-106). Rank r owns global rows [lo, hi) of each column.
+    col_i, col_f = ctx.alloc(max(rows, 8) * 8), ctx.alloc(max(rows, 8) * 8)
+    ctx.synth_iota("i64", col_i, rows, lo)
+    ctx.synth_iota("f64", col_f, rows, lo)
+    ctx.synchronize()
+
+    def gather_obj(obj):
+        if dist is None:
+            return [obj]
+        objs = [None] * world
+        dist.all_gather_object(objs, obj)
+        return objs
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # The exchange. native: the library's own RCCL communicator (ncclCommInitRank from an id rank 0 made and the gloo group
+    # carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up on every rank — or the ranks share a
+    # GPU (--backend gloo: a rehearsal, RCCL refuses two ranks on one device) — the 64-byte records take the detour over host
+    # memory through gloo instead (never a reported multi-GPU figure).
+    comm, comm_note = None, ""
+    if distributed and not rehearsal and args.exchange != "host":
+        try:
+            ids = [Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = Comm(ctx, ids[0], rank, world)
+        except Exception as e:  # noqa: BLE001
+            comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
+        if not all(gather_obj(comm is not None)):
+            if comm is not None:
+                comm.close()
+            comm = None
+            comm_note = comm_note or "native communicator unavailable on another rank"
+    overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and comm is not None and world > 1)
+    overlap = overlap and comm is not None
+    fused = args.step == "fused" or (args.step == "auto" and (world > 1 or distributed))
+    exs = [Records(ctx, world) for _ in range(2 if overlap else 1)]
+    ctx.set_async(True)
+    counter = [0]
+
+    def host_exchange(ex):
+        """gloo detour: this rank's records to the host, all-gather among the hosts, back, device fold."""
+        ctx.synchronize()
+        mine = torch.from_numpy(ex.local.download(np.int64, 8 * ex.n_columns))
+        everyone = torch.empty(8 * ex.n_columns * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(everyone, mine)
+        ex.gathered.upload(everyone.numpy())
+        ex.fold_on_device(ctx)
+
+    def exchange(ex, slot=None):
+        if comm is not None and slot is not None:
+            comm.sum_exchange_overlapped(slot, ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+        elif comm is not None:
+            comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+        elif world > 1:
+            host_exchange(ex)
+        else:
+            ex.fold_on_device(ctx)  # one rank: nothing to exchange, the rank-ordered fold of one record
+
+    def step(marks=None):
+        k = counter[0] % len(exs)
+        counter[0] += 1
+        ex = exs[k]
+        if overlap:
+            comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
+        if marks is not None:
+            ctx.mark(marks)
+        if fused:
+            ctx.sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))])
+        else:
+            ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
+            if marks is not None:
+                ctx.mark(marks + 1)
+            ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
+        if marks is not None:
+            ctx.mark(marks + 2)
+        exchange(ex, k if overlap else None)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        ctx.synchronize()
+        if comm is not None:
+            comm.synchronize()
+
+    hang_guard = None
+    if distributed:  # a collective that never completes must end the job with a reason, not with the driver's timeout
+        import threading
+
+        def hung():
+            print(f"rank {rank}: the headline's exchange did not complete within {args.headline_seconds:.0f} s "
+                  f"(exchange: {'ma_comm_*' if comm is not None else 'gloo over host memory'}, overlap: {overlap}); "
+                  "try --exchange host or --overlap off", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        hang_guard = threading.Timer(args.headline_seconds, hung)
+        hang_guard.daemon = True
+        hang_guard.start()
+    step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
+    fence()
+    if comm is not None:
+        # The library's communicator has only ever run with one rank before a multi-GPU node sees it: the set-up step's finals
+        # are checked on every rank, and if ANY rank's fold is wrong (or MA_BENCH_DISTRUST_NATIVE_COMM asks, for the test of
+        # this branch) all ranks drop to the host exchange before anything is timed.
+        good = _check(total_rows, exs[(counter[0] - 1) % len(exs)].results()) and not os.environ.get("MA_BENCH_DISTRUST_NATIVE_COMM")
+        if not all(gather_obj(bool(good))):
+            comm.synchronize()
+            comm.close()
+            comm, overlap = None, False
+            comm_note = "the library's communicator failed the set-up check on some rank: records over host memory (gloo) instead"
+            exs = exs[:1]
+            step()
+            fence()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # Kernel durations: timing marks (HIP events on the launch stream) around each scan, inside the timed region. A mark costs
+    # a few us of stream time; against 1.1 ms scans (10^9 rows on one GPU) every step carries them, against the 0.14 ms scans
+    # of an 8-way partition only every 4th step does (at least 3 steps).
+    every = 1 if rows >= 250_000_000 else max(1, min(4, args.steps // 3))
+    marked = {k: 3 * j for j, k in enumerate(range(0, args.steps, every))}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(marked.get(k))
+    fence()
+    elapsed = time.perf_counter() - t0
+    if hang_guard is not None:
+        hang_guard.cancel()
+    elapsed = max_over_ranks(elapsed)
+
+    # ---- verify the job's answer (outside the timed region) ------------------------------------------
+    finals = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
+    ok = _check(total_rows, finals)
+    if fused:
+        ms = [ctx.mark_elapsed_ms(m, m + 2) for m in marked.values()]
+        kernels = {"sum_fused": {"avg_ms": sum(ms) / len(ms), "min_ms": min(ms), "timed_steps": len(ms)}}
+    else:
+        ms_i = [ctx.mark_elapsed_ms(m, m + 1) for m in marked.values()]
+        ms_f = [ctx.mark_elapsed_ms(m + 1, m + 2) for m in marked.values()]
+        kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i), "timed_steps": len(ms_i)},
+                   "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f), "timed_steps": len(ms_f)}}
+    # per-rank scan time of a step (min / max over the ranks) and where the exchange's time goes (sampled every 4th exchange)
+    scan_ms = sum(v["avg_ms"] for v in kernels.values())
+    scans = gather_obj(scan_ms)
+    stats = comm.exchange_stats() if comm is not None else {"all_gather_us": 0.0, "fold_us": 0.0, "samples": 0, "rccl_ranks": 0}
+
+    rc = 0 if ok else 1
+    out = None
+    if rank == 0:
+        step_form = "one fused launch (ma_sum_fused: i64 + f64)" if fused else "ma_i64_sum + ma_f64_sum_dd"
+        if not distributed:
+            parallelism, exch = "row-chunk x1", "none (one GPU): device fold on the scan stream"
+        elif rehearsal:
+            parallelism = f"row-chunk x{world}, one process per rank (REHEARSAL: ranks share a GPU)"
+            exch = "gloo all-gather of the records over host memory + device fold"
+        else:
+            parallelism = f"row-chunk x{world}, one process per GPU"
+            exch = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
+                    ("" if overlap else ", on the scan stream")) if comm is not None else \
+                "gloo all-gather of the records over host memory + device fold"
+            if comm_note:
+                exch += f" [{comm_note}]"
+        if overlap:
+            exch += "; exchange of step k on a side stream, overlapped with the scans of step k + 1"
+        out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
+                           {"rccl_ranks": stats["rccl_ranks"], "launch": "torch.distributed.run" if world > 1 else "single process",
+                            "step": step_form, "host": "torch-free" if not distributed else "torch-free GPU path (gloo for rendezvous only)",
+                            "hip_runtime": _hip_runtime_path(),
+                            "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
+                            "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans)})
+        if (scaling == "strong" and world > 1) or args.force_dist:
+            _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
+    for b in (col_i, col_f):
+        b.free()
+    if distributed and not args.no_other_configs:
+        guard = _Deadline(args.other_seconds, result_fd, out, rc)  # every rank: none may outlive a hung collective
+        try:  # every rank takes part (collectives inside); rank 0 prints
+            from types import SimpleNamespace
+
+            orows = args.other_rows or args.rows  # these legs are per-GPU sized (one chunk / batch of `orows` rows per GPU)
+            oi, of = ctx.alloc(orows * 8), ctx.alloc(orows * 8)
+            ctx.synth_iota("i64", oi, orows, rank * orows)
+            ctx.synth_iota("f64", of, orows, rank * orows)
+            fence()
+
+            def alloc_zeroed(nbytes):
+                b = ctx.alloc(nbytes)
+                ctx.dev_memset(b, 0, nbytes)
+                return b
+
+            env = SimpleNamespace(ctx=ctx, rank=rank, world=world, exchange=lambda ex: exchange(ex), fence=fence,
+                                  max_over_ranks=max_over_ranks, gather=gather_obj, make_ex=lambda nc: Records(ctx, world, nc),
+                                  alloc=alloc_zeroed)
+            multi = ranks_other_configs(env, oi, of, orows, args.other_reps)
+            if not multi["parity_ok"]:
+                rc = 1
+            oi.free()
+            of.free()
+        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+            multi = {"error": f"{type(e).__name__}: {e}"}
+            rc = 1
+        guard.cancel()
+        if rank == 0:
+            out["other_configs"] = multi
+    if rank == 0:
+        if not distributed:
+            if not args.no_other_configs:
+                try:
+                    ctx.set_async(False)
+                    out["other_configs"] = gpu_other_configs(ctx, args.other_rows or args.rows, args.other_reps)
+                    parities = [v for v in _walk(out["other_configs"], "parity")]
+                    out["other_configs"]["parity_ok"] = all(parities)
+                    if not all(parities):
+                        rc = 1
+                except Exception as e:  # noqa: BLE001 — the headline line must still be printed
+                    out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+                    rc = 1
+            if not args.no_torch_hosted_leg:
+                ctx.set_async(False)
+                ctx.synchronize()
+                ctx.lib.ma_dev_pool_trim(ctx.handle, 0)  # the child needs the HBM; released blocks are cleared in the background:
+                time.sleep(2.5)                          # leave that behind before the child measures
+                out["torch_hosted"] = _torch_hosted_leg(args)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
+        _emit(result_fd, out)
+        if not ok:
+            print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
+    if comm is not None:
+        comm.close()
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+def run_ranks_torch(args, result_fd) -> int:
+    """--torch-hosted: N = 1, or one process per GPU under torch.distributed.run, with PyTorch as the host — torch imported
+    first (the library then runs on torch's bundled HIP runtime), columns in torch tensors, the library on torch's stream,
+    torch.distributed (RCCL) for the barrier. The form rounds 1-3 measured; kept as a labelled variant."""
     import numpy as np
     import torch  # first: the library then shares torch's HIP runtime (same SONAME)
     import torch.distributed as dist
@@ -1209,7 +1562,8 @@ def run_ranks(args, result_fd) -> int:
             exchange += "; exchange of step k on a side stream, overlapped with the scans of step k + 1"
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exchange,
                            {"rccl_ranks": world if (distributed and not rehearsal) else 0,
-                            "launch": "torch.distributed.run" if world > 1 else "single process"})
+                            "launch": "torch.distributed.run" if world > 1 else "single process",
+                            "host": "torch-hosted (torch imported first; its bundled HIP runtime)", "hip_runtime": _hip_runtime_path()})
         if (scaling == "strong" and world > 1) or args.force_dist:
             _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
     if distributed and not rehearsal and not args.no_other_configs:
@@ -1224,7 +1578,34 @@ def run_ranks(args, result_fd) -> int:
             ctx.synth_iota("f64", col_f, orows, rank * orows)
             if comm is not None:
                 comm.synchronize()  # the other legs use the in-stream exchange: nothing of the headline's may be in flight
-            multi = ranks_other_configs(ctx, dist, torch, dev, comm, col_i, col_f, orows, args.other_reps, rank, world)
+            from types import SimpleNamespace
+
+            def _exchange(ex):
+                if comm is not None:
+                    comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+                    ex._folded_on_device = True
+                else:
+                    ex.exchange()
+                    ex.fold_on_device(ctx)
+
+            def _fence():
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+
+            def _max(x):
+                t = torch.tensor([x], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+
+            def _gather(obj):
+                objs = [None] * world
+                dist.all_gather_object(objs, obj)
+                return objs
+
+            env = SimpleNamespace(ctx=ctx, rank=rank, world=world, exchange=_exchange, fence=_fence, max_over_ranks=_max,
+                                  gather=_gather, make_ex=lambda nc: ScalarExchange(dev, n_columns=nc),
+                                  alloc=lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device=dev))
+            multi = ranks_other_configs(env, col_i, col_f, orows, args.other_reps)
             if not multi["parity_ok"]:
                 rc = 1
         except Exception as e:  # noqa: BLE001 — the headline line must still be printed
@@ -1301,7 +1682,8 @@ def main() -> int:
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--exchange", default="native", choices=["native", "torch", "host"],
                     help="native = RCCL inside libminarrow_hip (ma_group_* in one process, ma_comm_* under a launcher); torch = "
-                         "torch.distributed's all-gather (launcher mode); host = host fold of pinned records (one process)")
+                         "torch.distributed's all-gather (--torch-hosted launcher mode only); host = host fold of pinned records "
+                         "(one process) / records over host memory through gloo (launcher mode)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
@@ -1311,6 +1693,16 @@ def main() -> int:
                     help="run each step's scalar exchange on a side stream, overlapped with the next "
                          "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP; torch events with --exchange torch). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
                          "it costs the scan more than it saves there, 876 vs 889 Grows/s)")
+    ap.add_argument("--torch-hosted", action="store_true",
+                    help="host the run in PyTorch as rounds 1-3 did: torch imported first (its bundled HIP runtime), columns in "
+                         "torch tensors, the library on torch's stream, torch.distributed's RCCL group for barriers")
+    ap.add_argument("--no-torch-hosted-leg", action="store_true",
+                    help="N = 1: skip the labelled extra key `torch_hosted` (the same headline in a --torch-hosted child process)")
+    ap.add_argument("--torch-hosted-seconds", type=float, default=240.0)
+    ap.add_argument("--step", default="auto", choices=["auto", "fused", "separate"],
+                    help="the step's scans: separate = ma_i64_sum + ma_f64_sum_dd (two launches: per-type kernel figures; the "
+                         "default at N = 1), fused = ONE ma_sum_fused launch over both columns (the default at N > 1, where a "
+                         "launch's fixed cost is 2.4 % of a 137-us scan)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",
@@ -1331,7 +1723,9 @@ def main() -> int:
         return 2
     if (world == 1 and args.gpus > 1) or args.force_group:
         return run_group(args, result_fd)
-    return run_ranks(args, result_fd)
+    if args.torch_hosted or args.exchange == "torch":
+        return run_ranks_torch(args, result_fd)
+    return run_native(args, result_fd)
 
 
 if __name__ == "__main__":

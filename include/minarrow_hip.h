@@ -48,8 +48,12 @@ extern "C" {
 
 /* 2 (round 3): + ma_ctx_hip_device, ma_pointer_device, ma_group_issue_kind, ma_group_peer_access; ma_ctx_device now
  * returns the LIBRARY ordinal (round-trip safe through ma_ctx_create); group calls are issued by per-member threads.
+ */
+/* 3 (round 4): + ma_ctx_mark / ma_ctx_mark_elapsed_ms (timing marks), ma_sum_fused (several long columns in ONE launch),
+ * ma_group_enqueue_sum_table, ma_group_exchange_stats, ma_comm_exchange_stats; ma_hip_runtime_path, ma_rccl_path; ma_dev_alloc_output searches only when asked to
+ * (MINARROW_HIP_OUTPUT_SEARCH=1 / ma_dev_output_search).
  * A binding compares ma_abi_version() with the MA_ABI_VERSION it was generated from. */
-#define MA_ABI_VERSION 2
+#define MA_ABI_VERSION 3
 
 typedef struct ma_ctx ma_ctx;
 typedef int32_t ma_status;
@@ -84,6 +88,10 @@ enum { MA_LOGICAL_AND = 0, MA_LOGICAL_OR = 1, MA_LOGICAL_XOR = 2 };
  * ---------------------------------------------------------------------------------------------- */
 
 int32_t ma_abi_version(void);
+/* The libamdhip64 this library is running on (the path the dynamic loader resolved its HIP entry points to). A process may
+ * hold more than one HIP runtime — PyTorch bundles its own — and device pointers, streams and RCCL communicators belong to
+ * exactly one of them. */
+const char* ma_hip_runtime_path(void);
 /* Number of devices the library may use: the visible HIP devices, or the entries of MINARROW_HIP_DEVICES (0 when there
  * is none; never initialises a device context). Device ordinals of this ABI index that list. */
 int32_t ma_device_count(void);
@@ -142,6 +150,13 @@ ma_status ma_ctx_timer_start(ma_ctx* ctx);
 ma_status ma_ctx_timer_stop(ma_ctx* ctx);
 /* Waits for the stop event; milliseconds between start and stop. */
 ma_status ma_ctx_timer_elapsed_ms(ma_ctx* ctx, float* out_ms);
+/* Timing marks, for a host without HIP headers that wants per-kernel durations inside a longer timed region: ma_ctx_mark
+ * records mark `index` (0 <= index < MA_CTX_MAX_MARKS; created on first use, re-recordable) on the context's stream behind
+ * everything enqueued so far; ma_ctx_mark_elapsed_ms waits for mark `to_index` and returns the milliseconds between the two.
+ * A mark costs a few microseconds of stream time (one event packet). Not recordable into a graph. */
+#define MA_CTX_MAX_MARKS 4096
+ma_status ma_ctx_mark(ma_ctx* ctx, int32_t index);
+ma_status ma_ctx_mark_elapsed_ms(ma_ctx* ctx, int32_t from_index, int32_t to_index, float* out_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Memory — the Vec64 stand-in (64-byte aligned, src/lib.rs:99; Cargo.toml:54 vec64 0.4.3) and
@@ -178,7 +193,13 @@ ma_status ma_host_unregister(void* ptr);
  * enqueued on it must have completed before it is freed (hipFree used to hide that by stalling the device). */
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
 /* A block meant to be WRITTEN by the streaming kernels — the `out` of apply_* (the reference allocates it itself:
- * `Vec64::with_capacity(len)`, src/kernels/arithmetic/dispatch.rs:88-89), a consolidated column. On MI355X the write
+ * `Vec64::with_capacity(len)`, src/kernels/arithmetic/dispatch.rs:88-89), a consolidated column. BY DEFAULT this is
+ * ma_dev_alloc (round 4): the placement search described below is opt-in — MINARROW_HIP_OUTPUT_SEARCH=1 in the environment,
+ * or ma_dev_output_search(1) — because what it buys depends on the blocks a process happens to draw (+5-10 % on the write
+ * stream on some boxes, nothing on others, for ~8 ms and up to 25 % of free HBM held while it runs); a caller that brings
+ * its own `out` gets its block's rate either way, and every read+write figure this repository reports is also given as a
+ * fraction of a plain copy into the same block. ma_dev_output_search(enabled): 1 / 0 switch the search on / off for the
+ * process, a negative value only queries; returns the previous setting. With the search on: on MI355X the write
  * rate of a region of HBM is a property of where the driver placed it: ~three quarters of the regions write at 5.4-5.8
  * TB/s under the kernels' store pattern, the rest at 6.3-6.8, while all of them read at 7.1-7.3. For
  * blocks of 256 MiB and more (MINARROW_HIP_OUTPUT_MIN_BYTES) this entry point tries 6 candidate blocks
@@ -197,6 +218,7 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
  * ma_dev_alloc_output_stats: what the calling thread's last search cost — wall time, bytes held at its peak, blocks measured /
  * considered, the good rate it compared against (all 0 when the plain path was taken; any pointer may be NULL). */
 ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, float* out_write_gbps);
+int32_t ma_dev_output_search(int32_t enabled);
 ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak_bytes, int32_t* out_blocks_measured,
                                     int32_t* out_blocks_considered, float* out_good_gbps);
 ma_status ma_dev_free(ma_ctx* ctx, void* dev_ptr);
@@ -330,6 +352,29 @@ ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const 
 ma_status ma_sum_chunks(ma_ctx* ctx, int32_t format_code, size_t n_chunks, const void* const* chunk_data,
                         const size_t* chunk_lens, const uint8_t* const* chunk_masks, const size_t* chunk_mask_offsets,
                         double* out_sum_f64, int64_t* out_sum_i64, uint64_t* out_valid_count);
+
+/* The sums of 1..MA_FUSED_MAX_COLUMNS LONG 8-byte columns — i64 ('l'), u64 ('L'), f64 ('g'), each dense or Bitmask-gated — in ONE
+ * launch: the per-column reduce of a table's numeric columns (BASELINE config 5), or the reference's two bench loops
+ * (`rayon_simd_sum_i64`, then `rayon_simd_sum_f64`, benches/benchmark_parallel_simd.rs:99-125) over one GPU's row chunk.
+ * A sum launch costs ~3.3 us beyond its bytes on MI355X (1.5 us until the first data arrives, 1.8 us of cross-workgroup
+ * hand-off after the last row; profiles/r04_probe_epilogue.jsonl) — per column with ma_i64_sum / ma_f64_sum_dd, once per
+ * call here: the columns' tiles run through the same workgroups back to back. Per-column semantics are those of
+ * ma_i64_sum / ma_u64_sum / ma_f64_sum_dd. Columns and outputs must be device-reachable (device or ma_alloc64_pinned
+ * memory: nothing is staged); the call only enqueues on an async context. Integer formats write out[0] = wrapping sum,
+ * out[1] = valid count; 'g' writes out[0], out[1] = the (hi, lo) double-double pair (bit patterns), out[2] = valid count —
+ * the slots of an exchange record (ma_fold_sum_records) when `out` is &record[0] resp. &record[2]. */
+#define MA_FUSED_MAX_COLUMNS 4
+typedef struct ma_fused_column {
+    const void* data;          /* element pointer of the window (8-byte aligned) */
+    size_t n;                  /* rows */
+    const uint8_t* mask_bits;  /* Arrow validity bitmap or NULL */
+    size_t mask_bit_offset;    /* bit of row 0 */
+    int64_t null_count;        /* 0 = known all-valid (dense kernel, like the reference's all_true gate); -1 = unknown */
+    int32_t format_code;       /* 'l', 'L' or 'g' */
+    int32_t reserved;          /* 0 */
+    uint64_t* out;             /* see above */
+} ma_fused_column;
+ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols);
 
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
  * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =
@@ -899,6 +944,24 @@ ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_
 ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets);
+/* The partitioned step in ONE launch per member: chunk i (on member i's device) of each of n_cols (1..MA_FUSED_MAX_COLUMNS)
+ * long 8-byte columns is scanned by a single ma_sum_fused launch — the reference's bench runs its i64 and its f64 loop
+ * back to back over the same partition (benches/benchmark_parallel_simd.rs:99-125). columns[k] = the record slot
+ * (0 <= slot < MA_GROUP_MAX_COLUMNS) that column k's result goes to: formats 'l' / 'L' fill its integer half, 'g' its float
+ * half (an integer and a float column may share a slot, as ma_group_enqueue_sum_i64 / _f64 on one slot do).
+ * chunk_data[k][i], chunk_lens[k][i]: member i's chunk of column k; chunk_masks (or chunk_masks[k]) and chunk_mask_offsets
+ * (or [k]) may be NULL. Then ma_group_exchange / ma_group_synchronize / ma_group_result as usual. */
+ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int32_t* columns, const int32_t* format_codes,
+                                     const void* const* const* chunk_data, const size_t* const* chunk_lens,
+                                     const uint8_t* const* const* chunk_masks, const size_t* const* chunk_mask_offsets);
+/* Where an exchange's time goes, for the first run on a multi-GPU node to explain itself: every 4th ma_group_exchange
+ * carries three HIP events on member 0's exchange stream (in front of the all-gather, behind it, behind the fold kernel).
+ * Averages in microseconds over the exchanges sampled since the last call (which waits for sampled exchanges still in
+ * flight: call it after ma_group_synchronize), their number, and the rank count RCCL itself reports for member 0's
+ * communicator (ncclCommCount; 0 with the host exchange, whose "fold" is the host loop inside ma_group_synchronize and
+ * whose all-gather time is 0: the kernels write their records straight into pinned host memory). Any output may be NULL. */
+ma_status ma_group_exchange_stats(ma_group* group, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
+                                  int32_t* out_rccl_ranks);
 ma_status ma_group_exchange(ma_group* group);
 ma_status ma_group_synchronize(ma_group* group);
 /* The sum of ONE column held as many chunks spread over the group's GPUs — a SuperArray, or one column of the batches of a
@@ -973,6 +1036,8 @@ ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, con
 typedef struct ma_comm ma_comm;
 #define MA_COMM_ID_BYTES 128
 int32_t ma_rccl_version(void);
+/* Which librccl the library opened: the one beside its own HIP runtime (see ma_hip_runtime_path), or "" when none. */
+const char* ma_rccl_path(void);
 ma_status ma_comm_unique_id(uint8_t* out_id);
 ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, ma_comm** out_comm);
 void ma_comm_destroy(ma_comm* comm);
@@ -985,6 +1050,9 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
 ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uint64_t* local_records, size_t slots_per_rank,
                                           size_t n_columns, uint64_t* gathered, uint64_t* out_finals);
 ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot);
+/* As ma_group_exchange_stats, for this rank's ma_comm_sum_exchange / _overlapped calls. */
+ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
+                                 int32_t* out_rccl_ranks);
 ma_status ma_comm_synchronize(ma_comm* comm);
 
 /* ------------------------------------------------------------------------------------------------

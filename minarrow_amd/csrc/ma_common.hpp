@@ -91,6 +91,7 @@ struct ma_ctx {
     uint32_t* dev_flags = nullptr;     // device word for elementwise kernels (divide-by-zero latch)
     hipEvent_t ev_start = nullptr;
     hipEvent_t ev_stop = nullptr;
+    std::vector<hipEvent_t> marks;     // ma_ctx_mark: timing events, created on first use of their index
     bool pending_flags = false;        // async mode: dev_flags must be inspected at the next synchronize
     std::atomic<bool> capturing{false};  // between ma_ctx_capture_begin / _end: calls are recorded into a hipGraph
     bool async_before_capture = false;

@@ -82,6 +82,9 @@ struct ma_group {
     std::vector<void*> mask_stage;
     std::vector<size_t> mask_stage_bytes;
     char note[512] = "";
+    ma::ExchangeTimer timer;        // member 0's exchange, every 4th call (ma_group_exchange_stats)
+    double host_fold_us = 0.0;      // host exchange: wall time of the host fold, summed ...
+    int host_fold_samples = 0;      // ... over this many synchronizes
 };
 
 using namespace ma;
@@ -199,6 +202,7 @@ void release_exchange(ma_group* g) {
     g->overlap = false;
     g->cur = g->last = 0;
     g->use_rccl = false;
+    g->timer.destroy();
 }
 
 void destroy_members(ma_group* g) {
@@ -448,12 +452,21 @@ ma_status exchange_locked(ma_group* g) {
     };
     auto xstream = [g](size_t i) { return g->overlap ? g->side[i]->stream : g->ctxs[i]->stream; };
     ma_status st = MA_OK;
-    if (g->threads) {  // one thread per device: each issues its own rank's all-gather, no ncclGroup needed
+    // One thread per device, each issuing its own rank's all-gather with no ncclGroup, is the form RCCL documents — but if one
+    // member fails before its call (hipSetDevice, the event record, the all-gather itself) the others have already enqueued
+    // theirs, those collectives never complete and the next synchronize blocks for good. That form has only ever run with ONE
+    // rank on hardware (the pool's boxes have one GPU), where it cannot happen; with more than one member the all-gathers go
+    // out from the calling thread inside ncclGroupStart / ncclGroupEnd, which enqueues nothing unless every call was accepted,
+    // and the members' threads then issue the folds.
+    if (g->threads && n == 1) {
         st = run_on_members(g, [&](size_t i) -> ma_status {
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
             MA_TRY(before(i));
+            const int tk = i == 0 ? g->timer.begin(xstream(0)) : -1;
             MA_NCCL(api, AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i)));
+            if (i == 0) g->timer.mark(tk, 1, xstream(0));
             MA_TRY(fold(i));
+            if (i == 0) g->timer.mark(tk, 2, xstream(0));
             return after(i);
         });
     } else {
@@ -461,6 +474,8 @@ ma_status exchange_locked(ma_group* g) {
             st = hipSetDevice(g->ctxs[i]->device) == hipSuccess ? before(i) : MA_ERR_DEVICE;
         }
         MA_TRY(st);
+        MA_HIP(hipSetDevice(g->ctxs[0]->device));
+        const int tk = g->timer.begin(xstream(0));
         MA_NCCL(api, GroupStart());
         for (size_t i = 0; i < n; ++i) {
             ncclResult_t r = api->AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i));
@@ -470,11 +485,16 @@ ma_status exchange_locked(ma_group* g) {
             }
         }
         MA_NCCL(api, GroupEnd());
-        for (size_t i = 0; i < n; ++i) {
-            MA_TRY(fold(i));
+        MA_HIP(hipSetDevice(g->ctxs[0]->device));
+        g->timer.mark(tk, 1, xstream(0));
+        // the folds (and the events that let the scan streams go on) go out from the members' issue threads; member 0's
+        // timing mark sits right behind its fold
+        st = run_on_members(g, [&](size_t i) -> ma_status {
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
-            MA_TRY(after(i));
-        }
+            MA_TRY(fold(i));
+            if (i == 0) g->timer.mark(tk, 2, xstream(0));
+            return after(i);
+        });
     }
     MA_TRY(st);
     if (g->overlap) {
@@ -504,6 +524,7 @@ ma_status synchronize_locked(ma_group* g) {
             return st[i];
         }
     if (!g->use_rccl) {
+        const auto t0 = std::chrono::steady_clock::now();
         for (int col = 0; col < kColumns; ++col) {
             HostFoldDD f;
             for (size_t i = 0; i < g->ctxs.size(); ++i) f.add(g->local[i] + (size_t)col * kRecordWords);
@@ -514,6 +535,8 @@ ma_status synchronize_locked(ma_group* g) {
             memcpy(&out[2], &total, 8);
             out[3] = f.fcnt;
         }
+        g->host_fold_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        ++g->host_fold_samples;
     }
     return MA_OK;
 }
@@ -690,6 +713,54 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
     return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, uint64_t* rec) {
         return ma_f64_sum_dd(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
                              chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (double*)&rec[2], (double*)&rec[3], &rec[4]);
+    });
+}
+
+// The partitioned step in ONE launch per member (round 4): the sums of up to MA_FUSED_MAX_COLUMNS long 8-byte columns whose
+// rows are partitioned over the group — the reference's bench runs its i64 and its f64 loop back to back over the same
+// partition (benches/benchmark_parallel_simd.rs:99-125); a table's per-column reduce does the same per column. Member i
+// scans chunk i of EVERY listed column with one ma_sum_fused launch and writes the columns' record slots of the current
+// set; ma_group_exchange / ma_group_result are unchanged. Per step and member this saves a launch's fixed cost per extra
+// column (~3.3 us of 137 us per 125 M-row chunk: profiles/r04_probe_epilogue.jsonl).
+ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int32_t* columns, const int32_t* format_codes,
+                                     const void* const* const* chunk_data, const size_t* const* chunk_lens,
+                                     const uint8_t* const* const* chunk_masks, const size_t* const* chunk_mask_offsets) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(n_cols >= 1 && n_cols <= MA_FUSED_MAX_COLUMNS, MA_ERR_INVALID_ARGUMENT, "ma_group_enqueue_sum_table takes 1..%d columns",
+               MA_FUSED_MAX_COLUMNS);
+    MA_REQUIRE(columns && format_codes && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int32_t k = 0; k < n_cols; ++k) {
+        MA_REQUIRE(columns[k] >= 0 && columns[k] < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", columns[k], kColumns);
+        MA_REQUIRE(format_codes[k] == 'l' || format_codes[k] == 'L' || format_codes[k] == 'g', MA_ERR_UNSUPPORTED,
+                   "format '%c' (the fused step takes the 8-byte formats l, L and g)", (char)format_codes[k]);
+        MA_REQUIRE(chunk_data[k] && chunk_lens[k], MA_ERR_INVALID_ARGUMENT, "column %d: NULL chunk table", k);
+        for (int32_t j = 0; j < k; ++j)  // two columns may share a record only as its integer half and its float half
+            MA_REQUIRE(columns[j] != columns[k] || (format_codes[j] == 'g') != (format_codes[k] == 'g'), MA_ERR_INVALID_ARGUMENT,
+                       "columns %d and %d would write the same slots of record %d", j, k, columns[k]);
+    }
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    DeviceLookup lookup;
+    for (int32_t k = 0; k < n_cols; ++k)
+        for (size_t i = 0; i < group->ctxs.size(); ++i) {
+            if (chunk_lens[k][i] == 0) continue;
+            MA_TRY(require_resident(group, lookup, i, chunk_data[k][i], "data", i));
+            if (chunk_masks && chunk_masks[k]) MA_TRY(require_resident(group, lookup, i, chunk_masks[k][i], "validity bitmap", i));
+        }
+    return run_on_members(group, [&](size_t i) -> ma_status {
+        uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];
+        ma_fused_column cols[MA_FUSED_MAX_COLUMNS];
+        for (int32_t k = 0; k < n_cols; ++k) {
+            uint64_t* rec = set + (size_t)columns[k] * kRecordWords;
+            cols[k].data = chunk_data[k][i];
+            cols[k].n = chunk_lens[k][i];
+            cols[k].mask_bits = (chunk_masks && chunk_masks[k]) ? chunk_masks[k][i] : nullptr;
+            cols[k].mask_bit_offset = (chunk_mask_offsets && chunk_mask_offsets[k]) ? chunk_mask_offsets[k][i] : 0;
+            cols[k].null_count = -1;
+            cols[k].format_code = format_codes[k];
+            cols[k].reserved = 0;
+            cols[k].out = format_codes[k] == 'g' ? rec + 2 : rec;
+        }
+        return ma_sum_fused(group->ctxs[i], (size_t)n_cols, cols);
     });
 }
 
@@ -948,6 +1019,30 @@ ma_status ma_group_exchange(ma_group* group) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     return exchange_locked(group);
+}
+
+ma_status ma_group_exchange_stats(ma_group* group, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
+                                  int32_t* out_rccl_ranks) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    if (!group->use_rccl) {  // host exchange: the records land in pinned memory by themselves, the fold runs in synchronize
+        if (out_all_gather_us) *out_all_gather_us = 0.0;
+        if (out_fold_us) *out_fold_us = group->host_fold_samples ? group->host_fold_us / group->host_fold_samples : 0.0;
+        if (out_samples) *out_samples = group->host_fold_samples;
+        if (out_rccl_ranks) *out_rccl_ranks = 0;
+        group->host_fold_us = 0.0;
+        group->host_fold_samples = 0;
+        return MA_OK;
+    }
+    MA_HIP(hipSetDevice(group->ctxs[0]->device));
+    group->timer.report(out_all_gather_us, out_fold_us, out_samples);
+    if (out_rccl_ranks) {
+        int n = 0;
+        const RcclApi* api = rccl();
+        if (!api || !api->CommCount || group->comms.empty() || api->CommCount(group->comms[0], &n) != ncclSuccess) n = 0;
+        *out_rccl_ranks = n;
+    }
+    return MA_OK;
 }
 
 ma_status ma_group_synchronize(ma_group* group) {

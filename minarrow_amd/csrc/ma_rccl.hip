@@ -18,10 +18,26 @@ bool g_rccl_ok = false;
 char g_rccl_err[256] = "";
 
 void load_rccl() {
-    // A name already loaded into the process (PyTorch's bundled build has the same SONAME) resolves to that copy.
-    static const char* kNames[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RCCL must sit on the SAME HIP runtime as this library: its communicators take our streams and device pointers. A
+    // process can hold two runtimes — a torch-free host of this library that imports torch.distributed for its gloo
+    // rendezvous has /opt/rocm's (ours, loaded first) and PyTorch's bundled one — and a bare dlopen("librccl.so.1") would
+    // then resolve to whichever RCCL was loaded first under that SONAME, i.e. PyTorch's, bound to the OTHER runtime
+    // (ncclCommInitRank fails with a device error). So: first the RCCL that lives next to the libamdhip64 we are linked
+    // against (dladdr of a HIP entry point), by path; only then by name.
+    static char beside[2][512];
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        const char* slash = strrchr(info.dli_fname, '/');
+        if (slash) {
+            const int dir = (int)(slash - info.dli_fname);
+            snprintf(beside[0], sizeof(beside[0]), "%.*s/librccl.so.1", dir, info.dli_fname);
+            snprintf(beside[1], sizeof(beside[1]), "%.*s/librccl.so", dir, info.dli_fname);
+        }
+    }
+    const char* kNames[] = {beside[0], beside[1], "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* name : kNames) {
+        if (!name[0]) continue;
         h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) {
             g_rccl.path = name;
@@ -46,6 +62,7 @@ void load_rccl() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
     g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
@@ -85,6 +102,7 @@ struct ma_comm {
     ma_ctx* side = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool used[2] = {false, false};
+    ma::ExchangeTimer timer;  // every 4th exchange: all-gather / fold durations (ma_comm_exchange_stats)
 };
 
 namespace ma {
@@ -92,6 +110,11 @@ ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal con
 }
 
 extern "C" {
+
+const char* ma_rccl_path(void) {
+    const RcclApi* api = rccl();
+    return api ? api->path : "";
+}
 
 int32_t ma_rccl_version(void) {
     const RcclApi* api = rccl();
@@ -150,6 +173,7 @@ void ma_comm_destroy(ma_comm* comm) {
         if (api) (void)api->CommDestroy(comm->comm);
     }
     if (comm->side) ma_ctx_destroy(comm->side);
+    comm->timer.destroy();
     delete comm;
 }
 
@@ -205,10 +229,13 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
     MA_NO_CAPTURE(ctx, "a collective");
     MA_HIP(hipSetDevice(ctx->device));
     const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
+    const int tk = comm->timer.begin(ctx->stream);
     MA_NCCL(api, AllGather(local_records, gathered, per_rank_words * 8, ncclChar, comm->comm, ctx->stream));
+    comm->timer.mark(tk, 1, ctx->stream);
     // column c is folded over (rank, slot) in that order: records c, c + n_columns, ...
     MA_TRY(enqueue_fold_columns(ctx, gathered, (size_t)comm->n_ranks * slots_per_rank, n_columns * kRecordWords, n_columns,
                                 out_finals));
+    comm->timer.mark(tk, 2, ctx->stream);
     if (!is_async(ctx)) MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
 }
@@ -241,9 +268,12 @@ ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uin
     MA_HIP(hipEventRecord(comm->ready[slot], ctx->stream));
     MA_HIP(hipStreamWaitEvent(side->stream, comm->ready[slot], 0));
     const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
+    const int tk = comm->timer.begin(side->stream);
     MA_NCCL(api, AllGather(local_records, gathered, per_rank_words * 8, ncclChar, comm->comm, side->stream));
+    comm->timer.mark(tk, 1, side->stream);
     MA_TRY(enqueue_fold_columns(side, gathered, (size_t)comm->n_ranks * slots_per_rank, n_columns * kRecordWords, n_columns,
                                 out_finals));
+    comm->timer.mark(tk, 2, side->stream);
     // ... and ma_comm_slot_wait(slot) puts the context's stream behind it
     MA_HIP(hipEventRecord(comm->done[slot], side->stream));
     comm->used[slot] = true;
@@ -267,6 +297,27 @@ ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) {
     }
     (void)hipGetLastError();
     MA_HIP(hipStreamWaitEvent(ctx->stream, comm->done[slot], 0));
+    return MA_OK;
+}
+
+ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
+                                 int32_t* out_rccl_ranks) {
+    MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    ma_ctx* ctx = comm->ctx;
+    MA_ENTER_PRIMARY(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    if (comm->side) {
+        std::lock_guard<std::mutex> lock(comm->side->mu);
+        comm->timer.report(out_all_gather_us, out_fold_us, out_samples);
+    } else {
+        comm->timer.report(out_all_gather_us, out_fold_us, out_samples);
+    }
+    if (out_rccl_ranks) {
+        int n = 0;
+        const RcclApi* api = rccl();
+        if (!api || !api->CommCount || api->CommCount(comm->comm, &n) != ncclSuccess) n = 0;
+        *out_rccl_ranks = n;
+    }
     return MA_OK;
 }
 

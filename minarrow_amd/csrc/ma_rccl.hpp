@@ -20,6 +20,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -33,6 +34,76 @@ struct RcclApi {
 const RcclApi* rccl();
 
 ma_status rccl_fail(ncclResult_t r, const char* what, const char* file, int line);
+
+// Where an exchange's time goes (ma_group_exchange_stats / ma_comm_exchange_stats): every 4th exchange carries three HIP
+// events on the stream it runs on — in front of the all-gather, behind it, behind the fold — so that the first scaling run
+// on a multi-GPU node explains itself (all-gather latency over xGMI vs. the fold kernel). An event costs the stream a few
+// microseconds, hence the sampling; on an overlapped exchange they sit on the side stream, off the scans' path.
+struct ExchangeTimer {
+    static constexpr int kRing = 8, kEvery = 4;
+    hipEvent_t ev[kRing][3] = {};
+    bool pending[kRing] = {};
+    uint64_t calls = 0;
+    int next = 0;
+    double sum_gather_us = 0.0, sum_fold_us = 0.0;
+    int samples = 0;
+
+    // -1: this exchange is not sampled; else the ring slot whose first event was recorded on `s`
+    int begin(hipStream_t s) {
+        if ((calls++ % kEvery) != 0) return -1;
+        const int k = next;
+        next = (next + 1) % kRing;
+        if (pending[k]) harvest_slot(k, true);
+        for (int j = 0; j < 3; ++j)
+            if (!ev[k][j] && hipEventCreate(&ev[k][j]) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
+        if (hipEventRecord(ev[k][0], s) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        return k;
+    }
+    void mark(int k, int which, hipStream_t s) {
+        if (k < 0) return;
+        if (hipEventRecord(ev[k][which], s) != hipSuccess) (void)hipGetLastError();
+        if (which == 2) pending[k] = true;
+    }
+    void harvest_slot(int k, bool wait) {
+        if (!pending[k]) return;
+        if (wait ? hipEventSynchronize(ev[k][2]) != hipSuccess : hipEventQuery(ev[k][2]) != hipSuccess) {
+            (void)hipGetLastError();
+            if (!wait) return;
+        }
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, ev[k][0], ev[k][1]) == hipSuccess && hipEventElapsedTime(&b, ev[k][1], ev[k][2]) == hipSuccess) {
+            sum_gather_us += (double)a * 1e3;
+            sum_fold_us += (double)b * 1e3;
+            ++samples;
+        } else {
+            (void)hipGetLastError();
+        }
+        pending[k] = false;
+    }
+    // averages over the samples taken since the last report (which waits for the sampled exchanges still in flight)
+    void report(double* gather_us, double* fold_us, int32_t* n) {
+        for (int k = 0; k < kRing; ++k) harvest_slot(k, true);
+        if (gather_us) *gather_us = samples ? sum_gather_us / samples : 0.0;
+        if (fold_us) *fold_us = samples ? sum_fold_us / samples : 0.0;
+        if (n) *n = samples;
+        sum_gather_us = sum_fold_us = 0.0;
+        samples = 0;
+    }
+    void destroy() {
+        for (auto& slot : ev)
+            for (hipEvent_t& e : slot)
+                if (e) {
+                    (void)hipEventDestroy(e);
+                    e = nullptr;
+                }
+    }
+};
 
 }  // namespace ma
 

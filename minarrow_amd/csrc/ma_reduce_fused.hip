@@ -1,0 +1,376 @@
+// ma_sum_fused: the sums of up to MA_FUSED_MAX_COLUMNS long 8-byte columns (i64 / u64 / f64, each dense or Bitmask-gated) in
+// ONE launch — a per-column reduce of a table's columns (BASELINE config 5: src/structs/chunked/super_table.rs:657-743 +
+// a reduce per column), or the two loops of the reference's sum bench over one row chunk
+// (benches/benchmark_parallel_simd.rs:99-125, `rayon_simd_sum_i64` then `rayon_simd_sum_f64`).
+//
+// Why one launch. tools/probe_epilogue.hip (profiles/r04_probe_epilogue.jsonl) splits a sum launch's fixed cost on MI355X:
+// ~1.5 us until the first tile's data has arrived (the ramp), ~1.8 us from the last workgroup's last row to the final store
+// (wave reduce -> LDS -> partial published with sc1 stores and drained -> ticket(s) -> the last arrival loads and folds every
+// partial), and the next dependent dispatch starts behind that. A 10^9-row column partitioned over 8 GPUs leaves each GPU
+// 137 us of scan per column: two launches pay the 3.3 us twice per step, one pays it once — the columns' tiles run through
+// the same workgroups back to back with no drain between them (tile index space = the columns' tiles concatenated,
+// tile g -> workgroup g mod grid), every workgroup keeps one accumulator set PER COLUMN in registers, and the epilogue
+// publishes and folds all columns' partials behind ONE ticket.
+//
+// Semantics per column are those of ma_i64_sum / ma_u64_sum / ma_f64_sum_dd (ma_reduce.hip): wrapping u64 accumulation for
+// integers (bit-exact in any order), double-double (Knuth two-sum) for f64 — within 1 ULP of the exactly rounded sum and
+// bit-reproducible for a fixed launch shape —, valid count = popcount of the window's validity bits (or n when dense).
+#include <limits>
+
+#include "ma_acc.hpp"
+#include "ma_device.hpp"
+
+namespace ma {
+
+constexpr int kFusedMax = MA_FUSED_MAX_COLUMNS;
+
+struct FusedCol {
+    const void* data;       // element pointer of the window (8-byte elements)
+    size_t n;               // rows
+    size_t head;            // rows in front of the first 16-byte boundary (0 or 1)
+    size_t n_tiles;         // full workgroup tiles behind `head`
+    size_t tile0;           // index of this column's tile 0 in the launch's concatenated tile space
+    const uint64_t* words;  // validity words (8-byte aligned base) or nullptr = dense
+    size_t bit_off;         // bit index of row 0 relative to `words`
+    size_t last_word;       // index of the last word that holds a window bit
+    uint64_t* out;          // integers: out[0] = sum, out[1] = valid count; f64: out[0], out[1] = (hi, lo), out[2] = valid count
+    int is_float;
+    int pad;
+};
+
+struct FusedArgs {
+    FusedCol col[kFusedMax];
+    int n_cols;
+    Partial* partials;      // column c's partial of workgroup b at [c * gridDim.x + b]
+    unsigned int* ticket;
+    uint64_t* done_word;    // pinned word stamped after the results (synchronous call that polls), or nullptr
+    uint64_t done_seq;
+};
+
+// One accumulator per (column, row-of-a-load): two 64-bit words that are a wrapping integer sum (a) or a double-double
+// (a = hi, b = lo) depending on the column's kind — a wave-uniform runtime choice, so one register set serves both.
+struct Acc2 {
+    uint64_t a, b;
+    __device__ __forceinline__ void init() { a = 0; b = 0; }
+    __device__ __forceinline__ void add_int(uint64_t x) { a += x; }
+    __device__ __forceinline__ void add_f64(double v) {
+        double hi = __longlong_as_double((long long)a), lo = __longlong_as_double((long long)b);
+        const double t = hi + v;
+        const double bp = t - hi;
+        const double e = (hi - (t - bp)) + (v - bp);
+        a = (uint64_t)__double_as_longlong(t);
+        b = (uint64_t)__double_as_longlong(lo + e);
+    }
+    __device__ __forceinline__ void merge(const Acc2& o, bool is_float) {
+        if (is_float) {
+            DDAcc x, y;
+            x.from_words(a, b);
+            y.from_words(o.a, o.b);
+            x.merge(y);
+            a = (uint64_t)__double_as_longlong(x.hi);
+            b = (uint64_t)__double_as_longlong(x.lo);
+        } else {
+            a += o.a;
+        }
+    }
+    __device__ __forceinline__ Acc2 shfl_down(int off) const {
+        Acc2 o;
+        o.a = (uint64_t)__shfl_down((unsigned long long)a, off, 64);
+        o.b = (uint64_t)__shfl_down((unsigned long long)b, off, 64);
+        return o;
+    }
+};
+
+constexpr unsigned kFTicketShards = 8;
+constexpr unsigned kFTicketShardWord0 = 64;   // same layout as ma_reduce.hip's arrival counters (the context's zeroed block)
+constexpr unsigned kFTicketShardStride = 16;
+constexpr unsigned kFShardFrom = 96;
+
+template <int UNROLL, bool ANY_MASKED, int PACE>
+__global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
+    typedef unsigned long long V __attribute__((ext_vector_type(2)));  // 16 bytes = two 8-byte rows
+    constexpr int R = 2;
+    constexpr int WPT = R * UNROLL;
+    constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
+    constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned G = gridDim.x, b = blockIdx.x;
+
+    Acc2 acc[kFusedMax][R];
+    uint64_t cnt[kFusedMax];
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        acc[c][0].init();
+        acc[c][1].init();
+        cnt[c] = 0;
+    }
+
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        if (c >= a.n_cols) continue;
+        const FusedCol& col = a.col[c];
+        const bool is_float = col.is_float != 0;
+        const bool masked = ANY_MASKED && col.words != nullptr;
+        const uint64_t* __restrict__ data = (const uint64_t*)col.data;
+        // this workgroup's first tile of the column: the smallest t >= 0 with (tile0 + t) mod G == b
+        const size_t first = (size_t)((b + G - (unsigned)(col.tile0 % G)) % G);
+        for (size_t t = first; t < col.n_tiles; t += G) {
+            const size_t row0 = col.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = (const V*)(data + row0) + lane;
+            V v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                v[u] = load16<V, true>(p + (size_t)u * 64);
+                if (u + 1 < UNROLL) pace_loads<PACE>();
+            }
+            if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
+            uint64_t aw = ~(uint64_t)0;
+            if constexpr (ANY_MASKED) {
+                if (masked) {
+                    aw = load_run_words<WPT>(col.words, col.bit_off + row0, col.last_word, lane);
+                    if (lane < (unsigned)WPT) cnt[c] += (uint64_t)__popcll(aw);
+                }
+            }
+            if (is_float) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned bits = (ANY_MASKED && masked) ? lane_bits<R>(aw, u, lane) : 3u;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double x = __longlong_as_double((long long)v[u][r]);
+                        acc[c][r].add_f64(((bits >> r) & 1u) ? x : 0.0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const unsigned bits = (ANY_MASKED && masked) ? lane_bits<R>(aw, u, lane) : 3u;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[c][r].add_int(((bits >> r) & 1u) ? (uint64_t)v[u][r] : 0);
+                }
+            }
+        }
+        // ragged rows of this column (the unaligned head, whatever follows the last full tile): the last workgroup's job
+        if (b == G - 1) {
+            const size_t tail_start = col.head + col.n_tiles * TILE_ROWS;
+            const size_t n_ragged = col.head + (col.n - tail_start);
+            for (size_t i = tid; i < n_ragged; i += kBlock) {
+                const size_t row = i < col.head ? i : tail_start + (i - col.head);
+                uint64_t x = as_global(data)[row];
+                unsigned valid = 1;
+                if (ANY_MASKED && masked) {
+                    valid = row_bit(col.words, col.bit_off + row);
+                    cnt[c] += valid;
+                }
+                if (is_float) acc[c][0].add_f64(valid ? __longlong_as_double((long long)x) : 0.0);
+                else acc[c][0].add_int(valid ? x : 0);
+            }
+        }
+        if (!masked && b == 0 && tid == 0) cnt[c] = col.n;  // dense: every row is valid; credited once
+    }
+
+    // ---- workgroup reduce, all columns ------------------------------------------------------------------------------
+    __shared__ Partial lds[kFusedMax][kWaves];
+    __shared__ int is_last;
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        if (c >= a.n_cols) continue;
+        const bool is_float = a.col[c].is_float != 0;
+        acc[c][0].merge(acc[c][1], is_float);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc[c][0].merge(acc[c][0].shfl_down(off), is_float);
+            cnt[c] += (uint64_t)__shfl_down((unsigned long long)cnt[c], off, 64);
+        }
+        if (lane == 0) {
+            lds[c][wave].a = acc[c][0].a;
+            lds[c][wave].b = acc[c][0].b;
+            lds[c][wave].cnt = cnt[c];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < kFusedMax; ++c) {
+            if (c >= a.n_cols) continue;
+            const bool is_float = a.col[c].is_float != 0;
+            Acc2 s;
+            s.a = lds[c][0].a;
+            s.b = lds[c][0].b;
+            uint64_t n = lds[c][0].cnt;
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) {
+                Acc2 o;
+                o.a = lds[c][w].a;
+                o.b = lds[c][w].b;
+                s.merge(o, is_float);
+                n += lds[c][w].cnt;
+            }
+            uint64_t* q = (uint64_t*)&a.partials[(size_t)c * G + b];
+            store_agent(q, s.a);
+            store_agent(q + 1, s.b);
+            store_agent(q + 2, n);
+        }
+        // publish (write-through stores, drained), then arrive: ma_reduce.hip's hand-off, once for all columns
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int last;
+        if (G <= kFShardFrom) {
+            last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+        } else {
+            const unsigned sh = b & (kFTicketShards - 1);
+            const unsigned members = (G - sh + kFTicketShards - 1) / kFTicketShards;
+            unsigned int* shard = a.ticket + kFTicketShardWord0 + sh * kFTicketShardStride;
+            last = 0;
+            if (__hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kFTicketShards - 1;
+            }
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+
+    // ---- the last workgroup folds every column's partials: in index order per thread, then across threads ------------
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        if (c >= a.n_cols) continue;
+        const bool is_float = a.col[c].is_float != 0;
+        Acc2 tot;
+        tot.init();
+        uint64_t tc = 0;
+        for (unsigned i = tid; i < G; i += kBlock) {
+            const uint64_t* q = (const uint64_t*)&a.partials[(size_t)c * G + i];
+            Acc2 o;
+            o.a = load_agent(q);
+            o.b = load_agent(q + 1);
+            tot.merge(o, is_float);
+            tc += load_agent(q + 2);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tot.merge(tot.shfl_down(off), is_float);
+            tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
+        }
+        if (lane == 0) {
+            lds[c][wave].a = tot.a;
+            lds[c][wave].b = tot.b;
+            lds[c][wave].cnt = tc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < kFusedMax; ++c) {
+            if (c >= a.n_cols) continue;
+            const bool is_float = a.col[c].is_float != 0;
+            Acc2 s;
+            s.a = lds[c][0].a;
+            s.b = lds[c][0].b;
+            uint64_t n = lds[c][0].cnt;
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) {
+                Acc2 o;
+                o.a = lds[c][w].a;
+                o.b = lds[c][w].b;
+                s.merge(o, is_float);
+                n += lds[c][w].cnt;
+            }
+            uint64_t* out = a.col[c].out;
+            if (is_float) {
+                DDAcc d;
+                d.from_words(s.a, s.b);
+                d.normalise();
+                out[0] = (uint64_t)__double_as_longlong(d.hi);
+                out[1] = (uint64_t)__double_as_longlong(d.lo);
+                out[2] = n;
+            } else {
+                out[0] = s.a;
+                out[1] = n;
+            }
+        }
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+        if (a.done_word) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int UNROLL, bool ANY_MASKED>
+static void launch_fused(ma_ctx* ctx, const FusedArgs& a, int grid, int pace) {
+    if constexpr (ANY_MASKED) {
+        hipLaunchKernelGGL((sum_fused_kernel<UNROLL, true, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else {
+        switch (pace) {
+            case 0: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
+            case 24: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 24>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 20>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
+        }
+    }
+}
+
+}  // namespace ma
+
+using namespace ma;
+
+extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(n_cols >= 1 && n_cols <= (size_t)kFusedMax && cols != nullptr, MA_ERR_INVALID_ARGUMENT,
+               "ma_sum_fused takes 1..%d columns", kFusedMax);
+    MA_ENTER(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    CallScope scope(ctx);
+    FusedArgs a{};
+    a.n_cols = (int)n_cols;
+    bool any_masked = false;
+    for (size_t c = 0; c < n_cols; ++c) {
+        const ma_fused_column& in = cols[c];
+        MA_REQUIRE(in.format_code == 'l' || in.format_code == 'L' || in.format_code == 'g', MA_ERR_UNSUPPORTED,
+                   "column %zu: format '%c' (ma_sum_fused takes the 8-byte formats l, L and g)", c, (char)in.format_code);
+        MA_REQUIRE(in.n == 0 || in.data != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu: data is NULL", c);
+        MA_REQUIRE(((uintptr_t)in.data & 7) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu: data pointer %p is not 8-byte aligned", c, in.data);
+        MA_REQUIRE(in.out != nullptr && ((uintptr_t)in.out & 7) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu: out is NULL or misaligned", c);
+        MA_REQUIRE(in.n == 0 || pointer_kind(in.data) != kPageable, MA_ERR_INVALID_ARGUMENT,
+                   "column %zu: ma_sum_fused scans device-resident (or pinned) columns in place; sum a pageable host column with "
+                   "ma_i64_sum / ma_f64_sum_dd", c);
+        MA_REQUIRE(pointer_kind(in.out) != kPageable, MA_ERR_INVALID_ARGUMENT,
+                   "column %zu: out must be device-reachable (device or ma_alloc64_pinned memory)", c);
+        FusedCol& col = a.col[c];
+        col.data = in.data;
+        col.n = in.n;
+        col.is_float = in.format_code == 'g';
+        col.out = in.out;
+        const bool masked = in.mask_bits != nullptr && in.null_count != 0 && in.n != 0;  // the all_true / null_count gate
+        if (masked) {
+            MA_REQUIRE(pointer_kind(in.mask_bits) != kPageable, MA_ERR_INVALID_ARGUMENT,
+                       "column %zu: the validity bitmap must be device-reachable", c);
+            MA_TRY(scope.in_mask(in.mask_bits, in.mask_bit_offset, in.n, &col.words, &col.bit_off));
+            col.last_word = (col.bit_off + in.n - 1) >> 6;
+            any_masked = true;
+        }
+    }
+    // Launch shape: ma_reduce.hip's — dense 8-byte scans one workgroup per CU with 8 paced loads per lane, anything with
+    // validity work between the loads two per CU with 4; mid-size jobs (<= 24 tiles per CU) three per CU.
+    const int unroll = any_masked ? 4 : 8;
+    const size_t tile_rows = (size_t)64 * 2 * (size_t)unroll * kWaves;
+    size_t total_tiles = 0;
+    for (size_t c = 0; c < n_cols; ++c) {
+        FusedCol& col = a.col[c];
+        col.head = (col.n && ((uintptr_t)col.data & 15)) ? 1 : 0;
+        col.n_tiles = (col.n - col.head) / tile_rows;
+        col.tile0 = total_tiles;
+        total_tiles += col.n_tiles;
+    }
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (any_masked ? 2 : 1);
+    if (!any_masked && ctx->blocks_per_cu <= 0 && total_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
+    int grid = grid_for(ctx, total_tiles, bpc);
+    if ((size_t)grid * n_cols > (size_t)kMaxGrid) grid = (int)((size_t)kMaxGrid / n_cols);
+    a.partials = ctx->partials;
+    a.ticket = ctx->ticket;
+    static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
+    const int sel = kPace[(ctx->variant >> 5) & 7];
+    const int pace = sel >= 0 ? sel : 20;
+    if (any_masked) launch_fused<4, true>(ctx, a, grid, 0);
+    else launch_fused<8, false>(ctx, a, grid, pace);
+    MA_HIP(hipGetLastError());
+    return end_call(ctx, scope);
+}

@@ -54,6 +54,12 @@ def addr_of(x) -> int:
     raise TypeError(f"cannot take the address of {type(x)!r}")
 
 
+class FusedColumn(C.Structure):
+    """struct ma_fused_column (include/minarrow_hip.h)."""
+    _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("mask_bits", C.c_void_p), ("mask_bit_offset", C.c_size_t),
+                ("null_count", C.c_int64), ("format_code", C.c_int32), ("reserved", C.c_int32), ("out", C.c_void_p)]
+
+
 class DeviceBuffer:
     """Device-resident bytes owned through ma_dev_alloc / ma_dev_free. output=True: ma_dev_alloc_output — a block meant
     to be written by the kernels, picked for its write rate (`write_gbps` holds the measured figure, 0 if none)."""
@@ -249,6 +255,15 @@ class Context:
         ffi.check(self.lib.ma_ctx_timer_elapsed_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
+    def mark(self, index: int) -> None:
+        """Record timing mark `index` on the context's stream (ma_ctx_mark)."""
+        ffi.check(self.lib.ma_ctx_mark(self.handle, index))
+
+    def mark_elapsed_ms(self, from_index: int, to_index: int) -> float:
+        ms = C.c_float()
+        ffi.check(self.lib.ma_ctx_mark_elapsed_ms(self.handle, from_index, to_index, C.byref(ms)))
+        return float(ms.value)
+
     # -- hipGraph capture ------------------------------------------------------------------------------
     def capture_begin(self) -> None:
         """Record (instead of run) every following call on this context until `capture_end`."""
@@ -342,6 +357,24 @@ class Context:
             fn = getattr(self.lib, f"ma_{tag}_sum")
             ffi.check(fn(self.handle, addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count),
                          addr_of(out_sum), addr_of(out_count)))
+
+    def sum_fused(self, columns) -> None:
+        """ONE launch for the sums of up to 4 long 8-byte columns (ma_sum_fused). `columns`: dicts / tuples
+        (fmt, data, n, out[, mask, mask_bit_offset, null_count]) with fmt in 'l', 'L', 'g'; `out` is a device-reachable
+        address: integers get out[0] = sum, out[1] = count, 'g' gets out[0], out[1] = (hi, lo) bits, out[2] = count."""
+        arr = (FusedColumn * len(columns))()
+        for i, col in enumerate(columns):
+            fmt, data, n, out = col[:4]
+            mask = col[4] if len(col) > 4 else None
+            arr[i].data = addr_of(data)
+            arr[i].n = int(n)
+            arr[i].mask_bits = addr_of(mask)
+            arr[i].mask_bit_offset = int(col[5]) if len(col) > 5 else 0
+            arr[i].null_count = int(col[6]) if len(col) > 6 else -1
+            arr[i].format_code = ord(fmt)
+            arr[i].reserved = 0
+            arr[i].out = addr_of(out)
+        ffi.check(self.lib.ma_sum_fused(self.handle, len(columns), C.addressof(arr)))
 
     def sum_columns(self, fmt: str, columns, lens, masks=None, mask_offsets=None):
         """Per-column (sums as float64 array, sums as wrapped int64 array or None for float formats, valid counts)
@@ -680,6 +713,39 @@ class Group:
         d, l, m, o, keep = self._tables(chunks, lens, masks, mask_offsets)
         ffi.check(getattr(self.lib, f"ma_group_enqueue_sum_{tag}")(self.handle, int(column), d, l, m, o))
 
+    def enqueue_sum_table(self, columns) -> None:
+        """ONE fused launch per member for several partitioned 8-byte columns (ma_group_enqueue_sum_table).
+        `columns`: tuples (fmt, record_slot, chunks, lens[, masks, mask_offsets]) with fmt in 'l', 'L', 'g'."""
+        k = len(columns)
+        n = self.size
+        slots = (C.c_int32 * k)(*[int(c[1]) for c in columns])
+        fmts = (C.c_int32 * k)(*[ord(c[0]) for c in columns])
+        keep = []
+        data_t, lens_t, masks_t, offs_t = ((C.c_void_p * k)() for _ in range(4))
+        any_mask = False
+        for j, c in enumerate(columns):
+            chunks, lens = c[2], c[3]
+            masks = c[4] if len(c) > 4 else None
+            offs = c[5] if len(c) > 5 else None
+            d = (C.c_void_p * n)(*[addr_of(x) for x in chunks])
+            ln = (C.c_size_t * n)(*[int(x) for x in lens])
+            keep += [d, ln]
+            data_t[j], lens_t[j] = C.addressof(d), C.addressof(ln)
+            if masks is not None:
+                m = (C.c_void_p * n)(*[addr_of(x) for x in masks])
+                o = (C.c_size_t * n)(*[int(x) for x in (offs or [0] * n)])
+                keep += [m, o]
+                masks_t[j], offs_t[j] = C.addressof(m), C.addressof(o)
+                any_mask = True
+        ffi.check(self.lib.ma_group_enqueue_sum_table(self.handle, k, slots, fmts, data_t, lens_t, masks_t if any_mask else None,
+                                                      offs_t if any_mask else None))
+
+    def exchange_stats(self):
+        """{all_gather_us, fold_us, samples, rccl_ranks} of the exchanges sampled since the last call (ma_group_exchange_stats)."""
+        g, f, k, r = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        ffi.check(self.lib.ma_group_exchange_stats(self.handle, C.byref(g), C.byref(f), C.byref(k), C.byref(r)))
+        return {"all_gather_us": g.value, "fold_us": f.value, "samples": int(k.value), "rccl_ranks": int(r.value)}
+
     def enqueue_sum_chunks(self, fmt: str, column: int, chunks, lens, masks=None, mask_offsets=None) -> None:
         """ONE column held as many chunks, chunk i on member i % size (ma_group_enqueue_sum_chunks). Enqueues only:
         exchange(), synchronize(), then result(column)."""
@@ -798,6 +864,11 @@ class Comm:
         """The exchange of record set `slot` (0 / 1) on the communicator's own stream; the context's stream goes on at once."""
         ffi.check(self.lib.ma_comm_sum_exchange_overlapped(self.handle, int(slot), addr_of(local_records), int(slots_per_rank),
                                                            int(n_columns), addr_of(gathered), addr_of(out_finals)))
+
+    def exchange_stats(self):
+        g, f, k, r = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        ffi.check(self.lib.ma_comm_exchange_stats(self.handle, C.byref(g), C.byref(f), C.byref(k), C.byref(r)))
+        return {"all_gather_us": g.value, "fold_us": f.value, "samples": int(k.value), "rccl_ranks": int(r.value)}
 
     def slot_wait(self, slot: int) -> None:
         """Puts the context's stream behind the last overlapped exchange of record set `slot`."""

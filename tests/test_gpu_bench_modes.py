@@ -41,6 +41,22 @@ def test_single_gpu_line_with_other_configs_and_cpu_baseline():
             assert oc["config5_supertable_8_batches"][tag][leg]["parity"] is True
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # `cores` is the pool that produced `value`; what a quota-bound host sustains is reported next to it
+    assert cb["cores"] == cb["pool_threads"] and 0 < cb["value_quota_bound"] <= cb["value"] * 1.001 and cb["cores_quota_bound"] >= 1
+    # the headline is the product's own form: no torch in the process, /opt/rocm's HIP runtime, timing marks for the kernels
+    assert out["config"]["host"] == "torch-free" and "torch" not in out["config"]["hip_runtime"]
+    assert set(out["kernels"]) == {"sum_i64", "sum_f64"} and out["roofline"]["kernel"].startswith("ma::sum_kernel")
+    th = out["torch_hosted"]  # the same headline hosted by PyTorch, as a labelled extra key
+    assert th["parity_ok"] and th["value"] > 0 and "torch" in th["hip_runtime"]
+
+
+def test_single_gpu_fused_step_and_torch_hosted_variant():
+    fused = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--no-torch-hosted-leg", "--step", "fused"])
+    assert fused["parity_ok"] and set(fused["kernels"]) == {"sum_fused"}
+    assert fused["kernels"]["sum_fused"]["bytes_per_launch"] == 2 * 8 * (1 << 24) and "sum_fused" in fused["roofline"]["kernel"]
+    hosted = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--torch-hosted"])
+    assert hosted["parity_ok"] and "torch-hosted" in hosted["config"]["host"] and "torch" in hosted["config"]["hip_runtime"]
+    assert hosted["result"]["i64_sum"] == fused["result"]["i64_sum"] and hosted["result"]["f64_sum"] == fused["result"]["f64_sum"]
 
 
 def test_one_process_group_mode_with_rccl():
@@ -53,6 +69,16 @@ def test_one_process_group_mode_with_rccl():
     assert "issue: threads" in out["config"]["parallelism"] and out["config"]["host_issue_us_per_step"] > 0
     assert out["n1_same_process"]["value"] > 0 and 0.2 < out["efficiency_vs_n1"] < 2.0
     assert out["config"]["rccl_ranks"] == 1 and "RCCL all-gather (ncclCommInitAll" in out["config"]["exchange"]
+    # the line explains itself: where the exchange's time goes (HIP events on member 0's exchange stream, every 4th step),
+    # what RCCL says its communicator's size is, the members' scan times, and the step's form
+    cfg = out["config"]
+    assert cfg["exchange_samples"] >= 1 and cfg["exchange_us"] > 0 and cfg["fold_us"] > 0
+    assert 0 < cfg["scan_ms_per_step_min_over_members"] <= cfg["scan_ms_per_step_max_over_members"]
+    assert "fused" in cfg["step"] and set(out["kernels"]) == {"sum_fused"} and cfg["host"] == "torch-free"
+    sep = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--no-other-configs",
+               "--step", "separate"])
+    assert sep["parity_ok"] and set(sep["kernels"]) == {"sum_i64", "sum_f64"}
+    assert sep["result"]["i64_sum"] == out["result"]["i64_sum"] and sep["result"]["f64_sum"] == out["result"]["f64_sum"]
     oc = out["other_configs"]  # the multi-GPU legs of configs 4 and 5 (one GPU here)
     assert oc["parity_ok"] is True
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
@@ -70,10 +96,13 @@ def test_one_process_group_mode_with_rccl():
     assert weak["result"]["i64_sum"] == out["result"]["i64_sum"]
 
 
-@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("torch", []), ("torch", ["--overlap"])])
+@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("host", []),
+                                             ("torch", ["--torch-hosted"]), ("torch", ["--torch-hosted", "--overlap"]),
+                                             ("native", ["--torch-hosted"])])
 def test_launcher_mode_one_rank(exchange, extra):
-    """One process per GPU under torch.distributed.run: the library's own communicator (ma_comm_*), torch's all-gather,
-    and torch's all-gather on a side stream (--overlap)."""
+    """One process per GPU under torch.distributed.run. Default: the GPU path is torch-free (gloo carries the rendezvous
+    only) and the exchange is the library's own communicator (ma_comm_*) or, as its fall-back, the records over host memory;
+    --torch-hosted: torch's runtime and streams, the library's communicator or torch.distributed's all-gather."""
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
                "--other-reps", "2", "--exchange", exchange, *extra])
@@ -83,19 +112,32 @@ def test_launcher_mode_one_rank(exchange, extra):
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True
     assert oc["parity_ok"] is True, oc
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
-    want = "ma_comm_*" if exchange == "native" else "torch.distributed"
+    hosted = "--torch-hosted" in extra
+    want = {"native": "ma_comm_*", "torch": "torch.distributed", "host": "device fold"}[exchange]
     assert want in out["config"]["exchange"]
-    if extra:
+    if "--overlap" in extra:
         assert "side stream" in out["config"]["exchange"]
+    if not hosted:
+        cfg = out["config"]
+        assert "torch-free" in cfg["host"] and "torch" not in cfg["hip_runtime"] and "fused" in cfg["step"]
+        assert {"exchange_us", "fold_us", "exchange_samples", "rccl_ranks", "scan_ms_per_step_min_over_ranks"} <= set(cfg)
+        if exchange == "native":
+            assert cfg["rccl_ranks"] == 1 and cfg["exchange_samples"] >= 1 and cfg["exchange_us"] > 0 and cfg["fold_us"] > 0
+    else:
+        assert "torch-hosted" in out["config"]["host"]
 
 
 def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(monkeypatch):
     """bench.py checks the set-up step's finals on every rank before timing anything; a communicator that folds wrongly
-    (forced here) is dropped for torch.distributed's exchange on all ranks, overlap included, and the line says so."""
+    (forced here) is dropped on all ranks — for the records over host memory in the default form, for torch.distributed's
+    exchange in the torch-hosted one — and the line says so."""
     monkeypatch.setenv("MA_BENCH_DISTRUST_NATIVE_COMM", "1")
-    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-               "127.0.0.1", "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
-               "--no-other-configs", "--overlap", "on"])
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+            "127.0.0.1", "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+            "--no-other-configs", "--overlap", "on"]
+    out = run(base)
+    assert out["parity_ok"] and "set-up check" in out["config"]["exchange"] and "host memory" in out["config"]["exchange"]
+    out = run(base + ["--torch-hosted"])
     assert out["parity_ok"] and "torch.distributed" in out["config"]["exchange"] and "set-up check" in out["config"]["exchange"]
     assert "side stream" in out["config"]["exchange"]
 

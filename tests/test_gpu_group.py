@@ -558,3 +558,58 @@ def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
         g.exchange()
         g.synchronize()
         assert g.result(7, 0)[:2] == (0, 0)
+
+
+@pytest.mark.parametrize("members, exchange", [(1, "host"), (3, "host"), (8, "host"), (1, "rccl"), (1, "rccl-overlap")])
+def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members, exchange):
+    """ma_group_enqueue_sum_table: the partitioned step as ONE launch per member (i64 + f64 chunk of each member, dense and
+    Bitmask-gated) must give the finals of the two-launch form bit for bit, through either exchange, step after step."""
+    from minarrow_amd.host import Group
+
+    n = 3_000_011
+    rng = np.random.default_rng(members * 11 + len(exchange))
+    ints = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+    flts = rng.standard_normal(n) * 1e9
+    bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
+    with Group([0] * members, exchange=exchange) as g:
+        ctxs = [g.member_ctx(i) for i in range(members)]
+        chunks = row_chunks(n, members)
+        lens = [b - a for a, b in chunks]
+        # every member's chunks live in its own context's allocations (same device here)
+        di = [ctxs[i].to_device(ints[a:b], 64) for i, (a, b) in enumerate(chunks)]
+        df = [ctxs[i].to_device(flts[a:b], 64) for i, (a, b) in enumerate(chunks)]
+        dm = [ctxs[i].to_device(bits, 16) for i in range(members)]
+        offs = [a for a, _ in chunks]
+        for masks in (None, dm):
+            for _ in range(3):  # overlapped exchanges alternate between two record sets
+                g.enqueue_sum_table([("l", 2, di, lens, masks, offs), ("g", 2, df, lens, masks, offs)])
+                g.exchange()
+            g.synchronize()
+            fused = g.result(2)
+            for _ in range(3):
+                g.enqueue_sum("i64", 5, di, lens, masks, offs if masks else None)
+                g.enqueue_sum("f64", 5, df, lens, masks, offs if masks else None)
+                g.exchange()
+            g.synchronize()
+            assert g.result(5) == fused
+            if masks is None:
+                want_i, want_c = oracle.sum_scalar(ints), n
+                exact = math.fsum(flts.tolist())
+            else:
+                want_i, want_c = oracle.masked_sum(ints, bits, 0)
+                valid = np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+                exact = math.fsum(flts[valid].tolist())
+            assert (fused[0], fused[1], fused[3]) == (want_i, want_c, want_c)
+            assert abs(fused[2] - exact) <= math.ulp(exact)
+        st = g.exchange_stats()
+        if exchange.startswith("rccl") and g.exchange_kind == "rccl":
+            assert st["rccl_ranks"] == 1 and st["samples"] >= 1 and st["all_gather_us"] > 0 and st["fold_us"] > 0
+        else:
+            assert st["rccl_ranks"] == 0 and st["all_gather_us"] == 0.0
+        # the argument checks: an unsupported format, two columns on the same half of one record
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.enqueue_sum_table([("i", 0, di, lens)])
+        assert e.value.status == ffi.MA_ERR_UNSUPPORTED
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.enqueue_sum_table([("l", 1, di, lens), ("L", 1, di, lens)])
+        assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT

@@ -370,6 +370,11 @@ def test_output_allocator_picks_by_measured_write_rate(ctx):
     (DESIGN.md §3.4); the rejected candidates are parked and handed out by the next allocations; small blocks take the
     plain path. The block must be usable like any other."""
     n = 40_000_000  # 320 MB
+    plain = ctx.alloc_output(n * 8)  # the search is opt-in (round 4): by default this is ma_dev_alloc, nothing is measured
+    assert plain.write_gbps == 0.0 and plain.alloc_stats["blocks_measured"] == 0
+    plain.free()
+    before = ctx.lib.ma_dev_output_search(1)
+    assert before == 0 and ctx.lib.ma_dev_output_search(-1) == 1
     out = ctx.alloc_output(n * 8)
     assert 1000.0 < out.write_gbps < 8000.0  # measured, and a plausible HBM figure
     a = ctx.alloc(n * 8)                     # a parked candidate when any was rejected, else a fresh block
@@ -384,3 +389,4 @@ def test_output_allocator_picks_by_measured_write_rate(ctx):
     assert small.write_gbps == 0.0
     for b in (a, again, small):
         b.free()
+    assert ctx.lib.ma_dev_output_search(0) == 1

@@ -1,0 +1,170 @@
+"""GPU parity tests for ma_sum_fused: several long 8-byte columns (i64 / u64 / f64, dense or Bitmask-gated) summed in ONE
+launch, through the C ABI. Per-column results must equal the single-column entry points' (ma_i64_sum, ma_f64_sum_dd), i.e.
+the oracle's restatement of benches/benchmark_parallel_simd.rs:44-98: integers and counts bit-exact, f64 within 1 ULP of the
+exactly rounded sum (math.fsum)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+def ulps(a: float, b: float) -> float:
+    return 0.0 if a == b else abs(a - b) / math.ulp(b)
+
+
+def unpack(bits, off, n):
+    return np.unpackbits(bits, bitorder="little")[off:off + n].astype(bool)
+
+
+def _records(ctx, n_cols):
+    return ctx.alloc(64 * n_cols)
+
+
+def _read(rec, c):
+    w = rec.download(np.uint64, 8, 64 * c)
+    return w
+
+
+@pytest.mark.parametrize("n_i,n_f", [(0, 0), (1, 3), (63, 64), (4096, 4097), (8191, 12345), (100_003, 70_001),
+                                      ((1 << 20) + 37, (1 << 20) - 5), (3_000_017, 2_500_000), (5, 3_000_017)])
+def test_i64_plus_f64_dense(ctx, oracle, n_i, n_f):
+    """The headline step's shape: an i64 column and an f64 column of (possibly) different lengths, one launch."""
+    rng = np.random.default_rng(n_i * 7 + n_f)
+    a = rng.integers(-(1 << 62), 1 << 62, size=n_i, dtype=np.int64)
+    f = rng.standard_normal(n_f) * 1e6
+    da, df = ctx.to_device(a, pad_bytes=64), ctx.to_device(f, pad_bytes=64)
+    rec = _records(ctx, 1)
+    ctx.dev_memset(rec, 0xAB, 64)
+    ctx.sum_fused([("l", da, n_i, rec.ptr), ("g", df, n_f, rec.ptr + 16)])
+    w = _read(rec, 0)
+    assert int(w[0]) == oracle.sum_scalar(a) & M64 and int(w[1]) == n_i
+    hi, lo = w[2:4].view(np.float64)
+    exact = math.fsum(f.tolist())
+    assert int(w[4]) == n_f
+    assert ulps(float(hi), exact) <= 1 if exact else hi == 0
+    # the pair is the one ma_f64_sum_dd gives for the same launch-independent exact arithmetic: hi + lo rounds to hi
+    assert float(hi) + float(lo) == float(hi)
+    single_i = ctx.sum("i64", da, n_i)
+    assert single_i == (oracle.sum_scalar(a), n_i)
+
+
+@pytest.mark.parametrize("n", [1, 64, 200, 4097, 9000, 100_003, (1 << 20) + 37])
+@pytest.mark.parametrize("bit_off", [0, 3, 64, 77, 130])
+def test_masked_columns(ctx, oracle, n, bit_off):
+    """Config 5's table step: i64 + f64 columns sharing one validity bitmap, plus a dense u64 column in the same launch."""
+    rng = np.random.default_rng(n * 31 + bit_off)
+    a = rng.integers(-(1 << 63), (1 << 63) - 1, size=n, dtype=np.int64)
+    f = rng.standard_normal(n) * 1e8
+    u = rng.integers(0, (1 << 64) - 1, size=n, dtype=np.uint64)
+    bits = rng.integers(0, 256, size=(bit_off + n + 7) // 8 + 8, dtype=np.uint8)
+    valid = unpack(bits, bit_off, n)
+    f[~valid] = np.nan  # null slots may hold anything
+    da, df, du = (ctx.to_device(x, pad_bytes=64) for x in (a, f, u))
+    m = ctx.to_device(bits, pad_bytes=16)
+    rec = _records(ctx, 2)
+    ctx.sum_fused([("l", da, n, rec.ptr, m, bit_off), ("g", df, n, rec.ptr + 16, m, bit_off), ("L", du, n, rec.ptr + 64)])
+    w0, w1 = _read(rec, 0), _read(rec, 1)
+    want_sum, want_cnt = oracle.masked_sum(a, bits, bit_off)
+    assert (int(w0[0]), int(w0[1])) == (want_sum & M64, want_cnt)
+    exact = math.fsum(f[valid].tolist())
+    hi = float(w0[2:3].view(np.float64)[0])
+    assert int(w0[4]) == want_cnt and (ulps(hi, exact) <= 1 if exact else hi == 0)
+    assert int(w1[0]) == int(u.sum(dtype=np.uint64)) and int(w1[1]) == n
+    # equal to the single-column entry points, bit for bit (same accumulators, same kind of fold)
+    assert ctx.sum("i64", da, n, mask=m, mask_bit_offset=bit_off) == (want_sum, want_cnt)
+    one_hi, one_lo, one_cnt = ctx.sum_dd("f64", df, n, mask=m, mask_bit_offset=bit_off)
+    assert one_cnt == want_cnt and ulps(one_hi, exact) <= 1 if exact else True
+
+
+def test_null_count_zero_takes_the_dense_kernel(ctx):
+    n = 300_000
+    a = np.arange(1, n + 1, dtype=np.int64)
+    none_set = np.zeros(n // 8 + 16, dtype=np.uint8)
+    d, m = ctx.to_device(a), ctx.to_device(none_set)
+    rec = _records(ctx, 1)
+    ctx.sum_fused([("l", d, n, rec.ptr, m, 0, 0)])  # null_count = 0: the bitmap is never read (simd.rs:144 gate)
+    w = _read(rec, 0)
+    assert (int(w[0]), int(w[1])) == (int(a.sum()), n)
+    ctx.sum_fused([("l", d, n, rec.ptr, m, 0, -1)])
+    w = _read(rec, 0)
+    assert (int(w[0]), int(w[1])) == (0, 0)
+
+
+def test_four_columns_unaligned_windows_and_async(ctx, oracle):
+    """Views that start mid-vector (data + 1 element), four columns, enqueue-only, repeated: every launch the same bits."""
+    n = 1_234_567
+    rng = np.random.default_rng(5)
+    cols = [rng.integers(-(1 << 62), 1 << 62, size=n + 1, dtype=np.int64) for _ in range(2)]
+    fl = [rng.standard_normal(n + 1) for _ in range(2)]
+    dev = [ctx.to_device(x, pad_bytes=64) for x in cols + fl]
+    rec = _records(ctx, 2)
+    spec = [("l", dev[0].ptr + 8, n, rec.ptr), ("g", dev[2].ptr + 8, n, rec.ptr + 16),
+            ("l", dev[1].ptr, n, rec.ptr + 64), ("g", dev[3].ptr, n, rec.ptr + 64 + 16)]
+    ctx.set_async(True)
+    seen = set()
+    for _ in range(5):
+        ctx.sum_fused(spec)
+        ctx.synchronize()
+        seen.add(rec.download(np.uint64, 16).tobytes())
+    ctx.set_async(False)
+    assert len(seen) == 1  # bit-reproducible for a fixed launch shape
+    w0, w1 = _read(rec, 0), _read(rec, 1)
+    assert int(w0[0]) == oracle.sum_scalar(cols[0][1:]) & M64 and int(w0[1]) == n
+    assert int(w1[0]) == oracle.sum_scalar(cols[1][:n]) & M64 and int(w1[1]) == n
+    assert ulps(float(w0[2:3].view(np.float64)[0]), math.fsum(fl[0][1:].tolist())) <= 1
+    assert ulps(float(w1[2:3].view(np.float64)[0]), math.fsum(fl[1][:n].tolist())) <= 1
+
+
+def test_rejections(ctx):
+    from minarrow_amd import ffi
+
+    n = 1000
+    a = np.arange(n, dtype=np.int64)
+    d = ctx.to_device(a)
+    rec = _records(ctx, 1)
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.sum_fused([("i", d, n, rec.ptr)])  # 4-byte format
+    assert e.value.status == ffi.MA_ERR_UNSUPPORTED
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.sum_fused([("l", a, n, rec.ptr)])  # pageable host column: not staged here
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.sum_fused([("l", d, n, rec.ptr)] * 5)  # more than MA_FUSED_MAX_COLUMNS
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+    with pytest.raises(ffi.MinarrowHipError) as e:
+        ctx.sum_fused([("l", d.ptr + 4, n - 1, rec.ptr)])  # not element-aligned
+    assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+def test_one_billion_rows_both_columns_one_launch(ctx):
+    """BASELINE configs[1] at full size as ONE launch: sum(0..10^9) over an i64 and an f64 iota column. Closed forms."""
+    n = 1_000_000_000
+    ci, cf = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    ctx.synth_iota("i64", ci, n, 0)
+    ctx.synth_iota("f64", cf, n, 0)
+    rec = _records(ctx, 1)
+    ctx.sum_fused([("l", ci, n, rec.ptr), ("g", cf, n, rec.ptr + 16)])
+    w = _read(rec, 0)
+    expect = n * (n - 1) // 2
+    assert int(w[0]) == expect and int(w[1]) == n and int(w[4]) == n
+    hi = float(w[2:3].view(np.float64)[0])
+    assert abs(hi - float(expect)) <= math.ulp(float(expect))
+    # the 8-way row-chunk partition of the multi-GPU step, each share as one fused launch: checksum of checksums
+    from minarrow_amd.parallel import fold_dd, row_chunks
+
+    tot_i, pairs = 0, []
+    recs = _records(ctx, 8)
+    for k, (lo, hi_) in enumerate(row_chunks(n, 8)):
+        ctx.sum_fused([("l", ci.ptr + lo * 8, hi_ - lo, recs.ptr + 64 * k), ("g", cf.ptr + lo * 8, hi_ - lo, recs.ptr + 64 * k + 16)])
+    for k in range(8):
+        w = _read(recs, k)
+        tot_i = (tot_i + int(w[0])) & M64
+        pairs.append(tuple(float(x) for x in w[2:4].view(np.float64)))
+    assert tot_i == expect & M64
+    assert abs(fold_dd(pairs) - float(expect)) <= math.ulp(float(expect))
+    ci.free()
+    cf.free()
