@@ -821,9 +821,11 @@ def run_group(args, result_fd) -> int:
 
     fused = args.step != "separate"  # the partitioned step as ONE launch per member (ma_group_enqueue_sum_table)
 
+    enqueue_fused = group.prepare_sum_table([("l", 0, cols_i, lens), ("g", 0, cols_f, lens)])  # pointer tables built once
+
     def step():
         if fused:
-            group.enqueue_sum_table([("l", 0, cols_i, lens), ("g", 0, cols_f, lens)])
+            enqueue_fused()
         else:
             group.enqueue_sum("i64", 0, cols_i, lens)
             group.enqueue_sum("f64", 0, cols_f, lens)
@@ -831,6 +833,7 @@ def run_group(args, result_fd) -> int:
 
     step()  # set-up, never timed: first use of the communicator and of the fold kernel
     group.synchronize()
+    ramp_steps, ramp_spent, settled = _settle(step, group.synchronize, args)  # clocks up, the box quiet (see run_native)
     for _ in range(args.warmup):
         step()
     group.synchronize()
@@ -874,7 +877,7 @@ def run_group(args, result_fd) -> int:
                        (f" [{group.exchange_note}]" if group.exchange_note else ""),
                        {"rccl_ranks": stats["rccl_ranks"], "launch": "single process",
                         "step": "one fused launch per member (ma_group_enqueue_sum_table)" if fused else "two launches per member",
-                        "host": "torch-free", "hip_runtime": _hip_runtime_path(),
+                        "host": "torch-free", "hip_runtime": _hip_runtime_path(), "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                         "host_issue_us_per_step": host_issue / args.steps * 1e6,
                         "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                         "scan_ms_per_step_min_over_members": min(per_member), "scan_ms_per_step_max_over_members": max(per_member)})
@@ -1040,6 +1043,30 @@ def ranks_other_configs(env, col_i, col_f, rows: int, reps: int):
     return res
 
 
+def _settle(step, synchronize, args):
+    """Un-timed steps in front of the warm-up: at least --ramp-ms of them (clocks), then on until three consecutive batches of
+    4 steps are within 1.5 % of the fastest batch seen (nothing else is using the memory system any more), at most
+    --settle-ms. Returns (steps run, milliseconds spent, whether it settled)."""
+    t0 = time.perf_counter()
+    steps, best, good = 0, None, 0
+    if args.ramp_ms <= 0:
+        return 0, 0.0, True
+    while True:
+        tb = time.perf_counter()
+        for _ in range(4):
+            step()
+        synchronize()
+        dt = time.perf_counter() - tb
+        steps += 4
+        spent = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+        good = good + 1 if dt <= best * 1.015 else 0
+        if spent >= args.ramp_ms and good >= 3:
+            return steps, spent, True
+        if spent >= max(args.settle_ms, args.ramp_ms):
+            return steps, spent, False
+
+
 def _hip_runtime_path():
     """The libamdhip64 the LIBRARY runs on (a process may map two: PyTorch bundles its own)."""
     try:
@@ -1175,6 +1202,8 @@ def run_native(args, result_fd) -> int:
         else:
             ex.fold_on_device(ctx)  # one rank: nothing to exchange, the rank-ordered fold of one record
 
+    fused_calls = {}
+
     def step(marks=None):
         k = counter[0] % len(exs)
         counter[0] += 1
@@ -1184,7 +1213,9 @@ def run_native(args, result_fd) -> int:
         if marks is not None:
             ctx.mark(marks)
         if fused:
-            ctx.sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))])
+            if id(ex) not in fused_calls:  # the argument table of a record set is built once
+                fused_calls[id(ex)] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))])
+            fused_calls[id(ex)]()
         else:
             ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
             if marks is not None:
@@ -1229,6 +1260,14 @@ def run_native(args, result_fd) -> int:
             exs = exs[:1]
             step()
             fence()
+    # Clocks: a GPU that was idle a moment ago needs ~0.1 s of work before its clocks are up (tools/probe_sustain.c: the first
+    # 20 ms of a process read at 4 TB/s, 7.2 from 0.1 s on). The process has only generated its columns so far; --ramp-ms of the
+    # step itself (default 200 ms, un-timed, before the W warm-up steps) put it where any host that has been running is.
+    # The same loop also waits out the kernel driver's background clear of VRAM that an EARLIER process released when it
+    # exited (35 GB/s, during which scans read 5 % slower: profiles/r04_read_rate_states_root_cause.txt — a torch-hosted
+    # process never saw it because importing torch takes longer than the clear): it goes on until three consecutive batches
+    # of 4 steps are within 1.5 % of the fastest batch so far, for at most --settle-ms.
+    ramp_steps, ramp_spent, settled = _settle(step, ctx.synchronize, args)
     for _ in range(args.warmup):
         step()
     fence()
@@ -1251,12 +1290,12 @@ def run_native(args, result_fd) -> int:
     ok = _check(total_rows, finals)
     if fused:
         ms = [ctx.mark_elapsed_ms(m, m + 2) for m in marked.values()]
-        kernels = {"sum_fused": {"avg_ms": sum(ms) / len(ms), "min_ms": min(ms), "timed_steps": len(ms)}}
+        kernels = {"sum_fused": {"avg_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms), "timed_steps": len(ms)}}
     else:
         ms_i = [ctx.mark_elapsed_ms(m, m + 1) for m in marked.values()]
         ms_f = [ctx.mark_elapsed_ms(m + 1, m + 2) for m in marked.values()]
-        kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i), "timed_steps": len(ms_i)},
-                   "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f), "timed_steps": len(ms_f)}}
+        kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i), "max_ms": max(ms_i), "timed_steps": len(ms_i)},
+                   "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f), "max_ms": max(ms_f), "timed_steps": len(ms_f)}}
     # per-rank scan time of a step (min / max over the ranks) and where the exchange's time goes (sampled every 4th exchange)
     scan_ms = sum(v["avg_ms"] for v in kernels.values())
     scans = gather_obj(scan_ms)
@@ -1283,6 +1322,7 @@ def run_native(args, result_fd) -> int:
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
                            {"rccl_ranks": stats["rccl_ranks"], "launch": "torch.distributed.run" if world > 1 else "single process",
                             "step": step_form, "host": "torch-free" if not distributed else "torch-free GPU path (gloo for rendezvous only)",
+                            "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                             "hip_runtime": _hip_runtime_path(),
                             "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                             "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans)})
@@ -1703,6 +1743,11 @@ def main() -> int:
                     help="the step's scans: separate = ma_i64_sum + ma_f64_sum_dd (two launches: per-type kernel figures; the "
                          "default at N = 1), fused = ONE ma_sum_fused launch over both columns (the default at N > 1, where a "
                          "launch's fixed cost is 2.4 % of a 137-us scan)")
+    ap.add_argument("--ramp-ms", type=float, default=200.0,
+                    help="un-timed milliseconds of the step in front of the warm-up steps, so that the GPU's clocks are up "
+                         "(0 = none)")
+    ap.add_argument("--settle-ms", type=float, default=3000.0,
+                    help="upper bound of the un-timed settle phase in front of the warm-up steps (see --ramp-ms)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",

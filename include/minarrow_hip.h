@@ -938,6 +938,11 @@ int32_t ma_group_peer_access(ma_group* group, int32_t from_member, int32_t to_me
  * one-GPU box exercise the refusals a multi-GPU node produces (a chunk resident on the wrong GPU, an owner without a
  * link to the destination). */
 ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable);
+/* TESTING ONLY. The next ma_group_exchange fails on `member` in front of its all-gather, as a lost device would make it: with
+ * per-member issue threads the other members have enqueued their collectives by then, so the group aborts every
+ * communicator (ncclCommAbort), marks itself broken — ma_group_exchange / ma_group_synchronize return MA_ERR_DEVICE from
+ * then on instead of blocking on a collective that cannot complete — and can only be destroyed. */
+ma_status ma_group_test_fail_next_exchange(ma_group* group, int32_t member);
 ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets);

@@ -62,6 +62,8 @@ struct ma_group {
     // overrides it so that the refusal paths can be exercised on a one-GPU box).
     std::vector<int> home;
     bool use_rccl = false;
+    bool broken = false;  // an exchange failed on some member after others had enqueued theirs: communicators aborted
+    int fail_member = -1; // ma_group_test_fail_next_exchange: that member's next exchange fails in front of its all-gather
     std::vector<ncclComm_t> comms;
     // RCCL: per member a device block of kColumns records (`local`), a device block of G x kColumns gathered records
     // and a pinned host block of kColumns x 4 finals the fold kernel writes. host: `local[i]` points into `host_records`.
@@ -412,6 +414,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
 }
 
 ma_status exchange_locked(ma_group* g) {
+    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "an earlier exchange of this group failed and its communicators were aborted: destroy the group");
     if (!g->use_rccl) return MA_OK;  // host exchange: the records are already in host memory once the streams drain
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
@@ -452,16 +455,21 @@ ma_status exchange_locked(ma_group* g) {
     };
     auto xstream = [g](size_t i) { return g->overlap ? g->side[i]->stream : g->ctxs[i]->stream; };
     ma_status st = MA_OK;
-    // One thread per device, each issuing its own rank's all-gather with no ncclGroup, is the form RCCL documents — but if one
-    // member fails before its call (hipSetDevice, the event record, the all-gather itself) the others have already enqueued
-    // theirs, those collectives never complete and the next synchronize blocks for good. That form has only ever run with ONE
-    // rank on hardware (the pool's boxes have one GPU), where it cannot happen; with more than one member the all-gathers go
-    // out from the calling thread inside ncclGroupStart / ncclGroupEnd, which enqueues nothing unless every call was accepted,
-    // and the members' threads then issue the folds.
-    if (g->threads && n == 1) {
+    // One thread per device, each issuing its own rank's all-gather with no ncclGroup: the form RCCL documents for one thread
+    // per device, and the only one that scales — an ncclAllGather costs the issuing thread ~230 us of host time
+    // (profiles/r04_share_1gpu.txt: host_issue_us_per_step 237 with the RCCL exchange against 7 with the host fold), so eight of
+    // them from ONE thread would make a 0.28-ms step host-bound at ~2 ms. The price: if one member fails before its call
+    // (hipSetDevice, the event record, the all-gather itself) the others have already enqueued theirs and those collectives
+    // can never complete. That case is handled below instead of avoided: every communicator is aborted (ncclCommAbort ends the
+    // kernels in flight) and the group is marked broken, so that the next synchronize returns an error instead of blocking.
+    if (g->threads) {
         st = run_on_members(g, [&](size_t i) -> ma_status {
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
             MA_TRY(before(i));
+            if ((int)i == g->fail_member) {
+                set_error("member %zu: injected failure in front of its all-gather (ma_group_test_fail_next_exchange)", i);
+                return MA_ERR_DEVICE;
+            }
             const int tk = i == 0 ? g->timer.begin(xstream(0)) : -1;
             MA_NCCL(api, AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i)));
             if (i == 0) g->timer.mark(tk, 1, xstream(0));
@@ -496,6 +504,20 @@ ma_status exchange_locked(ma_group* g) {
             return after(i);
         });
     }
+    const bool injected = g->fail_member >= 0;
+    g->fail_member = -1;
+    if (st != MA_OK && g->threads && (n > 1 || injected)) {
+        // some member's all-gather is on its stream without its peers': abort every communicator so that nothing waits for it
+        const std::string why = ma_last_error_string();
+        for (ncclComm_t& c : g->comms)
+            if (c && api->CommAbort) {
+                (void)api->CommAbort(c);
+                c = nullptr;
+            }
+        g->broken = true;
+        set_error("the group's exchange failed on a member and its communicators were aborted (the group must be destroyed): %s", why.c_str());
+        return st;
+    }
     MA_TRY(st);
     if (g->overlap) {
         g->set_used[set] = true;
@@ -506,6 +528,7 @@ ma_status exchange_locked(ma_group* g) {
 }
 
 ma_status synchronize_locked(ma_group* g) {
+    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "an earlier exchange of this group failed and its communicators were aborted: destroy the group");
     // every member is waited for even when one reports (a latched division by zero is cleared by its report)
     std::vector<ma_status> st(g->ctxs.size(), MA_OK);
     std::vector<std::string> msg(g->ctxs.size());
@@ -693,6 +716,14 @@ ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32
         const uint8_t can = peer_capable ? 1 : 0;
         group->peer[(size_t)member * G + j] = group->peer[j * G + (size_t)member] = can;
     }
+    return MA_OK;
+}
+
+ma_status ma_group_test_fail_next_exchange(ma_group* group, int32_t member) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
+    group->fail_member = member;
     return MA_OK;
 }
 

@@ -63,6 +63,7 @@ void load_rccl() {
     g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
     g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+    g_rccl.CommAbort = (decltype(g_rccl.CommAbort))sym("ncclCommAbort");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");

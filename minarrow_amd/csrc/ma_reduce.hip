@@ -163,8 +163,10 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         }
     }
 
-    // ---- ragged rows: the unaligned head and whatever follows the last full tile -----------------
-    if (blockIdx.x == gridDim.x - 1) {
+    // ---- ragged rows: the unaligned head and whatever follows the last full tile — on the first workgroup that has a
+    // tile less than the others (tiles are dealt round-robin, so the last full round ends at workgroup n_tiles mod grid - 1):
+    // its extra microsecond of row-at-a-time loads then overlaps the others' last tile instead of following it
+    if (blockIdx.x == (unsigned)(a.n_tiles % gridDim.x)) {
         const size_t tail_start = a.head + a.n_tiles * ((!MASKED && IL) ? (size_t)64 * R : TILE_ROWS);
         const size_t n_ragged = a.head + (a.n - tail_start);
         for (size_t i = tid; i < n_ragged; i += kBlock) {
@@ -255,11 +257,14 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     __syncthreads();
     if (!is_last) return;
 
-    // ---- the last workgroup folds every partial, in index order per thread, then across threads ----
+    // ---- the last workgroup's first wave folds every partial: in index order per lane (lane, lane + 64, ...), then across
+    // the lanes; lane 0 writes the results. One wave has all the parallelism 768 partials need (twelve loads per lane in
+    // flight at once), and nothing goes through LDS and two more barriers (round 4: -0.3 us on the launch's critical path).
+    if (wave != 0) return;
     Acc tot;
     tot.init();
     uint64_t tc = 0;
-    for (unsigned i = tid; i < gridDim.x; i += kBlock) {
+    for (unsigned i = lane; i < gridDim.x; i += 64) {
         const uint64_t* q = (const uint64_t*)&a.partials[i];
         Acc o;
         o.from_words(load_agent(q), load_agent(q + 1));
@@ -271,23 +276,9 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         tot.shfl_down_merge(off);
         tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
     }
-    __syncthreads();  // lds[] is reused
     if (lane == 0) {
-        tot.to_partial(lds[wave]);
-        lds[wave].cnt = tc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        Acc s;
-        s.from_words(lds[0].a, lds[0].b);
-        uint64_t c = lds[0].cnt;
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) {
-            Acc o;
-            o.from_words(lds[w].a, lds[w].b);
-            s.merge(o);
-            c += lds[w].cnt;
-        }
+        Acc s = tot;
+        uint64_t c = tc;
         double as_double;
         if constexpr (std::is_same<Acc, DDAcc>::value) {
             DDAcc& d = reinterpret_cast<DDAcc&>(s);

@@ -41,6 +41,7 @@ struct FusedCol {
 struct FusedArgs {
     FusedCol col[kFusedMax];
     int n_cols;
+    size_t total_tiles;     // all columns' full tiles
     Partial* partials;      // column c's partial of workgroup b at [c * gridDim.x + b]
     unsigned int* ticket;
     uint64_t* done_word;    // pinned word stamped after the results (synchronous call that polls), or nullptr
@@ -150,23 +151,32 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
                 }
             }
         }
-        // ragged rows of this column (the unaligned head, whatever follows the last full tile): the last workgroup's job
-        if (b == G - 1) {
-            const size_t tail_start = col.head + col.n_tiles * TILE_ROWS;
-            const size_t n_ragged = col.head + (col.n - tail_start);
-            for (size_t i = tid; i < n_ragged; i += kBlock) {
-                const size_t row = i < col.head ? i : tail_start + (i - col.head);
-                uint64_t x = as_global(data)[row];
-                unsigned valid = 1;
-                if (ANY_MASKED && masked) {
-                    valid = row_bit(col.words, col.bit_off + row);
-                    cnt[c] += valid;
-                }
-                if (is_float) acc[c][0].add_f64(valid ? __longlong_as_double((long long)x) : 0.0);
-                else acc[c][0].add_int(valid ? x : 0);
-            }
-        }
         if (!masked && b == 0 && tid == 0) cnt[c] = col.n;  // dense: every row is valid; credited once
+    }
+    // Ragged rows (a column's unaligned head, whatever follows its last full tile), behind ALL columns' tiles so that no
+    // workgroup stops between two columns for them, and on workgroups that have a tile less than the others: the concatenated
+    // tile space ends at workgroup total_tiles mod G - 1, column c's ragged rows go to workgroup (total_tiles + c) mod G.
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        if (c >= a.n_cols) continue;
+        const FusedCol& col = a.col[c];
+        if (b != (unsigned)((a.total_tiles + (size_t)c) % G)) continue;
+        const bool is_float = col.is_float != 0;
+        const bool masked = ANY_MASKED && col.words != nullptr;
+        const uint64_t* __restrict__ data = (const uint64_t*)col.data;
+        const size_t tail_start = col.head + col.n_tiles * TILE_ROWS;
+        const size_t n_ragged = col.head + (col.n - tail_start);
+        for (size_t i = tid; i < n_ragged; i += kBlock) {
+            const size_t row = i < col.head ? i : tail_start + (i - col.head);
+            uint64_t x = as_global(data)[row];
+            unsigned valid = 1;
+            if (ANY_MASKED && masked) {
+                valid = row_bit(col.words, col.bit_off + row);
+                cnt[c] += valid;
+            }
+            if (is_float) acc[c][0].add_f64(valid ? __longlong_as_double((long long)x) : 0.0);
+            else acc[c][0].add_int(valid ? x : 0);
+        }
     }
 
     // ---- workgroup reduce, all columns ------------------------------------------------------------------------------
@@ -231,16 +241,17 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
     __syncthreads();
     if (!is_last) return;
 
-    // ---- the last workgroup folds every column's partials: in index order per thread, then across threads ------------
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kFusedMax; ++c) {
-        if (c >= a.n_cols) continue;
+    // ---- the last workgroup folds the partials: WAVE w takes column w — its lanes load the column's partials in index
+    // order (lane, lane + 64, ...), merge across lanes, lane 0 writes the column's outputs — so the columns fold side by
+    // side and nothing goes through LDS again.
+    static_assert(kFusedMax <= kWaves, "one wave per column in the final fold");
+    if ((int)wave < a.n_cols) {
+        const int c = (int)wave;
         const bool is_float = a.col[c].is_float != 0;
         Acc2 tot;
         tot.init();
         uint64_t tc = 0;
-        for (unsigned i = tid; i < G; i += kBlock) {
+        for (unsigned i = lane; i < G; i += 64) {
             const uint64_t* q = (const uint64_t*)&a.partials[(size_t)c * G + i];
             Acc2 o;
             o.a = load_agent(q);
@@ -254,42 +265,23 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
             tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
         }
         if (lane == 0) {
-            lds[c][wave].a = tot.a;
-            lds[c][wave].b = tot.b;
-            lds[c][wave].cnt = tc;
+            uint64_t* out = a.col[c].out;
+            if (is_float) {
+                DDAcc d;
+                d.from_words(tot.a, tot.b);
+                d.normalise();
+                out[0] = (uint64_t)__double_as_longlong(d.hi);
+                out[1] = (uint64_t)__double_as_longlong(d.lo);
+                out[2] = tc;
+            } else {
+                out[0] = tot.a;
+                out[1] = tc;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have left this wave before the barrier below
         }
     }
     __syncthreads();
     if (tid == 0) {
-#pragma unroll
-        for (int c = 0; c < kFusedMax; ++c) {
-            if (c >= a.n_cols) continue;
-            const bool is_float = a.col[c].is_float != 0;
-            Acc2 s;
-            s.a = lds[c][0].a;
-            s.b = lds[c][0].b;
-            uint64_t n = lds[c][0].cnt;
-#pragma unroll
-            for (int w = 1; w < kWaves; ++w) {
-                Acc2 o;
-                o.a = lds[c][w].a;
-                o.b = lds[c][w].b;
-                s.merge(o, is_float);
-                n += lds[c][w].cnt;
-            }
-            uint64_t* out = a.col[c].out;
-            if (is_float) {
-                DDAcc d;
-                d.from_words(s.a, s.b);
-                d.normalise();
-                out[0] = (uint64_t)__double_as_longlong(d.hi);
-                out[1] = (uint64_t)__double_as_longlong(d.lo);
-                out[2] = n;
-            } else {
-                out[0] = s.a;
-                out[1] = n;
-            }
-        }
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
         if (a.done_word) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -360,6 +352,7 @@ extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_col
         col.tile0 = total_tiles;
         total_tiles += col.n_tiles;
     }
+    a.total_tiles = total_tiles;
     int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (any_masked ? 2 : 1);
     if (!any_masked && ctx->blocks_per_cu <= 0 && total_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
     int grid = grid_for(ctx, total_tiles, bpc);

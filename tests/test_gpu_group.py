@@ -613,3 +613,33 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
         with pytest.raises(ffi.MinarrowHipError) as e:
             g.enqueue_sum_table([("l", 1, di, lens), ("L", 1, di, lens)])
         assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
+
+
+def test_group_exchange_failure_on_a_member_aborts_instead_of_hanging():
+    """Per-member issue threads enqueue their own rank's all-gather; should one member fail in front of its call, the
+    others' collectives could never complete. The group then aborts its communicators and reports MA_ERR_DEVICE from
+    exchange and synchronize (no hang); only destroying it remains."""
+    from minarrow_amd.host import Group
+
+    with Group([0], exchange="rccl") as g:
+        if g.exchange_kind != "rccl":
+            pytest.skip("RCCL is not available on this box")
+        c = g.member_ctx(0)
+        n = 1 << 20
+        col = c.alloc(n * 8)
+        c.synth_iota("i64", col, n, 0)
+        g.enqueue_sum("i64", 0, [col], [n])
+        g.exchange()
+        g.synchronize()
+        assert g.result(0)[:2] == (n * (n - 1) // 2, n)
+        ffi.check(g.lib.ma_group_test_fail_next_exchange(g.handle, 0))
+        g.enqueue_sum("i64", 0, [col], [n])
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.exchange()
+        assert e.value.status == ffi.MA_ERR_DEVICE and "aborted" in str(e.value)
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.synchronize()
+        assert e.value.status == ffi.MA_ERR_DEVICE
+        with pytest.raises(ffi.MinarrowHipError):
+            g.exchange()
+        c.synchronize()  # the member's own stream is intact
