@@ -6,7 +6,7 @@ lib:
 oracle:
 	$(MAKE) -C oracle
 cpp: lib
-	$(MAKE) -C minarrow_amd/cpp
+	$(MAKE) -C tests/cpp
 bindings: 
 	python3 tools/gen_rust_ffi.py
 test-cpu: all
@@ -17,6 +17,6 @@ bench: all
 	python3 bench.py
 clean:
 	$(MAKE) -C minarrow_amd/csrc clean
-	$(MAKE) -C minarrow_amd/cpp clean
+	$(MAKE) -C tests/cpp clean
 	rm -rf oracle/_build oracle/_ref build
 .PHONY: all lib oracle cpp bindings test-cpu test-gpu bench clean

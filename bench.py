@@ -1043,10 +1043,12 @@ def ranks_other_configs(env, col_i, col_f, rows: int, reps: int):
     return res
 
 
-def _settle(step, synchronize, args):
+def _settle(step, synchronize, args, agree=None):
     """Un-timed steps in front of the warm-up: at least --ramp-ms of them (clocks), then on until three consecutive batches of
     4 steps are within 1.5 % of the fastest batch seen (nothing else is using the memory system any more), at most
-    --settle-ms. Returns (steps run, milliseconds spent, whether it settled)."""
+    --settle-ms. With several ranks every rank must run the SAME number of steps (each step ends in a collective): `agree`
+    turns this rank's "go on" into the ranks' common decision (any rank that wants to go on keeps all going).
+    Returns (steps run, milliseconds spent, whether it settled)."""
     t0 = time.perf_counter()
     steps, best, good = 0, None, 0
     if args.ramp_ms <= 0:
@@ -1061,10 +1063,13 @@ def _settle(step, synchronize, args):
         spent = (time.perf_counter() - t0) * 1e3
         best = dt if best is None else min(best, dt)
         good = good + 1 if dt <= best * 1.015 else 0
-        if spent >= args.ramp_ms and good >= 3:
-            return steps, spent, True
-        if spent >= max(args.settle_ms, args.ramp_ms):
-            return steps, spent, False
+        settled = spent >= args.ramp_ms and good >= 3
+        out_of_time = spent >= max(args.settle_ms, args.ramp_ms)
+        go_on = not (settled or out_of_time)
+        if agree is not None:
+            go_on = agree(go_on)
+        if not go_on:
+            return steps, spent, settled
 
 
 def _hip_runtime_path():
@@ -1267,7 +1272,17 @@ def run_native(args, result_fd) -> int:
     # exited (35 GB/s, during which scans read 5 % slower: profiles/r04_read_rate_states_root_cause.txt — a torch-hosted
     # process never saw it because importing torch takes longer than the clear): it goes on until three consecutive batches
     # of 4 steps are within 1.5 % of the fastest batch so far, for at most --settle-ms.
-    ramp_steps, ramp_spent, settled = _settle(step, ctx.synchronize, args)
+    def agree(go_on):  # any rank that wants another batch keeps every rank going (gloo, CPU side)
+        t = torch.tensor([1 if go_on else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
+    def drain():
+        ctx.synchronize()
+        if comm is not None:
+            comm.synchronize()
+
+    ramp_steps, ramp_spent, settled = _settle(step, drain, args, agree if dist is not None else None)
     for _ in range(args.warmup):
         step()
     fence()
@@ -1727,7 +1742,7 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
-    ap.add_argument("--headline-seconds", type=float, default=300.0,
+    ap.add_argument("--headline-seconds", type=float, default=120.0,
                     help="N > 1: give up (exit code 3, reason on stderr) when set-up + warm-up + timed steps take longer")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="run each step's scalar exchange on a side stream, overlapped with the next "

@@ -890,7 +890,9 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  *                            streams go straight on with the next step's scans into a SECOND record set (two steps in
  *                            flight; a set is re-filled only behind its last exchange). For back-to-back steps whose scans
  *                            are short against the exchange — a 10^9-row column over 8 GPUs: 0.14 ms per scan. ma_group_result
- *                            reads the set of the most recent exchange. (The multi-process twin: ma_comm_sum_exchange_overlapped.)
+ *                            reads the set of the most recent exchange: a record slot read after an exchange must have been
+ *                            enqueued in THAT step (MA_ERR_INVALID_ARGUMENT otherwise — it would come back from the other
+ *                            set, two steps old). (The multi-process twin: ma_comm_sum_exchange_overlapped.)
  *   MA_GROUP_EXCHANGE_FALLBACK_HOST  with MA_GROUP_EXCHANGE_RCCL: use the host fold when RCCL cannot be initialised
  *                            (library missing, members sharing a device); ma_group_exchange_note() then says why.
  * ma_group_create() = ma_group_create_ex() with flags 0, or RCCL|FALLBACK_HOST when the environment variable

@@ -527,7 +527,10 @@ static ma_status concat_column_by_chunks(ma_ctx* ctx, CallScope& scope, size_t e
     std::vector<MaskDesc> mdesc;
     if (has_join) mdesc.resize(n_chunks);
     DeviceRange data_role, mask_role;
-    const size_t kFirst = 4096, kMax = 32768;
+    // segments are whole multiples of the grid (workgroups deal chunks round-robin: 4096 chunks over 1536 workgroups left a
+    // third of them a chunk short for a third of the segment)
+    const size_t per_round = (size_t)grid_for(ctx, (size_t)1 << 30, 6);
+    const size_t kFirst = 4 * per_round, kMax = 21 * per_round;
     size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
     while (c0 < n_chunks) {
         const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
@@ -566,8 +569,8 @@ static ma_status concat_column_by_chunks(ma_ctx* ctx, CallScope& scope, size_t e
             row += chunk_lens[i];
         }
         const void* tab = nullptr;
-        int slot = -1;
-        MA_TRY(table_commit_mapped(ctx, cd, &tab, &slot));
+        TableSlotGuard guard(ctx);  // the slot is released (an event behind the launch) on every way out of this iteration
+        MA_TRY(table_commit_mapped(ctx, cd, &tab, &guard.slot));
         const int n = (int)(c1 - c0);
         const int grid = grid_for(ctx, (size_t)n, 6);
         const ConcatChunk* tcd = (const ConcatChunk*)tab;
@@ -590,9 +593,8 @@ else                                                                            
         }
 #undef MA_CONCAT_CHUNKS
         MA_HIP(hipGetLastError());
-        MA_TRY(table_release(ctx, slot));
         c0 = c1;
-        if (seg < kMax) seg *= 2;
+        if (seg < kMax) seg = seg * 2 < kMax ? seg * 2 : kMax;
     }
     if (has_join) {  // the join pass walks the list either side of a chunk: one compact table, uploaded
         void* dm = nullptr;

@@ -437,18 +437,46 @@ ma_status ctx_scratch(ma_ctx* ctx, size_t bytes, void** out) {
 ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host) {
     *out_host = nullptr;
     if (bytes == 0) return MA_OK;
-    const int k = ctx->table_next;
-    if (!ctx->table_ev[k]) MA_HIP(hipEventCreateWithFlags(&ctx->table_ev[k], hipEventDisableTiming));
-    if (ctx->table_busy[k]) {
-        MA_HIP(hipEventSynchronize(ctx->table_ev[k]));
-        ctx->table_busy[k] = false;
+    // Which slot: the first one (from the rotation point) whose last user has finished AND that is large enough; else any
+    // finished one (never-used slots first: they cost one allocation, an outgrown one costs a replacement); only when all 16
+    // are still being read does the host wait. A host whose GPU keeps up therefore cycles through two or three slots and
+    // the others are never allocated.
+    int pick = -1, spare = -1;
+    for (int i = 0; i < ma_ctx::kTableSlots && pick < 0; ++i) {
+        const int k = (ctx->table_next + i) % ma_ctx::kTableSlots;
+        if (ctx->table_busy[k]) {
+            const hipError_t q = hipEventQuery(ctx->table_ev[k]);
+            if (q == hipSuccess) {
+                ctx->table_busy[k] = false;
+            } else {
+                (void)hipGetLastError();
+                continue;
+            }
+        }
+        if (ctx->table_stage_bytes[k] >= bytes) pick = k;
+        else if (spare < 0 || (ctx->table_stage[spare] != nullptr && ctx->table_stage[k] == nullptr)) spare = k;
     }
+    if (pick < 0) pick = spare;
+    if (pick < 0) {
+        pick = ctx->table_next;
+        MA_HIP(hipEventSynchronize(ctx->table_ev[pick]));
+        ctx->table_busy[pick] = false;
+    }
+    const int k = pick;
+    ctx->table_cur = k;
+    if (!ctx->table_ev[k]) MA_HIP(hipEventCreateWithFlags(&ctx->table_ev[k], hipEventDisableTiming));
     if (bytes > ctx->table_stage_bytes[k]) {
-        if (ctx->table_stage[k]) MA_HIP(hipHostFree(ctx->table_stage[k]));
+        // A slot that is too small is replaced, not freed: hipHostFree drains the whole device, and a context that streams
+        // chunk lists of mixed sizes through its slots would pay that in the middle of its pipeline (the old buffers go when
+        // the context does). New slots are sized for the largest table the context has seen so far.
+        if (ctx->table_stage[k]) ctx->table_garbage.push_back(ctx->table_stage[k]);
         ctx->table_stage[k] = nullptr;
         ctx->table_stage_bytes[k] = 0;
-        const size_t want = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
-        MA_HIP(hipHostMalloc(&ctx->table_stage[k], want, hipHostMallocPortable));
+        if (bytes > ctx->table_high_water) ctx->table_high_water = bytes;
+        const size_t base = ctx->table_high_water;
+        const size_t want = (base + base / 2 + 4095) & ~(size_t)4095;
+        // Mapped: kernels read some tables in place (table_commit_mapped) — asked for, not left to the runtime's implicit mapping
+        MA_HIP(hipHostMalloc(&ctx->table_stage[k], want, hipHostMallocPortable | hipHostMallocMapped));
         ctx->table_stage_bytes[k] = want;
     }
     *out_host = ctx->table_stage[k];
@@ -457,9 +485,10 @@ ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host) {
 
 ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_dst) {
     if (bytes == 0) return MA_OK;
-    const int k = ctx->table_next;
-    MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit without table_begin");
-    ctx->table_next = (ctx->table_next + 1) % ma_ctx::kTableSlots;
+    const int k = ctx->table_cur;
+    MA_REQUIRE(k >= 0 && host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit without table_begin");
+    ctx->table_next = (k + 1) % ma_ctx::kTableSlots;
+    ctx->table_cur = -1;
     MA_HIP(hipMemcpyAsync(dev_dst, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     MA_HIP(hipEventRecord(ctx->table_ev[k], ctx->stream));
     ctx->table_busy[k] = true;
@@ -467,11 +496,13 @@ ma_status table_commit(ma_ctx* ctx, const void* host, size_t bytes, void* dev_ds
 }
 
 ma_status table_commit_mapped(ma_ctx* ctx, const void* host, const void** out_dev_alias, int* out_slot) {
-    const int k = ctx->table_next;
-    MA_REQUIRE(host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit_mapped without table_begin");
+    const int k = ctx->table_cur;
+    MA_REQUIRE(k >= 0 && host == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "table_commit_mapped without table_begin");
     void* alias = nullptr;
     MA_HIP(hipHostGetDevicePointer(&alias, ctx->table_stage[k], 0));
-    ctx->table_next = (ctx->table_next + 1) % ma_ctx::kTableSlots;
+    ctx->table_next = (k + 1) % ma_ctx::kTableSlots;
+    ctx->table_cur = -1;
+    ctx->table_busy[k] = true;  // until table_release records the event: never handed out in between
     *out_dev_alias = alias;
     *out_slot = k;
     return MA_OK;
@@ -885,6 +916,8 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (void* g : ctx->table_garbage) (void)hipHostFree(g);
+    ctx->table_garbage.clear();
     for (int k = 0; k < ma_ctx::kTableSlots; ++k) {
         if (ctx->table_stage[k]) (void)hipHostFree(ctx->table_stage[k]);
         if (ctx->table_ev[k]) (void)hipEventDestroy(ctx->table_ev[k]);

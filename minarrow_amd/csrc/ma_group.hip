@@ -77,6 +77,10 @@ struct ma_group {
     std::vector<ma_ctx*> side;
     std::vector<hipEvent_t> ev_ready[2], ev_done[2];
     bool set_used[2] = {false, false};
+    // Which record slots were filled into each set since its last exchange (overlap only): ma_group_result reads the set of
+    // the LAST exchange, and a column that was not enqueued in that step would come back from the other set — the value of
+    // two steps ago, or zeros — so it is refused instead.
+    uint32_t enq_mask[2] = {0, 0}, exchanged_mask[2] = {0, 0};
     uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
     uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
     // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
@@ -406,6 +410,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
         MA_TRY(require_resident(g, lookup, i, chunk_data[i], "data", i));
         if (chunk_masks) MA_TRY(require_resident(g, lookup, i, chunk_masks[i], "validity bitmap", i));
     }
+    g->enq_mask[g->overlap ? g->cur : 0] |= 1u << column;
     // enqueue only (the members are in async mode): all devices run concurrently
     return run_on_members(g, [&](size_t i) {
         uint64_t* set = (g->overlap && g->cur == 1) ? g->local1[i] : g->local[i];
@@ -523,6 +528,9 @@ ma_status exchange_locked(ma_group* g) {
         g->set_used[set] = true;
         g->last = set;
         g->cur = set ^ 1;
+        g->exchanged_mask[set] = g->enq_mask[set];
+        g->enq_mask[set] = 0;
+        g->enq_mask[set ^ 1] = 0;  // the set about to be filled starts empty
     }
     return MA_OK;
 }
@@ -770,6 +778,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
                        "columns %d and %d would write the same slots of record %d", j, k, columns[k]);
     }
     std::lock_guard<std::recursive_mutex> lock(group->mu);
+    for (int32_t k = 0; k < n_cols; ++k) group->enq_mask[group->overlap ? group->cur : 0] |= 1u << columns[k];
     DeviceLookup lookup;
     for (int32_t k = 0; k < n_cols; ++k)
         for (size_t i = 0; i < group->ctxs.size(); ++i) {
@@ -818,6 +827,7 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
         MA_TRY(require_resident(group, lookup, i % G, chunk_data[i], "data", i));
         if (chunk_masks) MA_TRY(require_resident(group, lookup, i % G, chunk_masks[i], "validity bitmap", i));
     }
+    group->enq_mask[group->overlap ? group->cur : 0] |= 1u << column;
     return run_on_members(group, [&](size_t m) -> ma_status {
         std::vector<const void*> d;
         std::vector<size_t> n, o;
@@ -1088,6 +1098,11 @@ ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
     std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(!(group->overlap && group->use_rccl) || !group->set_used[group->last] ||
+                   (group->exchanged_mask[group->last] >> column) & 1u,
+               MA_ERR_INVALID_ARGUMENT,
+               "column %d was not enqueued in the step of the last exchange: with overlapped exchanges the group alternates "
+               "between two record sets, and a column read after an exchange must have been enqueued in that step", column);
     const uint64_t* f = finals_of(group, (size_t)member, column);
     if (out_int_sum) *out_int_sum = (int64_t)f[0];
     if (out_int_count) *out_int_count = f[1];

@@ -762,10 +762,10 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     const ColDesc* d = nullptr;
     const ShortCol* sd = nullptr;
     ShortCol* pieces = expand ? (ShortCol*)((char*)scratch + col_bytes) : nullptr;
-    int slot = -1;
+    TableSlotGuard guard(ctx);  // a mapped table's slot is released behind the launches on every way out
     if (all_short) {
         const void* alias = nullptr;
-        MA_TRY(table_commit_mapped(ctx, sdesc, &alias, &slot));
+        MA_TRY(table_commit_mapped(ctx, sdesc, &alias, &guard.slot));
         sd = (const ShortCol*)alias;
     } else {
         MA_TRY(table_commit(ctx, desc, sizeof(ColDesc) * n_cols, scratch));
@@ -786,7 +786,6 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
         default: launch_columns<double>(ctx, d, sd, n_cols, n_segs, partials, true, (double*)of, (uint64_t*)oi, (uint64_t*)oc, total, partials2, (double*)olo, pieces, any_masked); break;
     }
     MA_HIP(hipGetLastError());
-    if (slot >= 0) MA_TRY(table_release(ctx, slot));
     return end_call(ctx, scope);
 }
 

@@ -51,6 +51,7 @@ struct OpStream {
     SideTile lt, rt;
     size_t tile_rows = 0;
     std::vector<size_t> tile_lens;    // rows of each gathered batch pair
+    std::vector<std::vector<char>> tile_validity;  // per gathered pair and column: did either side carry validity?
     std::vector<ArrowArray> held_l, held_r;  // the gathered input batches, kept until their tile has been computed
     std::deque<ArrowArray> ready;     // result batches not yet handed out
     bool inputs_done = false;
@@ -69,17 +70,25 @@ void drop_tile_ref(TileResult* tr) {
         delete tr;
     }
 }
+// What a slice child owns: a reference on the tile's result and ITS OWN buffers array — the Arrow C Data Interface lets a
+// consumer move a child out of its parent and release the parent first, so nothing a child points to may live in the parent.
+struct SliceChild {
+    TileResult* tr = nullptr;
+    const void* buffers[2] = {nullptr, nullptr};
+};
 struct SliceHolder {
     TileResult* tr = nullptr;
     std::vector<ArrowArray> kids;
     std::vector<ArrowArray*> kid_ptrs;
-    std::vector<const void*> kid_buffers;  // two per child
     const void* struct_buffers[1] = {nullptr};
 };
 void release_slice_child(ArrowArray* a) {
     if (!a || !a->release) return;
-    drop_tile_ref((TileResult*)a->private_data);
+    SliceChild* sc = (SliceChild*)a->private_data;
+    TileResult* tr = sc->tr;
+    delete sc;
     a->release = nullptr;
+    drop_tile_ref(tr);
 }
 void release_slice(ArrowArray* a) {
     if (!a || !a->release) return;
@@ -91,26 +100,36 @@ void release_slice(ArrowArray* a) {
     drop_tile_ref(tr);
 }
 // Rows [row0, row0 + n) of the tile result as an owned struct array (children share the tile's buffers through `offset`).
-bool make_slice(TileResult* tr, size_t row0, size_t n, ArrowArray* out) {
+// had_validity[c]: whether either input column of THIS batch pair carried validity — when neither did the slice's child has
+// no validity buffer and null_count 0, exactly what the batch-by-batch form (and the reference's mask union,
+// src/kernels/broadcast/super_array.rs:224) gives, even though another batch of the same tile made the tile's column nullable.
+bool make_slice(TileResult* tr, size_t row0, size_t n, const std::vector<char>& had_validity, ArrowArray* out) {
     SliceHolder* h = new (std::nothrow) SliceHolder();
     if (!h) return false;
     const size_t nc = (size_t)tr->whole.n_children;
     h->tr = tr;
     h->kids.resize(nc);
     h->kid_ptrs.resize(nc);
-    h->kid_buffers.resize(2 * nc);
     for (size_t c = 0; c < nc; ++c) {
         const ArrowArray* w = tr->whole.children[c];
         ArrowArray& k = h->kids[c];
         memset(&k, 0, sizeof(k));
-        h->kid_buffers[2 * c] = w->buffers[0];
-        h->kid_buffers[2 * c + 1] = w->buffers[1];
+        SliceChild* sc = new (std::nothrow) SliceChild();
+        if (!sc) {
+            for (size_t j = 0; j < c; ++j) release_slice_child(&h->kids[j]);
+            delete h;
+            return false;
+        }
+        sc->tr = tr;
+        const bool nullable = w->buffers[0] != nullptr && (c >= had_validity.size() || had_validity[c]);
+        sc->buffers[0] = nullable ? w->buffers[0] : nullptr;
+        sc->buffers[1] = w->buffers[1];
         k.length = (int64_t)n;
-        k.null_count = w->buffers[0] ? -1 : 0;
+        k.null_count = nullable ? -1 : 0;
         k.offset = w->offset + (int64_t)row0;
         k.n_buffers = 2;
-        k.buffers = &h->kid_buffers[2 * c];
-        k.private_data = tr;
+        k.buffers = sc->buffers;
+        k.private_data = sc;
         k.release = release_slice_child;
         tr->refs.fetch_add(1, std::memory_order_relaxed);
         h->kid_ptrs[c] = &k;
@@ -310,6 +329,7 @@ void gather_pair(OpStream* o, ArrowArray* l, ArrowArray* r) {
     const size_t n = (size_t)l->length, at = o->tile_rows;
     const ArrowArray* sides[2] = {l, r};
     SideTile* tiles[2] = {&o->lt, &o->rt};
+    std::vector<char> had(o->lt.values.size(), 0);
     for (int sd = 0; sd < 2; ++sd) {
         const ArrowArray* b = sides[sd];
         SideTile* t = tiles[sd];
@@ -318,6 +338,7 @@ void gather_pair(OpStream* o, ArrowArray* l, ArrowArray* r) {
             const size_t off = (size_t)k->offset + (size_t)b->offset;  // a struct's offset shifts every child
             if (n) memcpy(t->values[c] + at * t->elem[c], (const char*)k->buffers[1] + off * t->elem[c], n * t->elem[c]);
             const uint8_t* validity = k->null_count == 0 ? nullptr : (const uint8_t*)k->buffers[0];
+            if (validity) had[c] = 1;
             if (validity && !t->masked[c]) {  // the column's first batch with nulls in this tile: the rows so far are valid
                 memset(t->bits[c], 0, (kGatherRows / 64 + 2) * 8);
                 append_bits(t->bits[c], 0, nullptr, 0, 0, at);
@@ -329,6 +350,7 @@ void gather_pair(OpStream* o, ArrowArray* l, ArrowArray* r) {
     o->held_l.push_back(*l);
     o->held_r.push_back(*r);
     o->tile_lens.push_back(n);
+    o->tile_validity.push_back(std::move(had));
     o->tile_rows += n;
 }
 
@@ -378,7 +400,7 @@ void process_tile(OpStream* o) {
         size_t row0 = 0;
         std::vector<ArrowArray> outs(nb);
         for (size_t k = 0; k < nb && sliced; ++k) {
-            sliced = make_slice(tr, row0, o->tile_lens[k], &outs[k]);
+            sliced = make_slice(tr, row0, o->tile_lens[k], o->tile_validity[k], &outs[k]);
             row0 += o->tile_lens[k];
             if (!sliced)
                 for (size_t j = 0; j < k; ++j) outs[j].release(&outs[j]);
@@ -417,6 +439,7 @@ void process_tile(OpStream* o) {
     o->held_l.clear();
     o->held_r.clear();
     o->tile_lens.clear();
+    o->tile_validity.clear();
     o->tile_rows = 0;
     std::fill(o->lt.masked.begin(), o->lt.masked.end(), 0);
     std::fill(o->rt.masked.begin(), o->rt.masked.end(), 0);

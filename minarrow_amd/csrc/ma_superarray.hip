@@ -501,12 +501,12 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
         // The table is read where it was built (pinned host memory: one wave-uniform 32-byte read per chunk, issued a chunk
         // ahead of its use) unless variant bit 512 asks for the device copy.
         const void* tab = nullptr;
-        int slot = -1;
+        TableSlotGuard guard(ctx);  // releases the mapped slot behind the launch on every way out
         if (ctx->variant & 512) {
             MA_TRY(table_commit(ctx, host, bytes, dev_tab));
             tab = dev_tab;
         } else {
-            MA_TRY(table_commit_mapped(ctx, host, &tab, &slot));
+            MA_TRY(table_commit_mapped(ctx, host, &tab, &guard.slot));
         }
         const ChunkPair* dcd = (const ChunkPair*)tab;
         const ChunkMaskDesc* dmd = any_mask ? (const ChunkMaskDesc*)((const char*)tab + off_md) : nullptr;
@@ -527,7 +527,6 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
             hipLaunchKernelGGL((chunk_binary_kernel<T, U, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, dcd, dmd, (int)n, op,
                                ctx->dev_flags, smode, sbits);
         MA_HIP(hipGetLastError());
-        if (slot >= 0) MA_TRY(table_release(ctx, slot));
         return MA_OK;
     }
     MA_TRY(table_commit(ctx, host, bytes, dev_tab));
@@ -578,12 +577,13 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     // while the host describes segment k + 1 (8 ns per chunk on the host against 17 ns of kernel per 8192-row i32 pair:
     // after the first, small segment the host stays ahead). variant bit 1024: one segment whatever the length (A/B).
     constexpr size_t kPerChunk = sizeof(ChunkPair) + sizeof(ChunkMaskDesc) + 16;
-    const size_t kFirst = 4096, kMax = 32768;
+    const size_t per_round = (size_t)grid_for(ctx, (size_t)1 << 30, 6);  // segments are whole rounds of the chunk kernel's grid
+    const size_t kFirst = 4 * per_round, kMax = 21 * per_round;
     const bool segmented = n_chunks > 2 * kFirst && !(ctx->variant & 1024);
     char* dev_tab = nullptr;
     size_t n_segments = 1;
     if (segmented)
-        for (size_t c = 0, sz = kFirst; c + sz < n_chunks; c += sz, sz = sz < kMax ? sz * 2 : sz) ++n_segments;
+        for (size_t c = 0, sz = kFirst; c + sz < n_chunks; c += sz, sz = sz * 2 < kMax ? sz * 2 : kMax) ++n_segments;
     MA_TRY(ctx_scratch(ctx, kPerChunk * n_chunks + 256 * n_segments, (void**)&dev_tab));
     size_t c0 = 0, seg = segmented ? kFirst : n_chunks, dev_off = 0;
     while (c0 < n_chunks) {
@@ -592,7 +592,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
                                       out_data, out_masks, out_has_mask, any_mask, by_chunk, dev_tab + dev_off, smode, sbits)));
         dev_off += (kPerChunk * (c1 - c0) + 255) & ~(size_t)255;
         c0 = c1;
-        if (seg < kMax) seg *= 2;
+        if (seg < kMax) seg = seg * 2 < kMax ? seg * 2 : kMax;
     }
     return finish_batched(ctx, scope, std::is_integral<T>::value &&
                                           (op == MA_OP_DIVIDE || op == MA_OP_REMAINDER || op == MA_OP_FLOORDIV));

@@ -154,3 +154,51 @@ def test_gathered_batches_keep_error_positions(ctx):
     with pytest.raises(Exception) as e:
         reader.read_next_batch()
     assert "SuperTable chunk count mismatch: 5 vs 4" in str(e.value)
+
+
+def test_gathered_slices_own_their_buffers_and_carry_validity_only_where_a_side_had_it(ctx):
+    """Two properties of the slices a gathered tile is handed out as, checked on the raw C structs:
+    (1) a batch pair neither side of which had validity comes back WITHOUT a validity buffer (null_count 0) even when a
+        later pair of the same tile made the tile's column nullable — what the batch-by-batch form and the reference's mask
+        union (src/kernels/broadcast/super_array.rs:224) give;
+    (2) a child moved out of its parent stays valid after the parent is released (Arrow C Data Interface: moving children):
+        its `buffers` array is its own."""
+    from minarrow_amd.arrow_c import ArrowArray
+
+    n = 1000
+    dense = lambda v: pa.RecordBatch.from_pydict({"v": pa.array(np.arange(n, dtype=np.int64) + v)})  # noqa: E731
+    nulls = pa.RecordBatch.from_pydict({"v": pa.array(np.arange(n, dtype=np.int64), mask=np.arange(n) % 5 == 0)})
+    L, R = [dense(1), nulls, dense(7)], [dense(10), dense(20), dense(30)]
+    lhs = pa.RecordBatchReader.from_batches(L[0].schema, L)
+    rhs = pa.RecordBatchReader.from_batches(R[0].schema, R)
+    out = ArrowArrayStream()
+    l, r = ExportedStream(lhs), ExportedStream(rhs)
+    ctx.apply_arrow_stream_export(0, l.ptr, r.ptr, C.addressof(out))
+    get_next = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)(out.get_next)
+    release = C.CFUNCTYPE(None, C.c_void_p)
+    got = []
+    for k in range(3):
+        a = ArrowArray()
+        assert get_next(C.addressof(out), C.addressof(a)) == 0 and a.release and a.length == n and a.n_children == 1
+        got.append(a)
+    kids = [g.children[0].contents for g in got]
+    assert not kids[0].buffers[0] and kids[0].null_count == 0   # no side had validity: no bitmap, although the tile has one
+    assert kids[1].buffers[0] and kids[1].null_count == -1      # the pair with nulls carries the tile's bitmap
+    assert not kids[2].buffers[0] and kids[2].null_count == 0
+    # move batch 1's child out, release the parent, and only then read through the child
+    moved = ArrowArray()
+    C.memmove(C.addressof(moved), C.addressof(kids[1]), C.sizeof(ArrowArray))
+    kids[1].release = None  # "moved": the parent must not release it again
+    release(got[1].release)(C.addressof(got[1]))
+    assert moved.n_buffers == 2 and moved.buffers[0] and moved.buffers[1]
+    vals = np.ctypeslib.as_array(C.cast(moved.buffers[1], C.POINTER(C.c_int64)), shape=(moved.offset + n,))[moved.offset:]
+    np.testing.assert_array_equal(vals[1:5], (np.arange(n) + np.arange(n) + 20)[1:5])
+    bits = np.ctypeslib.as_array(C.cast(moved.buffers[0], C.POINTER(C.c_uint8)), shape=((moved.offset + n + 7) // 8,))
+    valid = np.unpackbits(bits, bitorder="little")[moved.offset:moved.offset + n].astype(bool)
+    np.testing.assert_array_equal(valid, np.arange(n) % 5 != 0)
+    release(moved.release)(C.addressof(moved))
+    for g in (got[0], got[2]):
+        release(g.release)(C.addressof(g))
+    end = ArrowArray()
+    assert get_next(C.addressof(out), C.addressof(end)) == 0 and not end.release  # end of stream
+    release(out.release)(C.addressof(out))

@@ -197,6 +197,41 @@ def test_config5_shape_consolidate_then_reduce(ctx):
     np.testing.assert_array_equal(first, np.arange(3, 7))
 
 
+def test_config5_full_size_eight_billion_rows_on_one_gpu(ctx):
+    """BASELINE configs[4] at its stated size on ONE GPU: a SuperTable column of 8 x 10^9-row i64 batches with 10 % nulls
+    (64 GB in, 64 GB + 1 GB of validity out: fits the 288 GB), consolidated and reduced. Size-independent properties: the
+    consolidated column reduces to the sum of the per-batch reduces (checksum of checksums, count included), its valid
+    count is the popcount of the joined bitmap, its dense sum is the closed form of v[i] = i + batch, windows across every
+    join equal the source rows, and the per-batch reduce as ONE ma_sum_chunks call agrees."""
+    k, n = 8, 1_000_000_000
+    M64 = (1 << 64) - 1
+    src = ctx.alloc(k * n * 8)
+    mstride = ((n + 511) // 512) * 64
+    masks_buf = ctx.alloc(k * mstride + 64)
+    chunks = [src.ptr + c * n * 8 for c in range(k)]
+    masks = [masks_buf.ptr + c * mstride for c in range(k)]
+    for c in range(k):
+        ctx.synth_iota("i64", chunks[c], n, c)  # benches/consolidate.rs:37-58: v = i + batch
+        ctx.synth_validity(masks[c], n, seed=0xABC + c, null_every=10)
+    out = ctx.alloc(k * n * 8)
+    out_mask = ctx.alloc(k * n // 8 + 64)
+    assert ctx.consolidate_column(8, chunks, [n] * k, out, masks, [0] * k, out_mask)
+    parts = [ctx.sum("i64", chunks[c], n, mask=masks[c]) for c in range(k)]
+    whole = ctx.sum("i64", out, k * n, mask=out_mask)
+    assert (whole[0] & M64, whole[1]) == (sum(p[0] for p in parts) & M64, sum(p[1] for p in parts))
+    assert 0.09 < 1 - whole[1] / (k * n) < 0.11
+    assert ctx.popcount_mask(out_mask, 0, k * n) == whole[1]
+    assert ctx.sum("i64", out, k * n)[0] & M64 == sum(n * (n - 1) // 2 + c * n for c in range(k)) & M64
+    for c in range(1, k):  # every join: the last rows of batch c - 1, the first of batch c
+        got = out.download(np.int64, 8, (c * n - 4) * 8)
+        np.testing.assert_array_equal(got, np.concatenate([np.arange(n - 4, n) + (c - 1), np.arange(0, 4) + c]))
+    total = ctx.sum_chunks("l", chunks, [n] * k, masks, [0] * k)
+    assert (total[1] & M64, total[2]) == (whole[0] & M64, whole[1])
+    for b in (src, masks_buf, out, out_mask):
+        b.free()
+    ctx.lib.ma_dev_pool_trim(ctx.handle, 0)  # 130 GB back to the driver before the next test
+
+
 # ---- bit-packed columns: ma_consolidate_boolean_column (BooleanArray data bits + validity) ----------------------
 
 def run_bool(ctx, chunks, masks=None, device=True):

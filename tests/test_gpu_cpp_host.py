@@ -1,4 +1,4 @@
-"""Runs minarrow_amd/cpp/ref_suite.bin: the reference's kernel tests (src/kernels/arithmetic/mod.rs:117-537,
+"""Runs tests/cpp/ref_suite.bin: the reference's kernel tests (src/kernels/arithmetic/mod.rs:117-537,
 src/kernels/bitmask/simd.rs:797-955) restated in C++ against the typed host mirror include/minarrow_hip.hpp,
 which sits directly on the C ABI (Vec64 = pinned hipHostMalloc memory used in place by the kernels)."""
 import subprocess
@@ -7,7 +7,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-BIN = ROOT / "minarrow_amd" / "cpp" / "ref_suite.bin"
+BIN = ROOT / "tests" / "cpp" / "ref_suite.bin"
 
 
 def build():

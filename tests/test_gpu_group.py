@@ -601,6 +601,12 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
                 exact = math.fsum(flts[valid].tolist())
             assert (fused[0], fused[1], fused[3]) == (want_i, want_c, want_c)
             assert abs(fused[2] - exact) <= math.ulp(exact)
+        if exchange == "rccl-overlap" and g.exchange_kind == "rccl":
+            # two record sets alternate: a slot that was not enqueued in the last exchange's step is refused, not served stale
+            with pytest.raises(ffi.MinarrowHipError) as e:
+                g.result(2)  # the last exchanges carried slot 5 only
+            assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT and "not enqueued" in str(e.value)
+            assert g.result(5) == fused
         st = g.exchange_stats()
         if exchange.startswith("rccl") and g.exchange_kind == "rccl":
             assert st["rccl_ranks"] == 1 and st["samples"] >= 1 and st["all_gather_us"] > 0 and st["fold_us"] > 0

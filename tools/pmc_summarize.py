@@ -26,12 +26,13 @@ rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 out = {"note": f"{rnd}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "
                f"--no-cpu-baseline --no-other-configs` (tools/collect_profiles.sh; profiles/{rnd}_pmc_*_counter_collection.csv); "
                f"KiB, median over launches; FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streaming loads; "
-               f"algorithmic bytes per launch = 8e9", "kernels": {}}
+               f"algorithmic bytes per launch = 8e9 (16e9 for the fused i64 + f64 launch)", "kernels": {}}
 for name, kib in fetch.items():
-    if "sum_kernel" not in name:
+    if "sum_kernel" not in name and "sum_fused_kernel" not in name:
         continue
     b = kib * 1024 * 2
-    key = "sum_f64_hbm_bytes_per_launch" if "double" in name else "sum_i64_hbm_bytes_per_launch"
+    key = "sum_fused_hbm_bytes_per_launch" if "sum_fused_kernel" in name else \
+        ("sum_f64_hbm_bytes_per_launch" if "double" in name else "sum_i64_hbm_bytes_per_launch")
     if n_f[name] >= 3 and b > 1e9:  # the 10^9-row launches, not the tiny ones of set-up
         out[key] = b
     out["kernels"][name[:120]] = {"launches": n_f[name], "fetch_bytes": b, "write_bytes": write.get(name, 0.0) * 1024}
