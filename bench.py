@@ -811,7 +811,7 @@ def run_group(args, result_fd) -> int:
                   issue="caller" if args.group_issue == "caller" else "threads")
     ctxs = [group.member_ctx(i) for i in range(world)]
     for c in ctxs:
-        c.set_variant(args.variant)
+        c.set_variant(args.variant | (4096 if args.handoff == "event" else 0))  # ctx variant bit 4096: overlapped exchanges wait on events
         c.set_blocks_per_cu(args.blocks_per_cu)
     cols_i = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
     cols_f = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
@@ -1197,8 +1197,11 @@ def run_native(args, result_fd) -> int:
         ex.gathered.upload(everyone.numpy())
         ex.fold_on_device(ctx)
 
-    def exchange(ex, slot=None):
-        if comm is not None and slot is not None:
+    def exchange(ex, slot=None, stamp=None):
+        if comm is not None and slot is not None and stamp is not None:
+            # the scan's final thread stamped `stamp[0]` with stamp[1]: the exchange stream waits for that, no event on the scan stream
+            comm.sum_exchange_overlapped_on_stamp(slot, stamp[0], stamp[1], ex.local, 1, ex.n_columns, ex.gathered, ex.final)
+        elif comm is not None and slot is not None:
             comm.sum_exchange_overlapped(slot, ex.local, 1, ex.n_columns, ex.gathered, ex.final)
         elif comm is not None:
             comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
@@ -1208,19 +1211,28 @@ def run_native(args, result_fd) -> int:
             ex.fold_on_device(ctx)  # one rank: nothing to exchange, the rank-ordered fold of one record
 
     fused_calls = {}
+    stamps = [ctx.stamp_alloc() for _ in exs] if (overlap and fused and args.handoff == "stamp") else None
+    stamp_seq = [0 for _ in exs]
 
     def step(marks=None):
         k = counter[0] % len(exs)
         counter[0] += 1
         ex = exs[k]
+        stamp = None
         if overlap:
             comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
         if marks is not None:
             ctx.mark(marks)
         if fused:
             if id(ex) not in fused_calls:  # the argument table of a record set is built once
-                fused_calls[id(ex)] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))])
-            fused_calls[id(ex)]()
+                fused_calls[id(ex)] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
+                                                            stamp=stamps[k] if stamps else 0)
+            if stamps:
+                stamp_seq[k] += 1
+                fused_calls[id(ex)](stamp_seq[k])
+                stamp = (stamps[k], stamp_seq[k])
+            else:
+                fused_calls[id(ex)]()
         else:
             ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
             if marks is not None:
@@ -1228,7 +1240,7 @@ def run_native(args, result_fd) -> int:
             ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if marks is not None:
             ctx.mark(marks + 2)
-        exchange(ex, k if overlap else None)
+        exchange(ex, k if overlap else None, stamp)
 
     def fence():
         if dist is not None:
@@ -1333,7 +1345,8 @@ def run_native(args, result_fd) -> int:
             if comm_note:
                 exch += f" [{comm_note}]"
         if overlap:
-            exch += "; exchange of step k on a side stream, overlapped with the scans of step k + 1"
+            exch += "; exchange of step k on a side stream, overlapped with the scans of step k + 1" + \
+                (" (hand-off: the scan kernel's stamp, no event on the scan stream)" if stamps else " (hand-off: an event)")
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
                            {"rccl_ranks": stats["rccl_ranks"], "launch": "torch.distributed.run" if world > 1 else "single process",
                             "step": step_form, "host": "torch-free" if not distributed else "torch-free GPU path (gloo for rendezvous only)",
@@ -1763,6 +1776,10 @@ def main() -> int:
                          "(0 = none)")
     ap.add_argument("--settle-ms", type=float, default=3000.0,
                     help="upper bound of the un-timed settle phase in front of the warm-up steps (see --ramp-ms)")
+    ap.add_argument("--handoff", default="stamp", choices=["stamp", "event"],
+                    help="overlapped exchanges: how the exchange stream learns that a step's records are complete — stamp = the "
+                         "fused scan's final thread stores a sequence number the exchange stream waits on (hipStreamWaitValue64: "
+                         "nothing but scans on the scan stream), event = an event recorded on the scan stream (rounds 2-3)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",

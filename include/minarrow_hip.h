@@ -50,7 +50,8 @@ extern "C" {
  * returns the LIBRARY ordinal (round-trip safe through ma_ctx_create); group calls are issued by per-member threads.
  */
 /* 3 (round 4): + ma_ctx_mark / ma_ctx_mark_elapsed_ms (timing marks), ma_sum_fused (several long columns in ONE launch),
- * ma_group_enqueue_sum_table, ma_group_exchange_stats, ma_comm_exchange_stats; ma_hip_runtime_path, ma_rccl_path; ma_dev_alloc_output searches only when asked to
+ * ma_sum_fused_stamped + ma_stamp_alloc / _free + ma_comm_sum_exchange_overlapped_on_stamp (event-free hand-off to the
+ * exchange stream), ma_group_enqueue_sum_table, ma_group_exchange_stats, ma_comm_exchange_stats; ma_hip_runtime_path, ma_rccl_path; ma_dev_alloc_output searches only when asked to
  * (MINARROW_HIP_OUTPUT_SEARCH=1 / ma_dev_output_search).
  * A binding compares ma_abi_version() with the MA_ABI_VERSION it was generated from. */
 #define MA_ABI_VERSION 3
@@ -375,6 +376,16 @@ typedef struct ma_fused_column {
     uint64_t* out;             /* see above */
 } ma_fused_column;
 ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols);
+/* The same launch, whose final thread additionally stores `stamp_value` to `*stamp` (device-reachable, 8-byte aligned) with a
+ * system-scope release BEHIND the results: a hand-off that another stream — or the host — can wait on without an event
+ * packet on this context's stream (hipStreamWaitValue64 on memory from ma_stamp_alloc; ma_comm_sum_exchange_overlapped_on_stamp
+ * does exactly that). An event record between two back-to-back scans costs the stream several microseconds; the stamp costs
+ * it nothing. */
+ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
+/* 64 bytes of signal memory on the context's device (hipExtMallocWithFlags(hipMallocSignalMemory); plain device memory when
+ * the runtime refuses), zeroed: what a stream can be made to wait on. Free with ma_stamp_free. */
+ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);
+ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp);
 
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
  * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =
@@ -1056,6 +1067,12 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
                                uint64_t* gathered, uint64_t* out_finals);
 ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uint64_t* local_records, size_t slots_per_rank,
                                           size_t n_columns, uint64_t* gathered, uint64_t* out_finals);
+/* ma_comm_sum_exchange_overlapped whose exchange stream waits for `*stamp >= stamp_value` (hipStreamWaitValue64) instead of
+ * an event recorded on the context's stream: the scans that fill this slot's records must end with a launch that stamps it
+ * (ma_sum_fused_stamped). The context's stream then carries nothing but the scans. */
+ma_status ma_comm_sum_exchange_overlapped_on_stamp(ma_comm* comm, int32_t slot, uint64_t* stamp, uint64_t stamp_value,
+                                                   const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
+                                                   uint64_t* gathered, uint64_t* out_finals);
 ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot);
 /* As ma_group_exchange_stats, for this rank's ma_comm_sum_exchange / _overlapped calls. */
 ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,

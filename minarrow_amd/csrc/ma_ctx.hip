@@ -1435,6 +1435,30 @@ ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak
     return MA_OK;
 }
 
+ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
+    MA_REQUIRE(ctx != nullptr && out_stamp != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_stamp is NULL");
+    *out_stamp = nullptr;
+    MA_ENTER_PRIMARY(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, 64, hipMallocSignalMemory) != hipSuccess) {
+        (void)hipGetLastError();
+        MA_HIP(hipMalloc(&p, 64));
+    }
+    MA_HIP(hipMemset(p, 0, 64));
+    *out_stamp = (uint64_t*)p;
+    return MA_OK;
+}
+
+ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp) {
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    if (!stamp) return MA_OK;
+    MA_ENTER_PRIMARY(ctx);
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipFree(stamp));
+    return MA_OK;
+}
+
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {
     MA_REQUIRE(ctx != nullptr && out_dev_ptr != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out pointer is NULL");
     *out_dev_ptr = nullptr;

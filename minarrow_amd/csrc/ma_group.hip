@@ -81,6 +81,13 @@ struct ma_group {
     // the LAST exchange, and a column that was not enqueued in that step would come back from the other set — the value of
     // two steps ago, or zeros — so it is refused instead.
     uint32_t enq_mask[2] = {0, 0}, exchanged_mask[2] = {0, 0};
+    // Event-free hand-off to the exchange stream (overlap only): the fused table launch of a step stamps stamp[set][member]
+    // with stamp_seq[set] behind its results, and the member's exchange stream waits for that value (hipStreamWaitValue64)
+    // instead of an event recorded on the scan stream — which then carries nothing but scans. stamp_ok[set]: every launch
+    // into the set since its last exchange was such a stamped one (anything else falls back to the event).
+    std::vector<uint64_t*> stamp[2];
+    uint64_t stamp_seq[2] = {0, 0};
+    bool stamp_ok[2] = {false, false};
     uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
     uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
     // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
@@ -97,6 +104,7 @@ using namespace ma;
 
 namespace ma {
 ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
 }
 
 namespace {
@@ -185,6 +193,8 @@ void release_exchange(ma_group* g) {
                 if (i < g->ev_done[k].size() && g->ev_done[k][i]) (void)hipEventDestroy(g->ev_done[k][i]);
             }
             if (i < g->side.size() && g->side[i]) ma_ctx_destroy(g->side[i]);
+            for (int k = 0; k < 2; ++k)
+                if (i < g->stamp[k].size() && g->stamp[k][i]) (void)hipFree(g->stamp[k][i]);
         }
         if (g->host_finals) (void)hipHostFree(g->host_finals);
     } else {
@@ -204,6 +214,8 @@ void release_exchange(ma_group* g) {
         g->ev_ready[k].clear();
         g->ev_done[k].clear();
         g->set_used[k] = false;
+        g->stamp[k].clear();
+        g->stamp_ok[k] = false;
     }
     g->overlap = false;
     g->cur = g->last = 0;
@@ -273,6 +285,16 @@ ma_status setup_rccl(ma_group* g, bool overlap) {
             for (int k = 0; k < 2; ++k) {
                 MA_HIP(hipEventCreateWithFlags(&g->ev_ready[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
                 MA_HIP(hipEventCreateWithFlags(&g->ev_done[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
+                if (g->stamp[k].size() < n) g->stamp[k].assign(n, nullptr);
+                if (ma_stamp_alloc(g->ctxs[i], &g->stamp[k][i]) != MA_OK) g->stamp[k][i] = nullptr;  // -> the event path
+                // does this runtime let a stream wait on that word? (0 >= 0: satisfied at once) — else the event path
+                if (g->stamp[k][i] &&
+                    (hipStreamWaitValue64(g->side[i]->stream, g->stamp[k][i], 0, hipStreamWaitValueGte, ~(uint64_t)0) != hipSuccess ||
+                     hipStreamSynchronize(g->side[i]->stream) != hipSuccess)) {
+                    (void)hipGetLastError();
+                    (void)hipFree(g->stamp[k][i]);
+                    g->stamp[k][i] = nullptr;
+                }
             }
         }
     }
@@ -411,6 +433,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
         if (chunk_masks) MA_TRY(require_resident(g, lookup, i, chunk_masks[i], "validity bitmap", i));
     }
     g->enq_mask[g->overlap ? g->cur : 0] |= 1u << column;
+    g->stamp_ok[g->overlap ? g->cur : 0] = false;  // not a stamped launch: this set's exchange waits on an event
     // enqueue only (the members are in async mode): all devices run concurrently
     return run_on_members(g, [&](size_t i) {
         uint64_t* set = (g->overlap && g->cur == 1) ? g->local1[i] : g->local[i];
@@ -430,8 +453,13 @@ ma_status exchange_locked(ma_group* g) {
     auto finals = [g, set](size_t i) { return set ? g->finals1[i] : g->finals[i]; };
     // which context issues the exchange of member i: its own (in-stream), or its side context (overlapped: behind the
     // scans that filled this set — an event — while the member's stream goes on with the other set)
-    auto before = [g, set](size_t i) -> ma_status {
+    const bool on_stamp = g->overlap && g->stamp_ok[set] && !(g->ctxs[0]->variant & 4096);  // variant bit 4096: always events (A/B)
+    auto before = [g, set, on_stamp](size_t i) -> ma_status {
         if (!g->overlap) return MA_OK;
+        if (on_stamp) {  // the scan stream carries nothing for the hand-off: the exchange stream waits for the kernel's stamp
+            MA_HIP(hipStreamWaitValue64(g->side[i]->stream, g->stamp[set][i], g->stamp_seq[set], hipStreamWaitValueGte, ~(uint64_t)0));
+            return MA_OK;
+        }
         MA_HIP(hipEventRecord(g->ev_ready[set][i], g->ctxs[i]->stream));
         MA_HIP(hipStreamWaitEvent(g->side[i]->stream, g->ev_ready[set][i], 0));
         return MA_OK;
@@ -531,6 +559,7 @@ ma_status exchange_locked(ma_group* g) {
         g->exchanged_mask[set] = g->enq_mask[set];
         g->enq_mask[set] = 0;
         g->enq_mask[set ^ 1] = 0;  // the set about to be filled starts empty
+        g->stamp_ok[set] = false;
     }
     return MA_OK;
 }
@@ -786,6 +815,12 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
             MA_TRY(require_resident(group, lookup, i, chunk_data[k][i], "data", i));
             if (chunk_masks && chunk_masks[k]) MA_TRY(require_resident(group, lookup, i, chunk_masks[k][i], "validity bitmap", i));
         }
+    // overlapped exchanges: this launch stamps the set's hand-off word behind its results (see ma_group::stamp)
+    const int cur_set = group->overlap ? group->cur : 0;
+    bool stamped = group->overlap && group->stamp[cur_set].size() == group->ctxs.size();
+    for (size_t i = 0; stamped && i < group->ctxs.size(); ++i) stamped = group->stamp[cur_set][i] != nullptr;
+    const uint64_t seq = stamped ? ++group->stamp_seq[cur_set] : 0;
+    group->stamp_ok[cur_set] = stamped;
     return run_on_members(group, [&](size_t i) -> ma_status {
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];
         ma_fused_column cols[MA_FUSED_MAX_COLUMNS];
@@ -800,7 +835,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
             cols[k].reserved = 0;
             cols[k].out = format_codes[k] == 'g' ? rec + 2 : rec;
         }
-        return ma_sum_fused(group->ctxs[i], (size_t)n_cols, cols);
+        return sum_fused_impl(group->ctxs[i], (size_t)n_cols, cols, stamped ? group->stamp[cur_set][i] : nullptr, seq);
     });
 }
 
@@ -828,6 +863,7 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
         if (chunk_masks) MA_TRY(require_resident(group, lookup, i % G, chunk_masks[i], "validity bitmap", i));
     }
     group->enq_mask[group->overlap ? group->cur : 0] |= 1u << column;
+    group->stamp_ok[group->overlap ? group->cur : 0] = false;
     return run_on_members(group, [&](size_t m) -> ma_status {
         std::vector<const void*> d;
         std::vector<size_t> n, o;

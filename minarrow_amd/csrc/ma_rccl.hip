@@ -241,8 +241,23 @@ ma_status ma_comm_sum_exchange(ma_comm* comm, const uint64_t* local_records, siz
     return MA_OK;
 }
 
+static ma_status exchange_overlapped(ma_comm* comm, int32_t slot, uint64_t* stamp, uint64_t stamp_value, const uint64_t* local_records,
+                                     size_t slots_per_rank, size_t n_columns, uint64_t* gathered, uint64_t* out_finals);
+
 ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uint64_t* local_records, size_t slots_per_rank,
                                           size_t n_columns, uint64_t* gathered, uint64_t* out_finals) {
+    return exchange_overlapped(comm, slot, nullptr, 0, local_records, slots_per_rank, n_columns, gathered, out_finals);
+}
+
+ma_status ma_comm_sum_exchange_overlapped_on_stamp(ma_comm* comm, int32_t slot, uint64_t* stamp, uint64_t stamp_value,
+                                                   const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
+                                                   uint64_t* gathered, uint64_t* out_finals) {
+    MA_REQUIRE(stamp != nullptr, MA_ERR_INVALID_ARGUMENT, "stamp is NULL");
+    return exchange_overlapped(comm, slot, stamp, stamp_value, local_records, slots_per_rank, n_columns, gathered, out_finals);
+}
+
+static ma_status exchange_overlapped(ma_comm* comm, int32_t slot, uint64_t* stamp, uint64_t stamp_value, const uint64_t* local_records,
+                                     size_t slots_per_rank, size_t n_columns, uint64_t* gathered, uint64_t* out_finals) {
     MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
     MA_REQUIRE(slot == 0 || slot == 1, MA_ERR_INVALID_ARGUMENT, "slot must be 0 or 1 (two record sets in flight)");
     MA_REQUIRE(local_records && gathered && out_finals, MA_ERR_INVALID_ARGUMENT, "NULL buffer");
@@ -265,9 +280,14 @@ ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uin
     }
     ma_ctx* side = comm->side;
     std::lock_guard<std::mutex> lock(side->mu);
-    // behind everything the context's stream has been given so far (the scans that wrote this slot's records) ...
-    MA_HIP(hipEventRecord(comm->ready[slot], ctx->stream));
-    MA_HIP(hipStreamWaitEvent(side->stream, comm->ready[slot], 0));
+    if (stamp) {
+        // ... behind the stamp the slot's last scan stores after its results: nothing at all goes onto the context's stream
+        MA_HIP(hipStreamWaitValue64(side->stream, stamp, stamp_value, hipStreamWaitValueGte, ~(uint64_t)0));
+    } else {
+        // behind everything the context's stream has been given so far (the scans that wrote this slot's records) ...
+        MA_HIP(hipEventRecord(comm->ready[slot], ctx->stream));
+        MA_HIP(hipStreamWaitEvent(side->stream, comm->ready[slot], 0));
+    }
     const size_t per_rank_words = slots_per_rank * n_columns * kRecordWords;
     const int tk = comm->timer.begin(side->stream);
     MA_NCCL(api, AllGather(local_records, gathered, per_rank_words * 8, ncclChar, comm->comm, side->stream));

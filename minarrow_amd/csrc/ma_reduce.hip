@@ -257,14 +257,13 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     __syncthreads();
     if (!is_last) return;
 
-    // ---- the last workgroup's first wave folds every partial: in index order per lane (lane, lane + 64, ...), then across
-    // the lanes; lane 0 writes the results. One wave has all the parallelism 768 partials need (twelve loads per lane in
-    // flight at once), and nothing goes through LDS and two more barriers (round 4: -0.3 us on the launch's critical path).
-    if (wave != 0) return;
+    // ---- the last workgroup folds every partial, in index order per thread, then across threads. All 256 threads load (one
+    // to three partials each for the shapes the host picks: independent loads, one round trip) — a single wave walking the
+    // list in a loop was tried in round 4 and cost 2 us at 768 workgroups (twelve dependent-looking trips per lane).
     Acc tot;
     tot.init();
     uint64_t tc = 0;
-    for (unsigned i = lane; i < gridDim.x; i += 64) {
+    for (unsigned i = tid; i < gridDim.x; i += kBlock) {
         const uint64_t* q = (const uint64_t*)&a.partials[i];
         Acc o;
         o.from_words(load_agent(q), load_agent(q + 1));
@@ -276,9 +275,23 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         tot.shfl_down_merge(off);
         tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
     }
+    __syncthreads();  // lds[] is reused
     if (lane == 0) {
-        Acc s = tot;
-        uint64_t c = tc;
+        tot.to_partial(lds[wave]);
+        lds[wave].cnt = tc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Acc s;
+        s.from_words(lds[0].a, lds[0].b);
+        uint64_t c = lds[0].cnt;
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            Acc o;
+            o.from_words(lds[w].a, lds[w].b);
+            s.merge(o);
+            c += lds[w].cnt;
+        }
         double as_double;
         if constexpr (std::is_same<Acc, DDAcc>::value) {
             DDAcc& d = reinterpret_cast<DDAcc&>(s);

@@ -240,50 +240,79 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
-
-    // ---- the last workgroup folds the partials: WAVE w takes column w — its lanes load the column's partials in index
-    // order (lane, lane + 64, ...), merge across lanes, lane 0 writes the column's outputs — so the columns fold side by
-    // side and nothing goes through LDS again.
-    static_assert(kFusedMax <= kWaves, "one wave per column in the final fold");
-    if ((int)wave < a.n_cols) {
-        const int c = (int)wave;
-        const bool is_float = a.col[c].is_float != 0;
-        Acc2 tot;
-        tot.init();
-        uint64_t tc = 0;
-        for (unsigned i = lane; i < G; i += 64) {
+    // ---- the last workgroup folds the partials. Every thread loads its share of EVERY column's partials first (index order
+    // per thread; the columns' loads are independent, so they are all in flight in one round trip — a wave per column walking
+    // its list in a loop was tried and cost 2 us more), then the columns are merged across lanes, the four waves' results
+    // meet in LDS once, and thread c finishes column c.
+    Acc2 tot[kFusedMax];
+    uint64_t tc[kFusedMax];
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        tot[c].init();
+        tc[c] = 0;
+    }
+    for (unsigned i = tid; i < G; i += kBlock) {
+#pragma unroll
+        for (int c = 0; c < kFusedMax; ++c) {
+            if (c >= a.n_cols) continue;
             const uint64_t* q = (const uint64_t*)&a.partials[(size_t)c * G + i];
             Acc2 o;
             o.a = load_agent(q);
             o.b = load_agent(q + 1);
-            tot.merge(o, is_float);
-            tc += load_agent(q + 2);
+            tot[c].merge(o, a.col[c].is_float != 0);
+            tc[c] += load_agent(q + 2);
         }
+    }
+    __syncthreads();  // lds[][] is reused
+#pragma unroll
+    for (int c = 0; c < kFusedMax; ++c) {
+        if (c >= a.n_cols) continue;
+        const bool is_float = a.col[c].is_float != 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            tot.merge(tot.shfl_down(off), is_float);
-            tc += (uint64_t)__shfl_down((unsigned long long)tc, off, 64);
+            tot[c].merge(tot[c].shfl_down(off), is_float);
+            tc[c] += (uint64_t)__shfl_down((unsigned long long)tc[c], off, 64);
         }
         if (lane == 0) {
-            uint64_t* out = a.col[c].out;
-            if (is_float) {
-                DDAcc d;
-                d.from_words(tot.a, tot.b);
-                d.normalise();
-                out[0] = (uint64_t)__double_as_longlong(d.hi);
-                out[1] = (uint64_t)__double_as_longlong(d.lo);
-                out[2] = tc;
-            } else {
-                out[0] = tot.a;
-                out[1] = tc;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have left this wave before the barrier below
+            lds[c][wave].a = tot[c].a;
+            lds[c][wave].b = tot[c].b;
+            lds[c][wave].cnt = tc[c];
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
-        if (a.done_word) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)tid < a.n_cols) {
+        const int c = (int)tid;
+        const bool is_float = a.col[c].is_float != 0;
+        Acc2 s;
+        s.a = lds[c][0].a;
+        s.b = lds[c][0].b;
+        uint64_t n = lds[c][0].cnt;
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            Acc2 o;
+            o.a = lds[c][w].a;
+            o.b = lds[c][w].b;
+            s.merge(o, is_float);
+            n += lds[c][w].cnt;
+        }
+        uint64_t* out = a.col[c].out;
+        if (is_float) {
+            DDAcc d;
+            d.from_words(s.a, s.b);
+            d.normalise();
+            out[0] = (uint64_t)__double_as_longlong(d.hi);
+            out[1] = (uint64_t)__double_as_longlong(d.lo);
+            out[2] = n;
+        } else {
+            out[0] = s.a;
+            out[1] = n;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have left before the stamp below
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
+            if (a.done_word) __hip_atomic_store(a.done_word, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -304,7 +333,22 @@ static void launch_fused(ma_ctx* ctx, const FusedArgs& a, int grid, int pace) {
 
 using namespace ma;
 
+namespace ma {
+ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
+}
+
 extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols) {
+    return sum_fused_impl(ctx, n_cols, cols, nullptr, 0);
+}
+
+extern "C" ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp,
+                                          uint64_t stamp_value) {
+    MA_REQUIRE(stamp != nullptr && ((uintptr_t)stamp & 7) == 0, MA_ERR_INVALID_ARGUMENT, "stamp is NULL or misaligned");
+    MA_REQUIRE(pointer_kind(stamp) != kPageable, MA_ERR_INVALID_ARGUMENT, "stamp must be device-reachable memory");
+    return sum_fused_impl(ctx, n_cols, cols, stamp, stamp_value);
+}
+
+ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(n_cols >= 1 && n_cols <= (size_t)kFusedMax && cols != nullptr, MA_ERR_INVALID_ARGUMENT,
                "ma_sum_fused takes 1..%d columns", kFusedMax);
@@ -362,6 +406,8 @@ extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_col
     static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
     const int sel = kPace[(ctx->variant >> 5) & 7];
     const int pace = sel >= 0 ? sel : 20;
+    a.done_word = stamp;  // stored (system-scope release) by the launch's final thread behind its results
+    a.done_seq = stamp_value;
     if (any_masked) launch_fused<4, true>(ctx, a, grid, 0);
     else launch_fused<8, false>(ctx, a, grid, pace);
     MA_HIP(hipGetLastError());

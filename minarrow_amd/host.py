@@ -376,7 +376,16 @@ class Context:
             arr[i].out = addr_of(out)
         ffi.check(self.lib.ma_sum_fused(self.handle, len(columns), C.addressof(arr)))
 
-    def prepare_sum_fused(self, columns):
+    def stamp_alloc(self) -> int:
+        """Address of 64 bytes of zeroed signal memory a stream can wait on (ma_stamp_alloc)."""
+        p = C.c_void_p()
+        ffi.check(self.lib.ma_stamp_alloc(self.handle, C.byref(p)))
+        return int(p.value)
+
+    def stamp_free(self, stamp: int) -> None:
+        ffi.check(self.lib.ma_stamp_free(self.handle, stamp))
+
+    def prepare_sum_fused(self, columns, stamp: int = 0):
         """The same call with its argument table built ONCE: returns a zero-argument callable for a stepping host (a Rust
         host builds its ma_fused_column array once too; the Python marshalling is ~30 us per call otherwise)."""
         arr = (FusedColumn * len(columns))()
@@ -387,7 +396,17 @@ class Context:
             arr[i].mask_bit_offset = int(col[5]) if len(col) > 5 else 0
             arr[i].null_count = int(col[6]) if len(col) > 6 else -1
             arr[i].format_code, arr[i].reserved = ord(fmt), 0
-        fn, handle, k, p = self.lib.ma_sum_fused, self.handle, len(columns), C.addressof(arr)
+        handle, k, p = self.handle, len(columns), C.addressof(arr)
+        if stamp:  # call(value): the launch's final thread stores `value` to the stamp behind its results (ma_sum_fused_stamped)
+            fs = self.lib.ma_sum_fused_stamped
+
+            def call_stamped(value, _keep=arr):
+                st = fs(handle, k, p, stamp, value)
+                if st:
+                    ffi.check(st)
+
+            return call_stamped
+        fn = self.lib.ma_sum_fused
 
         def call(_keep=arr):
             st = fn(handle, k, p)
@@ -922,6 +941,12 @@ class Comm:
         g, f, k, r = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
         ffi.check(self.lib.ma_comm_exchange_stats(self.handle, C.byref(g), C.byref(f), C.byref(k), C.byref(r)))
         return {"all_gather_us": g.value, "fold_us": f.value, "samples": int(k.value), "rccl_ranks": int(r.value)}
+
+    def sum_exchange_overlapped_on_stamp(self, slot: int, stamp: int, value: int, local_records, slots_per_rank: int, n_columns: int,
+                                         gathered, out_finals) -> None:
+        """As sum_exchange_overlapped, but the exchange stream waits for `*stamp >= value` instead of an event on the scan stream."""
+        ffi.check(self.lib.ma_comm_sum_exchange_overlapped_on_stamp(self.handle, int(slot), stamp, int(value), addr_of(local_records),
+                                                                   int(slots_per_rank), int(n_columns), addr_of(gathered), addr_of(out_finals)))
 
     def slot_wait(self, slot: int) -> None:
         """Puts the context's stream behind the last overlapped exchange of record set `slot`."""

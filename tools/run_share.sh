@@ -9,9 +9,11 @@ for s in fused separate; do
     sleep 3; python3 bench.py $P --no-torch-hosted-leg --step $s > $O/plain_$s.json 2>/dev/null
     sleep 3; python3 bench.py $P --gpus 1 --force-group --step $s > $O/group_$s.json 2>/dev/null
     sleep 3; python3 bench.py $P --gpus 1 --force-group --overlap on --step $s > $O/group_overlap_$s.json 2>/dev/null
+    sleep 3; python3 bench.py $P --gpus 1 --force-group --overlap on --handoff event --step $s > $O/group_overlap_event_handoff_$s.json 2>/dev/null
     sleep 3; python3 bench.py $P --gpus 1 --force-group --exchange host --step $s > $O/group_hostfold_$s.json 2>/dev/null
     sleep 3; python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29612 bench.py $P --gpus 1 --force-dist --overlap off --step $s > $O/ranks_$s.json 2>/dev/null
     sleep 3; python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29613 bench.py $P --gpus 1 --force-dist --overlap on --step $s > $O/ranks_overlap_$s.json 2>/dev/null
+    sleep 3; python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29614 bench.py $P --gpus 1 --force-dist --overlap on --handoff event --step $s > $O/ranks_overlap_event_handoff_$s.json 2>/dev/null
 done
 python3 - $O <<'PY'
 import json, glob, sys
