@@ -528,9 +528,16 @@ static ma_status concat_column_by_chunks(ma_ctx* ctx, CallScope& scope, size_t e
     if (has_join) mdesc.resize(n_chunks);
     DeviceRange data_role, mask_role;
     // segments are whole multiples of the grid (workgroups deal chunks round-robin: 4096 chunks over 1536 workgroups left a
-    // third of them a chunk short for a third of the segment)
+    // third of them a chunk short for a third of the segment). As FEW segments as keep the GPU fed: on output blocks that
+    // write fast, a copy kernel of under ~20 rounds runs 5-8 % below the rate the same rows reach inside one long sweep (the
+    // plain copy does too: profiles/r04_copy_windows.jsonl), so 4, 8, 16, 21, 21, 9 rounds (122 000 8-byte chunks; rounds
+    // 1-3's shape) cost 6.5 % where 4, 16, 59 cost 2 %. The host describes a round in ~6 us whatever the element width; the
+    // GPU copies one in 34 us (8192-row chunks of 8 bytes) or 17 us (4 bytes): the next segment may be 4x / 2x the one the
+    // GPU is working on without starving it.
     const size_t per_round = (size_t)grid_for(ctx, (size_t)1 << 30, 6);
-    const size_t kFirst = 4 * per_round, kMax = 21 * per_round;
+    const size_t avg_chunk_bytes = total / n_chunks * elem_size;
+    const size_t growth = avg_chunk_bytes >= ((size_t)48 << 10) ? 4 : 2;
+    const size_t kFirst = 4 * per_round, kMax = 64 * per_round;
     size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
     while (c0 < n_chunks) {
         const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
@@ -594,7 +601,7 @@ else                                                                            
 #undef MA_CONCAT_CHUNKS
         MA_HIP(hipGetLastError());
         c0 = c1;
-        if (seg < kMax) seg = seg * 2 < kMax ? seg * 2 : kMax;
+        if (seg < kMax) seg = seg * growth < kMax ? seg * growth : kMax;
     }
     if (has_join) {  // the join pass walks the list either side of a chunk: one compact table, uploaded
         void* dm = nullptr;

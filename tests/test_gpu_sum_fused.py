@@ -168,3 +168,60 @@ def test_one_billion_rows_both_columns_one_launch(ctx):
     assert abs(fold_dd(pairs) - float(expect)) <= math.ulp(float(expect))
     ci.free()
     cf.free()
+
+
+def test_stamped_launch_and_exchange_waiting_on_the_stamp(ctx, oracle):
+    """ma_sum_fused_stamped: the launch's final thread stores the caller's value to a signal word BEHIND its results, and
+    ma_comm_sum_exchange_overlapped_on_stamp makes the exchange stream wait for that word instead of an event on the scan
+    stream. Six steps alternate two record sets; every step's folded results must be that step's."""
+    from minarrow_amd.host import Comm
+
+    n = 1_000_003
+    rng = np.random.default_rng(41)
+    a = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+    f = rng.standard_normal(n) * 1e5
+    da, df = ctx.to_device(a, pad_bytes=64), ctx.to_device(f, pad_bytes=64)
+    stamp = ctx.stamp_alloc()
+    word = np.zeros(1, dtype=np.uint64)
+
+    def read_stamp():
+        assert ctx.lib.ma_dev_download(ctx.handle, word.ctypes.data, stamp, 8) == 0
+        return int(word[0])
+
+    assert read_stamp() == 0
+    rec = _records(ctx, 1)
+    call = ctx.prepare_sum_fused([("l", da, n, rec.ptr), ("g", df, n, rec.ptr + 16)], stamp=stamp)
+    call(5)
+    ctx.synchronize()
+    assert read_stamp() == 5
+    w = _read(rec, 0)
+    assert int(w[0]) == oracle.sum_scalar(a) & M64 and int(w[1]) == n and int(w[4]) == n
+
+    comm = Comm(ctx, Comm.unique_id(), 0, 1)
+    stamps = [ctx.stamp_alloc(), ctx.stamp_alloc()]
+    try:
+        ctx.set_async(True)
+        sets = [(ctx.alloc(64), ctx.alloc(64), ctx.alloc(32)) for _ in range(2)]
+        wants, seq = [], [0, 0]
+        for step in range(6):
+            k = step % 2
+            loc, gat, fin = sets[k]
+            lo, hi = (step * 4099) % 100_000, n - (step * 777) % 50_000
+            comm.slot_wait(k)
+            seq[k] += 1
+            launch = ctx.prepare_sum_fused([("l", da.offset(lo * 8), hi - lo, loc.ptr), ("g", df.offset(lo * 8), hi - lo, loc.ptr + 16)],
+                                           stamp=stamps[k])
+            launch(seq[k])
+            comm.sum_exchange_overlapped_on_stamp(k, stamps[k], seq[k], loc, 1, 1, gat, fin)
+            wants.append((k, oracle.sum_scalar(a[lo:hi]) & M64, hi - lo, math.fsum(f[lo:hi].tolist())))
+        comm.synchronize()
+        ctx.set_async(False)
+        ctx.synchronize()
+        for k, want_i, want_n, want_f in wants[-2:]:
+            r = sets[k][2].download(np.uint64, 4)
+            assert int(r[0]) == want_i and int(r[1]) == want_n and int(r[3]) == want_n
+            assert ulps(float(r[2:3].view(np.float64)[0]), want_f) <= 1
+    finally:
+        comm.close()
+        for s in stamps + [stamp]:
+            ctx.stamp_free(s)
