@@ -19,8 +19,18 @@ pairs, so the f64 result stays within 1 ULP and every rank holds bit-identical f
         bench.py --gpus N --steps K --warmup W   # one process per GPU, ma_comm_* (RCCL) for the exchange
 
 At N = 1 the line also carries `other_configs` (BASELINE configs 3, 4, 5 at 10^9 rows: per-kernel ms / GB/s / fraction of
-peak / fraction of the same-process copy rate / parity), measured after and outside the timed headline region, and
-`cpu_baseline`.
+peak / fraction of the same-process copy rate / parity), measured after and outside the timed headline region,
+`cpu_baseline`, and `torch_hosted` (the same headline hosted by PyTorch, in a child process).
+
+The process is a plain host of libminarrow_hip.so (round 4): no torch on the GPU path in any launch mode — columns from
+ma_dev_alloc, the library's own stream, per-kernel durations from its timing marks (HIP events on that stream, inside the
+timed region), /opt/rocm's HIP runtime (`config.hip_runtime`). Under torch.distributed.run the gloo backend carries the
+rendezvous, the barriers and the max-over-ranks on the CPU side only. At N > 1 the step is ONE fused launch per GPU
+(ma_sum_fused / ma_group_enqueue_sum_table) whose final thread stamps a word the exchange stream waits on (`--handoff`),
+and the line says where the exchange's time went (`exchange_us`, `fold_us`, `rccl_ranks` as ncclCommCount reports it,
+per-member / per-rank scan times). `--torch-hosted` = rounds 1-3's form (torch tensors and stream), kept as a labelled extra.
+An un-timed settle phase runs in front of the W warm-up steps (`config.clock_ramp`: clocks, and the driver's background
+clear of VRAM the previous process released — profiles/r04_read_rate_states_root_cause.txt).
 
 Prints ONE JSON line on rank 0.
 """
