@@ -104,7 +104,8 @@ using namespace ma;
 
 namespace ma {
 ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
-ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
+ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
+                         bool as_partials = false);
 }
 
 namespace {

@@ -103,6 +103,7 @@ struct ma_comm {
     ma_ctx* side = nullptr;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool used[2] = {false, false};
+    bool no_wait_value = false;  // hipStreamWaitValue64 failed once: overlapped exchanges are ordered by events from then on
     ma::ExchangeTimer timer;  // every 4th exchange: all-gather / fold durations (ma_comm_exchange_stats)
 };
 
@@ -280,10 +281,17 @@ static ma_status exchange_overlapped(ma_comm* comm, int32_t slot, uint64_t* stam
     }
     ma_ctx* side = comm->side;
     std::lock_guard<std::mutex> lock(side->mu);
-    if (stamp) {
+    bool waited = false;
+    if (stamp && !comm->no_wait_value) {
         // ... behind the stamp the slot's last scan stores after its results: nothing at all goes onto the context's stream
-        MA_HIP(hipStreamWaitValue64(side->stream, stamp, stamp_value, hipStreamWaitValueGte, ~(uint64_t)0));
-    } else {
+        if (hipStreamWaitValue64(side->stream, stamp, stamp_value, hipStreamWaitValueGte, ~(uint64_t)0) == hipSuccess) {
+            waited = true;
+        } else {  // a runtime without stream memory operations: the event below orders the same thing (the stamped launch is
+            (void)hipGetLastError();  // already on the context's stream), from now on without trying again
+            comm->no_wait_value = true;
+        }
+    }
+    if (!waited) {
         // behind everything the context's stream has been given so far (the scans that wrote this slot's records) ...
         MA_HIP(hipEventRecord(comm->ready[slot], ctx->stream));
         MA_HIP(hipStreamWaitEvent(side->stream, comm->ready[slot], 0));

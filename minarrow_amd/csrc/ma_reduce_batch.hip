@@ -645,6 +645,11 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
 
 using namespace ma;
 
+namespace ma {
+ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
+                         bool as_partials);  // ma_reduce_fused.hip
+}
+
 static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
                                   const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
                                   double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts, bool total,
@@ -685,6 +690,66 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
                                (double*)zf, (uint64_t*)zi, (uint64_t*)zc, (double*)zl);
         MA_HIP(hipGetLastError());
         return end_call(ctx, scope);
+    }
+    // A FEW LONG dense 8-byte columns on the device (the batches of a SuperTable column, a table of a few wide columns): the
+    // fused scan of ma_reduce_fused.hip, four columns per launch — the single-column sum's shape (paced loads, one
+    // cross-workgroup hand-off per launch) instead of a workgroup per 64-Ki-row segment: 8 x 67 M rows 6.85 -> 7.03 TB/s, 8 x 125 M
+    // rows 6.85 -> 7.15.
+    // Each launch leaves one Partial per column; the folds below are the general path's. variant bit 16384: general path (A/B).
+    if (elem == 8 && n_cols <= 16 && !(ctx->variant & 16384)) {
+        bool few_long = true;
+        for (size_t i = 0; i < n_cols && few_long; ++i) {
+            // dense columns only: with validity the fused scan reads at 6.4-6.7 TB/s where the segment path below reaches
+            // 6.9-7.0 (tools/ab_sum_columns.py)
+            few_long = col_lens[i] >= ((size_t)1 << 21) && pointer_kind(col_data[i]) == kDevice && !(col_masks && col_masks[i]);
+        }
+        if (few_long) {
+            void *of = nullptr, *oi = nullptr, *oc = nullptr, *olo = nullptr;
+            const size_t n_out = total ? 1 : n_cols;
+            MA_TRY(scope.out(out_sums_f64, n_out * 8, &of));
+            MA_TRY(scope.out(out_sums_i64, n_out * 8, &oi));
+            MA_TRY(scope.out(out_valid_counts, n_out * 8, &oc));
+            if (total) MA_TRY(scope.out(out_lo, 8, &olo));
+            void* scratch = nullptr;
+            MA_TRY(ctx_scratch(ctx, sizeof(Partial) * n_cols, &scratch));
+            Partial* partials = (Partial*)scratch;
+            {
+                NoSync enqueue_only;  // the composed launches are waited for once, by end_call below
+                for (size_t c0 = 0; c0 < n_cols; c0 += MA_FUSED_MAX_COLUMNS) {
+                    const size_t k = n_cols - c0 < MA_FUSED_MAX_COLUMNS ? n_cols - c0 : MA_FUSED_MAX_COLUMNS;
+                    ma_fused_column fc[MA_FUSED_MAX_COLUMNS] = {};
+                    for (size_t j = 0; j < k; ++j) {
+                        const size_t i = c0 + j;
+                        fc[j].data = col_data[i];
+                        fc[j].n = col_lens[i];
+                        fc[j].mask_bits = nullptr;
+                        fc[j].mask_bit_offset = 0;
+                        fc[j].null_count = -1;
+                        fc[j].format_code = format_code;
+                        fc[j].out = (uint64_t*)&partials[i];
+                    }
+                    MA_TRY(sum_fused_impl(ctx, k, fc, nullptr, 0, true));
+                }
+            }
+            const bool is_signed = format_code != 'L';
+            if (total) {
+                if (format_code == 'g')
+                    hipLaunchKernelGGL((total_fold_kernel<double>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)partials, n_cols,
+                                       1, (double*)of, (uint64_t*)oi, (uint64_t*)oc, (double*)olo);
+                else
+                    hipLaunchKernelGGL((total_fold_kernel<int64_t>), dim3(1), dim3(kBlock), 0, ctx->stream, (const Partial*)partials, n_cols,
+                                       is_signed ? 1 : 0, (double*)of, (uint64_t*)oi, (uint64_t*)oc, (double*)olo);
+            } else {
+                if (format_code == 'g')
+                    hipLaunchKernelGGL((column_fold_kernel<double>), dim3(1), dim3(kBlock), 0, ctx->stream, (const ColDesc*)nullptr, (int)n_cols,
+                                       n_cols, (const Partial*)partials, 1, (double*)of, (uint64_t*)oi, (uint64_t*)oc, 1);
+                else
+                    hipLaunchKernelGGL((column_fold_kernel<int64_t>), dim3(1), dim3(kBlock), 0, ctx->stream, (const ColDesc*)nullptr, (int)n_cols,
+                                       n_cols, (const Partial*)partials, is_signed ? 1 : 0, (double*)of, (uint64_t*)oi, (uint64_t*)oc, 1);
+            }
+            MA_HIP(hipGetLastError());
+            return end_call(ctx, scope);
+        }
     }
     // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
     bool all_short = n_cols >= 256;  // below that the table copy is a few microseconds and the segment form is as good

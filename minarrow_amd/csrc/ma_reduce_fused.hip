@@ -35,7 +35,7 @@ struct FusedCol {
     size_t last_word;       // index of the last word that holds a window bit
     uint64_t* out;          // integers: out[0] = sum, out[1] = valid count; f64: out[0], out[1] = (hi, lo), out[2] = valid count
     int is_float;
-    int pad;
+    int as_partial;         // internal callers (ma_sum_columns): `out` is a ma::Partial {a, b, count, 0} whatever the type
 };
 
 struct FusedArgs {
@@ -115,23 +115,8 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
         const uint64_t* __restrict__ data = (const uint64_t*)col.data;
         // this workgroup's first tile of the column: the smallest t >= 0 with (tile0 + t) mod G == b
         const size_t first = (size_t)((b + G - (unsigned)(col.tile0 % G)) % G);
-        for (size_t t = first; t < col.n_tiles; t += G) {
-            const size_t row0 = col.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
-            const V* __restrict__ p = (const V*)(data + row0) + lane;
-            V v[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                v[u] = load16<V, true>(p + (size_t)u * 64);
-                if (u + 1 < UNROLL) pace_loads<PACE>();
-            }
-            if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
-            uint64_t aw = ~(uint64_t)0;
-            if constexpr (ANY_MASKED) {
-                if (masked) {
-                    aw = load_run_words<WPT>(col.words, col.bit_off + row0, col.last_word, lane);
-                    if (lane < (unsigned)WPT) cnt[c] += (uint64_t)__popcll(aw);
-                }
-            }
+        // one tile's rows into the column's accumulators; `aw` = the run's validity words (bit j of word k = row 64 k + j)
+        auto consume = [&](const V (&v)[UNROLL], uint64_t aw) {
             if (is_float) {
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
@@ -149,6 +134,63 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[c][r].add_int(((bits >> r) & 1u) ? (uint64_t)v[u][r] : 0);
                 }
+            }
+        };
+        if constexpr (ANY_MASKED) {
+            // Validity work sits between a tile's loads and the next tile's: with four loads per lane and nothing requested
+            // ahead, the wave's bytes in flight drop to zero once per tile (two such columns of 125 M rows: 311 us against
+            // 2 x 144 for the single-column kernels). So the NEXT tile's rows and raw validity words are requested before
+            // this tile is consumed, the way ma_reduce_batch.hip's wave kernel does it and under the same rules (learnt
+            // there): a request is ALWAYS five loads — with nothing left to request every lane reads the first bytes of
+            // `partials` instead, and a dense column's "validity word" comes from there too — because loads issued on some
+            // paths only make the compiler's in-order wait counts assume the shortest queue; two register sets swap roles
+            // (a copy from "next" to "current" would wait for what it copies); the funnel shift of the words waits until
+            // they are wanted (finish_run_words).
+            const size_t n_mine = first < col.n_tiles ? (col.n_tiles - first + G - 1) / G : 0;  // this workgroup's tiles
+            auto issue = [&](size_t k, V (&v)[UNROLL], uint64_t& raw, size_t& row0) {
+                const bool real = k < n_mine;
+                row0 = col.head + (real ? first + k * G : 0) * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+                const V* __restrict__ p = real ? (const V*)(data + row0) + lane : (const V*)a.partials;
+                const size_t stride = real ? 64 : 0;
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, true>(p + (size_t)u * stride);
+                const bool m = real && masked;
+                // lane l <= WPT holds run word l (the last one only feeds the funnel shift); clamped, not skipped, past the
+                // window's last word — a full tile never needs a word behind it
+                size_t idx = ((col.bit_off + row0) >> 6) + (lane < (unsigned)WPT ? lane : (unsigned)WPT);
+                idx = idx < col.last_word ? idx : col.last_word;
+                raw = as_global(m ? col.words : (const uint64_t*)a.partials)[m ? idx : 0];
+            };
+            auto use = [&](const V (&v)[UNROLL], uint64_t raw, size_t row0) {
+                uint64_t aw = ~(uint64_t)0;
+                if (masked) {
+                    aw = finish_run_words(raw, col.bit_off + row0);
+                    if (lane < (unsigned)WPT) cnt[c] += (uint64_t)__popcll(aw);
+                }
+                consume(v, aw);
+            };
+            V va[UNROLL], vb[UNROLL];
+            uint64_t ra, rb;
+            size_t row_a, row_b;
+            issue(0, va, ra, row_a);
+            for (size_t k = 0; k < n_mine; k += 2) {
+                issue(k + 1, vb, rb, row_b);
+                use(va, ra, row_a);
+                issue(k + 2, va, ra, row_a);
+                if (k + 1 < n_mine) use(vb, rb, row_b);
+            }
+        } else {
+            for (size_t t = first; t < col.n_tiles; t += G) {
+                const size_t row0 = col.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+                const V* __restrict__ p = (const V*)(data + row0) + lane;
+                V v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    v[u] = load16<V, true>(p + (size_t)u * 64);
+                    if (u + 1 < UNROLL) pace_loads<PACE>();
+                }
+                if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
+                consume(v, ~(uint64_t)0);
             }
         }
         if (!masked && b == 0 && tid == 0) cnt[c] = col.n;  // dense: every row is valid; credited once
@@ -303,10 +345,15 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
             out[0] = (uint64_t)__double_as_longlong(d.hi);
             out[1] = (uint64_t)__double_as_longlong(d.lo);
             out[2] = n;
+        } else if (a.col[c].as_partial) {
+            out[0] = s.a;
+            out[1] = 0;
+            out[2] = n;
         } else {
             out[0] = s.a;
             out[1] = n;
         }
+        if (a.col[c].as_partial) out[3] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the results have left before the stamp below
         __builtin_amdgcn_wave_barrier();
         if (tid == 0) {
@@ -334,7 +381,8 @@ static void launch_fused(ma_ctx* ctx, const FusedArgs& a, int grid, int pace) {
 using namespace ma;
 
 namespace ma {
-ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
+ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
+                         bool as_partials = false);
 }
 
 extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols) {
@@ -348,7 +396,10 @@ extern "C" ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_f
     return sum_fused_impl(ctx, n_cols, cols, stamp, stamp_value);
 }
 
-ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value) {
+// as_partials: every column's `out` receives a 32-byte ma::Partial {sum or hi, 0 or lo, valid count, 0} — the input of
+// ma_reduce_batch.hip's folds — instead of the record words of the public entry points.
+ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
+                             bool as_partials) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(n_cols >= 1 && n_cols <= (size_t)kFusedMax && cols != nullptr, MA_ERR_INVALID_ARGUMENT,
                "ma_sum_fused takes 1..%d columns", kFusedMax);
@@ -374,6 +425,7 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
         col.data = in.data;
         col.n = in.n;
         col.is_float = in.format_code == 'g';
+        col.as_partial = as_partials ? 1 : 0;
         col.out = in.out;
         const bool masked = in.mask_bits != nullptr && in.null_count != 0 && in.n != 0;  // the all_true / null_count gate
         if (masked) {
@@ -397,7 +449,9 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
         total_tiles += col.n_tiles;
     }
     a.total_tiles = total_tiles;
-    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (any_masked ? 2 : 1);
+    // (with validity: the kernel keeps a tile requested ahead, so one workgroup per CU is enough for long columns — i64 + f64
+    // sharing a bitmap, 125 M rows each: 302.5 us at one, 306 at two, 314 at three; short jobs keep two)
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (any_masked ? (total_tiles > (size_t)24 * (size_t)ctx->num_cus ? 1 : 2) : 1);
     if (!any_masked && ctx->blocks_per_cu <= 0 && total_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
     int grid = grid_for(ctx, total_tiles, bpc);
     if ((size_t)grid * n_cols > (size_t)kMaxGrid) grid = (int)((size_t)kMaxGrid / n_cols);

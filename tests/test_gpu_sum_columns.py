@@ -312,3 +312,85 @@ def test_segment_form_finds_its_column_among_thousands(ctx):
     np.testing.assert_array_equal(i64, np.array([int(c.sum()) for c in cols], dtype=np.int64))
     tf, ti, tc = ctx.sum_chunks("l", ptrs, lens)
     assert tc == sum(lens) and int(ti) == int(arena.sum())
+
+
+@pytest.mark.parametrize("fmt", ["l", "L", "g"])
+@pytest.mark.parametrize("n_cols", [1, 4, 5, 9])
+def test_few_long_columns_take_the_fused_scan(ctx, fmt, n_cols):
+    """Up to 16 device-resident DENSE 8-byte columns of >= 2^21 rows each: ma_sum_columns / ma_sum_chunks run the fused scan
+    of ma_reduce_fused.hip, four columns per launch, and fold its per-column partials (with validity the segment path is the
+    faster one and stays). Results must be what the general path (ctx variant 16384) gives: integers bit-exact, floats
+    within 1 ULP of the exactly rounded sum; columns start on odd 8-byte offsets (a one-row head), ragged lengths; the same
+    list with validity at odd bit offsets on two thirds of the columns goes down the general path and must agree too."""
+    rng = np.random.default_rng(ord(fmt) * 31 + n_cols)
+    lens = [(1 << 21) + [5, 4097, 0, 70_001, 123, 8191, 1, 300_000, 64][i] for i in range(n_cols)]
+    cols = make_columns(rng, fmt, lens)
+    d_cols = [ctx.to_device(np.concatenate([np.zeros(1, c.dtype), c]), 64) for c in cols]
+    ptrs = [d.ptr + 8 for d in d_cols]
+    masks, offs, d_masks = [], [], []
+    for i, n in enumerate(lens):
+        if i % 3 == 0:
+            masks.append(None); offs.append(0); d_masks.append(None)
+        else:
+            off = [0, 3, 64, 77][i % 4]
+            m = rng.integers(0, 256, size=(off + n) // 8 + 16, dtype=np.uint8)
+            masks.append(m); offs.append(off); d_masks.append(ctx.to_device(m, 16))
+    valid = [np.unpackbits(m, bitorder="little")[o:o + n].astype(bool) if m is not None else np.ones(n, dtype=bool)
+             for m, o, n in zip(masks, offs, lens)]
+
+    def check(f, i64, cnt):
+        for k in range(n_cols):
+            assert cnt[k] == valid[k].sum(), k
+            sel = cols[k][valid[k]]
+            if fmt == "g":
+                exact = math.fsum(sel.tolist())
+                assert abs(f[k] - exact) <= math.ulp(exact), k
+            else:
+                assert (int(i64[k]) - int(sel.astype(object).sum())) % (1 << 64) == 0, k
+
+    got = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+    check(*got)
+    ctx.set_variant(16384)  # the general path: a workgroup per 65 536-row segment
+    try:
+        ref = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+        ref_total = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+    finally:
+        ctx.set_variant(0)
+    check(*ref)
+    np.testing.assert_array_equal(got[2], ref[2])
+    if fmt != "g":
+        np.testing.assert_array_equal(got[1], ref[1])
+        np.testing.assert_array_equal(got[0], ref[0])  # the f64 view of an integer sum
+    # the same list as ONE column
+    f, i64, cnt = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+    assert cnt == sum(int(v.sum()) for v in valid) == ref_total[2]
+    if fmt == "g":
+        exact = math.fsum(np.concatenate([c[v] for c, v in zip(cols, valid)]).tolist())
+        assert abs(f - exact) <= math.ulp(exact) and abs(ref_total[0] - exact) <= math.ulp(exact)
+    else:
+        assert i64 == ref_total[1] and f == ref_total[0]
+    # dense, no mask table at all: the fused scan — per column and as ONE column, against the general path too
+    f2, i2, c2 = ctx.sum_columns(fmt, ptrs, lens)
+    t2 = ctx.sum_chunks(fmt, ptrs, lens)
+    ctx.set_variant(16384)
+    try:
+        g2 = ctx.sum_columns(fmt, ptrs, lens)
+        gt = ctx.sum_chunks(fmt, ptrs, lens)
+    finally:
+        ctx.set_variant(0)
+    np.testing.assert_array_equal(c2, np.array(lens, dtype=np.uint64))
+    np.testing.assert_array_equal(c2, g2[2])
+    assert t2[2] == gt[2] == sum(lens)
+    for k in range(n_cols):
+        if fmt == "g":
+            exact = math.fsum(cols[k].tolist())
+            assert abs(f2[k] - exact) <= math.ulp(exact) and abs(g2[0][k] - exact) <= math.ulp(exact)
+        else:
+            assert (int(i2[k]) - int(cols[k].astype(object).sum())) % (1 << 64) == 0
+            assert i2[k] == g2[1][k] and f2[k] == g2[0][k]
+    if fmt == "g":
+        exact = math.fsum(np.concatenate(cols).tolist())
+        assert abs(t2[0] - exact) <= math.ulp(exact) and abs(gt[0] - exact) <= math.ulp(exact)
+    else:
+        assert t2[1] == gt[1] and t2[0] == gt[0]
+        assert (int(t2[1]) - sum(int(c.astype(object).sum()) for c in cols)) % (1 << 64) == 0
