@@ -699,9 +699,8 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     if (elem == 8 && n_cols <= 16 && !(ctx->variant & 16384)) {
         bool few_long = true;
         for (size_t i = 0; i < n_cols && few_long; ++i) {
-            // dense columns only: with validity the fused scan reads at 6.4-6.7 TB/s where the segment path below reaches
-            // 6.9-7.0 (tools/ab_sum_columns.py)
-            few_long = col_lens[i] >= ((size_t)1 << 21) && pointer_kind(col_data[i]) == kDevice && !(col_masks && col_masks[i]);
+            few_long = col_lens[i] >= ((size_t)1 << 21) && pointer_kind(col_data[i]) == kDevice;
+            if (few_long && col_masks && col_masks[i]) few_long = pointer_kind(col_masks[i]) == kDevice;
         }
         if (few_long) {
             void *of = nullptr, *oi = nullptr, *oc = nullptr, *olo = nullptr;
@@ -722,8 +721,8 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
                         const size_t i = c0 + j;
                         fc[j].data = col_data[i];
                         fc[j].n = col_lens[i];
-                        fc[j].mask_bits = nullptr;
-                        fc[j].mask_bit_offset = 0;
+                        fc[j].mask_bits = col_masks ? col_masks[i] : nullptr;
+                        fc[j].mask_bit_offset = col_mask_offsets ? col_mask_offsets[i] : 0;
                         fc[j].null_count = -1;
                         fc[j].format_code = format_code;
                         fc[j].out = (uint64_t*)&partials[i];

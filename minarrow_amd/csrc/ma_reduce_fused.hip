@@ -17,6 +17,8 @@
 // bit-reproducible for a fixed launch shape —, valid count = popcount of the window's validity bits (or n when dense).
 #include <limits>
 
+#include <type_traits>
+
 #include "ma_acc.hpp"
 #include "ma_device.hpp"
 
@@ -161,23 +163,47 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
                 idx = idx < col.last_word ? idx : col.last_word;
                 raw = as_global(m ? col.words : (const uint64_t*)a.partials)[m ? idx : 0];
             };
-            auto use = [&](const V (&v)[UNROLL], uint64_t raw, size_t row0) {
-                uint64_t aw = ~(uint64_t)0;
-                if (masked) {
-                    aw = finish_run_words(raw, col.bit_off + row0);
-                    if (lane < (unsigned)WPT) cnt[c] += (uint64_t)__popcll(aw);
+            // the loop once per (kind, validity) — both are uniform over the column, and left inside the loop they cost a
+            // dozen scalar branches per tile
+            auto run = [&](auto float_c, auto masked_c) {
+                constexpr bool F = decltype(float_c)::value, M = decltype(masked_c)::value;
+                auto use = [&](const V (&v)[UNROLL], uint64_t raw, size_t row0) {
+                    uint64_t aw = ~(uint64_t)0;
+                    if constexpr (M) {
+                        aw = finish_run_words(raw, col.bit_off + row0);
+                        if (lane < (unsigned)WPT) cnt[c] += (uint64_t)__popcll(aw);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const unsigned bits = M ? lane_bits<R>(aw, u, lane) : 3u;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if constexpr (F) {
+                                const double x = __longlong_as_double((long long)v[u][r]);
+                                acc[c][r].add_f64(((bits >> r) & 1u) ? x : 0.0);
+                            } else {
+                                acc[c][r].add_int(((bits >> r) & 1u) ? (uint64_t)v[u][r] : 0);
+                            }
+                        }
+                    }
+                };
+                V va[UNROLL], vb[UNROLL];
+                uint64_t ra, rb;
+                size_t row_a, row_b;
+                issue(0, va, ra, row_a);
+                for (size_t k = 0; k < n_mine; k += 2) {
+                    issue(k + 1, vb, rb, row_b);
+                    use(va, ra, row_a);
+                    issue(k + 2, va, ra, row_a);
+                    if (k + 1 < n_mine) use(vb, rb, row_b);
                 }
-                consume(v, aw);
             };
-            V va[UNROLL], vb[UNROLL];
-            uint64_t ra, rb;
-            size_t row_a, row_b;
-            issue(0, va, ra, row_a);
-            for (size_t k = 0; k < n_mine; k += 2) {
-                issue(k + 1, vb, rb, row_b);
-                use(va, ra, row_a);
-                issue(k + 2, va, ra, row_a);
-                if (k + 1 < n_mine) use(vb, rb, row_b);
+            if (is_float) {
+                if (masked) run(std::true_type{}, std::true_type{});
+                else run(std::true_type{}, std::false_type{});
+            } else {
+                if (masked) run(std::false_type{}, std::true_type{});
+                else run(std::false_type{}, std::false_type{});
             }
         } else {
             for (size_t t = first; t < col.n_tiles; t += G) {

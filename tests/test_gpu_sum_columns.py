@@ -317,11 +317,11 @@ def test_segment_form_finds_its_column_among_thousands(ctx):
 @pytest.mark.parametrize("fmt", ["l", "L", "g"])
 @pytest.mark.parametrize("n_cols", [1, 4, 5, 9])
 def test_few_long_columns_take_the_fused_scan(ctx, fmt, n_cols):
-    """Up to 16 device-resident DENSE 8-byte columns of >= 2^21 rows each: ma_sum_columns / ma_sum_chunks run the fused scan
-    of ma_reduce_fused.hip, four columns per launch, and fold its per-column partials (with validity the segment path is the
-    faster one and stays). Results must be what the general path (ctx variant 16384) gives: integers bit-exact, floats
-    within 1 ULP of the exactly rounded sum; columns start on odd 8-byte offsets (a one-row head), ragged lengths; the same
-    list with validity at odd bit offsets on two thirds of the columns goes down the general path and must agree too."""
+    """Up to 16 device-resident 8-byte columns of >= 2^21 rows each: ma_sum_columns / ma_sum_chunks run the fused scan of
+    ma_reduce_fused.hip, four columns per launch (dense or with validity: a tile requested ahead), and fold its per-column
+    partials. Results must be what the general path (ctx variant 16384) gives: integers bit-exact, floats within 1 ULP of
+    the exactly rounded sum; columns start on odd 8-byte offsets (a one-row head), validity at odd bit offsets on two thirds
+    of them, ragged lengths; then the same list dense."""
     rng = np.random.default_rng(ord(fmt) * 31 + n_cols)
     lens = [(1 << 21) + [5, 4097, 0, 70_001, 123, 8191, 1, 300_000, 64][i] for i in range(n_cols)]
     cols = make_columns(rng, fmt, lens)
