@@ -121,21 +121,32 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         }
     }
     // ---- full tiles: 16-byte loads, no bounds checks --------------------------------------------
-    for (size_t t = blockIdx.x; t < ((!MASKED && IL) ? 0 : a.n_tiles); t += gridDim.x) {
-        const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
-        const V* __restrict__ p = (const V*)(data + row0) + lane;
-        V v[UNROLL];
+    if constexpr (MASKED) {
+        // With validity a tile is few loads per lane and the validity work sits between one tile's loads and the next's: the
+        // wave's bytes in flight drop to zero once per tile, which the second wave per SIMD only partly covers (i8 / u8 with
+        // nulls 6.7 TB/s, f32 and i16 7.0, against 7.2-7.3 dense). So the NEXT tile's rows and raw validity words are
+        // requested before this tile is consumed — the scheme of ma_reduce_batch.hip's wave kernel and of the fused scan, and
+        // their rules: a request is ALWAYS UNROLL + 1 loads (with nothing left to request every lane reads the first bytes of
+        // `partials` instead), because loads issued on some paths only make the compiler's in-order wait counts assume the
+        // shortest queue; two register sets swap roles (a copy would wait for what it copies); the funnel shift of the words
+        // waits until they are wanted (finish_run_words).
+        const size_t G = gridDim.x, first = blockIdx.x;
+        const size_t n_mine = first < a.n_tiles ? (a.n_tiles - first + G - 1) / G : 0;  // this workgroup's tiles
+        auto issue = [&](size_t k, V (&v)[UNROLL], uint64_t& raw, size_t& row0) {
+            const bool real = k < n_mine;
+            row0 = a.head + (real ? first + k * G : 0) * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = real ? (const V*)(data + row0) + lane : (const V*)a.partials;
+            const size_t stride = real ? 64 : 0;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            v[u] = load16<V, NT>(p + (size_t)u * 64);
-            if (u + 1 < UNROLL) pace_loads<PACE>();
-        }
-        // the paced loads are all issued before anything is consumed (the asm statements split the scheduling region,
-        // and the scheduler would otherwise start on v[0] after three loads)
-        if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
-
-        if constexpr (MASKED) {
-            const uint64_t aw = load_run_words<WPT>(a.words, a.bit_off + row0, a.last_word, lane);
+            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(p + (size_t)u * stride);
+            // lane l <= WPT holds run word l (the last one only feeds the funnel shift); clamped, not skipped, past the
+            // window's last word — a full tile never needs a word behind it
+            size_t idx = ((a.bit_off + row0) >> 6) + (lane < (unsigned)WPT ? lane : (unsigned)WPT);
+            idx = idx < a.last_word ? idx : a.last_word;
+            raw = as_global(real ? a.words : (const uint64_t*)a.partials)[real ? idx : 0];
+        };
+        auto use = [&](const V (&v)[UNROLL], uint64_t raw, size_t row0) {
+            const uint64_t aw = finish_run_words(raw, a.bit_off + row0);
             if (lane < (unsigned)WPT) cnt += (uint64_t)__popcll(aw);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
@@ -150,15 +161,37 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
                     }
                 }
             }
-        } else {
+        };
+        V va[UNROLL], vb[UNROLL];
+        uint64_t ra, rb;
+        size_t row_a, row_b;
+        issue(0, va, ra, row_a);
+        for (size_t k = 0; k < n_mine; k += 2) {
+            issue(k + 1, vb, rb, row_b);
+            use(va, ra, row_a);
+            issue(k + 2, va, ra, row_a);
+            if (k + 1 < n_mine) use(vb, rb, row_b);
+        }
+    }
+    for (size_t t = blockIdx.x; t < ((MASKED || IL) ? 0 : a.n_tiles); t += gridDim.x) {
+        const size_t row0 = a.head + t * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+        const V* __restrict__ p = (const V*)(data + row0) + lane;
+        V v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if constexpr (kNarrow) {
-                    acc[0].add(narrow_vec_sum<T>(v[u], ~0u));
-                } else {
+        for (int u = 0; u < UNROLL; ++u) {
+            v[u] = load16<V, NT>(p + (size_t)u * 64);
+            if (u + 1 < UNROLL) pace_loads<PACE>();
+        }
+        // the paced loads are all issued before anything is consumed (the asm statements split the scheduling region,
+        // and the scheduler would otherwise start on v[0] after three loads)
+        if constexpr (PACE > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
-                }
+        for (int u = 0; u < UNROLL; ++u) {
+            if constexpr (kNarrow) {
+                acc[0].add(narrow_vec_sum<T>(v[u], ~0u));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r].add((T)v[u][r]);
             }
         }
     }
@@ -371,14 +404,17 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         case 4: unroll = (R * 16 < 64 && !masked) ? 16 : 8; break;
         default: break;
     }
-    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean ? 1 : 2);
+    // (with validity the kernel keeps a tile requested ahead — ONE wave per SIMD then carries two tiles in flight, and a
+    // second workgroup per CU only queues: i64 / i32 / i16 with 10 % nulls 7.29 / 7.25 / 7.15 TB/s at one per CU, 6.7 / 6.7 /
+    // 6.5 at two, tools/sweep_masked_sum.py; short columns keep two for their ramp; dense f32 keeps its two)
+    int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (lean || masked ? 1 : 2);
     if constexpr (R >= 8) {
         // narrow types, masked: a wave's validity run must fit one word per lane (R x unroll < 64): 4 loads of 8 rows, 2
         // loads of 16 rows; the bytes in flight per SIMD then come from more waves (2 / 3 workgroups per CU). Dense scans
         // have no such limit and take the 8-deep shape of the wider integers.
         if (masked) {
             unroll = R == 8 ? 4 : 2;
-            if (ctx->blocks_per_cu <= 0) bpc = R == 8 ? 2 : 3;  // swept: tools/sweep_narrow_sum.py (i8 masked: 3 -> 0.79, 4 -> 0.72)
+            if (ctx->blocks_per_cu <= 0) bpc = R == 8 ? 1 : 3;  // swept: tools/sweep_masked_sum.py (i8 with nulls: 1 -> 5.3 TB/s, 2 -> 6.1, 3 -> 6.85, 4 -> 5.8)
         } else if (unroll != 2 && unroll != 4) {
             unroll = 8;
         }
@@ -414,6 +450,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // half empty during the ramp and the tail of so short a scan; three per CU are 3-6 % faster there, and lose 3 %
     // from 2^26 rows on (profiles/r02_sweep_mid.jsonl).
     if (lean && R < 8 && ctx->blocks_per_cu <= 0 && a.n_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 3;
+    if (masked && R < 16 && ctx->blocks_per_cu <= 0 && a.n_tiles <= (size_t)24 * (size_t)ctx->num_cus) bpc = 2;
     size_t work = a.n_tiles;
     if (a.interleave) {
         a.n_tiles = (n - head) / ((size_t)64 * R);  // 1-KiB pieces
