@@ -185,22 +185,23 @@ __global__ __launch_bounds__(kBlock) void bit_words_kernel(BitArgs a) {
     }
 }
 
-// Scalar facts about one or two windows, accumulated into 4 device words:
-//   acc[0] += popcount(x)            acc[1] |= any bit set in x
-//   acc[2] |= any bit clear in x     acc[3] |= any bit where x != y
-// Epilogue (round 2): a workgroup adds its four words to the accumulator with agent-scope atomics, waits until they have
-// been performed, and takes a ticket; the workgroup whose ticket is the last reads the totals (sc1 loads), writes them to
-// the PINNED host slot, zeroes accumulator and ticket for the next launch and stamps the completion word the host polls
-// — no memset before, no copy after, no hipStreamSynchronize wake-up on the small-bitmap path (null counts).
+// Scalar facts about one or two windows, four words per workgroup:
+//   [0] = popcount(x)                [1] = any bit set in x
+//   [2] = any bit clear in x         [3] = any bit where x != y
+// Epilogue: the workgroup publishes its four words as one partial and takes a ticket (below); the workgroup whose arrival is
+// the last folds all partials, writes the totals to the PINNED host slot, re-arms the ticket and stamps the completion word
+// the host polls — no memset before, no copy after, no hipStreamSynchronize wake-up on the small-bitmap path (null counts).
+// the context's arrival counters, laid out as ma_reduce.hip uses them (kernels of one context are stream-ordered)
+constexpr unsigned kScanTicketShards = 8, kScanShardWord0 = 64, kScanShardStride = 16, kScanShardFrom = 96;
 struct ScanOut {
-    unsigned long long* acc;    // device: 4 totals + the ticket word behind them
+    Partial* partials;          // device: one 32-byte partial per workgroup (the context's)
+    unsigned int* ticket;       // device: the context's ticket word (+ shard counters), zero between launches
     unsigned long long* host;   // pinned: where the four totals go
     uint64_t* done_word;        // pinned: stamped with done_seq after the totals
     uint64_t done_seq;
 };
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so) {
-    unsigned long long* acc = so.acc;
     const size_t n_words = (a.n + 63) >> 6;
     const size_t stride = (size_t)gridDim.x * kBlock;
     unsigned long long pop = 0, any_set = 0, any_clear = 0, any_diff = 0;
@@ -256,16 +257,78 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so)
         any_clear |= __shfl_down(any_clear, off, 64);
         any_diff |= __shfl_down(any_diff, off, 64);
     }
+    // ---- the sum kernels' hand-off (ma_reduce.hip): one 32-byte partial per workgroup, published with write-through stores
+    // and drained, arrival on sharded tickets, the last workgroup folds every partial. Rounds 1-3 had every workgroup add its
+    // four words to four global words with atomics: 512 workgroups x 4 atomics on one cache line serialise at ~21 ns each — a
+    // 40-us tail on a 0.6-ms scan (popcount of a 4-GiB bitmap 6.78 -> 7.2 TB/s).
     __shared__ unsigned long long part[kWaves][4];
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long* q = part[threadIdx.x >> 6];
+    __shared__ int is_last;
+    const unsigned tid = threadIdx.x, G = gridDim.x, b = blockIdx.x;
+    if ((tid & 63) == 0) {
+        unsigned long long* q = part[tid >> 6];
         q[0] = pop;
         q[1] = any_set;
         q[2] = any_clear;
         q[3] = any_diff;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (tid == 0) {
+        pop = any_set = any_clear = any_diff = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            pop += part[w][0];
+            any_set |= part[w][1];
+            any_clear |= part[w][2];
+            any_diff |= part[w][3];
+        }
+        uint64_t* q = (uint64_t*)&so.partials[b];
+        store_agent(q, (uint64_t)pop);
+        store_agent(q + 1, (uint64_t)any_set);
+        store_agent(q + 2, (uint64_t)any_clear);
+        store_agent(q + 3, (uint64_t)any_diff);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed, not merely issued, before this workgroup arrives
+        int last;
+        if (G <= kScanShardFrom) {
+            last = __hip_atomic_fetch_add(so.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+        } else {  // workgroups b and b + 8 share an XCD: a shard's arrivals stay on one L2; its last arrival goes to the top
+            const unsigned sh = b & (kScanTicketShards - 1);
+            const unsigned members = (G - sh + kScanTicketShards - 1) / kScanTicketShards;
+            unsigned int* shard = so.ticket + kScanShardWord0 + sh * kScanShardStride;
+            last = 0;
+            if (__hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = __hip_atomic_fetch_add(so.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kScanTicketShards - 1;
+            }
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    pop = any_set = any_clear = any_diff = 0;
+    for (unsigned i = tid; i < G; i += kBlock) {  // independent loads: one round trip
+        const uint64_t* q = (const uint64_t*)&so.partials[i];
+        pop += load_agent(q);
+        any_set |= load_agent(q + 1);
+        any_clear |= load_agent(q + 2);
+        any_diff |= load_agent(q + 3);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pop += __shfl_down(pop, off, 64);
+        any_set |= __shfl_down(any_set, off, 64);
+        any_clear |= __shfl_down(any_clear, off, 64);
+        any_diff |= __shfl_down(any_diff, off, 64);
+    }
+    __syncthreads();  // part[][] is reused
+    if ((tid & 63) == 0) {
+        unsigned long long* q = part[tid >> 6];
+        q[0] = pop;
+        q[1] = any_set;
+        q[2] = any_clear;
+        q[3] = any_diff;
+    }
+    __syncthreads();
+    if (tid != 0) return;
     pop = any_set = any_clear = any_diff = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
@@ -274,22 +337,11 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so)
         any_clear |= part[w][2];
         any_diff |= part[w][3];
     }
-    if (pop) __hip_atomic_fetch_add(&acc[0], pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (any_set) __hip_atomic_fetch_or(&acc[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (any_clear) __hip_atomic_fetch_or(&acc[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (any_diff) __hip_atomic_fetch_or(&acc[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed, not merely issued, before this workgroup arrives
-    unsigned int* ticket = (unsigned int*)&acc[4];
-    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-    const uint64_t t0 = load_agent((const uint64_t*)&acc[0]), t1 = load_agent((const uint64_t*)&acc[1]);
-    const uint64_t t2 = load_agent((const uint64_t*)&acc[2]), t3 = load_agent((const uint64_t*)&acc[3]);
-    so.host[0] = t0;
-    so.host[1] = t1;
-    so.host[2] = t2;
-    so.host[3] = t3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store_agent((uint64_t*)&acc[i], 0);
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    so.host[0] = pop;
+    so.host[1] = any_set ? 1 : 0;
+    so.host[2] = any_clear ? 1 : 0;
+    so.host[3] = any_diff ? 1 : 0;
+    __hip_atomic_store(so.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this stream
     __hip_atomic_store(so.done_word, so.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -341,12 +393,14 @@ __device__ __forceinline__ unsigned eq_bits(const V16& x, T field_mask, T target
 // profiles/r03_sweep_eq_mask.jsonl). With the stores compiled out it reads at 6.8-7.5 TB/s like the sums; ANY form of the
 // stores costs 12-20 % of that (the few writes interleave with the read stream in HBM), the round-2 form — eight-byte
 // stores from the 2 .. 16 lanes that hold a finished word, one store instruction per 1-KiB step, 4 loads per lane, 8
-// workgroups per CU — cost 25-35 %: u8 4.88, u16 5.17, u32 5.62, u64 5.75 TB/s. Now (u8 5.65, u16 5.78, u32 5.88, u64 6.16):
+// workgroups per CU — cost 25-35 %: u8 4.88, u16 5.17, u32 5.62, u64 5.75 TB/s; round 3: u8 5.65, u16 5.78, u32 5.88, u64 6.16.
+// Now (u8 6.31, u16 6.62, u32 6.83, u64 6.95; profiles/r04_sweep_eq_mask.jsonl):
 //   * eight 16-byte loads in flight per lane and one or two workgroups per CU, the shape of the sums;
 //   * a wave collects the bits of its eight steps in its own 64 R bytes of LDS — lane l's R bits of step u ARE bits
 //     [(64 u + l) R, +R) of the wave's output, so no butterfly over the lanes is needed — and writes them back as ONE
 //     non-temporal store of 16 bytes per lane, contiguous;
-//   * that store is issued one trip late, behind the next trip's loads (see the loop).
+//   * that store is issued late, behind a later tile's loads (see the loop);
+//   * (round 4) the next tile's rows are requested before this tile's are compared, on ONE workgroup per CU.
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict__ data, size_t n_tiles, T field_mask,
                                                              T target, uint64_t* __restrict__ out) {
@@ -363,24 +417,29 @@ __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict
     __shared__ __attribute__((aligned(16))) uint8_t staged[2][kWaves][WAVE_BYTES];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const V* __restrict__ vp = (const V*)data;
-    // One trip behind: the words of trip k are stored AFTER the loads of trip k + 1 have been issued. vmcnt counts loads
-    // and stores in issue order, so a store issued in front of a trip's loads has to be acknowledged before the first of
-    // them can be consumed; issued behind them it is never waited for.
-    int par = 0;
-    bool pending = false;
-    size_t pending_step0 = 0;
+    // The words of tile k are stored AFTER the loads of a later tile have been issued: vmcnt counts loads and stores in issue
+    // order, so a store issued in front of a tile's loads has to be acknowledged before the first of them can be consumed;
+    // issued behind them it is never waited for. And the NEXT tile's rows are requested before this tile's are compared
+    // (round 4; the masked sums' scheme, ma_reduce.hip): a request is always UNROLL loads — this workgroup's first tile once
+    // more when nothing is left, so that the compiler's in-order wait counts see one queue length on every path — into two
+    // register sets that swap roles.
     auto flush = [&](int which, size_t at_step0) {
         if (lane < (unsigned)(WAVE_BYTES / 16)) {
             const u2 v = *(const u2*)(staged[which][wave] + lane * 16);
             __builtin_nontemporal_store(v, (u2a8*)((uint8_t*)out + at_step0 * STEP_BYTES + (size_t)lane * 16));  // `out` is 8-byte aligned
         }
     };
-    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const size_t step0 = (t * kWaves + wave) * UNROLL;  // index of this wave's first 1-KiB step
-        VL x[UNROLL];
+    const size_t G = gridDim.x, first = blockIdx.x;
+    const size_t n_mine = first < n_tiles ? (n_tiles - first + G - 1) / G : 0;  // this workgroup's tiles
+    if (n_mine == 0) return;
+    auto issue = [&](size_t k, VL (&x)[UNROLL], size_t& step0) {
+        const bool real = k < n_mine;
+        step0 = ((first + (real ? k * G : 0)) * kWaves + wave) * UNROLL;  // index of this wave's first 1-KiB step
+        const size_t stride = real ? 64 : 0;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) x[u] = load16<VL, true>((const VL*)vp + (step0 + u) * 64 + lane);
-        if (pending) flush(par ^ 1, pending_step0);
+        for (int u = 0; u < UNROLL; ++u) x[u] = load16<VL, true>((const VL*)vp + step0 * 64 + (size_t)u * stride + lane);
+    };
+    auto use = [&](const VL (&x)[UNROLL], int par) {
         uint8_t* mine = staged[par][wave];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -399,15 +458,25 @@ __global__ __launch_bounds__(kBlock) void eq_mask_vec_kernel(const T* __restrict
             }
         }
         // the wave reads back what ITS lanes wrote: LDS operations of one wave complete in order, the fences keep the
-        // compiler from moving the LDS loads of the flush above these stores (two buffers: the next trip writes the other)
+        // compiler from moving the LDS loads of the flush above these stores (two buffers: the next tile writes the other)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        pending = true;
-        pending_step0 = step0;
-        par ^= 1;
+    };
+    VL xa[UNROLL], xb[UNROLL];
+    size_t step_a = 0, step_b = 0;
+    issue(0, xa, step_a);
+    for (size_t k = 0; k < n_mine; k += 2) {
+        const size_t done_b = step_b;   // tile k - 1 sits in staged[1]
+        issue(k + 1, xb, step_b);
+        if (k > 0) flush(1, done_b);
+        use(xa, 0);                     // tile k
+        const size_t done_a = step_a;
+        issue(k + 2, xa, step_a);
+        flush(0, done_a);
+        if (k + 1 < n_mine) use(xb, 1);  // tile k + 1
     }
-    if (pending) flush(par ^ 1, pending_step0);
+    if ((n_mine & 1) == 0) flush(1, step_b);
 }
 
 template <typename T>
@@ -440,7 +509,7 @@ template <typename T>
 static void launch_eq_mask(ma_ctx* ctx, const T* d, size_t n, T field_mask, T target, uint64_t* ow) {
     // variant bit 2048: 4 loads per lane on 8 workgroups per CU (round 2's shape) for A/B; blocks_per_cu overrides the grid
     const bool old_shape = (ctx->variant & 2048) != 0;
-    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (old_shape ? 8 : sizeof(T) <= 2 ? 1 : 2);
+    const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (old_shape ? 8 : 1);  // with a tile requested ahead: one, for every width
     size_t done = old_shape ? launch_eq_mask_vec<T, 4>(ctx, d, n, field_mask, target, ow, bpc)
                             : launch_eq_mask_vec<T, 8>(ctx, d, n, field_mask, target, ow, bpc);
     if (done < n) {
@@ -478,7 +547,8 @@ static int vec_ok(const BitArgs& a, bool with_out) {
 static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out, bool staged) {
     MA_NO_CAPTURE(ctx, "a bitmap scan that returns its result to the host");
     ScanOut so;
-    so.acc = (unsigned long long*)(ctx->ticket + 32);  // 4 x u64 + the scan's ticket: byte 128 of the zeroed scratch block
+    so.partials = ctx->partials;
+    so.ticket = ctx->ticket;
     ResultSlot* slot = ctx->result;
     so.host = (unsigned long long*)&slot[3];  // one 32-byte slot
     volatile uint64_t* done = (volatile uint64_t*)&slot[2].b;
@@ -486,8 +556,11 @@ static ma_status scan_windows(ma_ctx* ctx, const BitArgs& a, BitScan* out, bool 
     so.done_seq = ++ctx->result_seq;
     const size_t n_words = (a.n + 63) >> 6;
     const int vec = vec_ok(a, false);
-    // vec: read-only stream like the sums (2 workgroups per CU, 8 x 16 bytes per lane in flight)
-    int grid = vec ? grid_for(ctx, n_words / 2 / ((size_t)kVecUnroll * kBlock) + 1, 2)
+    // vec: read-only stream like the sums (8 x 16 bytes per lane in flight)
+    // one window of 256 MiB or more: ONE workgroup per CU, the dense sums' shape (a 4-GiB popcount 601 us call to result against
+    // 626-636 at two; below that, and for two windows — sixteen loads per lane — two: tools/ab_bit_scan.py)
+    const int scan_bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : ((a.rw == nullptr && n_words >= ((size_t)1 << 25)) ? 1 : 2);
+    int grid = vec ? grid_for(ctx, n_words / 2 / ((size_t)kVecUnroll * kBlock) + 1, scan_bpc)
                    : grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
     if (vec) hipLaunchKernelGGL(bit_scan_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, so);
     else hipLaunchKernelGGL(bit_scan_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, so);
