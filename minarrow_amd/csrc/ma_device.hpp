@@ -288,9 +288,11 @@ __device__ __forceinline__ int64_t narrow_vec_sum(const V16& v, unsigned bits) {
         for (int k = 0; k < 4; ++k) {
             unsigned x = kSigned ? (d[k] ^ 0x80808080u) : d[k];
             const unsigned b = (bits >> (4 * k)) & 15u;
-            // 4 validity bits -> 4 byte masks: bit i lands on bit 8 i (no two partial products share a position)
-            const unsigned m = ((b * 0x00204081u) & 0x01010101u) * 0xFFu;
-            s = __builtin_amdgcn_sad_u8(x & m, 0u, s);
+            // 4 validity bits -> 4 bytes of 0 / 1: bit i lands on bit 8 i (no two partial products share a position); the
+            // valid bytes are then summed by ONE dot product with those bytes (v_dot4_u32_u8) — round 4; a second multiply
+            // to widen the bits into byte masks, an AND and v_sad_u8 before
+            const unsigned m01 = (b * 0x00204081u) & 0x01010101u;
+            s = __builtin_amdgcn_udot4(x, m01, s, false);
         }
         const int n_valid = __popc(bits & 0xFFFFu);
         return kSigned ? (int64_t)s - 128 * (int64_t)n_valid : (int64_t)s;

@@ -695,13 +695,20 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     // fused scan of ma_reduce_fused.hip, four columns per launch — the single-column sum's shape (paced loads, one
     // cross-workgroup hand-off per launch) instead of a workgroup per 64-Ki-row segment: 8 x 67 M rows 6.85 -> 7.03 TB/s, 8 x 125 M
     // rows 6.85 -> 7.15.
-    // Each launch leaves one Partial per column; the folds below are the general path's. variant bit 16384: general path (A/B).
+    // Each launch leaves one Partial per column; the folds below are the general path's. variant bit 16384: general path (A/B);
+    // bit 65536: the fused scan whatever the total size (tests of the multi-launch form at sizes a CPU check can follow).
     if (elem == 8 && n_cols <= 16 && !(ctx->variant & 16384)) {
         bool few_long = true;
+        size_t total_rows = 0;
         for (size_t i = 0; i < n_cols && few_long; ++i) {
             few_long = col_lens[i] >= ((size_t)1 << 21) && pointer_kind(col_data[i]) == kDevice;
             if (few_long && col_masks && col_masks[i]) few_long = pointer_kind(col_masks[i]) == kDevice;
+            total_rows += col_lens[i];
         }
+        // a fused launch costs ~4.5 us beyond its bytes and reads them 5 % faster than the two launches of the segment path
+        // (~6 us): one launch (<= 4 columns) always pays, more only from ~384 MiB per launch
+        const size_t launches = (n_cols + MA_FUSED_MAX_COLUMNS - 1) / MA_FUSED_MAX_COLUMNS;
+        if (launches > 1 && total_rows * 8 < launches * ((size_t)384 << 20) && !(ctx->variant & 65536)) few_long = false;  // bit 65536: tests
         if (few_long) {
             void *of = nullptr, *oi = nullptr, *oc = nullptr, *olo = nullptr;
             const size_t n_out = total ? 1 : n_cols;

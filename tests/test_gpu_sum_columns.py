@@ -348,7 +348,11 @@ def test_few_long_columns_take_the_fused_scan(ctx, fmt, n_cols):
             else:
                 assert (int(i64[k]) - int(sel.astype(object).sum())) % (1 << 64) == 0, k
 
-    got = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+    ctx.set_variant(65536)  # several launches' worth of columns take the fused scan from ~384 MiB per launch only: forced here
+    try:
+        got = ctx.sum_columns(fmt, ptrs, lens, d_masks, offs)
+    finally:
+        ctx.set_variant(0)
     check(*got)
     ctx.set_variant(16384)  # the general path: a workgroup per 65 536-row segment
     try:
@@ -362,16 +366,20 @@ def test_few_long_columns_take_the_fused_scan(ctx, fmt, n_cols):
         np.testing.assert_array_equal(got[1], ref[1])
         np.testing.assert_array_equal(got[0], ref[0])  # the f64 view of an integer sum
     # the same list as ONE column
-    f, i64, cnt = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+    ctx.set_variant(65536)
+    try:
+        f, i64, cnt = ctx.sum_chunks(fmt, ptrs, lens, d_masks, offs)
+        f2, i2, c2 = ctx.sum_columns(fmt, ptrs, lens)  # dense, no mask table at all: per column and as ONE column
+        t2 = ctx.sum_chunks(fmt, ptrs, lens)
+    finally:
+        ctx.set_variant(0)
     assert cnt == sum(int(v.sum()) for v in valid) == ref_total[2]
     if fmt == "g":
         exact = math.fsum(np.concatenate([c[v] for c, v in zip(cols, valid)]).tolist())
         assert abs(f - exact) <= math.ulp(exact) and abs(ref_total[0] - exact) <= math.ulp(exact)
     else:
         assert i64 == ref_total[1] and f == ref_total[0]
-    # dense, no mask table at all: the fused scan — per column and as ONE column, against the general path too
-    f2, i2, c2 = ctx.sum_columns(fmt, ptrs, lens)
-    t2 = ctx.sum_chunks(fmt, ptrs, lens)
+    # the dense results against the general path too
     ctx.set_variant(16384)
     try:
         g2 = ctx.sum_columns(fmt, ptrs, lens)
