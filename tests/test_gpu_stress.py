@@ -128,3 +128,40 @@ def test_sharded_ticket_handoff_under_uneven_load(oracle):
     assert not errors, errors[:5]
     assert sum(counts) > 2000 and len(oracle_checks) > 10, (counts, len(oracle_checks))
     print(f"{sum(counts)} reductions checked ({len(oracle_checks)} also against the oracle), 0 errors")
+
+
+def test_kernels_that_share_the_contexts_ticket_alternate(ctx, oracle):
+    """Sums, fused sums and bitmap scans all end with the same partial + ticket hand-off on the context's one set of arrival
+    counters (round 4: the scans joined). Interleaved on one stream in every order, small and large grids (one ticket / the
+    sharded form), each launch must find the counters re-armed by its predecessor: 400 rounds, every result checked."""
+    rng = np.random.default_rng(77)
+    n = 3_000_017
+    a = rng.integers(-(1 << 40), 1 << 40, size=n, dtype=np.int64)
+    f = rng.standard_normal(n)
+    bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
+    da, df, dm = ctx.to_device(a, 64), ctx.to_device(f, 64), ctx.to_device(bits, 16)
+    dm2 = ctx.to_device(bits, 16)
+    rec = ctx.alloc(256)
+    valid = np.unpackbits(bits, bitorder="little")
+    csum = np.concatenate([[0], np.cumsum(a, dtype=np.int64)])
+    cpop = np.concatenate([[0], np.cumsum(valid, dtype=np.int64)])
+    for it in range(400):
+        k = int(rng.integers(1, n))           # rows of this round: from one workgroup's worth to the whole column
+        if it % 5 == 0:
+            k = int(rng.integers(1, 5000))
+        order = rng.permutation(4)
+        for op in order:
+            if op == 0:
+                s, c = ctx.sum("i64", da, k)
+                assert (s, c) == (int(csum[k]), k)
+            elif op == 1:
+                assert ctx.popcount_mask(dm, 0, k) == int(cpop[k])
+            elif op == 2:
+                ctx.sum_fused([("l", da, k, rec.ptr), ("g", df, k, rec.ptr + 16)])
+                w = rec.download(np.uint64, 8)
+                assert int(w[0]) == int(csum[k]) & ((1 << 64) - 1) and int(w[1]) == k and int(w[4]) == k
+            else:
+                k8 = k & ~7  # all_eq addresses word-aligned windows
+                assert ctx.mask_all("all_eq", dm, 0, dm2, 0, max(k8, 64))
+                s, c = ctx.sum("i64", da, k, mask=dm)
+                assert c == int(cpop[k])
