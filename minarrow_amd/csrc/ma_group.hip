@@ -490,9 +490,8 @@ ma_status exchange_locked(ma_group* g) {
     auto xstream = [g](size_t i) { return g->overlap ? g->side[i]->stream : g->ctxs[i]->stream; };
     ma_status st = MA_OK;
     // One thread per device, each issuing its own rank's all-gather with no ncclGroup: the form RCCL documents for one thread
-    // per device, and the only one that scales — an ncclAllGather costs the issuing thread ~230 us of host time
-    // (profiles/r04_share_1gpu.txt: host_issue_us_per_step 237 with the RCCL exchange against 7 with the host fold), so eight of
-    // them from ONE thread would make a 0.28-ms step host-bound at ~2 ms. The price: if one member fails before its call
+    // per device; the members' launches and collectives are enqueued concurrently (8 members: 26 us per step instead of 53 from
+    // one thread, profiles/r03_group_issue.json). The price: if one member fails before its call
     // (hipSetDevice, the event record, the all-gather itself) the others have already enqueued theirs and those collectives
     // can never complete. That case is handled below instead of avoided: every communicator is aborted (ncclCommAbort ends the
     // kernels in flight) and the group is marked broken, so that the next synchronize returns an error instead of blocking.

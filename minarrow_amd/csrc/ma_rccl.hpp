@@ -53,8 +53,11 @@ struct ExchangeTimer {
     int begin(hipStream_t s) {
         if ((calls++ % kEvery) != 0) return -1;
         const int k = next;
+        if (pending[k]) {  // never WAIT here: a host that runs more than kRing samples ahead of its GPU would be throttled to the
+            harvest_slot(k, false);  // GPU's pace by its own instrumentation (it was, in round 4's first form: 240 us of "issue
+            if (pending[k]) return -1;  // time" per step that were this wait) — the sample is skipped instead
+        }
         next = (next + 1) % kRing;
-        if (pending[k]) harvest_slot(k, true);
         for (int j = 0; j < 3; ++j)
             if (!ev[k][j] && hipEventCreate(&ev[k][j]) != hipSuccess) {
                 (void)hipGetLastError();
