@@ -54,7 +54,12 @@ extern "C" {
  * exchange stream), ma_group_enqueue_sum_table, ma_group_exchange_stats, ma_comm_exchange_stats; ma_hip_runtime_path, ma_rccl_path; ma_dev_alloc_output searches only when asked to
  * (MINARROW_HIP_OUTPUT_SEARCH=1 / ma_dev_output_search).
  * A binding compares ma_abi_version() with the MA_ABI_VERSION it was generated from. */
-#define MA_ABI_VERSION 3
+/* 4 (round 5): + bounded waits and first-contact safety for the multi-GPU forms: ma_group_synchronize_for,
+ * ma_group_is_broken, ma_group_flags, ma_group_set_handoff / ma_group_handoff, ma_group_rebuild_exchange, ma_group_selftest
+ * (+ ma_selftest_report), ma_comm_synchronize_for, ma_comm_abort, ma_comm_is_broken, ma_comm_selftest, ma_stamp_is_signal;
+ * testing hooks ma_group_test_stall_next_exchange / _corrupt_next_exchange, ma_comm_test_stall_next_exchange /
+ * _corrupt_next_exchange. A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange. */
+#define MA_ABI_VERSION 4
 
 typedef struct ma_ctx ma_ctx;
 typedef int32_t ma_status;
@@ -388,6 +393,9 @@ ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column
  * the runtime refuses), zeroed: what a stream can be made to wait on. Free with ma_stamp_free. */
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);
 ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp);
+/* 1 when `stamp` (from ma_stamp_alloc) is the runtime's signal memory, 0 when it is a plain device word (the fall-back; a
+ * wait on it works the same), -1 when the pointer is not a live stamp. */
+int32_t ma_stamp_is_signal(const uint64_t* stamp);
 
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
  * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =
@@ -956,7 +964,7 @@ ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32
 /* TESTING ONLY. The next ma_group_exchange fails on `member` in front of its all-gather, as a lost device would make it: with
  * per-member issue threads the other members have enqueued their collectives by then, so the group aborts every
  * communicator (ncclCommAbort), marks itself broken — ma_group_exchange / ma_group_synchronize return MA_ERR_DEVICE from
- * then on instead of blocking on a collective that cannot complete — and can only be destroyed. */
+ * then on instead of blocking on a collective that cannot complete — until ma_group_rebuild_exchange or its destruction. */
 ma_status ma_group_test_fail_next_exchange(ma_group* group, int32_t member);
 ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
@@ -984,6 +992,82 @@ ma_status ma_group_exchange_stats(ma_group* group, double* out_all_gather_us, do
                                   int32_t* out_rccl_ranks);
 ma_status ma_group_exchange(ma_group* group);
 ma_status ma_group_synchronize(ma_group* group);
+
+/* ---- first contact with a multi-GPU node: bounded waits, a way down, a self-test -----------------------------------------
+ * The reference's parallel reduction is a plain `main` over a Rayon pool (benches/benchmark_parallel_simd.rs:81-125): a
+ * worker that fails ends the process with a message. A collective whose peer never arrives does not fail — the host blocks
+ * in ma_group_synchronize for good. A host that must not (a service, a benchmark under somebody else's clock) uses:
+ *
+ * ma_group_synchronize_for  ma_group_synchronize with a deadline in milliseconds (<= 0: none). It polls the members'
+ *     streams; when they have run empty it behaves exactly like ma_group_synchronize. Past the deadline it releases every
+ *     value a stream of the group may be held behind, aborts every communicator (ncclCommAbort: the collective kernels in
+ *     flight end), waits a bounded time for the streams to run empty, marks the group BROKEN and returns MA_ERR_DEVICE;
+ *     ma_last_error_string() names the members and phases that were still pending ("member 3 (device 3): exchange stream
+ *     (all-gather or fold in flight)"). A broken group refuses ma_group_exchange / _synchronize / _selftest with
+ *     MA_ERR_DEVICE instead of blocking; its member contexts, and every column allocated from them, stay usable.
+ * ma_group_is_broken        0 = healthy, 1 = broken and its streams have run empty (ma_group_rebuild_exchange will work),
+ *     2 = broken and some stream is STILL busy (a kernel that does not end: the device may need a reset; the group can only
+ *     be destroyed, which then leaks what it holds rather than wait).
+ * ma_group_rebuild_exchange a fresh exchange for the same members, as ma_group_create_ex(flags) would set one up: other
+ *     flags = one notch down (overlapped -> in-stream, issue threads -> MA_GROUP_ISSUE_CALLER's grouped calls, RCCL -> the
+ *     host fold). Works on a healthy group too (drains it first). Results of earlier exchanges are gone.
+ * ma_group_flags            the MA_GROUP_* flags that describe the exchange and issue form now in effect (after fall-backs).
+ * ma_group_set_handoff      overlapped exchanges only: how a member's exchange stream learns that the step's records are
+ *     complete. MA_GROUP_HANDOFF_STAMP (default): the fused scan's final thread stores a sequence number the exchange stream
+ *     waits on (hipStreamWaitValue64), nothing but scans on the scan stream; steps not enqueued by ma_group_enqueue_sum_table
+ *     use the event by themselves. MA_GROUP_HANDOFF_EVENT: always an event recorded on the scan stream (one more notch down
+ *     that needs no rebuild). ma_group_handoff: which one a stamped step would get now (-1: the group does not overlap).
+ * ma_group_selftest         proves the group's machinery with tagged data before a host trusts it with a job, every step under
+ *     `timeout_ms` (> 0): (MA_SELFTEST_EXCHANGE) rank-tagged 64-byte records through ma_group_exchange in the group's own
+ *     hand-off and issue form — with MA_SELFTEST_EXCHANGE_ALL_FORMS in every form the group can run (stamp / event hand-off x
+ *     issue threads / calling thread) — checking on EVERY member that the gathered blocks are the members' records in rank
+ *     order and that the finals are the member-ordered fold; (MA_SELFTEST_STAMPS) on every member a stamp stored by a kernel
+ *     on its scan stream and waited on by its exchange stream; (MA_SELFTEST_PEER_COPIES) a 1-MiB hipMemcpyPeerAsync round trip
+ *     i -> j -> i between every ordered pair of distinct, peer-capable devices. what = 0: those three. MA_OK only when
+ *     everything tried passed; a step that ran into the deadline leaves the group broken (as ma_group_synchronize_for).
+ *     out_report (may be NULL) says what was tried and what passed; `text` is the one-line summary a log wants. The group's
+ *     records are zeroed afterwards; anything the host had in flight is waited for first (same deadline). */
+typedef struct ma_selftest_report {
+    uint32_t struct_bytes;        /* sizeof(ma_selftest_report) of the library that filled it */
+    int32_t n_members, n_devices; /* members; distinct HIP devices among them */
+    int32_t exchange_kind;        /* 1 = RCCL all-gather + device fold, 0 = host fold */
+    int32_t rccl_ranks;           /* ncclCommCount of member 0's (or this rank's) communicator, 0 without RCCL */
+    uint32_t forms_tried, forms_ok; /* bit MA_SELFTEST_FORM_* per exchange form */
+    int32_t peer_pairs, peer_pairs_ok;
+    int32_t stamp_waits, stamp_waits_ok;
+    int32_t failed_form;          /* MA_SELFTEST_FORM_* of the form that failed, -1 */
+    int32_t failed_member;        /* the member (rank) a failure was seen on, -1 */
+    int32_t timed_out;            /* 1: the failure was a deadline (the group / communicator is broken now) */
+    double form_us[8];            /* wall microseconds of each form's exchange + wait */
+    double peer_us_max, stamp_us_max;
+    char text[1024];              /* "PASS: ..." / "FAIL: ..." */
+} ma_selftest_report;
+#define MA_SELFTEST_FORMS 8
+enum {
+    MA_SELFTEST_FORM_IN_STREAM_THREADS = 0, MA_SELFTEST_FORM_IN_STREAM_CALLER = 1,
+    MA_SELFTEST_FORM_OVERLAP_EVENT_THREADS = 2, MA_SELFTEST_FORM_OVERLAP_EVENT_CALLER = 3,
+    MA_SELFTEST_FORM_OVERLAP_STAMP_THREADS = 4, MA_SELFTEST_FORM_OVERLAP_STAMP_CALLER = 5,
+    MA_SELFTEST_FORM_HOST_FOLD = 6
+};
+enum { MA_SELFTEST_EXCHANGE = 1, MA_SELFTEST_EXCHANGE_ALL_FORMS = 2, MA_SELFTEST_PEER_COPIES = 4, MA_SELFTEST_STAMPS = 8 };
+enum { MA_GROUP_HANDOFF_STAMP = 0, MA_GROUP_HANDOFF_EVENT = 1 };
+ma_status ma_group_synchronize_for(ma_group* group, double timeout_ms);
+int32_t ma_group_is_broken(ma_group* group);
+ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags);
+uint32_t ma_group_flags(ma_group* group);
+ma_status ma_group_set_handoff(ma_group* group, int32_t kind);
+int32_t ma_group_handoff(ma_group* group);
+ma_status ma_group_selftest(ma_group* group, uint32_t what, double timeout_ms, ma_selftest_report* out_report);
+/* TESTING ONLY. The next ma_group_exchange holds `member`'s exchange in front of its all-gather behind a word nobody writes
+ * (hipStreamWaitValue64) — what a lost peer or a fabric fault looks like to the waiting host: ma_group_synchronize would
+ * block for good, ma_group_synchronize_for returns after its deadline. The abort path (and ma_group_destroy) releases the
+ * word, so the stream runs empty. With the host fold the member's scan stream is held. MA_ERR_UNSUPPORTED (at the exchange)
+ * on a runtime without stream memory operations. */
+ma_status ma_group_test_stall_next_exchange(ma_group* group, int32_t member);
+/* TESTING ONLY. The next ma_group_exchange flips one word of the records `member` gathered, in front of its fold: finals
+ * that are wrong on that member only and no error anywhere — what a host's own check of a set-up step is for. (Host fold: the
+ * job's integer finals are flipped.) */
+ma_status ma_group_test_corrupt_next_exchange(ma_group* group, int32_t member);
 /* The sum of ONE column held as many chunks spread over the group's GPUs — a SuperArray, or one column of the batches of a
  * SuperTable at the reference's own batch sizes (BASELINE config 5 with 8192-row batches: 122 000 chunks per 10^9 rows).
  * Chunk i belongs to member i % size and must be resident there; every member sums ITS chunks with one ma_sum_chunks
@@ -1080,6 +1164,23 @@ ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot);
 ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
                                  int32_t* out_rccl_ranks);
 ma_status ma_comm_synchronize(ma_comm* comm);
+/* The multi-process twins of ma_group_synchronize_for / _is_broken / _selftest (see there). ma_comm_synchronize_for waits for
+ * the context's stream and the communicator's exchange stream for at most timeout_ms; past the deadline the communicator is
+ * aborted (ma_comm_abort) and MA_ERR_DEVICE names the stream that was pending. An aborted communicator refuses every
+ * collective with MA_ERR_DEVICE and can only be destroyed; the ranks agree by their own means (the channel that carried the
+ * unique id) whether to make a new one (a fresh ma_comm_unique_id) or to go on without. ma_comm_abort is what a rank calls
+ * when ANOTHER rank reports the deadline: its own wait may have succeeded, the communicator is dead all the same.
+ * ma_comm_selftest is collective: every rank calls it; rank-tagged records go through ma_comm_sum_exchange (in-stream),
+ * ma_comm_sum_exchange_overlapped (event) and _on_stamp (stamp) — forms IN_STREAM_CALLER, OVERLAP_EVENT_CALLER,
+ * OVERLAP_STAMP_CALLER of the report — each under the deadline, the gathered blocks and the finals checked on this rank;
+ * `what` = 0 or MA_SELFTEST_EXCHANGE: the in-stream form and both overlapped ones; peer copies are not a communicator's. */
+ma_status ma_comm_synchronize_for(ma_comm* comm, double timeout_ms);
+ma_status ma_comm_abort(ma_comm* comm);
+int32_t ma_comm_is_broken(ma_comm* comm);
+ma_status ma_comm_selftest(ma_comm* comm, uint32_t what, double timeout_ms, ma_selftest_report* out_report);
+/* TESTING ONLY: as ma_group_test_stall_next_exchange / _corrupt_next_exchange, for this rank's next ma_comm_sum_exchange* call. */
+ma_status ma_comm_test_stall_next_exchange(ma_comm* comm);
+ma_status ma_comm_test_corrupt_next_exchange(ma_comm* comm);
 
 /* ------------------------------------------------------------------------------------------------
  * Testing hooks. Not part of what a binding needs (ma_group_test_set_member_device above is the other one).

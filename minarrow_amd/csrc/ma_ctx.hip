@@ -1435,17 +1435,32 @@ ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak
     return MA_OK;
 }
 
+// Live stamps and what each is made of: 1 = the runtime's signal memory, 0 = a plain device word.
+static std::mutex g_stamp_mu;
+static std::vector<std::pair<const uint64_t*, int>> g_stamps;
+
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
     MA_REQUIRE(ctx != nullptr && out_stamp != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_stamp is NULL");
     *out_stamp = nullptr;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
+    // Signal memory is one 8-byte value (the runtime refuses any other size). It is taken only if it can be zeroed like any
+    // other allocation; otherwise — and on a runtime without it — a 64-byte line of plain device memory: a stream waits on
+    // either (hipStreamWaitValue64), and a kernel's system-scope store reaches either.
     void* p = nullptr;
-    if (hipExtMallocWithFlags(&p, 64, hipMallocSignalMemory) != hipSuccess) {
+    int kind = 1;
+    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(p, 0, 8) != hipSuccess) {
         (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        kind = 0;
         MA_HIP(hipMalloc(&p, 64));
+        MA_HIP(hipMemset(p, 0, 64));
     }
-    MA_HIP(hipMemset(p, 0, 64));
+    {
+        std::lock_guard<std::mutex> lock(g_stamp_mu);
+        g_stamps.push_back({(const uint64_t*)p, kind});
+    }
     *out_stamp = (uint64_t*)p;
     return MA_OK;
 }
@@ -1455,8 +1470,23 @@ ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp) {
     if (!stamp) return MA_OK;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
+    {
+        std::lock_guard<std::mutex> lock(g_stamp_mu);
+        for (size_t i = 0; i < g_stamps.size(); ++i)
+            if (g_stamps[i].first == stamp) {
+                g_stamps.erase(g_stamps.begin() + (long)i);
+                break;
+            }
+    }
     MA_HIP(hipFree(stamp));
     return MA_OK;
+}
+
+int32_t ma_stamp_is_signal(const uint64_t* stamp) {
+    std::lock_guard<std::mutex> lock(g_stamp_mu);
+    for (const auto& e : g_stamps)
+        if (e.first == stamp) return e.second;
+    return -1;
 }
 
 ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr) {

@@ -25,115 +25,15 @@
 // Threads spin for ~200 us after a job (a stepping host never pays a wake-up) and then sleep on a condition variable.
 // MA_GROUP_ISSUE_CALLER / MINARROW_HIP_GROUP_ISSUE=caller keeps the round-2 form (the calling thread loops over the
 // members; the all-gathers inside one ncclGroupStart/End) for A/B measurements and as a fallback.
-#include <chrono>
-#include <condition_variable>
 #include <cstdlib>
-#include <functional>
 #include <map>
-#include <string>
-#include <thread>
-#include <vector>
 
-#include "ma_rccl.hpp"
-
-struct ma_group {
-    std::vector<ma_ctx*> ctxs;
-    std::recursive_mutex mu;  // recursive: the one-call forms (ma_group_sum_*) hold it across enqueue + exchange + synchronize
-    // ---- per-member issue threads (see the header comment). One job at a time, posted under `mu`.
-    bool threads = false;
-    std::vector<std::thread> workers;
-    const std::function<ma_status(size_t)>* job = nullptr;
-    std::atomic<uint64_t> job_seq{0};
-    struct alignas(64) Slot {
-        std::atomic<uint64_t> done{0};
-        ma_status status = MA_OK;
-        std::string message;
-    };
-    std::vector<Slot> slots;
-    std::mutex sleep_mu;
-    std::condition_variable work_cv, done_cv;
-    std::atomic<int> sleepers{0};
-    std::atomic<int> caller_waiting{0};
-    std::atomic<bool> stop{false};
-    // peer[i * G + j]: member i's device can address member j's device memory (same device, or hipDeviceCanAccessPeer and
-    // enabled at creation). Probed once; ma_group_consolidate_column refuses pairs that are not.
-    std::vector<uint8_t> peer;
-    // The HIP device a member's chunks must be resident on: its context's device (ma_group_test_set_member_device
-    // overrides it so that the refusal paths can be exercised on a one-GPU box).
-    std::vector<int> home;
-    bool use_rccl = false;
-    bool broken = false;  // an exchange failed on some member after others had enqueued theirs: communicators aborted
-    int fail_member = -1; // ma_group_test_fail_next_exchange: that member's next exchange fails in front of its all-gather
-    std::vector<ncclComm_t> comms;
-    // RCCL: per member a device block of kColumns records (`local`), a device block of G x kColumns gathered records
-    // and a pinned host block of kColumns x 4 finals the fold kernel writes. host: `local[i]` points into `host_records`.
-    std::vector<uint64_t*> local, gathered, finals;
-    // MA_GROUP_EXCHANGE_OVERLAP (RCCL exchange only): a second record set per member ([1]; the vectors above are set 0), an
-    // internal context per member whose stream carries the all-gather + fold of the set just filled while the member's own
-    // stream already scans into the other set, and per member and set one event each way. `cur` = the set being filled.
-    bool overlap = false;
-    int cur = 0, last = 0;  // last = the set of the most recent exchange (what ma_group_result reads)
-    std::vector<uint64_t*> local1, gathered1, finals1;
-    std::vector<ma_ctx*> side;
-    std::vector<hipEvent_t> ev_ready[2], ev_done[2];
-    bool set_used[2] = {false, false};
-    // Which record slots were filled into each set since its last exchange (overlap only): ma_group_result reads the set of
-    // the LAST exchange, and a column that was not enqueued in that step would come back from the other set — the value of
-    // two steps ago, or zeros — so it is refused instead.
-    uint32_t enq_mask[2] = {0, 0}, exchanged_mask[2] = {0, 0};
-    // Event-free hand-off to the exchange stream (overlap only): the fused table launch of a step stamps stamp[set][member]
-    // with stamp_seq[set] behind its results, and the member's exchange stream waits for that value (hipStreamWaitValue64)
-    // instead of an event recorded on the scan stream — which then carries nothing but scans. stamp_ok[set]: every launch
-    // into the set since its last exchange was such a stamped one (anything else falls back to the event).
-    std::vector<uint64_t*> stamp[2];
-    uint64_t stamp_seq[2] = {0, 0};
-    bool stamp_ok[2] = {false, false};
-    uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
-    uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
-    // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
-    // gathered into before the bit-granular join (re-used across calls in stream order)
-    std::vector<void*> mask_stage;
-    std::vector<size_t> mask_stage_bytes;
-    char note[512] = "";
-    ma::ExchangeTimer timer;        // member 0's exchange, every 4th call (ma_group_exchange_stats)
-    double host_fold_us = 0.0;      // host exchange: wall time of the host fold, summed ...
-    int host_fold_samples = 0;      // ... over this many synchronizes
-};
+#include "ma_group.hpp"
 
 using namespace ma;
-
-namespace ma {
-ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
-ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
-                         bool as_partials = false);
-}
+using namespace ma::grp;
 
 namespace {
-
-constexpr int kColumns = MA_GROUP_MAX_COLUMNS;
-constexpr size_t kBlockWords = (size_t)kColumns * kRecordWords;
-
-struct HostFoldDD {
-    uint64_t isum = 0, icnt = 0, fcnt = 0;
-    double hi = 0.0, lo = 0.0;
-    void add(const uint64_t* p) {
-        isum += p[0];
-        icnt += p[1];
-        double h, l;
-        memcpy(&h, &p[2], 8);
-        memcpy(&l, &p[3], 8);
-        const double t = hi + h;
-        const double bp = t - hi;
-        const double e = (hi - (t - bp)) + (h - bp);
-        hi = t;
-        lo += e + l;
-        fcnt += p[4];
-    }
-    double total() const {
-        const bool finite = (hi - hi == 0.0) && (lo - lo == 0.0);
-        return finite ? hi + lo : hi;
-    }
-};
 
 // Which device a pointer's memory is resident on (-1: pageable / pinned host memory, or NULL). A chunked column's
 // thousands of pointers run through a handful of allocations: each allocation is asked about once per call.
@@ -166,10 +66,14 @@ class DeviceLookup {
     std::vector<Seen> seen_;
 };
 
-void stop_workers(ma_group* g);
+}  // namespace
+
+namespace ma {
+namespace grp {
 
 // Frees the exchange's buffers and communicators (either kind); the members stay.
 void release_exchange(ma_group* g) {
+    release_waits(g, false);  // a stream held by a stall hook must run empty before it is waited for
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
         (void)hipSetDevice(g->ctxs[i]->device);
         (void)hipStreamSynchronize(g->ctxs[i]->stream);
@@ -195,7 +99,7 @@ void release_exchange(ma_group* g) {
             }
             if (i < g->side.size() && g->side[i]) ma_ctx_destroy(g->side[i]);
             for (int k = 0; k < 2; ++k)
-                if (i < g->stamp[k].size() && g->stamp[k][i]) (void)hipFree(g->stamp[k][i]);
+                if (i < g->stamp[k].size() && g->stamp[k][i]) (void)ma_stamp_free(g->ctxs[i], g->stamp[k][i]);
         }
         if (g->host_finals) (void)hipHostFree(g->host_finals);
     } else {
@@ -218,14 +122,26 @@ void release_exchange(ma_group* g) {
         g->stamp[k].clear();
         g->stamp_ok[k] = false;
     }
+    for (int k = 0; k < 2; ++k) g->enq_mask[k] = g->exchanged_mask[k] = 0;
     g->overlap = false;
     g->cur = g->last = 0;
     g->use_rccl = false;
     g->timer.destroy();
 }
 
+}  // namespace grp
+}  // namespace ma
+
+namespace {
+
 void destroy_members(ma_group* g) {
     stop_workers(g);
+    if (g->broken && !g->drained) {
+        // a stream that never ran empty after the abort: waiting for it (hipStreamSynchronize, hipFree) would block for good.
+        // What the group holds goes with the process instead.
+        g->ctxs.clear();
+        return;
+    }
     release_exchange(g);  // drains every member's stream first
     for (size_t i = 0; i < g->mask_stage.size() && i < g->ctxs.size(); ++i)
         if (g->mask_stage[i]) {
@@ -234,9 +150,21 @@ void destroy_members(ma_group* g) {
         }
     g->mask_stage.clear();
     g->mask_stage_bytes.clear();
+    for (size_t i = 0; i < g->ctxs.size(); ++i) {
+        (void)hipSetDevice(g->ctxs[i]->device);
+        if (i < g->stall_word.size() && g->stall_word[i]) (void)ma_stamp_free(g->ctxs[i], g->stall_word[i]);
+        if (i < g->rescue.size() && g->rescue[i]) (void)hipStreamDestroy(g->rescue[i]);
+    }
+    g->stall_word.clear();
+    g->rescue.clear();
     for (ma_ctx* c : g->ctxs) ma_ctx_destroy(c);
     g->ctxs.clear();
 }
+
+}  // namespace
+
+namespace ma {
+namespace grp {
 
 // RCCL exchange set-up. Returns MA_OK with g->use_rccl set, or a status + the thread's error string.
 ma_status setup_rccl(ma_group* g, bool overlap) {
@@ -293,7 +221,7 @@ ma_status setup_rccl(ma_group* g, bool overlap) {
                     (hipStreamWaitValue64(g->side[i]->stream, g->stamp[k][i], 0, hipStreamWaitValueGte, ~(uint64_t)0) != hipSuccess ||
                      hipStreamSynchronize(g->side[i]->stream) != hipSuccess)) {
                     (void)hipGetLastError();
-                    (void)hipFree(g->stamp[k][i]);
+                    (void)ma_stamp_free(g->ctxs[i], g->stamp[k][i]);
                     g->stamp[k][i] = nullptr;
                 }
             }
@@ -316,9 +244,8 @@ ma_status setup_host(ma_group* g) {
 
 // ---- issue threads ------------------------------------------------------------------------------------------------
 
-void worker_main(ma_group* g, size_t i) {
+static void worker_main(ma_group* g, size_t i, uint64_t seen) {  // seen = the job sequence at the thread's start
     (void)hipSetDevice(g->ctxs[i]->device);
-    uint64_t seen = 0;
     for (;;) {
         // wait for job `seen + 1`: spin for ~200 us (a stepping host never pays a wake-up), then sleep
         const auto t0 = std::chrono::steady_clock::now();
@@ -353,7 +280,8 @@ void start_workers(ma_group* g) {
     const size_t n = g->ctxs.size();
     g->slots = std::vector<ma_group::Slot>(n);
     g->workers.reserve(n);
-    for (size_t i = 0; i < n; ++i) g->workers.emplace_back(worker_main, g, i);
+    const uint64_t base = g->job_seq.load();  // a set of workers started later (ma_group_rebuild_exchange) joins here
+    for (size_t i = 0; i < n; ++i) g->workers.emplace_back(worker_main, g, i, base);
     g->threads = true;
 }
 
@@ -366,6 +294,7 @@ void stop_workers(ma_group* g) {
         if (t.joinable()) t.join();
     g->workers.clear();
     g->threads = false;
+    g->stop.store(false);  // the group may start a fresh set later (ma_group_rebuild_exchange)
 }
 
 // Runs fn(member) for every member — on the members' issue threads, concurrently, or in a loop on the calling thread — and
@@ -410,6 +339,11 @@ ma_status run_on_members(ma_group* g, const std::function<ma_status(size_t)>& fn
     return MA_OK;
 }
 
+}  // namespace grp
+}  // namespace ma
+
+namespace {
+
 // A chunk handed to member `member` must be resident on that member's device, or be host memory the device can
 // address: the kernels dereference it directly, and on a multi-GPU node a pointer into another GPU's HBM is a memory
 // fault, not a status. (one row chunk per GPU.)
@@ -442,9 +376,19 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
     });
 }
 
+}  // namespace
+
+namespace ma {
+namespace grp {
+
 ma_status exchange_locked(ma_group* g) {
-    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "an earlier exchange of this group failed and its communicators were aborted: destroy the group");
-    if (!g->use_rccl) return MA_OK;  // host exchange: the records are already in host memory once the streams drain
+    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
+    if (!g->use_rccl) {  // host exchange: the records are already in host memory once the streams drain
+        const int m = g->stall_member;
+        g->stall_member = -1;
+        if (m >= 0) MA_TRY(enqueue_stall(g, (size_t)m, g->ctxs[(size_t)m]->stream));
+        return MA_OK;
+    }
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
     const size_t n = g->ctxs.size();
@@ -454,7 +398,8 @@ ma_status exchange_locked(ma_group* g) {
     auto finals = [g, set](size_t i) { return set ? g->finals1[i] : g->finals[i]; };
     // which context issues the exchange of member i: its own (in-stream), or its side context (overlapped: behind the
     // scans that filled this set — an event — while the member's stream goes on with the other set)
-    const bool on_stamp = g->overlap && g->stamp_ok[set] && !(g->ctxs[0]->variant & 4096);  // variant bit 4096: always events (A/B)
+    // ma_group_set_handoff(event) — or variant bit 4096 on member 0, the tuning harness's switch — always takes the event
+    const bool on_stamp = g->overlap && g->stamp_ok[set] && g->handoff == 0 && !(g->ctxs[0]->variant & 4096);
     auto before = [g, set, on_stamp](size_t i) -> ma_status {
         if (!g->overlap) return MA_OK;
         if (on_stamp) {  // the scan stream carries nothing for the hand-off: the exchange stream waits for the kernel's stamp
@@ -488,6 +433,16 @@ ma_status exchange_locked(ma_group* g) {
         return enqueue_fold_columns(c, gathered(i), n, kBlockWords, kColumns, finals(i));
     };
     auto xstream = [g](size_t i) { return g->overlap ? g->side[i]->stream : g->ctxs[i]->stream; };
+    // testing hooks: a member whose exchange never starts (held behind its stall word), a member that folds flipped records
+    const int stall = g->stall_member, corrupt = g->corrupt_member;
+    g->stall_member = g->corrupt_member = -1;
+    auto hooks_before = [&](size_t i) -> ma_status { return (int)i == stall ? enqueue_stall(g, i, xstream(i)) : MA_OK; };
+    auto hooks_gathered = [&](size_t i) -> ma_status {
+        if ((int)i != corrupt) return MA_OK;
+        static const uint64_t kFlip = 0x5A5A5A5A5A5A5A5Aull;  // member i's copy of member 0's record 0, integer sum
+        MA_HIP(hipMemcpyAsync(gathered(i), &kFlip, 8, hipMemcpyHostToDevice, xstream(i)));
+        return MA_OK;
+    };
     ma_status st = MA_OK;
     // One thread per device, each issuing its own rank's all-gather with no ncclGroup: the form RCCL documents for one thread
     // per device; the members' launches and collectives are enqueued concurrently (8 members: 26 us per step instead of 53 from
@@ -503,9 +458,11 @@ ma_status exchange_locked(ma_group* g) {
                 set_error("member %zu: injected failure in front of its all-gather (ma_group_test_fail_next_exchange)", i);
                 return MA_ERR_DEVICE;
             }
+            MA_TRY(hooks_before(i));
             const int tk = i == 0 ? g->timer.begin(xstream(0)) : -1;
             MA_NCCL(api, AllGather(local(i), gathered(i), kBlockWords * 8, ncclChar, g->comms[i], xstream(i)));
             if (i == 0) g->timer.mark(tk, 1, xstream(0));
+            MA_TRY(hooks_gathered(i));
             MA_TRY(fold(i));
             if (i == 0) g->timer.mark(tk, 2, xstream(0));
             return after(i);
@@ -513,6 +470,7 @@ ma_status exchange_locked(ma_group* g) {
     } else {
         for (size_t i = 0; i < n && st == MA_OK; ++i) {
             st = hipSetDevice(g->ctxs[i]->device) == hipSuccess ? before(i) : MA_ERR_DEVICE;
+            if (st == MA_OK) st = hooks_before(i);
         }
         MA_TRY(st);
         MA_HIP(hipSetDevice(g->ctxs[0]->device));
@@ -532,6 +490,7 @@ ma_status exchange_locked(ma_group* g) {
         // timing mark sits right behind its fold
         st = run_on_members(g, [&](size_t i) -> ma_status {
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
+            MA_TRY(hooks_gathered(i));
             MA_TRY(fold(i));
             if (i == 0) g->timer.mark(tk, 2, xstream(0));
             return after(i);
@@ -542,13 +501,9 @@ ma_status exchange_locked(ma_group* g) {
     if (st != MA_OK && g->threads && (n > 1 || injected)) {
         // some member's all-gather is on its stream without its peers': abort every communicator so that nothing waits for it
         const std::string why = ma_last_error_string();
-        for (ncclComm_t& c : g->comms)
-            if (c && api->CommAbort) {
-                (void)api->CommAbort(c);
-                c = nullptr;
-            }
-        g->broken = true;
-        set_error("the group's exchange failed on a member and its communicators were aborted (the group must be destroyed): %s", why.c_str());
+        abort_locked(g, why.c_str());
+        set_error("the group's exchange failed on a member and its communicators were aborted (ma_group_rebuild_exchange, or "
+                  "destroy the group): %s", why.c_str());
         return st;
     }
     MA_TRY(st);
@@ -565,7 +520,7 @@ ma_status exchange_locked(ma_group* g) {
 }
 
 ma_status synchronize_locked(ma_group* g) {
-    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "an earlier exchange of this group failed and its communicators were aborted: destroy the group");
+    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
     // every member is waited for even when one reports (a latched division by zero is cleared by its report)
     std::vector<ma_status> st(g->ctxs.size(), MA_OK);
     std::vector<std::string> msg(g->ctxs.size());
@@ -590,16 +545,23 @@ ma_status synchronize_locked(ma_group* g) {
             for (size_t i = 0; i < g->ctxs.size(); ++i) f.add(g->local[i] + (size_t)col * kRecordWords);
             uint64_t* out = g->host_finals + (size_t)col * 4;
             const double total = f.total();
+            if (g->corrupt_member >= 0) f.isum ^= 0x5A5A5A5A5A5A5A5Aull;  // testing hook: finals that are wrong
             out[0] = f.isum;
             out[1] = f.icnt;
             memcpy(&out[2], &total, 8);
             out[3] = f.fcnt;
         }
+        g->corrupt_member = -1;
         g->host_fold_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         ++g->host_fold_samples;
     }
     return MA_OK;
 }
+
+}  // namespace grp
+}  // namespace ma
+
+namespace {
 
 // Peer capability between the members' devices, probed (and enabled) once. Returns how many ordered pairs of DISTINCT
 // devices there are and how many of them are peer-capable; the pairs that are not are listed in `missing`.
@@ -642,12 +604,61 @@ void probe_peers(ma_group* g, int* out_pairs, int* out_capable, std::string* mis
     *out_capable = capable;
 }
 
+}  // namespace
+
+namespace ma {
+namespace grp {
+
+// Sets up the exchange `flags` ask for on a group that has members but no exchange (creation, ma_group_rebuild_exchange),
+// starts the issue threads, writes the note.
+ma_status configure_exchange(ma_group* g, uint32_t flags) {
+    ma_status st = MA_OK;
+    char why[256] = "";
+    if (flags & MA_GROUP_EXCHANGE_RCCL) {
+        st = setup_rccl(g, (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0);
+        if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
+            snprintf(why, sizeof(why), "host fold instead of RCCL: %s", ma_last_error_string());
+            release_exchange(g);  // whatever the attempt allocated; the members stay
+            st = setup_host(g);
+        }
+    } else {
+        st = setup_host(g);
+    }
+    MA_TRY(st);
+    g->flags = flags;
+    // Issue threads unless the caller (flag) or the environment asks for the calling-thread loop.
+    const char* issue = getenv("MINARROW_HIP_GROUP_ISSUE");
+    bool threads = (flags & MA_GROUP_ISSUE_CALLER) == 0;
+    if (issue && strcmp(issue, "caller") == 0) threads = false;
+    if (issue && strcmp(issue, "threads") == 0) threads = true;
+    if (threads && !g->threads) start_workers(g);
+    if (!threads && g->threads) stop_workers(g);
+    // the note: why the exchange is what it is (if it is not what was asked for), then the peer matrix
+    const char* handoff = "";
+    if (g->overlap) {
+        int signal = 0, words = 0;
+        for (int k = 0; k < 2; ++k)
+            for (uint64_t* w : g->stamp[k]) {
+                if (!w) continue;
+                ++words;
+                if (ma_stamp_is_signal(w) == 1) ++signal;
+            }
+        handoff = words < 2 * (int)g->ctxs.size() ? " (hand-off: events; no waitable stamp words on this runtime)"
+                  : signal == words               ? " (hand-off: stamps in signal memory)"
+                                                  : " (hand-off: stamps in device memory)";
+    }
+    snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s%s%s", why, why[0] ? "; " : "", g->peer_note.c_str(),
+             g->threads ? "one thread per member" : "calling thread", g->overlap ? "; exchange overlapped on side streams" : "", handoff);
+    return MA_OK;
+}
+
 const uint64_t* finals_of(const ma_group* g, size_t member, int32_t column) {
     const uint64_t* base = !g->use_rccl ? g->host_finals : (g->overlap && g->last == 1) ? g->finals1[member] : g->finals[member];
     return base + (size_t)column * 4;
 }
 
-}  // namespace
+}  // namespace grp
+}  // namespace ma
 
 extern "C" {
 
@@ -674,30 +685,6 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
     int pairs = 0, capable = 0;
     std::string missing;
     probe_peers(g, &pairs, &capable, &missing);
-    ma_status st = MA_OK;
-    char why[256] = "";
-    if (flags & MA_GROUP_EXCHANGE_RCCL) {
-        st = setup_rccl(g, (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0);
-        if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
-            snprintf(why, sizeof(why), "host fold instead of RCCL: %s", ma_last_error_string());
-            release_exchange(g);  // whatever the attempt allocated; the members stay
-            st = setup_host(g);
-        }
-    } else {
-        st = setup_host(g);
-    }
-    if (st != MA_OK) {
-        destroy_members(g);
-        delete g;
-        return st;
-    }
-    // Issue threads unless the caller (flag) or the environment asks for the calling-thread loop.
-    const char* issue = getenv("MINARROW_HIP_GROUP_ISSUE");
-    bool threads = (flags & MA_GROUP_ISSUE_CALLER) == 0;
-    if (issue && strcmp(issue, "caller") == 0) threads = false;
-    if (issue && strcmp(issue, "threads") == 0) threads = true;
-    if (threads) start_workers(g);
-    // the note: why the exchange is what it is (if it is not what was asked for), then the peer matrix
     char peers[320];
     if (pairs == 0)
         snprintf(peers, sizeof(peers), "peer access: n/a (one device)");
@@ -706,8 +693,13 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
     else
         snprintf(peers, sizeof(peers), "peer access: %d/%d ordered device pairs (not peer-capable: %s)", capable, pairs,
                  missing.c_str());
-    snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s%s", why, why[0] ? "; " : "", peers,
-             g->threads ? "one thread per member" : "calling thread", g->overlap ? "; exchange overlapped on side streams" : "");
+    g->peer_note = peers;
+    const ma_status st = configure_exchange(g, flags);
+    if (st != MA_OK) {
+        destroy_members(g);
+        delete g;
+        return st;
+    }
     *out_group = g;
     return MA_OK;
 }
@@ -807,7 +799,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
                        "columns %d and %d would write the same slots of record %d", j, k, columns[k]);
     }
     std::lock_guard<std::recursive_mutex> lock(group->mu);
-    for (int32_t k = 0; k < n_cols; ++k) group->enq_mask[group->overlap ? group->cur : 0] |= 1u << columns[k];
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
     DeviceLookup lookup;
     for (int32_t k = 0; k < n_cols; ++k)
         for (size_t i = 0; i < group->ctxs.size(); ++i) {
@@ -817,11 +809,12 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
         }
     // overlapped exchanges: this launch stamps the set's hand-off word behind its results (see ma_group::stamp)
     const int cur_set = group->overlap ? group->cur : 0;
+    for (int32_t k = 0; k < n_cols; ++k) group->enq_mask[cur_set] |= 1u << columns[k];  // only once nothing can refuse the call
     bool stamped = group->overlap && group->stamp[cur_set].size() == group->ctxs.size();
     for (size_t i = 0; stamped && i < group->ctxs.size(); ++i) stamped = group->stamp[cur_set][i] != nullptr;
     const uint64_t seq = stamped ? ++group->stamp_seq[cur_set] : 0;
     group->stamp_ok[cur_set] = stamped;
-    return run_on_members(group, [&](size_t i) -> ma_status {
+    const ma_status st = run_on_members(group, [&](size_t i) -> ma_status {
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];
         ma_fused_column cols[MA_FUSED_MAX_COLUMNS];
         for (int32_t k = 0; k < n_cols; ++k) {
@@ -837,6 +830,10 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
         }
         return sum_fused_impl(group->ctxs[i], (size_t)n_cols, cols, stamped ? group->stamp[cur_set][i] : nullptr, seq);
     });
+    // A member that refused the launch (a misaligned pointer, say) never stamps `seq`: an exchange waiting for that value on
+    // its side stream would wait for good. The event path orders behind whatever did reach the streams.
+    if (st != MA_OK) group->stamp_ok[cur_set] = false;
+    return st;
 }
 
 // The sum of ONE column held as MANY chunks spread over the group — a SuperArray, or one column of a SuperTable's batches

@@ -36,6 +36,9 @@ const RcclApi* rccl();
 
 ma_status rccl_fail(ncclResult_t r, const char* what, const char* file, int line);
 
+// ma_group_guard.hip: one thread stores `value` to `*stamp` with a system-scope release, as the fused scan's final thread does.
+hipError_t launch_stamp_store(hipStream_t stream, uint64_t* stamp, uint64_t value);
+
 // Where an exchange's time goes (ma_group_exchange_stats / ma_comm_exchange_stats): every 4th exchange carries three HIP
 // events on the stream it runs on — in front of the all-gather, behind it, behind the fold — so that the first scaling run
 // on a multi-GPU node explains itself (all-gather latency over xGMI vs. the fold kernel). An event costs the stream a few

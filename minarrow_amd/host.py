@@ -687,6 +687,32 @@ class Context:
         return f.value, i.value, int(c.value), int(r.value), int(b.value)
 
 
+class SelftestReport(C.Structure):
+    """ma_selftest_report (include/minarrow_hip.h)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("n_members", C.c_int32), ("n_devices", C.c_int32), ("exchange_kind", C.c_int32),
+                ("rccl_ranks", C.c_int32), ("forms_tried", C.c_uint32), ("forms_ok", C.c_uint32), ("peer_pairs", C.c_int32),
+                ("peer_pairs_ok", C.c_int32), ("stamp_waits", C.c_int32), ("stamp_waits_ok", C.c_int32), ("failed_form", C.c_int32),
+                ("failed_member", C.c_int32), ("timed_out", C.c_int32), ("form_us", C.c_double * 8), ("peer_us_max", C.c_double),
+                ("stamp_us_max", C.c_double), ("text", C.c_char * 1024)]
+
+    FORM_NAMES = ("in-stream/threads", "in-stream/caller", "overlap-event/threads", "overlap-event/caller",
+                  "overlap-stamp/threads", "overlap-stamp/caller", "host-fold")
+
+    def as_dict(self, status: int = 0) -> dict:
+        forms = {name: {"ok": bool(self.forms_ok >> b & 1), "us": round(self.form_us[b], 1)}
+                 for b, name in enumerate(self.FORM_NAMES) if self.forms_tried >> b & 1}
+        return {"ok": status == 0, "text": self.text.decode(errors="replace"), "members": self.n_members, "devices": self.n_devices,
+                "exchange": "rccl" if self.exchange_kind == 1 else "host", "rccl_ranks": self.rccl_ranks, "forms": forms,
+                "peer_pairs": self.peer_pairs, "peer_pairs_ok": self.peer_pairs_ok, "peer_us_max": round(self.peer_us_max, 1),
+                "stamp_waits": self.stamp_waits, "stamp_waits_ok": self.stamp_waits_ok, "stamp_us_max": round(self.stamp_us_max, 1),
+                "failed_form": self.FORM_NAMES[self.failed_form] if 0 <= self.failed_form < len(self.FORM_NAMES) else None,
+                "failed_member": self.failed_member if self.failed_member >= 0 else None, "timed_out": bool(self.timed_out)}
+
+
+SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS = 1, 2, 4, 8
+GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8}
+
+
 class Group:
     """One process driving several GPUs (ma_group_*): member i scans chunk i on device i, one exchange ends the
     reduction. exchange = "rccl" (ncclCommInitAll + grouped all-gather + device fold), "rccl-or-host", or "host"."""
@@ -695,8 +721,7 @@ class Group:
 
     def __init__(self, devices, exchange: str = "host", issue: str = "threads"):
         self.lib = ffi.load_library()
-        flags = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8}[exchange] | \
-            {"threads": 0, "caller": 4}[issue]
+        flags = GROUP_FLAGS[exchange] | {"threads": 0, "caller": 4}[issue]
         n = len(devices)
         devs = (C.c_int32 * n)(*[int(d) for d in devices])
         h = C.c_void_p()
@@ -871,6 +896,57 @@ class Group:
     def synchronize(self) -> None:
         ffi.check(self.lib.ma_group_synchronize(self.handle))
 
+    def synchronize_for(self, timeout_ms: float) -> None:
+        """ma_group_synchronize_for: raises MinarrowHipError(MA_ERR_DEVICE) naming the pending members past the deadline;
+        the group is broken then (is_broken) until rebuild_exchange."""
+        ffi.check(self.lib.ma_group_synchronize_for(self.handle, float(timeout_ms)))
+
+    @property
+    def is_broken(self) -> int:
+        """0 healthy, 1 broken with idle streams (rebuild_exchange works), 2 broken with a stream still busy."""
+        return int(self.lib.ma_group_is_broken(self.handle))
+
+    @property
+    def flags(self) -> int:
+        return int(self.lib.ma_group_flags(self.handle))
+
+    @property
+    def overlapped(self) -> bool:
+        return bool(self.flags & 8)
+
+    @property
+    def handoff(self) -> Optional[str]:
+        """"stamp" / "event": what an overlapped, stamped step's exchange stream waits on; None when the group does not overlap."""
+        return {0: "stamp", 1: "event"}.get(int(self.lib.ma_group_handoff(self.handle)))
+
+    def set_handoff(self, kind: str) -> None:
+        ffi.check(self.lib.ma_group_set_handoff(self.handle, {"stamp": 0, "event": 1}[kind]))
+
+    def rebuild_exchange(self, exchange: str, issue: str = "threads") -> None:
+        """A fresh exchange for the same members (ma_group_rebuild_exchange): the member contexts and their buffers stay."""
+        ffi.check(self.lib.ma_group_rebuild_exchange(self.handle, GROUP_FLAGS[exchange] | {"threads": 0, "caller": 4}[issue]))
+
+    def selftest(self, timeout_ms: float, what: int = 0, raise_on_failure: bool = False) -> dict:
+        """ma_group_selftest: the report as a dict ({"ok", "text", "forms", ...})."""
+        rep = SelftestReport()
+        st = self.lib.ma_group_selftest(self.handle, int(what), float(timeout_ms), C.addressof(rep))
+        out = rep.as_dict(st)
+        if st != 0:
+            msg = self.lib.ma_last_error_string()
+            out["error"] = msg.decode() if msg else ""
+            if raise_on_failure:
+                raise ffi.MinarrowHipError(st, out["error"])
+        return out
+
+    def test_fail_next_exchange(self, member: int) -> None:
+        ffi.check(self.lib.ma_group_test_fail_next_exchange(self.handle, int(member)))
+
+    def test_stall_next_exchange(self, member: int) -> None:
+        ffi.check(self.lib.ma_group_test_stall_next_exchange(self.handle, int(member)))
+
+    def test_corrupt_next_exchange(self, member: int) -> None:
+        ffi.check(self.lib.ma_group_test_corrupt_next_exchange(self.handle, int(member)))
+
     def result(self, column: int = 0, member: int = 0):
         """(int sum, int count, f64 sum, f64 count) of `column` as GPU `member` holds them (after synchronize)."""
         i, ic, f, fc = C.c_int64(), C.c_uint64(), C.c_double(), C.c_uint64()
@@ -954,6 +1030,33 @@ class Comm:
 
     def synchronize(self) -> None:
         ffi.check(self.lib.ma_comm_synchronize(self.handle))
+
+    def synchronize_for(self, timeout_ms: float) -> None:
+        """ma_comm_synchronize_for: past the deadline the communicator is aborted and MinarrowHipError(MA_ERR_DEVICE) raised."""
+        ffi.check(self.lib.ma_comm_synchronize_for(self.handle, float(timeout_ms)))
+
+    def abort(self) -> None:
+        ffi.check(self.lib.ma_comm_abort(self.handle))
+
+    @property
+    def is_broken(self) -> int:
+        return int(self.lib.ma_comm_is_broken(self.handle))
+
+    def selftest(self, timeout_ms: float, what: int = 0) -> dict:
+        """ma_comm_selftest (collective: every rank calls it): the report as a dict."""
+        rep = SelftestReport()
+        st = self.lib.ma_comm_selftest(self.handle, int(what), float(timeout_ms), C.addressof(rep))
+        out = rep.as_dict(st)
+        if st != 0:
+            msg = self.lib.ma_last_error_string()
+            out["error"] = msg.decode() if msg else ""
+        return out
+
+    def test_stall_next_exchange(self) -> None:
+        ffi.check(self.lib.ma_comm_test_stall_next_exchange(self.handle))
+
+    def test_corrupt_next_exchange(self) -> None:
+        ffi.check(self.lib.ma_comm_test_corrupt_next_exchange(self.handle))
 
     def close(self) -> None:
         if self.handle:

@@ -1,0 +1,289 @@
+"""First-contact safety of the multi-GPU forms: bounded waits (ma_group_synchronize_for / ma_comm_synchronize_for), the way
+down (ma_group_rebuild_exchange, ma_group_set_handoff), the self-tests (ma_group_selftest / ma_comm_selftest) and the fault
+hooks that drive them on a one-GPU box (ma_*_test_stall_next_exchange: an exchange that never completes;
+ma_*_test_corrupt_next_exchange: finals that are wrong on one member). The job they guard is the reference's partitioned
+reduction, benches/benchmark_parallel_simd.rs:81-125."""
+import time
+
+import numpy as np
+import pytest
+
+from minarrow_amd import ffi
+from minarrow_amd.host import (SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS, Comm, Context,
+                               Group)
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 20
+TRI = N * (N - 1) // 2
+
+
+def _column(g, member=0):
+    c = g.member_ctx(member)
+    col_i, col_f = c.alloc(N * 8), c.alloc(N * 8)
+    c.synth_iota("i64", col_i, N, 0)
+    c.synth_iota("f64", col_f, N, 0)
+    return c, col_i, col_f
+
+
+def _step(g, col_i, col_f, fused=True):
+    if fused:
+        g.enqueue_sum_table([("l", 0, [col_i], [N]), ("g", 0, [col_f], [N])])
+    else:
+        g.enqueue_sum("i64", 0, [col_i], [N])
+        g.enqueue_sum("f64", 0, [col_f], [N])
+    g.exchange()
+
+
+def _rccl_group(exchange, issue="threads"):
+    g = Group([0], exchange=exchange, issue=issue)
+    if g.exchange_kind != "rccl":
+        g.close()
+        pytest.skip("RCCL is not available on this box")
+    return g
+
+
+def test_stamp_words_are_waitable_and_say_what_they_are(ctx):
+    s = ctx.stamp_alloc()
+    try:
+        assert ctx.lib.ma_stamp_is_signal(s) in (0, 1)  # 1: the runtime's signal memory (8 bytes), 0: a plain device word
+        col = ctx.alloc(N * 8)
+        out = ctx.alloc(64)
+        ctx.synth_iota("i64", col, N, 0)
+        call = ctx.prepare_sum_fused([("l", col, N, out.ptr)], stamp=s)
+        call(7)
+        ctx.synchronize()
+        assert int(out.download(np.int64, 1)[0]) == TRI
+    finally:
+        ctx.stamp_free(s)
+    assert ctx.lib.ma_stamp_is_signal(s) == -1
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "host"])
+@pytest.mark.parametrize("issue", ["threads", "caller"])
+def test_synchronize_for_is_synchronize_when_nothing_hangs(exchange, issue):
+    g = Group([0], exchange=exchange if exchange == "host" else exchange + "-or-host", issue=issue)
+    try:
+        c, col_i, col_f = _column(g)
+        for _ in range(5):
+            _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.is_broken == 0
+        assert g.result(0) == (TRI, N, float(TRI), N)
+        g.synchronize_for(0)  # <= 0: no deadline, plain synchronize
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("exchange, issue", [("rccl", "threads"), ("rccl", "caller"), ("rccl-overlap", "threads"),
+                                             ("rccl-overlap", "caller"), ("host", "threads")])
+def test_a_stalled_exchange_ends_in_an_error_not_a_hang_and_the_group_can_be_rebuilt(exchange, issue):
+    g = Group([0], exchange=exchange, issue=issue) if exchange == "host" else _rccl_group(exchange, issue)
+    try:
+        c, col_i, col_f = _column(g)
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        g.test_stall_next_exchange(0)
+        _step(g, col_i, col_f)
+        t0 = time.perf_counter()
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.synchronize_for(300)
+        waited = time.perf_counter() - t0
+        assert e.value.status == ffi.MA_ERR_DEVICE and "member 0" in str(e.value) and "did not finish within 300 ms" in str(e.value)
+        assert 0.25 < waited < 8.0, waited
+        assert g.is_broken == 1, "the abort released the stall: the streams must have run empty"
+        for call in (g.exchange, g.synchronize, lambda: g.synchronize_for(100), lambda: g.selftest(100, raise_on_failure=True)):
+            with pytest.raises(ffi.MinarrowHipError) as e2:
+                call()
+            assert e2.value.status == ffi.MA_ERR_DEVICE and "rebuild" in str(e2.value)
+        c.synchronize()  # the member's own context is intact, and so are its buffers
+        c.set_async(False)
+        assert c.sum("i64", col_i, N) == (TRI, N)
+        c.set_async(True)
+        # one notch down, same members, same columns
+        g.rebuild_exchange("rccl" if exchange.startswith("rccl") else "host", issue="caller")
+        assert g.is_broken == 0 and not g.overlapped and g.issue_kind == "caller"
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.result(0) == (TRI, N, float(TRI), N)
+        # ... and all the way down
+        g.rebuild_exchange("host")
+        assert g.exchange_kind == "host"
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.result(0) == (TRI, N, float(TRI), N)
+        # a stall can be armed again after a rebuild (its word carries a sequence, not a flag)
+        g.test_stall_next_exchange(0)
+        _step(g, col_i, col_f)
+        with pytest.raises(ffi.MinarrowHipError):
+            g.synchronize_for(200)
+        assert g.is_broken == 1
+    finally:
+        g.close()  # destroying a broken group must not block either
+
+
+def test_destroying_a_group_with_an_armed_stall_releases_it():
+    g = _rccl_group("rccl-overlap")
+    c, col_i, col_f = _column(g)
+    g.test_stall_next_exchange(0)
+    _step(g, col_i, col_f)
+    t0 = time.perf_counter()
+    g.close()
+    assert time.perf_counter() - t0 < 10.0
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "host"])
+def test_a_corrupted_exchange_is_visible_in_the_finals_and_only_once(exchange):
+    g = Group([0], exchange=exchange) if exchange == "host" else _rccl_group(exchange)
+    try:
+        c, col_i, col_f = _column(g)
+        g.test_corrupt_next_exchange(0)
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.is_broken == 0
+        assert g.result(0)[0] != TRI, "the hook flips the integer sum"
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.result(0) == (TRI, N, float(TRI), N)
+    finally:
+        g.close()
+
+
+def test_handoff_can_be_switched_without_a_rebuild():
+    g = _rccl_group("rccl-overlap")
+    try:
+        c, col_i, col_f = _column(g)
+        first = g.handoff
+        assert first in ("stamp", "event")
+        assert ("stamps in" in g.exchange_note) == (first == "stamp"), g.exchange_note
+        for kind in ("event", "stamp", "event"):
+            g.set_handoff(kind)
+            assert g.handoff == ("event" if kind == "event" else first)
+            for _ in range(3):
+                _step(g, col_i, col_f)
+            g.synchronize_for(20_000)
+            assert g.result(0) == (TRI, N, float(TRI), N)
+        assert g.lib.ma_group_set_handoff(g.handle, 7) == ffi.MA_ERR_INVALID_ARGUMENT
+    finally:
+        g.close()
+    with Group([0], exchange="host") as h:
+        assert h.handoff is None
+
+
+@pytest.mark.parametrize("exchange, issue", [("rccl", "threads"), ("rccl", "caller"), ("rccl-overlap", "threads"),
+                                             ("rccl-overlap", "caller"), ("host", "threads")])
+def test_selftest_passes_in_every_form_this_box_can_run(exchange, issue):
+    g = Group([0], exchange=exchange, issue=issue) if exchange == "host" else _rccl_group(exchange, issue)
+    try:
+        rep = g.selftest(20_000)  # the configured form + stamps + peer copies
+        assert rep["ok"] and rep["text"].startswith("PASS"), rep
+        assert rep["members"] == 1 and rep["devices"] == 1 and rep["peer_pairs"] == 0
+        assert len(rep["forms"]) == 1 and all(f["ok"] and f["us"] > 0 for f in rep["forms"].values()), rep
+        if exchange == "rccl-overlap":
+            (name,) = rep["forms"]
+            assert name == f"overlap-{g.handoff}/{issue}"
+            if g.handoff == "stamp":
+                assert rep["stamp_waits"] == rep["stamp_waits_ok"] == 2
+        if exchange.startswith("rccl"):
+            assert rep["rccl_ranks"] == 1 and rep["exchange"] == "rccl"
+        allf = g.selftest(20_000, SELFTEST_EXCHANGE | SELFTEST_EXCHANGE_ALL_FORMS)
+        want = {"rccl": 2, "rccl-overlap": 4 if g.handoff == "stamp" else 2, "host": 1}[exchange]
+        assert allf["ok"] and len(allf["forms"]) == want and all(f["ok"] for f in allf["forms"].values()), allf
+        assert g.issue_kind == issue, "the self-test leaves the issue form as it found it"
+        # the group still does its job afterwards, and the test left nothing behind in its records
+        c, col_i, col_f = _column(g)
+        _step(g, col_i, col_f)
+        g.synchronize_for(20_000)
+        assert g.result(0) == (TRI, N, float(TRI), N)
+    finally:
+        g.close()
+
+
+def test_selftest_over_several_members_sharing_the_device():
+    """[0] * n host-fold groups: the member-ordered fold of n tagged records on every member."""
+    with Group([0] * 5, exchange="host") as g:
+        rep = g.selftest(20_000)
+        assert rep["ok"] and rep["members"] == 5 and rep["devices"] == 1 and rep["forms"]["host-fold"]["ok"], rep
+
+
+def test_selftest_reports_a_stall_and_a_corruption():
+    g = _rccl_group("rccl-overlap")
+    try:
+        g.test_corrupt_next_exchange(0)
+        rep = g.selftest(20_000, SELFTEST_EXCHANGE)
+        assert not rep["ok"] and rep["text"].startswith("FAIL") and rep["failed_member"] == 0 and not rep["timed_out"], rep
+        assert "rank order" in rep["text"] or "fold" in rep["text"]
+        assert g.is_broken == 0
+        assert g.selftest(20_000)["ok"]  # the hook is spent; the group is fine
+        g.test_stall_next_exchange(0)
+        rep = g.selftest(300, SELFTEST_EXCHANGE)
+        assert not rep["ok"] and rep["timed_out"] and rep["failed_form"].startswith("overlap-"), rep
+        assert g.is_broken == 1
+        g.rebuild_exchange("rccl-overlap")
+        assert g.selftest(20_000)["ok"]
+    finally:
+        g.close()
+
+
+# ---- the multi-process communicator ------------------------------------------------------------------------------------------
+
+
+def _comm(ctx):
+    try:
+        return Comm(ctx, Comm.unique_id(), 0, 1)
+    except ffi.MinarrowHipError as e:
+        pytest.skip(f"RCCL is not available on this box: {e}")
+
+
+def _records(ctx):
+    local, gathered, final = ctx.alloc(64), ctx.alloc(64), ctx.alloc(32)
+    for b, nbytes in ((local, 64), (gathered, 64), (final, 32)):
+        ctx.dev_memset(b, 0, nbytes)
+    return local, gathered, final
+
+
+def test_comm_selftest_and_bounded_wait(ctx):
+    comm = _comm(ctx)
+    try:
+        rep = comm.selftest(20_000)
+        assert rep["ok"] and rep["rccl_ranks"] == 1, rep
+        assert rep["forms"]["in-stream/caller"]["ok"] and rep["forms"]["overlap-event/caller"]["ok"], rep
+        col = ctx.alloc(N * 8)
+        ctx.synth_iota("i64", col, N, 0)
+        local, gathered, final = _records(ctx)
+        ctx.set_async(True)
+        ctx.sum_into("i64", col, N, out_sum=local.ptr, out_count=local.ptr + 8)
+        comm.sum_exchange(local, 1, 1, gathered, final)
+        comm.synchronize_for(20_000)
+        assert [int(v) for v in final.download(np.uint64, 2)] == [TRI, N]
+        # corrupted once, then fine
+        comm.test_corrupt_next_exchange()
+        comm.sum_exchange(local, 1, 1, gathered, final)
+        comm.synchronize_for(20_000)
+        assert int(final.download(np.uint64, 1)[0]) != TRI
+        comm.sum_exchange_overlapped(0, local, 1, 1, gathered, final)
+        comm.synchronize_for(20_000)
+        assert [int(v) for v in final.download(np.uint64, 2)] == [TRI, N]
+        # a stall: error after the deadline, the communicator is dead, the context is not
+        comm.test_stall_next_exchange()
+        comm.sum_exchange_overlapped(1, local, 1, 1, gathered, final)
+        t0 = time.perf_counter()
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            comm.synchronize_for(300)
+        assert e.value.status == ffi.MA_ERR_DEVICE and "exchange stream" in str(e.value) and time.perf_counter() - t0 < 8.0
+        assert comm.is_broken == 1
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            comm.sum_exchange(local, 1, 1, gathered, final)
+        assert e.value.status == ffi.MA_ERR_DEVICE and "aborted" in str(e.value)
+        ctx.set_async(False)
+        assert ctx.sum("i64", col, N) == (TRI, N)
+    finally:
+        comm.close()
+    # the ranks agree on a new communicator: a fresh id, the same context
+    again = _comm(ctx)
+    try:
+        assert again.selftest(20_000)["ok"]
+        again.abort()  # what a rank does when ANOTHER rank reports the deadline
+        assert again.is_broken == 1
+    finally:
+        again.close()
