@@ -651,7 +651,7 @@ def _check(total_rows, finals):
         and abs(got_f - exact_f) <= math.ulp(exact_f)
 
 
-def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
+def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int, wait_ms: float = 0.0):
     """BASELINE configs 3, 4 and 5 of the multi-GPU kind, one process over N GPUs (after and outside the timed headline):
     config 3 = a SuperArray of N chunk pairs, one per GPU, added chunk by chunk with no exchange;
     config 4 = a 10^9-row i64 column with 10 % nulls, row-chunk partitioned over the N GPUs (strong scaling: N x fewer rows
@@ -670,11 +670,11 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     def timed_steps(step):
         for _ in range(4):  # first touches of every GPU's buffers, communicator and fold kernel stay outside the clock
             step()
-        group.synchronize()
+        group.synchronize_for(wait_ms)
         t0 = time.perf_counter()
         for _ in range(reps):
             step()
-        group.synchronize()
+        group.synchronize_for(wait_ms)
         return (time.perf_counter() - t0) / reps * 1e3
 
     # ---- config 3: a SuperArray of N chunks of `rows` rows, one per GPU: out_i = a_i + b_i (i64; b = the f64 column's bit
@@ -687,7 +687,7 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     for col in (cols_i, cols_f, outs):
         group.enqueue_sum("i64", 5, col, lens)
         group.exchange()
-        group.synchronize()
+        group.synchronize_for(wait_ms)
         sums.append(group.result(5)[0] & M64)
     ok3 = sums[2] == (sums[0] + sums[1]) & M64
     for r in (0, world - 1):
@@ -775,11 +775,11 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
         steps = max(1, min(reps, 3))
         for _ in range(1):
             group.consolidate_column(0, 8, cols_i, lens, whole, masks, zeros, wmask)
-        group.synchronize()
+        group.synchronize_for(wait_ms)
         t0 = time.perf_counter()
         for _ in range(steps):
             group.consolidate_column(0, 8, cols_i, lens, whole, masks, zeros, wmask)
-        group.synchronize()
+        group.synchronize_for(wait_ms)
         ms = (time.perf_counter() - t0) / steps * 1e3
         c0.set_async(False)
         s_w, c_w = c0.sum("i64", whole, rows * world, mask=wmask)
@@ -801,10 +801,106 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int):
     return res
 
 
+class _Downgrade(Exception):
+    """The current exchange form cannot be trusted with the job (a deadline, wrong finals, a failed self-test): one notch down."""
+
+
+class _Ladder:
+    """The forms an N > 1 run may take, best first; `down(why)` moves one notch and keeps the reason for the line's
+    `config.downgrades`."""
+
+    def __init__(self, notches):
+        self.notches, self.i, self.downgrades = list(notches), 0, []
+
+    @property
+    def cur(self):
+        return self.notches[self.i]
+
+    def down(self, why: str) -> bool:
+        self.downgrades.append({"abandoned": self.cur["name"], "why": " ".join(str(why).split())[:500]})
+        print(f"bench.py: {self.cur['name']} abandoned: {why}", file=sys.stderr, flush=True)
+        self.i += 1
+        return self.i < len(self.notches)
+
+
+class _Faults:
+    """MA_BENCH_FAULT="stall@setup,corrupt@setup,stall@timed,stall@preflight": faults for the tests of the way down (tests/
+    test_gpu_bench_modes.py), consumed in order; each arms the library's hook (ma_*_test_stall / _corrupt_next_exchange) once,
+    when the run reaches the phase it names."""
+
+    def __init__(self, spec):
+        self.items = [tuple(x.strip().split("@")) for x in (spec or "").split(",") if x.strip()]
+        self.fired = []
+
+    def arm(self, phase: str, hooks) -> None:
+        if self.items and self.items[0][1] == phase:
+            kind, _ = self.items.pop(0)
+            hooks[kind]()
+            self.fired.append(f"{kind}@{phase}")
+
+
+def _hang_guard(seconds: float, describe):
+    """The last resort: whatever blocks past every bounded wait (a runtime call that never returns) ends the process with a
+    reason and exit code 3 — never a re-exec, never a silent driver timeout."""
+    import threading
+
+    def hung():
+        print(f"bench.py: gave up after {seconds:.0f} s: {describe()}", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    t = threading.Timer(seconds, hung)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def _bounded(fn, seconds: float):
+    """fn() on a helper thread, waited for at most `seconds`: (finished, value, exception). A call that has not returned
+    (ncclCommInitAll / ncclCommInitRank waiting for a peer that never joins) is left behind on its daemon thread."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:  # noqa: BLE001 — handed to the caller
+            box["error"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    return (not t.is_alive()), box.get("value"), box.get("error")
+
+
+def _group_notches(args, overlap: bool):
+    """The one-process ladder: overlapped exchanges waiting on the scan's stamp -> on an event -> in-stream exchanges ->
+    the calling thread issuing grouped collectives instead of one issue thread per member -> the host fold (no RCCL)."""
+    issue = "caller" if args.group_issue == "caller" else "threads"
+    notches = []
+    if args.exchange != "host":
+        if overlap and args.handoff == "stamp":
+            notches.append({"name": f"rccl, overlapped, hand-off by stamp, issue {issue}", "exchange": "rccl-overlap", "issue": issue, "handoff": "stamp"})
+        if overlap:
+            notches.append({"name": f"rccl, overlapped, hand-off by event, issue {issue}", "exchange": "rccl-overlap", "issue": issue, "handoff": "event"})
+        notches.append({"name": f"rccl, in-stream, issue {issue}", "exchange": "rccl", "issue": issue, "handoff": None})
+        if issue == "threads":
+            notches.append({"name": "rccl, in-stream, issue caller (grouped)", "exchange": "rccl", "issue": "caller", "handoff": None})
+    notches.append({"name": f"host fold, issue {issue}", "exchange": "host", "issue": issue, "handoff": None})
+    return notches
+
+
 def run_group(args, result_fd) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher: ONE process drives the N GPUs through the C ABI's group
     API (one context per device, enqueue-only scans, one grouped RCCL all-gather + device fold per step) — the shape a
-    Rust host takes. No torch: device memory comes from ma_dev_alloc on each member's context."""
+    Rust host takes. No torch: device memory comes from ma_dev_alloc on each member's context.
+
+    First contact (round 5): nothing here waits without a deadline. The group is created on a helper thread (ncclCommInitAll);
+    ma_group_selftest runs first (`config.preflight`); the set-up step's finals are checked on every member; every wait of
+    the settle / warm-up / timed phases is ma_group_synchronize_for. A deadline, a failed self-test or wrong finals move the run
+    one notch down its ladder (_group_notches) — ma_group_rebuild_exchange keeps the members and their columns — and the
+    measurement starts over there, before anything is reported: `config.exchange` names the form that ran,
+    `config.downgrades` what was abandoned and why."""
     from minarrow_amd import ffi
     from minarrow_amd.host import Group
 
@@ -816,12 +912,31 @@ def run_group(args, result_fd) -> int:
     scaling, total_rows, chunks = _split(args, world)
     lens = [hi - lo for lo, hi in chunks]
     overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
-    group = Group(list(range(world)),
-                  exchange="host" if args.exchange == "host" else ("rccl-overlap-or-host" if overlap else "rccl-or-host"),
-                  issue="caller" if args.group_issue == "caller" else "threads")
+    ladder = _Ladder(_group_notches(args, overlap))
+    wait_ms = args.wait_seconds * 1e3
+    phase = ["creating the group"]
+    guard = _hang_guard(args.headline_seconds, lambda: f"one-process group mode, {ladder.cur['name'] if ladder.i < len(ladder.notches) else 'no form left'}, while {phase[0]}")
+    faults = _Faults(os.environ.get("MA_BENCH_FAULT"))
+
+    def create(notch):
+        return Group(list(range(world)), exchange=notch["exchange"], issue=notch["issue"])
+
+    group, left_behind = None, [False]  # left_behind: a helper thread is still inside a runtime call that never returned
+    while group is None:
+        notch = ladder.cur
+        done, value, err = _bounded(lambda n=notch: create(n), args.init_seconds if notch["exchange"] != "host" else args.headline_seconds)
+        if done and err is None:
+            group = value
+        elif notch["exchange"] == "host":
+            raise err if err is not None else RuntimeError("the host-fold group could not be created")
+        else:
+            why = f"creating the group did not return within {args.init_seconds:.0f} s (ncclCommInitAll)" if not done else f"{err}"
+            left_behind[0] = left_behind[0] or not done
+            while ladder.cur["exchange"] != "host":  # RCCL could not even be set up: straight to the form without it
+                ladder.down(why)
     ctxs = [group.member_ctx(i) for i in range(world)]
     for c in ctxs:
-        c.set_variant(args.variant | (4096 if args.handoff == "event" else 0))  # ctx variant bit 4096: overlapped exchanges wait on events
+        c.set_variant(args.variant)
         c.set_blocks_per_cu(args.blocks_per_cu)
     cols_i = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
     cols_f = [c.alloc(max(n, 8) * 8) for c, n in zip(ctxs, lens)]
@@ -830,76 +945,132 @@ def run_group(args, result_fd) -> int:
         c.synth_iota("f64", cols_f[r], lens[r], chunks[r][0])
 
     fused = args.step != "separate"  # the partitioned step as ONE launch per member (ma_group_enqueue_sum_table)
-
     enqueue_fused = group.prepare_sum_table([("l", 0, cols_i, lens), ("g", 0, cols_f, lens)])  # pointer tables built once
+    hooks = {"stall": lambda: group.test_stall_next_exchange(world - 1), "corrupt": lambda: group.test_corrupt_next_exchange(world - 1)}
 
-    def step():
+    def step(mark=None):
+        if mark is not None:  # timing marks (HIP events) on every member's stream, around its scan launch alone
+            for c in ctxs:
+                c.mark(mark)
         if fused:
             enqueue_fused()
         else:
             group.enqueue_sum("i64", 0, cols_i, lens)
             group.enqueue_sum("f64", 0, cols_f, lens)
+        if mark is not None:
+            for c in ctxs:
+                c.mark(mark + 1)
         group.exchange()
 
-    step()  # set-up, never timed: first use of the communicator and of the fold kernel
-    group.synchronize()
-    ramp_steps, ramp_spent, settled = _settle(step, group.synchronize, args)  # clocks up, the box quiet (see run_native)
-    for _ in range(args.warmup):
-        step()
-    group.synchronize()
-    group.exchange_stats()  # forget the set-up's samples
-    host_issue = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    host_issue = time.perf_counter() - t0  # the calling thread's time inside the enqueue calls (the GPUs are still busy)
-    group.synchronize()
-    elapsed = time.perf_counter() - t0
-    stats = group.exchange_stats()  # all-gather / fold durations on member 0's exchange stream, every 4th exchange
+    def drain():
+        group.synchronize_for(wait_ms)
 
-    finals = group.result(0)
-    ok = _check(total_rows, finals) and all(group.result(0, m) == finals for m in range(world))
-    # Kernel durations (outside the timed region): HIP events on each member's stream around 5 launches of its scan(s).
+    def apply(notch):
+        """Makes the group's exchange the notch's (a rebuild keeps members, contexts and columns)."""
+        have = ("host" if group.exchange_kind == "host" else ("rccl-overlap" if group.overlapped else "rccl"), group.issue_kind)
+        if group.is_broken or have != (notch["exchange"], notch["issue"]):
+            done, _, err = _bounded(lambda: group.rebuild_exchange(notch["exchange"], notch["issue"]), args.init_seconds)
+            if not done:
+                left_behind[0] = True
+                raise RuntimeError(f"rebuilding the exchange as '{notch['name']}' did not return within {args.init_seconds:.0f} s; "
+                                   "the group is held by that call")
+            if err is not None:
+                raise _Downgrade(f"the exchange could not be set up: {err}")
+        if notch["handoff"] is not None:
+            group.set_handoff(notch["handoff"])
+            if notch["handoff"] == "stamp" and group.handoff != "stamp":
+                raise _Downgrade("this runtime gave the group no waitable stamp words")
+
+    # Kernel durations come from timing marks (HIP events on each member's stream around its scan launch), inside the timed
+    # region like run_native's: every step against 1.1-ms scans, every 4th against the 0.14-ms scans of an 8-way partition.
+    every = 1 if lens[0] >= 250_000_000 else max(1, min(4, args.steps // 3))
+    marked = {k: 2 * j for j, k in enumerate(range(0, args.steps, every))}
+    preflight, attempts = None, 0
+    while True:
+        notch = ladder.cur
+        attempts += 1
+        try:
+            phase[0] = "setting up the exchange"
+            apply(notch)
+            phase[0] = "the self-test"
+            faults.arm("preflight", hooks)
+            # the notch's own exchange form + peer copies; the stamp waits only where the notch hands off by stamp
+            preflight = group.selftest(wait_ms, 1 | 4 | (8 if notch["handoff"] == "stamp" else 0))
+            if not preflight["ok"]:
+                raise _Downgrade("the self-test failed: " + preflight["text"])
+            phase[0] = "the set-up step"
+            faults.arm("setup", hooks)
+            step()  # set-up, never timed: first use of the communicator and of the fold kernel
+            drain()
+            wrong = [m for m in range(world) if not _check(total_rows, group.result(0, m))]
+            if wrong:
+                raise _Downgrade(f"the set-up step's finals are wrong on member(s) {wrong}: {group.result(0, wrong[0])}")
+            phase[0] = "the settle / warm-up steps"
+            ramp_steps, ramp_spent, settled = _settle(step, drain, args)  # clocks up, the box quiet (see run_native)
+            for _ in range(args.warmup):
+                step()
+            drain()
+            group.exchange_stats()  # forget the set-up's samples
+            phase[0] = "the timed steps"
+            faults.arm("timed", hooks)
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step(marked.get(k))
+            host_issue = time.perf_counter() - t0  # the calling thread's time inside the enqueue calls (the GPUs are still busy)
+            drain()
+            elapsed = time.perf_counter() - t0
+            stats = group.exchange_stats()  # all-gather / fold durations on member 0's exchange stream, every 4th exchange
+            finals = group.result(0)
+            ok = _check(total_rows, finals) and all(group.result(0, m) == finals for m in range(world))
+            if not ok:
+                raise _Downgrade(f"the timed steps' finals are wrong: {finals}")
+            break
+        except (_Downgrade, ffi.MinarrowHipError) as e:
+            if not ladder.down(str(e)):
+                guard.cancel()
+                print(f"bench.py: no exchange form left ({len(ladder.downgrades)} abandoned); last: {e}", file=sys.stderr, flush=True)
+                os._exit(1)  # nothing was measured; nothing here may wait for a stream or a helper thread on the way out
+    guard.cancel()
+
+    # Per-member scan time of a step, from the marks inside the timed loop (they bracket the scan launch alone in every form).
+    per_member = []
+    for c in ctxs:
+        ms = [c.mark_elapsed_ms(m, m + 1) for m in marked.values()]
+        per_member.append({"avg": sum(ms) / len(ms), "min": min(ms), "max": max(ms)})
+    if fused:
+        kernels = {"sum_fused": {"avg_ms": per_member[0]["avg"], "min_ms": per_member[0]["min"], "max_ms": per_member[0]["max"],
+                                 "timed_steps": len(marked)}}
+    else:  # two launches between the marks: split by the columns' equal bytes (the fused form is the default)
+        half = per_member[0]["avg"] / 2
+        kernels = {"sum_i64": {"avg_ms": half, "min_ms": per_member[0]["min"] / 2, "timed_steps": len(marked),
+                               "timed": "half of the marks' span over both launches"},
+                   "sum_f64": {"avg_ms": half, "min_ms": per_member[0]["min"] / 2, "timed_steps": len(marked),
+                               "timed": "half of the marks' span over both launches"}}
     c0 = ctxs[0]
-    slots = [c.alloc(64) for c in ctxs]
-
-    def scan_ms(m, which):
-        c, sl = ctxs[m], slots[m]
-        if which == "fused":
-            fn = lambda: c.sum_fused([("l", cols_i[m], lens[m], sl.ptr), ("g", cols_f[m], lens[m], sl.ptr + 16)])  # noqa: E731
-        elif which == "i64":
-            fn = lambda: c.sum_into("i64", cols_i[m], lens[m], out_sum=sl.ptr, out_count=sl.ptr + 8)  # noqa: E731
-        else:
-            fn = lambda: c.sum_into("f64", cols_f[m], lens[m], out_sum=sl.ptr, dd_lo=sl.ptr + 8, out_count=sl.ptr + 16)  # noqa: E731
-        return _timed(c, fn, 5, 1)
-
-    kernels = {}
-    for which in (("fused",) if fused else ("i64", "f64")):
-        ms = scan_ms(0, which)
-        kernels["sum_" + which] = {"avg_ms": ms, "min_ms": ms, "timed": "5 launches on GPU 0 after the timed region"}
-    per_member = [sum(scan_ms(m, w) for w in (("fused",) if fused else ("i64", "f64"))) for m in range(world)]
+    scan_min, scan_max = min(p["avg"] for p in per_member), max(p["avg"] for p in per_member)
+    form = ("RCCL all-gather (ncclCommInitAll; " +
+            ("one per member issue thread" if group.issue_kind == "threads" else "grouped on the calling thread") + ") + device fold, " +
+            (f"on side streams, overlapped with the next step's scans, hand-off by {group.handoff}" if group.overlapped else "on the scan streams")
+            if group.exchange_kind == "rccl" else "host fold of pinned records")
     out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
                        f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
-                       ("RCCL all-gather (ncclCommInitAll; grouped on the calling thread when there is more than one member) + "
-                        "device fold, " +
-                        ("on side streams, overlapped with the next step's scans" if overlap else "on the scan streams")
-                        if group.exchange_kind == "rccl" else "host fold of pinned records") +
-                       (f" [{group.exchange_note}]" if group.exchange_note else ""),
+                       form + (f" [{group.exchange_note}]" if group.exchange_note else ""),
                        {"rccl_ranks": stats["rccl_ranks"], "launch": "single process",
                         "step": "one fused launch per member (ma_group_enqueue_sum_table)" if fused else "two launches per member",
                         "host": "torch-free", "hip_runtime": _hip_runtime_path(), "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
+                        "exchange_form": notch["name"], "downgrades": ladder.downgrades, "attempts": attempts,
+                        "preflight": preflight, "faults_injected": faults.fired,
                         "host_issue_us_per_step": host_issue / args.steps * 1e6,
                         "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
-                        "scan_ms_per_step_min_over_members": min(per_member), "scan_ms_per_step_max_over_members": max(per_member)})
-    for sl in slots:
-        sl.free()
+                        "scan_ms_per_step_min": scan_min, "scan_ms_per_step_max": scan_max,
+                        "scan_ms_per_step_min_over_members": scan_min, "scan_ms_per_step_max_over_members": scan_max})
     rc = 0 if ok else 1
     for b in cols_i + cols_f:
         b.free()
     if (scaling == "strong" and world > 1) or args.force_group:
         _n1_same_process(c0, total_rows, args.steps, args.warmup, out)
     if not args.no_other_configs:
-        guard = _Deadline(args.other_seconds, result_fd, out, rc)
+        guard2 = _Deadline(args.other_seconds, result_fd, out, rc)
         try:
             rows = args.other_rows or args.rows
             cols_i = [c.alloc(rows * 8) for c in ctxs]
@@ -907,7 +1078,7 @@ def run_group(args, result_fd) -> int:
             for r, c in enumerate(ctxs):
                 c.synth_iota("i64", cols_i[r], rows, r * rows)
                 c.synth_iota("f64", cols_f[r], rows, r * rows)
-            out["other_configs"] = group_other_configs(group, ctxs, cols_i, cols_f, rows, args.other_reps)
+            out["other_configs"] = group_other_configs(group, ctxs, cols_i, cols_f, rows, args.other_reps, wait_ms)
             if not out["other_configs"]["parity_ok"]:
                 rc = 1
             for b in cols_i + cols_f:
@@ -915,10 +1086,13 @@ def run_group(args, result_fd) -> int:
         except Exception as e:  # noqa: BLE001 — the headline line must still be printed
             out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
             rc = 1
-        guard.cancel()
+        guard2.cancel()
     _emit(result_fd, out)
     if not ok:
         print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
+    if group.is_broken == 2 or left_behind[0]:
+        sys.stderr.flush()
+        os._exit(rc)  # a stream that never ran empty, or a thread still inside the runtime: nothing may wait for it on the way out
     group.close()
     return rc
 
@@ -1077,7 +1251,7 @@ def _settle(step, synchronize, args, agree=None):
         out_of_time = spent >= max(args.settle_ms, args.ramp_ms)
         go_on = not (settled or out_of_time)
         if agree is not None:
-            go_on = agree(go_on)
+            go_on = agree(go_on)  # may raise _Downgrade on every rank at once (a rank's bounded drain ran out)
         if not go_on:
             return steps, spent, settled
 
@@ -1174,29 +1348,95 @@ def run_native(args, result_fd) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # The exchange. native: the library's own RCCL communicator (ncclCommInitRank from an id rank 0 made and the gloo group
-    # carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up on every rank — or the ranks share a
-    # GPU (--backend gloo: a rehearsal, RCCL refuses two ranks on one device) — the 64-byte records take the detour over host
-    # memory through gloo instead (never a reported multi-GPU figure).
-    comm, comm_note = None, ""
-    if distributed and not rehearsal and args.exchange != "host":
-        try:
-            ids = [Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = Comm(ctx, ids[0], rank, world)
-        except Exception as e:  # noqa: BLE001
-            comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
-        if not all(gather_obj(comm is not None)):
-            if comm is not None:
-                comm.close()
-            comm = None
-            comm_note = comm_note or "native communicator unavailable on another rank"
-    overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and comm is not None and world > 1)
-    overlap = overlap and comm is not None
+    def all_ok(ok: bool) -> bool:
+        """The ranks' common verdict (gloo, CPU side; also the barrier every fence needs)."""
+        if dist is None:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def reasons(why: str) -> str:
+        """After all_ok said no: which ranks, and what they saw."""
+        seen = [(r, w) for r, w in enumerate(gather_obj(why)) if w]
+        return "; ".join(f"rank {r}: {w}" for r, w in seen[:4]) or "another rank reported a failure"
+
+    # The exchange and its way down (round 5). Best first: the library's own RCCL communicator (ncclCommInitRank from an id
+    # rank 0 made and the gloo group carried) with the exchange of step k overlapped with the scans of step k + 1, handed off
+    # by the scan's stamp -> by an event -> the same communicator in-stream -> the 64-byte records over host memory through gloo
+    # (no RCCL at all; also what a rehearsal with ranks sharing a GPU uses — never a reported multi-GPU figure). Nothing waits
+    # without a deadline: communicator creation runs on a helper thread, ma_comm_selftest goes first, every fence is
+    # ma_comm_synchronize_for; the ranks agree over gloo after each, and a deadline / failed self-test / wrong finals on ANY
+    # rank moves ALL ranks one notch down (the communicator is aborted, a new one is made from a fresh id) before anything is
+    # reported.
+    wait_ms = args.wait_seconds * 1e3
     fused = args.step == "fused" or (args.step == "auto" and (world > 1 or distributed))
-    exs = [Records(ctx, world) for _ in range(2 if overlap else 1)]
+    want_overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and world > 1)
+    notches = []
+    if distributed and not rehearsal and args.exchange != "host":
+        if want_overlap and fused and args.handoff == "stamp":
+            notches.append({"name": "ma_comm, overlapped, hand-off by stamp", "kind": "comm", "overlap": True, "stamp": True})
+        if want_overlap:
+            notches.append({"name": "ma_comm, overlapped, hand-off by event", "kind": "comm", "overlap": True, "stamp": False})
+        notches.append({"name": "ma_comm, in-stream", "kind": "comm", "overlap": False, "stamp": False})
+    if world > 1:
+        notches.append({"name": "records over host memory (gloo)", "kind": "host", "overlap": False, "stamp": False})
+    else:
+        notches.append({"name": "none (one rank): device fold on the scan stream", "kind": "none", "overlap": False, "stamp": False})
+    ladder = _Ladder(notches)
+    faults = _Faults(os.environ.get("MA_BENCH_FAULT"))
+    phase = ["setting up"]
+    hang_guard = None
+    if distributed:  # the last resort: a runtime or gloo call that never returns ends the job with a reason, not with the driver's timeout
+        hang_guard = _hang_guard(args.headline_seconds, lambda: f"rank {rank}, {ladder.cur['name'] if ladder.i < len(notches) else 'no form left'}, "
+                                                                f"while {phase[0]}")
+
+    from types import SimpleNamespace
+
+    S = SimpleNamespace(comm=None, overlap=False, exs=[], stamps=None, stamp_seq=[], fused_calls={}, counter=0, wedged=False)
     ctx.set_async(True)
-    counter = [0]
+
+    def teardown(abort: bool):
+        if S.comm is not None:
+            if abort and not S.comm.is_broken:
+                S.comm.abort()  # local: needs no peer; ends whatever collective of ours is still in flight
+            if S.comm.is_broken != 2:
+                S.comm.close()
+            S.comm = None
+        if abort:
+            ctx.synchronize()  # the scans themselves are this rank's own
+        for ex in S.exs:
+            ex.free()
+        for st in (S.stamps or []):
+            ctx.stamp_free(st)
+        S.exs, S.stamps, S.fused_calls, S.counter = [], None, {}, 0
+
+    def setup(notch):
+        S.overlap = notch["overlap"]
+        if notch["kind"] == "comm":
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids = [Comm.unique_id()]
+                except Exception as e:  # noqa: BLE001 — the other ranks wait in the broadcast below
+                    ids = [f"error: {e}"]
+            dist.broadcast_object_list(ids, src=0)
+            ok, why = False, ""
+            if isinstance(ids[0], (bytes, bytearray)):
+                done, value, err = _bounded(lambda: Comm(ctx, bytes(ids[0]), rank, world), args.init_seconds)
+                if done and err is None:
+                    S.comm, ok = value, True
+                elif not done:
+                    why, S.wedged = f"ncclCommInitRank did not return within {args.init_seconds:.0f} s", True
+                else:
+                    why = str(err)
+            else:
+                why = f"rank 0 could not make a communicator id ({ids[0]})"
+            if not all_ok(ok):
+                raise _Downgrade("the communicator could not be created: " + reasons(why))
+        S.exs = [Records(ctx, world) for _ in range(2 if S.overlap else 1)]
+        S.stamps = [ctx.stamp_alloc() for _ in S.exs] if notch["stamp"] else None
+        S.stamp_seq = [0 for _ in S.exs]
 
     def host_exchange(ex):
         """gloo detour: this rank's records to the host, all-gather among the hosts, back, device fold."""
@@ -1208,6 +1448,7 @@ def run_native(args, result_fd) -> int:
         ex.fold_on_device(ctx)
 
     def exchange(ex, slot=None, stamp=None):
+        comm = S.comm
         if comm is not None and slot is not None and stamp is not None:
             # the scan's final thread stamped `stamp[0]` with stamp[1]: the exchange stream waits for that, no event on the scan stream
             comm.sum_exchange_overlapped_on_stamp(slot, stamp[0], stamp[1], ex.local, 1, ex.n_columns, ex.gathered, ex.final)
@@ -1220,29 +1461,25 @@ def run_native(args, result_fd) -> int:
         else:
             ex.fold_on_device(ctx)  # one rank: nothing to exchange, the rank-ordered fold of one record
 
-    fused_calls = {}
-    stamps = [ctx.stamp_alloc() for _ in exs] if (overlap and fused and args.handoff == "stamp") else None
-    stamp_seq = [0 for _ in exs]
-
     def step(marks=None):
-        k = counter[0] % len(exs)
-        counter[0] += 1
-        ex = exs[k]
+        k = S.counter % len(S.exs)
+        S.counter += 1
+        ex = S.exs[k]
         stamp = None
-        if overlap:
-            comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
+        if S.overlap:
+            S.comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
         if marks is not None:
             ctx.mark(marks)
         if fused:
-            if id(ex) not in fused_calls:  # the argument table of a record set is built once
-                fused_calls[id(ex)] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
-                                                            stamp=stamps[k] if stamps else 0)
-            if stamps:
-                stamp_seq[k] += 1
-                fused_calls[id(ex)](stamp_seq[k])
-                stamp = (stamps[k], stamp_seq[k])
+            if k not in S.fused_calls:  # the argument table of a record set is built once
+                S.fused_calls[k] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
+                                                         stamp=S.stamps[k] if S.stamps else 0)
+            if S.stamps:
+                S.stamp_seq[k] += 1
+                S.fused_calls[k](S.stamp_seq[k])
+                stamp = (S.stamps[k], S.stamp_seq[k])
             else:
-                fused_calls[id(ex)]()
+                S.fused_calls[k]()
         else:
             ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
             if marks is not None:
@@ -1250,43 +1487,28 @@ def run_native(args, result_fd) -> int:
             ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if marks is not None:
             ctx.mark(marks + 2)
-        exchange(ex, k if overlap else None, stamp)
+        exchange(ex, k if S.overlap else None, stamp)
+
+    def drain_local() -> str:
+        """This rank's bounded wait; the reason when it ran out (never raises: the ranks decide together)."""
+        try:
+            if S.comm is not None:
+                S.comm.synchronize_for(wait_ms)  # the context's stream and the exchange stream
+            else:
+                ctx.synchronize()
+            return ""
+        except Exception as e:  # noqa: BLE001
+            return str(e)
 
     def fence():
-        if dist is not None:
-            dist.barrier()
-        ctx.synchronize()
-        if comm is not None:
-            comm.synchronize()
+        """Every rank's work has finished — or every rank learns that some rank's did not (one all-reduce: also the barrier)."""
+        why = drain_local()
+        if not all_ok(not why):
+            raise _Downgrade(reasons(why))
 
-    hang_guard = None
-    if distributed:  # a collective that never completes must end the job with a reason, not with the driver's timeout
-        import threading
+    def last_results():
+        return S.exs[(S.counter - 1) % len(S.exs)].results()
 
-        def hung():
-            print(f"rank {rank}: the headline's exchange did not complete within {args.headline_seconds:.0f} s "
-                  f"(exchange: {'ma_comm_*' if comm is not None else 'gloo over host memory'}, overlap: {overlap}); "
-                  "try --exchange host or --overlap off", file=sys.stderr, flush=True)
-            os._exit(3)
-
-        hang_guard = threading.Timer(args.headline_seconds, hung)
-        hang_guard.daemon = True
-        hang_guard.start()
-    step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
-    fence()
-    if comm is not None:
-        # The library's communicator has only ever run with one rank before a multi-GPU node sees it: the set-up step's finals
-        # are checked on every rank, and if ANY rank's fold is wrong (or MA_BENCH_DISTRUST_NATIVE_COMM asks, for the test of
-        # this branch) all ranks drop to the host exchange before anything is timed.
-        good = _check(total_rows, exs[(counter[0] - 1) % len(exs)].results()) and not os.environ.get("MA_BENCH_DISTRUST_NATIVE_COMM")
-        if not all(gather_obj(bool(good))):
-            comm.synchronize()
-            comm.close()
-            comm, overlap = None, False
-            comm_note = "the library's communicator failed the set-up check on some rank: records over host memory (gloo) instead"
-            exs = exs[:1]
-            step()
-            fence()
     # Clocks: a GPU that was idle a moment ago needs ~0.1 s of work before its clocks are up (tools/probe_sustain.c: the first
     # 20 ms of a process read at 4 TB/s, 7.2 from 0.1 s on). The process has only generated its columns so far; --ramp-ms of the
     # step itself (default 200 ms, un-timed, before the W warm-up steps) put it where any host that has been running is.
@@ -1294,37 +1516,86 @@ def run_native(args, result_fd) -> int:
     # exited (35 GB/s, during which scans read 5 % slower: profiles/r04_read_rate_states_root_cause.txt — a torch-hosted
     # process never saw it because importing torch takes longer than the clear): it goes on until three consecutive batches
     # of 4 steps are within 1.5 % of the fastest batch so far, for at most --settle-ms.
-    def agree(go_on):  # any rank that wants another batch keeps every rank going (gloo, CPU side)
-        t = torch.tensor([1 if go_on else 0], dtype=torch.int32)
+    settle_why = [""]
+
+    def settle_drain():
+        settle_why[0] = settle_why[0] or drain_local()
+
+    def agree(go_on):  # any rank that wants another batch keeps every rank going; any rank whose drain ran out stops all
+        t = torch.tensor([1 if go_on else 0, 1 if settle_why[0] else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return bool(t.item())
+        if int(t[1]):
+            raise _Downgrade(reasons(settle_why[0]))
+        return bool(int(t[0]))
 
-    def drain():
-        ctx.synchronize()
-        if comm is not None:
-            comm.synchronize()
-
-    ramp_steps, ramp_spent, settled = _settle(step, drain, args, agree if dist is not None else None)
-    for _ in range(args.warmup):
-        step()
-    fence()
     # Kernel durations: timing marks (HIP events on the launch stream) around each scan, inside the timed region. A mark costs
     # a few us of stream time; against 1.1 ms scans (10^9 rows on one GPU) every step carries them, against the 0.14 ms scans
     # of an 8-way partition only every 4th step does (at least 3 steps).
     every = 1 if rows >= 250_000_000 else max(1, min(4, args.steps // 3))
     marked = {k: 3 * j for j, k in enumerate(range(0, args.steps, every))}
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(marked.get(k))
-    fence()
-    elapsed = time.perf_counter() - t0
+    preflight, attempts = None, 0
+    while True:
+        notch = ladder.cur
+        attempts += 1
+        try:
+            phase[0] = "creating the communicator"
+            setup(notch)
+            hooks = {"stall": lambda: S.comm.test_stall_next_exchange(), "corrupt": lambda: S.comm.test_corrupt_next_exchange()}
+            if S.comm is not None:
+                phase[0] = "the self-test"
+                faults.arm("preflight", hooks)
+                # the notch's own form: in-stream / overlapped on an event / overlapped on the scan's stamp
+                rep = S.comm.selftest(wait_ms, 1 if not notch["overlap"] else (32 if notch["stamp"] else 16))
+                preflight = rep
+                if not all_ok(rep["ok"]):
+                    raise _Downgrade("the self-test failed: " + reasons("" if rep["ok"] else rep["text"]))
+            phase[0] = "the set-up step"
+            if S.comm is not None:
+                faults.arm("setup", hooks)
+            step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
+            fence()
+            # The library's communicator has only ever run with one rank before a multi-GPU node sees it: the set-up step's finals
+            # are checked on every rank (MA_BENCH_DISTRUST_NATIVE_COMM fails the check of every ma_comm form, for the test of this branch)
+            good = _check(total_rows, last_results()) and not (S.comm is not None and os.environ.get("MA_BENCH_DISTRUST_NATIVE_COMM"))
+            if not all_ok(good):
+                raise _Downgrade("the set-up check failed: " + reasons("" if good else f"finals {last_results()}"))
+            phase[0] = "the settle / warm-up steps"
+            settle_why[0] = ""
+            ramp_steps, ramp_spent, settled = _settle(step, settle_drain if dist is not None else (lambda: ctx.synchronize()), args,
+                                                      agree if dist is not None else None)
+            for _ in range(args.warmup):
+                step()
+            fence()
+            phase[0] = "the timed steps"
+            if S.comm is not None:
+                faults.arm("timed", hooks)
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step(marked.get(k))
+            host_issue = time.perf_counter() - t0  # this rank's time inside the enqueue calls (its GPU is still busy)
+            fence()
+            elapsed = time.perf_counter() - t0
+            finals = last_results()  # the LAST step's finals
+            ok = _check(total_rows, finals)
+            if notch["kind"] != "none" and ladder.i + 1 < len(notches) and not all_ok(ok):
+                raise _Downgrade("the timed steps' finals are wrong: " + reasons("" if ok else f"finals {finals}"))
+            break
+        except _Downgrade as e:
+            phase[0] = "leaving an exchange form"
+            wedged = not all_ok(not S.wedged)  # a creation that never returned, on any rank: no further RCCL attempts anywhere
+            teardown(abort=True)
+            more = ladder.down(str(e))
+            while more and wedged and ladder.cur["kind"] == "comm":
+                more = ladder.down("a rank's ncclCommInitRank never returned: no further RCCL attempts")
+            if not more:
+                print(f"bench.py: rank {rank}: no exchange form left ({len(ladder.downgrades)} abandoned); last: {e}", file=sys.stderr, flush=True)
+                os._exit(1)  # nothing was measured (every rank gets here together)
     if hang_guard is not None:
         hang_guard.cancel()
     elapsed = max_over_ranks(elapsed)
+    comm, overlap, exs, stamps = S.comm, S.overlap, S.exs, S.stamps
 
-    # ---- verify the job's answer (outside the timed region) ------------------------------------------
-    finals = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
-    ok = _check(total_rows, finals)
+    # ---- the job's answer was verified above, outside the timed region (finals, ok) -----------------------
     if fused:
         ms = [ctx.mark_elapsed_ms(m, m + 2) for m in marked.values()]
         kernels = {"sum_fused": {"avg_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms), "timed_steps": len(ms)}}
@@ -1351,18 +1622,23 @@ def run_native(args, result_fd) -> int:
             parallelism = f"row-chunk x{world}, one process per GPU"
             exch = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
                     ("" if overlap else ", on the scan stream")) if comm is not None else \
-                "gloo all-gather of the records over host memory + device fold"
-            if comm_note:
-                exch += f" [{comm_note}]"
+                ("gloo all-gather of the records over host memory + device fold" if world > 1 else
+                 "none (one rank): device fold on the scan stream")
         if overlap:
             exch += "; exchange of step k on a side stream, overlapped with the scans of step k + 1" + \
                 (" (hand-off: the scan kernel's stamp, no event on the scan stream)" if stamps else " (hand-off: an event)")
+        if ladder.downgrades:
+            exch += f" [after {len(ladder.downgrades)} abandoned form(s): config.downgrades]"
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
                            {"rccl_ranks": stats["rccl_ranks"], "launch": "torch.distributed.run" if world > 1 else "single process",
                             "step": step_form, "host": "torch-free" if not distributed else "torch-free GPU path (gloo for rendezvous only)",
                             "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                             "hip_runtime": _hip_runtime_path(),
+                            "exchange_form": ladder.cur["name"], "downgrades": ladder.downgrades, "attempts": attempts,
+                            "preflight": preflight, "faults_injected": faults.fired,
+                            "host_issue_us_per_step": host_issue / args.steps * 1e6,
                             "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
+                            "scan_ms_per_step_min": min(scans), "scan_ms_per_step_max": max(scans),
                             "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans)})
         if (scaling == "strong" and world > 1) or args.force_dist:
             _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
@@ -1422,6 +1698,9 @@ def run_native(args, result_fd) -> int:
         _emit(result_fd, out)
         if not ok:
             print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
+    if S.wedged:  # a helper thread is still inside ncclCommInitRank: nothing may wait for it on the way out
+        sys.stderr.flush()
+        os._exit(rc)
     if comm is not None:
         comm.close()
     ctx.close()
@@ -1765,8 +2044,17 @@ def main() -> int:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
-    ap.add_argument("--headline-seconds", type=float, default=120.0,
-                    help="N > 1: give up (exit code 3, reason on stderr) when set-up + warm-up + timed steps take longer")
+    ap.add_argument("--headline-seconds", type=float, default=240.0,
+                    help="N > 1: the last resort — give up (exit code 3, reason on stderr) when set-up + warm-up + timed steps, "
+                         "every downgrade included, take longer")
+    ap.add_argument("--init-seconds", type=float, default=60.0,
+                    help="N > 1: the deadline of creating (or rebuilding) the RCCL communicators — ncclCommInitAll / ncclCommInitRank "
+                         "load several hundred MB of device code on first use and rendezvous all ranks; past it RCCL is given up "
+                         "for the host exchange")
+    ap.add_argument("--wait-seconds", type=float, default=20.0,
+                    help="N > 1: the deadline of every single wait (group / communicator creation, the self-test's steps, the "
+                         "set-up step, each drain of the settle / warm-up / timed phases); past it the exchange form in use is "
+                         "abandoned for the next one down (config.downgrades)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="run each step's scalar exchange on a side stream, overlapped with the next "
                          "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP; torch events with --exchange torch). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "

@@ -1049,7 +1049,10 @@ enum {
     MA_SELFTEST_FORM_OVERLAP_STAMP_THREADS = 4, MA_SELFTEST_FORM_OVERLAP_STAMP_CALLER = 5,
     MA_SELFTEST_FORM_HOST_FOLD = 6
 };
-enum { MA_SELFTEST_EXCHANGE = 1, MA_SELFTEST_EXCHANGE_ALL_FORMS = 2, MA_SELFTEST_PEER_COPIES = 4, MA_SELFTEST_STAMPS = 8 };
+enum {
+    MA_SELFTEST_EXCHANGE = 1, MA_SELFTEST_EXCHANGE_ALL_FORMS = 2, MA_SELFTEST_PEER_COPIES = 4, MA_SELFTEST_STAMPS = 8,
+    MA_SELFTEST_OVERLAP_EVENT = 16, MA_SELFTEST_OVERLAP_STAMP = 32 /* ma_comm_selftest only: one overlapped form each */
+};
 enum { MA_GROUP_HANDOFF_STAMP = 0, MA_GROUP_HANDOFF_EVENT = 1 };
 ma_status ma_group_synchronize_for(ma_group* group, double timeout_ms);
 int32_t ma_group_is_broken(ma_group* group);
@@ -1173,7 +1176,8 @@ ma_status ma_comm_synchronize(ma_comm* comm);
  * ma_comm_selftest is collective: every rank calls it; rank-tagged records go through ma_comm_sum_exchange (in-stream),
  * ma_comm_sum_exchange_overlapped (event) and _on_stamp (stamp) — forms IN_STREAM_CALLER, OVERLAP_EVENT_CALLER,
  * OVERLAP_STAMP_CALLER of the report — each under the deadline, the gathered blocks and the finals checked on this rank;
- * `what` = 0 or MA_SELFTEST_EXCHANGE: the in-stream form and both overlapped ones; peer copies are not a communicator's. */
+ * `what`: MA_SELFTEST_EXCHANGE = the in-stream form, MA_SELFTEST_OVERLAP_EVENT / MA_SELFTEST_OVERLAP_STAMP = that overlapped
+ * form (both record sets), 0 or MA_SELFTEST_EXCHANGE_ALL_FORMS = all three; peer copies are not a communicator's. */
 ma_status ma_comm_synchronize_for(ma_comm* comm, double timeout_ms);
 ma_status ma_comm_abort(ma_comm* comm);
 int32_t ma_comm_is_broken(ma_comm* comm);

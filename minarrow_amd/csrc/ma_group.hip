@@ -361,6 +361,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
     MA_REQUIRE(g != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
     std::lock_guard<std::recursive_mutex> lock(g->mu);
+    MA_REQUIRE(!g->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
     DeviceLookup lookup;
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
         if (chunk_lens[i] == 0) continue;
@@ -852,6 +853,7 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
                "unsupported element format '%c' (numeric primitives only)", (char)format_code);
     const bool is_float = format_code == 'f' || format_code == 'g';
     std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
     const size_t G = group->ctxs.size();
     DeviceLookup lookup;
     for (size_t i = 0; i < n_chunks; ++i) {
@@ -1108,12 +1110,13 @@ ma_status ma_group_exchange_stats(ma_group* group, double* out_all_gather_us, do
         group->host_fold_samples = 0;
         return MA_OK;
     }
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);  // its sampled events may never fire
     MA_HIP(hipSetDevice(group->ctxs[0]->device));
     group->timer.report(out_all_gather_us, out_fold_us, out_samples);
     if (out_rccl_ranks) {
         int n = 0;
         const RcclApi* api = rccl();
-        if (!api || !api->CommCount || group->comms.empty() || api->CommCount(group->comms[0], &n) != ncclSuccess) n = 0;
+        if (!api || !api->CommCount || group->comms.empty() || !group->comms[0] || api->CommCount(group->comms[0], &n) != ncclSuccess) n = 0;
         *out_rccl_ranks = n;
     }
     return MA_OK;
@@ -1131,6 +1134,7 @@ ma_status ma_group_member_result(ma_group* group, int32_t member, int32_t column
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
     std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
     MA_REQUIRE(!(group->overlap && group->use_rccl) || !group->set_used[group->last] ||
                    (group->exchanged_mask[group->last] >> column) & 1u,
                MA_ERR_INVALID_ARGUMENT,

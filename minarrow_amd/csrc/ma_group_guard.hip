@@ -136,8 +136,7 @@ void look(ma_group* g, Pending& p) {
     p.all_done = all;
 }
 
-// Polls until every stream has run empty or `timeout_ms` have passed (spinning for the first 200 us: a step that is nearly
-// done is not made to pay a sleep's wake-up). True when all ran empty.
+// Polls until every stream has run empty or `timeout_ms` have passed. True when all ran empty.
 bool wait_streams(ma_group* g, double timeout_ms, Pending& p) {
     const auto t0 = Clock::now();
     for (;;) {
@@ -145,10 +144,12 @@ bool wait_streams(ma_group* g, double timeout_ms, Pending& p) {
         if (p.all_done || p.error != hipSuccess) return p.all_done;
         const double us = us_since(t0);
         if (us >= timeout_ms * 1e3) return false;
-        if (us < 200.0)
+        // a benchmark's timed region ends in this wait: poll back to back for the first 10 ms, then sleep 1/200 of the time
+        // waited so far (the overshoot stays under ~1 %)
+        if (us < 10e3)
             __builtin_ia32_pause();
         else
-            std::this_thread::sleep_for(std::chrono::microseconds(us < 5e3 ? 20 : 200));
+            std::this_thread::sleep_for(std::chrono::microseconds((long)std::min(500.0, std::max(20.0, us / 200.0))));
     }
 }
 
@@ -594,10 +595,13 @@ ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags) {
         MA_TRY(synchronize_locked(group));
     }
     release_exchange(group);  // drains (now idle) streams, frees both record sets, side contexts, stamps, communicators
-    group->broken = false;
     group->drained = true;
     group->handoff = 0;
-    return configure_exchange(group, flags);
+    const ma_status st = configure_exchange(group, flags);
+    // no exchange at all after a failed set-up (its pieces were released): the group stays refused until a rebuild succeeds
+    group->broken = st != MA_OK;
+    if (st != MA_OK) release_exchange(group);
+    return st;
 }
 
 ma_status ma_group_test_stall_next_exchange(ma_group* group, int32_t member) {

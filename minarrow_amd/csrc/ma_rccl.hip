@@ -5,6 +5,7 @@
 // form (one host thread driving every GPU) is ma_group_* (ma_group.hip).
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <mutex>
@@ -209,10 +210,12 @@ bool comm_wait_streams(ma_comm* comm, double timeout_ms, const char** which, hip
                                               : "the exchange stream (the wait for the scan's hand-off, the all-gather or the fold)";
             return false;
         }
-        if (us < 200.0)
+        // a benchmark's timed region ends in this wait: poll back to back for the first 10 ms, then sleep 1/200 of the time
+        // waited so far (the overshoot stays under ~1 %)
+        if (us < 10e3)
             __builtin_ia32_pause();
         else
-            std::this_thread::sleep_for(std::chrono::microseconds(us < 5e3 ? 20 : 200));
+            std::this_thread::sleep_for(std::chrono::microseconds((long)std::min(500.0, std::max(20.0, us / 200.0))));
     }
 }
 
@@ -267,7 +270,8 @@ ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n
     MA_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, MA_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, n_ranks);
     const RcclApi* api = rccl();
     if (!api) return MA_ERR_UNSUPPORTED;
-    MA_ENTER_PRIMARY(ctx);
+    // The context is NOT held while the ranks rendezvous (ncclCommInitRank returns once all n_ranks have joined — or never,
+    // when one does not): a host that runs this call under its own deadline keeps a usable context either way.
     MA_NO_CAPTURE(ctx, "ma_comm_create");
     MA_HIP(hipSetDevice(ctx->device));
     ncclUniqueId uid;
@@ -472,6 +476,7 @@ ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) {
 ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
                                  int32_t* out_rccl_ranks) {
     MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_REQUIRE(!comm->broken, MA_ERR_DEVICE, "%s", kCommBroken);  // its sampled events may never fire
     ma_ctx* ctx = comm->ctx;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
@@ -549,7 +554,7 @@ ma_status ma_comm_selftest(ma_comm* comm, uint32_t what, double timeout_ms, ma_s
     rep->struct_bytes = (uint32_t)sizeof(*rep);
     rep->failed_form = rep->failed_member = -1;
     MA_REQUIRE(!comm->broken, MA_ERR_DEVICE, "%s", kCommBroken);
-    (void)what;  // the exchange forms are all a communicator has
+    if (what == 0 || (what & MA_SELFTEST_EXCHANGE_ALL_FORMS)) what = MA_SELFTEST_EXCHANGE | MA_SELFTEST_OVERLAP_EVENT | MA_SELFTEST_OVERLAP_STAMP;
     ma_ctx* ctx = comm->ctx;
     const size_t n = (size_t)comm->n_ranks;
     constexpr size_t kCols = 4, kWords = kCols * kRecordWords;
@@ -595,6 +600,8 @@ ma_status ma_comm_selftest(ma_comm* comm, uint32_t what, double timeout_ms, ma_s
     std::vector<std::vector<uint64_t>> blocks;
     for (const Form& f : forms) {
         if (st != MA_OK) break;
+        const uint32_t need = f.slot < 0 ? MA_SELFTEST_EXCHANGE : (f.on_stamp ? MA_SELFTEST_OVERLAP_STAMP : MA_SELFTEST_OVERLAP_EVENT);
+        if (!(what & need)) continue;
         if (f.on_stamp && (!stamp || comm->no_wait_value)) continue;
         rep->forms_tried |= 1u << f.bit;
         ++round;

@@ -710,6 +710,7 @@ class SelftestReport(C.Structure):
 
 
 SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS = 1, 2, 4, 8
+SELFTEST_OVERLAP_EVENT, SELFTEST_OVERLAP_STAMP = 16, 32  # Comm.selftest only
 GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8}
 
 

@@ -127,19 +127,92 @@ def test_launcher_mode_one_rank(exchange, extra):
         assert "torch-hosted" in out["config"]["host"]
 
 
+LAUNCH = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+QUICK = ["--no-cpu-baseline", "--no-other-configs", "--wait-seconds", "2"]
+
+
 def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(monkeypatch):
     """bench.py checks the set-up step's finals on every rank before timing anything; a communicator that folds wrongly
-    (forced here) is dropped on all ranks — for the records over host memory in the default form, for torch.distributed's
-    exchange in the torch-hosted one — and the line says so."""
+    (forced here for every ma_comm form) is abandoned on all ranks, one notch at a time — stamp, event, in-stream — down to the
+    records over host memory in the default form, to torch.distributed's exchange in the torch-hosted one; the line says so."""
     monkeypatch.setenv("MA_BENCH_DISTRUST_NATIVE_COMM", "1")
-    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-            "127.0.0.1", "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+    base = [*LAUNCH, "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
             "--no-other-configs", "--overlap", "on"]
     out = run(base)
-    assert out["parity_ok"] and "set-up check" in out["config"]["exchange"] and "host memory" in out["config"]["exchange"]
+    cfg = out["config"]
+    assert out["parity_ok"] and [d["abandoned"] for d in cfg["downgrades"]] == [
+        "ma_comm, overlapped, hand-off by stamp", "ma_comm, overlapped, hand-off by event", "ma_comm, in-stream"]
+    assert all("set-up check" in d["why"] for d in cfg["downgrades"]) and "3 abandoned" in cfg["exchange"]
+    assert cfg["exchange_form"].startswith("none (one rank)") and cfg["rccl_ranks"] == 0
     out = run(base + ["--torch-hosted"])
     assert out["parity_ok"] and "torch.distributed" in out["config"]["exchange"] and "set-up check" in out["config"]["exchange"]
     assert "side stream" in out["config"]["exchange"]
+
+
+@pytest.mark.parametrize("fault, abandoned, runs_as", [
+    ("stall@setup", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
+    ("corrupt@setup", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
+    ("stall@preflight,stall@setup", ["rccl, overlapped, hand-off by stamp, issue threads", "rccl, overlapped, hand-off by event, issue threads"],
+     "rccl, in-stream, issue threads"),
+    ("stall@timed", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
+    ("stall@setup,stall@setup,corrupt@setup,stall@timed", None, "host fold, issue threads"),
+])
+def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, abandoned, runs_as):
+    """`bench.py --gpus N` in one process, on first contact with an exchange that never completes (or folds wrongly): the
+    line still comes, rc 0, parity ok, and names the form that ran and what was abandoned on the way (the faults are the
+    library's own test hooks, armed through MA_BENCH_FAULT)."""
+    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--overlap", "on", *QUICK], {"MA_BENCH_FAULT": fault},
+              timeout=240)
+    cfg = out["config"]
+    assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
+    assert cfg["exchange_form"] == runs_as, cfg["downgrades"]
+    got = [d["abandoned"] for d in cfg["downgrades"]]
+    if abandoned is not None:
+        assert got == abandoned
+    else:  # all the way down: every RCCL form abandoned in ladder order
+        assert got == ["rccl, overlapped, hand-off by stamp, issue threads", "rccl, overlapped, hand-off by event, issue threads",
+                       "rccl, in-stream, issue threads", "rccl, in-stream, issue caller (grouped)"]
+        assert "host fold" in cfg["exchange"] and cfg["rccl_ranks"] == 0
+    for d in cfg["downgrades"]:
+        assert ("did not finish within" in d["why"]) or ("finals are wrong" in d["why"]) or ("self-test failed" in d["why"]), d
+    assert cfg["preflight"]["ok"] and cfg["attempts"] == len(got) + 1
+
+
+@pytest.mark.parametrize("fault, abandoned, runs_as", [
+    ("stall@setup", ["ma_comm, overlapped, hand-off by stamp"], "ma_comm, overlapped, hand-off by event"),
+    ("corrupt@setup,stall@preflight", ["ma_comm, overlapped, hand-off by stamp", "ma_comm, overlapped, hand-off by event"], "ma_comm, in-stream"),
+    ("stall@timed", ["ma_comm, overlapped, hand-off by stamp"], "ma_comm, overlapped, hand-off by event"),
+])
+def test_launcher_mode_goes_down_its_ladder_instead_of_hanging(fault, abandoned, runs_as):
+    """The same under torch.distributed.run (one process per GPU, ma_comm_*): the ranks agree over gloo after every bounded
+    wait; the communicator is aborted and a new one made from a fresh id for the next form down."""
+    out = run([*LAUNCH, "--master-port", "29643", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--overlap", "on", *QUICK],
+              {"MA_BENCH_FAULT": fault}, timeout=240)
+    cfg = out["config"]
+    assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
+    assert [d["abandoned"] for d in cfg["downgrades"]] == abandoned and cfg["exchange_form"] == runs_as
+    assert cfg["rccl_ranks"] == 1 and cfg["preflight"]["ok"]
+
+
+def test_the_two_n_gt_1_modes_measure_alike():
+    """One process over the GPUs (ma_group_*) and one process per GPU (ma_comm_*) report the same keys, taken the same way —
+    timing marks around the scan inside the timed steps, every 4th exchange sampled — and agree within noise on one GPU."""
+    common = ["--rows", str(1 << 26), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-other-configs", "--overlap", "on"]
+    g = run([sys.executable, "bench.py", *common, "--gpus", "1", "--force-group"])
+    d = run([*LAUNCH, "--master-port", "29644", "bench.py", *common, "--gpus", "1", "--force-dist"])
+    shared = {"exchange_us", "fold_us", "exchange_samples", "host_issue_us_per_step", "scan_ms_per_step_min", "scan_ms_per_step_max",
+              "rccl_ranks", "exchange_form", "downgrades", "preflight", "attempts", "step", "clock_ramp"}
+    assert shared <= set(g["config"]) and shared <= set(d["config"])
+    assert g["parity_ok"] and d["parity_ok"] and g["result"] == d["result"]
+    assert set(g["kernels"]) == set(d["kernels"]) == {"sum_fused"}
+    assert g["kernels"]["sum_fused"]["timed_steps"] == d["kernels"]["sum_fused"]["timed_steps"] >= 3
+    for a, b in ((g["kernels"]["sum_fused"]["avg_ms"], d["kernels"]["sum_fused"]["avg_ms"]),
+                 (g["config"]["scan_ms_per_step_max"], d["config"]["scan_ms_per_step_max"]), (g["ms_per_step"], d["ms_per_step"])):
+        assert 0.8 < a / b < 1.25, (a, b)
+    for key in ("exchange_us", "fold_us"):  # a 1-rank all-gather and a 1-record fold: microseconds either way
+        assert 0 < g["config"][key] < 500 and 0 < d["config"][key] < 500
+    assert g["config"]["downgrades"] == d["config"]["downgrades"] == []
+    assert "hand-off by stamp" in g["config"]["exchange_form"] and "hand-off by stamp" in d["config"]["exchange_form"]
 
 
 @pytest.mark.parametrize("ranks", [2, 3])
