@@ -156,6 +156,20 @@ class Group {
         check(ma_group_exchange(g_));
     }
     void wait() const { check(ma_group_synchronize(g_)); }
+    // wait() with a deadline (ma_group_synchronize_for): past it the group's communicators are aborted and KernelError names
+    // the members and phases still pending — a Rayon worker's panic, instead of a host blocked for good. broken() then says
+    // whether rebuild() can give the same members a fresh exchange (1) or a stream never ran empty (2).
+    void wait_for(double timeout_ms) const { check(ma_group_synchronize_for(g_, timeout_ms)); }
+    int broken() const { return ma_group_is_broken(g_); }
+    void rebuild(uint32_t flags) const { check(ma_group_rebuild_exchange(g_, flags)); }
+    uint32_t flags() const { return ma_group_flags(g_); }
+    // Proves the exchange (rank-tagged records, in the group's own form), the stamp hand-off and every peer link before a job
+    // is trusted to them, each step under the deadline (ma_group_selftest). Returns the report; throws when something failed.
+    ma_selftest_report selftest(double timeout_ms, uint32_t what = 0) const {
+        ma_selftest_report rep;
+        check(ma_group_selftest(g_, what, timeout_ms, &rep));
+        return rep;
+    }
     std::pair<int64_t, double> sums(int32_t column) const {
         int64_t i = 0;
         double f = 0;

@@ -121,6 +121,7 @@ struct ma_ctx {
     size_t table_stage_bytes[kTableSlots] = {};
     hipEvent_t table_ev[kTableSlots] = {};
     bool table_busy[kTableSlots] = {};
+    bool table_mapped[kTableSlots] = {};  // committed in place (table_commit_mapped) and not yet released: its event says nothing yet
     size_t table_high_water = 0;          // largest table this context has staged (new slots are sized for it)
     std::vector<void*> table_garbage;     // outgrown staging buffers: freed with the context (hipHostFree drains the device)
     int table_next = 0;

@@ -444,6 +444,7 @@ ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host) {
     int pick = -1, spare = -1;
     for (int i = 0; i < ma_ctx::kTableSlots && pick < 0; ++i) {
         const int k = (ctx->table_next + i) % ma_ctx::kTableSlots;
+        if (ctx->table_mapped[k]) continue;  // a launched kernel reads it in place; its event is only recorded by table_release
         if (ctx->table_busy[k]) {
             const hipError_t q = hipEventQuery(ctx->table_ev[k]);
             if (q == hipSuccess) {
@@ -458,7 +459,11 @@ ma_status table_begin(ma_ctx* ctx, size_t bytes, void** out_host) {
     }
     if (pick < 0) pick = spare;
     if (pick < 0) {
-        pick = ctx->table_next;
+        for (int i = 0; i < ma_ctx::kTableSlots && pick < 0; ++i) {  // the oldest slot whose event HAS been recorded
+            const int k = (ctx->table_next + i) % ma_ctx::kTableSlots;
+            if (!ctx->table_mapped[k]) pick = k;
+        }
+        MA_REQUIRE(pick >= 0, MA_ERR_DEVICE, "every staging slot is held by a table read in place (table_commit_mapped without table_release)");
         MA_HIP(hipEventSynchronize(ctx->table_ev[pick]));
         ctx->table_busy[pick] = false;
     }
@@ -502,15 +507,18 @@ ma_status table_commit_mapped(ma_ctx* ctx, const void* host, const void** out_de
     MA_HIP(hipHostGetDevicePointer(&alias, ctx->table_stage[k], 0));
     ctx->table_next = (k + 1) % ma_ctx::kTableSlots;
     ctx->table_cur = -1;
-    ctx->table_busy[k] = true;  // until table_release records the event: never handed out in between
+    ctx->table_busy[k] = true;
+    ctx->table_mapped[k] = true;  // until table_release records the event: table_begin skips the slot without asking the event
     *out_dev_alias = alias;
     *out_slot = k;
     return MA_OK;
 }
 
 ma_status table_release(ma_ctx* ctx, int slot) {
-    MA_HIP(hipEventRecord(ctx->table_ev[slot], ctx->stream));
+    const hipError_t e = hipEventRecord(ctx->table_ev[slot], ctx->stream);
+    ctx->table_mapped[slot] = false;  // recorded or not, the reader has been launched: the event (or a drain) covers it from here
     ctx->table_busy[slot] = true;
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord(table_release)", __FILE__, __LINE__);
     return MA_OK;
 }
 
@@ -1435,7 +1443,8 @@ ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak
     return MA_OK;
 }
 
-// Live stamps and what each is made of: 1 = the runtime's signal memory, 0 = a plain device word.
+// Live stamps and what each is made of: 1 = the runtime's signal memory, 0 = a plain device word; +2 = the runtime reports
+// the word as HOST memory (signal memory is: profiles/r05_probe_signal.txt), i.e. the host may store to it directly.
 static std::mutex g_stamp_mu;
 static std::vector<std::pair<const uint64_t*, int>> g_stamps;
 
@@ -1457,6 +1466,11 @@ ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
         MA_HIP(hipMalloc(&p, 64));
         MA_HIP(hipMemset(p, 0, 64));
     }
+    if (kind == 1) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost && attr.hostPointer == p) kind |= 2;
+        (void)hipGetLastError();
+    }
     {
         std::lock_guard<std::mutex> lock(g_stamp_mu);
         g_stamps.push_back({(const uint64_t*)p, kind});
@@ -1464,6 +1478,25 @@ ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
     *out_stamp = (uint64_t*)p;
     return MA_OK;
 }
+
+// `*stamp = value` by a plain host store when the word is host memory: the one release that needs no queue of the GPU (a
+// write packet can end up behind the very wait it is meant to end when streams share a hardware queue).
+}  // extern "C" (the helper below is internal)
+namespace ma {
+bool stamp_host_store(uint64_t* stamp, uint64_t value);
+}
+bool ma::stamp_host_store(uint64_t* stamp, uint64_t value) {
+    {
+        std::lock_guard<std::mutex> lock(g_stamp_mu);
+        bool host = false;
+        for (const auto& e : g_stamps)
+            if (e.first == stamp) host = (e.second & 2) != 0;
+        if (!host) return false;
+    }
+    __atomic_store_n(stamp, value, __ATOMIC_RELEASE);
+    return true;
+}
+extern "C" {
 
 ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -1485,7 +1518,7 @@ ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp) {
 int32_t ma_stamp_is_signal(const uint64_t* stamp) {
     std::lock_guard<std::mutex> lock(g_stamp_mu);
     for (const auto& e : g_stamps)
-        if (e.first == stamp) return e.second;
+        if (e.first == stamp) return e.second & 1;
     return -1;
 }
 

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <memory>
+#include <mutex>
 
 #include "ma_group.hpp"
 
@@ -28,6 +30,40 @@ namespace ma {
 __global__ void stamp_store_kernel(uint64_t* stamp, uint64_t value) {
     // what the fused scan's final thread does behind its results (ma_reduce_fused.hip)
     __hip_atomic_store(stamp, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void guard_log(const char* fmt, ...) {
+    static const bool on = [] {
+        const char* e = getenv("MINARROW_HIP_GUARD_LOG");
+        return e && e[0] && e[0] != '0';
+    }();
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[minarrow_hip guard %9.3f ms] %s\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), buf);
+    fflush(stderr);
+}
+
+bool call_bounded(const std::function<void()>& fn, double timeout_ms) {
+    struct State {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+    };
+    auto st = std::make_shared<State>();
+    std::thread([st, fn] {
+        fn();
+        std::lock_guard<std::mutex> lock(st->mu);
+        st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lock(st->mu);
+    return st->cv.wait_for(lock, std::chrono::duration<double, std::milli>(timeout_ms), [&] { return st->done; });
 }
 
 hipError_t launch_stamp_store(hipStream_t stream, uint64_t* stamp, uint64_t value) {
@@ -51,7 +87,11 @@ hipStream_t rescue_stream(ma_group* g, size_t i) {
     if (g->rescue.size() < g->ctxs.size()) g->rescue.resize(g->ctxs.size(), nullptr);
     if (!g->rescue[i]) {
         (void)hipSetDevice(g->ctxs[i]->device);
-        if (hipStreamCreateWithFlags(&g->rescue[i], hipStreamNonBlocking) != hipSuccess) {
+        // highest priority: the runtime keeps a hardware-queue pool per priority, so this stream never sits behind a
+        // normal-priority one that is held (ordinary streams share hardware queues once a process has more than a few)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamCreateWithPriority(&g->rescue[i], hipStreamNonBlocking, greatest) != hipSuccess) {
             (void)hipGetLastError();
             g->rescue[i] = nullptr;
         }
@@ -63,9 +103,16 @@ hipStream_t rescue_stream(ma_group* g, size_t i) {
 // of the wait the stuck stream sits in), or a small copy there when the runtime has no stream memory operations. `value`
 // points at storage that outlives the copy.
 void write_word(ma_group* g, size_t i, uint64_t* word, const uint64_t* value) {
+    if (stamp_host_store(word, *value)) {  // host memory (signal memory is): no GPU queue involved at all
+        guard_log("member %zu: word %p <- %llu by a host store", i, (void*)word, (unsigned long long)*value);
+        return;
+    }
     hipStream_t s = rescue_stream(g, i);
     (void)hipSetDevice(g->ctxs[i]->device);
-    if (s && hipStreamWriteValue64(s, word, *value, 0) == hipSuccess) return;
+    const hipError_t w = s ? hipStreamWriteValue64(s, word, *value, 0) : hipErrorInvalidValue;
+    guard_log("member %zu: word %p <- %llu through the rescue stream: %s (signal memory: %d)", i, (void*)word,
+              (unsigned long long)*value, hipGetErrorString(w), ma_stamp_is_signal(word));
+    if (w == hipSuccess) return;
     (void)hipGetLastError();
     if (hipMemcpyAsync(word, value, 8, hipMemcpyHostToDevice, s) != hipSuccess) (void)hipGetLastError();
 }
@@ -203,6 +250,8 @@ ma_status enqueue_stall(ma_group* g, size_t member, hipStream_t stream) {
         return MA_ERR_UNSUPPORTED;
     }
     g->stall_armed = true;
+    guard_log("member %zu: exchange held behind its stall word %p >= %llu (testing hook; signal memory: %d)", member,
+              (void*)g->stall_word[member], (unsigned long long)g->stall_seq + 1, ma_stamp_is_signal(g->stall_word[member]));
     return MA_OK;
 }
 
@@ -210,6 +259,7 @@ void release_waits(ma_group* g, bool stamps_too) {
     static const uint64_t kAll = ~(uint64_t)0;
     const size_t n = g->ctxs.size();
     if (g->stall_armed) {
+        guard_log("releasing the stall words (sequence %llu)", (unsigned long long)g->stall_seq + 1);
         ++g->stall_seq;
         g->stall_release = g->stall_seq;
         for (size_t i = 0; i < n && i < g->stall_word.size(); ++i)
@@ -227,21 +277,35 @@ void release_waits(ma_group* g, bool stamps_too) {
 // it would run on freed communicator state). Then ncclCommAbort ends the collective kernels that are in flight — the ones
 // whose peer never arrived. Then a bounded wait for the streams to run empty.
 void abort_locked(ma_group* g, const char* why) {
-    (void)why;
+    guard_log("group abort: %s", why ? why : "");
     release_waits(g, true);
+    guard_log("group abort: held streams released; giving queued work 200 ms");
     {
         Pending p;
-        (void)wait_streams(g, 200.0, p);
+        const bool idle = wait_streams(g, 200.0, p);
+        guard_log("group abort: after 200 ms the streams are %s%s", idle ? "idle" : "still pending: ", idle ? "" : describe(g, p).c_str());
+        for (size_t i = 0; i < g->rescue.size(); ++i)
+            if (g->rescue[i]) guard_log("group abort: rescue stream of member %zu: %s", i, hipGetErrorString(hipStreamQuery(g->rescue[i])));
+        (void)hipGetLastError();
     }
     const RcclApi* api = g->comms.empty() ? nullptr : rccl();
     for (size_t i = 0; i < g->comms.size(); ++i) {
         if (!g->comms[i] || !api || !api->CommAbort) continue;
         (void)hipSetDevice(g->ctxs[i]->device);
-        (void)api->CommAbort(g->comms[i]);
+        guard_log("group abort: ncclCommAbort(member %zu)", i);
+        ncclComm_t comm = g->comms[i];
+        const int dev = g->ctxs[i]->device;
+        auto abort_fn = api->CommAbort;
+        // documented to return, but it waits for the communicator's work inside: a stream that is held for a reason nothing here
+        // could release would keep it for good. Bounded; a call that has not returned is left behind (drained stays false).
+        if (!call_bounded([comm, dev, abort_fn] { (void)hipSetDevice(dev); (void)abort_fn(comm); }, 5000.0))
+            guard_log("group abort: ncclCommAbort(member %zu) has not returned within 5 s: left behind", i);
         g->comms[i] = nullptr;
     }
+    guard_log("group abort: communicators aborted; waiting up to 5 s for the streams");
     Pending p;
     g->drained = wait_streams(g, 5000.0, p);
+    guard_log("group abort: streams %s", g->drained ? "have run empty" : "are STILL busy");
     g->broken = true;
     g->fail_member = g->stall_member = g->corrupt_member = -1;
 }
@@ -251,6 +315,7 @@ ma_status synchronize_for_locked(ma_group* g, double timeout_ms) {
     if (!(timeout_ms > 0)) return synchronize_locked(g);
     Pending p;
     if (!wait_streams(g, timeout_ms, p)) {
+        guard_log("group wait: %.0f ms passed with streams pending", timeout_ms);
         if (p.error != hipSuccess) {
             const hipError_t e = p.error;
             const size_t m = p.error_member;
@@ -498,11 +563,12 @@ struct SelfTest {
             for (size_t i = 0; i < n; ++i) {
                 ++rep->stamp_waits;
                 MA_HIP(hipSetDevice(g->ctxs[i]->device));
-                // the wait first, so that it really is one; then the store from a kernel on the scan stream
-                MA_HIP(hipStreamWaitValue64(g->side[i]->stream, g->stamp[k][i], seq, hipStreamWaitValueGte, ~(uint64_t)0));
+                // the order of a real step: the storing kernel is on the scan stream before the exchange stream is made to wait
+                // (the other order could sit behind its own wait where the two streams share a hardware queue)
                 const auto t0 = std::chrono::steady_clock::now();
                 hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, g->ctxs[i]->stream, g->stamp[k][i], seq);
                 MA_HIP(hipGetLastError());
+                MA_HIP(hipStreamWaitValue64(g->side[i]->stream, g->stamp[k][i], seq, hipStreamWaitValueGte, ~(uint64_t)0));
                 MA_TRY(wait_one(i, g->side[i]->stream, "the exchange stream's wait for a stamp a kernel on the scan stream stores"));
                 MA_TRY(wait_one(i, g->ctxs[i]->stream, "the stamping kernel"));
                 const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -594,7 +660,9 @@ ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags) {
     } else {
         MA_TRY(synchronize_locked(group));
     }
+    guard_log("group rebuild: releasing the old exchange (flags %u -> %u)", group->flags, flags);
     release_exchange(group);  // drains (now idle) streams, frees both record sets, side contexts, stamps, communicators
+    guard_log("group rebuild: setting up the new exchange");
     group->drained = true;
     group->handoff = 0;
     const ma_status st = configure_exchange(group, flags);

@@ -133,14 +133,19 @@ ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal con
 namespace {
 
 hipStream_t comm_rescue(ma_comm* comm) {
-    if (!comm->rescue && hipStreamCreateWithFlags(&comm->rescue, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        comm->rescue = nullptr;
+    if (!comm->rescue) {  // highest priority: its own hardware-queue pool, never behind a held normal-priority stream
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamCreateWithPriority(&comm->rescue, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            comm->rescue = nullptr;
+        }
     }
     return comm->rescue;
 }
 
 void comm_write_word(ma_comm* comm, uint64_t* word, const uint64_t* value) {
+    if (stamp_host_store(word, *value)) return;  // host memory (signal memory is): no GPU queue involved
     hipStream_t s = comm_rescue(comm);
     if (s && hipStreamWriteValue64(s, word, *value, 0) == hipSuccess) return;
     (void)hipGetLastError();
@@ -224,14 +229,24 @@ bool comm_wait_streams(ma_comm* comm, double timeout_ms, const char** which, hip
 void comm_abort(ma_comm* comm) {
     if (comm->broken) return;
     (void)hipSetDevice(comm->ctx->device);
+    guard_log("rank %d abort: releasing held streams; giving queued work 200 ms", comm->rank);
     comm_release_waits(comm, true);
     const char* which = "";
     hipError_t e = hipSuccess;
     (void)comm_wait_streams(comm, 200.0, &which, &e);
     const RcclApi* api = rccl();
-    if (comm->comm && api && api->CommAbort) (void)api->CommAbort(comm->comm);
+    guard_log("rank %d abort: ncclCommAbort", comm->rank);
+    if (comm->comm && api && api->CommAbort) {
+        ncclComm_t c = comm->comm;
+        const int dev = comm->ctx->device;
+        auto abort_fn = api->CommAbort;
+        if (!call_bounded([c, dev, abort_fn] { (void)hipSetDevice(dev); (void)abort_fn(c); }, 5000.0))
+            guard_log("rank %d abort: ncclCommAbort has not returned within 5 s: left behind", comm->rank);
+    }
     comm->comm = nullptr;
+    guard_log("rank %d abort: waiting up to 5 s for the streams", comm->rank);
     comm->drained = comm_wait_streams(comm, 5000.0, &which, &e);
+    guard_log("rank %d abort: streams %s", comm->rank, comm->drained ? "have run empty" : "are STILL busy");
     comm->broken = true;
     comm->stall_next = comm->corrupt_next = false;
 }

@@ -10,6 +10,8 @@
 
 #include <rccl/rccl.h>
 
+#include <functional>
+
 #include "ma_common.hpp"
 
 namespace ma {
@@ -35,6 +37,16 @@ struct RcclApi {
 const RcclApi* rccl();
 
 ma_status rccl_fail(ncclResult_t r, const char* what, const char* file, int line);
+
+// MINARROW_HIP_GUARD_LOG=1: the bounded waits, aborts and rebuilds of ma_group_* / ma_comm_* say on stderr what they do, step
+// by step with a timestamp — the trace a first run on a multi-GPU node leaves behind when something does not return.
+void guard_log(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// ma_ctx.hip: stores by the host when `stamp` (from ma_stamp_alloc) is host memory — signal memory is —; false otherwise.
+bool stamp_host_store(uint64_t* stamp, uint64_t value);
+// ma_group_guard.hip: fn() on a helper thread, waited for at most timeout_ms; false when it has not returned (the thread is
+// left behind). For runtime calls that are documented to return but wait on the GPU inside (ncclCommAbort).
+bool call_bounded(const std::function<void()>& fn, double timeout_ms);
 
 // ma_group_guard.hip: one thread stores `value` to `*stamp` with a system-scope release, as the fused scan's final thread does.
 hipError_t launch_stamp_store(hipStream_t stream, uint64_t* stamp, uint64_t value);

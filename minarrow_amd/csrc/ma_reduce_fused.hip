@@ -462,6 +462,10 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
             any_masked = true;
         }
     }
+    // as_partials = the nested use by ma_sum_columns (its few-long-columns route): this call's scope ends before the outer
+    // call's launches have run, so nothing may have been staged into it — the outer call only hands over device operands.
+    MA_REQUIRE(!as_partials || !scope.staged(), MA_ERR_INVALID_ARGUMENT,
+               "internal: the nested fused scan was handed an operand that had to be staged");
     // Launch shape: ma_reduce.hip's — dense 8-byte scans one workgroup per CU with 8 paced loads per lane, anything with
     // validity work between the loads two per CU with 4; mid-size jobs (<= 24 tiles per CU) three per CU.
     const int unroll = any_masked ? 4 : 8;

@@ -311,6 +311,27 @@ bool small_pair(const OpStream* o, const ArrowArray* l, const ArrowArray* r) {
     return (size_t)l->length * widest < kGatherBytes;
 }
 
+// May this pair share the current tile? Always — except under integer Div / Rem / FloorDiv, where the dense kernel and the
+// Bitmask-gated one DISAGREE on a zero divisor: dense raises MA_ERR_DIVIDE_BY_ZERO (the reference's panic,
+// src/kernels/arithmetic/std.rs:53-77), gated writes 0 and clears the row's validity bit (std.rs:95-138). A tile column is
+// gated as soon as ONE of its batches carried validity, so a dense batch gathered next to a nullable one would have its zero
+// divisor turned into a quiet 0 (and, its slice carrying no bitmap, a VALID 0) where the batch-by-batch form raises. Under
+// those operators a tile therefore holds, per integer column, either only batches with validity or only batches without.
+bool joins_tile(const OpStream* o, const ArrowArray* l, const ArrowArray* r) {
+    if (o->tile_rows == 0 || o->tile_lens.empty()) return true;
+    if (o->op != MA_OP_DIVIDE && o->op != MA_OP_REMAINDER && o->op != MA_OP_FLOORDIV) return true;
+    const size_t nc = o->lt.values.size();
+    const std::vector<char>& tile_had = o->tile_validity.front();  // uniform over the tile's batches by this very rule
+    for (size_t c = 0; c < nc; ++c) {
+        const char fl = o->lhs_schema.children[c]->format[0], fr = o->rhs_schema.children[c]->format[0];
+        if ((fl == 'f' || fl == 'g') || (fr == 'f' || fr == 'g')) continue;  // a float result: no division error either way
+        const ArrowArray *kl = l->children[c], *kr = r->children[c];
+        const bool had = (kl->null_count != 0 && kl->buffers[0]) || (kr->null_count != 0 && kr->buffers[0]);
+        if (had != (tile_had[c] != 0)) return false;
+    }
+    return true;
+}
+
 ma_status ensure_tiles(OpStream* o) {
     for (SideTile* t : {&o->lt, &o->rt})
         for (size_t c = 0; c < t->values.size(); ++c) {
@@ -481,7 +502,7 @@ int op_get_next(ArrowArrayStream* self, ArrowArray* out) {
                 break;
             }
             if (o->gather_ok == 1 && small_pair(o, &l, &r) && ensure_tiles(o) == MA_OK) {
-                if (o->tile_rows + (size_t)l.length > kGatherRows) process_tile(o);
+                if (o->tile_rows + (size_t)l.length > kGatherRows || !joins_tile(o, &l, &r)) process_tile(o);
                 if (o->pending_rc) {  // the tile's replay met an error: this pair is not computed (as batch by batch)
                     l.release(&l);
                     r.release(&r);

@@ -10,6 +10,7 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "big: a gpu test that holds 16 GB of HBM or more")
 
 
 @pytest.fixture(scope="session")

@@ -657,6 +657,25 @@ static void parallel_mirror_suite() {
         g.wait();
         auto both = g.sums(1);
         ASSERT(both.first == want && both.second == (double)want);
+        // first contact, the C++ way: the self-test first, bounded waits, and a stalled exchange that ends in a KernelError
+        // (not a blocked host) after which the same group — and the columns scattered over it — go on with a fresh exchange
+        const ma_selftest_report rep = g.selftest(20000.0);
+        ASSERT(std::string(rep.text).rfind("PASS", 0) == 0 && rep.n_members == n_dev && rep.forms_ok == rep.forms_tried && rep.forms_tried != 0);
+        g.enqueue_sums(1, ci, cf);
+        g.wait_for(20000.0);
+        ASSERT(g.broken() == 0 && g.sums(1).first == want);
+        ASSERT(ma_group_test_stall_next_exchange(g.get(), n_dev - 1) == MA_OK);
+        g.enqueue_sums(1, ci, cf);
+        bool timed_out = false;
+        try {
+            g.wait_for(250.0);
+        } catch (const ma::KernelError& e) {
+            timed_out = std::string(e.what()).find("did not finish within 250 ms") != std::string::npos;
+        }
+        ASSERT(timed_out && g.broken() == 1);
+        g.rebuild(0u);  // the host fold: no collective left to wait for
+        ASSERT(g.broken() == 0 && !g.rccl());
+        ASSERT(g.rayon_simd_sum_i64(ci, &valid) == want && valid == n);
         // a column with the wrong number of chunks is refused on the host
         ma::ShardedColumn<int64_t> bad = ci;
         bad.chunks.push_back(ci.chunks[0]);

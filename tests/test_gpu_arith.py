@@ -578,6 +578,7 @@ def test_async_divide_by_zero_is_reported_at_synchronize(ctx):
 # 3. BASELINE size (config 3): 1 B-row f64 add / mul, array (+) array and array (+) scalar
 # ======================================================================================================
 
+@pytest.mark.big
 def test_one_billion_rows_f64_add_mul(ctx):
     """a[i] = i, b[i] = n - i. a + b == n everywhere (sum == n^2, exact); a * 2.5 and a * b are checked on
     windows against numpy and through the verified sum kernel (linearity: sum(a * 2.5) == 2.5 * sum(a))."""
@@ -606,6 +607,7 @@ def test_one_billion_rows_f64_add_mul(ctx):
         buf.free()
 
 
+@pytest.mark.big
 def test_more_than_2_to_32_rows_elementwise(ctx):
     """64-bit row indexing in the elementwise kernels: 2^32 + 1 000 003 u8 rows, array (+) scalar, checked on windows
     at both ends and across the 2^32 boundary (values are (i mod 251) so every window is predictable)."""

@@ -202,3 +202,37 @@ def test_gathered_slices_own_their_buffers_and_carry_validity_only_where_a_side_
     end = ArrowArray()
     assert get_next(C.addressof(out), C.addressof(end)) == 0 and not end.release  # end of stream
     release(out.release)(C.addressof(out))
+
+
+@pytest.mark.parametrize("op", [3, 4, 6])  # Divide, Remainder, FloorDiv
+def test_a_dense_zero_divisor_gathered_next_to_a_nullable_batch_still_raises(ctx, op):
+    """Integer Div / Rem / FloorDiv: the dense kernel raises on a zero divisor (the reference panics,
+    src/kernels/arithmetic/std.rs:53-77), the Bitmask-gated one nulls the row out (std.rs:95-138). A tile column is gated
+    as soon as one of its batches has validity — so a DENSE batch with a zero divisor must never share a tile with a nullable
+    one, or its error would turn into a quiet, valid 0. Pairs 0-1 dense, 2 nullable (its zero divisor nulls the row), 3 dense,
+    4 dense with a zero divisor: batches 0-3 come back as the batch-by-batch form gives them, batch 4 is the error."""
+    rng = np.random.default_rng(40 + op)
+    n = 600
+    mk = lambda vals, mask=None: pa.RecordBatch.from_pydict({"v": pa.array(vals, type=pa.int64(), mask=mask)})  # noqa: E731
+    L = [mk(rng.integers(-1000, 1000, size=n)) for _ in range(6)]
+    R = [mk(rng.integers(1, 50, size=n)) for _ in range(6)]
+    nullable = rng.integers(1, 50, size=n)
+    nullable[10] = 0                      # a zero divisor in the nullable batch: that row becomes null, no error
+    R[2] = mk(nullable, mask=np.arange(n) % 7 == 3)
+    bad = rng.integers(1, 50, size=n)
+    bad[123] = 0
+    R[4] = mk(bad)                        # dense: the reference panics here
+    reader = run_operator(ctx, op, L, R)
+    single = lambda l, r: list(run_operator(ctx, op, [l], [r]))[0]  # noqa: E731 — the batch-by-batch form of one pair
+    for k in range(4):
+        b = reader.read_next_batch()
+        assert b.column(0).equals(single(L[k], R[k]).column(0)), k
+        if k != 2:
+            assert b.column(0).null_count == 0 and b.column(0).buffers()[0] is None
+        else:
+            valid = np.array(b.column(0).is_valid())
+            assert not valid[10] and valid.sum() == n - 1 - int((np.arange(n) % 7 == 3).sum()) + int(10 % 7 == 3)
+    with pytest.raises(Exception) as e:
+        reader.read_next_batch()
+    assert "batch 4" in str(e.value) and "by zero in a dense integer kernel" in str(e.value)
+    del reader

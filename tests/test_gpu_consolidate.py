@@ -197,12 +197,16 @@ def test_config5_shape_consolidate_then_reduce(ctx):
     np.testing.assert_array_equal(first, np.arange(3, 7))
 
 
+@pytest.mark.big
 def test_config5_full_size_eight_billion_rows_on_one_gpu(ctx):
-    """BASELINE configs[4] at its stated size on ONE GPU: a SuperTable column of 8 x 10^9-row i64 batches with 10 % nulls
-    (64 GB in, 64 GB + 1 GB of validity out: fits the 288 GB), consolidated and reduced. Size-independent properties: the
-    consolidated column reduces to the sum of the per-batch reduces (checksum of checksums, count included), its valid
-    count is the popcount of the joined bitmap, its dense sum is the closed form of v[i] = i + batch, windows across every
-    join equal the source rows, and the per-batch reduce as ONE ma_sum_chunks call agrees."""
+    """BASELINE configs[4] at its stated size on ONE GPU: a SuperTable of 8 x 10^9-row batches with 10 % nulls, BOTH its
+    columns — i64 v = i + batch and f64 v = (i + batch) as f64, benches/consolidate.rs:37-58's pattern (the bench scales the
+    float by 0.1; integer-valued here so that every sum has an exact closed form) — consolidated and reduced, one column after
+    the other through the same 64 GB in + 64 GB out (+ 1 GB of validity each way: fits the 288 GB). Size-independent
+    properties per column: the consolidated column reduces to the sum of the per-batch reduces (checksum of checksums, count
+    included), its valid count is the popcount of the joined bitmap, its dense sum is the closed form, windows across every
+    join equal the source rows, and the per-batch reduce as ONE ma_sum_chunks call agrees. f64: every sum within 1 ULP of
+    the exact value — which the i64 column, sharing the bitmap and the values, supplies for the gated sums."""
     k, n = 8, 1_000_000_000
     M64 = (1 << 64) - 1
     src = ctx.alloc(k * n * 8)
@@ -210,23 +214,54 @@ def test_config5_full_size_eight_billion_rows_on_one_gpu(ctx):
     masks_buf = ctx.alloc(k * mstride + 64)
     chunks = [src.ptr + c * n * 8 for c in range(k)]
     masks = [masks_buf.ptr + c * mstride for c in range(k)]
-    for c in range(k):
-        ctx.synth_iota("i64", chunks[c], n, c)  # benches/consolidate.rs:37-58: v = i + batch
-        ctx.synth_validity(masks[c], n, seed=0xABC + c, null_every=10)
     out = ctx.alloc(k * n * 8)
     out_mask = ctx.alloc(k * n // 8 + 64)
+    dense_exact = sum(n * (n - 1) // 2 + c * n for c in range(k))  # 4.0e18 < 2^63
+    for c in range(k):
+        ctx.synth_validity(masks[c], n, seed=0xABC + c, null_every=10)
+
+    def within_one_ulp(got, exact_int):
+        return abs(got - exact_int) <= math.ulp(float(exact_int))
+
+    # ---- the i64 column ------------------------------------------------------------------------------------------------
+    for c in range(k):
+        ctx.synth_iota("i64", chunks[c], n, c)  # benches/consolidate.rs:37-58: v = i + batch
     assert ctx.consolidate_column(8, chunks, [n] * k, out, masks, [0] * k, out_mask)
     parts = [ctx.sum("i64", chunks[c], n, mask=masks[c]) for c in range(k)]
     whole = ctx.sum("i64", out, k * n, mask=out_mask)
     assert (whole[0] & M64, whole[1]) == (sum(p[0] for p in parts) & M64, sum(p[1] for p in parts))
     assert 0.09 < 1 - whole[1] / (k * n) < 0.11
     assert ctx.popcount_mask(out_mask, 0, k * n) == whole[1]
-    assert ctx.sum("i64", out, k * n)[0] & M64 == sum(n * (n - 1) // 2 + c * n for c in range(k)) & M64
+    assert ctx.sum("i64", out, k * n)[0] & M64 == dense_exact & M64
     for c in range(1, k):  # every join: the last rows of batch c - 1, the first of batch c
         got = out.download(np.int64, 8, (c * n - 4) * 8)
         np.testing.assert_array_equal(got, np.concatenate([np.arange(n - 4, n) + (c - 1), np.arange(0, 4) + c]))
     total = ctx.sum_chunks("l", chunks, [n] * k, masks, [0] * k)
     assert (total[1] & M64, total[2]) == (whole[0] & M64, whole[1])
+    gated_exact, gated_count = whole[0], whole[1]  # < 2^63: no wrap, the exact gated sum of the shared values
+    assert 0 < gated_exact < dense_exact
+    # ---- the f64 column of the same table: same values, same bitmaps, the same two buffers -----------------------------------
+    ctx.dev_memset(out, 0xA5, k * n * 8)
+    ctx.dev_memset(out_mask, 0x5A, k * n // 8 + 64)
+    for c in range(k):
+        ctx.synth_iota("f64", chunks[c], n, c)
+    assert ctx.consolidate_column(8, chunks, [n] * k, out, masks, [0] * k, out_mask)
+    fparts = [ctx.sum_dd("f64", chunks[c], n, mask=masks[c]) for c in range(k)]
+    for c, (hi, lo, cnt) in enumerate(fparts):  # each batch's gated sum against its i64 twin (exact)
+        assert cnt == parts[c][1] and within_one_ulp(hi + lo, parts[c][0]), c
+    fwhole = ctx.sum("f64", out, k * n, mask=out_mask)
+    assert fwhole[1] == gated_count and within_one_ulp(fwhole[0], gated_exact)
+    from minarrow_amd.parallel import fold_dd
+
+    assert within_one_ulp(fold_dd([(p[0], p[1]) for p in fparts]), gated_exact)  # the logical consolidate: sum of per-batch sums
+    assert ctx.popcount_mask(out_mask, 0, k * n) == gated_count
+    dense = ctx.sum("f64", out, k * n)
+    assert dense[1] == k * n and within_one_ulp(dense[0], dense_exact)
+    for c in range(1, k):
+        got = out.download(np.float64, 8, (c * n - 4) * 8)
+        np.testing.assert_array_equal(got, np.concatenate([np.arange(n - 4, n) + (c - 1), np.arange(0, 4) + c]).astype(np.float64))
+    ftotal = ctx.sum_chunks("g", chunks, [n] * k, masks, [0] * k)
+    assert ftotal[2] == gated_count and within_one_ulp(ftotal[0], gated_exact)
     for b in (src, masks_buf, out, out_mask):
         b.free()
     ctx.lib.ma_dev_pool_trim(ctx.handle, 0)  # 130 GB back to the driver before the next test

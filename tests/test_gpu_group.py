@@ -242,6 +242,7 @@ def test_comm_one_rank(ctx, oracle):
         comm.close()
 
 
+@pytest.mark.big
 def test_group_one_billion_rows_with_nulls_partitioned_eight_ways(ctx):
     """BASELINE config 4 at full size through the group API: a 10^9-row i64 column with 10 % nulls, row-chunk
     partitioned over 8 members (sharing this box's GPU; host exchange) — the job's finals must equal the single-call

@@ -299,6 +299,7 @@ def test_repeatable_and_async(ctx):
 
 # ---- BASELINE sizes: 1 B rows (config 2 / config 4 shape), size-independent properties ---------------------
 
+@pytest.mark.big
 def test_one_billion_rows(ctx):
     """n = 10^9 (benches/benchmark_parallel_simd.rs:39). i64: closed form, bit exact. f64: within 1 ULP
     (= 64 at this magnitude) of the exactly rounded closed form. Checksum-of-checksums: eight 125 M-row
@@ -326,6 +327,7 @@ def test_one_billion_rows(ctx):
     buf.free()
 
 
+@pytest.mark.big
 def test_more_than_2_to_32_rows(ctx):
     """Row indices are 64-bit end to end: 2^32 + 300 000 007 i32 rows (18.4 GB). data[i] = wrap_i32(i); one full
     cycle of i32 values sums to -2^31, the remainder is a plain arithmetic series."""

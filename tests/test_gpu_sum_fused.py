@@ -140,6 +140,7 @@ def test_rejections(ctx):
     assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
 
 
+@pytest.mark.big
 def test_one_billion_rows_both_columns_one_launch(ctx):
     """BASELINE configs[1] at full size as ONE launch: sum(0..10^9) over an i64 and an f64 iota column. Closed forms."""
     n = 1_000_000_000
@@ -168,6 +169,32 @@ def test_one_billion_rows_both_columns_one_launch(ctx):
     assert abs(fold_dd(pairs) - float(expect)) <= math.ulp(float(expect))
     ci.free()
     cf.free()
+
+
+@pytest.mark.big
+def test_one_billion_rows_gated_i64_and_f64_sharing_a_bitmap_one_launch(ctx):
+    """The fused Bitmask-gated step at full size (BASELINE configs[3]'s column next to its f64 twin, configs[4]'s per-GPU step
+    at 8x its share): a 10^9-row i64 and a 10^9-row f64 column (v[i] = i) sharing ONE validity bitmap with 10 % nulls, both in
+    one launch, against the single-column kernels: the i64 sum and both counts bit for bit, the f64 sum within 1 ULP of the
+    exact gated sum (the i64 result: same values, no wrap). Also at an unaligned bit offset."""
+    n = 1_000_000_000
+    ci, cf = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    mask = ctx.alloc(n // 8 + 192)
+    ctx.synth_iota("i64", ci, n, 0)
+    ctx.synth_iota("f64", cf, n, 0)
+    ctx.synth_validity(mask, n + 77, seed=0xFEED, null_every=10)
+    for off in (0, 77):
+        rec = _records(ctx, 1)
+        ctx.sum_fused([("l", ci, n, rec.ptr, mask, off), ("g", cf, n, rec.ptr + 16, mask, off)])
+        w = _read(rec, 0)
+        si, cnt = ctx.sum("i64", ci, n, mask=mask, mask_bit_offset=off)
+        hi, lo, fcnt = ctx.sum_dd("f64", cf, n, mask=mask, mask_bit_offset=off)
+        assert 0.09 < 1 - cnt / n < 0.11 and cnt == ctx.popcount_mask(mask, off, n)
+        assert int(w[0]) == si & M64 and int(w[1]) == cnt == int(w[4]) == fcnt
+        fh, fl = (float(x) for x in w[2:4].view(np.float64))
+        assert abs((fh + fl) - si) <= math.ulp(float(si)) and abs((hi + lo) - si) <= math.ulp(float(si))
+    for b in (ci, cf, mask):
+        b.free()
 
 
 def test_stamped_launch_and_exchange_waiting_on_the_stamp(ctx, oracle):
