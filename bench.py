@@ -144,27 +144,29 @@ def cpu_baseline(rows: int, budget_s: float):
         config0[name] = {"best_us": min(times) * 1e6, "median_us": sorted(times)[len(times) // 2] * 1e6,
                          "grows_per_s": small.size / min(times) / 1e9}
     other = cpu_other_configs(oracle, np)
+    # What the box's cores SUSTAIN is the headline of this leg: the median over the repetitions of the pool sized to the CPU
+    # time the container may burn (cgroup quota; every visible thread when there is none) — `cores` = that pool. On a GPU box the
+    # container sees every host thread but may only burn `cgroup_cpu_quota` CPUs' worth of time per period, so a larger pool's
+    # best-of-N is an un-throttled burst inside one period: reported next to it as `value_burst` / `cores_burst`, never as `value`.
+    sustained_threads = min(candidates) if quota else best_threads
     return {
-        "value": results[best_threads]["value"],
-        "value_median": results[best_threads]["value_median"],
+        "value": results[sustained_threads]["value_median"],
+        "cores": sustained_threads,
+        "value_burst": results[best_threads]["value"],
+        "cores_burst": best_threads,
+        "value_best_of_n_same_pool": results[sustained_threads]["value"],
         "unit": "Grows/s",
         "rows": rows,
-        # cores = the threads that produced `value`: the pool size of the fastest configuration. On a GPU box the container
-        # sees every host thread but may only burn `cgroup_cpu_quota` CPUs' worth of time per period, so a large pool's
-        # best-of-N is an un-throttled burst inside one period; what a quota-bound host SUSTAINS is `value_quota_bound` (the
-        # median of the pool sized to the quota, `cores_quota_bound` threads).
-        "cores": best_threads,
-        "pool_threads": best_threads,
-        "value_quota_bound": results[min(candidates)]["value_median"] if quota else results[best_threads]["value_median"],
-        "cores_quota_bound": min(candidates) if quota else best_threads,
+        "pool_threads": sustained_threads,
         "cgroup_cpu_quota": quota,
         "host_threads_visible": visible,
         "kind": "port",
         "sample": f"{rows} rows per column" + (" (the metric's own size)" if rows == 1_000_000_000 else " (bounded sample)") +
                   f": a {rows}-row i64 and a {rows}-row f64 iota column, one at a time, chunks of 2^20 rows, 4-lane accumulators, "
-                  f"persistent pinned pool of {best_threads} threads (tried {candidates}; {visible} host threads visible, cgroup "
-                  f"CPU quota {quota if quota else 'none'}; host MemAvailable {avail // (1 << 30) if avail else '?'} GiB), "
-                  f"value = best of N reps, value_median = median "
+                  f"persistent pinned pools of {candidates} threads tried ({visible} host threads visible, cgroup CPU quota "
+                  f"{quota if quota else 'none'}; host MemAvailable {avail // (1 << 30) if avail else '?'} GiB); value = the MEDIAN over "
+                  f"the repetitions of the {sustained_threads}-thread pool (what the box sustains), value_burst = the best single "
+                  f"repetition of the fastest pool ({best_threads} threads) "
                   f"(C restatement of benches/benchmark_parallel_simd.rs:44-98)",
         "detail": {str(t): r for t, r in results.items()},
         "config0_1m_rows": config0,
@@ -538,11 +540,12 @@ def _result_line(args, world, scaling, total_rows, rows_gpu0, elapsed, kernels, 
     dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])  # the dominant kernel: the launch the step spends most time in
     dom_name, dom_ms, bytes_per_launch = names.get(dom, dom), kernels[dom]["avg_ms"], kernels[dom]["bytes_per_launch"]
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, pmc_meta = None, {}
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists() and rows_gpu0 == 1_000_000_000:  # the counters were collected on the full-size workload only
         try:
-            traffic = json.loads(pmc.read_text()).get(f"{dom}_hbm_bytes_per_launch")
+            pmc_meta = json.loads(pmc.read_text())
+            traffic = pmc_meta.get(f"{dom}_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     if world == 1:
@@ -597,9 +600,12 @@ def _result_line(args, world, scaling, total_rows, rows_gpu0, elapsed, kernels, 
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this "
-                              "command (tools/collect_profiles.sh), FETCH_SIZE doubled per the gfx950 correction"
-                              if traffic is not None else None,
+            # NOT a counter read in this run: rocprofv3 --pmc passes are separate runs (the guide's rule), so the figure is
+            # replayed from the committed collection
+            "traffic_source": (f"REPLAYED from profiles/pmc_traffic.json (collected {pmc_meta.get('collected', '?')} on "
+                               f"{pmc_meta.get('box', 'a gpurun MI355X box')} by tools/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE / "
+                               "--pmc WRITE_SIZE passes over this command, FETCH_SIZE doubled per the gfx950 correction) — not "
+                               "measured in this run") if traffic is not None else None,
         },
     }
 
@@ -1266,6 +1272,18 @@ def _hip_runtime_path():
         return None
 
 
+def _profiler_attached():
+    """A rocprofv3 / rocprof tool library in this process? Its preloaded library has initialised the GPU before main(), and a
+    process that has must not start another GPU program by exec — nor, to be safe, spawn a GPU child at all under it."""
+    if any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) or (k == "LD_PRELOAD" and "rocprof" in v) for k, v in os.environ.items()):
+        return True
+    try:
+        with open("/proc/self/maps") as f:
+            return any("librocprofiler" in line or "librocprof-sys" in line for line in f)
+    except Exception:
+        return False
+
+
 def _torch_hosted_leg(args):
     """The same headline hosted by PyTorch (torch imported first: its bundled HIP runtime, torch tensors, torch's stream —
     what rounds 1-3 reported), in a child process, as a labelled extra key next to the product's own figure."""
@@ -1687,7 +1705,9 @@ def run_native(args, result_fd) -> int:
                 except Exception as e:  # noqa: BLE001 — the headline line must still be printed
                     out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
                     rc = 1
-            if not args.no_torch_hosted_leg:
+            if not args.no_torch_hosted_leg and _profiler_attached():
+                out["torch_hosted"] = {"skipped": "a profiler is attached to this process: no GPU child process is started under it"}
+            elif not args.no_torch_hosted_leg:
                 ctx.set_async(False)
                 ctx.synchronize()
                 ctx.lib.ma_dev_pool_trim(ctx.handle, 0)  # the child needs the HBM; released blocks are cleared in the background:
@@ -2093,6 +2113,10 @@ def main() -> int:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes here
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1 or args.force_group or args.force_dist:
+        # the library's bounded waits, aborts and rebuilds leave a timestamped trace on stderr: what a first run on a
+        # multi-GPU node needs when something does not return
+        os.environ.setdefault("MINARROW_HIP_GUARD_LOG", "1")
     if world > 1 and world != args.gpus:
         print(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}", file=sys.stderr)
         return 2

@@ -965,6 +965,11 @@ class Group:
 
     def close(self) -> None:
         if self.handle:
+            # A bounded drain first: freeing device memory waits for the device, and a stream that is still held (a collective
+            # whose peer never came; a stall hook) would keep that wait for good. Past the deadline the library aborts the
+            # communicators and releases what it can — the group is going away anyway.
+            if self.lib.ma_group_is_broken(self.handle) == 0:
+                self.lib.ma_group_synchronize_for(self.handle, 2000.0)
             for c in self._members:  # buffers still alive on a member's device go first; the views die with the group
                 for buf in list(c._buffers):
                     buf.free()

@@ -41,8 +41,10 @@ def test_single_gpu_line_with_other_configs_and_cpu_baseline():
             assert oc["config5_supertable_8_batches"][tag][leg]["parity"] is True
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    # `cores` is the pool that produced `value`; what a quota-bound host sustains is reported next to it
-    assert cb["cores"] == cb["pool_threads"] and 0 < cb["value_quota_bound"] <= cb["value"] * 1.001 and cb["cores_quota_bound"] >= 1
+    # `value` is what the box sustains (the median of the pool sized to the CPU quota, `cores` threads); the un-throttled burst
+    # of a larger pool rides along under its own name
+    assert cb["cores"] == cb["pool_threads"] and 0 < cb["value"] <= cb["value_burst"] * 1.001 and cb["cores_burst"] >= cb["cores"]
+    assert cb["cgroup_cpu_quota"] is None or cb["cores"] <= cb["cgroup_cpu_quota"]
     # the headline is the product's own form: no torch in the process, /opt/rocm's HIP runtime, timing marks for the kernels
     assert out["config"]["host"] == "torch-free" and "torch" not in out["config"]["hip_runtime"]
     assert set(out["kernels"]) == {"sum_i64", "sum_f64"} and out["roofline"]["kernel"].startswith("ma::sum_kernel")
@@ -128,7 +130,7 @@ def test_launcher_mode_one_rank(exchange, extra):
 
 
 LAUNCH = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
-QUICK = ["--no-cpu-baseline", "--no-other-configs", "--wait-seconds", "2"]
+QUICK = ["--no-cpu-baseline", "--no-other-configs", "--wait-seconds", "0.6"]
 
 
 def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(monkeypatch):
@@ -150,7 +152,6 @@ def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(m
 
 
 @pytest.mark.parametrize("fault, abandoned, runs_as", [
-    ("stall@setup", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
     ("corrupt@setup", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
     ("stall@preflight,stall@setup", ["rccl, overlapped, hand-off by stamp, issue threads", "rccl, overlapped, hand-off by event, issue threads"],
      "rccl, in-stream, issue threads"),
@@ -179,7 +180,6 @@ def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, abandoned, ru
 
 
 @pytest.mark.parametrize("fault, abandoned, runs_as", [
-    ("stall@setup", ["ma_comm, overlapped, hand-off by stamp"], "ma_comm, overlapped, hand-off by event"),
     ("corrupt@setup,stall@preflight", ["ma_comm, overlapped, hand-off by stamp", "ma_comm, overlapped, hand-off by event"], "ma_comm, in-stream"),
     ("stall@timed", ["ma_comm, overlapped, hand-off by stamp"], "ma_comm, overlapped, hand-off by event"),
 ])

@@ -545,13 +545,14 @@ def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
                 sel = [c[np.unpackbits(m, bitorder="little")[o:o + n].astype(bool)] if (masked and m is not None) else c
                        for c, m, o, n in zip(cols, masks, offs, lens)]
                 allv = np.concatenate(sel)
+                is_float = np.dtype(dt).kind == "f"  # the exact value once, not once per member
+                exact = math.fsum(allv.astype(np.float64).tolist()) if is_float else int(allv.astype(np.int64).sum(dtype=object))
                 for m_ in range(members):
                     isum, icnt, fsum, fcnt = g.result(col, m_)
-                    if np.dtype(dt).kind == "f":
-                        exact = math.fsum(allv.astype(np.float64).tolist())
+                    if is_float:
                         assert fcnt == allv.size and abs(fsum - exact) <= math.ulp(exact)
                     else:
-                        assert icnt == allv.size and (isum - int(allv.astype(object).sum())) % (1 << 64) == 0
+                        assert icnt == allv.size and (isum - exact) % (1 << 64) == 0
             for b in d_cols + [m for m in d_masks if m is not None]:
                 b.free()
         # an empty chunk list is a zero record on every member

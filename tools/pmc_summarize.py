@@ -23,7 +23,11 @@ def per_kernel(path, counter):
 fetch, n_f = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
-out = {"note": f"{rnd}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "
+import datetime
+import socket
+
+out = {"collected": datetime.date.today().isoformat(), "box": f"gpurun MI355X box '{socket.gethostname()}'", "round": rnd,
+       "note": f"{rnd}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "
                f"--no-cpu-baseline --no-other-configs` (tools/collect_profiles.sh; profiles/{rnd}_pmc_*_counter_collection.csv); "
                f"KiB, median over launches; FETCH_SIZE doubled per the gfx950 correction for 16-B/lane streaming loads; "
                f"algorithmic bytes per launch = 8e9 (16e9 for the fused i64 + f64 launch)", "kernels": {}}
