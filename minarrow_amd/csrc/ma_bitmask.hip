@@ -353,7 +353,10 @@ __global__ __launch_bounds__(kBlock) void bit_scan_kernel(BitArgs a, ScanOut so)
 // The R result bits of one 16-byte load. 4- and 8-byte elements compare one by one; 1- and 2-byte elements are compared
 // four / two at a time inside their 32-bit words: y = (word & mask) ^ target has a zero byte exactly where the row
 // matches, ~(((y & 0x7F..) + 0x7F..) | y) & 0x80.. marks the zero bytes (exact per byte: the add cannot carry out of a
-// byte), and one multiply gathers the four marks into a nibble — 10 operations per 4 rows instead of 14.
+// byte; the ~ & is ONE v_bfi), and the marks — bytes of 0x80 or 0 — are gathered by a dot product with the bytes' bit
+// weights (v_dot4_u32_u8: dword 0 with 1, 2, 4, 8, dword 1 with 16 .. 128, accumulating; dwords 2 and 3 the same into the
+// upper byte), one shift by 7 at the end: 7 operations per 4 rows (round 5; 10 with the multiply-and-shift gather of round 4,
+// 14 comparing row by row — counters: profiles/r05_subfamily_counters.md).
 template <typename T, typename V16>
 __device__ __forceinline__ unsigned eq_bits(const V16& x, T field_mask, T target) {
     constexpr int R = 16 / (int)sizeof(T);
@@ -362,23 +365,34 @@ __device__ __forceinline__ unsigned eq_bits(const V16& x, T field_mask, T target
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 d = __builtin_bit_cast(u4, x);
         const unsigned m4 = (unsigned)(uint8_t)field_mask * 0x01010101u, t4 = (unsigned)(uint8_t)target * 0x01010101u;
+        unsigned lo = 0, hi = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned y = (d[i] & m4) ^ t4;
-            const unsigned z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
-            // marks at bits 7, 15, 23, 31 -> bits 0, 8, 16, 24 -> x (1 + 2^7 + 2^14 + 2^21): bits 21..24 hold them in order
-            bits |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);
+            const unsigned t = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+            const unsigned z = ~t & 0x80808080u;  // 0x80 in every byte that matched
+            const unsigned w = (i & 1) ? 0x80402010u : 0x08040201u;
+            if (i < 2) lo = __builtin_amdgcn_udot4(z, w, lo, false);
+            else hi = __builtin_amdgcn_udot4(z, w, hi, false);
         }
+        bits = (lo >> 7) | ((hi >> 7) << 8);  // each sum is 0x80 x (the byte of its eight marks)
     } else if constexpr (sizeof(T) == 2) {
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 d = __builtin_bit_cast(u4, x);
         const unsigned m2 = (unsigned)(uint16_t)field_mask * 0x00010001u, t2 = (unsigned)(uint16_t)target * 0x00010001u;
+        unsigned acc = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned y = (d[i] & m2) ^ t2;
-            const unsigned z = ~(((y & 0x7FFF7FFFu) + 0x7FFF7FFFu) | y) & 0x80008000u;
-            bits |= (((z >> 15) | (z >> 30)) & 3u) << (2 * i);
+            const unsigned t = ((y & 0x7FFF7FFFu) + 0x7FFF7FFFu) | y;
+            const unsigned z = ~t & 0x80008000u;  // 0x8000 in every halfword that matched
+            // halves x (2^(2i), 2^(2i+1)): 0x8000 x the pair's two result bits, accumulated over the four dwords (v_dot2_u32_u16)
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned short, z),
+                                         __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned short,
+                                                            (unsigned)((1u << (2 * i)) | (2u << (2 * i + 16)))),
+                                         acc, false);
         }
+        bits = acc >> 15;
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) bits |= ((T)((T)x[r] & field_mask) == target ? 1u : 0u) << r;

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
     constexpr int WPT = R * UNROLL;                  // validity words per wave run
     constexpr size_t WAVE_ROWS = (size_t)64 * R * UNROLL;
     constexpr size_t TILE_ROWS = WAVE_ROWS * kWaves;
-    static_assert(!MASKED || WPT < 64, "a wave must be able to load its validity words in one instruction");
+    // (1-byte rows at 8 loads per lane: 128 run words, two per lane — the kDeepBytes branch below)
+    constexpr bool kDeepBytes = MASKED && sizeof(T) == 1 && UNROLL == 8;
+    static_assert(!MASKED || WPT < 64 || kDeepBytes, "a wave must be able to load its validity words in one instruction");
     constexpr bool kNarrow = sizeof(T) <= 2;  // 8 / 16 rows per load: summed inside 32-bit registers (narrow_vec_sum)
 
     const unsigned tid = threadIdx.x;
@@ -121,7 +123,61 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
         }
     }
     // ---- full tiles: 16-byte loads, no bounds checks --------------------------------------------
-    if constexpr (MASKED) {
+    if constexpr (kDeepBytes) {
+        // 1-byte rows with validity in the shape of the dense scans (round 5): EIGHT loads per lane, one workgroup per CU, the
+        // next tile requested before this one is consumed. A wave's run is 8 KiB of rows = 128 validity words: lane l holds run
+        // words l and 64 + l (two wave loads; a third fetches word 128, the funnel partner of the last one, on every lane).
+        // With 2 loads per tile — all that fits a one-word-per-lane run — the per-tile work (funnel shift, count, addresses,
+        // loop) was spread over 2 loads and three workgroups per CU had to cover it: 35-43 vector instructions per load and a
+        // quarter of the wave cycles in issue stalls (profiles/r05_subfamily_counters.md), 6.88 TB/s against 7.25 dense.
+        const size_t G = gridDim.x, first = blockIdx.x;
+        const size_t n_mine = first < a.n_tiles ? (a.n_tiles - first + G - 1) / G : 0;
+        auto issue = [&](size_t k, V (&v)[UNROLL], uint64_t (&raw)[3], size_t& row0) {
+            const bool real = k < n_mine;
+            row0 = a.head + (real ? first + k * G : 0) * TILE_ROWS + (size_t)wave * WAVE_ROWS;
+            const V* __restrict__ p = real ? (const V*)(data + row0) + lane : (const V*)a.partials;
+            const size_t stride = real ? 64 : 0;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = load16<V, NT>(p + (size_t)u * stride);
+            const size_t w0 = (a.bit_off + row0) >> 6;
+            const auto gw = as_global(real ? a.words : (const uint64_t*)a.partials);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {  // clamped, not skipped, past the window's last word: a full tile never needs a word behind it
+                size_t idx = w0 + (size_t)(64 * j) + (j < 2 ? lane : 0u);
+                idx = idx < a.last_word ? idx : a.last_word;
+                raw[j] = gw[real ? idx : 0];  // (streamed or plain: the same rate, profiles/r05_sweep_gated_bytes.jsonl)
+            }
+        };
+        auto use = [&](const V (&v)[UNROLL], const uint64_t (&raw)[3], size_t row0) {
+            const unsigned sh = (unsigned)((a.bit_off + row0) & 63);
+            uint64_t w[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint64_t nx = (uint64_t)__shfl_down((unsigned long long)raw[j], 1, 64);
+                const uint64_t first_of_next = (uint64_t)__shfl((unsigned long long)raw[j + 1], 0, 64);
+                if (lane == 63) nx = first_of_next;
+                w[j] = sh ? ((raw[j] >> sh) | (nx << (64 - sh))) : raw[j];
+                cnt += (uint64_t)__popcll(w[j]);  // every lane holds two distinct run words
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                // rows of load u on lane l: bits [(64 u + l) 16, +16) of the run = word 16 u + l / 4, quarter l % 4
+                const uint64_t word = (uint64_t)__shfl((unsigned long long)w[u / 4], (u * 16 + (int)(lane >> 2)) & 63, 64);
+                const unsigned bits = (unsigned)(word >> ((lane & 3u) * 16u)) & 0xFFFFu;
+                acc[0].add(narrow_vec_sum<T>(v[u], bits));
+            }
+        };
+        V va[UNROLL], vb[UNROLL];
+        uint64_t ra[3], rb[3];
+        size_t row_a, row_b;
+        issue(0, va, ra, row_a);
+        for (size_t k = 0; k < n_mine; k += 2) {
+            issue(k + 1, vb, rb, row_b);
+            use(va, ra, row_a);
+            issue(k + 2, va, ra, row_a);
+            if (k + 1 < n_mine) use(vb, rb, row_b);
+        }
+    } else if constexpr (MASKED) {
         // With validity a tile is few loads per lane and the validity work sits between one tile's loads and the next's: the
         // wave's bytes in flight drop to zero once per tile, which the second wave per SIMD only partly covers (i8 / u8 with
         // nulls 6.7 TB/s, f32 and i16 7.0, against 7.2-7.3 dense). So the NEXT tile's rows and raw validity words are
@@ -413,8 +469,11 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
         // loads of 16 rows; the bytes in flight per SIMD then come from more waves (2 / 3 workgroups per CU). Dense scans
         // have no such limit and take the 8-deep shape of the wider integers.
         if (masked) {
-            unroll = R == 8 ? 4 : 2;
-            if (ctx->blocks_per_cu <= 0) bpc = R == 8 ? 1 : 3;  // swept: tools/sweep_masked_sum.py (i8 with nulls: 1 -> 5.3 TB/s, 2 -> 6.1, 3 -> 6.85, 4 -> 5.8)
+            // 2-byte rows: 4 loads of 8 rows (a 32-word run). 1-byte rows: 8 loads of 16 rows, two run words per lane (round 5);
+            // ctx variant unroll = 2 keeps round 4's shape — 2 loads, three workgroups per CU — for A/B.
+            const bool old_bytes = R == 16 && ((variant >> 1) & 7) == 1;
+            unroll = R == 8 ? 4 : (old_bytes ? 2 : 8);
+            if (ctx->blocks_per_cu <= 0) bpc = (R == 8 || !old_bytes) ? 1 : 3;  // swept: tools/sweep_masked_sum.py
         } else if (unroll != 2 && unroll != 4) {
             unroll = 8;
         }
@@ -465,7 +524,15 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     } while (0)
     if constexpr (R >= 8) {  // narrow types: masked = the one shape per width chosen above (deeper overflows the validity run)
         constexpr int U = R == 8 ? 4 : 2;
-        if (masked) MA_LAUNCH_U(U, true);
+        bool deep = false;
+        if constexpr (R == 16) {
+            if (masked && unroll == 8) {
+                MA_LAUNCH_U(8, true);
+                deep = true;
+            }
+        }
+        if (deep) {
+        } else if (masked) MA_LAUNCH_U(U, true);
         else if (unroll == 2) MA_LAUNCH_U(2, false);
         else if (unroll == 4) MA_LAUNCH_U(4, false);
         else MA_LAUNCH_U(8, false);
