@@ -1527,7 +1527,7 @@ def run_native(args, result_fd) -> int:
     def last_results():
         return S.exs[(S.counter - 1) % len(S.exs)].results()
 
-    # Clocks: a GPU that was idle a moment ago needs ~0.1 s of work before its clocks are up (tools/probe_sustain.c: the first
+    # Clocks: a GPU that was idle a moment ago needs ~0.1 s of work before its clocks are up (tools/archive/probe_sustain.c: the first
     # 20 ms of a process read at 4 TB/s, 7.2 from 0.1 s on). The process has only generated its columns so far; --ramp-ms of the
     # step itself (default 200 ms, un-timed, before the W warm-up steps) put it where any host that has been running is.
     # The same loop also waits out the kernel driver's background clear of VRAM that an EARLIER process released when it

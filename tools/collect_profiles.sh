@@ -5,7 +5,7 @@
 # VRAM its predecessor released in the background, and scans read 5 % slower meanwhile (profiles/r04_read_rate_states_root_cause.txt).
 set -u
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/profiles
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
@@ -25,13 +25,7 @@ python3 tools/pmc_summarize.py $O/${R}_pmc_fetch_counter_collection.csv $O/${R}_
 step "one process, group API, RCCL exchange (1 GPU)"; timeout -k 10 300 python3 bench.py --gpus 1 --force-group --no-cpu-baseline > $O/${R}_bench_group_1gpu_rccl.json 2> $O/${R}_bench_group.err || exit 1
 step "launcher, one rank, native communicator, torch-free GPU path"; timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-dist --no-cpu-baseline > $O/${R}_bench_ranks_1gpu_native_comm.json 2> $O/${R}_bench_ranks.err || exit 1
 step "the per-GPU share of the 8-way partition (125 M rows per column) on ONE GPU"; bash tools/run_share.sh gpurun_out/profiles/share > $O/${R}_share_1gpu.txt 2>&1
-step "ten torch-free processes, 2 s apart (the read-rate states: every one should be a 7.3 TB/s process)"
-gcc -std=gnu99 -O2 -w -Iinclude tools/probe_proc.c -Lminarrow_amd/lib -lminarrow_hip -Wl,-rpath,$PWD/minarrow_amd/lib -o /tmp/probe_proc || exit 1
-: > $O/${R}_ten_torch_free_processes.jsonl
-for i in 1 2 3 4 5 6 7 8 9 10; do sleep 2; PROBE_TAG=p$i timeout -k 5 60 /tmp/probe_proc 1000000000 2 1 10 >> $O/${R}_ten_torch_free_processes.jsonl 2>/dev/null; done
-python3 -c "
-import json
-print([json.loads(l)['min'] for l in open('$O/${R}_ten_torch_free_processes.jsonl')])"
+step "the sub-family kernels by counters"; bash tools/pmc_subfamily.sh $R > $O/${R}_subfamily.log 2>&1
 step "size sweep (torch-free)"; timeout -k 10 400 python3 tools/sweep_sizes.py > $O/${R}_sweep_sizes.jsonl 2>/dev/null || exit 1
 step "fused vs single-column sums"; timeout -k 10 300 python3 tools/sweep_fused.py > $O/${R}_sweep_fused.jsonl 2>/dev/null || exit 1
 step "the chunked regime's forms on one block"; timeout -k 10 300 python3 tools/ab_chunked.py > $O/${R}_ab_chunked.jsonl 2>/dev/null || exit 1
