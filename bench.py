@@ -1275,11 +1275,12 @@ def _hip_runtime_path():
 def _profiler_attached():
     """A rocprofv3 / rocprof tool library in this process? Its preloaded library has initialised the GPU before main(), and a
     process that has must not start another GPU program by exec — nor, to be safe, spawn a GPU child at all under it."""
-    if any(k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_")) or (k == "LD_PRELOAD" and "rocprof" in v) for k, v in os.environ.items()):
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return True
-    try:
-        with open("/proc/self/maps") as f:
-            return any("librocprofiler" in line or "librocprof-sys" in line for line in f)
+    try:  # the TOOL library (rocprofv3's librocprofiler-sdk-tool, rocprof's librocprofiler64 / libroctracer64) — NOT
+        with open("/proc/self/maps") as f:  # librocprofiler-register, which the HIP runtime itself always maps
+            return any(("librocprofiler-sdk-tool" in line) or ("librocprofiler64" in line) or ("libroctracer64" in line) or
+                       ("librocprof-sys" in line) for line in f)
     except Exception:
         return False
 

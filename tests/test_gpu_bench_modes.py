@@ -99,8 +99,7 @@ def test_one_process_group_mode_with_rccl():
 
 
 @pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("host", []),
-                                             ("torch", ["--torch-hosted"]), ("torch", ["--torch-hosted", "--overlap"]),
-                                             ("native", ["--torch-hosted"])])
+                                             ("torch", ["--torch-hosted", "--overlap"]), ("native", ["--torch-hosted"])])
 def test_launcher_mode_one_rank(exchange, extra):
     """One process per GPU under torch.distributed.run. Default: the GPU path is torch-free (gloo carries the rendezvous
     only) and the exchange is the library's own communicator (ma_comm_*) or, as its fall-back, the records over host memory;
@@ -215,7 +214,7 @@ def test_the_two_n_gt_1_modes_measure_alike():
     assert "hand-off by stamp" in g["config"]["exchange_form"] and "hand-off by stamp" in d["config"]["exchange_form"]
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("ranks", [3])
 def test_launcher_rehearsal_partitions_the_column_over_several_ranks(ranks):
     """The N > 1 headline's own code path with more than one rank on a one-GPU box: `--backend gloo` lets the ranks share
     the visible GPU (RCCL refuses that) and carries the 64-byte records over host memory — never a reported number, but
