@@ -389,8 +389,11 @@ ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols);
  * does exactly that). An event record between two back-to-back scans costs the stream several microseconds; the stamp costs
  * it nothing. */
 ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
-/* 64 bytes of signal memory on the context's device (hipExtMallocWithFlags(hipMallocSignalMemory); plain device memory when
- * the runtime refuses), zeroed: what a stream can be made to wait on. Free with ma_stamp_free. */
+/* A zeroed word on the context's device that a stream can be made to wait on (hipStreamWaitValue64) and a kernel's
+ * system-scope store reaches. A plain 64-byte device line by default: the wait is then a one-wave kernel that spins, which
+ * leaves the other streams' dispatches alone; MINARROW_HIP_STAMP_SIGNAL=1 asks for the runtime's signal memory instead (8 bytes,
+ * host memory; the wait becomes a packet the command processor polls — measured to hold up the scan stream of an overlapped
+ * step by 19-25 %, profiles/r05_share_1gpu.txt — but a host store can release it). Free with ma_stamp_free. */
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);
 ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp);
 /* 1 when `stamp` (from ma_stamp_alloc) is the runtime's signal memory, 0 when it is a plain device word (the fall-back; a

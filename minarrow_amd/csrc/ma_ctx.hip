@@ -1448,17 +1448,44 @@ ma_status ma_dev_alloc_output_stats(double* out_search_ms, size_t* out_held_peak
 static std::mutex g_stamp_mu;
 static std::vector<std::pair<const uint64_t*, int>> g_stamps;
 
+}  // extern "C"
+namespace ma {
+bool stamp_host_store(uint64_t* stamp, uint64_t value);
+bool stamp_default_is_signal();
+ma_status stamp_alloc_kind(ma_ctx* ctx, uint64_t** out_stamp, bool want_signal);
+}  // namespace ma
+extern "C" {
+
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
+    return ma::stamp_alloc_kind(ctx, out_stamp, ma::stamp_default_is_signal());
+}
+}  // extern "C"
+
+// Which memory a hand-off stamp lives in. A stream waits on either kind (hipStreamWaitValue64) and a kernel's system-scope
+// store reaches either, but the wait is not the same thing: on the runtime's SIGNAL memory (one 8-byte value — any other size
+// is refused — and host memory: profiles/r05_probe_signal.txt) it is a barrier-value packet the command processor polls, on
+// a plain device word a one-wave kernel that spins. Measured on the overlapped step of the 8-way share (125 M rows per
+// column, one fused scan per step, profiles/r05_share_1gpu.txt): with the stamp in signal memory the SCAN kernel between
+// its timing marks takes 0.342-0.360 ms instead of 0.288 — the packet the exchange stream's queue sits in holds up the scan
+// stream's dispatches — so hand-off stamps are device words (rounds 3-4's de-facto form: their 64-byte signal request was
+// always refused), MINARROW_HIP_STAMP_SIGNAL=1 asks for signal memory (A/B). Signal memory is what the group's stall words
+// use (testing hooks): a host store releases them with no GPU queue involved.
+bool ma::stamp_default_is_signal() {
+    static const bool on = [] {
+        const char* e = getenv("MINARROW_HIP_STAMP_SIGNAL");
+        return e && e[0] && e[0] != '0';
+    }();
+    return on;
+}
+
+ma_status ma::stamp_alloc_kind(ma_ctx* ctx, uint64_t** out_stamp, bool want_signal) {
     MA_REQUIRE(ctx != nullptr && out_stamp != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or out_stamp is NULL");
     *out_stamp = nullptr;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
-    // Signal memory is one 8-byte value (the runtime refuses any other size). It is taken only if it can be zeroed like any
-    // other allocation; otherwise — and on a runtime without it — a 64-byte line of plain device memory: a stream waits on
-    // either (hipStreamWaitValue64), and a kernel's system-scope store reaches either.
     void* p = nullptr;
     int kind = 1;
-    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(p, 0, 8) != hipSuccess) {
+    if (!want_signal || hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(p, 0, 8) != hipSuccess) {
         (void)hipGetLastError();
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -1481,10 +1508,6 @@ ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
 
 // `*stamp = value` by a plain host store when the word is host memory: the one release that needs no queue of the GPU (a
 // write packet can end up behind the very wait it is meant to end when streams share a hardware queue).
-}  // extern "C" (the helper below is internal)
-namespace ma {
-bool stamp_host_store(uint64_t* stamp, uint64_t value);
-}
 bool ma::stamp_host_store(uint64_t* stamp, uint64_t value) {
     {
         std::lock_guard<std::mutex> lock(g_stamp_mu);

@@ -241,7 +241,7 @@ ma_status enqueue_stall(ma_group* g, size_t member, hipStream_t stream) {
     const size_t n = g->ctxs.size();
     if (g->stall_word.size() < n) g->stall_word.resize(n, nullptr);
     MA_HIP(hipSetDevice(g->ctxs[member]->device));
-    if (!g->stall_word[member]) MA_TRY(ma_stamp_alloc(g->ctxs[member], &g->stall_word[member]));
+    if (!g->stall_word[member]) MA_TRY(stamp_alloc_kind(g->ctxs[member], &g->stall_word[member], true));  // host-releasable
     (void)rescue_stream(g, member);  // made now: not while a stream is stuck
     // the word holds the sequence of the last stall that was released; this one waits for the next
     if (hipStreamWaitValue64(stream, g->stall_word[member], g->stall_seq + 1, hipStreamWaitValueGte, ~(uint64_t)0) != hipSuccess) {

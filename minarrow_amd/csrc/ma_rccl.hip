@@ -157,7 +157,7 @@ void comm_write_word(ma_comm* comm, uint64_t* word, const uint64_t* value) {
 ma_status hook_stall(ma_comm* comm, hipStream_t stream) {
     if (!comm->stall_next) return MA_OK;
     comm->stall_next = false;
-    if (!comm->stall_word) MA_TRY(ma_stamp_alloc(comm->ctx, &comm->stall_word));
+    if (!comm->stall_word) MA_TRY(stamp_alloc_kind(comm->ctx, &comm->stall_word, true));  // host-releasable
     (void)comm_rescue(comm);
     if (hipStreamWaitValue64(stream, comm->stall_word, comm->stall_seq + 1, hipStreamWaitValueGte, ~(uint64_t)0) != hipSuccess) {
         (void)hipGetLastError();

@@ -44,6 +44,8 @@ void guard_log(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 // ma_ctx.hip: stores by the host when `stamp` (from ma_stamp_alloc) is host memory — signal memory is —; false otherwise.
 bool stamp_host_store(uint64_t* stamp, uint64_t value);
+// ma_ctx.hip: ma_stamp_alloc with the kind of memory chosen (signal memory: the host can release a wait on it by a store).
+ma_status stamp_alloc_kind(ma_ctx* ctx, uint64_t** out_stamp, bool want_signal);
 // ma_group_guard.hip: fn() on a helper thread, waited for at most timeout_ms; false when it has not returned (the thread is
 // left behind). For runtime calls that are documented to return but wait on the GPU inside (ncclCommAbort).
 bool call_bounded(const std::function<void()>& fn, double timeout_ms);
