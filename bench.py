@@ -1592,8 +1592,13 @@ def run_native(args, result_fd) -> int:
             for k in range(args.steps):
                 step(marked.get(k))
             host_issue = time.perf_counter() - t0  # this rank's time inside the enqueue calls (its GPU is still busy)
-            fence()
+            # This rank's clock stops when ITS work has finished (a bounded wait); the job's time is the MAX over the ranks, taken
+            # below. The ranks' verdict on the wait (one gloo all-reduce, ~0.2 ms) is outside the 5.5 ms that 20 steps of an 8-way
+            # partition take — every step's exchange is a collective of all ranks anyway, so none runs ahead of the slowest.
+            why = drain_local()
             elapsed = time.perf_counter() - t0
+            if not all_ok(not why):
+                raise _Downgrade(reasons(why))
             finals = last_results()  # the LAST step's finals
             ok = _check(total_rows, finals)
             if notch["kind"] != "none" and ladder.i + 1 < len(notches) and not all_ok(ok):

@@ -108,8 +108,12 @@ void write_word(ma_group* g, size_t i, uint64_t* word, const uint64_t* value) {
         return;
     }
     hipStream_t s = rescue_stream(g, i);
+    if (!s) {  // never the null stream: it would wait for the very streams that are held
+        guard_log("member %zu: no rescue stream: word %p is not released", i, (void*)word);
+        return;
+    }
     (void)hipSetDevice(g->ctxs[i]->device);
-    const hipError_t w = s ? hipStreamWriteValue64(s, word, *value, 0) : hipErrorInvalidValue;
+    const hipError_t w = hipStreamWriteValue64(s, word, *value, 0);
     guard_log("member %zu: word %p <- %llu through the rescue stream: %s (signal memory: %d)", i, (void*)word,
               (unsigned long long)*value, hipGetErrorString(w), ma_stamp_is_signal(word));
     if (w == hipSuccess) return;

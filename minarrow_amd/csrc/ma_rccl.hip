@@ -147,7 +147,8 @@ hipStream_t comm_rescue(ma_comm* comm) {
 void comm_write_word(ma_comm* comm, uint64_t* word, const uint64_t* value) {
     if (stamp_host_store(word, *value)) return;  // host memory (signal memory is): no GPU queue involved
     hipStream_t s = comm_rescue(comm);
-    if (s && hipStreamWriteValue64(s, word, *value, 0) == hipSuccess) return;
+    if (!s) return;  // never the null stream: it would wait for the very streams that are held
+    if (hipStreamWriteValue64(s, word, *value, 0) == hipSuccess) return;
     (void)hipGetLastError();
     if (hipMemcpyAsync(word, value, 8, hipMemcpyHostToDevice, s) != hipSuccess) (void)hipGetLastError();
 }
