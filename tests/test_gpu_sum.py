@@ -425,6 +425,33 @@ def test_narrow_int_sums_dense_and_masked(ctx, oracle, tag, dt, n):
         m.free()
 
 
+@pytest.mark.parametrize("tag,dt", [("i8", np.int8), ("u8", np.uint8)])
+def test_gated_byte_sums_in_the_deep_shape_with_a_tight_bitmap(ctx, oracle, tag, dt):
+    """Round 5's shape of the Bitmask-gated 1-byte sums: 8 loads per lane, a wave's run of 8192 rows = 128 validity words held
+    two per lane, a third load for the funnel partner of the last — clamped, not skipped, at the window's last word. Whole
+    numbers of 32 768-row workgroup tiles and ragged tails, every funnel phase incl. 0 (where word 128 is NOT part of the
+    window) and 63, the bitmap allocated to the byte (whole words, the reference's convention, and nothing behind them)."""
+    rng = np.random.default_rng(len(tag) + 50)
+    info = np.iinfo(dt)
+    tile = 32768
+    for n in (tile, 3 * tile, 5 * tile + 4097, 16 * tile - 1):
+        a = rng.integers(info.min, info.max, size=n, endpoint=True).astype(dt)
+        d = ctx.to_device(a)
+        for off in (0, 1, 13, 63, 64, 127):
+            n_words = (off + n + 63) // 64
+            bits = rng.integers(0, 256, size=n_words * 8, dtype=np.uint8)
+            m = ctx.to_device(bits)  # exactly the window's words
+            want = oracle.masked_sum(a, bits, off)
+            assert ctx.sum(tag, d, n, mask=m, mask_bit_offset=off) == want, (tag, n, off)
+            ctx.set_variant(2)  # round 4's shape (2 loads per lane) must agree
+            try:
+                assert ctx.sum(tag, d, n, mask=m, mask_bit_offset=off) == want, (tag, n, off, "round-4 shape")
+            finally:
+                ctx.set_variant(0)
+            m.free()
+        d.free()
+
+
 @pytest.mark.parametrize("tag,dt", NARROW)
 def test_narrow_int_sum_of_a_large_column(ctx, tag, dt):
     """2^31 + 77 rows (more than 32 bits of index for the 1-byte types' byte offsets would need; the per-load 32-bit partial
