@@ -126,7 +126,7 @@ bool read_word(ma_group* g, size_t i, const uint64_t* word, uint64_t* out) {
     hipStream_t s = rescue_stream(g, i);
     if (!s) return false;
     static thread_local uint64_t* pinned = nullptr;
-    if (!pinned && hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault) != hipSuccess) {
+    if (!pinned && hipHostMalloc((void**)&pinned, 64, hipHostMallocPortable) != hipSuccess) {  // every member's device copies into it
         (void)hipGetLastError();
         pinned = nullptr;
         return false;

@@ -33,11 +33,11 @@ def test_cpp_host_fails_loudly_without_a_gpu():
     assert r.returncode == 2 and "no HIP device is visible" in r.stdout
 
 
-def _build_example(tmp_path):
-    exe = tmp_path / "chunked_column"
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / "chunked_column.c"),
+def _build_example(tmp_path, name="chunked_column"):
+    exe = tmp_path / name
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(ROOT / "examples" / f"{name}.c"),
                     f"-L{ROOT / 'minarrow_amd' / 'lib'}", "-lminarrow_hip", f"-Wl,-rpath,{ROOT / 'minarrow_amd' / 'lib'}",
-                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+                    "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(exe)], check=True)
     return exe
 
 
@@ -54,6 +54,29 @@ def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
     from minarrow_amd import ffi
 
     exe = _build_example(tmp_path)
+    if ffi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device is visible" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_of_the_partitioned_sums_with_bounded_waits(tmp_path):
+    """examples/partitioned_sum.c: a C99 host over every visible GPU — the group with the overlapped RCCL exchange, the
+    self-test first, a stepping loop whose waits are bounded; the third step's exchange is stalled with the library's fault
+    hook: the host gets an error naming the pending member after its deadline, rebuilds the exchange one notch down on the same
+    members and columns, and every step's totals (on every GPU) match the closed forms."""
+    exe = _build_example(tmp_path, "partitioned_sum")
+    r = subprocess.run([str(exe), str((1 << 22) + 77), "6", "300"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "self-test: PASS" in r.stdout and "did not finish within 300 ms" in r.stdout and "one notch down" in r.stdout
+    assert r.stdout.strip().splitlines()[-1].startswith("ok: 6 steps"), r.stdout
+
+
+def test_c_partitioned_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    from minarrow_amd import ffi
+
+    exe = _build_example(tmp_path, "partitioned_sum")
     if ffi.device_count() > 0:
         pytest.skip("a GPU is visible")
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
