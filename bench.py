@@ -807,6 +807,17 @@ def group_other_configs(group, ctxs, cols_i, cols_f, rows: int, reps: int, wait_
     return res
 
 
+def _overlapped_scans(k, ms_per_step):
+    """Two scan lanes: consecutive scans overlap by design, so the span between a scan's marks (its start under the previous
+    scan's stragglers to its own end) is not time the GPU spent on it alone — the sum of the spans exceeds the wall clock. What a
+    launch costs the job is the step time; the span is kept beside it."""
+    k["span_ms"] = {"avg": k["avg_ms"], "min": k["min_ms"], "max": k.get("max_ms")}
+    k["avg_ms"] = k["min_ms"] = ms_per_step
+    k.pop("max_ms", None)
+    k["timed"] = ("consecutive scans overlap (two scan lanes): avg_ms = the job's wall time per step; span_ms = between a scan's own "
+                  "marks, its start under the previous scan's stragglers included")
+
+
 class _Downgrade(Exception):
     """The current exchange form cannot be trusted with the job (a deadline, wrong finals, a failed self-test): one notch down."""
 
@@ -880,11 +891,15 @@ def _bounded(fn, seconds: float):
 
 
 def _group_notches(args, overlap: bool):
-    """The one-process ladder: overlapped exchanges waiting on the scan's stamp -> on an event -> in-stream exchanges ->
-    the calling thread issuing grouped collectives instead of one issue thread per member -> the host fold (no RCCL)."""
+    """The one-process ladder: overlapped exchanges waiting on the scan's stamp, consecutive steps on two scan lanes gated on each
+    other's early stamp -> one scan stream -> hand-off by an event -> in-stream exchanges -> the calling thread issuing grouped
+    collectives instead of one issue thread per member -> the host fold (no RCCL)."""
     issue = "caller" if args.group_issue == "caller" else "threads"
     notches = []
     if args.exchange != "host":
+        if overlap and args.handoff == "stamp" and args.scan_lanes != "off" and args.step != "separate":  # lanes gate FUSED (stamped) steps
+            notches.append({"name": f"rccl, overlapped, hand-off by stamp, two scan lanes, issue {issue}", "exchange": "rccl-overlap-lanes",
+                            "issue": issue, "handoff": "stamp"})
         if overlap and args.handoff == "stamp":
             notches.append({"name": f"rccl, overlapped, hand-off by stamp, issue {issue}", "exchange": "rccl-overlap", "issue": issue, "handoff": "stamp"})
         if overlap:
@@ -955,17 +970,19 @@ def run_group(args, result_fd) -> int:
     hooks = {"stall": lambda: group.test_stall_next_exchange(world - 1), "corrupt": lambda: group.test_corrupt_next_exchange(world - 1)}
 
     def step(mark=None):
-        if mark is not None:  # timing marks (HIP events) on every member's stream, around its scan launch alone
-            for c in ctxs:
-                c.mark(mark)
         if fused:
+            if mark is not None:  # timing marks (HIP events) on every member's scanning stream, right around its scan launch
+                group.mark_next_scan(mark, mark + 1)
             enqueue_fused()
         else:
+            if mark is not None:
+                for c in ctxs:
+                    c.mark(mark)
             group.enqueue_sum("i64", 0, cols_i, lens)
             group.enqueue_sum("f64", 0, cols_f, lens)
-        if mark is not None:
-            for c in ctxs:
-                c.mark(mark + 1)
+            if mark is not None:
+                for c in ctxs:
+                    c.mark(mark + 1)
         group.exchange()
 
     def drain():
@@ -973,7 +990,8 @@ def run_group(args, result_fd) -> int:
 
     def apply(notch):
         """Makes the group's exchange the notch's (a rebuild keeps members, contexts and columns)."""
-        have = ("host" if group.exchange_kind == "host" else ("rccl-overlap" if group.overlapped else "rccl"), group.issue_kind)
+        have = ("host" if group.exchange_kind == "host" else
+                ("rccl-overlap-lanes" if group.scan_lanes else "rccl-overlap") if group.overlapped else "rccl", group.issue_kind)
         if group.is_broken or have != (notch["exchange"], notch["issue"]):
             done, _, err = _bounded(lambda: group.rebuild_exchange(notch["exchange"], notch["issue"]), args.init_seconds)
             if not done:
@@ -982,6 +1000,8 @@ def run_group(args, result_fd) -> int:
                                    "the group is held by that call")
             if err is not None:
                 raise _Downgrade(f"the exchange could not be set up: {err}")
+        if notch["exchange"] == "rccl-overlap-lanes" and not group.scan_lanes:
+            raise _Downgrade("two scan lanes could not be set up: " + group.exchange_note)
         if notch["handoff"] is not None:
             group.set_handoff(notch["handoff"])
             if notch["handoff"] == "stamp" and group.handoff != "stamp":
@@ -1040,12 +1060,14 @@ def run_group(args, result_fd) -> int:
 
     # Per-member scan time of a step, from the marks inside the timed loop (they bracket the scan launch alone in every form).
     per_member = []
-    for c in ctxs:
-        ms = [c.mark_elapsed_ms(m, m + 1) for m in marked.values()]
+    for mi, c in enumerate(ctxs):
+        ms = [group.mark_elapsed_ms(mi, m, m + 1) if fused else c.mark_elapsed_ms(m, m + 1) for m in marked.values()]
         per_member.append({"avg": sum(ms) / len(ms), "min": min(ms), "max": max(ms)})
     if fused:
         kernels = {"sum_fused": {"avg_ms": per_member[0]["avg"], "min_ms": per_member[0]["min"], "max_ms": per_member[0]["max"],
                                  "timed_steps": len(marked)}}
+        if group.scan_lanes:
+            _overlapped_scans(kernels["sum_fused"], elapsed / args.steps * 1e3)
     else:  # two launches between the marks: split by the columns' equal bytes (the fused form is the default)
         half = per_member[0]["avg"] / 2
         kernels = {"sum_i64": {"avg_ms": half, "min_ms": per_member[0]["min"] / 2, "timed_steps": len(marked),
@@ -1056,7 +1078,8 @@ def run_group(args, result_fd) -> int:
     scan_min, scan_max = min(p["avg"] for p in per_member), max(p["avg"] for p in per_member)
     form = ("RCCL all-gather (ncclCommInitAll; " +
             ("one per member issue thread" if group.issue_kind == "threads" else "grouped on the calling thread") + ") + device fold, " +
-            (f"on side streams, overlapped with the next step's scans, hand-off by {group.handoff}" if group.overlapped else "on the scan streams")
+            (f"on side streams, overlapped with the next step's scans, hand-off by {group.handoff}" +
+             (", consecutive steps on two scan lanes gated on the early stamp" if group.scan_lanes else "") if group.overlapped else "on the scan streams")
             if group.exchange_kind == "rccl" else "host fold of pinned records")
     out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
                        f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
@@ -1069,7 +1092,8 @@ def run_group(args, result_fd) -> int:
                         "host_issue_us_per_step": host_issue / args.steps * 1e6,
                         "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                         "scan_ms_per_step_min": scan_min, "scan_ms_per_step_max": scan_max,
-                        "scan_ms_per_step_min_over_members": scan_min, "scan_ms_per_step_max_over_members": scan_max})
+                        "scan_ms_per_step_min_over_members": scan_min, "scan_ms_per_step_max_over_members": scan_max,
+                        "scan_ms_is_span_of_overlapping_scans": bool(group.scan_lanes)})
     rc = 0 if ok else 1
     for b in cols_i + cols_f:
         b.free()
@@ -1393,6 +1417,9 @@ def run_native(args, result_fd) -> int:
     want_overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and world > 1)
     notches = []
     if distributed and not rehearsal and args.exchange != "host":
+        if want_overlap and fused and args.handoff == "stamp" and args.scan_lanes != "off":
+            notches.append({"name": "ma_comm, overlapped, hand-off by stamp, two scan lanes", "kind": "comm", "overlap": True, "stamp": True,
+                            "lanes": True})
         if want_overlap and fused and args.handoff == "stamp":
             notches.append({"name": "ma_comm, overlapped, hand-off by stamp", "kind": "comm", "overlap": True, "stamp": True})
         if want_overlap:
@@ -1402,6 +1429,8 @@ def run_native(args, result_fd) -> int:
         notches.append({"name": "records over host memory (gloo)", "kind": "host", "overlap": False, "stamp": False})
     else:
         notches.append({"name": "none (one rank): device fold on the scan stream", "kind": "none", "overlap": False, "stamp": False})
+    for nt in notches:
+        nt.setdefault("lanes", False)
     ladder = _Ladder(notches)
     faults = _Faults(os.environ.get("MA_BENCH_FAULT"))
     phase = ["setting up"]
@@ -1412,7 +1441,8 @@ def run_native(args, result_fd) -> int:
 
     from types import SimpleNamespace
 
-    S = SimpleNamespace(comm=None, overlap=False, exs=[], stamps=None, stamp_seq=[], fused_calls={}, counter=0, wedged=False)
+    S = SimpleNamespace(comm=None, overlap=False, exs=[], stamps=None, stamp_seq=[], fused_calls={}, counter=0, wedged=False,
+                        lanes=False, ctx2=None, mark_ctx={})
     ctx.set_async(True)
 
     def teardown(abort: bool):
@@ -1426,9 +1456,11 @@ def run_native(args, result_fd) -> int:
             ctx.synchronize()  # the scans themselves are this rank's own
         for ex in S.exs:
             ex.free()
+        if S.ctx2 is not None:
+            S.ctx2.synchronize()
         for st in (S.stamps or []):
             ctx.stamp_free(st)
-        S.exs, S.stamps, S.fused_calls, S.counter = [], None, {}, 0
+        S.exs, S.stamps, S.fused_calls, S.counter, S.lanes, S.mark_ctx = [], None, {}, 0, False, {}
 
     def setup(notch):
         S.overlap = notch["overlap"]
@@ -1456,6 +1488,18 @@ def run_native(args, result_fd) -> int:
         S.exs = [Records(ctx, world) for _ in range(2 if S.overlap else 1)]
         S.stamps = [ctx.stamp_alloc() for _ in S.exs] if notch["stamp"] else None
         S.stamp_seq = [0 for _ in S.exs]
+        # Two scan lanes: record set 1 is filled by scans on a SECOND context of this device, and every stamped scan is gated on the
+        # early stamp of the scan before it (word 1 of that scan's stamp line, stored by every workgroup as soon as its rows are
+        # scanned): its ramp runs under the previous scan's stragglers and hand-off (125 M rows per column: 0.2842 -> 0.2737 ms per
+        # step, profiles/r05_probe_early_stamp.jsonl)
+        S.lanes = bool(notch["lanes"]) and S.stamps is not None and all(ctx.lib.ma_stamp_is_signal(st) == 0 for st in S.stamps)
+        if notch["lanes"] and not S.lanes:
+            raise _Downgrade("two scan lanes need stamps in plain device words")
+        if S.lanes and S.ctx2 is None:
+            S.ctx2 = Context(device_index)
+            S.ctx2.set_variant(args.variant)
+            S.ctx2.set_blocks_per_cu(args.blocks_per_cu)
+            S.ctx2.set_async(True)
 
     def host_exchange(ex):
         """gloo detour: this rank's records to the host, all-gather among the hosts, back, device fold."""
@@ -1482,17 +1526,22 @@ def run_native(args, result_fd) -> int:
 
     def step(marks=None):
         k = S.counter % len(S.exs)
+        first = S.counter == 0
         S.counter += 1
         ex = S.exs[k]
         stamp = None
+        sc = S.ctx2 if (S.lanes and k == 1) else ctx  # the context that fills record set k
         if S.overlap:
-            S.comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
+            S.comm.slot_wait(k, sc if S.lanes else None)  # the scans below overwrite record set k: behind its last exchange
+        if S.lanes and not first:  # ... and under the stragglers of the scan before it (the other lane), not beside its whole length
+            sc.wait_value(S.stamps[k ^ 1] + 8, S.stamp_seq[k ^ 1])
         if marks is not None:
-            ctx.mark(marks)
+            sc.mark(marks)
+            S.mark_ctx[marks] = sc
         if fused:
             if k not in S.fused_calls:  # the argument table of a record set is built once
-                S.fused_calls[k] = ctx.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
-                                                         stamp=S.stamps[k] if S.stamps else 0)
+                S.fused_calls[k] = sc.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
+                                                        stamp=S.stamps[k] if S.stamps else 0, early=(S.stamps[k] + 8) if S.lanes else 0)
             if S.stamps:
                 S.stamp_seq[k] += 1
                 S.fused_calls[k](S.stamp_seq[k])
@@ -1505,7 +1554,7 @@ def run_native(args, result_fd) -> int:
                 ctx.mark(marks + 1)
             ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
         if marks is not None:
-            ctx.mark(marks + 2)
+            sc.mark(marks + 2)
         exchange(ex, k if S.overlap else None, stamp)
 
     def drain_local() -> str:
@@ -1515,6 +1564,8 @@ def run_native(args, result_fd) -> int:
                 S.comm.synchronize_for(wait_ms)  # the context's stream and the exchange stream
             else:
                 ctx.synchronize()
+            if S.ctx2 is not None:
+                S.ctx2.synchronize()  # the second lane's scans: their exchanges have finished, so have they
             return ""
         except Exception as e:  # noqa: BLE001
             return str(e)
@@ -1621,15 +1672,17 @@ def run_native(args, result_fd) -> int:
 
     # ---- the job's answer was verified above, outside the timed region (finals, ok) -----------------------
     if fused:
-        ms = [ctx.mark_elapsed_ms(m, m + 2) for m in marked.values()]
+        ms = [S.mark_ctx.get(m, ctx).mark_elapsed_ms(m, m + 2) for m in marked.values()]
         kernels = {"sum_fused": {"avg_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms), "timed_steps": len(ms)}}
+        if S.lanes:
+            _overlapped_scans(kernels["sum_fused"], elapsed / args.steps * 1e3)
     else:
         ms_i = [ctx.mark_elapsed_ms(m, m + 1) for m in marked.values()]
         ms_f = [ctx.mark_elapsed_ms(m + 1, m + 2) for m in marked.values()]
         kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i), "max_ms": max(ms_i), "timed_steps": len(ms_i)},
                    "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f), "max_ms": max(ms_f), "timed_steps": len(ms_f)}}
     # per-rank scan time of a step (min / max over the ranks) and where the exchange's time goes (sampled every 4th exchange)
-    scan_ms = sum(v["avg_ms"] for v in kernels.values())
+    scan_ms = sum(v.get("span_ms", {}).get("avg", v["avg_ms"]) for v in kernels.values())  # two scan lanes: the span between the marks
     scans = gather_obj(scan_ms)
     stats = comm.exchange_stats() if comm is not None else {"all_gather_us": 0.0, "fold_us": 0.0, "samples": 0, "rccl_ranks": 0}
 
@@ -1651,6 +1704,8 @@ def run_native(args, result_fd) -> int:
         if overlap:
             exch += "; exchange of step k on a side stream, overlapped with the scans of step k + 1" + \
                 (" (hand-off: the scan kernel's stamp, no event on the scan stream)" if stamps else " (hand-off: an event)")
+        if S.lanes:
+            exch += "; consecutive steps on two scan contexts, each gated on the early stamp of the one before"
         if ladder.downgrades:
             exch += f" [after {len(ladder.downgrades)} abandoned form(s): config.downgrades]"
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
@@ -1663,7 +1718,8 @@ def run_native(args, result_fd) -> int:
                             "host_issue_us_per_step": host_issue / args.steps * 1e6,
                             "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                             "scan_ms_per_step_min": min(scans), "scan_ms_per_step_max": max(scans),
-                            "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans)})
+                            "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans),
+                            "scan_ms_is_span_of_overlapping_scans": bool(S.lanes)})
         if (scaling == "strong" and world > 1) or args.force_dist:
             _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
     for b in (col_i, col_f):
@@ -1724,6 +1780,8 @@ def run_native(args, result_fd) -> int:
         _emit(result_fd, out)
         if not ok:
             print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
+    if S.ctx2 is not None:
+        S.ctx2.close()
     if S.wedged:  # a helper thread is still inside ncclCommInitRank: nothing may wait for it on the way out
         sys.stderr.flush()
         os._exit(rc)
@@ -2104,6 +2162,10 @@ def main() -> int:
                     help="overlapped exchanges: how the exchange stream learns that a step's records are complete — stamp = the "
                          "fused scan's final thread stores a sequence number the exchange stream waits on (hipStreamWaitValue64: "
                          "nothing but scans on the scan stream), event = an event recorded on the scan stream (rounds 2-3)")
+    ap.add_argument("--scan-lanes", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1, overlapped exchange with the stamp hand-off: consecutive steps on TWO scan streams per GPU, each gated "
+                         "on the early stamp of the step before it (its ramp runs under that step's stragglers: 0.2842 -> 0.2737 ms at "
+                         "125 M rows per column). auto / on = the first notch of the ladder; off = one scan stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",

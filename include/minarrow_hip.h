@@ -58,7 +58,9 @@ extern "C" {
  * ma_group_is_broken, ma_group_flags, ma_group_set_handoff / ma_group_handoff, ma_group_rebuild_exchange, ma_group_selftest
  * (+ ma_selftest_report), ma_comm_synchronize_for, ma_comm_abort, ma_comm_is_broken, ma_comm_selftest, ma_stamp_is_signal;
  * testing hooks ma_group_test_stall_next_exchange / _corrupt_next_exchange, ma_comm_test_stall_next_exchange /
- * _corrupt_next_exchange. A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange. */
+ * _corrupt_next_exchange. A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange.
+ * + ma_sum_fused_stamped_early, ma_ctx_wait_value, MA_GROUP_SCAN_LANES, ma_group_join_lanes (consecutive scans on two streams, the
+ * next one gated on the early stamp of the one before). */
 #define MA_ABI_VERSION 4
 
 typedef struct ma_ctx ma_ctx;
@@ -389,6 +391,14 @@ ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols);
  * does exactly that). An event record between two back-to-back scans costs the stream several microseconds; the stamp costs
  * it nothing. */
 ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
+/* The same, and additionally EVERY workgroup stores stamp_value to `*early_stamp` as soon as ITS rows are scanned — the first to
+ * finish gets there first: "this launch has begun to drain". A scan on ANOTHER context of the device that waits for it
+ * (ma_ctx_wait_value(other, early_stamp, stamp_value)) starts its ramp under this launch's stragglers and hand-off instead of
+ * behind them, without running beside its whole scan: consecutive independent scans alternated over two contexts this way read
+ * 7.04 -> 7.31 TB/s at 125 M rows per column, 5.67 -> 7.04 at 2^24 (profiles/r05_probe_early_stamp.jsonl). early_stamp may be
+ * word 1 of the line ma_stamp_alloc returned for `stamp` (a device-word stamp is 64 bytes). */
+ma_status ma_sum_fused_stamped_early(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
+                                     uint64_t* early_stamp);
 /* A zeroed word on the context's device that a stream can be made to wait on (hipStreamWaitValue64) and a kernel's
  * system-scope store reaches. A plain 64-byte device line by default: the wait is then a one-wave kernel that spins, which
  * leaves the other streams' dispatches alone; MINARROW_HIP_STAMP_SIGNAL=1 asks for the runtime's signal memory instead (8 bytes,
@@ -396,6 +406,10 @@ ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column
  * step by 19-25 %, profiles/r05_share_1gpu.txt — but a host store can release it). Free with ma_stamp_free. */
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);
 ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp);
+/* Makes the context's stream wait until `*word >= value` (hipStreamWaitValue64; `word` from ma_stamp_alloc): the consumer side of
+ * ma_sum_fused_stamped for a host that orders two contexts without events. Enqueue-only. MA_ERR_UNSUPPORTED on a runtime without
+ * stream memory operations. Whoever waits must be sure the value will be written: a wait nobody ends holds the stream for good. */
+ma_status ma_ctx_wait_value(ma_ctx* ctx, const uint64_t* word, uint64_t value);
 /* 1 when `stamp` (from ma_stamp_alloc) is the runtime's signal memory, 0 when it is a plain device word (the fall-back; a
  * wait on it works the same), -1 when the pointer is not a live stamp. */
 int32_t ma_stamp_is_signal(const uint64_t* stamp);
@@ -917,6 +931,18 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  *                            reads the set of the most recent exchange: a record slot read after an exchange must have been
  *                            enqueued in THAT step (MA_ERR_INVALID_ARGUMENT otherwise — it would come back from the other
  *                            set, two steps old). (The multi-process twin: ma_comm_sum_exchange_overlapped.)
+ *   MA_GROUP_SCAN_LANES      with MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP: every member gets a SECOND scan stream.
+ *                            Record set 0 is filled by scans on the member's own stream, set 1 by scans on the second one, so
+ *                            consecutive ma_group_enqueue_sum_table steps run on two streams — and each is gated on the EARLY
+ *                            stamp of the step before it (stored by every workgroup of that step as soon as its rows are
+ *                            scanned): its ramp runs under the previous step's stragglers and hand-off instead of behind them
+ *                            (125 M rows per column and member: 0.2842 -> 0.2737 ms per step, 7.04 -> 7.31 TB/s; 2^24 rows:
+ *                            -19 %; 10^9: no change — profiles/r05_probe_early_stamp.jsonl), without the two scans running
+ *                            side by side for their whole length. Ordering: work the host enqueues ITSELF on a member's context
+ *                            is seen by the group (the next step on the second lane is ordered behind all of it), but such work
+ *                            is ordered behind a step that runs on the second lane only after ma_group_join_lanes (enqueue-only)
+ *                            or ma_group_synchronize. Ignored (ma_group_exchange_note says so) without the overlapped RCCL
+ *                            exchange or where stamps are not plain device words.
  *   MA_GROUP_EXCHANGE_FALLBACK_HOST  with MA_GROUP_EXCHANGE_RCCL: use the host fold when RCCL cannot be initialised
  *                            (library missing, members sharing a device); ma_group_exchange_note() then says why.
  * ma_group_create() = ma_group_create_ex() with flags 0, or RCCL|FALLBACK_HOST when the environment variable
@@ -944,7 +970,10 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ma_group ma_group;
 #define MA_GROUP_MAX_COLUMNS 16
-enum { MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2, MA_GROUP_ISSUE_CALLER = 4, MA_GROUP_EXCHANGE_OVERLAP = 8 };
+enum {
+    MA_GROUP_EXCHANGE_RCCL = 1, MA_GROUP_EXCHANGE_FALLBACK_HOST = 2, MA_GROUP_ISSUE_CALLER = 4, MA_GROUP_EXCHANGE_OVERLAP = 8,
+    MA_GROUP_SCAN_LANES = 16
+};
 ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
 ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group);
 void ma_group_destroy(ma_group* group);
@@ -995,6 +1024,14 @@ ma_status ma_group_exchange_stats(ma_group* group, double* out_all_gather_us, do
                                   int32_t* out_rccl_ranks);
 ma_status ma_group_exchange(ma_group* group);
 ma_status ma_group_synchronize(ma_group* group);
+/* Timing marks around the scans of a group step, for a host that wants every member's scan time inside a longer timed region:
+ * ma_group_mark_next_scan makes the NEXT ma_group_enqueue_sum_table record marks from_index / to_index (ma_ctx_mark's index space)
+ * on every member's scanning context right around its scan launch — behind whatever the launch waits for (with
+ * MA_GROUP_SCAN_LANES: the early stamp of the step before), in front of the exchange; ma_group_mark_elapsed_ms waits for member's
+ * mark to_index and returns the milliseconds between the two (with two scan lanes consecutive steps overlap by design: the sum of
+ * the scans' times then exceeds the steps' wall time). */
+ma_status ma_group_mark_next_scan(ma_group* group, int32_t from_index, int32_t to_index);
+ma_status ma_group_mark_elapsed_ms(ma_group* group, int32_t member, int32_t from_index, int32_t to_index, float* out_ms);
 
 /* ---- first contact with a multi-GPU node: bounded waits, a way down, a self-test -----------------------------------------
  * The reference's parallel reduction is a plain `main` over a Rayon pool (benches/benchmark_parallel_simd.rs:81-125): a
@@ -1058,6 +1095,10 @@ enum {
 };
 enum { MA_GROUP_HANDOFF_STAMP = 0, MA_GROUP_HANDOFF_EVENT = 1 };
 ma_status ma_group_synchronize_for(ma_group* group, double timeout_ms);
+/* MA_GROUP_SCAN_LANES: every member's own stream waits (an event) for everything its second scan lane has been given so far —
+ * what a host calls before it enqueues work of its own on a member's context that must come AFTER the group's steps. A no-op
+ * for a group without lanes. Enqueue-only. */
+ma_status ma_group_join_lanes(ma_group* group);
 int32_t ma_group_is_broken(ma_group* group);
 ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags);
 uint32_t ma_group_flags(ma_group* group);
@@ -1166,6 +1207,10 @@ ma_status ma_comm_sum_exchange_overlapped_on_stamp(ma_comm* comm, int32_t slot, 
                                                    const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
                                                    uint64_t* gathered, uint64_t* out_finals);
 ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot);
+/* ma_comm_slot_wait for a host that fills the slot's records from ANOTHER context of the communicator's device (two scan
+ * contexts in turn, the second gated on the first's early stamp: ma_sum_fused_stamped_early): `ctx`'s stream is the one put
+ * behind the slot's last exchange. */
+ma_status ma_comm_slot_wait_on(ma_comm* comm, int32_t slot, ma_ctx* ctx);
 /* As ma_group_exchange_stats, for this rank's ma_comm_sum_exchange / _overlapped calls. */
 ma_status ma_comm_exchange_stats(ma_comm* comm, double* out_all_gather_us, double* out_fold_us, int32_t* out_samples,
                                  int32_t* out_rccl_ranks);

@@ -79,6 +79,8 @@ struct ma_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::atomic<bool> async{false};      // read without the lock by ma::Enter (may a busy context fan out?)
+    std::atomic<uint64_t> calls{0};      // entry points that have entered this context (a group with two scan lanes looks at
+                                         // it to learn that the host enqueued work of its own on a member's context)
     int num_cus = 0;
     int blocks_per_cu = 0;  // 0 = each kernel's own default
     int variant = 0;

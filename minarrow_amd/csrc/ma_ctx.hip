@@ -558,6 +558,7 @@ ma_status make_lane(ma_ctx* root, ma_ctx** out);  // defined with the context co
 Enter::Enter(ma_ctx*& ctx, bool primary_only) {
     if (ctx == nullptr) return;  // the entry point reports the NULL itself
     ma_ctx* root = ctx->parent ? ctx->parent : ctx;
+    root->calls.fetch_add(1, std::memory_order_relaxed);
     for (int i = 0; i < t_n_held; ++i)
         if (t_held[i].root == root) {  // a composed entry point calling its parts: same lane, no second lock
             ctx = t_held[i].lane;
@@ -1535,6 +1536,22 @@ ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp) {
             }
     }
     MA_HIP(hipFree(stamp));
+    return MA_OK;
+}
+
+ma_status ma_ctx_wait_value(ma_ctx* ctx, const uint64_t* word, uint64_t value) {
+    MA_REQUIRE(ctx != nullptr && word != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx or word is NULL");
+    MA_REQUIRE(((uintptr_t)word & 7) == 0 && pointer_kind(word) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "the word must be 8-byte aligned, device-reachable memory (ma_stamp_alloc)");
+    MA_ENTER_PRIMARY(ctx);
+    MA_NO_CAPTURE(ctx, "ma_ctx_wait_value");
+    MA_HIP(hipSetDevice(ctx->device));
+    const hipError_t e = hipStreamWaitValue64(ctx->stream, (void*)word, value, hipStreamWaitValueGte, ~(uint64_t)0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("this runtime has no stream memory operations (hipStreamWaitValue64: %s): order the streams with events", hipGetErrorString(e));
+        return MA_ERR_UNSUPPORTED;
+    }
     return MA_OK;
 }
 

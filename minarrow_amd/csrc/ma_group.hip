@@ -83,6 +83,11 @@ void release_exchange(ma_group* g) {
         (void)hipSetDevice(g->ctxs[i]->device);
         (void)hipStreamSynchronize(g->side[i]->stream);
     }
+    for (size_t i = 0; i < g->scan2.size(); ++i) {
+        if (!g->scan2[i]) continue;
+        (void)hipSetDevice(g->ctxs[i]->device);
+        (void)hipStreamSynchronize(g->scan2[i]->stream);
+    }
     if (g->use_rccl || !g->comms.empty()) {
         const RcclApi* api = rccl();
         for (ncclComm_t c : g->comms)
@@ -98,6 +103,8 @@ void release_exchange(ma_group* g) {
                 if (i < g->ev_done[k].size() && g->ev_done[k][i]) (void)hipEventDestroy(g->ev_done[k][i]);
             }
             if (i < g->side.size() && g->side[i]) ma_ctx_destroy(g->side[i]);
+            if (i < g->scan2.size() && g->scan2[i]) ma_ctx_destroy(g->scan2[i]);
+            if (i < g->ev_lane.size() && g->ev_lane[i]) (void)hipEventDestroy(g->ev_lane[i]);
             for (int k = 0; k < 2; ++k)
                 if (i < g->stamp[k].size() && g->stamp[k][i]) (void)ma_stamp_free(g->ctxs[i], g->stamp[k][i]);
         }
@@ -115,6 +122,11 @@ void release_exchange(ma_group* g) {
     g->gathered1.clear();
     g->finals1.clear();
     g->side.clear();
+    g->scan2.clear();
+    g->ev_lane.clear();
+    g->seen_calls.clear();
+    g->lanes2 = false;
+    g->prev_set = -1;
     for (int k = 0; k < 2; ++k) {
         g->ev_ready[k].clear();
         g->ev_done[k].clear();
@@ -167,7 +179,7 @@ namespace ma {
 namespace grp {
 
 // RCCL exchange set-up. Returns MA_OK with g->use_rccl set, or a status + the thread's error string.
-ma_status setup_rccl(ma_group* g, bool overlap) {
+ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
     const size_t n = g->ctxs.size();
     for (size_t i = 0; i < n; ++i)
         for (size_t j = i + 1; j < n; ++j)
@@ -228,6 +240,33 @@ ma_status setup_rccl(ma_group* g, bool overlap) {
         }
     }
     g->overlap = overlap;
+    // two scan lanes: only with stamps on every member (the early stamp is word 1 of the stamp's 64-byte device line)
+    bool all_stamps = overlap;
+    for (int k = 0; k < 2 && all_stamps; ++k) {
+        all_stamps = g->stamp[k].size() == n;
+        for (size_t i = 0; all_stamps && i < n; ++i) all_stamps = g->stamp[k][i] != nullptr && ma_stamp_is_signal(g->stamp[k][i]) == 0;
+    }
+    if (lanes && all_stamps) {
+        g->scan2.assign(n, nullptr);
+        g->ev_lane.assign(n, nullptr);
+        g->seen_calls.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            MA_TRY(ma_ctx_create(g->ctxs[i]->ordinal, &g->scan2[i]));  // an independent context: its own stream, partials, tickets
+            MA_TRY(ma_ctx_set_async(g->scan2[i], 1));
+            MA_HIP(hipSetDevice(devs[i]));
+            MA_HIP(hipEventCreateWithFlags(&g->ev_lane[i], hipEventDisableTiming | hipEventReleaseToDevice));
+            g->seen_calls[i] = g->ctxs[i]->calls.load();
+        }
+        g->lanes2 = true;
+    }
+    return MA_OK;
+}
+
+ma_status order_lane_if_foreign(ma_group* g, size_t i) {
+    if (!g->lanes2 || g->ctxs[i]->calls.load(std::memory_order_relaxed) == g->seen_calls[i]) return MA_OK;
+    MA_HIP(hipSetDevice(g->ctxs[i]->device));
+    MA_HIP(hipEventRecord(g->ev_lane[i], g->ctxs[i]->stream));
+    MA_HIP(hipStreamWaitEvent(g->scan2[i]->stream, g->ev_lane[i], 0));
     return MA_OK;
 }
 
@@ -357,7 +396,7 @@ ma_status require_resident(ma_group* g, DeviceLookup& lookup, size_t member, con
 }
 
 ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* chunk_data, const size_t* chunk_lens,
-                              const uint8_t* const* chunk_masks, const std::function<ma_status(size_t, uint64_t*)>& launch) {
+                              const uint8_t* const* chunk_masks, const std::function<ma_status(size_t, ma_ctx*, uint64_t*)>& launch) {
     MA_REQUIRE(g != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     MA_REQUIRE(column >= 0 && column < kColumns, MA_ERR_INVALID_ARGUMENT, "column %d out of range [0,%d)", column, kColumns);
     std::lock_guard<std::recursive_mutex> lock(g->mu);
@@ -368,12 +407,15 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
         MA_TRY(require_resident(g, lookup, i, chunk_data[i], "data", i));
         if (chunk_masks) MA_TRY(require_resident(g, lookup, i, chunk_masks[i], "validity bitmap", i));
     }
-    g->enq_mask[g->overlap ? g->cur : 0] |= 1u << column;
-    g->stamp_ok[g->overlap ? g->cur : 0] = false;  // not a stamped launch: this set's exchange waits on an event
+    const int cur_set = g->overlap ? g->cur : 0;
+    g->enq_mask[cur_set] |= 1u << column;
+    g->stamp_ok[cur_set] = false;  // not a stamped launch: this set's exchange waits on an event
+    g->prev_set = -1;
     // enqueue only (the members are in async mode): all devices run concurrently
     return run_on_members(g, [&](size_t i) {
         uint64_t* set = (g->overlap && g->cur == 1) ? g->local1[i] : g->local[i];
-        return launch(i, set + (size_t)column * kRecordWords);
+        if (cur_set == 1) MA_TRY(order_lane_if_foreign(g, i));
+        return launch(i, scan_ctx(g, cur_set, i), set + (size_t)column * kRecordWords);
     });
 }
 
@@ -407,7 +449,7 @@ ma_status exchange_locked(ma_group* g) {
             MA_HIP(hipStreamWaitValue64(g->side[i]->stream, g->stamp[set][i], g->stamp_seq[set], hipStreamWaitValueGte, ~(uint64_t)0));
             return MA_OK;
         }
-        MA_HIP(hipEventRecord(g->ev_ready[set][i], g->ctxs[i]->stream));
+        MA_HIP(hipEventRecord(g->ev_ready[set][i], scan_ctx(g, set, i)->stream));
         MA_HIP(hipStreamWaitEvent(g->side[i]->stream, g->ev_ready[set][i], 0));
         return MA_OK;
     };
@@ -419,7 +461,7 @@ ma_status exchange_locked(ma_group* g) {
             const hipError_t q = hipEventQuery(g->ev_done[set ^ 1][i]);  // finished already: no barrier packet on the stream
             if (q == hipErrorNotReady) {
                 (void)hipGetLastError();
-                MA_HIP(hipStreamWaitEvent(g->ctxs[i]->stream, g->ev_done[set ^ 1][i], 0));
+                MA_HIP(hipStreamWaitEvent(scan_ctx(g, set ^ 1, i)->stream, g->ev_done[set ^ 1][i], 0));  // the lane that fills it
             } else if (q != hipSuccess) {
                 (void)hipGetLastError();
                 return hip_fail(q, "hipEventQuery(exchange done)", __FILE__, __LINE__);
@@ -528,6 +570,10 @@ ma_status synchronize_locked(ma_group* g) {
     (void)run_on_members(g, [&](size_t i) -> ma_status {
         st[i] = ma_ctx_synchronize(g->ctxs[i]);
         if (st[i] != MA_OK) msg[i] = ma_last_error_string();
+        if (g->lanes2 && st[i] == MA_OK) {
+            st[i] = ma_ctx_synchronize(g->scan2[i]);
+            if (st[i] != MA_OK) msg[i] = ma_last_error_string();
+        }
         if (g->overlap && st[i] == MA_OK && hipStreamSynchronize(g->side[i]->stream) != hipSuccess) {
             st[i] = MA_ERR_DEVICE;
             msg[i] = "the exchange stream of a group member failed";
@@ -539,6 +585,8 @@ ma_status synchronize_locked(ma_group* g) {
             set_error("%s", msg[i].c_str());
             return st[i];
         }
+    if (g->lanes2)  // everything has finished: whatever the host enqueued itself is behind us
+        for (size_t i = 0; i < g->ctxs.size(); ++i) g->seen_calls[i] = g->ctxs[i]->calls.load(std::memory_order_relaxed);
     if (!g->use_rccl) {
         const auto t0 = std::chrono::steady_clock::now();
         for (int col = 0; col < kColumns; ++col) {
@@ -616,7 +664,8 @@ ma_status configure_exchange(ma_group* g, uint32_t flags) {
     ma_status st = MA_OK;
     char why[256] = "";
     if (flags & MA_GROUP_EXCHANGE_RCCL) {
-        st = setup_rccl(g, (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0);
+        st = setup_rccl(g, (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0,
+                        (flags & MA_GROUP_SCAN_LANES) != 0 && (flags & MA_GROUP_EXCHANGE_OVERLAP) != 0);
         if (st != MA_OK && (flags & MA_GROUP_EXCHANGE_FALLBACK_HOST)) {
             snprintf(why, sizeof(why), "host fold instead of RCCL: %s", ma_last_error_string());
             release_exchange(g);  // whatever the attempt allocated; the members stay
@@ -650,6 +699,10 @@ ma_status configure_exchange(ma_group* g, uint32_t flags) {
     }
     snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s%s%s", why, why[0] ? "; " : "", g->peer_note.c_str(),
              g->threads ? "one thread per member" : "calling thread", g->overlap ? "; exchange overlapped on side streams" : "", handoff);
+    if (g->lanes2) strncat(g->note, "; two scan lanes per member, gated on the early stamp", sizeof(g->note) - strlen(g->note) - 1);
+    else if (flags & MA_GROUP_SCAN_LANES)
+        strncat(g->note, "; two scan lanes asked for but not set up (they need the overlapped RCCL exchange with stamps in device words)",
+                sizeof(g->note) - strlen(g->note) - 1);
     return MA_OK;
 }
 
@@ -761,8 +814,8 @@ ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets) {
     MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, uint64_t* rec) {
-        return ma_i64_sum(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
+    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, ma_ctx* c, uint64_t* rec) {
+        return ma_i64_sum(c, chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
                           chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (int64_t*)&rec[0], &rec[1]);
     });
 }
@@ -771,8 +824,8 @@ ma_status ma_group_enqueue_sum_f64(ma_group* group, int32_t column, const double
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets) {
     MA_REQUIRE(group && chunk_data && chunk_lens, MA_ERR_INVALID_ARGUMENT, "NULL argument");
-    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, uint64_t* rec) {
-        return ma_f64_sum_dd(group->ctxs[i], chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
+    return enqueue_sum_members(group, column, (const void* const*)chunk_data, chunk_lens, chunk_masks, [&](size_t i, ma_ctx* c, uint64_t* rec) {
+        return ma_f64_sum_dd(c, chunk_data[i], chunk_lens[i], chunk_masks ? chunk_masks[i] : nullptr,
                              chunk_mask_offsets ? chunk_mask_offsets[i] : 0, -1, (double*)&rec[2], (double*)&rec[3], &rec[4]);
     });
 }
@@ -815,8 +868,33 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     for (size_t i = 0; stamped && i < group->ctxs.size(); ++i) stamped = group->stamp[cur_set][i] != nullptr;
     const uint64_t seq = stamped ? ++group->stamp_seq[cur_set] : 0;
     group->stamp_ok[cur_set] = stamped;
+    // two scan lanes: this step runs on the lane of its record set; when the call before it was a stamped step on the OTHER lane
+    // it starts as soon as that step's first workgroup has scanned its rows (the early stamp), not beside its whole scan
+    const bool lanes = group->lanes2;
+    const bool gate = lanes && stamped && group->prev_set >= 0 && group->prev_set != cur_set;
+    const int prev_set = group->prev_set;
+    const uint64_t prev_seq = group->prev_seq;
+    const int mark_from = group->mark_from, mark_to = group->mark_to;
+    group->mark_from = group->mark_to = -1;
+    if (mark_from >= 0) {
+        if (group->mark_lane.size() < (size_t)MA_CTX_MAX_MARKS) group->mark_lane.assign(MA_CTX_MAX_MARKS, 0);
+        group->mark_lane[(size_t)mark_from] = group->mark_lane[(size_t)mark_to] = (uint8_t)((group->lanes2 && cur_set == 1) ? 1 : 0);
+    }
     const ma_status st = run_on_members(group, [&](size_t i) -> ma_status {
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];
+        ma_ctx* sc = scan_ctx(group, cur_set, i);
+        if (lanes) {
+            if (sc != group->ctxs[i]) {  // the tuning knobs follow the member's context
+                sc->variant = group->ctxs[i]->variant;
+                sc->blocks_per_cu = group->ctxs[i]->blocks_per_cu;
+                sc->grid_override = group->ctxs[i]->grid_override;
+                MA_TRY(order_lane_if_foreign(group, i));
+            }
+            if (gate) {
+                MA_HIP(hipSetDevice(sc->device));
+                MA_HIP(hipStreamWaitValue64(sc->stream, group->stamp[prev_set][i] + 1, prev_seq, hipStreamWaitValueGte, ~(uint64_t)0));
+            }
+        }
         ma_fused_column cols[MA_FUSED_MAX_COLUMNS];
         for (int32_t k = 0; k < n_cols; ++k) {
             uint64_t* rec = set + (size_t)columns[k] * kRecordWords;
@@ -829,11 +907,20 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
             cols[k].reserved = 0;
             cols[k].out = format_codes[k] == 'g' ? rec + 2 : rec;
         }
-        return sum_fused_impl(group->ctxs[i], (size_t)n_cols, cols, stamped ? group->stamp[cur_set][i] : nullptr, seq);
+        if (mark_from >= 0) MA_TRY(ma_ctx_mark(sc, mark_from));  // behind the lane's waits: the marks bracket the scan alone
+        MA_TRY(sum_fused_impl(sc, (size_t)n_cols, cols, stamped ? group->stamp[cur_set][i] : nullptr, seq, false,
+                              (lanes && stamped) ? group->stamp[cur_set][i] + 1 : nullptr));
+        if (mark_to >= 0) MA_TRY(ma_ctx_mark(sc, mark_to));
+        return MA_OK;
     });
     // A member that refused the launch (a misaligned pointer, say) never stamps `seq`: an exchange waiting for that value on
     // its side stream would wait for good. The event path orders behind whatever did reach the streams.
     if (st != MA_OK) group->stamp_ok[cur_set] = false;
+    if (lanes) {
+        group->prev_set = (st == MA_OK && stamped) ? cur_set : -1;
+        group->prev_seq = seq;
+        for (size_t i = 0; i < group->ctxs.size(); ++i) group->seen_calls[i] = group->ctxs[i]->calls.load(std::memory_order_relaxed);
+    }
     return st;
 }
 
@@ -861,9 +948,12 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
         MA_TRY(require_resident(group, lookup, i % G, chunk_data[i], "data", i));
         if (chunk_masks) MA_TRY(require_resident(group, lookup, i % G, chunk_masks[i], "validity bitmap", i));
     }
-    group->enq_mask[group->overlap ? group->cur : 0] |= 1u << column;
-    group->stamp_ok[group->overlap ? group->cur : 0] = false;
+    const int cur_set = group->overlap ? group->cur : 0;
+    group->enq_mask[cur_set] |= 1u << column;
+    group->stamp_ok[cur_set] = false;
+    group->prev_set = -1;
     return run_on_members(group, [&](size_t m) -> ma_status {
+        if (cur_set == 1) MA_TRY(order_lane_if_foreign(group, m));
         std::vector<const void*> d;
         std::vector<size_t> n, o;
         std::vector<const uint8_t*> k;
@@ -875,7 +965,7 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
         }
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[m] : group->local[m];
         uint64_t* rec = set + (size_t)column * kRecordWords;
-        ma_ctx* c = group->ctxs[m];
+        ma_ctx* c = scan_ctx(group, cur_set, m);
         return is_float ? sum_chunks_dd(c, format_code, d.size(), d.data(), n.data(), chunk_masks ? k.data() : nullptr, o.data(),
                                         (double*)&rec[2], (double*)&rec[3], nullptr, &rec[4])
                         : sum_chunks_dd(c, format_code, d.size(), d.data(), n.data(), chunk_masks ? k.data() : nullptr, o.data(),
@@ -1089,6 +1179,29 @@ ma_status ma_group_consolidate_column(ma_group* group, int32_t dest_member, size
     MA_HIP(hipSetDevice(dest->device));
     return ma_consolidate_boolean_column(dest, n_chunks, bits.data(), slot_bit.data(), chunk_lens, nullptr, nullptr, out_mask,
                                          nullptr, nullptr);
+}
+
+ma_status ma_group_mark_next_scan(ma_group* group, int32_t from_index, int32_t to_index) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_REQUIRE(from_index >= 0 && from_index < MA_CTX_MAX_MARKS && to_index >= 0 && to_index < MA_CTX_MAX_MARKS && from_index != to_index,
+               MA_ERR_INVALID_ARGUMENT, "marks %d, %d (two different indices in [0,%d))", from_index, to_index, MA_CTX_MAX_MARKS);
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    group->mark_from = from_index;
+    group->mark_to = to_index;
+    return MA_OK;
+}
+
+ma_status ma_group_mark_elapsed_ms(ma_group* group, int32_t member, int32_t from_index, int32_t to_index, float* out_ms) {
+    MA_REQUIRE(group != nullptr && out_ms != nullptr, MA_ERR_INVALID_ARGUMENT, "group or out_ms is NULL");
+    MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
+    MA_REQUIRE(from_index >= 0 && from_index < MA_CTX_MAX_MARKS && to_index >= 0 && to_index < MA_CTX_MAX_MARKS, MA_ERR_INVALID_ARGUMENT,
+               "mark index out of range");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(group->mark_lane.size() == (size_t)MA_CTX_MAX_MARKS, MA_ERR_INVALID_ARGUMENT, "no marks have been recorded (ma_group_mark_next_scan)");
+    MA_REQUIRE(group->mark_lane[(size_t)from_index] == group->mark_lane[(size_t)to_index], MA_ERR_INVALID_ARGUMENT,
+               "marks %d and %d were recorded on different scan lanes", from_index, to_index);
+    ma_ctx* c = (group->mark_lane[(size_t)from_index] && group->lanes2) ? group->scan2[(size_t)member] : group->ctxs[(size_t)member];
+    return ma_ctx_mark_elapsed_ms(c, from_index, to_index, out_ms);
 }
 
 ma_status ma_group_exchange(ma_group* group) {

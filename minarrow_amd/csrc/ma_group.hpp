@@ -81,6 +81,24 @@ struct ma_group {
     std::vector<uint64_t*> stamp[2];
     uint64_t stamp_seq[2] = {0, 0};
     bool stamp_ok[2] = {false, false};
+    // MA_GROUP_SCAN_LANES (overlapped RCCL exchange only): a SECOND scan context per member. Record set 0 is filled by scans on
+    // the member's own context, set 1 by scans on scan2[i] — consecutive steps therefore run on two streams, and a stamped step
+    // on one lane is gated on the EARLY stamp of the step before it on the other (stored by every workgroup as soon as its rows
+    // are scanned): its ramp runs under that step's stragglers and hand-off instead of behind them (125 M rows per column:
+    // 0.2842 -> 0.2737 ms per step, profiles/r05_probe_early_stamp.jsonl), without the two scans running side by side for their
+    // whole length (which costs 2-5 % from 10^8 rows on). ev_lane / seen_calls: when the host — or a group call that is not such a
+    // step — has put work of its own on a member's context (ma_ctx::calls moved), the next lane-1 launch is ordered behind ALL
+    // of it with an event first.
+    bool lanes2 = false;
+    std::vector<ma_ctx*> scan2;
+    std::vector<hipEvent_t> ev_lane;
+    std::vector<uint64_t> seen_calls;
+    // ma_group_mark_next_scan: the next table step records these two timing marks on every member's scanning context, right
+    // around the scan launch (behind the lane's waits, in front of the exchange); mark_lane[index] = which lane holds mark index
+    int mark_from = -1, mark_to = -1;
+    std::vector<uint8_t> mark_lane;
+    int prev_set = -1;       // the set the previous call — a stamped table step — filled; -1: anything else
+    uint64_t prev_seq = 0;   // ... and the sequence its stamps carry
     uint64_t* host_records = nullptr;  // pinned, G x kColumns records (host exchange)
     uint64_t* host_finals = nullptr;   // pinned (RCCL: G x kColumns x 4) or plain (host: kColumns x 4) finals
     // ma_group_consolidate_column: per destination member a grow-only device arena the chunks' validity bytes are
@@ -96,7 +114,7 @@ struct ma_group {
 namespace ma {
 ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
-                         bool as_partials = false);
+                         bool as_partials = false, uint64_t* early_stamp = nullptr);
 
 namespace grp {
 
@@ -127,9 +145,15 @@ struct HostFoldDD {
     }
 };
 
+// The context whose stream fills record set `set` on member i.
+inline ma_ctx* scan_ctx(const ma_group* g, int set, size_t i) { return (g->lanes2 && set == 1) ? g->scan2[i] : g->ctxs[i]; }
+
 // ma_group.hip
 void release_exchange(ma_group* g);
-ma_status setup_rccl(ma_group* g, bool overlap);
+ma_status setup_rccl(ma_group* g, bool overlap, bool lanes);
+// Lane 1 of member i behind everything the member's own stream has been given so far (an event), when something other than the
+// group's stepping has touched the member's context since the group last looked.
+ma_status order_lane_if_foreign(ma_group* g, size_t i);
 ma_status setup_host(ma_group* g);
 void start_workers(ma_group* g);
 void stop_workers(ma_group* g);

@@ -147,7 +147,7 @@ bool read_word(ma_group* g, size_t i, const uint64_t* word, uint64_t* out) {
 }
 
 struct Pending {
-    std::vector<uint8_t> scan, side;  // 1 = that stream of the member has run empty
+    std::vector<uint8_t> scan, side, lane;  // 1 = that stream of the member has run empty (lane: the second scan lane)
     bool all_done = false;
     hipError_t error = hipSuccess;
     size_t error_member = 0;
@@ -159,13 +159,15 @@ void look(ma_group* g, Pending& p) {
     if (p.scan.empty()) {
         p.scan.assign(n, 0);
         p.side.assign(n, 0);
+        p.lane.assign(n, 0);
     }
     bool all = true;
     for (size_t i = 0; i < n; ++i) {
         (void)hipSetDevice(g->ctxs[i]->device);
-        hipStream_t streams[2] = {g->ctxs[i]->stream, (g->overlap && i < g->side.size() && g->side[i]) ? g->side[i]->stream : nullptr};
-        uint8_t* done[2] = {&p.scan[i], &p.side[i]};
-        for (int k = 0; k < 2; ++k) {
+        hipStream_t streams[3] = {g->ctxs[i]->stream, (g->overlap && i < g->side.size() && g->side[i]) ? g->side[i]->stream : nullptr,
+                                  (g->lanes2 && i < g->scan2.size() && g->scan2[i]) ? g->scan2[i]->stream : nullptr};
+        uint8_t* done[3] = {&p.scan[i], &p.side[i], &p.lane[i]};
+        for (int k = 0; k < 3; ++k) {
             if (*done[k]) continue;
             if (!streams[k]) {
                 *done[k] = 1;
@@ -210,7 +212,7 @@ std::string describe(ma_group* g, const Pending& p) {
     const size_t n = g->ctxs.size();
     int listed = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (p.scan[i] && p.side[i]) continue;
+        if (p.scan[i] && p.side[i] && p.lane[i]) continue;
         if (++listed > 8) {
             text += "; ...";
             break;
@@ -219,6 +221,7 @@ std::string describe(ma_group* g, const Pending& p) {
         std::string what;
         if (!p.scan[i]) what = g->overlap ? "scan stream (scans, or the wait for an earlier exchange of the set being re-filled)" :
                                             (g->use_rccl ? "stream (scan, all-gather or fold)" : "stream (scan)");
+        if (!p.lane[i]) what += (what.empty() ? "" : " and ") + std::string("second scan lane (a scan, or its wait for the step before it)");
         if (!p.side[i]) {
             if (!what.empty()) what += " and ";
             // which hand-off the last exchange used, and whether its value has arrived
@@ -401,12 +404,14 @@ struct SelfTest {
                 continue;
             }
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
-            MA_HIP(hipMemcpyAsync(local, blocks[i].data(), kBlockWords * 8, hipMemcpyHostToDevice, g->ctxs[i]->stream));
+            hipStream_t fill = scan_ctx(g, set, i)->stream;  // the stream that fills this record set (the second lane for set 1)
+            MA_HIP(hipMemcpyAsync(local, blocks[i].data(), kBlockWords * 8, hipMemcpyHostToDevice, fill));
             if (want_stamp) {
-                hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, g->ctxs[i]->stream, g->stamp[set][i], seq);
+                hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, fill, g->stamp[set][i], seq);
                 MA_HIP(hipGetLastError());
             }
         }
+        g->prev_set = -1;
         g->stamp_ok[set] = want_stamp;
         g->enq_mask[set] = (kColumns >= 32) ? ~0u : ((1u << kColumns) - 1u);
         const auto t0 = std::chrono::steady_clock::now();
@@ -580,6 +585,24 @@ struct SelfTest {
                 ++rep->stamp_waits_ok;
             }
         }
+        if (g->lanes2) {  // the lanes' gate: lane 1 waits on the EARLY word of set 0's stamp, stored by a kernel on lane 0 (and back)
+            for (int k = 0; k < 2; ++k) {
+                const uint64_t seq = ++g->stamp_seq[k];
+                for (size_t i = 0; i < n; ++i) {
+                    ++rep->stamp_waits;
+                    MA_HIP(hipSetDevice(g->ctxs[i]->device));
+                    hipStream_t from = scan_ctx(g, k, i)->stream, to = scan_ctx(g, k ^ 1, i)->stream;
+                    hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, from, g->stamp[k][i] + 1, seq);
+                    MA_HIP(hipGetLastError());
+                    hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, from, g->stamp[k][i], seq);  // the set's sequence stays level
+                    MA_HIP(hipGetLastError());
+                    MA_HIP(hipStreamWaitValue64(to, g->stamp[k][i] + 1, seq, hipStreamWaitValueGte, ~(uint64_t)0));
+                    MA_TRY(wait_one(i, to, "a scan lane's wait for the early stamp a kernel on the other lane stores"));
+                    MA_TRY(wait_one(i, from, "the stamping kernel"));
+                    ++rep->stamp_waits_ok;
+                }
+            }
+        }
         if (rep->stamp_waits)
             say("stamp waits %d/%d ok (slowest %.0f us from launch to the exchange stream running on)", rep->stamp_waits_ok,
                 rep->stamp_waits, rep->stamp_us_max);
@@ -608,9 +631,10 @@ int32_t ma_group_is_broken(ma_group* group) {
 uint32_t ma_group_flags(ma_group* group) {
     if (!group) return 0;
     std::lock_guard<std::recursive_mutex> lock(group->mu);
-    uint32_t f = group->flags & ~(uint32_t)(MA_GROUP_ISSUE_CALLER | MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP);
+    uint32_t f = group->flags & ~(uint32_t)(MA_GROUP_ISSUE_CALLER | MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP | MA_GROUP_SCAN_LANES);
     if (group->use_rccl) f |= MA_GROUP_EXCHANGE_RCCL;
     if (group->overlap) f |= MA_GROUP_EXCHANGE_OVERLAP;
+    if (group->lanes2) f |= MA_GROUP_SCAN_LANES;
     if (!group->threads) f |= MA_GROUP_ISSUE_CALLER;
     return f;
 }
@@ -635,6 +659,20 @@ int32_t ma_group_handoff(ma_group* group) {
             if (!w) return MA_GROUP_HANDOFF_EVENT;
     }
     return MA_GROUP_HANDOFF_STAMP;
+}
+
+ma_status ma_group_join_lanes(ma_group* group) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
+    if (!group->lanes2) return MA_OK;
+    for (size_t i = 0; i < group->ctxs.size(); ++i) {  // the member's own stream behind everything its second lane has been given
+        MA_HIP(hipSetDevice(group->ctxs[i]->device));
+        MA_HIP(hipEventRecord(group->ev_lane[i], group->scan2[i]->stream));
+        MA_HIP(hipStreamWaitEvent(group->ctxs[i]->stream, group->ev_lane[i], 0));
+    }
+    group->prev_set = -1;
+    return MA_OK;
 }
 
 ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags) {

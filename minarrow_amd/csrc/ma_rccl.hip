@@ -469,11 +469,14 @@ static ma_status exchange_overlapped(ma_comm* comm, int32_t slot, uint64_t* stam
     return MA_OK;
 }
 
-ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) {
+ma_status ma_comm_slot_wait(ma_comm* comm, int32_t slot) { return ma_comm_slot_wait_on(comm, slot, comm ? comm->ctx : nullptr); }
+
+ma_status ma_comm_slot_wait_on(ma_comm* comm, int32_t slot, ma_ctx* ctx) {
     MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(ctx->device == comm->ctx->device, MA_ERR_INVALID_ARGUMENT, "the context must be on the communicator's device");
     MA_REQUIRE(slot == 0 || slot == 1, MA_ERR_INVALID_ARGUMENT, "slot must be 0 or 1");
     if (!comm->side || !comm->used[slot]) return MA_OK;
-    ma_ctx* ctx = comm->ctx;
     MA_ENTER_PRIMARY(ctx);
     MA_HIP(hipSetDevice(ctx->device));
     // Two steps ago, normally long finished: then the host's look at the event is the whole wait, and the stream is spared a

@@ -688,7 +688,7 @@ using namespace ma;
 
 namespace ma {
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
-                         bool as_partials);  // ma_reduce_fused.hip
+                         bool as_partials, uint64_t* early_stamp);  // ma_reduce_fused.hip
 }
 
 static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
@@ -775,7 +775,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
                         fc[j].format_code = format_code;
                         fc[j].out = (uint64_t*)&partials[i];
                     }
-                    MA_TRY(sum_fused_impl(ctx, k, fc, nullptr, 0, true));
+                    MA_TRY(sum_fused_impl(ctx, k, fc, nullptr, 0, true, nullptr));
                 }
             }
             const bool is_signed = format_code != 'L';

@@ -48,6 +48,8 @@ struct FusedArgs {
     unsigned int* ticket;
     uint64_t* done_word;    // pinned word stamped after the results (synchronous call that polls), or nullptr
     uint64_t done_seq;
+    uint64_t* early_word;   // stamped with done_seq by every workgroup as soon as ITS rows are scanned (the first to finish gets
+                            // there first): "this launch has begun to drain" — what the NEXT scan on another stream waits for
 };
 
 // One accumulator per (column, row-of-a-load): two 64-bit words that are a wrapping integer sum (a) or a double-double
@@ -247,6 +249,9 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
         }
     }
 
+    // this workgroup's rows are scanned: the launch has begun to drain (see FusedArgs::early_word)
+    if (a.early_word && tid == 0) __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
     // ---- workgroup reduce, all columns ------------------------------------------------------------------------------
     __shared__ Partial lds[kFusedMax][kWaves];
     __shared__ int is_last;
@@ -408,7 +413,7 @@ using namespace ma;
 
 namespace ma {
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
-                         bool as_partials = false);
+                         bool as_partials = false, uint64_t* early_stamp = nullptr);
 }
 
 extern "C" ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols) {
@@ -422,10 +427,19 @@ extern "C" ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_f
     return sum_fused_impl(ctx, n_cols, cols, stamp, stamp_value);
 }
 
+extern "C" ma_status ma_sum_fused_stamped_early(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp,
+                                                uint64_t stamp_value, uint64_t* early_stamp) {
+    MA_REQUIRE(stamp != nullptr && ((uintptr_t)stamp & 7) == 0, MA_ERR_INVALID_ARGUMENT, "stamp is NULL or misaligned");
+    MA_REQUIRE(early_stamp != nullptr && ((uintptr_t)early_stamp & 7) == 0, MA_ERR_INVALID_ARGUMENT, "early_stamp is NULL or misaligned");
+    MA_REQUIRE(pointer_kind(stamp) != kPageable && pointer_kind(early_stamp) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "stamps must be device-reachable memory");
+    return sum_fused_impl(ctx, n_cols, cols, stamp, stamp_value, false, early_stamp);
+}
+
 // as_partials: every column's `out` receives a 32-byte ma::Partial {sum or hi, 0 or lo, valid count, 0} — the input of
 // ma_reduce_batch.hip's folds — instead of the record words of the public entry points.
 ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
-                             bool as_partials) {
+                             bool as_partials, uint64_t* early_stamp) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
     MA_REQUIRE(n_cols >= 1 && n_cols <= (size_t)kFusedMax && cols != nullptr, MA_ERR_INVALID_ARGUMENT,
                "ma_sum_fused takes 1..%d columns", kFusedMax);
@@ -492,6 +506,7 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
     const int pace = sel >= 0 ? sel : 20;
     a.done_word = stamp;  // stored (system-scope release) by the launch's final thread behind its results
     a.done_seq = stamp_value;
+    a.early_word = early_stamp;  // stored by every workgroup as soon as its rows are scanned (FusedArgs::early_word)
     if (any_masked) launch_fused<4, true>(ctx, a, grid, 0);
     else launch_fused<8, false>(ctx, a, grid, pace);
     MA_HIP(hipGetLastError());

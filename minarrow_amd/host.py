@@ -382,10 +382,14 @@ class Context:
         ffi.check(self.lib.ma_stamp_alloc(self.handle, C.byref(p)))
         return int(p.value)
 
+    def wait_value(self, word: int, value: int) -> None:
+        """The context's stream waits until `*word >= value` (ma_ctx_wait_value)."""
+        ffi.check(self.lib.ma_ctx_wait_value(self.handle, int(word), int(value)))
+
     def stamp_free(self, stamp: int) -> None:
         ffi.check(self.lib.ma_stamp_free(self.handle, stamp))
 
-    def prepare_sum_fused(self, columns, stamp: int = 0):
+    def prepare_sum_fused(self, columns, stamp: int = 0, early: int = 0):
         """The same call with its argument table built ONCE: returns a zero-argument callable for a stepping host (a Rust
         host builds its ma_fused_column array once too; the Python marshalling is ~30 us per call otherwise)."""
         arr = (FusedColumn * len(columns))()
@@ -397,6 +401,15 @@ class Context:
             arr[i].null_count = int(col[6]) if len(col) > 6 else -1
             arr[i].format_code, arr[i].reserved = ord(fmt), 0
         handle, k, p = self.handle, len(columns), C.addressof(arr)
+        if stamp and early:  # ... and every workgroup stores it to `early` as soon as its rows are scanned (ma_sum_fused_stamped_early)
+            fe = self.lib.ma_sum_fused_stamped_early
+
+            def call_stamped_early(value, _keep=arr):
+                st = fe(handle, k, p, stamp, value, early)
+                if st:
+                    ffi.check(st)
+
+            return call_stamped_early
         if stamp:  # call(value): the launch's final thread stores `value` to the stamp behind its results (ma_sum_fused_stamped)
             fs = self.lib.ma_sum_fused_stamped
 
@@ -711,7 +724,8 @@ class SelftestReport(C.Structure):
 
 SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS = 1, 2, 4, 8
 SELFTEST_OVERLAP_EVENT, SELFTEST_OVERLAP_STAMP = 16, 32  # Comm.selftest only
-GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8}
+GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "rccl-overlap-or-host": 3 | 8,
+               "rccl-overlap-lanes": 1 | 8 | 16, "rccl-overlap-lanes-or-host": 3 | 8 | 16}
 
 
 class Group:
@@ -916,6 +930,22 @@ class Group:
         return bool(self.flags & 8)
 
     @property
+    def scan_lanes(self) -> bool:
+        """Two scan streams per member, consecutive stamped steps gated on each other's early stamp (MA_GROUP_SCAN_LANES)."""
+        return bool(self.flags & 16)
+
+    def mark_next_scan(self, from_index: int, to_index: int) -> None:
+        ffi.check(self.lib.ma_group_mark_next_scan(self.handle, int(from_index), int(to_index)))
+
+    def mark_elapsed_ms(self, member: int, from_index: int, to_index: int) -> float:
+        ms = C.c_float()
+        ffi.check(self.lib.ma_group_mark_elapsed_ms(self.handle, int(member), int(from_index), int(to_index), C.addressof(ms)))
+        return float(ms.value)
+
+    def join_lanes(self) -> None:
+        ffi.check(self.lib.ma_group_join_lanes(self.handle))
+
+    @property
     def handoff(self) -> Optional[str]:
         """"stamp" / "event": what an overlapped, stamped step's exchange stream waits on; None when the group does not overlap."""
         return {0: "stamp", 1: "event"}.get(int(self.lib.ma_group_handoff(self.handle)))
@@ -1030,9 +1060,13 @@ class Comm:
         ffi.check(self.lib.ma_comm_sum_exchange_overlapped_on_stamp(self.handle, int(slot), stamp, int(value), addr_of(local_records),
                                                                    int(slots_per_rank), int(n_columns), addr_of(gathered), addr_of(out_finals)))
 
-    def slot_wait(self, slot: int) -> None:
-        """Puts the context's stream behind the last overlapped exchange of record set `slot`."""
-        ffi.check(self.lib.ma_comm_slot_wait(self.handle, int(slot)))
+    def slot_wait(self, slot: int, ctx: Optional["Context"] = None) -> None:
+        """Puts the context's stream (or `ctx`'s: a second scan context of the same device) behind the last overlapped exchange
+        of record set `slot`."""
+        if ctx is None:
+            ffi.check(self.lib.ma_comm_slot_wait(self.handle, int(slot)))
+        else:
+            ffi.check(self.lib.ma_comm_slot_wait_on(self.handle, int(slot), ctx.handle))
 
     def synchronize(self) -> None:
         ffi.check(self.lib.ma_comm_synchronize(self.handle))

@@ -142,54 +142,49 @@ def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(m
     out = run(base)
     cfg = out["config"]
     assert out["parity_ok"] and [d["abandoned"] for d in cfg["downgrades"]] == [
-        "ma_comm, overlapped, hand-off by stamp", "ma_comm, overlapped, hand-off by event", "ma_comm, in-stream"]
-    assert all("set-up check" in d["why"] for d in cfg["downgrades"]) and "3 abandoned" in cfg["exchange"]
+        "ma_comm, overlapped, hand-off by stamp, two scan lanes", "ma_comm, overlapped, hand-off by stamp",
+        "ma_comm, overlapped, hand-off by event", "ma_comm, in-stream"]
+    assert all("set-up check" in d["why"] for d in cfg["downgrades"]) and "4 abandoned" in cfg["exchange"]
     assert cfg["exchange_form"].startswith("none (one rank)") and cfg["rccl_ranks"] == 0
     out = run(base + ["--torch-hosted"])
     assert out["parity_ok"] and "torch.distributed" in out["config"]["exchange"] and "set-up check" in out["config"]["exchange"]
     assert "side stream" in out["config"]["exchange"]
 
 
-@pytest.mark.parametrize("fault, abandoned, runs_as", [
-    ("corrupt@setup", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
-    ("stall@preflight,stall@setup", ["rccl, overlapped, hand-off by stamp, issue threads", "rccl, overlapped, hand-off by event, issue threads"],
-     "rccl, in-stream, issue threads"),
-    ("stall@timed", ["rccl, overlapped, hand-off by stamp, issue threads"], "rccl, overlapped, hand-off by event, issue threads"),
-    ("stall@setup,stall@setup,corrupt@setup,stall@timed", None, "host fold, issue threads"),
-])
-def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, abandoned, runs_as):
+G = ["rccl, overlapped, hand-off by stamp, two scan lanes, issue threads", "rccl, overlapped, hand-off by stamp, issue threads",
+     "rccl, overlapped, hand-off by event, issue threads", "rccl, in-stream, issue threads", "rccl, in-stream, issue caller (grouped)",
+     "host fold, issue threads"]  # the one-process ladder, best first
+L = ["ma_comm, overlapped, hand-off by stamp, two scan lanes", "ma_comm, overlapped, hand-off by stamp",
+     "ma_comm, overlapped, hand-off by event", "ma_comm, in-stream", "none (one rank): device fold on the scan stream"]
+
+
+@pytest.mark.parametrize("fault, notches_down", [("corrupt@setup", 1), ("stall@preflight,stall@setup", 2), ("stall@timed", 1),
+                                                 ("stall@setup,stall@setup,corrupt@setup,stall@timed,stall@preflight", 5)])
+def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_down):
     """`bench.py --gpus N` in one process, on first contact with an exchange that never completes (or folds wrongly): the
     line still comes, rc 0, parity ok, and names the form that ran and what was abandoned on the way (the faults are the
-    library's own test hooks, armed through MA_BENCH_FAULT)."""
+    library's own test hooks, armed through MA_BENCH_FAULT) — all the way down to the host fold."""
     out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--overlap", "on", *QUICK], {"MA_BENCH_FAULT": fault},
               timeout=240)
     cfg = out["config"]
     assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
-    assert cfg["exchange_form"] == runs_as, cfg["downgrades"]
-    got = [d["abandoned"] for d in cfg["downgrades"]]
-    if abandoned is not None:
-        assert got == abandoned
-    else:  # all the way down: every RCCL form abandoned in ladder order
-        assert got == ["rccl, overlapped, hand-off by stamp, issue threads", "rccl, overlapped, hand-off by event, issue threads",
-                       "rccl, in-stream, issue threads", "rccl, in-stream, issue caller (grouped)"]
+    assert [d["abandoned"] for d in cfg["downgrades"]] == G[:notches_down] and cfg["exchange_form"] == G[notches_down], cfg["downgrades"]
+    if notches_down == 5:
         assert "host fold" in cfg["exchange"] and cfg["rccl_ranks"] == 0
     for d in cfg["downgrades"]:
         assert ("did not finish within" in d["why"]) or ("finals are wrong" in d["why"]) or ("self-test failed" in d["why"]), d
-    assert cfg["preflight"]["ok"] and cfg["attempts"] == len(got) + 1
+    assert cfg["preflight"]["ok"] and cfg["attempts"] == notches_down + 1
 
 
-@pytest.mark.parametrize("fault, abandoned, runs_as", [
-    ("corrupt@setup,stall@preflight", ["ma_comm, overlapped, hand-off by stamp", "ma_comm, overlapped, hand-off by event"], "ma_comm, in-stream"),
-    ("stall@timed", ["ma_comm, overlapped, hand-off by stamp"], "ma_comm, overlapped, hand-off by event"),
-])
-def test_launcher_mode_goes_down_its_ladder_instead_of_hanging(fault, abandoned, runs_as):
+@pytest.mark.parametrize("fault, notches_down", [("corrupt@setup,stall@preflight", 2), ("stall@timed", 1)])
+def test_launcher_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_down):
     """The same under torch.distributed.run (one process per GPU, ma_comm_*): the ranks agree over gloo after every bounded
     wait; the communicator is aborted and a new one made from a fresh id for the next form down."""
     out = run([*LAUNCH, "--master-port", "29643", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--overlap", "on", *QUICK],
               {"MA_BENCH_FAULT": fault}, timeout=240)
     cfg = out["config"]
     assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
-    assert [d["abandoned"] for d in cfg["downgrades"]] == abandoned and cfg["exchange_form"] == runs_as
+    assert [d["abandoned"] for d in cfg["downgrades"]] == L[:notches_down] and cfg["exchange_form"] == L[notches_down]
     assert cfg["rccl_ranks"] == 1 and cfg["preflight"]["ok"]
 
 
@@ -211,7 +206,11 @@ def test_the_two_n_gt_1_modes_measure_alike():
     for key in ("exchange_us", "fold_us"):  # a 1-rank all-gather and a 1-record fold: microseconds either way
         assert 0 < g["config"][key] < 500 and 0 < d["config"][key] < 500
     assert g["config"]["downgrades"] == d["config"]["downgrades"] == []
-    assert "hand-off by stamp" in g["config"]["exchange_form"] and "hand-off by stamp" in d["config"]["exchange_form"]
+    assert "two scan lanes" in g["config"]["exchange_form"] and "two scan lanes" in d["config"]["exchange_form"]
+    assert "two scan lanes" in g["config"]["exchange"] and "two scan contexts" in d["config"]["exchange"]
+    # one scan stream, for the record: the same job, the same result
+    one = run([sys.executable, "bench.py", *common, "--gpus", "1", "--force-group", "--scan-lanes", "off"])
+    assert one["parity_ok"] and one["result"] == g["result"] and "two scan lanes" not in one["config"]["exchange_form"]
 
 
 @pytest.mark.parametrize("ranks", [3])

@@ -76,7 +76,7 @@ def test_synchronize_for_is_synchronize_when_nothing_hangs(exchange, issue):
 
 
 @pytest.mark.parametrize("exchange, issue", [("rccl", "threads"), ("rccl", "caller"), ("rccl-overlap", "threads"),
-                                             ("rccl-overlap", "caller"), ("host", "threads")])
+                                             ("rccl-overlap", "caller"), ("rccl-overlap-lanes", "threads"), ("host", "threads")])
 def test_a_stalled_exchange_ends_in_an_error_not_a_hang_and_the_group_can_be_rebuilt(exchange, issue):
     g = Group([0], exchange=exchange, issue=issue) if exchange == "host" else _rccl_group(exchange, issue)
     try:
@@ -171,7 +171,7 @@ def test_handoff_can_be_switched_without_a_rebuild():
 
 
 @pytest.mark.parametrize("exchange, issue", [("rccl", "threads"), ("rccl", "caller"), ("rccl-overlap", "threads"),
-                                             ("rccl-overlap", "caller"), ("host", "threads")])
+                                             ("rccl-overlap", "caller"), ("rccl-overlap-lanes", "threads"), ("host", "threads")])
 def test_selftest_passes_in_every_form_this_box_can_run(exchange, issue):
     g = Group([0], exchange=exchange, issue=issue) if exchange == "host" else _rccl_group(exchange, issue)
     try:
@@ -179,15 +179,16 @@ def test_selftest_passes_in_every_form_this_box_can_run(exchange, issue):
         assert rep["ok"] and rep["text"].startswith("PASS"), rep
         assert rep["members"] == 1 and rep["devices"] == 1 and rep["peer_pairs"] == 0
         assert len(rep["forms"]) == 1 and all(f["ok"] and f["us"] > 0 for f in rep["forms"].values()), rep
-        if exchange == "rccl-overlap":
+        if exchange.startswith("rccl-overlap"):
             (name,) = rep["forms"]
             assert name == f"overlap-{g.handoff}/{issue}"
-            if g.handoff == "stamp":
-                assert rep["stamp_waits"] == rep["stamp_waits_ok"] == 2
+            if g.handoff == "stamp":  # one wait per record set; with two scan lanes also the lanes' early-stamp gate, both ways
+                assert rep["stamp_waits"] == rep["stamp_waits_ok"] == (4 if exchange.endswith("lanes") else 2)
+            assert g.scan_lanes == exchange.endswith("lanes")
         if exchange.startswith("rccl"):
             assert rep["rccl_ranks"] == 1 and rep["exchange"] == "rccl"
         allf = g.selftest(20_000, SELFTEST_EXCHANGE | SELFTEST_EXCHANGE_ALL_FORMS)
-        want = {"rccl": 2, "rccl-overlap": 4 if g.handoff == "stamp" else 2, "host": 1}[exchange]
+        want = {"rccl": 2, "rccl-overlap": 4 if g.handoff == "stamp" else 2, "rccl-overlap-lanes": 4, "host": 1}[exchange]
         assert allf["ok"] and len(allf["forms"]) == want and all(f["ok"] for f in allf["forms"].values()), allf
         assert g.issue_kind == issue, "the self-test leaves the issue form as it found it"
         # the group still does its job afterwards, and the test left nothing behind in its records
@@ -287,3 +288,52 @@ def test_comm_selftest_and_bounded_wait(ctx):
         assert again.is_broken == 1
     finally:
         again.close()
+
+
+def test_two_scan_lanes_give_every_step_its_own_results():
+    """MA_GROUP_SCAN_LANES: consecutive stamped steps run on two scan streams per member, each gated on the early stamp of the one
+    before. Steps over DIFFERENT columns in turn (so that a step served by the wrong lane's records, or started before its
+    input was ready, would show), every step's finals checked; work the host enqueues itself on the member's context in between
+    (a column rewritten in place) is seen by the step that follows it, on either lane; marks bracket the scan on whichever lane."""
+    g = _rccl_group("rccl-overlap-lanes")
+    try:
+        assert g.scan_lanes and "two scan lanes" in g.exchange_note
+        c = g.member_ctx(0)
+        sizes = [N, N // 2 + 64, N - 128, 3 * N // 4]
+        cols = []
+        for k, n in enumerate(sizes):
+            ci, cf = c.alloc(n * 8), c.alloc(n * 8)
+            c.synth_iota("i64", ci, n, k)
+            c.synth_iota("f64", cf, n, k)
+            cols.append((ci, cf, n, k))
+        want = lambda n, k: (n * (n - 1) // 2 + k * n, n, float(n * (n - 1) // 2 + k * n), n)  # noqa: E731
+        for step in range(12):
+            ci, cf, n, k = cols[step % len(cols)]
+            if step % 5 == 4:
+                g.mark_next_scan(2 * step, 2 * step + 1)
+            g.enqueue_sum_table([("l", 0, [ci], [n]), ("g", 0, [cf], [n])])
+            g.exchange()
+            if step % 3 == 2:  # read every third step's finals; the others are overwritten two steps later, unread
+                g.synchronize_for(20_000)
+                assert g.result(0) == want(n, k), (step, g.result(0))
+                if step % 5 == 4:
+                    assert 0 < g.mark_elapsed_ms(0, 2 * step, 2 * step + 1) < 50
+        # the host's own work on the member's context between two steps: the column the NEXT step scans is rewritten in place
+        ci, cf, n, k = cols[0]
+        for rounds in range(4):  # whichever lane the next step lands on
+            c.synth_iota("i64", ci, n, 100 + rounds)
+            c.synth_iota("f64", cf, n, 100 + rounds)
+            g.enqueue_sum_table([("l", 0, [ci], [n]), ("g", 0, [cf], [n])])
+            g.exchange()
+            g.join_lanes()  # what follows on the member's context comes after the step, whichever lane ran it
+        g.synchronize_for(20_000)
+        assert g.result(0) == want(n, 103)
+        # non-stamped enqueues still work on a group with lanes (they take the set's lane, ordered by events)
+        g.enqueue_sum("i64", 1, [ci], [n])
+        g.exchange()
+        g.enqueue_sum("i64", 1, [cols[1][0]], [cols[1][2]])
+        g.exchange()
+        g.synchronize_for(20_000)
+        assert g.result(1)[:2] == want(cols[1][2], 1)[:2]
+    finally:
+        g.close()
