@@ -818,6 +818,28 @@ def _overlapped_scans(k, ms_per_step):
                   "marks, its start under the previous scan's stragglers included")
 
 
+def _lanes_trial(step, drain, set_lanes, agree_max=None, batch=32, rounds=3):
+    """Two scan lanes or one scan stream? What the lanes gain depends on how the runtime mapped this process's streams onto hardware
+    queues (most often 3-4 % per step of the 8-way share, sometimes nothing, now and then -1 %), so the run measures: `rounds` x
+    (`batch` steps with the lanes, `batch` without; long enough for the overlap to reach its steady state), un-timed, in front of the
+    warm-up steps; the fastest batch of each form counts
+    (with several ranks: the slowest rank's). Returns (ms per step with lanes, without)."""
+    best = {True: float("inf"), False: float("inf")}
+    for _ in range(rounds):
+        for on in (True, False):
+            set_lanes(on)
+            step()
+            drain()
+            t0 = time.perf_counter()
+            for _ in range(batch):
+                step()
+            drain()
+            best[on] = min(best[on], (time.perf_counter() - t0) / batch * 1e3)
+    if agree_max is not None:
+        best = {on: agree_max(v) for on, v in best.items()}
+    return best[True], best[False]
+
+
 class _Downgrade(Exception):
     """The current exchange form cannot be trusted with the job (a deadline, wrong finals, a failed self-test): one notch down."""
 
@@ -1011,7 +1033,7 @@ def run_group(args, result_fd) -> int:
     # region like run_native's: every step against 1.1-ms scans, every 4th against the 0.14-ms scans of an 8-way partition.
     every = 1 if lens[0] >= 250_000_000 else max(1, min(4, args.steps // 3))
     marked = {k: 2 * j for j, k in enumerate(range(0, args.steps, every))}
-    preflight, attempts = None, 0
+    preflight, attempts, lanes_trial = None, 0, None
     while True:
         notch = ladder.cur
         attempts += 1
@@ -1033,6 +1055,14 @@ def run_group(args, result_fd) -> int:
                 raise _Downgrade(f"the set-up step's finals are wrong on member(s) {wrong}: {group.result(0, wrong[0])}")
             phase[0] = "the settle / warm-up steps"
             ramp_steps, ramp_spent, settled = _settle(step, drain, args)  # clocks up, the box quiet (see run_native)
+            if group.scan_lanes and args.scan_lanes == "auto":
+                phase[0] = "the two-lanes trial"
+                with_lanes, without = _lanes_trial(step, drain, group.set_scan_lanes)
+                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without}
+                group.set_scan_lanes(True)
+                if with_lanes > without * 0.995:
+                    raise _Downgrade(f"two scan lanes measured no faster than one scan stream in this process "
+                                     f"({with_lanes:.4f} against {without:.4f} ms per step, un-timed trial)")
             for _ in range(args.warmup):
                 step()
             drain()
@@ -1088,7 +1118,7 @@ def run_group(args, result_fd) -> int:
                         "step": "one fused launch per member (ma_group_enqueue_sum_table)" if fused else "two launches per member",
                         "host": "torch-free", "hip_runtime": _hip_runtime_path(), "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                         "exchange_form": notch["name"], "downgrades": ladder.downgrades, "attempts": attempts,
-                        "preflight": preflight, "faults_injected": faults.fired,
+                        "preflight": preflight, "faults_injected": faults.fired, "scan_lanes_trial": lanes_trial,
                         "host_issue_us_per_step": host_issue / args.steps * 1e6,
                         "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                         "scan_ms_per_step_min": scan_min, "scan_ms_per_step_max": scan_max,
@@ -1442,7 +1472,7 @@ def run_native(args, result_fd) -> int:
     from types import SimpleNamespace
 
     S = SimpleNamespace(comm=None, overlap=False, exs=[], stamps=None, stamp_seq=[], fused_calls={}, counter=0, wedged=False,
-                        lanes=False, ctx2=None, mark_ctx={})
+                        lanes=False, ctx2=None, mark_ctx={}, lanes_since=0)
     ctx.set_async(True)
 
     def teardown(abort: bool):
@@ -1460,7 +1490,7 @@ def run_native(args, result_fd) -> int:
             S.ctx2.synchronize()
         for st in (S.stamps or []):
             ctx.stamp_free(st)
-        S.exs, S.stamps, S.fused_calls, S.counter, S.lanes, S.mark_ctx = [], None, {}, 0, False, {}
+        S.exs, S.stamps, S.fused_calls, S.counter, S.lanes, S.mark_ctx, S.lanes_since = [], None, {}, 0, False, {}, 0
 
     def setup(notch):
         S.overlap = notch["overlap"]
@@ -1496,7 +1526,13 @@ def run_native(args, result_fd) -> int:
         if notch["lanes"] and not S.lanes:
             raise _Downgrade("two scan lanes need stamps in plain device words")
         if S.lanes and S.ctx2 is None:
-            S.ctx2 = Context(device_index)
+            # (an ordinary stream, like the group's second lanes: ma_group.hip setup_rccl has the measurements behind that)
+            if os.environ.get("MINARROW_HIP_SCAN_LANE_CLASS", "normal")[0] == "h":  # A/B: the lane's stream in the high priority class
+                os.environ["MINARROW_HIP_STREAM_PRIORITY"] = "high"
+            try:
+                S.ctx2 = Context(device_index)
+            finally:
+                os.environ.pop("MINARROW_HIP_STREAM_PRIORITY", None)
             S.ctx2.set_variant(args.variant)
             S.ctx2.set_blocks_per_cu(args.blocks_per_cu)
             S.ctx2.set_async(True)
@@ -1526,7 +1562,7 @@ def run_native(args, result_fd) -> int:
 
     def step(marks=None):
         k = S.counter % len(S.exs)
-        first = S.counter == 0
+        first = S.counter == S.lanes_since
         S.counter += 1
         ex = S.exs[k]
         stamp = None
@@ -1539,15 +1575,16 @@ def run_native(args, result_fd) -> int:
             sc.mark(marks)
             S.mark_ctx[marks] = sc
         if fused:
-            if k not in S.fused_calls:  # the argument table of a record set is built once
-                S.fused_calls[k] = sc.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
+            key = (k, S.lanes)
+            if key not in S.fused_calls:  # the argument table of a record set (and form) is built once
+                S.fused_calls[key] = sc.prepare_sum_fused([("l", col_i, rows, ex.slot_ptr(0)), ("g", col_f, rows, ex.slot_ptr(2))],
                                                         stamp=S.stamps[k] if S.stamps else 0, early=(S.stamps[k] + 8) if S.lanes else 0)
             if S.stamps:
                 S.stamp_seq[k] += 1
-                S.fused_calls[k](S.stamp_seq[k])
+                S.fused_calls[key](S.stamp_seq[k])
                 stamp = (S.stamps[k], S.stamp_seq[k])
             else:
-                S.fused_calls[k]()
+                S.fused_calls[key]()
         else:
             ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
             if marks is not None:
@@ -1603,7 +1640,7 @@ def run_native(args, result_fd) -> int:
     # of an 8-way partition only every 4th step does (at least 3 steps).
     every = 1 if rows >= 250_000_000 else max(1, min(4, args.steps // 3))
     marked = {k: 3 * j for j, k in enumerate(range(0, args.steps, every))}
-    preflight, attempts = None, 0
+    preflight, attempts, lanes_trial = None, 0, None
     while True:
         notch = ladder.cur
         attempts += 1
@@ -1633,6 +1670,18 @@ def run_native(args, result_fd) -> int:
             settle_why[0] = ""
             ramp_steps, ramp_spent, settled = _settle(step, settle_drain if dist is not None else (lambda: ctx.synchronize()), args,
                                                       agree if dist is not None else None)
+            if S.lanes and args.scan_lanes == "auto":
+                phase[0] = "the two-lanes trial"
+
+                def set_lanes(on):  # both lanes idle (the trial drains in front of every switch); the first step after it is un-gated
+                    S.lanes, S.lanes_since = on, S.counter
+
+                with_lanes, without = _lanes_trial(step, fence, set_lanes, max_over_ranks)
+                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without}
+                set_lanes(True)
+                if with_lanes > without * 0.995:  # the same figures on every rank (max over ranks): every rank decides alike
+                    raise _Downgrade(f"two scan lanes measured no faster than one scan stream ({with_lanes:.4f} against {without:.4f} ms "
+                                     "per step, un-timed trial)")
             for _ in range(args.warmup):
                 step()
             fence()
@@ -1714,7 +1763,7 @@ def run_native(args, result_fd) -> int:
                             "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                             "hip_runtime": _hip_runtime_path(),
                             "exchange_form": ladder.cur["name"], "downgrades": ladder.downgrades, "attempts": attempts,
-                            "preflight": preflight, "faults_injected": faults.fired,
+                            "preflight": preflight, "faults_injected": faults.fired, "scan_lanes_trial": lanes_trial,
                             "host_issue_us_per_step": host_issue / args.steps * 1e6,
                             "exchange_us": stats["all_gather_us"], "fold_us": stats["fold_us"], "exchange_samples": stats["samples"],
                             "scan_ms_per_step_min": min(scans), "scan_ms_per_step_max": max(scans),
@@ -2165,7 +2214,9 @@ def main() -> int:
     ap.add_argument("--scan-lanes", default="auto", choices=["auto", "on", "off"],
                     help="N > 1, overlapped exchange with the stamp hand-off: consecutive steps on TWO scan streams per GPU, each gated "
                          "on the early stamp of the step before it (its ramp runs under that step's stragglers: 0.2842 -> 0.2737 ms at "
-                         "125 M rows per column). auto / on = the first notch of the ladder; off = one scan stream")
+                         "125 M rows per column on most boxes). auto = the first notch of the ladder, kept only if an un-timed trial in front "
+                         "of the warm-up steps measures it faster than one scan stream in THIS process (the gain depends on how the "
+                         "runtime mapped the streams onto hardware queues); on = without the trial; off = one scan stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--force-group", action="store_true",

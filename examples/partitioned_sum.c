@@ -1,12 +1,13 @@
 /* The reference's parallel sums — `slice.par_chunks(..).map(simd_sum).sum()` for an i64 and an f64 column
  * (benches/benchmark_parallel_simd.rs:81-125) — partitioned over every visible GPU from ONE C99 host through the C ABI alone,
  * written the way a host that must not hang writes it:
- *   1. a group over the GPUs with the best exchange (RCCL all-gather + device fold, overlapped with the next step's scans);
+ *   1. a group over the GPUs with the best exchange (RCCL all-gather + device fold, overlapped with the next step's scans,
+ *      consecutive steps on two scan lanes gated on each other's early stamp);
  *   2. ma_group_selftest before the machinery is trusted with a job (rank-tagged records through the exchange, every peer link,
  *      the stamp hand-off — each step under a deadline);
  *   3. a stepping loop whose waits are bounded (ma_group_synchronize_for); when one runs out — injected here with the library's
  *      own fault hook on the third step — the group is rebuilt ONE NOTCH DOWN (same members, same columns) and the job goes on:
- *      overlapped -> in-stream -> the calling thread issuing grouped collectives -> the host fold;
+ *      two scan lanes -> one -> in-stream -> the calling thread issuing grouped collectives -> the host fold;
  *   4. every step's totals against their closed forms.
  * Build:  gcc -std=c99 -Iinclude examples/partitioned_sum.c -Lminarrow_amd/lib -lminarrow_hip -Wl,-rpath,$PWD/minarrow_amd/lib
  * Run:    ./a.out [rows per column = 2^26] [steps = 8] [deadline in ms = 500]
@@ -32,6 +33,7 @@
 
 /* one notch down from the flags in effect */
 static uint32_t next_notch(uint32_t flags) {
+    if (flags & MA_GROUP_SCAN_LANES) return flags & ~(uint32_t)MA_GROUP_SCAN_LANES;                            /* one scan stream */
     if (flags & MA_GROUP_EXCHANGE_OVERLAP) return flags & ~(uint32_t)MA_GROUP_EXCHANGE_OVERLAP;              /* in-stream */
     if ((flags & MA_GROUP_EXCHANGE_RCCL) && !(flags & MA_GROUP_ISSUE_CALLER)) return flags | MA_GROUP_ISSUE_CALLER; /* grouped calls */
     return 0;                                                                                                  /* host fold */
@@ -39,6 +41,7 @@ static uint32_t next_notch(uint32_t flags) {
 
 static const char* form_name(uint32_t flags) {
     if (!(flags & MA_GROUP_EXCHANGE_RCCL)) return "host fold of pinned records";
+    if (flags & MA_GROUP_SCAN_LANES) return "RCCL, overlapped on side streams, consecutive steps on two scan lanes";
     if (flags & MA_GROUP_EXCHANGE_OVERLAP) return "RCCL, overlapped on side streams";
     return (flags & MA_GROUP_ISSUE_CALLER) ? "RCCL, in-stream, grouped on the calling thread" : "RCCL, in-stream, one issue thread per GPU";
 }
@@ -57,7 +60,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) devices[i] = i;
 
     ma_group* g = NULL;
-    CHECK(ma_group_create_ex(devices, n, MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP | MA_GROUP_EXCHANGE_FALLBACK_HOST, &g));
+    CHECK(ma_group_create_ex(devices, n,
+                             MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP | MA_GROUP_SCAN_LANES | MA_GROUP_EXCHANGE_FALLBACK_HOST, &g));
     printf("group of %d GPU(s): %s [%s]\n", n, form_name(ma_group_flags(g)), ma_group_exchange_note(g));
 
     /* 64-row-aligned row chunks (a chunk's validity window then starts on a word); chunk i lives on GPU i */

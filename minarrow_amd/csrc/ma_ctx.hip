@@ -815,6 +815,9 @@ const char* ma_status_name(ma_status s) {
     }
 }
 
+// +1 / -1: the next context this thread creates gets its stream in the high / low priority class (ma::create_ctx_in_class)
+static thread_local int t_stream_class = 0;
+
 static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_ctx** out_ctx, bool map_ordinal = true) {
     MA_REQUIRE(out_ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
     *out_ctx = nullptr;
@@ -855,7 +858,15 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
     } else {
-        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        // MINARROW_HIP_STREAM_PRIORITY=high|low (read at every creation): the context's stream in that priority class — the
+        // runtime keeps a hardware-queue pool per class, so a "high" context never shares a hardware queue with ordinary ones
+        const char* prio = getenv("MINARROW_HIP_STREAM_PRIORITY");
+        const int cls = t_stream_class ? t_stream_class : (prio && prio[0] == 'h') ? 1 : (prio && prio[0] == 'l') ? -1 : 0;
+        int least = 0, greatest = 0;
+        if (cls != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, cls > 0 ? greatest : least);
+        else
+            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
             delete c;
             return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
@@ -892,6 +903,16 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
 }  // extern "C"
 
 namespace ma {
+// An independent context (own stream, partials, tickets) whose stream is in another priority class than ordinary contexts'.
+// The runtime keeps a pool of hardware queues per class: two streams of one class may be mapped onto the same hardware queue —
+// where a wait on one holds up the other — two streams of different classes never are.
+ma_status create_ctx_in_class(int32_t device_ordinal, int cls, ma_ctx** out) {
+    t_stream_class = cls;
+    const ma_status st = ma_ctx_create(device_ordinal, out);
+    t_stream_class = 0;
+    return st;
+}
+
 ma_status make_lane(ma_ctx* root, ma_ctx** out) {
     int prev = 0;
     (void)hipGetDevice(&prev);

@@ -251,19 +251,28 @@ ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
         g->ev_lane.assign(n, nullptr);
         g->seen_calls.assign(n, 0);
         for (size_t i = 0; i < n; ++i) {
-            MA_TRY(ma_ctx_create(g->ctxs[i]->ordinal, &g->scan2[i]));  // an independent context: its own stream, partials, tickets
+            // An independent context (its own stream, partials, tickets). What the lanes gain depends on how the runtime maps the
+            // member's streams onto hardware queues, process by process: the step of the 8-way share 0.287 -> 0.275-0.279 ms on most
+            // boxes, nothing (or +1 %) on some, where lane 1's wait for the early stamp ends up behind lane 0's whole scan in one
+            // hardware queue. Putting lane 1 into the HIGH priority class (its own queue pool: MINARROW_HIP_SCAN_LANE_CLASS=high)
+            // makes the bare scans gain every time (tools/probe_early_stamp.py high) but loses the gain once the exchange stream
+            // is in the picture (tools/run_share_lanes.sh: 0.287 against 0.275-0.279) — so: the ordinary class, and a host that
+            // MEASURES both forms before it settles on one (ma_group_set_scan_lanes; bench.py's un-timed trial).
+            const char* cls = getenv("MINARROW_HIP_SCAN_LANE_CLASS");
+            MA_TRY(create_ctx_in_class(g->ctxs[i]->ordinal, (cls && cls[0] == 'h') ? +1 : 0, &g->scan2[i]));
             MA_TRY(ma_ctx_set_async(g->scan2[i], 1));
             MA_HIP(hipSetDevice(devs[i]));
             MA_HIP(hipEventCreateWithFlags(&g->ev_lane[i], hipEventDisableTiming | hipEventReleaseToDevice));
             g->seen_calls[i] = g->ctxs[i]->calls.load();
         }
         g->lanes2 = true;
+        g->lanes_on = true;
     }
     return MA_OK;
 }
 
 ma_status order_lane_if_foreign(ma_group* g, size_t i) {
-    if (!g->lanes2 || g->ctxs[i]->calls.load(std::memory_order_relaxed) == g->seen_calls[i]) return MA_OK;
+    if (!g->lanes2 || !g->lanes_on || g->ctxs[i]->calls.load(std::memory_order_relaxed) == g->seen_calls[i]) return MA_OK;
     MA_HIP(hipSetDevice(g->ctxs[i]->device));
     MA_HIP(hipEventRecord(g->ev_lane[i], g->ctxs[i]->stream));
     MA_HIP(hipStreamWaitEvent(g->scan2[i]->stream, g->ev_lane[i], 0));
@@ -870,7 +879,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     group->stamp_ok[cur_set] = stamped;
     // two scan lanes: this step runs on the lane of its record set; when the call before it was a stamped step on the OTHER lane
     // it starts as soon as that step's first workgroup has scanned its rows (the early stamp), not beside its whole scan
-    const bool lanes = group->lanes2;
+    const bool lanes = group->lanes2 && group->lanes_on;
     const bool gate = lanes && stamped && group->prev_set >= 0 && group->prev_set != cur_set;
     const int prev_set = group->prev_set;
     const uint64_t prev_seq = group->prev_seq;
@@ -878,7 +887,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     group->mark_from = group->mark_to = -1;
     if (mark_from >= 0) {
         if (group->mark_lane.size() < (size_t)MA_CTX_MAX_MARKS) group->mark_lane.assign(MA_CTX_MAX_MARKS, 0);
-        group->mark_lane[(size_t)mark_from] = group->mark_lane[(size_t)mark_to] = (uint8_t)((group->lanes2 && cur_set == 1) ? 1 : 0);
+        group->mark_lane[(size_t)mark_from] = group->mark_lane[(size_t)mark_to] = (uint8_t)((group->lanes2 && group->lanes_on && cur_set == 1) ? 1 : 0);
     }
     const ma_status st = run_on_members(group, [&](size_t i) -> ma_status {
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];

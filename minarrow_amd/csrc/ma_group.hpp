@@ -90,6 +90,7 @@ struct ma_group {
     // step — has put work of its own on a member's context (ma_ctx::calls moved), the next lane-1 launch is ordered behind ALL
     // of it with an event first.
     bool lanes2 = false;
+    bool lanes_on = true;  // ma_group_set_scan_lanes: with the lanes set up, whether steps use them (a host measures both and keeps the faster)
     std::vector<ma_ctx*> scan2;
     std::vector<hipEvent_t> ev_lane;
     std::vector<uint64_t> seen_calls;
@@ -113,6 +114,7 @@ struct ma_group {
 
 namespace ma {
 ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+ma_status create_ctx_in_class(int32_t device_ordinal, int cls, ma_ctx** out);  // ma_ctx.hip: +1 high / -1 low priority stream
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
                          bool as_partials = false, uint64_t* early_stamp = nullptr);
 
@@ -146,7 +148,7 @@ struct HostFoldDD {
 };
 
 // The context whose stream fills record set `set` on member i.
-inline ma_ctx* scan_ctx(const ma_group* g, int set, size_t i) { return (g->lanes2 && set == 1) ? g->scan2[i] : g->ctxs[i]; }
+inline ma_ctx* scan_ctx(const ma_group* g, int set, size_t i) { return (g->lanes2 && g->lanes_on && set == 1) ? g->scan2[i] : g->ctxs[i]; }
 
 // ma_group.hip
 void release_exchange(ma_group* g);

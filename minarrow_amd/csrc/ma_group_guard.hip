@@ -87,11 +87,12 @@ hipStream_t rescue_stream(ma_group* g, size_t i) {
     if (g->rescue.size() < g->ctxs.size()) g->rescue.resize(g->ctxs.size(), nullptr);
     if (!g->rescue[i]) {
         (void)hipSetDevice(g->ctxs[i]->device);
-        // highest priority: the runtime keeps a hardware-queue pool per priority, so this stream never sits behind a
-        // normal-priority one that is held (ordinary streams share hardware queues once a process has more than a few)
+        // the LOW priority class: the runtime keeps a hardware-queue pool per class, so this stream never sits behind an ordinary
+        // one that is held (ordinary streams share hardware queues once a process has more than a few) — nor behind the second
+        // scan lanes, which live in the high class
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) (void)hipGetLastError();
-        if (hipStreamCreateWithPriority(&g->rescue[i], hipStreamNonBlocking, greatest) != hipSuccess) {
+        if (hipStreamCreateWithPriority(&g->rescue[i], hipStreamNonBlocking, least) != hipSuccess) {
             (void)hipGetLastError();
             g->rescue[i] = nullptr;
         }
@@ -634,7 +635,7 @@ uint32_t ma_group_flags(ma_group* group) {
     uint32_t f = group->flags & ~(uint32_t)(MA_GROUP_ISSUE_CALLER | MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP | MA_GROUP_SCAN_LANES);
     if (group->use_rccl) f |= MA_GROUP_EXCHANGE_RCCL;
     if (group->overlap) f |= MA_GROUP_EXCHANGE_OVERLAP;
-    if (group->lanes2) f |= MA_GROUP_SCAN_LANES;
+    if (group->lanes2 && group->lanes_on) f |= MA_GROUP_SCAN_LANES;
     if (!group->threads) f |= MA_GROUP_ISSUE_CALLER;
     return f;
 }
@@ -661,11 +662,26 @@ int32_t ma_group_handoff(ma_group* group) {
     return MA_GROUP_HANDOFF_STAMP;
 }
 
+ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on) {
+    MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    std::lock_guard<std::recursive_mutex> lock(group->mu);
+    MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
+    if (!group->lanes2) {
+        MA_REQUIRE(!on, MA_ERR_UNSUPPORTED, "this group has no second scan lanes (create or rebuild it with MA_GROUP_SCAN_LANES)");
+        return MA_OK;
+    }
+    if (group->lanes_on == (on != 0)) return MA_OK;
+    MA_TRY(synchronize_locked(group));  // a set is never filled from two streams at once
+    group->lanes_on = on != 0;
+    group->prev_set = -1;
+    return MA_OK;
+}
+
 ma_status ma_group_join_lanes(ma_group* group) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_REQUIRE(!group->broken, MA_ERR_DEVICE, "%s", kBrokenMessage);
-    if (!group->lanes2) return MA_OK;
+    if (!group->lanes2 || !group->lanes_on) return MA_OK;
     for (size_t i = 0; i < group->ctxs.size(); ++i) {  // the member's own stream behind everything its second lane has been given
         MA_HIP(hipSetDevice(group->ctxs[i]->device));
         MA_HIP(hipEventRecord(group->ev_lane[i], group->scan2[i]->stream));

@@ -133,10 +133,10 @@ ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal con
 namespace {
 
 hipStream_t comm_rescue(ma_comm* comm) {
-    if (!comm->rescue) {  // highest priority: its own hardware-queue pool, never behind a held normal-priority stream
+    if (!comm->rescue) {  // the low priority class: its own hardware-queue pool, never behind a held ordinary (or high-class) stream
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) (void)hipGetLastError();
-        if (hipStreamCreateWithPriority(&comm->rescue, hipStreamNonBlocking, greatest) != hipSuccess) {
+        if (hipStreamCreateWithPriority(&comm->rescue, hipStreamNonBlocking, least) != hipSuccess) {
             (void)hipGetLastError();
             comm->rescue = nullptr;
         }

@@ -138,7 +138,7 @@ def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(m
     records over host memory in the default form, to torch.distributed's exchange in the torch-hosted one; the line says so."""
     monkeypatch.setenv("MA_BENCH_DISTRUST_NATIVE_COMM", "1")
     base = [*LAUNCH, "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
-            "--no-other-configs", "--overlap", "on"]
+            "--no-other-configs", "--overlap", "on", "--scan-lanes", "on"]
     out = run(base)
     cfg = out["config"]
     assert out["parity_ok"] and [d["abandoned"] for d in cfg["downgrades"]] == [
@@ -164,8 +164,8 @@ def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_down)
     """`bench.py --gpus N` in one process, on first contact with an exchange that never completes (or folds wrongly): the
     line still comes, rc 0, parity ok, and names the form that ran and what was abandoned on the way (the faults are the
     library's own test hooks, armed through MA_BENCH_FAULT) — all the way down to the host fold."""
-    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--overlap", "on", *QUICK], {"MA_BENCH_FAULT": fault},
-              timeout=240)
+    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--overlap", "on", "--scan-lanes", "on", *QUICK],
+              {"MA_BENCH_FAULT": fault}, timeout=240)
     cfg = out["config"]
     assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
     assert [d["abandoned"] for d in cfg["downgrades"]] == G[:notches_down] and cfg["exchange_form"] == G[notches_down], cfg["downgrades"]
@@ -180,8 +180,8 @@ def test_group_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_down)
 def test_launcher_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_down):
     """The same under torch.distributed.run (one process per GPU, ma_comm_*): the ranks agree over gloo after every bounded
     wait; the communicator is aborted and a new one made from a fresh id for the next form down."""
-    out = run([*LAUNCH, "--master-port", "29643", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--overlap", "on", *QUICK],
-              {"MA_BENCH_FAULT": fault}, timeout=240)
+    out = run([*LAUNCH, "--master-port", "29643", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--overlap", "on", "--scan-lanes", "on",
+               *QUICK], {"MA_BENCH_FAULT": fault}, timeout=240)
     cfg = out["config"]
     assert out["parity_ok"] and cfg["faults_injected"] == fault.split(",")
     assert [d["abandoned"] for d in cfg["downgrades"]] == L[:notches_down] and cfg["exchange_form"] == L[notches_down]
@@ -191,7 +191,8 @@ def test_launcher_mode_goes_down_its_ladder_instead_of_hanging(fault, notches_do
 def test_the_two_n_gt_1_modes_measure_alike():
     """One process over the GPUs (ma_group_*) and one process per GPU (ma_comm_*) report the same keys, taken the same way —
     timing marks around the scan inside the timed steps, every 4th exchange sampled — and agree within noise on one GPU."""
-    common = ["--rows", str(1 << 26), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-other-configs", "--overlap", "on"]
+    common = ["--rows", str(1 << 26), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-other-configs", "--overlap", "on",
+              "--scan-lanes", "on"]
     g = run([sys.executable, "bench.py", *common, "--gpus", "1", "--force-group"])
     d = run([*LAUNCH, "--master-port", "29644", "bench.py", *common, "--gpus", "1", "--force-dist"])
     shared = {"exchange_us", "fold_us", "exchange_samples", "host_issue_us_per_step", "scan_ms_per_step_min", "scan_ms_per_step_max",
@@ -209,8 +210,29 @@ def test_the_two_n_gt_1_modes_measure_alike():
     assert "two scan lanes" in g["config"]["exchange_form"] and "two scan lanes" in d["config"]["exchange_form"]
     assert "two scan lanes" in g["config"]["exchange"] and "two scan contexts" in d["config"]["exchange"]
     # one scan stream, for the record: the same job, the same result
-    one = run([sys.executable, "bench.py", *common, "--gpus", "1", "--force-group", "--scan-lanes", "off"])
+    one = run([sys.executable, "bench.py", *common[:-2], "--gpus", "1", "--force-group", "--scan-lanes", "off"])
     assert one["parity_ok"] and one["result"] == g["result"] and "two scan lanes" not in one["config"]["exchange_form"]
+
+
+@pytest.mark.parametrize("mode", ["group", "ranks"])
+def test_the_scan_lanes_are_kept_only_if_the_untimed_trial_measures_them_faster(mode):
+    """--scan-lanes auto (the default at N > 1): what two scan lanes gain depends on how the runtime mapped this process's streams
+    onto hardware queues, so the run measures a few un-timed steps each way in front of the warm-up and keeps the lanes only if
+    they are faster here; otherwise it goes one notch down and says why. Either way the line carries the trial's figures."""
+    args = ["--rows", str(1 << 26), "--steps", "8", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--overlap", "on"]
+    if mode == "group":
+        out = run([sys.executable, "bench.py", *args, "--gpus", "1", "--force-group"])
+    else:
+        out = run([*LAUNCH, "--master-port", "29645", "bench.py", *args, "--gpus", "1", "--force-dist"])
+    cfg = out["config"]
+    trial = cfg["scan_lanes_trial"]
+    assert out["parity_ok"] and trial["two_scan_lanes_ms_per_step"] > 0 and trial["one_scan_stream_ms_per_step"] > 0
+    kept = trial["two_scan_lanes_ms_per_step"] <= trial["one_scan_stream_ms_per_step"] * 0.995
+    assert ("two scan lanes" in cfg["exchange_form"]) == kept
+    if kept:
+        assert cfg["downgrades"] == []
+    else:
+        assert len(cfg["downgrades"]) == 1 and "measured no faster" in cfg["downgrades"][0]["why"]
 
 
 @pytest.mark.parametrize("ranks", [3])

@@ -252,3 +252,62 @@ def test_stamped_launch_and_exchange_waiting_on_the_stamp(ctx, oracle):
         comm.close()
         for s in stamps + [stamp]:
             ctx.stamp_free(s)
+
+
+def test_two_contexts_alternate_gated_on_the_early_stamp(ctx, oracle):
+    """ma_sum_fused_stamped_early + ma_ctx_wait_value: consecutive independent scans on two contexts of one device, each made to
+    wait for the EARLY stamp of the one before (stored by every workgroup as soon as its rows are scanned) — its ramp runs under the
+    previous scan's stragglers. Every scan's results must be its own (distinct columns in turn, dense and gated), the final stamps
+    end at their sequences, and the early word never runs ahead of a launch that has not started."""
+    from minarrow_amd.host import Context
+
+    other = Context(0)
+    lanes = [ctx, other]
+    rng = np.random.default_rng(77)
+    n = 3_000_017
+    cols = []
+    for k in range(4):
+        a = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
+        f = rng.standard_normal(n) * 1e6
+        bits = rng.integers(0, 256, size=(n + 77) // 8 + 16, dtype=np.uint8)
+        cols.append((a, f, bits, ctx.to_device(a, 64), ctx.to_device(f, 64), ctx.to_device(bits, 16)))
+    stamps = [c.stamp_alloc() for c in lanes]
+    recs = [_records(ctx, 1) for _ in range(8)]
+    for c in lanes:
+        c.set_async(True)
+    seq = [0, 0]
+    try:
+        for step in range(8):
+            lane, (a, f, bits, da, df, dm) = step & 1, cols[step % 4]
+            gated = step >= 4
+            if step:
+                lanes[lane].wait_value(stamps[lane ^ 1] + 8, seq[lane ^ 1])
+            seq[lane] += 1
+            mask = (dm, 13) if gated else ()
+            lanes[lane].prepare_sum_fused([("l", da, n, recs[step].ptr, *mask), ("g", df, n, recs[step].ptr + 16, *mask)],
+                                          stamp=stamps[lane], early=stamps[lane] + 8)(seq[lane])
+        for c in lanes:
+            c.synchronize()
+        word = np.zeros(2, dtype=np.uint64)
+        for lane, c in enumerate(lanes):
+            assert c.lib.ma_dev_download(c.handle, word.ctypes.data, stamps[lane], 16) == 0
+            assert [int(w) for w in word] == [4, 4]  # final and early stamp both at the lane's last sequence
+        for step in range(8):
+            a, f, bits, *_ = cols[step % 4]
+            w = _read(recs[step], 0)
+            if step >= 4:
+                want_s, want_c = oracle.masked_sum(a, bits, 13)
+                valid = np.unpackbits(bits, bitorder="little")[13:13 + n].astype(bool)
+                exact = math.fsum(f[valid].tolist())
+            else:
+                want_s, want_c = oracle.sum_scalar(a), n
+                exact = math.fsum(f.tolist())
+            assert int(w[0]) == want_s & M64 and int(w[1]) == want_c == int(w[4]), step
+            hi, lo = (float(x) for x in w[2:4].view(np.float64))
+            assert abs((hi + lo) - exact) <= math.ulp(exact), step
+    finally:
+        for c in lanes:
+            c.set_async(False)
+        for c, st in zip(lanes, stamps):
+            c.stamp_free(st)
+        other.close()

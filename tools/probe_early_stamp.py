@@ -12,12 +12,18 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from minarrow_amd.host import Context  # noqa: E402
 
+import os  # noqa: E402
+
 K = 4
-ctxs = [Context(0), Context(0)]
+ctxs = [Context(0)]
+if len(sys.argv) > 1:  # "high" / "low": the second context's stream in another priority class (its own hardware-queue pool)
+    os.environ["MINARROW_HIP_STREAM_PRIORITY"] = sys.argv[1]
+ctxs.append(Context(0))
+os.environ.pop("MINARROW_HIP_STREAM_PRIORITY", None)
 a = ctxs[0]
 stamps = [c.stamp_alloc() for c in ctxs]
 seq = [0, 0]
-for rows, steps in ((1 << 24, 2000), (1 << 26, 600), (125_000_000, 400), (250_000_000, 200), (1_000_000_000, 60)):
+for rows, steps in ((1 << 24, 2000), (1 << 26, 600), (125_000_000, 400), (250_000_000, 200), (1_000_000_000, 60))[:int(os.environ.get("PROBE_SIZES", "5"))]:
     pairs = [(a.alloc(rows * 8), a.alloc(rows * 8)) for _ in range(K if rows < 500_000_000 else 2)]
     for ci, cf in pairs:
         a.synth_iota("i64", ci, rows, 0)
@@ -25,8 +31,10 @@ for rows, steps in ((1 << 24, 2000), (1 << 26, 600), (125_000_000, 400), (250_00
     recs = [a.alloc(256) for _ in range(2 * len(pairs))]
     for c in ctxs:
         c.set_async(True)
-    calls = [[c.prepare_sum_fused([("l", ci, rows, recs[2 * j + k].ptr), ("g", cf, rows, recs[2 * j + k].ptr + 16)], stamp=stamps[k])
-              for j, (ci, cf) in enumerate(pairs)] for k, c in enumerate(ctxs)]
+    # stamped launches; the "early" form additionally stores the value to word 1 of the stamp's line as soon as a workgroup is done
+    calls = {early: [[c.prepare_sum_fused([("l", ci, rows, recs[2 * j + k].ptr), ("g", cf, rows, recs[2 * j + k].ptr + 16)], stamp=stamps[k],
+                                          early=(stamps[k] + 8) if early else 0)
+                      for j, (ci, cf) in enumerate(pairs)] for k, c in enumerate(ctxs)] for early in (False, True)}
     row = {"rows_per_column": rows, "steps": steps}
 
     def run(form):
@@ -36,9 +44,7 @@ for rows, steps in ((1 << 24, 2000), (1 << 26, 600), (125_000_000, 400), (250_00
                 other = lane ^ 1
                 ctxs[lane].wait_value(stamps[other] + (8 if form == "early" else 0), seq[other])
             seq[lane] += 1
-            calls[lane][k % len(pairs)](seq[lane])
-        for c in ctxs:
-            c.set_variant(262144 if form == "early" else 0)
+            calls[form == "early"][lane][k % len(pairs)](seq[lane])
         for k in range(8):
             step(k)
         for c in ctxs:
@@ -63,6 +69,5 @@ for rows, steps in ((1 << 24, 2000), (1 << 26, 600), (125_000_000, 400), (250_00
     print(json.dumps(row), flush=True)
     for c in ctxs:
         c.set_async(False)
-        c.set_variant(0)
     for x in (*[c for p in pairs for c in p], *recs):
         x.free()
