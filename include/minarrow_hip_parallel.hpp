@@ -163,6 +163,11 @@ class Group {
     int broken() const { return ma_group_is_broken(g_); }
     void rebuild(uint32_t flags) const { check(ma_group_rebuild_exchange(g_, flags)); }
     uint32_t flags() const { return ma_group_flags(g_); }
+    // MA_GROUP_SCAN_LANES (with RCCL | OVERLAP): consecutive enqueue_table steps alternate between two scan streams per GPU, each
+    // gated on the early stamp of the one before. set_scan_lanes switches them on / off without a rebuild (a host measures both);
+    // join_lanes puts every member's own stream behind its second lane (before the host enqueues work of its own there).
+    void set_scan_lanes(bool on) const { check(ma_group_set_scan_lanes(g_, on ? 1 : 0)); }
+    void join_lanes() const { check(ma_group_join_lanes(g_)); }
     // Proves the exchange (rank-tagged records, in the group's own form), the stamp hand-off and every peer link before a job
     // is trusted to them, each step under the deadline (ma_group_selftest). Returns the report; throws when something failed.
     ma_selftest_report selftest(double timeout_ms, uint32_t what = 0) const {

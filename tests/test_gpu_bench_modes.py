@@ -78,19 +78,16 @@ def test_one_process_group_mode_with_rccl():
     assert 0 < cfg["scan_ms_per_step_min_over_members"] <= cfg["scan_ms_per_step_max_over_members"]
     assert "fused" in cfg["step"] and set(out["kernels"]) == {"sum_fused"} and cfg["host"] == "torch-free"
     sep = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--no-other-configs",
-               "--step", "separate"])
+               "--step", "separate", "--exchange", "host"])  # two launches per member AND the host fold, in one run
     assert sep["parity_ok"] and set(sep["kernels"]) == {"sum_i64", "sum_f64"}
     assert sep["result"]["i64_sum"] == out["result"]["i64_sum"] and sep["result"]["f64_sum"] == out["result"]["f64_sum"]
+    assert sep["config"]["rccl_ranks"] == 0 and "host fold" in sep["config"]["exchange"]
     oc = out["other_configs"]  # the multi-GPU legs of configs 4 and 5 (one GPU here)
     assert oc["parity_ok"] is True
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True  # chunk fan-out over the group, no exchange
     assert oc["config5_physical_consolidate_onto_gpu0"]["parity"] is True  # the gather onto one member
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["rows_total"] == 1 << 24
-    host = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--exchange", "host",
-                "--no-other-configs"])
-    assert host["parity_ok"] and host["config"]["rccl_ranks"] == 0 and "host fold" in host["config"]["exchange"]
-    assert host["result"]["i64_sum"] == out["result"]["i64_sum"] and host["result"]["f64_sum"] == out["result"]["f64_sum"]
     weak = run([sys.executable, "bench.py", *SMALL, "--gpus", "1", "--force-group", "--no-cpu-baseline", "--scaling", "weak",
                 "--group-issue", "caller", "--no-other-configs", "--overlap", "on"])
     assert weak["parity_ok"] and weak["scaling"] == "weak" and "issue: caller" in weak["config"]["parallelism"]

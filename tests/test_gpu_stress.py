@@ -19,7 +19,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SECONDS = float(os.environ.get("MA_STRESS_SECONDS", "12"))  # a longer soak: MA_STRESS_SECONDS=300 pytest -s tests/test_gpu_stress.py
+SECONDS = float(os.environ.get("MA_STRESS_SECONDS", "6"))  # a longer soak: MA_STRESS_SECONDS=300 pytest -s tests/test_gpu_stress.py
 N_MAX = 3_000_000
 
 
