@@ -3,7 +3,7 @@
 ma_reduce.hip publishes one partial per workgroup with write-through stores and lets the LAST arrival fold them; grids
 above 96 workgroups arrive on eight sharded counters whose last arrivals arrive at a top counter (ma_reduce.hip, the
 "sharded two-level arrival ticket"). That transitive last-arriver detection is not one of the hand-off forms the MI355X
-guide lists as measured, so it is exercised here for ~12 s on every GPU test run: random grids across 97..2048 (and a few
+guide lists as measured, so it is exercised here for ~6 s on every GPU test run: random grids across 97..2048 (and a few
 below 96: the single-counter form), four private contexts issuing asynchronously back to back from four host threads, a
 fifth context streaming large elementwise kernels on the same device the whole time (uneven, shifting load on the CUs and
 the L2s), dense and Bitmask-gated, i64 and f64, both publish forms (fence-free and MINARROW_HIP_FENCED_REDUCE's) — every
