@@ -818,7 +818,19 @@ def _overlapped_scans(k, ms_per_step):
                   "marks, its start under the previous scan's stragglers included")
 
 
-def _lanes_trial(step, drain, set_lanes, agree_max=None, batch=32, rounds=3):
+def _lanes_trial(step, drain, set_lanes, agree_max=None, batch=32, rounds=3, reseat=None, tries=3):
+    """_lanes_trial_once, up to `tries` times: when the lanes measure no faster than one stream (both lanes mapped onto one hardware
+    queue, where the second lane's wait sits behind the first lane's whole scan), `reseat()` gives the second lane a fresh context —
+    a new stream, mapped anew — and the trial runs again. Returns (ms per step with lanes, without, tries used)."""
+    for attempt in range(1, tries + 1):
+        with_lanes, without = _lanes_trial_once(step, drain, set_lanes, agree_max, batch, rounds)
+        if with_lanes <= without * 0.985 or reseat is None or attempt == tries:
+            return with_lanes, without, attempt
+        drain()
+        reseat()
+
+
+def _lanes_trial_once(step, drain, set_lanes, agree_max=None, batch=32, rounds=3):
     """Two scan lanes or one scan stream? What the lanes gain depends on how the runtime mapped this process's streams onto hardware
     queues (most often 3-4 % per step of the 8-way share, sometimes nothing, now and then -1 %), so the run measures: `rounds` x
     (`batch` steps with the lanes, `batch` without; long enough for the overlap to reach its steady state), un-timed, in front of the
@@ -1057,10 +1069,10 @@ def run_group(args, result_fd) -> int:
             ramp_steps, ramp_spent, settled = _settle(step, drain, args)  # clocks up, the box quiet (see run_native)
             if group.scan_lanes and args.scan_lanes == "auto":
                 phase[0] = "the two-lanes trial"
-                with_lanes, without = _lanes_trial(step, drain, group.set_scan_lanes)
-                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without}
+                with_lanes, without, tries = _lanes_trial(step, drain, group.set_scan_lanes, reseat=lambda: group.set_scan_lanes(2))
+                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without, "tries": tries}
                 group.set_scan_lanes(True)
-                if with_lanes > without * 0.995:
+                if with_lanes > without * 0.985:  # kept only for a clear gain: a marginal one does not always survive into the timed steps
                     raise _Downgrade(f"two scan lanes measured no faster than one scan stream in this process "
                                      f"({with_lanes:.4f} against {without:.4f} ms per step, un-timed trial)")
             for _ in range(args.warmup):
@@ -1676,10 +1688,19 @@ def run_native(args, result_fd) -> int:
                 def set_lanes(on):  # both lanes idle (the trial drains in front of every switch); the first step after it is un-gated
                     S.lanes, S.lanes_since = on, S.counter
 
-                with_lanes, without = _lanes_trial(step, fence, set_lanes, max_over_ranks)
-                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without}
+                def reseat():  # a fresh second scan context on every rank (new stream); its prepared launches go with the old one
+                    S.ctx2.synchronize()
+                    S.ctx2.close()
+                    S.ctx2 = Context(device_index)
+                    S.ctx2.set_variant(args.variant)
+                    S.ctx2.set_blocks_per_cu(args.blocks_per_cu)
+                    S.ctx2.set_async(True)
+                    S.fused_calls = {k: v for k, v in S.fused_calls.items() if not k[1]}
+
+                with_lanes, without, tries = _lanes_trial(step, fence, set_lanes, max_over_ranks, reseat=reseat)
+                lanes_trial = {"two_scan_lanes_ms_per_step": with_lanes, "one_scan_stream_ms_per_step": without, "tries": tries}
                 set_lanes(True)
-                if with_lanes > without * 0.995:  # the same figures on every rank (max over ranks): every rank decides alike
+                if with_lanes > without * 0.985:  # kept only for a clear gain: a marginal one does not always survive into the timed steps  # the same figures on every rank (max over ranks): every rank decides alike
                     raise _Downgrade(f"two scan lanes measured no faster than one scan stream ({with_lanes:.4f} against {without:.4f} ms "
                                      "per step, un-timed trial)")
             for _ in range(args.warmup):

@@ -1102,7 +1102,8 @@ ma_status ma_group_join_lanes(ma_group* group);
 /* MA_GROUP_SCAN_LANES: use the second lanes (1) or run every step on the members' own streams (0) without a rebuild. What the lanes
  * gain depends on how the runtime maps the member's streams onto hardware queues, process by process (most often -3 ... -4 % per
  * step of the 8-way share, sometimes nothing): a host measures a few un-timed steps each way and keeps the faster, as bench.py
- * does. Drains the group first. MA_ERR_UNSUPPORTED for on = 1 on a group without lanes. */
+ * does. on = 2: use them on FRESH second contexts (new streams, mapped onto hardware queues anew: worth one or two tries when the
+ * lanes measured no faster). Drains the group first. MA_ERR_UNSUPPORTED for on != 0 on a group without lanes. */
 ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on);
 int32_t ma_group_is_broken(ma_group* group);
 ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags);

@@ -670,8 +670,19 @@ ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on) {
         MA_REQUIRE(!on, MA_ERR_UNSUPPORTED, "this group has no second scan lanes (create or rebuild it with MA_GROUP_SCAN_LANES)");
         return MA_OK;
     }
-    if (group->lanes_on == (on != 0)) return MA_OK;
+    if (on != 2 && group->lanes_on == (on != 0)) return MA_OK;
     MA_TRY(synchronize_locked(group));  // a set is never filled from two streams at once
+    if (on == 2) {
+        // fresh second lanes: new contexts, i.e. new streams, which the runtime maps onto hardware queues anew — what a host tries
+        // when its trial found the lanes no faster than one stream (both lanes in one hardware queue)
+        for (size_t i = 0; i < group->ctxs.size(); ++i) {
+            ma_ctx* fresh = nullptr;
+            MA_TRY(create_ctx_in_class(group->ctxs[i]->ordinal, 0, &fresh));
+            MA_TRY(ma_ctx_set_async(fresh, 1));
+            ma_ctx_destroy(group->scan2[i]);
+            group->scan2[i] = fresh;
+        }
+    }
     group->lanes_on = on != 0;
     group->prev_set = -1;
     return MA_OK;

@@ -942,8 +942,9 @@ class Group:
         ffi.check(self.lib.ma_group_mark_elapsed_ms(self.handle, int(member), int(from_index), int(to_index), C.addressof(ms)))
         return float(ms.value)
 
-    def set_scan_lanes(self, on: bool) -> None:
-        ffi.check(self.lib.ma_group_set_scan_lanes(self.handle, 1 if on else 0))
+    def set_scan_lanes(self, on) -> None:
+        """False / True, or 2 = on, with fresh second contexts (new streams: the runtime maps them onto hardware queues anew)."""
+        ffi.check(self.lib.ma_group_set_scan_lanes(self.handle, int(on)))
 
     def join_lanes(self) -> None:
         ffi.check(self.lib.ma_group_join_lanes(self.handle))

@@ -223,8 +223,8 @@ def test_the_scan_lanes_are_kept_only_if_the_untimed_trial_measures_them_faster(
         out = run([*LAUNCH, "--master-port", "29645", "bench.py", *args, "--gpus", "1", "--force-dist"])
     cfg = out["config"]
     trial = cfg["scan_lanes_trial"]
-    assert out["parity_ok"] and trial["two_scan_lanes_ms_per_step"] > 0 and trial["one_scan_stream_ms_per_step"] > 0
-    kept = trial["two_scan_lanes_ms_per_step"] <= trial["one_scan_stream_ms_per_step"] * 0.995
+    assert out["parity_ok"] and trial["two_scan_lanes_ms_per_step"] > 0 and trial["one_scan_stream_ms_per_step"] > 0 and 1 <= trial["tries"] <= 3
+    kept = trial["two_scan_lanes_ms_per_step"] <= trial["one_scan_stream_ms_per_step"] * 0.985
     assert ("two scan lanes" in cfg["exchange_form"]) == kept
     if kept:
         assert cfg["downgrades"] == []
