@@ -391,12 +391,16 @@ ma_status ma_sum_fused(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols);
  * does exactly that). An event record between two back-to-back scans costs the stream several microseconds; the stamp costs
  * it nothing. */
 ma_status ma_sum_fused_stamped(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value);
-/* The same, and additionally EVERY workgroup stores stamp_value to `*early_stamp` as soon as ITS rows are scanned — the first to
- * finish gets there first: "this launch has begun to drain". A scan on ANOTHER context of the device that waits for it
- * (ma_ctx_wait_value(other, early_stamp, stamp_value)) starts its ramp under this launch's stragglers and hand-off instead of
- * behind them, without running beside its whole scan: consecutive independent scans alternated over two contexts this way read
- * 7.04 -> 7.31 TB/s at 125 M rows per column, 5.67 -> 7.04 at 2^24 (profiles/r05_probe_early_stamp.jsonl). early_stamp may be
- * word 1 of the line ma_stamp_alloc returned for `stamp` (a device-word stamp is 64 bytes). */
+/* The same, and additionally stamp_value is stored to `*early_stamp` while the launch DRAINS: when the workgroups of two of the
+ * chip's eight XCDs have all scanned their rows (grids of up to 96 workgroups: by the first workgroup that has). A scan on ANOTHER
+ * context of the device that waits for it (ma_ctx_wait_value(other, early_stamp, stamp_value)) starts its ramp under this launch's
+ * stragglers and hand-off instead of behind them, without running beside its whole scan: consecutive independent scans alternated
+ * over two contexts this way read 7.04 -> 7.31 TB/s at 125 M rows per column, 5.67 -> 7.04 at 2^24
+ * (profiles/r05_probe_early_stamp.jsonl). The trigger is a measured choice: stored by the FIRST workgroup to finish, the overlap
+ * grows from step to step in two processes of three until scans run side by side for most of their length and the gain is gone;
+ * from the first whole XCD on it does not (profiles/r05_early_mode.txt: 36 of 36 processes at 0.274-0.279 ms per step against
+ * 0.286-0.293 on one stream). early_stamp may be word 1 of the line ma_stamp_alloc returned for `stamp` (a device-word stamp is
+ * 64 bytes). */
 ma_status ma_sum_fused_stamped_early(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
                                      uint64_t* early_stamp);
 /* A zeroed word on the context's device that a stream can be made to wait on (hipStreamWaitValue64) and a kernel's
@@ -934,11 +938,12 @@ ma_status ma_apply_arrow_stream_export(ma_ctx* ctx, int32_t op, struct ArrowArra
  *   MA_GROUP_SCAN_LANES      with MA_GROUP_EXCHANGE_RCCL | MA_GROUP_EXCHANGE_OVERLAP: every member gets a SECOND scan stream.
  *                            Record set 0 is filled by scans on the member's own stream, set 1 by scans on the second one, so
  *                            consecutive ma_group_enqueue_sum_table steps run on two streams — and each is gated on the EARLY
- *                            stamp of the step before it (stored by every workgroup of that step as soon as its rows are
- *                            scanned): its ramp runs under the previous step's stragglers and hand-off instead of behind them
- *                            (125 M rows per column and member: 0.2842 -> 0.2737 ms per step, 7.04 -> 7.31 TB/s; 2^24 rows:
- *                            -19 %; 10^9: no change — profiles/r05_probe_early_stamp.jsonl), without the two scans running
- *                            side by side for their whole length. Ordering: work the host enqueues ITSELF on a member's context
+ *                            stamp of the step before it (stored when the workgroups of two of the eight XCDs have scanned
+ *                            their rows — ma_sum_fused_stamped_early): its ramp runs under the previous step's stragglers and
+ *                            hand-off instead of behind them (125 M rows per column and member WITH the exchange: 0.288-0.292
+ *                            -> 0.275-0.278 ms per step, profiles/r05_share_lanes_ab.txt; 2^24 rows: -19 %; 10^9: no change —
+ *                            profiles/r05_probe_early_stamp.jsonl), without the two scans running side by side for their
+ *                            whole length. Ordering: work the host enqueues ITSELF on a member's context
  *                            is seen by the group (the next step on the second lane is ordered behind all of it), but such work
  *                            is ordered behind a step that runs on the second lane only after ma_group_join_lanes (enqueue-only)
  *                            or ma_group_synchronize. Ignored (ma_group_exchange_note says so) without the overlapped RCCL

@@ -48,8 +48,20 @@ struct FusedArgs {
     unsigned int* ticket;
     uint64_t* done_word;    // pinned word stamped after the results (synchronous call that polls), or nullptr
     uint64_t done_seq;
-    uint64_t* early_word;   // stamped with done_seq by every workgroup as soon as ITS rows are scanned (the first to finish gets
-                            // there first): "this launch has begun to drain" — what the NEXT scan on another stream waits for
+    // "This launch has begun to drain": the word the NEXT scan, on another stream, waits for before it starts (done_seq is stored).
+    // WHEN it is stored decides whether consecutive scans overlap by their tails only or run away into overlapping for most of
+    // their length (a scan that starts early slows the stragglers of the one before, whose own successor then starts earlier
+    // still; from 10^8 rows on that costs what the overlap gains). early_mode, over 5 boxes x 4 processes x 2 launch modes at
+    // 125 M rows per column (tools/run_early_quarters.sh; step on one scan stream: 0.286-0.293 ms; "ran away" = span of a scan
+    // between its marks >= 0.43 ms instead of ~0.30):
+    //   0  the first workgroup that has scanned its rows                  0.271-0.300, ran away in 16 of 24 processes
+    //   1-3  the arrival that completes 1/4, 1/2, 3/4 of a ticket shard   (3/4:) 0.271-0.300, ran away in 8 of 36
+    //   4  the first whole shard (the workgroups of one XCD) has arrived  0.273-0.280, ran away in 1 of 48
+    //   5  two whole shards have arrived — the default                    0.274-0.279, never in 36
+    //   6  four / 7: six whole shards                                      0.275-0.281 / 0.278-0.280, never
+    // Grids of up to 96 workgroups arrive on one ticket: mode 0 there (short scans; free-running overlap is a gain below 10^8 rows).
+    uint64_t* early_word;
+    unsigned early_mode;
 };
 
 // One accumulator per (column, row-of-a-load): two 64-bit words that are a wrapping integer sum (a) or a double-double
@@ -250,7 +262,8 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
     }
 
     // this workgroup's rows are scanned: the launch has begun to drain (see FusedArgs::early_word)
-    if (a.early_word && tid == 0) __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.early_word && a.early_mode == 0 && tid == 0)
+        __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     // ---- workgroup reduce, all columns ------------------------------------------------------------------------------
     __shared__ Partial lds[kFusedMax][kWaves];
@@ -304,9 +317,16 @@ __global__ __launch_bounds__(kBlock) void sum_fused_kernel(FusedArgs a) {
             const unsigned members = (G - sh + kFTicketShards - 1) / kFTicketShards;
             unsigned int* shard = a.ticket + kFTicketShardWord0 + sh * kFTicketShardStride;
             last = 0;
-            if (__hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            const unsigned before = __hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.early_word && a.early_mode >= 1 && a.early_mode <= 3 && before + 1 == (members * a.early_mode + 3) / 4)
+                __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (before == members - 1) {
                 __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kFTicketShards - 1;
+                const unsigned shards_done = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                last = shards_done == kFTicketShards;
+                // early_mode 4..7: the early stamp when 1 / 2 / 4 / 6 whole shards (XCDs) have arrived
+                if (a.early_word && a.early_mode >= 4 && shards_done == (a.early_mode == 4 ? 1u : a.early_mode == 5 ? 2u : a.early_mode == 6 ? 4u : 6u))
+                    __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         is_last = last;
@@ -506,7 +526,11 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
     const int pace = sel >= 0 ? sel : 20;
     a.done_word = stamp;  // stored (system-scope release) by the launch's final thread behind its results
     a.done_seq = stamp_value;
-    a.early_word = early_stamp;  // stored by every workgroup as soon as its rows are scanned (FusedArgs::early_word)
+    a.early_word = early_stamp;
+    {   // FusedArgs::early_mode; ctx variant bits 19-21 override (tuning): 0 = the default, v = mode v - 1
+        const unsigned sel = ((unsigned)ctx->variant >> 19) & 7u;
+        a.early_mode = grid > (int)kFShardFrom ? (sel ? sel - 1 : 5u) : 0u;
+    }
     if (any_masked) launch_fused<4, true>(ctx, a, grid, 0);
     else launch_fused<8, false>(ctx, a, grid, pace);
     MA_HIP(hipGetLastError());

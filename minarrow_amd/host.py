@@ -401,7 +401,7 @@ class Context:
             arr[i].null_count = int(col[6]) if len(col) > 6 else -1
             arr[i].format_code, arr[i].reserved = ord(fmt), 0
         handle, k, p = self.handle, len(columns), C.addressof(arr)
-        if stamp and early:  # ... and every workgroup stores it to `early` as soon as its rows are scanned (ma_sum_fused_stamped_early)
+        if stamp and early:  # ... and the launch stores it to `early` while it drains (ma_sum_fused_stamped_early)
             fe = self.lib.ma_sum_fused_stamped_early
 
             def call_stamped_early(value, _keep=arr):
