@@ -878,7 +878,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     const uint64_t seq = stamped ? ++group->stamp_seq[cur_set] : 0;
     group->stamp_ok[cur_set] = stamped;
     // two scan lanes: this step runs on the lane of its record set; when the call before it was a stamped step on the OTHER lane
-    // it starts as soon as that step's first workgroup has scanned its rows (the early stamp), not beside its whole scan
+    // it starts when that step has begun to drain (its early stamp: FusedArgs::early_word), not beside its whole scan
     const bool lanes = group->lanes2 && group->lanes_on;
     const bool gate = lanes && stamped && group->prev_set >= 0 && group->prev_set != cur_set;
     const int prev_set = group->prev_set;

@@ -88,8 +88,7 @@ hipStream_t rescue_stream(ma_group* g, size_t i) {
     if (!g->rescue[i]) {
         (void)hipSetDevice(g->ctxs[i]->device);
         // the LOW priority class: the runtime keeps a hardware-queue pool per class, so this stream never sits behind an ordinary
-        // one that is held (ordinary streams share hardware queues once a process has more than a few) — nor behind the second
-        // scan lanes, which live in the high class
+        // one that is held (ordinary streams share hardware queues once a process has more than a few)
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) (void)hipGetLastError();
         if (hipStreamCreateWithPriority(&g->rescue[i], hipStreamNonBlocking, least) != hipSuccess) {
@@ -708,20 +707,8 @@ ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags) {
     if (group->broken) {
         if (!group->drained) {  // one more bounded look: the streams may have run empty since the abort
             grp::release_waits(group, true);
-            const auto t0 = std::chrono::steady_clock::now();
-            bool idle = false;
-            while (!idle && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
-                idle = true;
-                for (size_t i = 0; i < group->ctxs.size(); ++i) {
-                    (void)hipSetDevice(group->ctxs[i]->device);
-                    if (hipStreamQuery(group->ctxs[i]->stream) != hipSuccess) idle = false;
-                    if (group->overlap && i < group->side.size() && group->side[i] && hipStreamQuery(group->side[i]->stream) != hipSuccess)
-                        idle = false;
-                    (void)hipGetLastError();
-                }
-                if (!idle) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-            }
-            group->drained = idle;
+            Pending p;  // scan streams, exchange streams, second scan lanes
+            group->drained = wait_streams(group, 2000.0, p);
         }
         MA_REQUIRE(group->drained, MA_ERR_DEVICE,
                    "the group's streams are still busy after its communicators were aborted: it cannot be rebuilt (the device may "
