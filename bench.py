@@ -819,9 +819,9 @@ def _overlapped_scans(k, ms_per_step):
 
 
 def _lanes_trial(step, drain, set_lanes, agree_max=None, batch=32, rounds=3, reseat=None, tries=3):
-    """_lanes_trial_once, up to `tries` times: when the lanes measure no faster than one stream (both lanes mapped onto one hardware
-    queue, where the second lane's wait sits behind the first lane's whole scan), `reseat()` gives the second lane a fresh context —
-    a new stream, mapped anew — and the trial runs again. Returns (ms per step with lanes, without, tries used)."""
+    """_lanes_trial_once, up to `tries` times: when the lanes measure no faster than one stream (consecutive scans overlapping for
+    most of their length instead of by their tails: DESIGN.md §3.1), `reseat()` gives the second lane a fresh context — a new stream
+    — and the trial runs again from rest. Returns (ms per step with lanes, without, tries used)."""
     for attempt in range(1, tries + 1):
         with_lanes, without = _lanes_trial_once(step, drain, set_lanes, agree_max, batch, rounds)
         if with_lanes <= without * 0.985 or reseat is None or attempt == tries:
@@ -831,8 +831,9 @@ def _lanes_trial(step, drain, set_lanes, agree_max=None, batch=32, rounds=3, res
 
 
 def _lanes_trial_once(step, drain, set_lanes, agree_max=None, batch=32, rounds=3):
-    """Two scan lanes or one scan stream? What the lanes gain depends on how the runtime mapped this process's streams onto hardware
-    queues (most often 3-4 % per step of the 8-way share, sometimes nothing, now and then -1 %), so the run measures: `rounds` x
+    """Two scan lanes or one scan stream? The lanes gain 4-5 % per step of the 8-way share as long as consecutive scans overlap by
+    their tails only; a process in which the overlap runs away gains nothing (seen with earlier triggers of the early stamp, never
+    on a multi-GPU node, which this pool does not have), so the run measures: `rounds` x
     (`batch` steps with the lanes, `batch` without; long enough for the overlap to reach its steady state), un-timed, in front of the
     warm-up steps; the fastest batch of each form counts
     (with several ranks: the slowest rank's). Returns (ms per step with lanes, without)."""

@@ -1104,11 +1104,12 @@ ma_status ma_group_synchronize_for(ma_group* group, double timeout_ms);
  * what a host calls before it enqueues work of its own on a member's context that must come AFTER the group's steps. A no-op
  * for a group without lanes. Enqueue-only. */
 ma_status ma_group_join_lanes(ma_group* group);
-/* MA_GROUP_SCAN_LANES: use the second lanes (1) or run every step on the members' own streams (0) without a rebuild. What the lanes
- * gain depends on how the runtime maps the member's streams onto hardware queues, process by process (most often -3 ... -4 % per
- * step of the 8-way share, sometimes nothing): a host measures a few un-timed steps each way and keeps the faster, as bench.py
- * does. on = 2: use them on FRESH second contexts (new streams, mapped onto hardware queues anew: worth one or two tries when the
- * lanes measured no faster). Drains the group first. MA_ERR_UNSUPPORTED for on != 0 on a group without lanes. */
+/* MA_GROUP_SCAN_LANES: use the second lanes (1) or run every step on the members' own streams (0) without a rebuild. The lanes gain
+ * -4 ... -5 % per step of the 8-way share while consecutive scans overlap by their tails only (36 of 36 processes on this pool's
+ * one-GPU boxes: profiles/r05_early_mode.txt); a host that wants to be sure on its own node measures a few dozen un-timed steps
+ * each way and keeps the faster, as bench.py does. on = 2: use them on FRESH second contexts (new streams; the steps start from
+ * rest: worth a try when the lanes measured no faster). Drains the group first. MA_ERR_UNSUPPORTED for on != 0 on a group without
+ * lanes. */
 ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on);
 int32_t ma_group_is_broken(ma_group* group);
 ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags);

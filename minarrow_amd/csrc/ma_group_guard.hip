@@ -672,8 +672,8 @@ ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on) {
     if (on != 2 && group->lanes_on == (on != 0)) return MA_OK;
     MA_TRY(synchronize_locked(group));  // a set is never filled from two streams at once
     if (on == 2) {
-        // fresh second lanes: new contexts, i.e. new streams, which the runtime maps onto hardware queues anew — what a host tries
-        // when its trial found the lanes no faster than one stream (both lanes in one hardware queue)
+        // fresh second lanes: new contexts, i.e. new streams, and the steps start from rest — what a host tries when its trial found
+        // the lanes no faster than one stream
         for (size_t i = 0; i < group->ctxs.size(); ++i) {
             ma_ctx* fresh = nullptr;
             MA_TRY(create_ctx_in_class(group->ctxs[i]->ordinal, 0, &fresh));
