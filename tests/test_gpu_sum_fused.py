@@ -256,8 +256,8 @@ def test_stamped_launch_and_exchange_waiting_on_the_stamp(ctx, oracle):
 
 def test_two_contexts_alternate_gated_on_the_early_stamp(ctx, oracle):
     """ma_sum_fused_stamped_early + ma_ctx_wait_value: consecutive independent scans on two contexts of one device, each made to
-    wait for the EARLY stamp of the one before (stored by every workgroup as soon as its rows are scanned) — its ramp runs under the
-    previous scan's stragglers. Every scan's results must be its own (distinct columns in turn, dense and gated), the final stamps
+    wait for the EARLY stamp of the one before (stored while that launch drains: two of its eight ticket shards have arrived) — its
+    ramp runs under the previous scan's stragglers. Every scan's results must be its own (distinct columns in turn, dense and gated), the final stamps
     end at their sequences, and the early word never runs ahead of a launch that has not started."""
     from minarrow_amd.host import Context
 
@@ -311,3 +311,34 @@ def test_two_contexts_alternate_gated_on_the_early_stamp(ctx, oracle):
         for c, st in zip(lanes, stamps):
             c.stamp_free(st)
         other.close()
+
+
+@pytest.mark.parametrize("mode", range(8))
+@pytest.mark.parametrize("rows", [50_000, 3_000_017])
+def test_every_trigger_of_the_early_stamp_stores_it_once_and_leaves_the_results_alone(ctx, oracle, mode, rows):
+    """FusedArgs::early_mode (ma_reduce_fused.hip): the early stamp stored by the first workgroup to finish (0), by the arrival that
+    completes 1/4, 1/2, 3/4 of a ticket shard (1-3), or when 1 / 2 / 4 / 6 whole shards have arrived (4-7; 5 is the default) — ctx
+    variant bits 19-21 = mode + 1. Whatever the trigger (and on a grid of up to 96 workgroups, where the first workgroup stores it
+    whatever was asked for), after the launch both words hold the sequence and the sums are the column's."""
+    rng = np.random.default_rng(1000 + mode)
+    a = rng.integers(-(1 << 62), 1 << 62, size=rows, dtype=np.int64)
+    f = rng.standard_normal(rows) * 1e3
+    da, df = ctx.to_device(a, 64), ctx.to_device(f, 64)
+    rec = _records(ctx, 1)
+    stamp = ctx.stamp_alloc()
+    ctx.set_variant((mode + 1) << 19)
+    try:
+        word = np.zeros(2, dtype=np.uint64)
+        for seq in (1, 2, 3):  # the tickets are ready for the next launch each time
+            ctx.prepare_sum_fused([("l", da, rows, rec.ptr), ("g", df, rows, rec.ptr + 16)], stamp=stamp, early=stamp + 8)(seq)
+            ctx.synchronize()
+            assert ctx.lib.ma_dev_download(ctx.handle, word.ctypes.data, stamp, 16) == 0
+            assert [int(x) for x in word] == [seq, seq]
+            w = _read(rec, 0)
+            assert int(w[0]) == oracle.sum_scalar(a) & M64 and int(w[1]) == rows == int(w[4])
+            hi, lo = (float(x) for x in w[2:4].view(np.float64))
+            exact = math.fsum(f.tolist())
+            assert abs((hi + lo) - exact) <= math.ulp(exact)
+    finally:
+        ctx.set_variant(0)
+        ctx.stamp_free(stamp)
