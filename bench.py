@@ -2205,7 +2205,7 @@ def main() -> int:
     ap.add_argument("--headline-seconds", type=float, default=240.0,
                     help="N > 1: the last resort — give up (exit code 3, reason on stderr) when set-up + warm-up + timed steps, "
                          "every downgrade included, take longer")
-    ap.add_argument("--init-seconds", type=float, default=60.0,
+    ap.add_argument("--init-seconds", type=float, default=90.0,
                     help="N > 1: the deadline of creating (or rebuilding) the RCCL communicators — ncclCommInitAll / ncclCommInitRank "
                          "load several hundred MB of device code on first use and rendezvous all ranks; past it RCCL is given up "
                          "for the host exchange")
