@@ -981,6 +981,8 @@ enum {
 };
 ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_group** out_group);
 ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, uint32_t flags, ma_group** out_group);
+/* Waits at most 10 s for what the members' streams still hold, then aborts the communicators (as ma_group_synchronize_for does) —
+ * never an unbounded wait; what a stream that still has not run empty holds is left to the process. */
 void ma_group_destroy(ma_group* group);
 int32_t ma_group_size(ma_group* group);
 ma_ctx* ma_group_ctx(ma_group* group, int32_t index);
@@ -1203,6 +1205,7 @@ int32_t ma_rccl_version(void);
 const char* ma_rccl_path(void);
 ma_status ma_comm_unique_id(uint8_t* out_id);
 ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, ma_comm** out_comm);
+/* Bounded like ma_group_destroy: 10 s for what is in flight, then the abort path. */
 void ma_comm_destroy(ma_comm* comm);
 int32_t ma_comm_rank(ma_comm* comm);
 int32_t ma_comm_size(ma_comm* comm);

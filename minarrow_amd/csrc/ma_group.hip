@@ -776,6 +776,12 @@ ma_status ma_group_create(const int32_t* device_ordinals, int32_t n_members, ma_
 
 void ma_group_destroy(ma_group* group) {
     if (!group) return;
+    {   // Never an unbounded wait: releasing the exchange synchronizes the members' streams, and one that is still held (a
+        // collective whose peer never came) would keep that for good. 10 s for whatever is in flight; past them the communicators
+        // are aborted, and what a stream that STILL has not run empty holds goes with the process (destroy_members).
+        std::lock_guard<std::recursive_mutex> lock(group->mu);
+        if (!group->broken) (void)synchronize_for_locked(group, destroy_wait_ms());
+    }
     destroy_members(group);
     delete group;
 }

@@ -49,6 +49,12 @@ void guard_log(const char* fmt, ...) {
     fflush(stderr);
 }
 
+double destroy_wait_ms() {
+    const char* e = getenv("MINARROW_HIP_DESTROY_WAIT_MS");  // read at every destroy: a host may set it late
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 10000.0;
+}
+
 bool call_bounded(const std::function<void()>& fn, double timeout_ms) {
     struct State {
         std::mutex mu;

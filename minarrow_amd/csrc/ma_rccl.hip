@@ -306,6 +306,12 @@ ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n
 void ma_comm_destroy(ma_comm* comm) {
     if (!comm) return;
     (void)hipSetDevice(comm->ctx->device);
+    if (!comm->broken) {  // never an unbounded wait below: 10 s for what is in flight, then the abort path (itself bounded)
+        comm_release_waits(comm, false);
+        const char* which = "";
+        hipError_t e = hipSuccess;
+        if (!comm_wait_streams(comm, destroy_wait_ms(), &which, &e)) comm_abort(comm);
+    }
     if (comm->broken && !comm->drained) {  // a stream that never ran empty: nothing here may wait for it
         delete comm;
         return;

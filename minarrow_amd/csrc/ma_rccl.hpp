@@ -50,6 +50,10 @@ ma_status stamp_alloc_kind(ma_ctx* ctx, uint64_t** out_stamp, bool want_signal);
 // left behind). For runtime calls that are documented to return but wait on the GPU inside (ncclCommAbort).
 bool call_bounded(const std::function<void()>& fn, double timeout_ms);
 
+// ma_group_guard.hip: how long ma_group_destroy / ma_comm_destroy wait for work still in flight before they abort (10 s;
+// MINARROW_HIP_DESTROY_WAIT_MS).
+double destroy_wait_ms();
+
 // ma_group_guard.hip: one thread stores `value` to `*stamp` with a system-scope release, as the fused scan's final thread does.
 hipError_t launch_stamp_store(hipStream_t stream, uint64_t* stamp, uint64_t value);
 

@@ -132,6 +132,40 @@ def test_destroying_a_group_with_an_armed_stall_releases_it():
     assert time.perf_counter() - t0 < 10.0
 
 
+def test_the_library_s_own_destroy_is_bounded_too(ctx, monkeypatch):
+    """ma_group_destroy / ma_comm_destroy as a C or Rust host calls them, without host.py's drain in front: a stalled exchange in
+    flight must not keep them (MINARROW_HIP_DESTROY_WAIT_MS for work in flight — 10 s by default —, then the abort path)."""
+    monkeypatch.setenv("MINARROW_HIP_DESTROY_WAIT_MS", "300")
+    col_i, col_f = ctx.alloc(N * 8), ctx.alloc(N * 8)  # the fixture's context owns the columns: nothing dies with the group
+    ctx.synth_iota("i64", col_i, N, 0)
+    ctx.synth_iota("f64", col_f, N, 0)
+    ctx.synchronize()
+    g = _rccl_group("rccl-overlap")
+    g.test_stall_next_exchange(0)
+    _step(g, col_i, col_f)
+    for m in g._members:
+        m.handle = None  # views of contexts the group owns
+    t0 = time.perf_counter()
+    g.lib.ma_group_destroy(g.handle)
+    g.handle = None
+    assert time.perf_counter() - t0 < 8.0
+
+    comm = _comm(ctx)
+    local, gathered, final = _records(ctx)
+    ctx.set_async(True)
+    try:
+        ctx.sum_into("i64", col_i, N, out_sum=local.ptr, out_count=local.ptr + 8)
+        comm.test_stall_next_exchange()
+        comm.sum_exchange(local, 1, 1, gathered, final)
+        t0 = time.perf_counter()
+        comm.lib.ma_comm_destroy(comm.handle)
+        comm.handle = None
+        assert time.perf_counter() - t0 < 8.0
+        ctx.synchronize()  # the abort path released the held stream
+    finally:
+        ctx.set_async(False)
+
+
 @pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "host"])
 def test_a_corrupted_exchange_is_visible_in_the_finals_and_only_once(exchange):
     g = Group([0], exchange=exchange) if exchange == "host" else _rccl_group(exchange)
