@@ -1535,9 +1535,9 @@ def run_native(args, result_fd) -> int:
         S.stamps = [ctx.stamp_alloc() for _ in S.exs] if notch["stamp"] else None
         S.stamp_seq = [0 for _ in S.exs]
         # Two scan lanes: record set 1 is filled by scans on a SECOND context of this device, and every stamped scan is gated on the
-        # early stamp of the scan before it (word 1 of that scan's stamp line, stored by every workgroup as soon as its rows are
-        # scanned): its ramp runs under the previous scan's stragglers and hand-off (125 M rows per column: 0.2842 -> 0.2737 ms per
-        # step, profiles/r05_probe_early_stamp.jsonl)
+        # early stamp of the scan before it (word 1 of that scan's stamp line, stored when the workgroups of two of the eight XCDs have
+        # scanned their rows): its ramp runs under the previous scan's stragglers and hand-off (125 M rows per column with the
+        # exchange: 0.288-0.291 -> 0.275-0.278 ms per step, profiles/r05_share_lanes_ab.txt)
         S.lanes = bool(notch["lanes"]) and S.stamps is not None and all(ctx.lib.ma_stamp_is_signal(st) == 0 for st in S.stamps)
         if notch["lanes"] and not S.lanes:
             raise _Downgrade("two scan lanes need stamps in plain device words")

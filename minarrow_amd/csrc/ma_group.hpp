@@ -83,8 +83,8 @@ struct ma_group {
     bool stamp_ok[2] = {false, false};
     // MA_GROUP_SCAN_LANES (overlapped RCCL exchange only): a SECOND scan context per member. Record set 0 is filled by scans on
     // the member's own context, set 1 by scans on scan2[i] — consecutive steps therefore run on two streams, and a stamped step
-    // on one lane is gated on the EARLY stamp of the step before it on the other (stored by every workgroup as soon as its rows
-    // are scanned): its ramp runs under that step's stragglers and hand-off instead of behind them (125 M rows per column:
+    // on one lane is gated on the EARLY stamp of the step before it on the other (stored while that step drains: FusedArgs::early_word,
+    // ma_reduce_fused.hip): its ramp runs under that step's stragglers and hand-off instead of behind them (125 M rows per column:
     // 0.2842 -> 0.2737 ms per step, profiles/r05_probe_early_stamp.jsonl), without the two scans running side by side for their
     // whole length (which costs 2-5 % from 10^8 rows on). ev_lane / seen_calls: when the host — or a group call that is not such a
     // step — has put work of its own on a member's context (ma_ctx::calls moved), the next lane-1 launch is ordered behind ALL
