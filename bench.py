@@ -649,6 +649,49 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
             b.free()
 
 
+def _pipelined_leg(ctx, col_i, col_f, rows: int, steps: int, warmup: int, line: dict):
+    """The same 2 x `rows`-row job as a PIPELINE of steps (N = 1, after the timed headline, labelled, never `value`): every step is
+    one fused i64 + f64 scan (ma_sum_fused's kernel) through ma_scan_lanes_* — consecutive steps on two streams of the GPU, each
+    started when the step before it has begun to drain — the form the N > 1 modes run per GPU (two scan lanes). What a host that
+    streams independent sums gets beyond the one-stream headline: no launch ramp and no spread of finish times between the scans."""
+    import numpy as np
+
+    from minarrow_amd.host import ScanLanes
+
+    rec = None
+    try:
+        rec = ctx.alloc(64 * 2)
+        ctx.dev_memset(rec, 0, 128)
+        with ScanLanes(ctx) as lanes:
+            calls = [lanes.prepare_sum_fused([("l", col_i, rows, rec.ptr + 64 * k), ("g", col_f, rows, rec.ptr + 64 * k + 16)])
+                     for k in range(2)]
+            for k in range(max(2, warmup)):
+                calls[k & 1]()
+            lanes.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                calls[k & 1]()
+            lanes.synchronize()
+            el = time.perf_counter() - t0
+        ok = True
+        for k in range(2):
+            w = rec.download(np.uint64, 8, 64 * k)
+            hi, lo = (float(x) for x in w[2:4].view(np.float64))
+            ok = ok and _check(rows, (int(w[0]), int(w[1]), hi + lo, int(w[4])))
+        gbps = rows * 16 * steps / el / 1e9
+        line["pipelined"] = {"value": rows * 2 * steps / el / 1e9, "unit": "Grows/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+                             "hbm_gbps": gbps, "frac_of_peak": gbps / HBM_PEAK_GBPS, "parity_ok": ok,
+                             "step": "one fused launch (ma_sum_fused's kernel: i64 + f64) per step through ma_scan_lanes_*: consecutive "
+                                     "steps on two streams, each started by the early stamp of the one before",
+                             "note": "wall clock over the steps; the scans overlap by their tails, so this is a rate of the pipeline, "
+                                     "not of one kernel — the roofline object above is the one-stream headline's"}
+    except Exception as e:  # noqa: BLE001 — never at the expense of the headline
+        line["pipelined"] = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if rec is not None:
+            rec.free()
+
+
 def _check(total_rows, finals):
     got_i, cnt_i, got_f, cnt_f = finals
     expect = total_rows * (total_rows - 1) // 2
@@ -1796,6 +1839,8 @@ def run_native(args, result_fd) -> int:
                             "scan_ms_is_span_of_overlapping_scans": bool(S.lanes)})
         if (scaling == "strong" and world > 1) or args.force_dist:
             _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
+    if rank == 0 and not distributed and not args.no_pipelined_leg:
+        _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
     for b in (col_i, col_f):
         b.free()
     if distributed and not args.no_other_configs:
@@ -2220,6 +2265,8 @@ def main() -> int:
     ap.add_argument("--torch-hosted", action="store_true",
                     help="host the run in PyTorch as rounds 1-3 did: torch imported first (its bundled HIP runtime), columns in "
                          "torch tensors, the library on torch's stream, torch.distributed's RCCL group for barriers")
+    ap.add_argument("--no-pipelined-leg", action="store_true",
+                    help="N = 1: skip the labelled `pipelined` key (the same job as a pipeline of fused steps through ma_scan_lanes_*)")
     ap.add_argument("--no-torch-hosted-leg", action="store_true",
                     help="N = 1: skip the labelled extra key `torch_hosted` (the same headline in a --torch-hosted child process)")
     ap.add_argument("--torch-hosted-seconds", type=float, default=240.0)

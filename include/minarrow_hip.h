@@ -60,7 +60,8 @@ extern "C" {
  * testing hooks ma_group_test_stall_next_exchange / _corrupt_next_exchange, ma_comm_test_stall_next_exchange /
  * _corrupt_next_exchange. A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange.
  * + ma_sum_fused_stamped_early, ma_ctx_wait_value, MA_GROUP_SCAN_LANES, ma_group_join_lanes (consecutive scans on two streams, the
- * next one gated on the early stamp of the one before). */
+ * next one gated on the early stamp of the one before); ma_scan_lanes_* (the same pipeline for a host that drives one GPU
+ * without a group). */
 #define MA_ABI_VERSION 4
 
 typedef struct ma_ctx ma_ctx;
@@ -417,6 +418,31 @@ ma_status ma_ctx_wait_value(ma_ctx* ctx, const uint64_t* word, uint64_t value);
 /* 1 when `stamp` (from ma_stamp_alloc) is the runtime's signal memory, 0 when it is a plain device word (the fall-back; a
  * wait on it works the same), -1 when the pointer is not a live stamp. */
 int32_t ma_stamp_is_signal(const uint64_t* stamp);
+
+/* ---- back-to-back sums on one GPU as a pipeline ----------------------------------------------------------------------------
+ * The reference's hot loop — `for _ in 0..N { sum(&arr) }` over an IntegerArray / FloatArray, one pass per call
+ * (benches/hotloop_benchmark_std.rs:109-127, benches/hotloop_benchmark_simd.rs) — enqueued on ONE stream pays a launch's fixed
+ * cost (ramp + hand-off, ~3.3 us) and the spread of the workgroups' finish times behind every scan: 2^24-row i64 + f64 steps run
+ * at 0.70-0.73 of the HBM peak that way, 125 M-row steps at 0.885. A ma_scan_lanes puts consecutive ma_sum_fused scans on two
+ * streams of the context's device in turn — the context's own and one it owns — and starts each when the scan in front of it has
+ * begun to drain (ma_sum_fused_stamped_early's early stamp), not beside its whole length: what MA_GROUP_SCAN_LANES does per
+ * member of a group, for a host without one (figures: profiles/r05_scan_lanes_api.jsonl).
+ *   ma_scan_lanes_sum_fused  enqueue-only whatever mode the context is in; arguments and results as ma_sum_fused. The scans in
+ *                            flight must not share `out` records (two lanes may finish in either order); the columns are only read.
+ *                            Work the host enqueued on `ctx` BEFORE the call is seen (a per-context call counter) and the scan is
+ *                            ordered behind all of it.
+ *   ma_scan_lanes_join       ctx's stream behind everything the second lane has been given (enqueue-only): call it before
+ *                            anything else on `ctx` that reads the scans' results or overwrites their columns.
+ *   ma_scan_lanes_synchronize  waits for both lanes; a latched device condition of either comes back as its status.
+ * MA_ERR_UNSUPPORTED from _create on a runtime without stream memory operations (hipStreamWaitValue64). One pipeline per context
+ * at a time; destroy it before the context. */
+typedef struct ma_scan_lanes ma_scan_lanes;
+ma_status ma_scan_lanes_create(ma_ctx* ctx, ma_scan_lanes** out_lanes);
+ma_status ma_scan_lanes_sum_fused(ma_scan_lanes* lanes, size_t n_cols, const ma_fused_column* cols);
+ma_status ma_scan_lanes_join(ma_scan_lanes* lanes);
+ma_status ma_scan_lanes_synchronize(ma_scan_lanes* lanes);
+uint64_t ma_scan_lanes_scans(ma_scan_lanes* lanes);
+void ma_scan_lanes_destroy(ma_scan_lanes* lanes);
 
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
  * rayon_simd_sum_* (benches/benchmark_parallel_simd.rs:87) for a row-chunk partition over GPUs. record r =

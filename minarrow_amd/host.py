@@ -728,6 +728,62 @@ GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "
                "rccl-overlap-lanes": 1 | 8 | 16, "rccl-overlap-lanes-or-host": 3 | 8 | 16}
 
 
+class ScanLanes:
+    """Back-to-back fused sums on one GPU as a pipeline (ma_scan_lanes_*): consecutive scans on two streams of the context's
+    device, each started when the one before it has begun to drain — the reference's hot loop of sums
+    (benches/hotloop_benchmark_std.rs:109-127) without a launch's fixed cost between the scans."""
+
+    def __init__(self, ctx: "Context"):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = C.c_void_p()
+        ffi.check(self.lib.ma_scan_lanes_create(ctx.handle, C.byref(h)))
+        self.handle = h.value
+
+    def prepare_sum_fused(self, columns):
+        """A zero-argument callable that enqueues one fused scan of `columns` ((format, data, n, out[, mask, bit offset[,
+        null count]]) each, as Context.sum_fused) on the lane whose turn it is; the argument table is built once."""
+        arr = (FusedColumn * len(columns))()
+        for i, col in enumerate(columns):
+            fmt, data, n, out = col[:4]
+            arr[i].data, arr[i].n, arr[i].out = addr_of(data), int(n), addr_of(out)
+            arr[i].mask_bits = addr_of(col[4] if len(col) > 4 else None)
+            arr[i].mask_bit_offset = int(col[5]) if len(col) > 5 else 0
+            arr[i].null_count = int(col[6]) if len(col) > 6 else -1
+            arr[i].format_code, arr[i].reserved = ord(fmt), 0
+        fn, handle, k, p = self.lib.ma_scan_lanes_sum_fused, self.handle, len(columns), C.addressof(arr)
+
+        def call(_keep=arr):
+            st = fn(handle, k, p)
+            if st:
+                ffi.check(st)
+
+        return call
+
+    def sum_fused(self, columns) -> None:
+        self.prepare_sum_fused(columns)()
+
+    def join(self) -> None:
+        ffi.check(self.lib.ma_scan_lanes_join(self.handle))
+
+    def synchronize(self) -> None:
+        ffi.check(self.lib.ma_scan_lanes_synchronize(self.handle))
+
+    @property
+    def scans(self) -> int:
+        return int(self.lib.ma_scan_lanes_scans(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.ma_scan_lanes_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class Group:
     """One process driving several GPUs (ma_group_*): member i scans chunk i on device i, one exchange ends the
     reduction. exchange = "rccl" (ncclCommInitAll + grouped all-gather + device fold), "rccl-or-host", or "host"."""

@@ -50,6 +50,8 @@ def test_single_gpu_line_with_other_configs_and_cpu_baseline():
     assert set(out["kernels"]) == {"sum_i64", "sum_f64"} and out["roofline"]["kernel"].startswith("ma::sum_kernel")
     th = out["torch_hosted"]  # the same headline hosted by PyTorch, as a labelled extra key
     assert th["parity_ok"] and th["value"] > 0 and "torch" in th["hip_runtime"]
+    pl = out["pipelined"]  # the same job as a pipeline of fused steps on two streams (ma_scan_lanes_*), labelled, never `value`
+    assert pl["parity_ok"] and pl["value"] > 0 and 0 < pl["frac_of_peak"] <= 1.0 and "ma_scan_lanes" in pl["step"]
 
 
 def test_single_gpu_fused_step_and_torch_hosted_variant():
