@@ -190,4 +190,30 @@ class Group {
     ma_group* g_ = nullptr;
 };
 
+// Back-to-back sums on ONE GPU as a pipeline (ma_scan_lanes_*): the reference's hot loop of sums
+// (benches/hotloop_benchmark_std.rs:109-127) with consecutive fused scans on two streams of the context's device, each started
+// when the one before it has begun to drain. enqueue() only enqueues, whatever mode the context is in; every scan in flight
+// writes its OWN records; join() before anything else on the context that reads them or overwrites the columns.
+class ScanLanes {
+  public:
+    explicit ScanLanes(ma_ctx* ctx) { check(ma_scan_lanes_create(ctx, &l_)); }
+    ~ScanLanes() { ma_scan_lanes_destroy(l_); }
+    ScanLanes(const ScanLanes&) = delete;
+    ScanLanes& operator=(const ScanLanes&) = delete;
+    void enqueue(const std::vector<ma_fused_column>& cols) const { check(ma_scan_lanes_sum_fused(l_, cols.size(), cols.data())); }
+    // one i64 and one f64 column into the integer and the float slots of one 64-byte record ({sum, count, hi, lo, count})
+    void enqueue_pair(const int64_t* ints, const double* floats, size_t n, uint64_t* record) const {
+        ma_fused_column c[2] = {};
+        c[0].data = ints, c[0].n = n, c[0].null_count = -1, c[0].format_code = 'l', c[0].out = record;
+        c[1].data = floats, c[1].n = n, c[1].null_count = -1, c[1].format_code = 'g', c[1].out = record + 2;
+        check(ma_scan_lanes_sum_fused(l_, 2, c));
+    }
+    void join() const { check(ma_scan_lanes_join(l_)); }
+    void synchronize() const { check(ma_scan_lanes_synchronize(l_)); }
+    uint64_t scans() const { return ma_scan_lanes_scans(l_); }
+
+  private:
+    ma_scan_lanes* l_ = nullptr;
+};
+
 }  // namespace ma

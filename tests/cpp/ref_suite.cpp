@@ -690,6 +690,44 @@ static void parallel_mirror_suite() {
     }
 }
 
+// The reference's hot loop of sums (benches/hotloop_benchmark_std.rs:109-127: one pass per call over the same arrays) as a
+// pipeline on one GPU (ma::ScanLanes over ma_scan_lanes_*): consecutive fused scans on two streams, each into its own record,
+// with a kernel of the host's own on the context in between (ordered in front of the scan that reads what it wrote).
+static void scan_lanes_suite() {
+    std::printf("scan lanes (ma::ScanLanes)\n");
+    ma_ctx* ctx = nullptr;
+    ASSERT(ma_ctx_create(0, &ctx) == MA_OK);
+    const size_t n = 1500007;
+    void *di = nullptr, *df = nullptr, *dout = nullptr, *rec = nullptr;
+    ASSERT(ma_dev_alloc(ctx, n * 8 + 64, &di) == MA_OK && ma_dev_alloc(ctx, n * 8 + 64, &df) == MA_OK);
+    ASSERT(ma_dev_alloc(ctx, n * 8 + 64, &dout) == MA_OK && ma_dev_alloc(ctx, 64 * 6, &rec) == MA_OK);
+    ASSERT(ma_synth_iota_i64(ctx, (int64_t*)di, n, 0) == MA_OK && ma_synth_iota_f64(ctx, (double*)df, n, 0) == MA_OK);
+    ASSERT(ma_ctx_set_async(ctx, 1) == MA_OK);
+    const int64_t tri = (int64_t)(n * (n - 1) / 2);
+    {
+        ma::ScanLanes lanes(ctx);
+        for (int k = 0; k < 6; ++k) {
+            lanes.join();  // the add below overwrites what the scan before it read
+            ASSERT(ma_apply_int_i64_scalar_rhs(ctx, (const int64_t*)di, n, (int64_t)k, MA_OP_ADD, nullptr, 0, (int64_t*)dout, nullptr) == MA_OK);
+            lanes.enqueue_pair((const int64_t*)dout, (const double*)df, n, (uint64_t*)rec + 8 * k);
+        }
+        lanes.synchronize();
+        ASSERT(lanes.scans() == 6);
+        uint64_t w[48];
+        ASSERT(ma_dev_download(ctx, w, rec, sizeof(w)) == MA_OK);
+        for (int k = 0; k < 6; ++k) {
+            double hi, lo;
+            std::memcpy(&hi, &w[8 * k + 2], 8);
+            std::memcpy(&lo, &w[8 * k + 3], 8);
+            ASSERT((int64_t)w[8 * k] == tri + (int64_t)k * (int64_t)n && w[8 * k + 1] == n && w[8 * k + 4] == n);
+            ASSERT(hi + lo == (double)tri);  // < 2^53: exact
+        }
+    }
+    ASSERT(ma_ctx_set_async(ctx, 0) == MA_OK);
+    for (void* p : {di, df, dout, rec}) ASSERT(ma_dev_free(ctx, p) == MA_OK);
+    ma_ctx_destroy(ctx);
+}
+
 // rayon_simd_sum_{i64,f64} over the GPUs of the node, driven from ONE compiled host process straight through the C ABI
 // (benches/benchmark_parallel_simd.rs:81-98: `par_chunks(1 << 20).map(simd_sum).sum()` — here one row chunk per device,
 // the partials meeting in the library's exchange). Every visible device takes part (one on the test pool: the RCCL
@@ -855,6 +893,7 @@ int main() {
         device_residency_suite();
         multi_gpu_group_suite();
         parallel_mirror_suite();
+        scan_lanes_suite();
         // fused scalar broadcast: [10,20,30] * 2 = [20,40,60] (src/kernels/broadcast/array.rs:685-700)
         Vec64<int32_t> arr{10, 20, 30};
         ASSERT((apply_int_i32_scalar_rhs(arr, 2, Op::Multiply).data == std::vector<int32_t>{20, 40, 60}));
