@@ -641,6 +641,13 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
         line["n1_same_process"] = {"value": v1, "unit": "Grows/s", "ms_per_step": el / steps * 1e3, "steps": steps,
                                    "rows_per_column": total_rows, "gpu": 0}
         line["efficiency_vs_n1"] = line["value"] / (line["n_gpus"] * v1)
+        # ... and the same job on this one GPU as a PIPELINE of fused steps (what every GPU of the N > 1 modes runs with two scan
+        # lanes): the like-for-like denominator of a run whose steps are pipelined
+        piped = {}
+        _pipelined_leg(ctx, col_i, col_f, total_rows, steps, warmup, piped)
+        line["n1_same_process"]["pipelined"] = piped.get("pipelined")
+        pv = (piped.get("pipelined") or {}).get("value")
+        line["efficiency_vs_n1_pipelined"] = line["value"] / (line["n_gpus"] * pv) if pv else None
     except Exception as e:  # noqa: BLE001 — never at the expense of the headline
         line["n1_same_process"] = {"error": f"{type(e).__name__}: {e}"}
         line["efficiency_vs_n1"] = None

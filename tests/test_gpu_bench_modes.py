@@ -72,6 +72,8 @@ def test_one_process_group_mode_with_rccl():
     assert out["scaling"] == "strong" and out["config"]["rows_total_per_column"] == 1 << 24
     assert "issue: threads" in out["config"]["parallelism"] and out["config"]["host_issue_us_per_step"] > 0
     assert out["n1_same_process"]["value"] > 0 and 0.2 < out["efficiency_vs_n1"] < 2.0
+    piped = out["n1_same_process"]["pipelined"]  # the like-for-like denominator: the same job on one GPU as a pipeline of fused steps
+    assert piped["parity_ok"] and piped["value"] > 0 and 0.2 < out["efficiency_vs_n1_pipelined"] < 2.0
     assert out["config"]["rccl_ranks"] == 1 and "RCCL all-gather (ncclCommInitAll" in out["config"]["exchange"]
     # the line explains itself: where the exchange's time goes (HIP events on member 0's exchange stream, every 4th step),
     # what RCCL says its communicator's size is, the members' scan times, and the step's form
@@ -108,6 +110,7 @@ def test_launcher_mode_one_rank(exchange, extra):
                "--other-reps", "2", "--exchange", exchange, *extra])
     assert out["parity_ok"] and out["n_gpus"] == 1 and out["scaling"] == "strong"
     assert out["n1_same_process"]["value"] > 0 and out["efficiency_vs_n1"] > 0
+    assert out["n1_same_process"]["pipelined"]["parity_ok"] and out["efficiency_vs_n1_pipelined"] > 0
     oc = out["other_configs"]  # configs 4 and 5 through the same exchange; config 3 needs none
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True
     assert oc["parity_ok"] is True, oc
