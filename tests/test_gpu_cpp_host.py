@@ -73,6 +73,27 @@ def test_c_example_of_the_partitioned_sums_with_bounded_waits(tmp_path):
     assert r.stdout.strip().splitlines()[-1].startswith("ok: 6 steps"), r.stdout
 
 
+@pytest.mark.gpu
+def test_c_example_of_the_hot_loop_of_sums_on_one_stream_and_on_two_scan_lanes(tmp_path):
+    """examples/hot_loop_sums.c: the reference's hot loop (one sum call per pass over the same arrays) from a C99 host — every
+    pass one fused launch on the context's stream, then the same passes through ma_scan_lanes_*; every pass's record against the
+    closed forms."""
+    exe = _build_example(tmp_path, "hot_loop_sums")
+    r = subprocess.run([str(exe), str((1 << 22) + 77), "40"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("ok: 40 passes"), r.stdout
+
+
+def test_c_hot_loop_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    from minarrow_amd import ffi
+
+    exe = _build_example(tmp_path, "hot_loop_sums")
+    if ffi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device is visible" in r.stdout
+
+
 def test_c_partitioned_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
     from minarrow_amd import ffi
 
