@@ -644,7 +644,8 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
         # ... and the same job on this one GPU as a PIPELINE of fused steps (what every GPU of the N > 1 modes runs with two scan
         # lanes): the like-for-like denominator of a run whose steps are pipelined
         piped = {}
-        _pipelined_leg(ctx, col_i, col_f, total_rows, steps, warmup, piped)
+        if not _counters_serialise_dispatches():
+            _pipelined_leg(ctx, col_i, col_f, total_rows, steps, warmup, piped)
         line["n1_same_process"]["pipelined"] = piped.get("pipelined")
         pv = (piped.get("pipelined") or {}).get("value")
         line["efficiency_vs_n1_pipelined"] = line["value"] / (line["n_gpus"] * pv) if pv else None
@@ -1405,6 +1406,14 @@ def _profiler_attached():
         return False
 
 
+def _counters_serialise_dispatches():
+    """A profiler that collects hardware counters (rocprofv3 --pmc / -i) lets ONE kernel run at a time, whatever stream it is on.
+    hipStreamWaitValue64 on a device word is a kernel that polls the word: a scan gated on ANOTHER stream's early stamp can then be
+    let in ahead of the scan that stores the stamp — and polls for good. Nothing that waits across streams runs under counters."""
+    return bool(os.environ.get("ROCPROF_COUNTER_COLLECTION") or os.environ.get("ROCPROF_COUNTERS") or
+                os.environ.get("ROCPROF_COUNTER_GROUPS") or os.environ.get("ROCPROFILER_PC_SAMPLING_BETA_ENABLED"))
+
+
 def _torch_hosted_leg(args):
     """The same headline hosted by PyTorch (torch imported first: its bundled HIP runtime, torch tensors, torch's stream —
     what rounds 1-3 reported), in a child process, as a labelled extra key next to the product's own figure."""
@@ -1847,7 +1856,11 @@ def run_native(args, result_fd) -> int:
         if (scaling == "strong" and world > 1) or args.force_dist:
             _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
     if rank == 0 and not distributed and not args.no_pipelined_leg:
-        _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
+        if _counters_serialise_dispatches():
+            out["pipelined"] = {"skipped": "a profiler is collecting hardware counters: it lets one kernel run at a time, and a scan "
+                                           "gated on another stream's early stamp cannot run serialised"}
+        else:
+            _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
     for b in (col_i, col_f):
         b.free()
     if distributed and not args.no_other_configs:

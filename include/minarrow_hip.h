@@ -435,7 +435,11 @@ int32_t ma_stamp_is_signal(const uint64_t* stamp);
  *                            anything else on `ctx` that reads the scans' results or overwrites their columns.
  *   ma_scan_lanes_synchronize  waits for both lanes; a latched device condition of either comes back as its status.
  * MA_ERR_UNSUPPORTED from _create on a runtime without stream memory operations (hipStreamWaitValue64). One pipeline per context
- * at a time; destroy it before the context. */
+ * at a time; destroy it before the context. NOT under a profiler that collects hardware counters (rocprofv3 --pmc): it lets one
+ * kernel run at a time whatever its stream, the wait on a device word is itself a kernel that polls, and a scan gated on the other
+ * stream's early stamp can be let in ahead of the scan that stores it — the same holds for ma_ctx_wait_value, for the stamp
+ * hand-off of the overlapped exchanges and for MA_GROUP_SCAN_LANES (whose waits at least are bounded: ma_group_synchronize_for).
+ * Kernel tracing (--kernel-trace) does not serialise and is fine (profiles/r05_lanes_kernel_trace.txt). */
 typedef struct ma_scan_lanes ma_scan_lanes;
 ma_status ma_scan_lanes_create(ma_ctx* ctx, ma_scan_lanes** out_lanes);
 ma_status ma_scan_lanes_sum_fused(ma_scan_lanes* lanes, size_t n_cols, const ma_fused_column* cols);
