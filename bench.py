@@ -494,13 +494,13 @@ class _Deadline:
     fault), the headline line must still reach the driver: after `seconds` the line is printed without them and the
     process ends with the headline's own exit code."""
 
-    def __init__(self, seconds, result_fd, out, rc):
+    def __init__(self, seconds, result_fd, out, rc, key="other_configs", what="the multi-GPU configs 3-5 leg"):
         import threading
 
         def fire():
             if out is not None:
                 late = dict(out)
-                late["other_configs"] = {"error": f"the multi-GPU configs 3-5 leg did not finish within {seconds:.0f} s"}
+                late[key] = {"error": f"{what} did not finish within {seconds:.0f} s"}
                 _emit(result_fd, late)
             os._exit(rc)
 
@@ -1859,8 +1859,11 @@ def run_native(args, result_fd) -> int:
         if _counters_serialise_dispatches():
             out["pipelined"] = {"skipped": "a profiler is collecting hardware counters: it lets one kernel run at a time, and a scan "
                                            "gated on another stream's early stamp cannot run serialised"}
-        else:
+        else:  # a wait across streams that never ends must not cost the headline: past the deadline the line goes out without the leg
+            leg_guard = _Deadline(30.0 + (args.steps + args.warmup) * rows * 16 / 1e12, result_fd, out, 0 if ok else 1, "pipelined",
+                                  "the pipelined leg (ma_scan_lanes_*)")
             _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
+            leg_guard.cancel()
     for b in (col_i, col_f):
         b.free()
     if distributed and not args.no_other_configs:
