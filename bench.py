@@ -610,7 +610,7 @@ def _result_line(args, world, scaling, total_rows, rows_gpu0, elapsed, kernels, 
     }
 
 
-def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
+def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict, result_fd=None, rc: int = 0):
     """The whole `total_rows`-row job on ONE GPU inside the same process, after the timed region (strong scaling at N > 1):
     the columns are generated on this context's device, the same step (i64 scan + f64 scan + record fold) is timed over
     the same number of steps with the wall clock, and the line gets `n1_same_process` + `efficiency_vs_n1` =
@@ -645,7 +645,12 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict):
         # lanes): the like-for-like denominator of a run whose steps are pipelined
         piped = {}
         if not _counters_serialise_dispatches():
+            # a wait across streams that never ends must not cost the line: past the deadline it goes out without this key
+            leg_guard = _Deadline(30.0 + (steps + warmup) * total_rows * 16 / 1e12, result_fd, line, rc, "efficiency_vs_n1_pipelined",
+                                  "the pipelined one-GPU leg (ma_scan_lanes_*)") if result_fd is not None else None
             _pipelined_leg(ctx, col_i, col_f, total_rows, steps, warmup, piped)
+            if leg_guard is not None:
+                leg_guard.cancel()
         line["n1_same_process"]["pipelined"] = piped.get("pipelined")
         pv = (piped.get("pipelined") or {}).get("value")
         line["efficiency_vs_n1_pipelined"] = line["value"] / (line["n_gpus"] * pv) if pv else None
@@ -1195,7 +1200,7 @@ def run_group(args, result_fd) -> int:
     for b in cols_i + cols_f:
         b.free()
     if (scaling == "strong" and world > 1) or args.force_group:
-        _n1_same_process(c0, total_rows, args.steps, args.warmup, out)
+        _n1_same_process(c0, total_rows, args.steps, args.warmup, out, result_fd, rc)
     if not args.no_other_configs:
         guard2 = _Deadline(args.other_seconds, result_fd, out, rc)
         try:
@@ -1854,7 +1859,7 @@ def run_native(args, result_fd) -> int:
                             "scan_ms_per_step_min_over_ranks": min(scans), "scan_ms_per_step_max_over_ranks": max(scans),
                             "scan_ms_is_span_of_overlapping_scans": bool(S.lanes)})
         if (scaling == "strong" and world > 1) or args.force_dist:
-            _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
+            _n1_same_process(ctx, total_rows, args.steps, args.warmup, out, result_fd, rc)
     if rank == 0 and not distributed and not args.no_pipelined_leg:
         if _counters_serialise_dispatches():
             out["pipelined"] = {"skipped": "a profiler is collecting hardware counters: it lets one kernel run at a time, and a scan "
