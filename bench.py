@@ -1865,8 +1865,8 @@ def run_native(args, result_fd) -> int:
             out["pipelined"] = {"skipped": "a profiler is collecting hardware counters: it lets one kernel run at a time, and a scan "
                                            "gated on another stream's early stamp cannot run serialised"}
         else:  # a wait across streams that never ends must not cost the headline: past the deadline the line goes out without the leg
-            leg_guard = _Deadline(30.0 + (args.steps + args.warmup) * rows * 16 / 1e12, result_fd, out, 0 if ok else 1, "pipelined",
-                                  "the pipelined leg (ma_scan_lanes_*)")
+            leg_guard = _Deadline(args.pipelined_seconds + (args.steps + args.warmup) * rows * 16 / 1e12, result_fd, out, 0 if ok else 1,
+                                  "pipelined", "the pipelined leg (ma_scan_lanes_*)")
             _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
             leg_guard.cancel()
     for b in (col_i, col_f):
@@ -2293,6 +2293,8 @@ def main() -> int:
     ap.add_argument("--torch-hosted", action="store_true",
                     help="host the run in PyTorch as rounds 1-3 did: torch imported first (its bundled HIP runtime), columns in "
                          "torch tensors, the library on torch's stream, torch.distributed's RCCL group for barriers")
+    ap.add_argument("--pipelined-seconds", type=float, default=30.0,
+                    help="N = 1: the deadline of the `pipelined` leg; past it the line is printed without the leg and the process ends")
     ap.add_argument("--no-pipelined-leg", action="store_true",
                     help="N = 1: skip the labelled `pipelined` key (the same job as a pipeline of fused steps through ma_scan_lanes_*)")
     ap.add_argument("--no-torch-hosted-leg", action="store_true",
