@@ -210,6 +210,8 @@ class Context:
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self) -> None:
         if self.handle:
+            for lanes in list(getattr(self, "_scan_lanes", ())):  # a pipeline goes before the context it borrows
+                lanes.close()
             for buf in list(getattr(self, "_buffers", ())):  # device blocks that outlived their users
                 buf.free()
             self.lib.ma_ctx_destroy(self.handle)
@@ -738,6 +740,9 @@ class ScanLanes:
         h = C.c_void_p()
         ffi.check(self.lib.ma_scan_lanes_create(ctx.handle, C.byref(h)))
         self.handle = h.value
+        if not hasattr(ctx, "_scan_lanes"):
+            ctx._scan_lanes = []
+        ctx._scan_lanes.append(self)
 
     def prepare_sum_fused(self, columns):
         """A zero-argument callable that enqueues one fused scan of `columns` ((format, data, n, out[, mask, bit offset[,
@@ -776,6 +781,8 @@ class ScanLanes:
         if self.handle:
             self.lib.ma_scan_lanes_destroy(self.handle)
             self.handle = None
+            if self in getattr(self.ctx, "_scan_lanes", ()):
+                self.ctx._scan_lanes.remove(self)
 
     def __enter__(self):
         return self
