@@ -2,7 +2,8 @@
 pipeline (ma_scan_lanes_*: consecutive scans on two streams, each started by the early stamp of the one before). Four distinct
 column pairs in turn (nothing is served from a cache that a stepping host would not have), 5 x `reps` scans each way, the
 fastest batch counts (the slowest is printed too); wall time per scan and TB/s of the 16 bytes per row pair. MA_BENCH_VARIANT=<int>: the context's variant
-word (bits 19-21 = early_mode + 1: when the early stamp is stored, ma_reduce_fused.hip).
+word (bits 19-21 = early_mode + 1: when the early stamp is stored, ma_reduce_fused.hip). MA_BENCH_SINGLE=1: ONE i64 column per
+scan (8 bytes per row) instead of the i64 + f64 pair.
 -> profiles/r05_scan_lanes_api.jsonl"""
 import json
 import os
@@ -21,6 +22,8 @@ def main():
     with Context(0) as ctx:
         ctx.set_async(True)
         variant = int(os.environ.get("MA_BENCH_VARIANT", "0"))
+        single = os.environ.get("MA_BENCH_SINGLE", "") not in ("", "0")
+        row_bytes = 8 if single else 16
         ctx.set_variant(variant)
         for rows in sizes:
             pairs = []
@@ -30,12 +33,14 @@ def main():
                 ctx.synth_iota("f64", cf, rows, k * rows)
                 pairs.append((ci, cf))
             rec = ctx.alloc(64 * 4)
-            reps = max(40, min(400, int(2e9 / rows)))
-            plain = [ctx.prepare_sum_fused([("l", ci, rows, rec.ptr + 64 * k), ("g", cf, rows, rec.ptr + 64 * k + 16)])
-                     for k, (ci, cf) in enumerate(pairs)]
+            reps = max(40, min(400, int(2e9 / rows)))  # (per scan: rows x 8 or 16 bytes)
+            def table(k, ci, cf):
+                cols = [("l", ci, rows, rec.ptr + 64 * k), ("g", cf, rows, rec.ptr + 64 * k + 16)]
+                return cols[:1] if single else cols
+
+            plain = [ctx.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
             with ScanLanes(ctx) as lanes:
-                piped = [lanes.prepare_sum_fused([("l", ci, rows, rec.ptr + 64 * k), ("g", cf, rows, rec.ptr + 64 * k + 16)])
-                         for k, (ci, cf) in enumerate(pairs)]
+                piped = [lanes.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
                 best = {"one_stream": float("inf"), "scan_lanes": float("inf")}
                 worst = {"one_stream": 0.0, "scan_lanes": 0.0}
                 for _ in range(5):
@@ -51,10 +56,10 @@ def main():
                         worst[name] = max(worst[name], (time.perf_counter() - t0) / reps)
                 want = [(k * rows * rows + rows * (rows - 1) // 2) & ((1 << 64) - 1) for k in range(4)]
                 got = [int(rec.download(np.uint64, 1, 64 * k)[0]) for k in range(4)]
-            print(json.dumps({"rows_per_column": rows, "variant": variant, "scans": reps, "parity": got == want,
+            print(json.dumps({"rows_per_column": rows, "columns_per_scan": 1 if single else 2, "variant": variant, "scans": reps, "parity": got == want,
                               "one_stream_us": round(best["one_stream"] * 1e6, 2), "scan_lanes_us": round(best["scan_lanes"] * 1e6, 2),
-                              "one_stream_tbps": round(rows * 16 / best["one_stream"] / 1e12, 3),
-                              "scan_lanes_tbps": round(rows * 16 / best["scan_lanes"] / 1e12, 3),
+                              "one_stream_tbps": round(rows * row_bytes / best["one_stream"] / 1e12, 3),
+                              "scan_lanes_tbps": round(rows * row_bytes / best["scan_lanes"] / 1e12, 3),
                               "ratio": round(best["scan_lanes"] / best["one_stream"], 4),
                               "slowest_batch_us": [round(worst["one_stream"] * 1e6, 2), round(worst["scan_lanes"] * 1e6, 2)]}), flush=True)
             for ci, cf in pairs:
