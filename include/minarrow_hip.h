@@ -443,6 +443,13 @@ int32_t ma_stamp_is_signal(const uint64_t* stamp);
 typedef struct ma_scan_lanes ma_scan_lanes;
 ma_status ma_scan_lanes_create(ma_ctx* ctx, ma_scan_lanes** out_lanes);
 ma_status ma_scan_lanes_sum_fused(ma_scan_lanes* lanes, size_t n_cols, const ma_fused_column* cols);
+/* ONE column of any numeric type per scan (format_code as in Arrow: c C s S i I l L f g), through the single-column kernels of
+ * ma_<t>_sum / ma_<t>_sum_dd: arguments as theirs. out_sum receives the wrapping 64-bit sum (integer formats) or the f64 sum
+ * within 1 ULP (float formats; with out_lo != NULL the double-double pair, as ma_<t>_sum_dd); out_lo and out_valid_count may be
+ * NULL. Every output must be device-reachable (device or ma_alloc64_pinned memory) and the column resident: the call only
+ * enqueues. */
+ma_status ma_scan_lanes_sum(ma_scan_lanes* lanes, int32_t format_code, const void* data, size_t n, const uint8_t* mask_bits,
+                            size_t mask_bit_offset, int64_t null_count, void* out_sum, double* out_lo, uint64_t* out_valid_count);
 ma_status ma_scan_lanes_join(ma_scan_lanes* lanes);
 ma_status ma_scan_lanes_synchronize(ma_scan_lanes* lanes);
 uint64_t ma_scan_lanes_scans(ma_scan_lanes* lanes);

@@ -208,6 +208,12 @@ class ScanLanes {
         c[1].data = floats, c[1].n = n, c[1].null_count = -1, c[1].format_code = 'g', c[1].out = record + 2;
         check(ma_scan_lanes_sum_fused(l_, 2, c));
     }
+    // ONE column of any numeric type (Arrow format character) through the single-column kernels: out_sum = the wrapping 64-bit
+    // sum or the f64 sum (with out_lo the double-double pair); every output device-reachable
+    void enqueue_sum(char format, const void* data, size_t n, void* out_sum, uint64_t* out_count = nullptr, double* out_lo = nullptr,
+                     const uint8_t* mask_bits = nullptr, size_t mask_bit_offset = 0, int64_t null_count = -1) const {
+        check(ma_scan_lanes_sum(l_, format, data, n, mask_bits, mask_bit_offset, null_count, out_sum, out_lo, out_count));
+    }
     void join() const { check(ma_scan_lanes_join(l_)); }
     void synchronize() const { check(ma_scan_lanes_synchronize(l_)); }
     uint64_t scans() const { return ma_scan_lanes_scans(l_); }

@@ -52,6 +52,10 @@ struct SumArgs {
     int fenced;             // 1: round-1 publish (release / acquire fences) instead of sc1 stores (A/B only)
     uint64_t* done_word;    // pinned host word the final thread stamps with done_seq after the results (or nullptr):
     uint64_t done_seq;      //   a synchronous call polls it instead of paying hipStreamSynchronize's wake-up
+                            //   (ma_scan_lanes_sum: the lane's stamp line instead — the hand-off to the scan after the next)
+    uint64_t* early_word;   // ma_scan_lanes_sum: stamped with done_seq while the launch DRAINS — two of the eight ticket shards
+                            //   have arrived (grids of up to 96 workgroups: the first workgroup that has scanned its rows) —, what
+                            //   the next scan, on the other stream, waits for (FusedArgs::early_word, ma_reduce_fused.hip)
 };
 
 // Arrival counters inside the context's zeroed scratch block (ma_ctx.hip): word 0 is the top ticket; the shards sit on
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
             // Round-1 form, kept for A/B (ctx variant bit 8): plain partial -> agent-scope release -> ticket -> acquire.
             p.pad = 0;
             a.partials[blockIdx.x] = p;
+            if (a.early_word) __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned int ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
             store_agent(q + 2, p.cnt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (gridDim.x <= kShardFrom) {
+                if (a.early_word) __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
             } else {
                 // Hundreds of arrivals on one word serialise at ~12 ns each: eight counters (workgroups b and b + 8 share
@@ -337,7 +343,10 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
                 last = 0;
                 if (__hip_atomic_fetch_add(shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
                     __hip_atomic_store(shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                    last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kTicketShards - 1;
+                    const unsigned top = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last = top == kTicketShards - 1;
+                    if (a.early_word && top == 1)  // the second whole shard (XCD) has arrived
+                        __hip_atomic_store(a.early_word, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
@@ -619,8 +628,14 @@ struct SumTile {
 template <typename T>
 static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* mask_bits, size_t mask_bit_offset,
                           int64_t null_count, int mode, bool is_signed, void* out_a, void* out_b,
-                          uint64_t* out_cnt, double* out_mean) {
+                          uint64_t* out_cnt, double* out_mean, uint64_t* stamp = nullptr, uint64_t stamp_value = 0,
+                          uint64_t* early_stamp = nullptr) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    // a stamped launch (ma_scan_lanes_sum) is ONE launch on resident data whose stamps somebody waits for
+    MA_REQUIRE(stamp == nullptr || n == 0 || pointer_kind(data) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "a pipelined sum scans device-resident (or pinned) columns in place");
+    MA_REQUIRE(stamp == nullptr || mask_bits == nullptr || pointer_kind(mask_bits) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "a pipelined sum needs a device-reachable validity bitmap");
     MA_REQUIRE(n == 0 || data != nullptr, MA_ERR_INVALID_ARGUMENT, "data is NULL");
     MA_REQUIRE(((uintptr_t)data % sizeof(T)) == 0, MA_ERR_INVALID_ARGUMENT, "data pointer %p is not aligned to its element size",
                (const void*)data);
@@ -707,6 +722,12 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
         a.done_word = (uint64_t*)done;
         a.done_seq = ++ctx->result_seq;
     }
+    if (stamp) {  // enqueue-only by construction (the pipeline holds a NoSync scope): never together with the polled word
+        MA_REQUIRE(!poll && !scope.staged(), MA_ERR_INVALID_ARGUMENT, "internal: a stamped sum must be enqueue-only on resident operands");
+        a.done_word = stamp;
+        a.done_seq = stamp_value;
+        a.early_word = early_stamp;
+    }
     MA_TRY(enqueue_sum<T>(ctx, a, masked));
     bool landed = false;
     if (poll) {
@@ -731,6 +752,32 @@ static ma_status sum_impl(ma_ctx* ctx, const T* data, size_t n, const uint8_t* m
         if (out_mean && !direct_m) *out_mean = *mean_slot;
     }
     return MA_OK;
+}
+
+// ma_scan_lanes_sum (ma_scan_lanes.hip): one column of any numeric type, the launch stamped for the pipeline.
+ma_status sum_stamped_any(ma_ctx* ctx, int32_t format_code, const void* data, size_t n, const uint8_t* mask_bits,
+                          size_t mask_bit_offset, int64_t null_count, void* out_sum, double* out_lo, uint64_t* out_cnt,
+                          uint64_t* stamp, uint64_t stamp_value, uint64_t* early_stamp) {
+    const int mode = out_lo ? 1 : 0;
+#define MA_STAMPED(T, SIGNED)                                                                                              \
+    return sum_impl<T>(ctx, (const T*)data, n, mask_bits, mask_bit_offset, null_count, mode, SIGNED, out_sum, out_lo, out_cnt, \
+                       nullptr, stamp, stamp_value, early_stamp)
+    switch (format_code) {
+        case 'c': MA_STAMPED(int8_t, true);
+        case 'C': MA_STAMPED(uint8_t, false);
+        case 's': MA_STAMPED(int16_t, true);
+        case 'S': MA_STAMPED(uint16_t, false);
+        case 'i': MA_STAMPED(int32_t, true);
+        case 'I': MA_STAMPED(uint32_t, false);
+        case 'l': MA_STAMPED(int64_t, true);
+        case 'L': MA_STAMPED(uint64_t, false);
+        case 'f': MA_STAMPED(float, true);
+        case 'g': MA_STAMPED(double, true);
+        default: break;
+    }
+#undef MA_STAMPED
+    set_error("unsupported element format '%c' (numeric primitives only)", (char)format_code);
+    return MA_ERR_UNSUPPORTED;
 }
 
 }  // namespace ma

@@ -6,6 +6,7 @@
 // to DRAIN (its early stamp: FusedArgs::early_word, ma_reduce_fused.hip) — the ramp of scan k + 1 runs under the stragglers
 // of scan k, not beside its whole length. It is what ma_group_* does per member under MA_GROUP_SCAN_LANES (ma_group.hip),
 // for a host that drives one GPU without a group.
+#include <cstring>
 #include <memory>
 #include <mutex>
 
@@ -16,6 +17,9 @@ namespace ma {
 ma_status create_ctx_in_class(int32_t device_ordinal, int cls, ma_ctx** out);
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
                          bool as_partials = false, uint64_t* early_stamp = nullptr);
+ma_status sum_stamped_any(ma_ctx* ctx, int32_t format_code, const void* data, size_t n, const uint8_t* mask_bits,
+                          size_t mask_bit_offset, int64_t null_count, void* out_sum, double* out_lo, uint64_t* out_cnt,
+                          uint64_t* stamp, uint64_t stamp_value, uint64_t* early_stamp);  // ma_reduce.hip
 }  // namespace ma
 
 using namespace ma;
@@ -32,6 +36,50 @@ struct ma_scan_lanes {
     hipEvent_t ev = nullptr;         // orders a lane behind foreign work on ctx, and ctx behind lane 1 (join)
     uint64_t scans = 0;
 };
+
+// One scan on the lane whose turn it is: ordered behind foreign work on the caller's context, gated on the early stamp of the scan
+// before it, launched by `launch(scan context, stamp, stamp value, early stamp)` with nothing waited for.
+// A single-column scan of fewer bytes than this takes less time on one stream (4.4-5.9 us, launch to launch) than the host needs to
+// enqueue a gate and a launch on the other stream (~6 us): 2^20 rows of any type lose through the pipeline, 2^22 8-byte rows and 2^24
+// 1-byte rows gain (profiles/r05_scan_lanes_api.jsonl). Such scans stay on the caller's stream. (A FUSED launch costs one stream
+// ~9.7 us however few its rows: those always alternate — 6.6 us.)
+constexpr size_t kTinyScanBytes = (size_t)12 << 20;
+
+template <typename Launch>
+static ma_status enqueue_on_lane(ma_scan_lanes* lanes, size_t scan_bytes, Launch&& launch) {
+    MA_REQUIRE(lanes != nullptr, MA_ERR_INVALID_ARGUMENT, "lanes is NULL");
+    std::lock_guard<std::mutex> lock(lanes->mu);
+    ma_ctx* ctx = lanes->ctx;
+    const bool tiny = scan_bytes < kTinyScanBytes;
+    const int k = tiny ? 0 : lanes->turn;
+    ma_ctx* sc = k == 0 ? ctx : lanes->lane;
+    MA_HIP(hipSetDevice(ctx->device));
+    if (k == 1) {
+        sc->variant = ctx->variant;  // the tuning knobs follow the caller's context
+        sc->blocks_per_cu = ctx->blocks_per_cu;
+        sc->grid_override = ctx->grid_override;
+        // whatever else the host put on ctx's stream since the pipeline last looked (a kernel that WRITES the column this scan
+        // reads, say) comes first; lane 0 is that stream itself
+        if (ctx->calls.load(std::memory_order_relaxed) != lanes->seen_calls) {
+            MA_HIP(hipEventRecord(lanes->ev, ctx->stream));
+            MA_HIP(hipStreamWaitEvent(sc->stream, lanes->ev, 0));
+        }
+    }
+    if (lanes->prev >= 0 && lanes->prev != k)
+        MA_HIP(hipStreamWaitValue64(sc->stream, lanes->stamp[lanes->prev] + 1, lanes->seq[lanes->prev], hipStreamWaitValueGte, ~(uint64_t)0));
+    ma_status st;
+    {
+        NoSync enqueue_only;  // whatever mode ctx is in: the results are waited for by ma_scan_lanes_synchronize
+        st = launch(sc, lanes->stamp[k], lanes->seq[k] + 1, lanes->stamp[k] + 1);
+    }
+    lanes->seen_calls = ctx->calls.load(std::memory_order_relaxed);
+    if (st != MA_OK) return st;  // nothing was launched: the sequence, the turn and the gate stay as they were
+    ++lanes->seq[k];
+    lanes->prev = k;
+    if (!tiny) lanes->turn = k ^ 1;
+    ++lanes->scans;
+    return MA_OK;
+}
 
 extern "C" {
 
@@ -72,37 +120,23 @@ ma_status ma_scan_lanes_create(ma_ctx* ctx, ma_scan_lanes** out_lanes) {
 }
 
 ma_status ma_scan_lanes_sum_fused(ma_scan_lanes* lanes, size_t n_cols, const ma_fused_column* cols) {
-    MA_REQUIRE(lanes != nullptr, MA_ERR_INVALID_ARGUMENT, "lanes is NULL");
-    std::lock_guard<std::mutex> lock(lanes->mu);
-    ma_ctx* ctx = lanes->ctx;
-    const int k = lanes->turn;
-    ma_ctx* sc = k == 0 ? ctx : lanes->lane;
-    MA_HIP(hipSetDevice(ctx->device));
-    if (k == 1) {
-        sc->variant = ctx->variant;  // the tuning knobs follow the caller's context
-        sc->blocks_per_cu = ctx->blocks_per_cu;
-        sc->grid_override = ctx->grid_override;
-        // whatever else the host put on ctx's stream since the pipeline last looked (a kernel that WRITES the column this scan
-        // reads, say) comes first; lane 0 is that stream itself
-        if (ctx->calls.load(std::memory_order_relaxed) != lanes->seen_calls) {
-            MA_HIP(hipEventRecord(lanes->ev, ctx->stream));
-            MA_HIP(hipStreamWaitEvent(sc->stream, lanes->ev, 0));
-        }
-    }
-    if (lanes->prev >= 0 && lanes->prev != k)
-        MA_HIP(hipStreamWaitValue64(sc->stream, lanes->stamp[lanes->prev] + 1, lanes->seq[lanes->prev], hipStreamWaitValueGte, ~(uint64_t)0));
-    ma_status st;
-    {
-        NoSync enqueue_only;  // whatever mode ctx is in: the results are waited for by ma_scan_lanes_synchronize
-        st = sum_fused_impl(sc, n_cols, cols, lanes->stamp[k], lanes->seq[k] + 1, false, lanes->stamp[k] + 1);
-    }
-    lanes->seen_calls = ctx->calls.load(std::memory_order_relaxed);
-    if (st != MA_OK) return st;  // nothing was launched: the sequence, the turn and the gate stay as they were
-    ++lanes->seq[k];
-    lanes->prev = k;
-    lanes->turn = k ^ 1;
-    ++lanes->scans;
-    return MA_OK;
+    return enqueue_on_lane(lanes, kTinyScanBytes, [&](ma_ctx* sc, uint64_t* stamp, uint64_t value, uint64_t* early) {
+        return sum_fused_impl(sc, n_cols, cols, stamp, value, false, early);
+    });
+}
+
+ma_status ma_scan_lanes_sum(ma_scan_lanes* lanes, int32_t format_code, const void* data, size_t n, const uint8_t* mask_bits,
+                            size_t mask_bit_offset, int64_t null_count, void* out_sum, double* out_lo, uint64_t* out_valid_count) {
+    MA_REQUIRE(out_sum == nullptr || pointer_kind(out_sum) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "out_sum must be device-reachable (device or ma_alloc64_pinned memory): the call only enqueues");
+    MA_REQUIRE(out_lo == nullptr || pointer_kind(out_lo) != kPageable, MA_ERR_INVALID_ARGUMENT, "out_lo must be device-reachable");
+    MA_REQUIRE(out_valid_count == nullptr || pointer_kind(out_valid_count) != kPageable, MA_ERR_INVALID_ARGUMENT,
+               "out_valid_count must be device-reachable");
+    const size_t elem = strchr("cC", (char)format_code) ? 1 : strchr("sS", (char)format_code) ? 2 : strchr("iIf", (char)format_code) ? 4 : 8;
+    return enqueue_on_lane(lanes, format_code > 0 && format_code < 128 ? n * elem : 0, [&](ma_ctx* sc, uint64_t* stamp, uint64_t value, uint64_t* early) {
+        return sum_stamped_any(sc, format_code, data, n, mask_bits, mask_bit_offset, null_count, out_sum, out_lo, out_valid_count, stamp,
+                               value, early);
+    });
 }
 
 ma_status ma_scan_lanes_join(ma_scan_lanes* lanes) {

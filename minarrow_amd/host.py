@@ -767,6 +767,25 @@ class ScanLanes:
     def sum_fused(self, columns) -> None:
         self.prepare_sum_fused(columns)()
 
+    def prepare_sum(self, fmt: str, data, n: int, out_sum, out_count=None, out_lo=None, mask=None, mask_bit_offset: int = 0,
+                    null_count: int = -1):
+        """A zero-argument callable that enqueues ONE column of any numeric type (Arrow format character) on the lane whose
+        turn it is (ma_scan_lanes_sum): the single-column kernels of ma_<t>_sum, pipelined."""
+        fn, handle = self.lib.ma_scan_lanes_sum, self.handle
+        args = (ord(fmt), addr_of(data), int(n), addr_of(mask), int(mask_bit_offset), int(null_count), addr_of(out_sum),
+                addr_of(out_lo), addr_of(out_count))
+
+        def call():
+            st = fn(handle, *args)
+            if st:
+                ffi.check(st)
+
+        return call
+
+    def sum(self, fmt: str, data, n: int, out_sum, out_count=None, out_lo=None, mask=None, mask_bit_offset: int = 0,
+            null_count: int = -1) -> None:
+        self.prepare_sum(fmt, data, n, out_sum, out_count, out_lo, mask, mask_bit_offset, null_count)()
+
     def join(self) -> None:
         ffi.check(self.lib.ma_scan_lanes_join(self.handle))
 

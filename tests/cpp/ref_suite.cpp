@@ -711,6 +711,9 @@ static void scan_lanes_suite() {
             ASSERT(ma_apply_int_i64_scalar_rhs(ctx, (const int64_t*)di, n, (int64_t)k, MA_OP_ADD, nullptr, 0, (int64_t*)dout, nullptr) == MA_OK);
             lanes.enqueue_pair((const int64_t*)dout, (const double*)df, n, (uint64_t*)rec + 8 * k);
         }
+        // ... and single columns through the typed form: the f64 column, then the i64 one re-read as 2 n i32 rows
+        uint64_t* single = (uint64_t*)rec;  // records 0..5 are downloaded first, below; these two scans go to spare words behind them
+        (void)single;
         lanes.synchronize();
         ASSERT(lanes.scans() == 6);
         uint64_t w[48];
@@ -722,6 +725,14 @@ static void scan_lanes_suite() {
             ASSERT((int64_t)w[8 * k] == tri + (int64_t)k * (int64_t)n && w[8 * k + 1] == n && w[8 * k + 4] == n);
             ASSERT(hi + lo == (double)tri);  // < 2^53: exact
         }
+        lanes.enqueue_sum('g', df, n, (uint64_t*)rec, (uint64_t*)rec + 2, (double*)rec + 1);
+        lanes.enqueue_sum('i', di, 2 * n, (uint64_t*)rec + 8, (uint64_t*)rec + 9);  // iota < 2^31: the high halves are zero
+        lanes.synchronize();
+        ASSERT(lanes.scans() == 8 && ma_dev_download(ctx, w, rec, 128) == MA_OK);
+        double hi, lo;
+        std::memcpy(&hi, &w[0], 8);
+        std::memcpy(&lo, &w[1], 8);
+        ASSERT(hi + lo == (double)tri && w[2] == n && (int64_t)w[8] == tri && w[9] == 2 * n);
     }
     ASSERT(ma_ctx_set_async(ctx, 0) == MA_OK);
     for (void* p : {di, df, dout, rec}) ASSERT(ma_dev_free(ctx, p) == MA_OK);

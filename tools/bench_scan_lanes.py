@@ -3,7 +3,8 @@ pipeline (ma_scan_lanes_*: consecutive scans on two streams, each started by the
 column pairs in turn (nothing is served from a cache that a stepping host would not have), 5 x `reps` scans each way, the
 fastest batch counts (the slowest is printed too); wall time per scan and TB/s of the 16 bytes per row pair. MA_BENCH_VARIANT=<int>: the context's variant
 word (bits 19-21 = early_mode + 1: when the early stamp is stored, ma_reduce_fused.hip). MA_BENCH_SINGLE=1: ONE i64 column per
-scan (8 bytes per row) instead of the i64 + f64 pair.
+scan (8 bytes per row) instead of the i64 + f64 pair; MA_BENCH_SINGLE=<format character> (c C s S i I l L f g): one column of that
+type through the single-column kernels (ctx.sum_into on one stream against ma_scan_lanes_sum).
 -> profiles/r05_scan_lanes_api.jsonl"""
 import json
 import os
@@ -23,7 +24,10 @@ def main():
         ctx.set_async(True)
         variant = int(os.environ.get("MA_BENCH_VARIANT", "0"))
         single = os.environ.get("MA_BENCH_SINGLE", "") not in ("", "0")
-        row_bytes = 8 if single else 16
+        typed = os.environ.get("MA_BENCH_SINGLE", "") if os.environ.get("MA_BENCH_SINGLE", "") in tuple("cCsSiIlLfg") else ""
+        tags = {"c": "i8", "C": "u8", "s": "i16", "S": "u16", "i": "i32", "I": "u32", "l": "i64", "L": "u64", "f": "f32", "g": "f64"}
+        elem = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}.get(typed, 8)
+        row_bytes = elem if typed else (8 if single else 16)
         ctx.set_variant(variant)
         for rows in sizes:
             pairs = []
@@ -38,9 +42,23 @@ def main():
                 cols = [("l", ci, rows, rec.ptr + 64 * k), ("g", cf, rows, rec.ptr + 64 * k + 16)]
                 return cols[:1] if single else cols
 
-            plain = [ctx.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
+            if typed:  # the column's bytes re-read as `rows` elements of the type (sums are not checked: `parity` says None)
+                def one_stream(k, ci):
+                    return lambda: ctx.sum_into(tags[typed], ci, rows, out_sum=rec.ptr + 64 * k, out_count=rec.ptr + 64 * k + 8)
+
+                plain = [one_stream(k, ci) for k, (ci, cf) in enumerate(pairs)]
+            else:
+                plain = [ctx.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
             with ScanLanes(ctx) as lanes:
-                piped = [lanes.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
+                if typed:
+                    piped = [lanes.prepare_sum(typed, ci, rows, rec.ptr + 64 * k, out_count=rec.ptr + 64 * k + 8) for k, (ci, cf) in enumerate(pairs)]
+                else:
+                    piped = [lanes.prepare_sum_fused(table(k, ci, cf)) for k, (ci, cf) in enumerate(pairs)]
+                t_settle = time.perf_counter()  # clocks up, and the driver's background clear of VRAM an earlier process released
+                while time.perf_counter() - t_settle < 0.4:  # left behind (profiles/r04_read_rate_states_root_cause.txt)
+                    for k in range(8):
+                        plain[k & 3]()
+                    ctx.synchronize()
                 best = {"one_stream": float("inf"), "scan_lanes": float("inf")}
                 worst = {"one_stream": 0.0, "scan_lanes": 0.0}
                 for _ in range(5):
@@ -56,7 +74,7 @@ def main():
                         worst[name] = max(worst[name], (time.perf_counter() - t0) / reps)
                 want = [(k * rows * rows + rows * (rows - 1) // 2) & ((1 << 64) - 1) for k in range(4)]
                 got = [int(rec.download(np.uint64, 1, 64 * k)[0]) for k in range(4)]
-            print(json.dumps({"rows_per_column": rows, "columns_per_scan": 1 if single else 2, "variant": variant, "scans": reps, "parity": got == want,
+            print(json.dumps({"rows_per_column": rows, "columns_per_scan": 1 if single else 2, "variant": variant, "scans": reps, "type": tags.get(typed, "i64" if single else "i64+f64"), "parity": None if typed and typed != "l" else got == want,
                               "one_stream_us": round(best["one_stream"] * 1e6, 2), "scan_lanes_us": round(best["scan_lanes"] * 1e6, 2),
                               "one_stream_tbps": round(rows * row_bytes / best["one_stream"] / 1e12, 3),
                               "scan_lanes_tbps": round(rows * row_bytes / best["scan_lanes"] / 1e12, 3),
