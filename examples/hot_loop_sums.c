@@ -1,5 +1,5 @@
 /* The reference's hot loop — N passes of `sum` over the same IntegerArray<i64> and FloatArray<f64>
- * (benches/hotloop_benchmark_std.rs:109-127, benches/hotloop_benchmark_simd.rs: one call per pass, results kept) — on one GPU
+ * (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127, benches/hotloop_benchmark_simd.rs: one call per pass, results kept) — on one GPU
  * from a C99 host through the C ABI alone, two ways:
  *   1. every pass one ma_sum_fused launch on the context's stream (asynchronous context, one record per pass);
  *   2. the same launches through ma_scan_lanes_*: consecutive passes on two streams of the GPU, each started when the pass in

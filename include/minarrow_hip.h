@@ -421,7 +421,8 @@ int32_t ma_stamp_is_signal(const uint64_t* stamp);
 
 /* ---- back-to-back sums on one GPU as a pipeline ----------------------------------------------------------------------------
  * The reference's hot loop — `for _ in 0..N { sum(&arr) }` over an IntegerArray / FloatArray, one pass per call
- * (benches/hotloop_benchmark_std.rs:109-127, benches/hotloop_benchmark_simd.rs) — enqueued on ONE stream pays a launch's fixed
+ * (benches/hotloop_benchmark_avg_std.rs:48-62 and hotloop_benchmark_avg_simd.rs:34,217: ITERATIONS passes, an i64 and an f64 sum
+ * each; the pass itself: hotloop_benchmark_std.rs:109-127) — enqueued on ONE stream pays a launch's fixed
  * cost (ramp + hand-off, ~3.3 us) and the spread of the workgroups' finish times behind every scan: 2^24-row i64 + f64 steps run
  * at 0.70-0.73 of the HBM peak that way, 125 M-row steps at 0.885. A ma_scan_lanes puts consecutive ma_sum_fused scans on two
  * streams of the context's device in turn — the context's own and one it owns — and starts each when the scan in front of it has

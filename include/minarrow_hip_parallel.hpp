@@ -191,7 +191,7 @@ class Group {
 };
 
 // Back-to-back sums on ONE GPU as a pipeline (ma_scan_lanes_*): the reference's hot loop of sums
-// (benches/hotloop_benchmark_std.rs:109-127) with consecutive fused scans on two streams of the context's device, each started
+// (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127) with consecutive fused scans on two streams of the context's device, each started
 // when the one before it has begun to drain. enqueue() only enqueues, whatever mode the context is in; every scan in flight
 // writes its OWN records; join() before anything else on the context that reads them or overwrites the columns.
 class ScanLanes {

@@ -1,5 +1,5 @@
 // Back-to-back sums of mid-size columns on ONE GPU — the reference's hot loop, `for _ in 0..N { sum(&arr) }` over an
-// IntegerArray / FloatArray (benches/hotloop_benchmark_std.rs:109-127) — as a pipeline. A launch costs ~3.3 us beyond its
+// IntegerArray / FloatArray (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127) — as a pipeline. A launch costs ~3.3 us beyond its
 // bytes (ramp + hand-off) and one stream starts scan k + 1 only behind the LAST workgroup of scan k:
 // 2^24-row sums run at 0.70-0.73 of peak that way, the 125 M-row step of an 8-way partition at 0.885. ma_scan_lanes_* puts
 // consecutive fused scans on two streams of the device in turn and starts each one when the scan in front of it has begun

@@ -733,7 +733,7 @@ GROUP_FLAGS = {"host": 0, "rccl": 1, "rccl-or-host": 3, "rccl-overlap": 1 | 8, "
 class ScanLanes:
     """Back-to-back fused sums on one GPU as a pipeline (ma_scan_lanes_*): consecutive scans on two streams of the context's
     device, each started when the one before it has begun to drain — the reference's hot loop of sums
-    (benches/hotloop_benchmark_std.rs:109-127) without a launch's fixed cost between the scans."""
+    (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127) without a launch's fixed cost between the scans."""
 
     def __init__(self, ctx: "Context"):
         self.ctx, self.lib = ctx, ctx.lib

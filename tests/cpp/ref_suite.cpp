@@ -690,7 +690,7 @@ static void parallel_mirror_suite() {
     }
 }
 
-// The reference's hot loop of sums (benches/hotloop_benchmark_std.rs:109-127: one pass per call over the same arrays) as a
+// The reference's hot loop of sums (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127: one pass per call over the same arrays) as a
 // pipeline on one GPU (ma::ScanLanes over ma_scan_lanes_*): consecutive fused scans on two streams, each into its own record,
 // with a kernel of the host's own on the context in between (ordered in front of the scan that reads what it wrote).
 static void scan_lanes_suite() {

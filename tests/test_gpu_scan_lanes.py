@@ -1,6 +1,6 @@
 """GPU parity tests for ma_scan_lanes_*: back-to-back fused sums on one GPU as a pipeline — consecutive scans on two streams of
 the context's device, each started when the one before it has begun to drain. The reference's shape is its hot loop of sums
-(benches/hotloop_benchmark_std.rs:109-127: one pass per call over an IntegerArray / FloatArray); every scan's results must be
+(benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127: one pass per call over an IntegerArray / FloatArray); every scan's results must be
 the ones ma_sum_fused gives on one stream: integers and counts bit-exact, f64 within 1 ULP of the exactly rounded sum."""
 import math
 
