@@ -2,8 +2,10 @@
  * (benches/hotloop_benchmark_avg_std.rs:48-62: ITERATIONS passes, an i64 and an f64 sum each; the pass itself: hotloop_benchmark_std.rs:109-127, benches/hotloop_benchmark_simd.rs: one call per pass, results kept) — on one GPU
  * from a C99 host through the C ABI alone, two ways:
  *   1. every pass one ma_sum_fused launch on the context's stream (asynchronous context, one record per pass);
- *   2. the same launches through ma_scan_lanes_*: consecutive passes on two streams of the GPU, each started when the pass in
- *      front of it has begun to drain — no launch ramp and no spread of finish times between the passes.
+ *   2. the same launches through ma_scan_lanes_sum_fused: consecutive passes on two streams of the GPU, each started when the pass
+ *      in front of it has begun to drain — no launch ramp and no spread of finish times between the passes;
+ *   3. every pass two single-column scans (the kernels of ma_i64_sum and ma_f64_sum_dd) through ma_scan_lanes_sum — the form that
+ *      takes any numeric type.
  * Every pass's record is checked against the closed forms of the bench's own input (v[i] = i).
  * Build:  gcc -std=c99 -Iinclude examples/hot_loop_sums.c -Lminarrow_amd/lib -lminarrow_hip -Wl,-rpath,$PWD/minarrow_amd/lib
  * Run:    ./a.out [rows per column = 2^24] [passes = 64]
@@ -75,10 +77,10 @@ int main(int argc, char** argv) {
     cols[0].data = ints, cols[0].n = rows, cols[0].null_count = -1, cols[0].format_code = 'l';
     cols[1].data = floats, cols[1].n = rows, cols[1].null_count = -1, cols[1].format_code = 'g';
 
-    double ms[2] = {0, 0};
+    double ms[3] = {0, 0, 0};
     ma_scan_lanes* lanes = NULL;
     CHECK(ma_scan_lanes_create(ctx, &lanes));
-    for (int form = 0; form < 2; ++form) {
+    for (int form = 0; form < 3; ++form) {
         for (int round = 0; round < 2; ++round) { /* the first round warms the clocks up */
             CHECK(ma_dev_memset(ctx, records, 0, (size_t)passes * 64));
             CHECK(ma_ctx_synchronize(ctx));
@@ -86,22 +88,30 @@ int main(int argc, char** argv) {
             for (int k = 0; k < passes; ++k) {
                 cols[0].out = (uint64_t*)records + 8 * k;
                 cols[1].out = (uint64_t*)records + 8 * k + 2;
-                if (form == 0) CHECK(ma_sum_fused(ctx, 2, cols));
-                else CHECK(ma_scan_lanes_sum_fused(lanes, 2, cols));
+                uint64_t* rec = (uint64_t*)records + 8 * k;
+                if (form == 0) {
+                    CHECK(ma_sum_fused(ctx, 2, cols));
+                } else if (form == 1) {
+                    CHECK(ma_scan_lanes_sum_fused(lanes, 2, cols));
+                } else {
+                    CHECK(ma_scan_lanes_sum(lanes, 'l', ints, rows, NULL, 0, 0, rec, NULL, rec + 1));
+                    CHECK(ma_scan_lanes_sum(lanes, 'g', floats, rows, NULL, 0, 0, rec + 2, (double*)(rec + 3), rec + 4));
+                }
             }
             if (form == 0) CHECK(ma_ctx_synchronize(ctx));
             else CHECK(ma_scan_lanes_synchronize(lanes));
             ms[form] = (now_ms() - t0) / passes;
             if (!records_match(ctx, records, passes, rows)) {
-                fprintf(stderr, "%s: a pass's record does not match the closed forms\n", form ? "pipeline" : "one stream");
+                fprintf(stderr, "form %d: a pass's record does not match the closed forms\n", form);
                 return 1;
             }
         }
     }
     ma_scan_lanes_destroy(lanes);
     const double gb = (double)rows * 16e-9;
-    printf("ok: %d passes over 2 x %zu rows; one stream %.2f us per pass (%.2f TB/s), two scan lanes %.2f us (%.2f TB/s)\n", passes, rows,
-           ms[0] * 1e3, gb / ms[0], ms[1] * 1e3, gb / ms[1]);
+    printf("ok: %d passes over 2 x %zu rows; one stream %.2f us per pass (%.2f TB/s), two scan lanes %.2f us (%.2f TB/s), "
+           "two scan lanes with one column per scan %.2f us (%.2f TB/s)\n",
+           passes, rows, ms[0] * 1e3, gb / ms[0], ms[1] * 1e3, gb / ms[1], ms[2] * 1e3, gb / ms[2]);
     CHECK(ma_ctx_set_async(ctx, 0));
     CHECK(ma_dev_free(ctx, ints));
     CHECK(ma_dev_free(ctx, floats));
