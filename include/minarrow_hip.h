@@ -1239,7 +1239,11 @@ ma_status ma_group_sum_f64(ma_group* group, const double* const* chunk_data, con
 typedef struct ma_comm ma_comm;
 #define MA_COMM_ID_BYTES 128
 int32_t ma_rccl_version(void);
-/* Which librccl the library opened: the one beside its own HIP runtime (see ma_hip_runtime_path), or "" when none. */
+/* Which librccl the library opened: the one MINARROW_HIP_RCCL_PATH names (and no other: a path that does not open is an
+ * error), else the one beside its own HIP runtime (see ma_hip_runtime_path); "" when none. When the named library is the
+ * loopback collective double of tests/loopback_rccl (a test stand-in that lets several ranks share ONE device so that the
+ * multi-rank paths can be rehearsed on a one-GPU box) the string starts with "REHEARSAL", ma_rccl_version is 9900, and
+ * ma_group_exchange_note starts with "REHEARSAL" too: nothing measured through it is a multi-GPU figure. */
 const char* ma_rccl_path(void);
 ma_status ma_comm_unique_id(uint8_t* out_id);
 ma_status ma_comm_create(ma_ctx* ctx, const uint8_t* id, int32_t rank, int32_t n_ranks, ma_comm** out_comm);

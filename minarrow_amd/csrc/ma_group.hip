@@ -181,13 +181,13 @@ namespace grp {
 // RCCL exchange set-up. Returns MA_OK with g->use_rccl set, or a status + the thread's error string.
 ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
     const size_t n = g->ctxs.size();
-    for (size_t i = 0; i < n; ++i)
+    const RcclApi* api = rccl();
+    if (!api) return MA_ERR_UNSUPPORTED;
+    for (size_t i = 0; i < n && !api->loopback; ++i)  // the loopback double (a rehearsal on one GPU) takes ranks that share a device
         for (size_t j = i + 1; j < n; ++j)
             MA_REQUIRE(g->ctxs[i]->device != g->ctxs[j]->device, MA_ERR_UNSUPPORTED,
                        "an RCCL communicator needs distinct devices (members %zu and %zu share device %d)", i, j,
                        g->ctxs[i]->device);
-    const RcclApi* api = rccl();
-    if (!api) return MA_ERR_UNSUPPORTED;
     std::vector<int> devs(n);
     for (size_t i = 0; i < n; ++i) devs[i] = g->ctxs[i]->device;
     g->comms.assign(n, nullptr);  // non-empty from here on: release_exchange frees the RCCL-side resources
@@ -708,6 +708,14 @@ ma_status configure_exchange(ma_group* g, uint32_t flags) {
     }
     snprintf(g->note, sizeof(g->note), "%s%s%s; issue: %s%s%s", why, why[0] ? "; " : "", g->peer_note.c_str(),
              g->threads ? "one thread per member" : "calling thread", g->overlap ? "; exchange overlapped on side streams" : "", handoff);
+    if (g->use_rccl) {
+        const RcclApi* api = rccl();
+        if (api && api->loopback) {  // first in the note: nothing measured through the double is a multi-GPU figure
+            char rest[sizeof(g->note)];
+            snprintf(rest, sizeof(rest), "%s", g->note);
+            snprintf(g->note, sizeof(g->note), "REHEARSAL: collectives by the loopback double (MINARROW_HIP_RCCL_PATH), not RCCL; %s", rest);
+        }
+    }
     if (g->lanes2) strncat(g->note, "; two scan lanes per member, gated on the early stamp", sizeof(g->note) - strlen(g->note) - 1);
     else if (flags & MA_GROUP_SCAN_LANES)
         strncat(g->note, "; two scan lanes asked for but not set up (they need the overlapped RCCL exchange with stamps in device words)",

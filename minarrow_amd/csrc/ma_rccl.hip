@@ -42,17 +42,38 @@ void load_rccl() {
     }
     const char* kNames[] = {beside[0], beside[1], "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
+    // MINARROW_HIP_RCCL_PATH first, and nothing else when it is set: the host named the collective library — another RCCL
+    // build, or the loopback double of tests/loopback_rccl that rehearses the multi-rank paths on one GPU. A path that does
+    // not open is an error, not a reason to fall back silently to the system's RCCL.
+    static char named[512];
+    const char* over = getenv("MINARROW_HIP_RCCL_PATH");
+    if (over && over[0]) {
+        snprintf(named, sizeof(named), "%s", over);
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            snprintf(g_rccl_err, sizeof(g_rccl_err), "cannot open MINARROW_HIP_RCCL_PATH=%s: %s", named, dlerror());
+            return;
+        }
+        g_rccl.path = named;
+        g_rccl.named = true;
+    }
     for (const char* name : kNames) {
+        if (h) break;
         if (!name[0]) continue;
         h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (h) {
-            g_rccl.path = name;
-            break;
-        }
+        if (h) g_rccl.path = name;
     }
     if (!h) {
         snprintf(g_rccl_err, sizeof(g_rccl_err), "cannot open librccl.so.1: %s", dlerror());
         return;
+    }
+    // only the loopback double has this symbol: it, unlike a fabric, takes several ranks on one device
+    if (auto info = (const char* (*)(void))dlsym(h, "ncclLoopbackDoubleInfo")) {
+        g_rccl.loopback = true;
+        static char labelled[600];
+        snprintf(labelled, sizeof(labelled), "REHEARSAL (loopback collective double, not RCCL): %s", g_rccl.path);
+        g_rccl.path = labelled;
+        (void)info;
     }
     bool ok = true;
     auto sym = [&](const char* name) -> void* {

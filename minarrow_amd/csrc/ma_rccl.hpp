@@ -29,7 +29,9 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    const char* path = "";  // which library name resolved
+    const char* path = "";  // which library name resolved ("REHEARSAL (...): <path>" for the loopback double)
+    bool named = false;     // MINARROW_HIP_RCCL_PATH chose it
+    bool loopback = false;  // tests/loopback_rccl's stand-in (exports ncclLoopbackDoubleInfo): ranks may share a device
 };
 
 // The process-wide RCCL entry points, or nullptr (with the thread's error string set) when the library cannot be
