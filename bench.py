@@ -20,7 +20,7 @@ pairs, so the f64 result stays within 1 ULP and every rank holds bit-identical f
 
 At N = 1 the line also carries `other_configs` (BASELINE configs 3, 4, 5 at 10^9 rows: per-kernel ms / GB/s / fraction of
 peak / fraction of the same-process copy rate / parity), measured after and outside the timed headline region,
-`cpu_baseline`, and `torch_hosted` (the same headline hosted by PyTorch, in a child process).
+and `cpu_baseline`.
 
 The process is a plain host of libminarrow_hip.so (round 4): no torch on the GPU path in any launch mode — columns from
 ma_dev_alloc, the library's own stream, per-kernel durations from its timing marks (HIP events on that stream, inside the
@@ -28,7 +28,13 @@ timed region), /opt/rocm's HIP runtime (`config.hip_runtime`). Under torch.distr
 rendezvous, the barriers and the max-over-ranks on the CPU side only. At N > 1 the step is ONE fused launch per GPU
 (ma_sum_fused / ma_group_enqueue_sum_table) whose final thread stamps a word the exchange stream waits on (`--handoff`),
 and the line says where the exchange's time went (`exchange_us`, `fold_us`, `rccl_ranks` as ncclCommCount reports it,
-per-member / per-rank scan times). `--torch-hosted` = rounds 1-3's form (torch tensors and stream), kept as a labelled extra.
+per-member / per-rank scan times).
+
+REHEARSAL. With MINARROW_HIP_RCCL_PATH naming the loopback collective double (tests/loopback_rccl: RCCL's entry points with
+collective liveness semantics on ONE device) both N > 1 modes run on a one-GPU box with their ranks sharing the GPU — members
+i -> device i % visible, GPU_MAX_HW_QUEUES raised so that no two streams share a hardware queue — through the very ladder a
+multi-GPU node would take. Every such line says REHEARSAL in `config.parallelism` and `config.exchange` and carries
+`"rehearsal": true`: it checks ordering and liveness, it is never a multi-GPU figure (like `--backend gloo`).
 An un-timed settle phase runs in front of the W warm-up steps (`config.clock_ramp`: clocks, and the driver's background
 clear of VRAM the previous process released — profiles/r04_read_rate_states_root_cause.txt).
 
@@ -912,6 +918,17 @@ def _lanes_trial_once(step, drain, set_lanes, agree_max=None, batch=32, rounds=3
     return best[True], best[False]
 
 
+def _loopback_double() -> bool:
+    """True when the library's collectives are the loopback double's (MINARROW_HIP_RCCL_PATH names tests/loopback_rccl's stand-in):
+    ranks may share a GPU, and nothing measured is a multi-GPU figure."""
+    if not os.environ.get("MINARROW_HIP_RCCL_PATH"):
+        return False
+    from minarrow_amd import ffi
+
+    path = ffi.load_library().ma_rccl_path()
+    return bool(path) and path.decode().startswith("REHEARSAL")
+
+
 class _Downgrade(Exception):
     """The current exchange form cannot be trusted with the job (a deadline, wrong finals, a failed self-test): one notch down."""
 
@@ -1020,10 +1037,12 @@ def run_group(args, result_fd) -> int:
     from minarrow_amd.host import Group
 
     n_dev = ffi.device_count()
-    if n_dev < args.gpus:
+    double = _loopback_double()
+    if n_dev < args.gpus and not (double and n_dev >= 1):
         print(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible", file=sys.stderr)
         return 2
     world = args.gpus
+    devices = [i % n_dev for i in range(world)]  # one member per GPU; a rehearsal through the loopback double wraps around
     scaling, total_rows, chunks = _split(args, world)
     lens = [hi - lo for lo, hi in chunks]
     overlap = args.overlap == "on" or (args.overlap == "auto" and world > 1)
@@ -1034,7 +1053,7 @@ def run_group(args, result_fd) -> int:
     faults = _Faults(os.environ.get("MA_BENCH_FAULT"))
 
     def create(notch):
-        return Group(list(range(world)), exchange=notch["exchange"], issue=notch["issue"])
+        return Group(devices, exchange=notch["exchange"], issue=notch["issue"])
 
     group, left_behind = None, [False]  # left_behind: a helper thread is still inside a runtime call that never returned
     while group is None:
@@ -1184,9 +1203,11 @@ def run_group(args, result_fd) -> int:
              (", consecutive steps on two scan lanes gated on the early stamp" if group.scan_lanes else "") if group.overlapped else "on the scan streams")
             if group.exchange_kind == "rccl" else "host fold of pinned records")
     out = _result_line(args, world, scaling, total_rows, lens[0], elapsed, kernels, ok, finals,
-                       f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}",
-                       form + (f" [{group.exchange_note}]" if group.exchange_note else ""),
-                       {"rccl_ranks": stats["rccl_ranks"], "launch": "single process",
+                       f"row-chunk x{world}, ONE process (ma_group_*), issue: {group.issue_kind}" +
+                       (f" (REHEARSAL: {world} members share {n_dev} GPU(s))" if double else ""),
+                       ("REHEARSAL through the loopback collective double, not RCCL: " if double else "") + form +
+                       (f" [{group.exchange_note}]" if group.exchange_note else ""),
+                       {"rehearsal": bool(double), "rccl_ranks": stats["rccl_ranks"], "launch": "single process",
                         "step": "one fused launch per member (ma_group_enqueue_sum_table)" if fused else "two launches per member",
                         "host": "torch-free", "hip_runtime": _hip_runtime_path(), "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                         "exchange_form": notch["name"], "downgrades": ladder.downgrades, "attempts": attempts,
@@ -1277,7 +1298,7 @@ def ranks_other_configs(env, col_i, col_f, rows: int, reps: int):
     """The multi-GPU legs of configs 3-5 with one process per GPU: every rank scans its chunk / its batch, ONE exchange per
     step. `env` carries the run's plumbing — ctx, rank, world, make_ex(n_columns) -> records object, exchange(ex) (all-gather +
     device fold through whichever exchange the headline used), fence() (barrier + device drain), max_over_ranks(x),
-    gather(obj), alloc(bytes) — so that the torch-hosted and the torch-free run share this function."""
+    gather(obj), alloc(bytes)."""
     from minarrow_amd.parallel import fold_dd, row_chunks
 
     ctx, rank, world = env.ctx, env.rank, env.world
@@ -1419,29 +1440,6 @@ def _counters_serialise_dispatches():
                 os.environ.get("ROCPROF_COUNTER_GROUPS") or os.environ.get("ROCPROFILER_PC_SAMPLING_BETA_ENABLED"))
 
 
-def _torch_hosted_leg(args):
-    """The same headline hosted by PyTorch (torch imported first: its bundled HIP runtime, torch tensors, torch's stream —
-    what rounds 1-3 reported), in a child process, as a labelled extra key next to the product's own figure."""
-    import subprocess
-
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--torch-hosted", "--gpus", "1", "--steps", str(args.steps), "--warmup",
-           str(args.warmup), "--rows", str(args.rows), "--no-other-configs", "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.torch_hosted_seconds, cwd=str(ROOT))
-        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-        if r.returncode != 0 or not lines:
-            return {"error": f"exit code {r.returncode}: {r.stderr[-300:]}"}
-        child = json.loads(lines[-1])
-        return {"value": child["value"], "unit": child["unit"], "ms_per_step": child["ms_per_step"], "parity_ok": child["parity_ok"],
-                "roofline_frac": child["roofline"]["frac"], "roofline_kernel": child["roofline"]["kernel"],
-                "kernels": {k: {"avg_ms": v["avg_ms"], "gbps": v["gbps"]} for k, v in child["kernels"].items()},
-                "hip_runtime": child["config"].get("hip_runtime"),
-                "note": "`bench.py --torch-hosted` in a child process, started after this process had released its columns and "
-                        "paused (the driver clears released VRAM in the background: profiles/r04_read_rate_states_root_cause.txt)"}
-    except Exception as e:  # noqa: BLE001 — an extra leg must not cost the line
-        return {"error": f"{type(e).__name__}: {e}"}
-
-
 def run_native(args, result_fd) -> int:
     """The default: this process is a plain host of libminarrow_hip.so, the way a Rust binary would be — the library is loaded
     FIRST and runs on /opt/rocm's HIP runtime, columns come from ma_dev_alloc, kernels run on the context's own stream, per-kernel
@@ -1461,6 +1459,7 @@ def run_native(args, result_fd) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_dist
     rehearsal = args.backend == "gloo"
+    double = distributed and not rehearsal and _loopback_double()  # ranks share the GPU(s), the exchange is still ma_comm_*
     dist = torch = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1472,7 +1471,7 @@ def run_native(args, result_fd) -> int:
 
         dist.init_process_group("gloo")
     n_dev = ffi.device_count()
-    device_index = local_rank % max(n_dev, 1) if rehearsal else local_rank
+    device_index = local_rank % max(n_dev, 1) if (rehearsal or double) else local_rank
     ctx = Context(device_index)
     ctx.set_variant(args.variant)
     ctx.set_blocks_per_cu(args.blocks_per_cu)
@@ -1834,8 +1833,9 @@ def run_native(args, result_fd) -> int:
             parallelism = f"row-chunk x{world}, one process per rank (REHEARSAL: ranks share a GPU)"
             exch = "gloo all-gather of the records over host memory + device fold"
         else:
-            parallelism = f"row-chunk x{world}, one process per GPU"
-            exch = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
+            parallelism = f"row-chunk x{world}, one process per GPU" + (f" (REHEARSAL: {world} ranks share {n_dev} GPU(s))" if double else "")
+            exch = (("REHEARSAL through the loopback collective double, not RCCL: " if double else "") +
+                    "RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
                     ("" if overlap else ", on the scan stream")) if comm is not None else \
                 ("gloo all-gather of the records over host memory + device fold" if world > 1 else
                  "none (one rank): device fold on the scan stream")
@@ -1847,7 +1847,8 @@ def run_native(args, result_fd) -> int:
         if ladder.downgrades:
             exch += f" [after {len(ladder.downgrades)} abandoned form(s): config.downgrades]"
         out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exch,
-                           {"rccl_ranks": stats["rccl_ranks"], "launch": "torch.distributed.run" if world > 1 else "single process",
+                           {"rehearsal": bool(rehearsal or double), "rccl_ranks": stats["rccl_ranks"],
+                            "launch": "torch.distributed.run" if world > 1 else "single process",
                             "step": step_form, "host": "torch-free" if not distributed else "torch-free GPU path (gloo for rendezvous only)",
                             "clock_ramp": {"ms": ramp_spent, "steps": ramp_steps, "settled": settled},
                             "hip_runtime": _hip_runtime_path(),
@@ -1914,14 +1915,6 @@ def run_native(args, result_fd) -> int:
                 except Exception as e:  # noqa: BLE001 — the headline line must still be printed
                     out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
                     rc = 1
-            if not args.no_torch_hosted_leg and _profiler_attached():
-                out["torch_hosted"] = {"skipped": "a profiler is attached to this process: no GPU child process is started under it"}
-            elif not args.no_torch_hosted_leg:
-                ctx.set_async(False)
-                ctx.synchronize()
-                ctx.lib.ma_dev_pool_trim(ctx.handle, 0)  # the child needs the HBM; released blocks are cleared in the background:
-                time.sleep(2.5)                          # leave that behind before the child measures
-                out["torch_hosted"] = _torch_hosted_leg(args)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
         _emit(result_fd, out)
@@ -1934,299 +1927,6 @@ def run_native(args, result_fd) -> int:
         os._exit(rc)
     if comm is not None:
         comm.close()
-    ctx.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
-    return rc
-
-
-def run_ranks_torch(args, result_fd) -> int:
-    """--torch-hosted: N = 1, or one process per GPU under torch.distributed.run, with PyTorch as the host — torch imported
-    first (the library then runs on torch's bundled HIP runtime), columns in torch tensors, the library on torch's stream,
-    torch.distributed (RCCL) for the barrier. The form rounds 1-3 measured; kept as a labelled variant."""
-    import numpy as np
-    import torch  # first: the library then shares torch's HIP runtime (same SONAME)
-    import torch.distributed as dist
-
-    from minarrow_amd.host import Comm, Context
-    from minarrow_amd.parallel import ScalarExchange
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or args.force_dist
-    rehearsal = args.backend == "gloo"
-    device_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    scaling, total_rows, chunks = _split(args, world)
-    lo, hi = chunks[rank]
-    rows = hi - lo  # this rank's row chunk of each column
-    stream = torch.cuda.current_stream(dev)
-    ctx = Context(device_index, stream=stream.cuda_stream)
-    ctx.set_variant(args.variant)
-    ctx.set_blocks_per_cu(args.blocks_per_cu)
-
-    # Columns resident in HBM before anything is timed (construction excluded, as in
-    # benches/benchmark_parallel_simd.rs:103-106). Rank r owns global rows [lo, hi) of each column.
-    col_i = torch.empty(max(rows, 8), dtype=torch.int64, device=dev)
-    col_f = torch.empty(max(rows, 8), dtype=torch.float64, device=dev)
-    ctx.synth_iota("i64", col_i, rows, lo)
-    ctx.synth_iota("f64", col_f, rows, lo)
-
-    # Per-rank record the kernels write into: [0] i64 sum, [1] i64 count, [2] f64 hi bits, [3] f64 lo bits,
-    # [4] f64 count (minarrow_amd/parallel.py). Overlap: the exchange + fold of step k run on a side stream while the
-    # main stream already scans step k + 1 (two record sets in flight; a step's scans wait for the exchange that last
-    # used their record set). Default at N > 1: the partitioned column leaves each GPU 0.14 ms of scan per column, and
-    # an all-gather's latency is a fifth of that. With the native communicator the library does it itself
-    # (ma_comm_sum_exchange_overlapped: its own stream, device-scope events); with torch's exchange the side stream is the
-    # one torch.distributed's collective is issued under.
-    overlap = (args.overlap == "on") or (args.overlap == "auto" and distributed and not rehearsal and world > 1)
-    # The exchange. Native: the library's own RCCL communicator (ma_comm_*: ncclCommInitRank from an id rank 0 made and
-    # torch.distributed's store carried), ONE all-gather + the rank-ordered fold per step. When that cannot be set up
-    # on every rank (or --exchange torch) the same records go through torch.distributed's all-gather instead.
-    comm, comm_note = None, ""
-    if distributed and not rehearsal and args.exchange != "torch":
-        try:
-            ids = [Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = Comm(ctx, ids[0], rank, world)
-        except Exception as e:  # noqa: BLE001 — any failure means the torch path
-            comm, comm_note = None, f"native communicator unavailable on rank {rank}: {e}"
-        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
-            comm_note = "native communicator unavailable on another rank"
-    torch_overlap = overlap and comm is None
-    side = torch.cuda.Stream(dev) if torch_overlap else stream
-    ctx_side = Context(device_index, stream=side.cuda_stream) if torch_overlap else ctx
-    ctx_side.set_async(True)
-
-    exs = [ScalarExchange(dev) for _ in range(2 if overlap else 1)]
-    scanned = [torch.cuda.Event() for _ in exs]
-    exchanged = [torch.cuda.Event() for _ in exs]
-    in_use = [False for _ in exs]
-    ctx.set_async(True)
-    counter = [0]
-
-    def step(ev=None):
-        k = counter[0] % len(exs)
-        counter[0] += 1
-        ex = exs[k]
-        if overlap and comm is not None:
-            comm.slot_wait(k)  # the scans below overwrite record set k: behind its last exchange
-        elif overlap and in_use[k]:
-            stream.wait_event(exchanged[k])
-        if ev:
-            ev[0].record(stream)
-        ctx.sum_into("i64", col_i, rows, out_sum=ex.slot_ptr(0), out_count=ex.slot_ptr(1))
-        if ev:
-            ev[1].record(stream)
-        ctx.sum_into("f64", col_f, rows, out_sum=ex.slot_ptr(2), dd_lo=ex.slot_ptr(3), out_count=ex.slot_ptr(4))
-        if ev:
-            ev[2].record(stream)
-        if overlap and comm is not None:  # all-gather + fold on the communicator's own stream; this one goes on
-            comm.sum_exchange_overlapped(k, ex.local, 1, 1, ex.gathered, ex.final)
-            ex._folded_on_device = True
-        elif overlap:
-            scanned[k].record(stream)
-            with torch.cuda.stream(side):
-                side.wait_event(scanned[k])
-                ex.exchange()
-                ex.fold_on_device(ctx_side)
-                exchanged[k].record(side)
-            in_use[k] = True
-        elif comm is not None:
-            comm.sum_exchange(ex.local, 1, 1, ex.gathered, ex.final)
-            ex._folded_on_device = True
-        else:
-            ex.exchange()  # N > 1: one all-gather of 64 bytes per rank; N = 1: nothing to exchange
-            ex.fold_on_device(ctx)  # rank-ordered fold of the N records -> the job's final scalars, on the GPU
-
-    def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    hang_guard = None
-    if distributed:  # a collective that never completes must end the job with a reason, not with the driver's timeout
-        import threading
-
-        def hung():
-            print(f"rank {rank}: the headline's exchange did not complete within {args.headline_seconds:.0f} s "
-                  f"(exchange: {'ma_comm_*' if comm is not None else 'torch.distributed'}, overlap: {overlap}); "
-                  "try --exchange torch or --overlap off", file=sys.stderr, flush=True)
-            os._exit(3)
-
-        hang_guard = threading.Timer(args.headline_seconds, hung)
-        hang_guard.daemon = True
-        hang_guard.start()
-    step()  # set-up, never timed: first use of the communicator and of the fold kernel (also when --warmup 0)
-    fence()
-    if comm is not None:
-        # The library's communicator has only ever run with one rank before a multi-GPU node sees it: the set-up step's
-        # finals are checked on every rank, and if ANY rank's fold is wrong (or MA_BENCH_DISTRUST_NATIVE_COMM asks, for the
-        # test of this branch) all ranks drop to torch.distributed's all-gather before anything is timed.
-        good = _check(total_rows, exs[(counter[0] - 1) % len(exs)].results()) and not os.environ.get("MA_BENCH_DISTRUST_NATIVE_COMM")
-        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            comm.synchronize()
-            comm.close()
-            comm = None
-            comm_note = "the library's communicator failed the set-up check on some rank: torch.distributed's exchange instead"
-            torch_overlap = overlap
-            if torch_overlap:
-                side = torch.cuda.Stream(dev)
-                ctx_side = Context(device_index, stream=side.cuda_stream)
-                ctx_side.set_async(True)
-            for ex in exs:
-                ex._folded_on_device = False
-            for _ in exs:  # every record set once through the new exchange
-                step()
-            fence()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # Kernel durations: HIP events on the launch stream around each scan, inside the timed region. An event costs a few us of
-    # stream time; against 1.1 ms scans (10^9 rows on one GPU) every step carries them, against the 0.14 ms scans of an
-    # 8-way partition only every 4th step does (at least 3 steps) — 14 us per step would be 5 % of the step there
-    # (profiles/r03_strong_share_1gpu.json).
-    every = 1 if rows >= 250_000_000 else max(1, min(4, args.steps // 3))
-    events = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in range(0, args.steps, every)}
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events.get(k))
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.synchronize()
-    if hang_guard is not None:
-        hang_guard.cancel()
-
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    torch.cuda.synchronize(dev)
-
-    # ---- verify the job's answer (outside the timed region) ------------------------------------------
-    finals = exs[(counter[0] - 1) % len(exs)].results()  # the LAST step's finals
-    ok = _check(total_rows, finals)
-    ms_i = [e[0].elapsed_time(e[1]) for e in events.values()]
-    ms_f = [e[1].elapsed_time(e[2]) for e in events.values()]
-    kernels = {"sum_i64": {"avg_ms": sum(ms_i) / len(ms_i), "min_ms": min(ms_i), "timed_steps": len(ms_i)},
-               "sum_f64": {"avg_ms": sum(ms_f) / len(ms_f), "min_ms": min(ms_f), "timed_steps": len(ms_f)}}
-
-    rc = 0 if ok else 1
-    out = None
-    if rank == 0:
-        if not distributed:
-            parallelism, exchange = "row-chunk x1", "none (one GPU): device fold on the scan stream"
-        elif rehearsal:
-            parallelism = f"row-chunk x{world}, one process per rank (REHEARSAL: ranks share a GPU)"
-            exchange = "gloo all-gather of the records over host memory + device fold"
-        else:
-            parallelism = f"row-chunk x{world}, one process per GPU"
-            exchange = ("RCCL all-gather (ma_comm_*: ncclCommInitRank inside libminarrow_hip) + device fold" +
-                        ("" if overlap else ", on the scan stream")
-                        if comm is not None else
-                        "RCCL all-gather (torch.distributed) + device fold" + ("" if overlap else ", on the scan stream"))
-            if comm_note:
-                exchange += f" [{comm_note}]"
-        if overlap:
-            exchange += "; exchange of step k on a side stream, overlapped with the scans of step k + 1"
-        out = _result_line(args, world, scaling, total_rows, rows, elapsed, kernels, ok, finals, parallelism, exchange,
-                           {"rccl_ranks": world if (distributed and not rehearsal) else 0,
-                            "launch": "torch.distributed.run" if world > 1 else "single process",
-                            "host": "torch-hosted (torch imported first; its bundled HIP runtime)", "hip_runtime": _hip_runtime_path()})
-        if (scaling == "strong" and world > 1) or args.force_dist:
-            _n1_same_process(ctx, total_rows, args.steps, args.warmup, out)
-    if distributed and not rehearsal and not args.no_other_configs:
-        guard = _Deadline(args.other_seconds, result_fd, out, rc)  # every rank: none may outlive a hung collective
-        try:  # every rank takes part (collectives inside); rank 0 prints
-            orows = args.other_rows or args.rows  # these legs are per-GPU sized (one chunk / batch of `orows` rows per GPU)
-            del col_i, col_f
-            torch.cuda.empty_cache()
-            col_i = torch.empty(orows, dtype=torch.int64, device=dev)
-            col_f = torch.empty(orows, dtype=torch.float64, device=dev)
-            ctx.synth_iota("i64", col_i, orows, rank * orows)
-            ctx.synth_iota("f64", col_f, orows, rank * orows)
-            if comm is not None:
-                comm.synchronize()  # the other legs use the in-stream exchange: nothing of the headline's may be in flight
-            from types import SimpleNamespace
-
-            def _exchange(ex):
-                if comm is not None:
-                    comm.sum_exchange(ex.local, 1, ex.n_columns, ex.gathered, ex.final)
-                    ex._folded_on_device = True
-                else:
-                    ex.exchange()
-                    ex.fold_on_device(ctx)
-
-            def _fence():
-                dist.barrier()
-                torch.cuda.synchronize(dev)
-
-            def _max(x):
-                t = torch.tensor([x], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t.item())
-
-            def _gather(obj):
-                objs = [None] * world
-                dist.all_gather_object(objs, obj)
-                return objs
-
-            env = SimpleNamespace(ctx=ctx, rank=rank, world=world, exchange=_exchange, fence=_fence, max_over_ranks=_max,
-                                  gather=_gather, make_ex=lambda nc: ScalarExchange(dev, n_columns=nc),
-                                  alloc=lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device=dev))
-            multi = ranks_other_configs(env, col_i, col_f, orows, args.other_reps)
-            if not multi["parity_ok"]:
-                rc = 1
-        except Exception as e:  # noqa: BLE001 — the headline line must still be printed
-            multi = {"error": f"{type(e).__name__}: {e}"}
-            rc = 1
-        guard.cancel()
-        if rank == 0:
-            out["other_configs"] = multi
-    if rank == 0:
-        if world == 1 and not distributed:
-            del col_i, col_f
-            torch.cuda.empty_cache()
-            if not args.no_other_configs:
-                try:
-                    ctx.set_async(False)
-                    out["other_configs"] = gpu_other_configs(ctx, args.other_rows or args.rows, args.other_reps)
-                    parities = [v for v in _walk(out["other_configs"], "parity")]
-                    out["other_configs"]["parity_ok"] = all(parities)
-                    if not all(parities):
-                        rc = 1
-                except Exception as e:  # noqa: BLE001 — the headline line must still be printed
-                    out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
-                    rc = 1
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_rows, args.cpu_seconds)
-        _emit(result_fd, out)
-        if not ok:
-            print(f"PARITY FAILURE: {finals} over {total_rows} rows", file=sys.stderr)
-
-    if comm is not None:
-        comm.close()
-    if ctx_side is not ctx:
-        ctx_side.close()
     ctx.close()
     if distributed:
         dist.barrier()
@@ -2268,10 +1968,9 @@ def main() -> int:
                     help="N > 1: time limit of the configs 3-5 leg; past it the headline line is printed without it")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--exchange", default="native", choices=["native", "torch", "host"],
-                    help="native = RCCL inside libminarrow_hip (ma_group_* in one process, ma_comm_* under a launcher); torch = "
-                         "torch.distributed's all-gather (--torch-hosted launcher mode only); host = host fold of pinned records "
-                         "(one process) / records over host memory through gloo (launcher mode)")
+    ap.add_argument("--exchange", default="native", choices=["native", "host"],
+                    help="native = RCCL inside libminarrow_hip (ma_group_* in one process, ma_comm_* under a launcher); host = host "
+                         "fold of pinned records (one process) / records over host memory through gloo (launcher mode)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank). gloo: rehearsal only — several ranks share the visible "
                          "GPU(s) and the 64-byte records cross host memory; never a reported number")
@@ -2288,18 +1987,12 @@ def main() -> int:
                          "abandoned for the next one down (config.downgrades)")
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"], nargs="?", const="on",
                     help="run each step's scalar exchange on a side stream, overlapped with the next "
-                         "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP; torch events with --exchange torch). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
+                         "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
                          "it costs the scan more than it saves there, 876 vs 889 Grows/s)")
-    ap.add_argument("--torch-hosted", action="store_true",
-                    help="host the run in PyTorch as rounds 1-3 did: torch imported first (its bundled HIP runtime), columns in "
-                         "torch tensors, the library on torch's stream, torch.distributed's RCCL group for barriers")
     ap.add_argument("--pipelined-seconds", type=float, default=30.0,
                     help="N = 1: the deadline of the `pipelined` leg; past it the line is printed without the leg and the process ends")
     ap.add_argument("--no-pipelined-leg", action="store_true",
                     help="N = 1: skip the labelled `pipelined` key (the same job as a pipeline of fused steps through ma_scan_lanes_*)")
-    ap.add_argument("--no-torch-hosted-leg", action="store_true",
-                    help="N = 1: skip the labelled extra key `torch_hosted` (the same headline in a --torch-hosted child process)")
-    ap.add_argument("--torch-hosted-seconds", type=float, default=240.0)
     ap.add_argument("--step", default="auto", choices=["auto", "fused", "separate"],
                     help="the step's scans: separate = ma_i64_sum + ma_f64_sum_dd (two launches: per-type kernel figures; the "
                          "default at N = 1), fused = ONE ma_sum_fused launch over both columns (the default at N > 1, where a "
@@ -2343,8 +2036,6 @@ def main() -> int:
         return 2
     if (world == 1 and args.gpus > 1) or args.force_group:
         return run_group(args, result_fd)
-    if args.torch_hosted or args.exchange == "torch":
-        return run_ranks_torch(args, result_fd)
     return run_native(args, result_fd)
 
 

@@ -15,7 +15,7 @@
 
 namespace ma {
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[4096] = "";
 
 // Pinned blocks of 1 MiB and more are recycled: hipHostMalloc pins pages at a few GB/s (a 256-MiB Vec64 costs ~40 ms to
 // allocate and as much to free), which would make an allocator built on it 50x slower than malloc for exactly the
@@ -553,7 +553,7 @@ NoSync::NoSync() { ++t_nosync; }
 NoSync::~NoSync() { --t_nosync; }
 bool nosync_active() { return t_nosync > 0; }
 
-ma_status make_lane(ma_ctx* root, ma_ctx** out);  // defined with the context constructor below
+ma_status make_lane(ma_ctx* root, ma_ctx** out, int cls = 0);  // defined with the context constructor below
 
 Enter::Enter(ma_ctx*& ctx, bool primary_only) {
     if (ctx == nullptr) return;  // the entry point reports the NULL itself
@@ -913,10 +913,12 @@ ma_status create_ctx_in_class(int32_t device_ordinal, int cls, ma_ctx** out) {
     return st;
 }
 
-ma_status make_lane(ma_ctx* root, ma_ctx** out) {
+ma_status make_lane(ma_ctx* root, ma_ctx** out, int cls) {
     int prev = 0;
     (void)hipGetDevice(&prev);
+    t_stream_class = cls;
     ma_status st = ctx_create_impl(root->device, nullptr, false, out, false);  // root->device is already a HIP ordinal
+    t_stream_class = 0;
     if (st == MA_OK) {
         (*out)->parent = root;
         (*out)->ordinal = root->ordinal;

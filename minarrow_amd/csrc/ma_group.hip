@@ -165,7 +165,11 @@ void destroy_members(ma_group* g) {
     for (size_t i = 0; i < g->ctxs.size(); ++i) {
         (void)hipSetDevice(g->ctxs[i]->device);
         if (i < g->stall_word.size() && g->stall_word[i]) (void)ma_stamp_free(g->ctxs[i], g->stall_word[i]);
-        if (i < g->rescue.size() && g->rescue[i]) (void)hipStreamDestroy(g->rescue[i]);
+        if (i < g->rescue.size() && g->rescue[i]) {  // one per device, shared by that device's members
+            bool first = true;
+            for (size_t j = 0; j < i; ++j) first = first && g->rescue[j] != g->rescue[i];
+            if (first) (void)hipStreamDestroy(g->rescue[i]);
+        }
     }
     g->stall_word.clear();
     g->rescue.clear();
@@ -222,7 +226,7 @@ ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
             MA_HIP(hipMemset(g->local1[i], 0, kBlockWords * 8));
             MA_HIP(hipMemset(g->gathered1[i], 0, n * kBlockWords * 8));
             g->finals1[i] = g->host_finals + (n + i) * kColumns * 4;
-            MA_TRY(make_lane(g->ctxs[i], &g->side[i]));
+            MA_TRY(make_lane(g->ctxs[i], &g->side[i], g->carrier_class));
             for (int k = 0; k < 2; ++k) {
                 MA_HIP(hipEventCreateWithFlags(&g->ev_ready[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
                 MA_HIP(hipEventCreateWithFlags(&g->ev_done[k][i], hipEventDisableTiming | hipEventReleaseToDevice));
@@ -739,9 +743,18 @@ ma_status ma_group_create_ex(const int32_t* device_ordinals, int32_t n_members, 
     MA_REQUIRE(device_ordinals != nullptr && n_members > 0 && n_members <= 1024, MA_ERR_INVALID_ARGUMENT,
                "a group needs 1..1024 members");
     ma_group* g = new ma_group();
+    // A rehearsal (the loopback collective double stands in for RCCL and the members share a device): every stream that can
+    // carry a collective — the members' own and their exchange streams — goes into the HIGH priority class, whose pool of
+    // hardware queues those streams then have to themselves (GPU_MAX_HW_QUEUES >= members). A rank's collective kernel spins until
+    // its peers' have run, and streams that share a hardware queue run in order; everything else (second scan lanes, copy
+    // streams) may share queues, because it only ever waits for work that was enqueued before it. Few queues matter as much as
+    // distinct ones: a device runs 23 of them at a time (tests/loopback_rccl/selfcheck.cpp `slots`), one more and dependent
+    // work crawls from time slice to time slice.
+    const RcclApi* double_api = (flags & MA_GROUP_EXCHANGE_RCCL) ? rccl() : nullptr;
+    g->carrier_class = (double_api && double_api->loopback) ? 1 : 0;
     for (int32_t i = 0; i < n_members; ++i) {
         ma_ctx* c = nullptr;
-        ma_status st = ma_ctx_create(device_ordinals[i], &c);
+        ma_status st = create_ctx_in_class(device_ordinals[i], g->carrier_class, &c);
         if (st == MA_OK) st = ma_ctx_set_async(c, 1);  // members only ever enqueue; the group synchronises them
         if (st != MA_OK) {
             if (c) ma_ctx_destroy(c);

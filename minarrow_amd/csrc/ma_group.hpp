@@ -55,6 +55,7 @@ struct ma_group {
     // One stream per member that nothing else is ever enqueued on: the abort path writes the release values of stall words
     // and stamps through it while the member's own streams are stuck.
     std::vector<hipStream_t> rescue;
+    int carrier_class = 0;  // the stream priority class of the members' and exchange streams (+1 in a rehearsal through the loopback double)
     int handoff = 0;      // overlapped exchanges: 0 = the scan's stamp when the step was a stamped launch, 1 = always an event
     std::string peer_note;  // the peer-access summary of ma_group_exchange_note (probed once at creation)
     std::vector<ncclComm_t> comms;
@@ -113,7 +114,7 @@ struct ma_group {
 };
 
 namespace ma {
-ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+ma_status make_lane(ma_ctx* root, ma_ctx** out, int cls = 0);  // ma_ctx.hip: an internal context of root's device, own stream (in priority class cls) + scratch
 ma_status create_ctx_in_class(int32_t device_ordinal, int cls, ma_ctx** out);  // ma_ctx.hip: +1 high / -1 low priority stream
 ma_status sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* cols, uint64_t* stamp, uint64_t stamp_value,
                          bool as_partials = false, uint64_t* early_stamp = nullptr);

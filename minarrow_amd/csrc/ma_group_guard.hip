@@ -39,7 +39,7 @@ void guard_log(const char* fmt, ...) {
     }();
     if (!on) return;
     static const auto t0 = std::chrono::steady_clock::now();
-    char buf[512];
+    char buf[4096];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -91,6 +91,8 @@ double us_since(Clock::time_point t0) { return std::chrono::duration<double, std
 
 hipStream_t rescue_stream(ma_group* g, size_t i) {
     if (g->rescue.size() < g->ctxs.size()) g->rescue.resize(g->ctxs.size(), nullptr);
+    for (size_t j = 0; j < g->ctxs.size() && !g->rescue[i]; ++j)  // one per device: it only ever carries 8-byte writes
+        if (g->rescue[j] && g->ctxs[j]->device == g->ctxs[i]->device) g->rescue[i] = g->rescue[j];
     if (!g->rescue[i]) {
         (void)hipSetDevice(g->ctxs[i]->device);
         // the LOW priority class: the runtime keeps a hardware-queue pool per class, so this stream never sits behind an ordinary
@@ -223,7 +225,7 @@ std::string describe(ma_group* g, const Pending& p) {
             text += "; ...";
             break;
         }
-        char buf[320];
+        char buf[400];
         std::string what;
         if (!p.scan[i]) what = g->overlap ? "scan stream (scans, or the wait for an earlier exchange of the set being re-filled)" :
                                             (g->use_rccl ? "stream (scan, all-gather or fold)" : "stream (scan)");
@@ -240,6 +242,18 @@ std::string describe(ma_group* g, const Pending& p) {
                 what += buf;
             } else {
                 what += "exchange stream (all-gather or fold in flight)";
+            }
+        }
+        if (g->lanes2 && (!p.scan[i] || !p.lane[i])) {
+            // a lane's scan is gated on the EARLY stamp (word 1) of the step before it on the other lane: what the words hold,
+            // against the sequence of each set's last stamped step
+            for (int k = 0; k < 2; ++k) {
+                uint64_t fin = 0, early = 0;
+                if (i < g->stamp[k].size() && g->stamp[k][i] && read_word(g, i, g->stamp[k][i], &fin) && read_word(g, i, g->stamp[k][i] + 1, &early)) {
+                    snprintf(buf, sizeof(buf), "; set %d stamps: final %lld early %lld of sequence %llu", k, (long long)fin, (long long)early,
+                             (unsigned long long)g->stamp_seq[k]);
+                    what += buf;
+                }
             }
         }
         snprintf(buf, sizeof(buf), "%smember %zu (device %d): %s", text.empty() ? "" : "; ", i, g->ctxs[i]->device, what.c_str());

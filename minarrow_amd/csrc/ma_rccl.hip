@@ -148,7 +148,7 @@ static const char* const kCommBroken =
     "this communicator was aborted (a bounded wait ran out, here or on another rank): destroy it; the ranks may agree on a new one";
 
 namespace ma {
-ma_status make_lane(ma_ctx* root, ma_ctx** out);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
+ma_status make_lane(ma_ctx* root, ma_ctx** out, int cls = 0);  // ma_ctx.hip: an internal context of root's device, own stream + scratch
 }
 
 namespace {

@@ -27,8 +27,11 @@
 // payloads here are reduction records (a few hundred bytes per rank).
 //
 // One device, many ranks: every rank's kernel spins while it waits, and streams that share a hardware queue run in order. The
-// process must therefore have at least as many hardware queues as streams that can wait on each other: start it with
-// GPU_MAX_HW_QUEUES >= 4 x ranks (the runtime's default is 4); ncclCommInitAll says so on stderr when it is not.
+// streams that carry the ranks' collectives must therefore each have a hardware queue of their own. The library sees to it: in
+// a rehearsal it puts those streams (the members' and their exchange streams) into the high priority class, whose queue pool
+// they have to themselves — the process needs GPU_MAX_HW_QUEUES >= ranks (the runtime's default is 4; ncclCommInitAll says so on
+// stderr when it is not) and no more than that: a device runs 23 hardware queues at a time (selfcheck `slots`), and with more
+// alive, work that waits on work in another queue crawls from time slice to time slice.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -444,10 +447,10 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
         for (int j = i + 1; j < ndev; ++j) shared_device |= (devlist ? devlist[i] : i) == (devlist ? devlist[j] : j);
     if (shared_device) {
         const char* q = getenv("GPU_MAX_HW_QUEUES");
-        if (!q || atoi(q) < 4 * ndev)
+        if ((q ? atoi(q) : 4) < ndev)
             say("%d ranks share a device and GPU_MAX_HW_QUEUES is %s: streams that share a hardware queue run in order, and a rank "
                 "whose peer's kernel sits behind its own spinning kernel never finishes. Start the process with GPU_MAX_HW_QUEUES >= %d",
-                ndev, q ? q : "unset (4)", 4 * ndev);
+                ndev, q ? q : "unset (4)", ndev);
     }
     std::shared_ptr<World> w = make_local_world(ndev);
     if (!w) return ncclUnhandledCudaError;

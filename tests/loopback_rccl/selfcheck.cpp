@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE: checks the loopback collective double (loopback_rccl.hip) by itself, without libminarrow_hip.so, on
 // one GPU. What it rehearses is the combine step of the reference's partitioned reduction (benches/benchmark_parallel_simd.rs:81-98).
 //
-//   selfcheck queues K        how many of K streams share a hardware queue with a held one (GPU_MAX_HW_QUEUES in effect)
+//   selfcheck queues K [C]    how many of K streams share a hardware queue with a held one (GPU_MAX_HW_QUEUES in effect),
+//                             after C streams were created, used and destroyed
+//   selfcheck slots K [0|1]   K - 1 queues busy (1: spinning kernels, 0: value waits): does a K-th queue still get to run?
 //   selfcheck single N ITERS  ncclCommInitAll over N ranks on device 0, one host thread per rank, ITERS all-gathers + all-reduces
 //   selfcheck grouped N ITERS the same from ONE thread inside ncclGroupStart/End
 //   selfcheck abort N         rank N-1 never posts: the others block on the GPU; ncclCommAbort ends them within a second
@@ -98,8 +100,19 @@ static bool rank_check(RankState& r, int n, int iter) {
     return true;
 }
 
-static int mode_queues(int k) {
+static int mode_queues(int k, int churn) {
     HIP_OK(hipSetDevice(0));
+    // streams created, used once and destroyed beforehand: does the runtime hand their hardware queues back?
+    for (int done = 0; done < churn; done += 24) {
+        std::vector<hipStream_t> t(24);
+        uint64_t* w = nullptr;
+        HIP_OK(hipHostMalloc((void**)&w, 24 * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        for (auto& x : t) HIP_OK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        for (size_t j = 0; j < t.size(); ++j) HIP_OK(hipStreamWriteValue64(t[j], w + j, 1, 0));
+        for (auto& x : t) HIP_OK(hipStreamSynchronize(x));
+        for (auto& x : t) HIP_OK(hipStreamDestroy(x));
+        HIP_OK(hipHostFree(w));
+    }
     std::vector<hipStream_t> s((size_t)k);
     for (auto& x : s) HIP_OK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
     uint64_t* words = nullptr;  // pinned host memory: [0] holds stream 0, [j] is written by stream j
@@ -117,13 +130,58 @@ static int mode_queues(int k) {
             return 1;
         }
     const char* q = getenv("GPU_MAX_HW_QUEUES");
-    printf("ok queues: %d streams, GPU_MAX_HW_QUEUES=%s: %d of %d sit behind the held stream's hardware queue\n", k, q ? q : "unset", behind,
-           k - 1);
+    printf("ok queues: %d streams (after %d created and destroyed), GPU_MAX_HW_QUEUES=%s: %d of %d sit behind the held stream's hardware queue\n",
+           k, churn, q ? q : "unset", behind, k - 1);
+    return 0;
+}
+
+__global__ void spin_until(const uint64_t* flag, uint64_t* seen) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0) __builtin_amdgcn_s_sleep(32);
+    *seen = 1;
+}
+__global__ void set_flag(uint64_t* flag) { __hip_atomic_store(flag, (uint64_t)1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// K - 1 streams (a hardware queue each) hold a kernel that spins — or a hipStreamWaitValue64 — on a flag that a kernel on the K-th
+// stream, enqueued LAST, sets: does the K-th queue get a hardware slot while the others are all busy? (the limit of a rehearsal)
+static int mode_slots(int k, bool spin) {
+    HIP_OK(hipSetDevice(0));
+    std::vector<hipStream_t> s((size_t)k);
+    for (auto& x : s) HIP_OK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    uint64_t* w = nullptr;
+    HIP_OK(hipHostMalloc((void**)&w, (size_t)(k + 1) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(w, 0, (size_t)(k + 1) * 8);
+    for (int j = 0; j + 1 < k; ++j) {
+        if (spin) hipLaunchKernelGGL(spin_until, dim3(1), dim3(1), 0, s[(size_t)j], w, w + 1 + j);
+        else HIP_OK(hipStreamWaitValue64(s[(size_t)j], w, 1, hipStreamWaitValueGte, ~(uint64_t)0));
+    }
+    HIP_OK(hipGetLastError());
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(set_flag, dim3(1), dim3(1), 0, s[(size_t)k - 1], w);
+    HIP_OK(hipGetLastError());
+    bool all = true;
+    for (auto& x : s) all = drained(x, 3000.0) && all;
+    const double ms = ms_since(t0);
+    if (!all) {
+        __atomic_store_n(w, (uint64_t)1, __ATOMIC_RELEASE);  // the host releases what the last queue could not
+        for (auto& x : s) (void)drained(x, 5000.0);
+    }
+    printf("ok slots: %d queues busy with %s, the releasing kernel on queue %d %s (%.1f ms)\n", k - 1, spin ? "spinning kernels" : "value waits", k,
+           all ? "RAN" : "NEVER ran within 3 s: more queues than hardware slots starve", ms);
     return 0;
 }
 
 static int mode_single(int n, int iters, bool grouped) {
     HIP_OK(hipSetDevice(0));
+    // SELFCHECK_IDLE_STREAMS=E: E more streams (each used once, so that its hardware queue exists) stay alive beside the ranks'
+    static std::vector<hipStream_t> idle(getenv("SELFCHECK_IDLE_STREAMS") ? (size_t)atoi(getenv("SELFCHECK_IDLE_STREAMS")) : 0);
+    if (!idle.empty()) {
+        uint64_t* w = nullptr;
+        HIP_OK(hipHostMalloc((void**)&w, idle.size() * 8, hipHostMallocMapped | hipHostMallocCoherent));
+        for (auto& x : idle) HIP_OK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        for (size_t j = 0; j < idle.size(); ++j) HIP_OK(hipStreamWriteValue64(idle[j], w + j, 1, 0));
+        for (auto& x : idle) HIP_OK(hipStreamSynchronize(x));
+    }
     std::vector<ncclComm_t> comms((size_t)n);
     std::vector<int> devs((size_t)n, 0);
     NCCL_OK(ncclCommInitAll(comms.data(), n, devs.data()));
@@ -175,8 +233,8 @@ static int mode_single(int n, int iters, bool grouped) {
         fprintf(stderr, "%d checks failed (count %d)\n", bad.load(), count);
         return 1;
     }
-    printf("ok %s: %d ranks x %d iterations (all-gather + all-reduce each), %.1f us per iteration\n", grouped ? "grouped" : "single", n,
-           iters, ms * 1e3 / iters);
+    printf("ok %s: %d ranks x %d iterations (all-gather + all-reduce each), %.1f us per iteration (%zu idle streams beside them)\n",
+           grouped ? "grouped" : "single", n, iters, ms * 1e3 / iters, idle.size());
     return 0;
 }
 
@@ -258,7 +316,8 @@ static int mode_procs(int n, int iters) {
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "";
     const int a = argc > 2 ? atoi(argv[2]) : 2, b = argc > 3 ? atoi(argv[3]) : 50;
-    if (!strcmp(mode, "queues")) return mode_queues(a);
+    if (!strcmp(mode, "queues")) return mode_queues(a, argc > 3 ? b : 0);
+    if (!strcmp(mode, "slots")) return mode_slots(a, argc > 3 ? b != 0 : true);
     if (!strcmp(mode, "single")) return mode_single(a, b, false);
     if (!strcmp(mode, "grouped")) return mode_single(a, b, true);
     if (!strcmp(mode, "abort")) return mode_abort(a);

@@ -48,19 +48,17 @@ def test_single_gpu_line_with_other_configs_and_cpu_baseline():
     # the headline is the product's own form: no torch in the process, /opt/rocm's HIP runtime, timing marks for the kernels
     assert out["config"]["host"] == "torch-free" and "torch" not in out["config"]["hip_runtime"]
     assert set(out["kernels"]) == {"sum_i64", "sum_f64"} and out["roofline"]["kernel"].startswith("ma::sum_kernel")
-    th = out["torch_hosted"]  # the same headline hosted by PyTorch, as a labelled extra key
-    assert th["parity_ok"] and th["value"] > 0 and "torch" in th["hip_runtime"]
+    assert "torch_hosted" not in out  # retired in round 6: the torch-free host had matched it for three rounds
     pl = out["pipelined"]  # the same job as a pipeline of fused steps on two streams (ma_scan_lanes_*), labelled, never `value`
     assert pl["parity_ok"] and pl["value"] > 0 and 0 < pl["frac_of_peak"] <= 1.0 and "ma_scan_lanes" in pl["step"]
 
 
-def test_single_gpu_fused_step_and_torch_hosted_variant():
-    fused = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--no-torch-hosted-leg", "--step", "fused"])
+def test_single_gpu_fused_step():
+    fused = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--step", "fused"])
     assert fused["parity_ok"] and set(fused["kernels"]) == {"sum_fused"}
     assert fused["kernels"]["sum_fused"]["bytes_per_launch"] == 2 * 8 * (1 << 24) and "sum_fused" in fused["roofline"]["kernel"]
-    hosted = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--torch-hosted"])
-    assert hosted["parity_ok"] and "torch-hosted" in hosted["config"]["host"] and "torch" in hosted["config"]["hip_runtime"]
-    assert hosted["result"]["i64_sum"] == fused["result"]["i64_sum"] and hosted["result"]["f64_sum"] == fused["result"]["f64_sum"]
+    sep = run([sys.executable, "bench.py", *SMALL, "--no-cpu-baseline", "--no-other-configs", "--no-pipelined-leg"])
+    assert sep["result"]["i64_sum"] == fused["result"]["i64_sum"] and sep["result"]["f64_sum"] == fused["result"]["f64_sum"]
 
 
 def test_one_process_group_mode_with_rccl():
@@ -99,12 +97,10 @@ def test_one_process_group_mode_with_rccl():
     assert weak["result"]["i64_sum"] == out["result"]["i64_sum"]
 
 
-@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("host", []),
-                                             ("torch", ["--torch-hosted", "--overlap"])])
+@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("host", [])])
 def test_launcher_mode_one_rank(exchange, extra):
-    """One process per GPU under torch.distributed.run. Default: the GPU path is torch-free (gloo carries the rendezvous
-    only) and the exchange is the library's own communicator (ma_comm_*) or, as its fall-back, the records over host memory;
-    --torch-hosted: torch's runtime and streams, the library's communicator or torch.distributed's all-gather."""
+    """One process per GPU under torch.distributed.run: the GPU path is torch-free (gloo carries the rendezvous only) and the
+    exchange is the library's own communicator (ma_comm_*) or, as its fall-back, the records over host memory."""
     out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
                "--other-reps", "2", "--exchange", exchange, *extra])
@@ -115,19 +111,15 @@ def test_launcher_mode_one_rank(exchange, extra):
     assert oc["config3_i64_add_one_chunk_per_gpu"]["parity"] is True
     assert oc["parity_ok"] is True, oc
     assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
-    hosted = "--torch-hosted" in extra
-    want = {"native": "ma_comm_*", "torch": "torch.distributed", "host": "device fold"}[exchange]
+    want = {"native": "ma_comm_*", "host": "device fold"}[exchange]
     assert want in out["config"]["exchange"]
     if "--overlap" in extra:
         assert "side stream" in out["config"]["exchange"]
-    if not hosted:
-        cfg = out["config"]
-        assert "torch-free" in cfg["host"] and "torch" not in cfg["hip_runtime"] and "fused" in cfg["step"]
-        assert {"exchange_us", "fold_us", "exchange_samples", "rccl_ranks", "scan_ms_per_step_min_over_ranks"} <= set(cfg)
-        if exchange == "native":
-            assert cfg["rccl_ranks"] == 1 and cfg["exchange_samples"] >= 1 and cfg["exchange_us"] > 0 and cfg["fold_us"] > 0
-    else:
-        assert "torch-hosted" in out["config"]["host"]
+    cfg = out["config"]
+    assert "torch-free" in cfg["host"] and "torch" not in cfg["hip_runtime"] and "fused" in cfg["step"] and cfg["rehearsal"] is False
+    assert {"exchange_us", "fold_us", "exchange_samples", "rccl_ranks", "scan_ms_per_step_min_over_ranks"} <= set(cfg)
+    if exchange == "native":
+        assert cfg["rccl_ranks"] == 1 and cfg["exchange_samples"] >= 1 and cfg["exchange_us"] > 0 and cfg["fold_us"] > 0
 
 
 LAUNCH = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
@@ -137,7 +129,7 @@ QUICK = ["--no-cpu-baseline", "--no-other-configs", "--wait-seconds", "0.6"]
 def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(monkeypatch):
     """bench.py checks the set-up step's finals on every rank before timing anything; a communicator that folds wrongly
     (forced here for every ma_comm form) is abandoned on all ranks, one notch at a time — stamp, event, in-stream — down to the
-    records over host memory in the default form, to torch.distributed's exchange in the torch-hosted one; the line says so."""
+    records over host memory; the line says so."""
     monkeypatch.setenv("MA_BENCH_DISTRUST_NATIVE_COMM", "1")
     base = [*LAUNCH, "--master-port", "29642", "bench.py", *SMALL, "--gpus", "1", "--force-dist", "--no-cpu-baseline",
             "--no-other-configs", "--overlap", "on", "--scan-lanes", "on"]
@@ -148,9 +140,6 @@ def test_launcher_mode_falls_back_when_the_native_communicator_fails_its_check(m
         "ma_comm, overlapped, hand-off by event", "ma_comm, in-stream"]
     assert all("set-up check" in d["why"] for d in cfg["downgrades"]) and "4 abandoned" in cfg["exchange"]
     assert cfg["exchange_form"].startswith("none (one rank)") and cfg["rccl_ranks"] == 0
-    out = run(base + ["--torch-hosted"])
-    assert out["parity_ok"] and "torch.distributed" in out["config"]["exchange"] and "set-up check" in out["config"]["exchange"]
-    assert "side stream" in out["config"]["exchange"]
 
 
 G = ["rccl, overlapped, hand-off by stamp, two scan lanes, issue threads", "rccl, overlapped, hand-off by stamp, issue threads",
@@ -257,3 +246,64 @@ def test_launcher_rehearsal_partitions_the_column_over_several_ranks(ranks):
                 "127.0.0.1", "--master-port", str(29660 + ranks), "bench.py", "--rows", str(1 << 22), "--steps", "2", "--warmup", "1",
                 "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline", "--scaling", "weak"])
     assert weak["parity_ok"] and weak["scaling"] == "weak" and weak["result"]["rows"] == ranks << 22
+
+
+# ---- REHEARSAL: both N > 1 modes with PEERS, on this box's one GPU, through the loopback collective double ---------------------
+# (tests/test_gpu_rehearsal.py starts the session these run in: MINARROW_HIP_RCCL_PATH, GPU_MAX_HW_QUEUES are in the environment)
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("members", [8])
+def test_rehearsal_group_mode_with_eight_members_keeps_the_top_notch(members):
+    """`bench.py --gpus 8` as the driver starts it on an 8-GPU node, here with the eight members on one GPU: ncclCommInitAll over
+    8 ranks, eight issue threads, the overlapped exchange waiting on the scans' stamps, two scan lanes per member — the line
+    says REHEARSAL, nothing was abandoned on the way, every member holds the same finals."""
+    out = run([sys.executable, "bench.py", "--rows", str(1 << 26), "--steps", "6", "--warmup", "2", "--gpus", str(members), "--no-cpu-baseline",
+               "--other-rows", str(1 << 22), "--other-reps", "2", "--scan-lanes", "on"], timeout=400)
+    cfg = out["config"]
+    assert out["parity_ok"] and out["n_gpus"] == members and cfg["rehearsal"] is True
+    assert "REHEARSAL" in cfg["parallelism"] and cfg["exchange"].startswith("REHEARSAL") and "loopback" in cfg["exchange"]
+    assert cfg["downgrades"] == [] and cfg["exchange_form"] == G[0] and cfg["attempts"] == 1, cfg["downgrades"]
+    assert cfg["rccl_ranks"] == members and cfg["preflight"]["ok"] and cfg["preflight"]["members"] == members
+    assert cfg["rows_per_gpu_per_column"] == (1 << 26) // members
+    oc = out["other_configs"]  # configs 3-5's multi-GPU legs: one chunk / one batch per member, ONE exchange per step
+    assert oc["parity_ok"] is True, oc
+    assert oc["config4_i64_sum_10pct_nulls_row_chunks"]["parity"] and oc["config5_supertable_one_batch_per_gpu"]["parity"]
+    assert oc["config5_physical_consolidate_onto_gpu0"]["parity"] is True
+
+
+@pytest.mark.rehearsal
+def test_rehearsal_group_mode_goes_down_its_ladder_with_peers():
+    """A stalled LAST member of four during the set-up step and wrong finals on it one notch further down: two forms abandoned,
+    the third does the job — with peers whose collectives really were waiting."""
+    out = run([sys.executable, "bench.py", *SMALL, "--gpus", "4", "--scan-lanes", "on", *QUICK], {"MA_BENCH_FAULT": "stall@setup,corrupt@setup"},
+              timeout=300)
+    cfg = out["config"]
+    assert out["parity_ok"] and cfg["rehearsal"] is True and cfg["faults_injected"] == ["stall@setup", "corrupt@setup"]
+    assert [d["abandoned"] for d in cfg["downgrades"]] == G[:2] and cfg["exchange_form"] == G[2] and cfg["rccl_ranks"] == 4
+    assert "member 3" in cfg["downgrades"][0]["why"] and "finals are wrong" in cfg["downgrades"][1]["why"]
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("ranks", [2])
+def test_rehearsal_launcher_mode_with_two_rank_processes_keeps_the_top_notch(ranks):
+    """The driver's N > 1 command — torch.distributed.run, one process per rank, ma_comm_* — with two rank processes on one GPU:
+    ncclCommInitRank across processes, the overlapped exchange on the scans' stamps, two scan contexts per rank."""
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", "29671", "bench.py", "--rows", str(1 << 26), "--steps", "6", "--warmup", "2", "--gpus", str(ranks),
+               "--no-cpu-baseline", "--other-rows", str(1 << 22), "--other-reps", "2", "--scan-lanes", "on"], {"GPU_MAX_HW_QUEUES": "4"}, timeout=400)
+    cfg = out["config"]
+    assert out["parity_ok"] and out["n_gpus"] == ranks and cfg["rehearsal"] is True
+    assert "REHEARSAL" in cfg["parallelism"] and cfg["exchange"].startswith("REHEARSAL")
+    assert cfg["downgrades"] == [] and cfg["exchange_form"] == L[0] and cfg["rccl_ranks"] == ranks and cfg["preflight"]["ok"]
+    assert out["other_configs"]["parity_ok"] is True, out["other_configs"]
+
+
+@pytest.mark.rehearsal
+def test_rehearsal_launcher_mode_goes_down_its_ladder_with_a_peer():
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29672", "bench.py", *SMALL, "--gpus", "2", "--scan-lanes", "on", *QUICK],
+              {"MA_BENCH_FAULT": "stall@setup,corrupt@setup", "GPU_MAX_HW_QUEUES": "4"}, timeout=300)
+    cfg = out["config"]
+    assert out["parity_ok"] and cfg["rehearsal"] is True
+    assert [d["abandoned"] for d in cfg["downgrades"]] == L[:2] and cfg["exchange_form"] == L[2] and cfg["rccl_ranks"] == 2

@@ -7,6 +7,7 @@ one rank; on an 8-GPU node the same test covers 8)."""
 import ctypes as C
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -109,26 +110,46 @@ def _device_lists(members):
 def test_group_over_distinct_devices(oracle, exchange, issue):
     """One member per visible GPU (up to 8). With exchange = "rccl": ncclCommInitAll + all-gather (one per member issue
     thread, or grouped on the calling thread) + device fold — every member must hold the same finals."""
-    from minarrow_amd.host import Group
-
     n_dev = min(ffi.device_count(), 8)
     assert n_dev >= 1
+    _partitioned_sums_on_every_member(oracle, list(range(n_dev)), exchange, issue)
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("members", [2, 4, 8])
+@pytest.mark.parametrize("issue", ["threads", "caller"])
+@pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "rccl-overlap-lanes"])
+def test_rehearsal_group_of_members_sharing_the_device(oracle, members, exchange, issue):
+    """The same job with 2 / 4 / 8 members on device 0 through the loopback collective double: every member's all-gather waits
+    on the GPU for its peers' (issued by eight threads at once, or grouped on the calling thread), in-stream, on side
+    streams, and with two scan lanes — bit-identical finals on every member."""
+    _partitioned_sums_on_every_member(oracle, [0] * members, exchange, issue)
+
+
+def _partitioned_sums_on_every_member(oracle, devices, exchange, issue):
+    from minarrow_amd.host import Group
+
+    n_dev = len(devices)
     n = 3_000_017
     rng = np.random.default_rng(11)
     ints = rng.integers(-(1 << 62), 1 << 62, size=n, dtype=np.int64)
     flts = rng.standard_normal(n) * 1e12
     bits = rng.integers(0, 256, size=n // 8 + 64, dtype=np.uint8)
-    with Group(list(range(n_dev)), exchange=exchange, issue=issue) as g:
+    n_distinct = len(set(devices))
+    with Group(devices, exchange=exchange, issue=issue) as g:
         assert g.exchange_kind == exchange.split("-")[0] and g.issue_kind == issue
-        assert ("overlapped on side streams" in g.exchange_note) == (exchange == "rccl-overlap")
+        assert ("overlapped on side streams" in g.exchange_note) == exchange.startswith("rccl-overlap")
+        assert g.scan_lanes == exchange.endswith("lanes")
         note = g.exchange_note
         assert "instead of RCCL" not in note and "peer access:" in note and ("one thread per member" in note) == (issue == "threads")
+        # several members on one device: only the loopback double takes that, and the note says what it is
+        assert note.startswith("REHEARSAL") == (exchange != "host" and n_distinct < n_dev)
         # peer capability is probed between every pair of members at creation; a member always reaches itself
         assert all(g.peer_access(i, i) for i in range(n_dev)) and not g.peer_access(0, n_dev) and not g.peer_access(-1, 0)
-        if n_dev > 1:
-            assert f"/{n_dev * (n_dev - 1)} ordered device pairs" in note
+        if n_distinct > 1:
+            assert f"/{n_distinct * (n_distinct - 1)} ordered device pairs" in note
         ctxs = [g.member_ctx(i) for i in range(n_dev)]
-        assert len({c.hip_device for c in ctxs}) == n_dev
+        assert len({c.hip_device for c in ctxs}) == n_distinct
         chunks = row_chunks(n, n_dev)
         di, df, dm = _chunk_tables(ctxs, ints, flts, bits, chunks)
         lens = [b - a for a, b in chunks]
@@ -142,6 +163,8 @@ def test_group_over_distinct_devices(oracle, exchange, issue):
             g.enqueue_sum("f64", 5, df, lens, dm, offs)
             g.exchange()
         g.synchronize()
+        if exchange != "host":
+            assert g.exchange_stats()["rccl_ranks"] == n_dev
         valid = np.unpackbits(bits, bitorder="little")[:n].astype(bool)
         for m in range(n_dev):
             isum, icnt, fsum, fcnt = g.result(0, m)
@@ -511,7 +534,9 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
     print(f"{sum(done)} group calls from two threads checked, 0 errors")
 
 
-@pytest.mark.parametrize("members,exchange", [(1, "rccl"), (1, "rccl-overlap"), (4, "host"), (8, "host")])
+@pytest.mark.parametrize("members,exchange", [(1, "rccl"), (1, "rccl-overlap"), (4, "host"), (8, "host"),
+                                              pytest.param(4, "rccl", marks=pytest.mark.rehearsal),
+                                              pytest.param(8, "rccl-overlap", marks=pytest.mark.rehearsal)])
 @pytest.mark.parametrize("issue", ["threads", "caller"])
 def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
     """ma_group_enqueue_sum_chunks: ONE column held as 3000 chunks (ragged, some empty, validity at odd bit offsets on two
@@ -562,7 +587,9 @@ def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
         assert g.result(7, 0)[:2] == (0, 0)
 
 
-@pytest.mark.parametrize("members, exchange", [(1, "host"), (3, "host"), (8, "host"), (1, "rccl"), (1, "rccl-overlap")])
+@pytest.mark.parametrize("members, exchange", [(1, "host"), (3, "host"), (8, "host"), (1, "rccl"), (1, "rccl-overlap")] +
+                         [pytest.param(m, x, marks=pytest.mark.rehearsal)
+                          for m in (2, 4, 8) for x in ("rccl", "rccl-overlap", "rccl-overlap-lanes")])
 def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members, exchange):
     """ma_group_enqueue_sum_table: the partitioned step as ONE launch per member (i64 + f64 chunk of each member, dense and
     Bitmask-gated) must give the finals of the two-launch form bit for bit, through either exchange, step after step."""
@@ -586,14 +613,15 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
             for _ in range(3):  # overlapped exchanges alternate between two record sets
                 g.enqueue_sum_table([("l", 2, di, lens, masks, offs), ("g", 2, df, lens, masks, offs)])
                 g.exchange()
-            g.synchronize()
+            g.synchronize_for(20_000)
             fused = g.result(2)
             for _ in range(3):
                 g.enqueue_sum("i64", 5, di, lens, masks, offs if masks else None)
                 g.enqueue_sum("f64", 5, df, lens, masks, offs if masks else None)
                 g.exchange()
-            g.synchronize()
+            g.synchronize_for(20_000)
             assert g.result(5) == fused
+            assert all(g.result(5, m) == fused for m in range(members)), "every member folds the same gathered records"
             if masks is None:
                 want_i, want_c = oracle.sum_scalar(ints), n
                 exact = math.fsum(flts.tolist())
@@ -603,7 +631,7 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
                 exact = math.fsum(flts[valid].tolist())
             assert (fused[0], fused[1], fused[3]) == (want_i, want_c, want_c)
             assert abs(fused[2] - exact) <= math.ulp(exact)
-        if exchange == "rccl-overlap" and g.exchange_kind == "rccl":
+        if exchange.startswith("rccl-overlap") and g.exchange_kind == "rccl":
             # two record sets alternate: a slot that was not enqueued in the last exchange's step is refused, not served stale
             with pytest.raises(ffi.MinarrowHipError) as e:
                 g.result(2)  # the last exchanges carried slot 5 only
@@ -611,7 +639,7 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
             assert g.result(5) == fused
         st = g.exchange_stats()
         if exchange.startswith("rccl") and g.exchange_kind == "rccl":
-            assert st["rccl_ranks"] == 1 and st["samples"] >= 1 and st["all_gather_us"] > 0 and st["fold_us"] > 0
+            assert st["rccl_ranks"] == members and st["samples"] >= 1 and st["all_gather_us"] > 0 and st["fold_us"] > 0
         else:
             assert st["rccl_ranks"] == 0 and st["all_gather_us"] == 0.0
         # the argument checks: an unsupported format, two columns on the same half of one record
@@ -623,31 +651,43 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
         assert e.value.status == ffi.MA_ERR_INVALID_ARGUMENT
 
 
-def test_group_exchange_failure_on_a_member_aborts_instead_of_hanging():
+@pytest.mark.parametrize("members, failing", [(1, 0), pytest.param(2, 1, marks=pytest.mark.rehearsal),
+                                              pytest.param(8, 3, marks=pytest.mark.rehearsal)])
+def test_group_exchange_failure_on_a_member_aborts_instead_of_hanging(members, failing):
     """Per-member issue threads enqueue their own rank's all-gather; should one member fail in front of its call, the
-    others' collectives could never complete. The group then aborts its communicators and reports MA_ERR_DEVICE from
-    exchange and synchronize (no hang); only destroying it remains."""
+    others' collectives could never complete (rehearsal: 7 members' all-gathers really are on the GPU, spinning for the 8th).
+    The group then aborts its communicators and reports MA_ERR_DEVICE from exchange and synchronize (no hang); a rebuild — or
+    destroying it — remains."""
     from minarrow_amd.host import Group
 
-    with Group([0], exchange="rccl") as g:
+    with Group([0] * members, exchange="rccl") as g:
         if g.exchange_kind != "rccl":
             pytest.skip("RCCL is not available on this box")
-        c = g.member_ctx(0)
+        c = g.member_ctx(failing)
         n = 1 << 20
         col = c.alloc(n * 8)
         c.synth_iota("i64", col, n, 0)
-        g.enqueue_sum("i64", 0, [col], [n])
+        cols, lens = [col] * members, [n if m == failing else 0 for m in range(members)]  # one non-empty chunk, the failing member's
+        g.enqueue_sum("i64", 0, cols, lens)
         g.exchange()
         g.synchronize()
-        assert g.result(0)[:2] == (n * (n - 1) // 2, n)
-        ffi.check(g.lib.ma_group_test_fail_next_exchange(g.handle, 0))
-        g.enqueue_sum("i64", 0, [col], [n])
+        assert all(g.result(0, m)[:2] == (n * (n - 1) // 2, n) for m in range(members))
+        ffi.check(g.lib.ma_group_test_fail_next_exchange(g.handle, failing))
+        g.enqueue_sum("i64", 0, cols, lens)
+        t0 = time.perf_counter()
         with pytest.raises(ffi.MinarrowHipError) as e:
             g.exchange()
-        assert e.value.status == ffi.MA_ERR_DEVICE and "aborted" in str(e.value)
+        assert e.value.status == ffi.MA_ERR_DEVICE and "aborted" in str(e.value) and f"member {failing}" in str(e.value)
+        assert time.perf_counter() - t0 < 8.0 and g.is_broken == 1, "the peers' all-gathers were ended by the abort"
         with pytest.raises(ffi.MinarrowHipError) as e:
             g.synchronize()
         assert e.value.status == ffi.MA_ERR_DEVICE
         with pytest.raises(ffi.MinarrowHipError):
             g.exchange()
         c.synchronize()  # the member's own stream is intact
+        if members > 1:  # the same members, a fresh exchange
+            g.rebuild_exchange("rccl", issue="caller")
+            g.enqueue_sum("i64", 0, cols, lens)
+            g.exchange()
+            g.synchronize_for(20_000)
+            assert all(g.result(0, m)[:2] == (n * (n - 1) // 2, n) for m in range(members))

@@ -7,6 +7,7 @@ import time
 
 import numpy as np
 import pytest
+from conftest import run_rank_processes
 
 from minarrow_amd import ffi
 from minarrow_amd.host import (SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS, Comm, Context,
@@ -35,8 +36,8 @@ def _step(g, col_i, col_f, fused=True):
     g.exchange()
 
 
-def _rccl_group(exchange, issue="threads"):
-    g = Group([0], exchange=exchange, issue=issue)
+def _rccl_group(exchange, issue="threads", members=1):
+    g = Group([0] * members, exchange=exchange, issue=issue)
     if g.exchange_kind != "rccl":
         g.close()
         pytest.skip("RCCL is not available on this box")
@@ -371,3 +372,218 @@ def test_two_scan_lanes_give_every_step_its_own_results():
         assert g.result(1)[:2] == want(cols[1][2], 1)[:2]
     finally:
         g.close()
+
+
+# ---- the same, with PEERS: several members on this box's one GPU through the loopback collective double -----------------------
+# (tests/test_gpu_rehearsal.py starts the one session these run in; tests/loopback_rccl is the stand-in for RCCL)
+
+REHEARSAL_FORMS = [("rccl", "threads"), ("rccl", "caller"), ("rccl-overlap", "threads"), ("rccl-overlap", "caller"),
+                   ("rccl-overlap-lanes", "threads"), ("rccl-overlap-lanes", "caller")]
+
+
+def _table(g):
+    """Per member an i64 and an f64 column of N rows (0, 1, 2, ...) in that member's own allocations."""
+    ctxs = [g.member_ctx(m) for m in range(g.size)]
+    cols_i, cols_f = [c.alloc(N * 8) for c in ctxs], [c.alloc(N * 8) for c in ctxs]
+    for c, a, b in zip(ctxs, cols_i, cols_f):
+        c.synth_iota("i64", a, N, 0)
+        c.synth_iota("f64", b, N, 0)
+    return ctxs, cols_i, cols_f
+
+
+def _table_step(g, cols_i, cols_f, fused=True):
+    lens = [N] * g.size
+    if fused:
+        g.enqueue_sum_table([("l", 0, cols_i, lens), ("g", 0, cols_f, lens)])
+    else:
+        g.enqueue_sum("i64", 0, cols_i, lens)
+        g.enqueue_sum("f64", 0, cols_f, lens)
+    g.exchange()
+
+
+def _want(g):
+    k = g.size
+    return (TRI * k, N * k, float(TRI * k), N * k)
+
+
+def _same_on_every_member(g, want):
+    got = [g.result(0, m) for m in range(g.size)]
+    assert all(r == want for r in got), got
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("members, stalled", [(8, 3), (2, 1)])
+@pytest.mark.parametrize("exchange, issue", REHEARSAL_FORMS)
+def test_rehearsal_a_stalled_member_among_peers(members, stalled, exchange, issue):
+    """Member 3 of 8 never starts its all-gather: the seven others' collectives are on the GPU, waiting for it — what a lost peer
+    looks like over xGMI. ma_group_synchronize_for names the member within its deadline, the abort ends all eight communicators,
+    every stream runs empty, and one notch down the same members and columns do the job."""
+    g = _rccl_group(exchange, issue, members)
+    try:
+        ctxs, cols_i, cols_f = _table(g)
+        for _ in range(3):
+            _table_step(g, cols_i, cols_f)
+        g.synchronize_for(20_000)
+        _same_on_every_member(g, _want(g))
+        g.test_stall_next_exchange(stalled)
+        _table_step(g, cols_i, cols_f)
+        t0 = time.perf_counter()
+        with pytest.raises(ffi.MinarrowHipError) as e:
+            g.synchronize_for(400)
+        waited = time.perf_counter() - t0
+        text = str(e.value)
+        assert e.value.status == ffi.MA_ERR_DEVICE and f"member {stalled} " in text and "did not finish within 400 ms" in text
+        assert 0.35 < waited < 8.0, waited
+        assert g.is_broken == 1, "the abort released the stall and ended the peers' collectives: every stream must have run empty"
+        with pytest.raises(ffi.MinarrowHipError) as e2:
+            g.exchange()
+        assert "rebuild" in str(e2.value)
+        for c, col in zip(ctxs, cols_i):  # every member's own context and buffers are intact
+            c.synchronize()
+            c.set_async(False)
+            assert c.sum("i64", col, N) == (TRI, N)
+            c.set_async(True)
+        down = {"rccl-overlap-lanes": "rccl-overlap", "rccl-overlap": "rccl", "rccl": "rccl"}[exchange]
+        g.rebuild_exchange(down, issue="caller" if exchange == "rccl" else issue)
+        assert g.is_broken == 0 and g.exchange_kind == "rccl"
+        for fused in (True, False, True):
+            _table_step(g, cols_i, cols_f, fused)
+        g.synchronize_for(20_000)
+        _same_on_every_member(g, _want(g))
+        assert g.exchange_stats()["rccl_ranks"] == members
+    finally:
+        g.close()
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("members", [2, 4, 8])
+@pytest.mark.parametrize("exchange, issue", REHEARSAL_FORMS)
+def test_rehearsal_selftest_with_peers(members, exchange, issue):
+    """ma_group_selftest where its peer columns are not "n/a": rank-tagged records of 2 / 4 / 8 members through the exchange in the
+    configured form and in every form, the gathered blocks in rank order and the member-ordered fold on EVERY member."""
+    g = _rccl_group(exchange, issue, members)
+    try:
+        rep = g.selftest(20_000)
+        assert rep["ok"] and rep["text"].startswith("PASS"), rep
+        assert rep["members"] == members and rep["devices"] == 1 and rep["rccl_ranks"] == members and rep["exchange"] == "rccl"
+        assert f"{members} members on 1 device(s)" in rep["text"]
+        assert len(rep["forms"]) == 1 and all(f["ok"] and f["us"] > 0 for f in rep["forms"].values()), rep
+        if exchange.startswith("rccl-overlap") and g.handoff == "stamp":
+            assert rep["stamp_waits"] == rep["stamp_waits_ok"] == members * (4 if exchange.endswith("lanes") else 2)
+        allf = g.selftest(20_000, SELFTEST_EXCHANGE | SELFTEST_EXCHANGE_ALL_FORMS)
+        want = {"rccl": 2, "rccl-overlap": 4 if g.handoff == "stamp" else 2, "rccl-overlap-lanes": 4}[exchange]
+        assert allf["ok"] and len(allf["forms"]) == want and all(f["ok"] for f in allf["forms"].values()), allf
+        assert g.issue_kind == issue
+        ctxs, cols_i, cols_f = _table(g)
+        _table_step(g, cols_i, cols_f)
+        g.synchronize_for(20_000)
+        _same_on_every_member(g, _want(g))
+    finally:
+        g.close()
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap"])
+def test_rehearsal_a_corrupted_member_is_the_only_one_with_wrong_finals(exchange):
+    g = _rccl_group(exchange, "threads", 8)
+    try:
+        ctxs, cols_i, cols_f = _table(g)
+        g.test_corrupt_next_exchange(5)  # member 5's copy of member 0's record is flipped in front of ITS fold
+        _table_step(g, cols_i, cols_f)
+        g.synchronize_for(20_000)
+        got = [g.result(0, m) for m in range(8)]
+        assert got[5][0] != _want(g)[0] and all(got[m] == _want(g) for m in range(8) if m != 5), got
+        rep = None
+        g.test_corrupt_next_exchange(6)
+        rep = g.selftest(20_000, SELFTEST_EXCHANGE)
+        assert not rep["ok"] and rep["failed_member"] == 6 and not rep["timed_out"] and g.is_broken == 0, rep
+        g.test_stall_next_exchange(2)
+        rep = g.selftest(400, SELFTEST_EXCHANGE)
+        assert not rep["ok"] and rep["timed_out"] and g.is_broken == 1, rep
+        g.rebuild_exchange(exchange)
+        assert g.selftest(20_000)["ok"]
+    finally:
+        g.close()
+
+
+@pytest.mark.rehearsal
+def test_rehearsal_destroying_a_group_of_eight_with_a_stalled_member_is_bounded(monkeypatch):
+    monkeypatch.setenv("MINARROW_HIP_DESTROY_WAIT_MS", "300")
+    g = _rccl_group("rccl-overlap-lanes", "threads", 8)
+    ctxs, cols_i, cols_f = _table(g)
+    g.test_stall_next_exchange(7)
+    _table_step(g, cols_i, cols_f)
+    t0 = time.perf_counter()
+    g.close()
+    assert time.perf_counter() - t0 < 10.0
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("issue", ["threads", "caller"])
+def test_rehearsal_two_scan_lanes_in_front_of_a_rendezvous(issue):
+    """MA_GROUP_SCAN_LANES with 4 members: consecutive stamped steps alternate between two scan streams per member, each gated on
+    the early stamp of the step before, and every step's exchange is a rendezvous of all four. Steps over DIFFERENT columns in
+    turn; every third step's finals are read on every member."""
+    g = _rccl_group("rccl-overlap-lanes", issue, 4)
+    try:
+        assert g.scan_lanes and "two scan lanes" in g.exchange_note
+        ctxs = [g.member_ctx(m) for m in range(4)]
+        sizes = [N, N // 2 + 64, N - 128]
+        tables = []
+        for k, n in enumerate(sizes):
+            ci, cf = [c.alloc(n * 8) for c in ctxs], [c.alloc(n * 8) for c in ctxs]
+            for m, c in enumerate(ctxs):
+                c.synth_iota("i64", ci[m], n, k + m)
+                c.synth_iota("f64", cf[m], n, k + m)
+            tables.append((ci, cf, n, k))
+
+        def want(n, k):
+            s = sum(n * (n - 1) // 2 + (k + m) * n for m in range(4))
+            return (s, 4 * n, float(s), 4 * n)
+
+        for step in range(18):
+            ci, cf, n, k = tables[step % 3]
+            g.enqueue_sum_table([("l", 0, ci, [n] * 4), ("g", 0, cf, [n] * 4)])
+            g.exchange()
+            if step % 3 == 2 or step == 17:
+                g.synchronize_for(20_000)
+                _same_on_every_member(g, want(n, k))
+        g.set_scan_lanes(False)  # the same steps on one scan stream per member, without a rebuild
+        for step in range(4):
+            ci, cf, n, k = tables[step % 3]
+            g.enqueue_sum_table([("l", 0, ci, [n] * 4), ("g", 0, cf, [n] * 4)])
+            g.exchange()
+        g.synchronize_for(20_000)
+        _same_on_every_member(g, want(tables[0][2], 0))
+    finally:
+        g.close()
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("world", [2, 3])
+def test_rehearsal_comm_across_processes(world):
+    """ma_comm_* with PEERS: 2 / 3 processes (one context each on device 0), the exchange in-stream, overlapped on an event and
+    overlapped on the scan's stamp, the communicator's self-test in every form — every rank ends up with the same finals, folded
+    in rank order."""
+    outs = run_rank_processes(world, "exchange")
+    n = 1 << 20
+    total = n * world
+    want = [total * (total - 1) // 2, total]
+    for o in outs:
+        assert o["selftest_ok"] and o["rccl_ranks"] == world and o["rehearsal"], o
+        assert o["forms"] == ["in-stream/caller", "overlap-event/caller", "overlap-stamp/caller"], o
+        for name in ("in_stream", "overlapped_event", "overlapped_stamp", "all_reduce"):
+            assert o[name] == want, (name, o)
+        assert o["f64_within_1ulp"], o
+    assert len({tuple(o["finals_bits"]) for o in outs}) == 1, "bit-identical finals on every rank"
+
+
+@pytest.mark.rehearsal
+def test_rehearsal_a_stalled_rank_and_a_vanished_rank():
+    """Rank 1's exchange never starts (stall hook): rank 0's collective waits on the GPU for it; ma_comm_synchronize_for ends in an
+    error on BOTH ranks within its deadline, both abort, their contexts stay usable, and a new communicator from a fresh id works.
+    Then rank 1 leaves without a word: rank 0's next exchange times out the same way instead of hanging."""
+    outs = run_rank_processes(2, "stall")
+    for o in outs:
+        assert o["timed_out"] and o["broken"] == 1 and o["waited_s"] < 8.0 and o["ctx_ok"] and o["second_comm_ok"], o
+    assert outs[0]["vanished_peer_timed_out"] and outs[0]["vanished_waited_s"] < 8.0 and outs[0]["ctx_ok_after_vanish"], outs[0]

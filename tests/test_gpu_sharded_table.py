@@ -117,5 +117,19 @@ def test_sharded_table_checks_in_a_torch_first_process():
     assert r.returncode == 0 and "sharded-table checks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("world", [2, 4])
+def test_rehearsal_sharded_table_records_across_rank_processes(world):
+    """The same per-(batch, column) records with PEERS: 2 / 4 rank processes on this box's one GPU, 3 batches x 2 columns of records
+    per rank in ONE ma_comm_sum_exchange through the loopback collective double (tests/loopback_rccl), folded per column over
+    (rank, batch) in that order on every rank: i64 bit-exact, f64 within 1 ULP of the exactly rounded sum, the same bits everywhere."""
+    from conftest import run_rank_processes
+
+    outs = run_rank_processes(world, "sharded")
+    assert all(o["i64_ok"] and o["f64_ok"] for o in outs), outs
+    assert len({tuple(o["finals_bits"]) for o in outs}) == 1
+
+
 if __name__ == "__main__":
     main()
