@@ -650,13 +650,8 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict, 
         # ... and the same job on this one GPU as a PIPELINE of fused steps (what every GPU of the N > 1 modes runs with two scan
         # lanes): the like-for-like denominator of a run whose steps are pipelined
         piped = {}
-        if not _counters_serialise_dispatches():
-            # a wait across streams that never ends must not cost the line: past the deadline it goes out without this key
-            leg_guard = _Deadline(30.0 + (steps + warmup) * total_rows * 16 / 1e12, result_fd, line, rc, "efficiency_vs_n1_pipelined",
-                                  "the pipelined one-GPU leg (ma_scan_lanes_*)") if result_fd is not None else None
+        if not _counters_serialise_dispatches():  # (its waits across streams are bounded by the library: ma_scan_lanes_synchronize_for)
             _pipelined_leg(ctx, col_i, col_f, total_rows, steps, warmup, piped)
-            if leg_guard is not None:
-                leg_guard.cancel()
         line["n1_same_process"]["pipelined"] = piped.get("pipelined")
         pv = (piped.get("pipelined") or {}).get("value")
         line["efficiency_vs_n1_pipelined"] = line["value"] / (line["n_gpus"] * pv) if pv else None
@@ -668,7 +663,7 @@ def _n1_same_process(ctx, total_rows: int, steps: int, warmup: int, line: dict, 
             b.free()
 
 
-def _pipelined_leg(ctx, col_i, col_f, rows: int, steps: int, warmup: int, line: dict):
+def _pipelined_leg(ctx, col_i, col_f, rows: int, steps: int, warmup: int, line: dict, wait_ms: float = 30e3):
     """The same 2 x `rows`-row job as a PIPELINE of steps (N = 1, after the timed headline, labelled, never `value`): every step is
     one fused i64 + f64 scan (ma_sum_fused's kernel) through ma_scan_lanes_* — consecutive steps on two streams of the GPU, each
     started when the step before it has begun to drain — the form the N > 1 modes run per GPU (two scan lanes). What a host that
@@ -684,13 +679,14 @@ def _pipelined_leg(ctx, col_i, col_f, rows: int, steps: int, warmup: int, line: 
         with ScanLanes(ctx) as lanes:
             calls = [lanes.prepare_sum_fused([("l", col_i, rows, rec.ptr + 64 * k), ("g", col_f, rows, rec.ptr + 64 * k + 16)])
                      for k in range(2)]
+            wait_ms += (steps + warmup) * rows * 16 / 1e9  # plus what the bytes themselves take at 1 TB/s
             for k in range(max(2, warmup)):
                 calls[k & 1]()
-            lanes.synchronize()
+            lanes.synchronize_for(wait_ms)
             t0 = time.perf_counter()
             for k in range(steps):
                 calls[k & 1]()
-            lanes.synchronize()
+            lanes.synchronize_for(wait_ms)  # the bounded form: polls both lanes back to back for the first 10 ms
             el = time.perf_counter() - t0
         ok = True
         for k in range(2):
@@ -1865,11 +1861,8 @@ def run_native(args, result_fd) -> int:
         if _counters_serialise_dispatches():
             out["pipelined"] = {"skipped": "a profiler is collecting hardware counters: it lets one kernel run at a time, and a scan "
                                            "gated on another stream's early stamp cannot run serialised"}
-        else:  # a wait across streams that never ends must not cost the headline: past the deadline the line goes out without the leg
-            leg_guard = _Deadline(args.pipelined_seconds + (args.steps + args.warmup) * rows * 16 / 1e12, result_fd, out, 0 if ok else 1,
-                                  "pipelined", "the pipelined leg (ma_scan_lanes_*)")
-            _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out)
-            leg_guard.cancel()
+        else:  # a wait across streams that never ends costs the leg, not the headline: ma_scan_lanes_synchronize_for returns an error
+            _pipelined_leg(ctx, col_i, col_f, rows, args.steps, args.warmup, out, args.pipelined_seconds * 1e3)
     for b in (col_i, col_f):
         b.free()
     if distributed and not args.no_other_configs:
@@ -1990,7 +1983,7 @@ def main() -> int:
                          "step's scans (ma_comm_sum_exchange_overlapped / MA_GROUP_EXCHANGE_OVERLAP). auto = on when N > 1 (0.14 ms scans per GPU at 8 GPUs), off at N = 1 (nothing to hide; "
                          "it costs the scan more than it saves there, 876 vs 889 Grows/s)")
     ap.add_argument("--pipelined-seconds", type=float, default=30.0,
-                    help="N = 1: the deadline of the `pipelined` leg; past it the line is printed without the leg and the process ends")
+                    help="N = 1: the deadline of the `pipelined` leg's waits (ma_scan_lanes_synchronize_for); past it the leg reports its error")
     ap.add_argument("--no-pipelined-leg", action="store_true",
                     help="N = 1: skip the labelled `pipelined` key (the same job as a pipeline of fused steps through ma_scan_lanes_*)")
     ap.add_argument("--step", default="auto", choices=["auto", "fused", "separate"],
@@ -2026,6 +2019,8 @@ def main() -> int:
     os.dup2(2, 1)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes here
 
+    if os.environ.get("MA_BENCH_FAULT"):  # the library's fault hooks act only when this was set before it is loaded
+        os.environ.setdefault("MINARROW_HIP_TEST_HOOKS", "1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or args.gpus > 1 or args.force_group or args.force_dist:
         # the library's bounded waits, aborts and rebuilds leave a timestamped trace on stderr: what a first run on a

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "minarrow_hip.h"
+#include "minarrow_hip_testing.h" /* the fault hook below: live only when MINARROW_HIP_TEST_HOOKS=1 is in the environment */
 
 #define CHECK(call)                                                                                  \
     do {                                                                                             \
@@ -100,7 +101,7 @@ int main(int argc, char** argv) {
     const double want_f = (double)want_i; /* exactly rounded: the f64 total must be within 1 ULP of it */
     int rebuilt = 0, stalled = 0;
     for (int step = 0; step < steps; ++step) {
-        const int stall_now = step == 2 && !stalled;
+        const int stall_now = step == 2 && !stalled && ma_test_hooks_enabled();
         if (stall_now) { /* a peer that never arrives, as the waiting host sees it (once) */
             CHECK(ma_group_test_stall_next_exchange(g, n - 1));
             stalled = 1;

@@ -58,11 +58,15 @@ extern "C" {
  * ma_group_is_broken, ma_group_flags, ma_group_set_handoff / ma_group_handoff, ma_group_rebuild_exchange, ma_group_selftest
  * (+ ma_selftest_report), ma_comm_synchronize_for, ma_comm_abort, ma_comm_is_broken, ma_comm_selftest, ma_stamp_is_signal;
  * testing hooks ma_group_test_stall_next_exchange / _corrupt_next_exchange, ma_comm_test_stall_next_exchange /
- * _corrupt_next_exchange. A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange.
+ * _corrupt_next_exchange (since round 6 in minarrow_hip_testing.h). A broken group no longer has to be destroyed: ma_group_rebuild_exchange gives it a fresh exchange.
  * + ma_sum_fused_stamped_early, ma_ctx_wait_value, MA_GROUP_SCAN_LANES, ma_group_join_lanes (consecutive scans on two streams, the
  * next one gated on the early stamp of the one before); ma_scan_lanes_* (the same pipeline for a host that drives one GPU
  * without a group). */
-#define MA_ABI_VERSION 4
+/* 5 (round 6): + ma_scan_lanes_synchronize_for, ma_scan_lanes_is_broken (the single-GPU pipeline's waits are bounded too;
+ * ma_scan_lanes_destroy is). The testing hooks (ma_*_test_*, ma_test_pow_series) moved to include/minarrow_hip_testing.h and are
+ * inert (MA_ERR_UNSUPPORTED) unless MINARROW_HIP_TEST_HOOKS=1 was in the environment when the library was loaded.
+ * MINARROW_HIP_RCCL_PATH names the collective library to open instead of the system's RCCL (ma_rccl_path). */
+#define MA_ABI_VERSION 5
 
 typedef struct ma_ctx ma_ctx;
 typedef int32_t ma_status;
@@ -413,7 +417,8 @@ ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);
 ma_status ma_stamp_free(ma_ctx* ctx, uint64_t* stamp);
 /* Makes the context's stream wait until `*word >= value` (hipStreamWaitValue64; `word` from ma_stamp_alloc): the consumer side of
  * ma_sum_fused_stamped for a host that orders two contexts without events. Enqueue-only. MA_ERR_UNSUPPORTED on a runtime without
- * stream memory operations. Whoever waits must be sure the value will be written: a wait nobody ends holds the stream for good. */
+ * stream memory operations. Whoever waits must be sure the value will be written: a wait nobody ends holds the stream for good
+ * (ma_scan_lanes_* and ma_group_* wrap their own waits in bounded forms: prefer those to gating by hand). */
 ma_status ma_ctx_wait_value(ma_ctx* ctx, const uint64_t* word, uint64_t value);
 /* 1 when `stamp` (from ma_stamp_alloc) is the runtime's signal memory, 0 when it is a plain device word (the fall-back; a
  * wait on it works the same), -1 when the pointer is not a live stamp. */
@@ -435,11 +440,14 @@ int32_t ma_stamp_is_signal(const uint64_t* stamp);
  *   ma_scan_lanes_join       ctx's stream behind everything the second lane has been given (enqueue-only): call it before
  *                            anything else on `ctx` that reads the scans' results or overwrites their columns.
  *   ma_scan_lanes_synchronize  waits for both lanes; a latched device condition of either comes back as its status.
+ *   ma_scan_lanes_synchronize_for  the same under a deadline (below): the form for a host's loop.
+ * A pipeline and its context are driven by ONE host thread at a time (entries another thread makes on the context while a scan
+ * is being enqueued are ordered behind by the NEXT scan on the second lane, not by this one).
  * MA_ERR_UNSUPPORTED from _create on a runtime without stream memory operations (hipStreamWaitValue64). One pipeline per context
  * at a time; destroy it before the context. NOT under a profiler that collects hardware counters (rocprofv3 --pmc): it lets one
  * kernel run at a time whatever its stream, the wait on a device word is itself a kernel that polls, and a scan gated on the other
  * stream's early stamp can be let in ahead of the scan that stores it — the same holds for ma_ctx_wait_value, for the stamp
- * hand-off of the overlapped exchanges and for MA_GROUP_SCAN_LANES (whose waits at least are bounded: ma_group_synchronize_for).
+ * hand-off of the overlapped exchanges and for MA_GROUP_SCAN_LANES (their waits at least are bounded: ma_scan_lanes_synchronize_for, ma_group_synchronize_for).
  * Kernel tracing (--kernel-trace) does not serialise and is fine (profiles/r05_lanes_kernel_trace.txt). */
 typedef struct ma_scan_lanes ma_scan_lanes;
 ma_status ma_scan_lanes_create(ma_ctx* ctx, ma_scan_lanes** out_lanes);
@@ -453,7 +461,20 @@ ma_status ma_scan_lanes_sum(ma_scan_lanes* lanes, int32_t format_code, const voi
                             size_t mask_bit_offset, int64_t null_count, void* out_sum, double* out_lo, uint64_t* out_valid_count);
 ma_status ma_scan_lanes_join(ma_scan_lanes* lanes);
 ma_status ma_scan_lanes_synchronize(ma_scan_lanes* lanes);
+/* ma_scan_lanes_synchronize with a deadline — what a host that loops like benches/hotloop_benchmark_avg_std.rs:48-62 should call:
+ * the pipeline's gates are waits across streams, and a wait nobody ends holds a stream for good. Polls both lanes' streams for
+ * at most timeout_ms (<= 0: no deadline, plain ma_scan_lanes_synchronize). Past the deadline it stores all-ones into every
+ * stamp word of the pipeline through a stream of its own in the low priority class (made at creation: its hardware queue is
+ * never behind a held ordinary stream), so that every gate opens and both streams — lane 0 is the CALLER's context — run empty,
+ * waits up to 2 s for that, marks the pipeline broken and returns MA_ERR_DEVICE; the error string names each lane that was
+ * still pending, how many of its scans had finished, and the early stamp its gate was waiting for (have / want). The results of
+ * the scans that were in flight are undefined. A broken pipeline takes no more scans (MA_ERR_DEVICE): destroy it — the context
+ * takes a new one. ma_scan_lanes_is_broken: 0 healthy, 1 broken with both streams empty, 2 broken with a stream still busy
+ * (the device may need a reset; ma_scan_lanes_destroy then leaves what that stream may still use to the process). */
+ma_status ma_scan_lanes_synchronize_for(ma_scan_lanes* lanes, double timeout_ms);
+int32_t ma_scan_lanes_is_broken(ma_scan_lanes* lanes);
 uint64_t ma_scan_lanes_scans(ma_scan_lanes* lanes);
+/* Bounded like ma_group_destroy: MINARROW_HIP_DESTROY_WAIT_MS (10 s) for the scans in flight, then the release above. */
 void ma_scan_lanes_destroy(ma_scan_lanes* lanes);
 
 /* Fold of per-rank (or per-chunk) reduction records after their exchange — the `.sum()` over per-chunk partials of
@@ -1033,16 +1054,6 @@ int32_t ma_group_issue_kind(ma_group* group);
 /* 1 when member from_member's device can address member to_member's device memory (same device, or peer access probed
  * and enabled at creation), 0 when not, -1 for a bad argument. */
 int32_t ma_group_peer_access(ma_group* group, int32_t from_member, int32_t to_member);
-/* TESTING ONLY. Makes the residency and peer checks treat `member` as if its device were HIP device `hip_device`, with
- * (peer_capable != 0) or without peer access between it and every other member; nothing is launched differently. Lets a
- * one-GPU box exercise the refusals a multi-GPU node produces (a chunk resident on the wrong GPU, an owner without a
- * link to the destination). */
-ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable);
-/* TESTING ONLY. The next ma_group_exchange fails on `member` in front of its all-gather, as a lost device would make it: with
- * per-member issue threads the other members have enqueued their collectives by then, so the group aborts every
- * communicator (ncclCommAbort), marks itself broken — ma_group_exchange / ma_group_synchronize return MA_ERR_DEVICE from
- * then on instead of blocking on a collective that cannot complete — until ma_group_rebuild_exchange or its destruction. */
-ma_status ma_group_test_fail_next_exchange(ma_group* group, int32_t member);
 ma_status ma_group_enqueue_sum_i64(ma_group* group, int32_t column, const int64_t* const* chunk_data,
                                    const size_t* chunk_lens, const uint8_t* const* chunk_masks,
                                    const size_t* chunk_mask_offsets);
@@ -1157,16 +1168,6 @@ uint32_t ma_group_flags(ma_group* group);
 ma_status ma_group_set_handoff(ma_group* group, int32_t kind);
 int32_t ma_group_handoff(ma_group* group);
 ma_status ma_group_selftest(ma_group* group, uint32_t what, double timeout_ms, ma_selftest_report* out_report);
-/* TESTING ONLY. The next ma_group_exchange holds `member`'s exchange in front of its all-gather behind a word nobody writes
- * (hipStreamWaitValue64) — what a lost peer or a fabric fault looks like to the waiting host: ma_group_synchronize would
- * block for good, ma_group_synchronize_for returns after its deadline. The abort path (and ma_group_destroy) releases the
- * word, so the stream runs empty. With the host fold the member's scan stream is held. MA_ERR_UNSUPPORTED (at the exchange)
- * on a runtime without stream memory operations. */
-ma_status ma_group_test_stall_next_exchange(ma_group* group, int32_t member);
-/* TESTING ONLY. The next ma_group_exchange flips one word of the records `member` gathered, in front of its fold: finals
- * that are wrong on that member only and no error anywhere — what a host's own check of a set-up step is for. (Host fold: the
- * job's integer finals are flipped.) */
-ma_status ma_group_test_corrupt_next_exchange(ma_group* group, int32_t member);
 /* The sum of ONE column held as many chunks spread over the group's GPUs — a SuperArray, or one column of the batches of a
  * SuperTable at the reference's own batch sizes (BASELINE config 5 with 8192-row batches: 122 000 chunks per 10^9 rows).
  * Chunk i belongs to member i % size and must be resident there; every member sums ITS chunks with one ma_sum_chunks
@@ -1259,7 +1260,11 @@ ma_status ma_comm_sum_exchange_overlapped(ma_comm* comm, int32_t slot, const uin
                                           size_t n_columns, uint64_t* gathered, uint64_t* out_finals);
 /* ma_comm_sum_exchange_overlapped whose exchange stream waits for `*stamp >= stamp_value` (hipStreamWaitValue64) instead of
  * an event recorded on the context's stream: the scans that fill this slot's records must end with a launch that stamps it
- * (ma_sum_fused_stamped). The context's stream then carries nothing but the scans. */
+ * (ma_sum_fused_stamped). The context's stream then carries nothing but the scans. The stamp stays the CALLER's: should the
+ * communicator be aborted while its exchange stream waits on it, the abort releases that wait by storing all-ones into the
+ * word — only while the word is still a live stamp (never into one ma_stamp_free has taken back) — and stores `stamp_value`
+ * back once the streams have run empty; if they never do (ma_comm_is_broken == 2) the word keeps all-ones and must not be
+ * handed to another communicator: take a fresh stamp. */
 ma_status ma_comm_sum_exchange_overlapped_on_stamp(ma_comm* comm, int32_t slot, uint64_t* stamp, uint64_t stamp_value,
                                                    const uint64_t* local_records, size_t slots_per_rank, size_t n_columns,
                                                    uint64_t* gathered, uint64_t* out_finals);
@@ -1287,22 +1292,7 @@ ma_status ma_comm_synchronize_for(ma_comm* comm, double timeout_ms);
 ma_status ma_comm_abort(ma_comm* comm);
 int32_t ma_comm_is_broken(ma_comm* comm);
 ma_status ma_comm_selftest(ma_comm* comm, uint32_t what, double timeout_ms, ma_selftest_report* out_report);
-/* TESTING ONLY: as ma_group_test_stall_next_exchange / _corrupt_next_exchange, for this rank's next ma_comm_sum_exchange* call. */
-ma_status ma_comm_test_stall_next_exchange(ma_comm* comm);
-ma_status ma_comm_test_corrupt_next_exchange(ma_comm* comm);
 
-/* ------------------------------------------------------------------------------------------------
- * Testing hooks. Not part of what a binding needs (ma_group_test_set_member_device above is the other one).
- * ma_test_pow_series evaluates, element by element, the series float Power is built from — the device stand-ins for the
- * host libm calls of `(rhs * lhs.ln()).exp()` (src/kernels/arithmetic/std.rs:153, simd.rs:570,585):
- *   which 0: in = f64 x,  out[i] = ln x           as the f64 Power path computes it (pow_f64_ln)
- *   which 1: in = f32 a,  out[i] = ln a  in f64   as the f32 Power path computes it before rounding to f32 (pow_f32_ln)
- *   which 2: in = f32 y,  out[i] = exp y in f64   as the f32 Power path computes it before rounding to f32 (pow_f32_exp;
- *                                                 |y| <= 150)
- * tests/test_gpu_pow_series.py holds them to tests/golden/pow_series_kat.npz (tools/check_pow_series.py: 265-bit decimal
- * arithmetic). Buffers may be host or device memory.
- * ---------------------------------------------------------------------------------------------- */
-ma_status ma_test_pow_series(ma_ctx* ctx, int32_t which, const void* in, double* out, size_t n);
 
 #ifdef __cplusplus
 } /* extern "C" */

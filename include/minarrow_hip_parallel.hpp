@@ -216,6 +216,9 @@ class ScanLanes {
     }
     void join() const { check(ma_scan_lanes_join(l_)); }
     void synchronize() const { check(ma_scan_lanes_synchronize(l_)); }
+    // the form for a host's loop: past the deadline the gates are released, the pipeline is broken and the error names the lane
+    void synchronize_for(double timeout_ms) const { check(ma_scan_lanes_synchronize_for(l_, timeout_ms)); }
+    int is_broken() const { return ma_scan_lanes_is_broken(l_); }
     uint64_t scans() const { return ma_scan_lanes_scans(l_); }
 
   private:

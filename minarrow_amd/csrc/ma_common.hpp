@@ -159,6 +159,12 @@ struct NoSync {
     ~NoSync();
 };
 bool nosync_active();
+// ma_testhooks.hip: MA_OK when the fault hooks are live in this process (MINARROW_HIP_TEST_HOOKS=1 at load), else
+// MA_ERR_UNSUPPORTED with the reason in the thread's error string. Every ma_*_test_* entry point starts with it.
+ma_status test_hooks_enabled();
+// How many entry points THIS thread has entered so far (every context): the difference around a call a pipeline makes itself is
+// what that call added to ma_ctx::calls, so that a snapshot of the counter can be told from foreign work without a lock.
+uint64_t entries_by_this_thread();
 inline bool is_async(const ma_ctx* ctx) { return ctx->async || nosync_active(); }
 // Waits for the context's stream and turns a latched device condition (dense integer divide by zero) into its status.
 ma_status sync_and_check(ma_ctx* ctx);

@@ -547,7 +547,10 @@ constexpr int kMaxHeld = 8;
 thread_local Held t_held[kMaxHeld];
 thread_local int t_n_held = 0;
 thread_local int t_nosync = 0;
+thread_local uint64_t t_entries = 0;
 }  // namespace
+
+uint64_t entries_by_this_thread() { return t_entries; }
 
 NoSync::NoSync() { ++t_nosync; }
 NoSync::~NoSync() { --t_nosync; }
@@ -559,6 +562,7 @@ Enter::Enter(ma_ctx*& ctx, bool primary_only) {
     if (ctx == nullptr) return;  // the entry point reports the NULL itself
     ma_ctx* root = ctx->parent ? ctx->parent : ctx;
     root->calls.fetch_add(1, std::memory_order_relaxed);
+    ++t_entries;
     for (int i = 0; i < t_n_held; ++i)
         if (t_held[i].root == root) {  // a composed entry point calling its parts: same lane, no second lock
             ctx = t_held[i].lane;

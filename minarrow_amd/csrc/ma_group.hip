@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <map>
 
+#include "minarrow_hip_testing.h"
+
 #include "ma_group.hpp"
 
 using namespace ma;
@@ -826,6 +828,7 @@ const char* ma_group_exchange_note(ma_group* group) { return group ? group->note
 
 ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32_t hip_device, int32_t peer_capable) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_TRY(test_hooks_enabled());
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     const size_t G = group->ctxs.size();
     MA_REQUIRE(member >= 0 && (size_t)member < G, MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
@@ -840,6 +843,7 @@ ma_status ma_group_test_set_member_device(ma_group* group, int32_t member, int32
 
 ma_status ma_group_test_fail_next_exchange(ma_group* group, int32_t member) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_TRY(test_hooks_enabled());
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     group->fail_member = member;
@@ -1234,6 +1238,8 @@ ma_status ma_group_mark_elapsed_ms(ma_group* group, int32_t member, int32_t from
                "mark index out of range");
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_REQUIRE(group->mark_lane.size() == (size_t)MA_CTX_MAX_MARKS, MA_ERR_INVALID_ARGUMENT, "no marks have been recorded (ma_group_mark_next_scan)");
+    MA_REQUIRE(group->mark_lane[(size_t)from_index] != 255 && group->mark_lane[(size_t)to_index] != 255, MA_ERR_INVALID_ARGUMENT,
+               "these marks were recorded on second scan lanes that ma_group_set_scan_lanes(2) has replaced since");
     MA_REQUIRE(group->mark_lane[(size_t)from_index] == group->mark_lane[(size_t)to_index], MA_ERR_INVALID_ARGUMENT,
                "marks %d and %d were recorded on different scan lanes", from_index, to_index);
     ma_ctx* c = (group->mark_lane[(size_t)from_index] && group->lanes2) ? group->scan2[(size_t)member] : group->ctxs[(size_t)member];

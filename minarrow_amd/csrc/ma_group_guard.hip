@@ -20,6 +20,8 @@
 #include <memory>
 #include <mutex>
 
+#include "minarrow_hip_testing.h"
+
 #include "ma_group.hpp"
 
 using namespace ma;
@@ -295,8 +297,13 @@ void release_waits(ma_group* g, bool stamps_too) {
     }
     if (stamps_too)
         for (int k = 0; k < 2; ++k)
-            for (size_t i = 0; i < n && i < g->stamp[k].size(); ++i)
-                if (g->stamp[k][i]) write_word(g, i, g->stamp[k][i], &kAll);
+            for (size_t i = 0; i < n && i < g->stamp[k].size(); ++i) {
+                if (!g->stamp[k][i]) continue;
+                write_word(g, i, g->stamp[k][i], &kAll);
+                // the scan lanes' gates wait on word 1 of the line (the early stamp): a lane parked behind a step that will never
+                // run would otherwise keep the group from ever running empty
+                if (g->lanes2) write_word(g, i, g->stamp[k][i] + 1, &kAll);
+            }
 }
 
 // The order matters. First everything a stream of the group may be HELD behind is released and the streams get a moment:
@@ -377,7 +384,15 @@ struct SelfTest {
     ma_selftest_report* rep;
     std::string text;
     std::vector<std::vector<uint64_t>> blocks;  // per member: kColumns tagged records
+    // ... and their pinned twins, the source of the async uploads (a copy from pageable memory blocks inside the runtime behind a
+    // stuck stream, in front of every deadline); one block per form and member, kept until the test ends — or, on a group that
+    // ended up broken, for good: a copy still queued behind a stuck stream must not read freed memory
+    std::vector<uint64_t*> pinned;
     uint64_t round = 0;
+    ~SelfTest() {
+        if (g->broken) return;
+        for (uint64_t* p : pinned) (void)hipHostFree(p);
+    }
 
     void say(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
         char buf[400];
@@ -425,7 +440,11 @@ struct SelfTest {
             }
             MA_HIP(hipSetDevice(g->ctxs[i]->device));
             hipStream_t fill = scan_ctx(g, set, i)->stream;  // the stream that fills this record set (the second lane for set 1)
-            MA_HIP(hipMemcpyAsync(local, blocks[i].data(), kBlockWords * 8, hipMemcpyHostToDevice, fill));
+            uint64_t* stage = nullptr;
+            MA_HIP(hipHostMalloc((void**)&stage, kBlockWords * 8, hipHostMallocPortable));
+            pinned.push_back(stage);
+            memcpy(stage, blocks[i].data(), kBlockWords * 8);
+            MA_HIP(hipMemcpyAsync(local, stage, kBlockWords * 8, hipMemcpyHostToDevice, fill));
             if (want_stamp) {
                 hipLaunchKernelGGL(stamp_store_kernel, dim3(1), dim3(1), 0, fill, g->stamp[set][i], seq);
                 MA_HIP(hipGetLastError());
@@ -510,15 +529,24 @@ struct SelfTest {
         const size_t n = g->ctxs.size();
         constexpr size_t kBytes = (size_t)1 << 20;
         std::vector<void*> a(n, nullptr), b(n, nullptr), c(n, nullptr);
-        std::vector<uint64_t> pattern(kBytes / 8), back(kBytes / 8);
+        // pinned staging: an async copy from / into pageable memory blocks INSIDE the runtime until it has run — behind a stuck
+        // stream that is for good, in front of the deadline below — and would land in freed memory if it ran after a timeout
+        uint64_t *pattern = nullptr, *back = nullptr;
+        if (hipHostMalloc((void**)&pattern, kBytes, hipHostMallocPortable) != hipSuccess ||
+            hipHostMalloc((void**)&back, kBytes, hipHostMallocPortable) != hipSuccess) {
+            if (pattern) (void)hipHostFree(pattern);
+            return hip_fail(hipGetLastError(), "self-test staging buffers", __FILE__, __LINE__);
+        }
         ma_status st = MA_OK;
         int slow_i = -1, slow_j = -1;
-        auto cleanup = [&] {
+        auto cleanup = [&] {  // never on a broken group: a stuck stream may still use the buffers — they go with the process
             for (size_t i = 0; i < n; ++i) {
                 (void)hipSetDevice(g->ctxs[i]->device);
                 for (void* p : {a[i], b[i], c[i]})
                     if (p) (void)hipFree(p);
             }
+            (void)hipHostFree(pattern);
+            (void)hipHostFree(back);
         };
         for (size_t i = 0; i < n && st == MA_OK; ++i)
             for (size_t j = 0; j < n && st == MA_OK; ++j) {
@@ -535,15 +563,15 @@ struct SelfTest {
                         return hip_fail(e, "self-test peer buffers", __FILE__, __LINE__);
                     }
                 }
-                for (size_t w = 0; w < pattern.size(); ++w) pattern[w] = (w * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)i << 56) ^ ((uint64_t)j << 48);
+                for (size_t w = 0; w < kBytes / 8; ++w) pattern[w] = (w * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)i << 56) ^ ((uint64_t)j << 48);
                 hipStream_t s = g->ctxs[i]->stream;
                 hipError_t e = hipSetDevice(di);
                 const auto t0 = std::chrono::steady_clock::now();
-                if (e == hipSuccess) e = hipMemcpyAsync(a[i], pattern.data(), kBytes, hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(a[i], pattern, kBytes, hipMemcpyHostToDevice, s);
                 if (e == hipSuccess) e = hipMemsetAsync(c[i], 0, kBytes, s);
                 if (e == hipSuccess) e = hipMemcpyPeerAsync(b[j], dj, a[i], di, kBytes, s);  // i -> j over the link ...
                 if (e == hipSuccess) e = hipMemcpyPeerAsync(c[i], di, b[j], dj, kBytes, s);  // ... and back
-                if (e == hipSuccess) e = hipMemcpyAsync(back.data(), c[i], kBytes, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(back, c[i], kBytes, hipMemcpyDeviceToHost, s);
                 if (e != hipSuccess) {
                     cleanup();
                     return hip_fail(e, "self-test peer copy", __FILE__, __LINE__);
@@ -553,7 +581,7 @@ struct SelfTest {
                 st = wait_one(i, s, what);
                 if (st != MA_OK) break;
                 const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                if (memcmp(back.data(), pattern.data(), kBytes) != 0) {
+                if (memcmp(back, pattern, kBytes) != 0) {
                     rep->failed_member = (int)i;
                     say("peer copy %d -> %d -> %d returned different bytes", di, dj, di);
                     set_error("self-test: the peer-copy round trip %d -> %d -> %d returned different bytes", di, dj, di);
@@ -697,10 +725,16 @@ ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on) {
         for (size_t i = 0; i < group->ctxs.size(); ++i) {
             ma_ctx* fresh = nullptr;
             MA_TRY(create_ctx_in_class(group->ctxs[i]->ordinal, 0, &fresh));
-            MA_TRY(ma_ctx_set_async(fresh, 1));
+            const ma_status st = ma_ctx_set_async(fresh, 1);
+            if (st != MA_OK) {
+                ma_ctx_destroy(fresh);
+                return st;
+            }
             ma_ctx_destroy(group->scan2[i]);
             group->scan2[i] = fresh;
         }
+        for (uint8_t& lane : group->mark_lane)  // the marks the old lane contexts recorded went with them
+            if (lane == 1) lane = 255;
     }
     group->lanes_on = on != 0;
     group->prev_set = -1;
@@ -750,6 +784,7 @@ ma_status ma_group_rebuild_exchange(ma_group* group, uint32_t flags) {
 
 ma_status ma_group_test_stall_next_exchange(ma_group* group, int32_t member) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_TRY(test_hooks_enabled());
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     group->stall_member = member;
@@ -758,6 +793,7 @@ ma_status ma_group_test_stall_next_exchange(ma_group* group, int32_t member) {
 
 ma_status ma_group_test_corrupt_next_exchange(ma_group* group, int32_t member) {
     MA_REQUIRE(group != nullptr, MA_ERR_INVALID_ARGUMENT, "group is NULL");
+    MA_TRY(test_hooks_enabled());
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     MA_REQUIRE(member >= 0 && (size_t)member < group->ctxs.size(), MA_ERR_INVALID_ARGUMENT, "member %d out of range", member);
     group->corrupt_member = member;
@@ -789,7 +825,7 @@ ma_status ma_group_selftest(ma_group* group, uint32_t what, double timeout_ms, m
         if (api && api->CommCount && !g->comms.empty() && g->comms[0] && api->CommCount(g->comms[0], &ranks) == ncclSuccess)
             rep->rccl_ranks = ranks;
     }
-    SelfTest t{g, timeout_ms, rep, {}, {}, 0};
+    SelfTest t{g, timeout_ms, rep, {}, {}, {}, 0};
     t.say("%zu members on %d device(s), %s exchange%s", n, rep->n_devices, g->use_rccl ? "RCCL" : "host-fold",
           g->use_rccl ? (g->overlap ? " overlapped on side streams" : " on the scan streams") : "");
     // whatever the host had in flight first, under the same deadline

@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+#include "minarrow_hip_testing.h"
+
 #include "ma_rccl.hpp"
 
 namespace ma {
@@ -140,7 +142,11 @@ struct ma_comm {
     bool stall_next = false, corrupt_next = false, stall_armed = false;
     uint64_t* stall_word = nullptr;
     uint64_t stall_seq = 0, stall_release = 0;
-    uint64_t* last_stamp = nullptr;  // the word the last overlapped-on-stamp exchange made the exchange stream wait on
+    // The word the last overlapped-on-stamp exchange made the exchange stream wait on, and the value it waits for. The CALLER
+    // owns that word: the abort path writes into it only while the library still knows it as a live stamp (ma_stamp_is_signal
+    // >= 0: not freed since), and puts the awaited sequence back once the streams have run empty.
+    uint64_t* last_stamp = nullptr;
+    uint64_t last_stamp_value = 0;
     hipStream_t rescue = nullptr;    // nothing else is ever enqueued here: release values are written through it
 };
 
@@ -205,7 +211,10 @@ void comm_release_waits(ma_comm* comm, bool stamps_too) {
         comm_write_word(comm, comm->stall_word, &comm->stall_release);
         comm->stall_armed = false;
     }
-    if (stamps_too && comm->last_stamp) comm_write_word(comm, comm->last_stamp, &kAll);
+    if (stamps_too && comm->last_stamp) {
+        if (ma_stamp_is_signal(comm->last_stamp) >= 0) comm_write_word(comm, comm->last_stamp, &kAll);
+        else comm->last_stamp = nullptr;  // freed by its owner since: nothing of ours can still wait on it, nothing is written
+    }
 }
 
 // True when the context's stream and the exchange stream have run empty within timeout_ms; *which = the one still pending.
@@ -269,6 +278,13 @@ void comm_abort(ma_comm* comm) {
     guard_log("rank %d abort: waiting up to 5 s for the streams", comm->rank);
     comm->drained = comm_wait_streams(comm, 5000.0, &which, &e);
     guard_log("rank %d abort: streams %s", comm->rank, comm->drained ? "have run empty" : "are STILL busy");
+    if (comm->drained && comm->last_stamp && ma_stamp_is_signal(comm->last_stamp) >= 0) {
+        // nothing waits on the caller's stamp any more: it gets the sequence that was being waited for back instead of the
+        // all-ones that released the wait — a stamp that kept all-ones would satisfy every wait of a later communicator at once
+        comm_write_word(comm, comm->last_stamp, &comm->last_stamp_value);
+        if (comm->rescue) (void)hipStreamSynchronize(comm->rescue);  // its own queue, two 8-byte writes: cannot be held
+    }
+    comm->last_stamp = nullptr;
     comm->broken = true;
     comm->stall_next = comm->corrupt_next = false;
 }
@@ -471,6 +487,7 @@ static ma_status exchange_overlapped(ma_comm* comm, int32_t slot, uint64_t* stam
         if (hipStreamWaitValue64(side->stream, stamp, stamp_value, hipStreamWaitValueGte, ~(uint64_t)0) == hipSuccess) {
             waited = true;
             comm->last_stamp = stamp;
+            comm->last_stamp_value = stamp_value;
         } else {  // a runtime without stream memory operations: the event below orders the same thing (the stamped launch is
             (void)hipGetLastError();  // already on the context's stream), from now on without trying again
             comm->no_wait_value = true;
@@ -581,12 +598,14 @@ int32_t ma_comm_is_broken(ma_comm* comm) { return !comm || !comm->broken ? 0 : (
 
 ma_status ma_comm_test_stall_next_exchange(ma_comm* comm) {
     MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_TRY(test_hooks_enabled());
     comm->stall_next = true;
     return MA_OK;
 }
 
 ma_status ma_comm_test_corrupt_next_exchange(ma_comm* comm) {
     MA_REQUIRE(comm != nullptr, MA_ERR_INVALID_ARGUMENT, "comm is NULL");
+    MA_TRY(test_hooks_enabled());
     comm->corrupt_next = true;
     return MA_OK;
 }

@@ -14,6 +14,7 @@ from pathlib import Path
 _ROOT = Path(__file__).resolve().parent
 LIB_PATH = _ROOT / "lib" / "libminarrow_hip.so"
 HEADER_PATH = _ROOT.parent / "include" / "minarrow_hip.h"
+TESTING_HEADER_PATH = _ROOT.parent / "include" / "minarrow_hip_testing.h"  # the fault hooks: inert unless MINARROW_HIP_TEST_HOOKS=1 at load
 
 MA_OK = 0
 MA_ERR_LENGTH_MISMATCH = 1
@@ -111,7 +112,7 @@ def load_library() -> C.CDLL:
     if lib.ma_abi_version() != header_abi_version():
         raise LibraryNotBuilt(f"{LIB_PATH} has ABI version {lib.ma_abi_version()}, include/minarrow_hip.h declares "
                               f"{header_abi_version()}: rebuild it (make -C minarrow_amd/csrc)")
-    for name, (ret, args) in parse_header().items():
+    for name, (ret, args) in {**parse_header(), **parse_header(TESTING_HEADER_PATH)}.items():
         fn = getattr(lib, name)
         if ret.replace(" ", "") == "constchar*":
             fn.restype = C.c_char_p

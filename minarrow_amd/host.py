@@ -792,6 +792,20 @@ class ScanLanes:
     def synchronize(self) -> None:
         ffi.check(self.lib.ma_scan_lanes_synchronize(self.handle))
 
+    def synchronize_for(self, timeout_ms: float) -> None:
+        """ma_scan_lanes_synchronize_for: past the deadline every gate of the pipeline is released, the pipeline is broken
+        (is_broken; destroy it) and MinarrowHipError(MA_ERR_DEVICE) names the lane and the sequence that was waited for."""
+        ffi.check(self.lib.ma_scan_lanes_synchronize_for(self.handle, float(timeout_ms)))
+
+    @property
+    def is_broken(self) -> int:
+        """0 healthy, 1 broken with both streams empty, 2 broken with a stream still busy."""
+        return int(self.lib.ma_scan_lanes_is_broken(self.handle))
+
+    def test_hold_next_scan(self) -> None:
+        """TESTING ONLY (include/minarrow_hip_testing.h): the next scan sits behind a gate that never opens."""
+        ffi.check(self.lib.ma_scan_lanes_test_hold_next_scan(self.handle))
+
     @property
     def scans(self) -> int:
         return int(self.lib.ma_scan_lanes_scans(self.handle))

@@ -7,6 +7,9 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
+# The library's fault hooks (include/minarrow_hip_testing.h) act only when this is in the environment when the library is LOADED:
+# the test sessions — and the bench.py / rank processes they start — are the hosts that want them.
+os.environ.setdefault("MINARROW_HIP_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

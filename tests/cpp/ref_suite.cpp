@@ -16,6 +16,7 @@
 #include "minarrow_hip.hpp"
 #include "minarrow_hip_routing.hpp"
 #include "minarrow_hip_parallel.hpp"
+#include "minarrow_hip_testing.h"  // the fault hooks (live: the suite is started with MINARROW_HIP_TEST_HOOKS=1)
 
 using namespace ma;
 using Op = ArithmeticOperator;

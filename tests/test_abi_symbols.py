@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = ffi.load_library()
     missing = [name for name in ffi.parse_header() if not hasattr(lib, name)]
     assert not missing, missing
-    assert lib.ma_abi_version() == ffi.header_abi_version() == 4
+    assert lib.ma_abi_version() == ffi.header_abi_version() == 5
 
 
 def test_every_entry_point_cites_the_reference():
@@ -75,8 +75,39 @@ def test_library_exports_nothing_but_the_c_abi():
 
     out = subprocess.run(["nm", "-D", "--defined-only", str(ffi.LIB_PATH)], capture_output=True, text=True, check=True).stdout
     exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
-    declared = set(ffi.parse_header())
+    declared = set(ffi.parse_header()) | set(ffi.parse_header(ffi.TESTING_HEADER_PATH))
     assert exported == declared, (sorted(exported - declared)[:5], sorted(declared - exported)[:5])
+
+
+def test_fault_hooks_live_apart_from_the_product_abi_and_are_inert_by_default():
+    """The fault hooks (stall / corrupt / fail an exchange, pretend a member lives elsewhere, hold a scan, the Power series) are
+    declared in include/minarrow_hip_testing.h, not in the product header and not in the Rust binding, and do nothing unless
+    MINARROW_HIP_TEST_HOOKS=1 was set when the library was loaded."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    product, testing = set(ffi.parse_header()), set(ffi.parse_header(ffi.TESTING_HEADER_PATH))
+    assert not product & testing
+    assert not [n for n in product if "_test_" in n or n.startswith("ma_test_")], "a hook is declared in the product header"
+    assert all("_test_" in n or n.startswith("ma_test_") for n in testing) and len(testing) >= 9
+    assert "TESTING ONLY" not in ffi.HEADER_PATH.read_text()
+    binding = (Path(__file__).resolve().parent.parent / "bindings" / "minarrow_hip_sys.rs").read_text()
+    assert not [n for n in testing if n in binding]
+    # a NULL handle is refused as such only when the hooks are live; by default "disabled" comes first... but argument checks are
+    # allowed to come first: use the one hook that needs no handle state — every hook reports MA_ERR_UNSUPPORTED when disabled
+    code = ("import ctypes as C; from minarrow_amd import ffi; l = ffi.load_library(); "
+            "st = l.ma_test_pow_series(1, 0, None, None, 0); print(l.ma_test_hooks_enabled(), st, l.ma_last_error_string().decode())")
+    root = str(Path(__file__).resolve().parent.parent)
+    off = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root,
+                         env={k: v for k, v in os.environ.items() if k != "MINARROW_HIP_TEST_HOOKS"})
+    assert off.returncode == 0, off.stderr
+    enabled, status, message = off.stdout.strip().split(" ", 2)
+    assert (enabled, int(status)) == ("0", ffi.MA_ERR_UNSUPPORTED) and "MINARROW_HIP_TEST_HOOKS=1" in message
+    on = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root,
+                        env=dict(os.environ, MINARROW_HIP_TEST_HOOKS="1"))
+    assert on.returncode == 0 and on.stdout.split()[:2] == ["1", "0"], on.stdout + on.stderr  # n == 0: nothing to do, MA_OK
 
 
 def test_rust_binding_file_covers_every_entry_point():

@@ -157,3 +157,128 @@ def test_a_pipelined_single_column_sum_refuses_host_resident_operands(ctx):
         lanes.sum("l", dev, 4096, out.ptr, out_count=out.ptr + 8)
         lanes.synchronize()
         assert [int(x) for x in out.download(np.uint64, 2)] == [4096 * 4095 // 2, 4096]
+
+
+def test_two_hundred_gated_scans_while_more_streams_than_hardware_queues_are_busy():
+    """The one-GPU case of the queue-aliasing hazard: the runtime maps a process's streams onto 4 hardware queues, so with 8 other
+    contexts stepping through their own scans the pipeline's two lanes share queues with them — a gate (a wait across streams)
+    then sits in a queue in front of, or behind, somebody else's work. Every gate waits for work enqueued BEFORE it, so the
+    pipeline must still drain, under a deadline, with every pass's own results."""
+    import threading
+
+    rows = (1 << 22) + 77
+    tri = rows * (rows - 1) // 2
+    others = [Context(0) for _ in range(8)]
+    stop = threading.Event()
+    errors = []
+
+    def busy(c, seed):
+        try:
+            c.set_async(True)
+            col = c.alloc(rows * 8)
+            out = c.alloc(64)
+            c.synth_iota("i64", col, rows, seed)
+            while not stop.is_set():
+                for _ in range(20):
+                    c.sum_into("i64", col, rows, out_sum=out.ptr, out_count=out.ptr + 8)
+                c.synchronize()
+                got = out.download(np.int64, 2)
+                if (int(got[0]), int(got[1])) != (tri + seed * rows, rows):
+                    errors.append((seed, got.tolist()))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=busy, args=(c, k)) for k, c in enumerate(others)]
+    try:
+        with Context(0) as ctx:
+            ctx.set_async(True)
+            ints, flts = ctx.alloc(rows * 8), ctx.alloc(rows * 8)
+            ctx.synth_iota("i64", ints, rows, 0)
+            ctx.synth_iota("f64", flts, rows, 0)
+            rec = ctx.alloc(64 * 200)
+            ctx.dev_memset(rec, 0, 64 * 200)
+            ctx.synchronize()
+            [t.start() for t in threads]
+            with ScanLanes(ctx) as lanes:
+                for k in range(200):
+                    lanes.sum_fused([("l", ints, rows, rec.ptr + 64 * k), ("g", flts, rows, rec.ptr + 64 * k + 16)])
+                    if k % 50 == 49:
+                        lanes.synchronize_for(30_000)
+                assert lanes.scans == 200 and lanes.is_broken == 0
+            stop.set()
+            [t.join(timeout=60) for t in threads]
+            assert not any(t.is_alive() for t in threads) and not errors, errors[:3]
+            w = rec.download(np.uint64, 8 * 200).reshape(200, 8)
+            assert (w[:, 0] == tri).all() and (w[:, 1] == rows).all() and (w[:, 4] == rows).all()
+            hi_lo = w[:, 2:4].copy().view(np.float64)
+            assert (hi_lo.sum(axis=1) == float(tri)).all()  # < 2^53: exact
+    finally:
+        stop.set()
+        for c in others:
+            c.close()
+
+
+def test_a_gate_nobody_opens_is_an_error_within_the_deadline_not_a_hung_host():
+    """ma_scan_lanes_synchronize_for: a scan that never starts (the hold hook: a word nobody writes) keeps every later scan behind
+    its early stamp. The wait returns after its deadline with an error that names the lane and the sequence, the gates have been
+    released, both streams have run empty — the caller's context, whose stream is lane 0, is usable at once — and the pipeline
+    takes no more scans; destroying it does not block; the context takes a new one."""
+    import time
+
+    from minarrow_amd import ffi
+
+    rows = (1 << 22) + 5
+    tri = rows * (rows - 1) // 2
+    with Context(0) as ctx:
+        ints, flts = ctx.alloc(rows * 8), ctx.alloc(rows * 8)
+        ctx.synth_iota("i64", ints, rows, 0)
+        ctx.synth_iota("f64", flts, rows, 0)
+        rec = ctx.alloc(64 * 8)
+        ctx.dev_memset(rec, 0, 64 * 8)
+        for held_scan in (1, 2):  # the held scan on the pipeline's own stream, then on the caller's
+            lanes = ScanLanes(ctx)
+            cols = lambda k: [("l", ints, rows, rec.ptr + 64 * k), ("g", flts, rows, rec.ptr + 64 * k + 16)]  # noqa: E731
+            lanes.sum_fused(cols(0))
+            if held_scan == 2:
+                lanes.sum_fused(cols(1))
+            lanes.synchronize_for(20_000)
+            lanes.test_hold_next_scan()
+            for k in range(2, 6):
+                lanes.sum_fused(cols(k))
+            t0 = time.perf_counter()
+            with pytest.raises(ffi.MinarrowHipError) as e:
+                lanes.synchronize_for(300)
+            waited = time.perf_counter() - t0
+            text = str(e.value)
+            assert e.value.status == ffi.MA_ERR_DEVICE and "did not finish within 300 ms" in text and "lane " in text, text
+            assert "early stamp" in text and "of sequence" in text and "have run empty" in text, text
+            assert 0.28 < waited < 5.0 and lanes.is_broken == 1, (waited, lanes.is_broken)
+            with pytest.raises(ffi.MinarrowHipError) as e2:
+                lanes.sum_fused(cols(7))
+            assert e2.value.status == ffi.MA_ERR_DEVICE and "destroy it" in str(e2.value)
+            with pytest.raises(ffi.MinarrowHipError):
+                lanes.synchronize()
+            t0 = time.perf_counter()
+            lanes.close()
+            assert time.perf_counter() - t0 < 2.0
+            assert ctx.sum("i64", ints, rows) == (tri, rows)  # the context itself is fine
+            with ScanLanes(ctx) as again:  # ... and takes a new pipeline
+                again.sum_fused(cols(6))
+                again.synchronize_for(20_000)
+            _check(rec, 6, tri, rows, float(tri))
+
+
+def test_the_fault_hooks_are_inert_in_a_process_that_did_not_ask_for_them():
+    """MINARROW_HIP_TEST_HOOKS is read when the library is loaded: without it the hold hook refuses, and nothing is held."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    code = ("from minarrow_amd import ffi\nfrom minarrow_amd.host import Context, ScanLanes\n"
+            "with Context(0) as c:\n    with ScanLanes(c) as l:\n        st = l.lib.ma_scan_lanes_test_hold_next_scan(l.handle)\n"
+            "        print(st, l.lib.ma_test_hooks_enabled())\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(Path(__file__).resolve().parent.parent),
+                       env={k: v for k, v in os.environ.items() if k != "MINARROW_HIP_TEST_HOOKS"})
+    assert r.returncode == 0 and r.stdout.split() == ["3", "0"], r.stdout + r.stderr  # MA_ERR_UNSUPPORTED
