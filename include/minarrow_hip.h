@@ -144,7 +144,17 @@ int32_t ma_ctx_lane_count(ma_ctx* ctx);
 ma_status ma_ctx_set_blocks_per_cu(ma_ctx* ctx, int32_t blocks_per_cu);
 /* Tuning harness: absolute workgroup count for the streaming kernels (0 = built-in default). */
 ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups);
-/* Kernel variant selector used by the tuning harness (0 = default). See DESIGN.md §kernels. */
+/* Forces one of two PRODUCT paths that the library otherwise picks by the size or shape of its input, so that a test (or a host
+ * that knows better) reaches the path a 10^9-row input takes with an input a CPU check can follow. 0 = the library's own choice.
+ * The six FORM bits, live in every build:
+ *     16 / 32   SuperArray ops: the 4 x 16-byte / the 8 x 16-byte tile per lane, whatever the chunk lengths
+ *    128 / 256  chunk lists (consolidate, SuperArray ops): the tile form (one searched table) / the chunk-per-workgroup form
+ *  16384        ma_sum_columns: never the fused few-long-columns scan (the general two-launch path)
+ *  65536        ma_sum_columns: the fused few-long-columns scan whatever the total size
+ * Any other bit is a TUNING form — an older launch shape, another unroll depth or load pacing, the piece-interleaved mapping,
+ * the fenced publish, the early stamp's trigger: measured against the defaults and not kept (profiles/HISTORY.md). Those exist
+ * only in a library built with `make -C minarrow_amd/csrc TUNING=1` (build/tuning/libminarrow_hip.so, what tools/ sweeps load);
+ * the shipped library does not contain their kernels and returns MA_ERR_UNSUPPORTED for them instead of silently running a slower form. */
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant);
 /* Host-resident (pageable) operands of the elementwise entry points and of the sum / mean reductions — a Rust &[T] /
  * Vec64<T> that was not allocated with ma_alloc64_pinned; the reference's kernels read such slices in place

@@ -541,8 +541,13 @@ constexpr int clamp_unroll(int unroll, bool masked) {
 
 template <typename T, int OP, int KIND, bool MASKED>
 static void launch_vec(ma_ctx* ctx, const BinArgs<T>& a, int grid, int unroll) {
-    if (unroll == 8) hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    if constexpr (MA_TUNING) {  // the 4-deep tile is a tuning form (ctx variant unroll = 4): not in the shipped library
+        if (unroll != 8) {
+            hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((binary_vec_kernel<T, OP, KIND, MASKED, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
 template <typename T, int OP, bool MASKED>
@@ -591,14 +596,14 @@ ma_status enqueue_binary(ma_ctx* ctx, BinArgs<T> a, bool fma, bool masked, bool 
     // (a(+)b 3.92 ms, a(+)scalar 2.59 ms, fma 5.36 ms at 10^9 f64 rows; device-to-device spread is ~10 %).
     int unroll = 8;
     int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 6;
-    switch ((ctx->variant >> 1) & 7) {
+    switch ((tuning_variant(ctx) >> 1) & 7) {
         case 2: unroll = 4; break;
         case 3: unroll = 8; break;
         default: break;
     }
     if (fma) {
         unroll = 8;
-        switch ((ctx->variant >> 1) & 7) {
+        switch ((tuning_variant(ctx) >> 1) & 7) {
             case 1: unroll = 2; break;
             case 2: unroll = 4; break;
             default: break;
@@ -629,10 +634,15 @@ ma_status enqueue_binary(ma_ctx* ctx, BinArgs<T> a, bool fma, bool masked, bool 
         if (fma) {
             if constexpr (!kInt) {
 #define MA_FMA_LAUNCH(M, U) hipLaunchKernelGGL((fma_vec_kernel<T, M, U>), dim3(grid), dim3(kBlock), 0, ctx->stream, a)
-                if (masked) {
-                    if (unroll == 8) MA_FMA_LAUNCH(true, 8); else if (unroll == 2) MA_FMA_LAUNCH(true, 2); else MA_FMA_LAUNCH(true, 4);
-                } else {
-                    if (unroll == 8) MA_FMA_LAUNCH(false, 8); else if (unroll == 2) MA_FMA_LAUNCH(false, 2); else MA_FMA_LAUNCH(false, 4);
+                if constexpr (MA_TUNING) {
+                    if (masked) {
+                        if (unroll == 2) MA_FMA_LAUNCH(true, 2); else if (unroll == 4) MA_FMA_LAUNCH(true, 4);
+                    } else {
+                        if (unroll == 2) MA_FMA_LAUNCH(false, 2); else if (unroll == 4) MA_FMA_LAUNCH(false, 4);
+                    }
+                }
+                if (unroll == 8) {
+                    if (masked) MA_FMA_LAUNCH(true, 8); else MA_FMA_LAUNCH(false, 8);
                 }
 #undef MA_FMA_LAUNCH
             }

@@ -522,10 +522,15 @@ static size_t launch_eq_mask_vec(ma_ctx* ctx, const T* d, size_t n, T field_mask
 template <typename T>
 static void launch_eq_mask(ma_ctx* ctx, const T* d, size_t n, T field_mask, T target, uint64_t* ow) {
     // variant bit 2048: 4 loads per lane on 8 workgroups per CU (round 2's shape) for A/B; blocks_per_cu overrides the grid
-    const bool old_shape = (ctx->variant & 2048) != 0;
+    const bool old_shape = (tuning_variant(ctx) & 2048) != 0;
     const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (old_shape ? 8 : 1);  // with a tile requested ahead: one, for every width
-    size_t done = old_shape ? launch_eq_mask_vec<T, 4>(ctx, d, n, field_mask, target, ow, bpc)
-                            : launch_eq_mask_vec<T, 8>(ctx, d, n, field_mask, target, ow, bpc);
+    size_t done = 0;
+    if constexpr (MA_TUNING) {
+        done = old_shape ? launch_eq_mask_vec<T, 4>(ctx, d, n, field_mask, target, ow, bpc)
+                         : launch_eq_mask_vec<T, 8>(ctx, d, n, field_mask, target, ow, bpc);
+    } else {
+        done = launch_eq_mask_vec<T, 8>(ctx, d, n, field_mask, target, ow, bpc);
+    }
     if (done < n) {
         const size_t n_words = ((n - done) + 63) >> 6;
         int grid = grid_for(ctx, (n_words + kWaves - 1) / kWaves, 8);

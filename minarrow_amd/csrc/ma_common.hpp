@@ -159,6 +159,26 @@ struct NoSync {
     ~NoSync();
 };
 bool nosync_active();
+
+// ---- kernel-form selectors (ma_ctx_set_variant) -------------------------------------------------------------------------------
+// Two kinds of bits share ma_ctx::variant. FORM bits force one of two PRODUCT paths that the library otherwise picks by size or
+// shape, so that a test can reach the path a 10^9-row input takes with an input a CPU check can follow: they are live in every
+// build (kFormBits, six of them; include/minarrow_hip.h lists them). TUNING bits select forms that were measured against the
+// defaults and not kept — older launch shapes, other unroll depths and load pacings, the fenced publish, the piece-interleaved
+// mapping, the stamp's trigger: they exist only in a library built with -DMA_TUNING=1 (make -C minarrow_amd/csrc TUNING=1 -> build/
+// tuning/libminarrow_hip.so, what tools/ sweeps load through MINARROW_HIP_LIB). In the shipped build tuning_variant() is the
+// constant 0: the branches fold away, their kernels are never instantiated, and ma_ctx_set_variant refuses the bits
+// (MA_ERR_UNSUPPORTED) instead of letting a host select a slower kernel silently.
+#ifndef MA_TUNING
+#define MA_TUNING 0
+#endif
+constexpr int kFormBits = 16 | 32 | 128 | 256 | 16384 | 65536;
+inline int form_variant(const ma_ctx* ctx) { return ctx->variant & kFormBits; }
+#if MA_TUNING
+inline int tuning_variant(const ma_ctx* ctx) { return ctx->variant; }
+#else
+constexpr int tuning_variant(const ma_ctx*) { return 0; }
+#endif
 // ma_testhooks.hip: MA_OK when the fault hooks are live in this process (MINARROW_HIP_TEST_HOOKS=1 at load), else
 // MA_ERR_UNSUPPORTED with the reason in the thread's error string. Every ma_*_test_* entry point starts with it.
 ma_status test_hooks_enabled();

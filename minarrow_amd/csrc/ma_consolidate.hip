@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void concat_bits_chunk_kernel(const MaskDes
 // chunk starts inside a word: `has_join`, decided by the host); otherwise concat_mask_kernel.
 static void launch_concat_bits(ma_ctx* ctx, const MaskDesc* compact, size_t n_chunks, size_t total, uint64_t* ow, bool has_join) {
     const bool many_short = n_chunks >= 1024 && total / n_chunks <= ((size_t)1 << 20) && n_chunks < ((size_t)1 << 31);
-    if (!many_short || (ctx->variant & 128)) {  // variant bit 128: the searching form (A/B, tests)
+    if (!many_short || (form_variant(ctx) & 128)) {  // variant bit 128: the searching form (A/B, tests)
         launch_concat_mask(ctx, nullptr, n_chunks, total, ow, compact);
         return;
     }
@@ -538,7 +538,7 @@ static ma_status concat_column_by_chunks(ma_ctx* ctx, CallScope& scope, size_t e
     const size_t avg_chunk_bytes = total / n_chunks * elem_size;
     const size_t growth = avg_chunk_bytes >= ((size_t)48 << 10) ? 4 : 2;
     const size_t kFirst = 4 * per_round, kMax = 64 * per_round;
-    size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(ctx->variant & 1024)) ? kFirst : n_chunks, row = 0;
+    size_t c0 = 0, seg = (n_chunks > 2 * kFirst && !(tuning_variant(ctx) & 1024)) ? kFirst : n_chunks, row = 0;
     while (c0 < n_chunks) {
         const size_t c1 = c0 + seg < n_chunks ? c0 + seg : n_chunks;
         ConcatChunk* cd = nullptr;
@@ -624,8 +624,8 @@ static bool chunk_form_wanted(const ma_ctx* ctx, size_t n_chunks, const size_t* 
         if (chunk_lens[i] > longest) longest = chunk_lens[i];
     const size_t avg = total / n_chunks;
     bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
-    if (ctx->variant & 128) by_chunk = false;
-    if (ctx->variant & 256) by_chunk = true;
+    if (form_variant(ctx) & 128) by_chunk = false;
+    if (form_variant(ctx) & 256) by_chunk = true;
     return by_chunk;
 }
 

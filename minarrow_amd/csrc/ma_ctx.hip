@@ -375,7 +375,7 @@ ma_status CallScope::out_mask(uint8_t* bits, size_t len_bits, uint64_t** out_wor
 // command-processor write, no kernel) and the host polls that word for up to poll_us; a long call falls through to the
 // blocking wait, and so does a faulted one (whose stamp never comes), which then reports its error.
 ma_status stream_wait(ma_ctx* ctx) {
-    if (ctx->poll_us > 0 && !ctx->capturing && ctx->result && !(ctx->variant & 128)) {
+    if (ctx->poll_us > 0 && !ctx->capturing && ctx->result && !(tuning_variant(ctx) & 128)) {
         volatile uint64_t* done = (volatile uint64_t*)&ctx->result[2].cnt;
         const uint64_t seq = ++ctx->result_seq;
         if (hipStreamWriteValue64(ctx->stream, (void*)done, seq, 0) == hipSuccess) {
@@ -1098,6 +1098,9 @@ ma_status ma_ctx_set_grid(ma_ctx* ctx, int32_t workgroups) {
 
 ma_status ma_ctx_set_variant(ma_ctx* ctx, int32_t variant) {
     MA_REQUIRE(ctx != nullptr, MA_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    MA_REQUIRE(MA_TUNING || (variant & ~kFormBits) == 0, MA_ERR_UNSUPPORTED,
+               "variant %d has tuning bits (%d): this build of the library keeps the form bits %d only; the forms those bits select live "
+               "in a library built with TUNING=1 (make -C minarrow_amd/csrc TUNING=1)", variant, variant & ~kFormBits, kFormBits);
     MA_ENTER_PRIMARY(ctx);
     ctx->variant = variant;
     return MA_OK;

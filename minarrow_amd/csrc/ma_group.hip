@@ -277,8 +277,8 @@ ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
     return MA_OK;
 }
 
-ma_status order_lane_if_foreign(ma_group* g, size_t i) {
-    if (!g->lanes2 || !g->lanes_on || g->ctxs[i]->calls.load(std::memory_order_relaxed) == g->seen_calls[i]) return MA_OK;
+ma_status order_lane_if_foreign(ma_group* g, size_t i, uint64_t now) {
+    if (!g->lanes2 || !g->lanes_on || now == g->seen_calls[i]) return MA_OK;
     MA_HIP(hipSetDevice(g->ctxs[i]->device));
     MA_HIP(hipEventRecord(g->ev_lane[i], g->ctxs[i]->stream));
     MA_HIP(hipStreamWaitEvent(g->scan2[i]->stream, g->ev_lane[i], 0));
@@ -429,7 +429,7 @@ ma_status enqueue_sum_members(ma_group* g, int32_t column, const void* const* ch
     // enqueue only (the members are in async mode): all devices run concurrently
     return run_on_members(g, [&](size_t i) {
         uint64_t* set = (g->overlap && g->cur == 1) ? g->local1[i] : g->local[i];
-        if (cur_set == 1) MA_TRY(order_lane_if_foreign(g, i));
+        if (cur_set == 1) MA_TRY(order_lane_if_foreign(g, i, g->ctxs[i]->calls.load(std::memory_order_relaxed)));
         return launch(i, scan_ctx(g, cur_set, i), set + (size_t)column * kRecordWords);
     });
 }
@@ -457,7 +457,7 @@ ma_status exchange_locked(ma_group* g) {
     // which context issues the exchange of member i: its own (in-stream), or its side context (overlapped: behind the
     // scans that filled this set — an event — while the member's stream goes on with the other set)
     // ma_group_set_handoff(event) — or variant bit 4096 on member 0, the tuning harness's switch — always takes the event
-    const bool on_stamp = g->overlap && g->stamp_ok[set] && g->handoff == 0 && !(g->ctxs[0]->variant & 4096);
+    const bool on_stamp = g->overlap && g->stamp_ok[set] && g->handoff == 0 && !(tuning_variant(g->ctxs[0]) & 4096);
     auto before = [g, set, on_stamp](size_t i) -> ma_status {
         if (!g->overlap) return MA_OK;
         if (on_stamp) {  // the scan stream carries nothing for the hand-off: the exchange stream waits for the kernel's stamp
@@ -923,12 +923,17 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     const ma_status st = run_on_members(group, [&](size_t i) -> ma_status {
         uint64_t* set = (group->overlap && group->cur == 1) ? group->local1[i] : group->local[i];
         ma_ctx* sc = scan_ctx(group, cur_set, i);
+        // The member's call counter ONCE, in front of everything: what it shows beyond seen_calls[i] is foreign work. Entries this
+        // step makes itself on the member's context are added to the snapshot below; one another host thread makes meanwhile is
+        // not, so the next lane-1 step is ordered behind it.
+        const uint64_t now = lanes ? group->ctxs[i]->calls.load(std::memory_order_relaxed) : 0;
+        const uint64_t own0 = entries_by_this_thread();
         if (lanes) {
             if (sc != group->ctxs[i]) {  // the tuning knobs follow the member's context
                 sc->variant = group->ctxs[i]->variant;
                 sc->blocks_per_cu = group->ctxs[i]->blocks_per_cu;
                 sc->grid_override = group->ctxs[i]->grid_override;
-                MA_TRY(order_lane_if_foreign(group, i));
+                MA_TRY(order_lane_if_foreign(group, i, now));
             }
             if (gate) {
                 MA_HIP(hipSetDevice(sc->device));
@@ -951,6 +956,7 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
         MA_TRY(sum_fused_impl(sc, (size_t)n_cols, cols, stamped ? group->stamp[cur_set][i] : nullptr, seq, false,
                               (lanes && stamped) ? group->stamp[cur_set][i] + 1 : nullptr));
         if (mark_to >= 0) MA_TRY(ma_ctx_mark(sc, mark_to));
+        if (lanes) group->seen_calls[i] = now + (sc == group->ctxs[i] ? entries_by_this_thread() - own0 : 0);
         return MA_OK;
     });
     // A member that refused the launch (a misaligned pointer, say) never stamps `seq`: an exchange waiting for that value on
@@ -959,7 +965,6 @@ ma_status ma_group_enqueue_sum_table(ma_group* group, int32_t n_cols, const int3
     if (lanes) {
         group->prev_set = (st == MA_OK && stamped) ? cur_set : -1;
         group->prev_seq = seq;
-        for (size_t i = 0; i < group->ctxs.size(); ++i) group->seen_calls[i] = group->ctxs[i]->calls.load(std::memory_order_relaxed);
     }
     return st;
 }
@@ -993,7 +998,7 @@ ma_status ma_group_enqueue_sum_chunks(ma_group* group, int32_t column, int32_t f
     group->stamp_ok[cur_set] = false;
     group->prev_set = -1;
     return run_on_members(group, [&](size_t m) -> ma_status {
-        if (cur_set == 1) MA_TRY(order_lane_if_foreign(group, m));
+        if (cur_set == 1) MA_TRY(order_lane_if_foreign(group, m, group->ctxs[m]->calls.load(std::memory_order_relaxed)));
         std::vector<const void*> d;
         std::vector<size_t> n, o;
         std::vector<const uint8_t*> k;

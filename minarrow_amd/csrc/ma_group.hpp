@@ -156,7 +156,7 @@ void release_exchange(ma_group* g);
 ma_status setup_rccl(ma_group* g, bool overlap, bool lanes);
 // Lane 1 of member i behind everything the member's own stream has been given so far (an event), when something other than the
 // group's stepping has touched the member's context since the group last looked.
-ma_status order_lane_if_foreign(ma_group* g, size_t i);
+ma_status order_lane_if_foreign(ma_group* g, size_t i, uint64_t now);  // now = the member context's call counter as the caller read it
 ma_status setup_host(ma_group* g);
 void start_workers(ma_group* g);
 void stop_workers(ma_group* g);

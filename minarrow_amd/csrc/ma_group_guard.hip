@@ -700,7 +700,7 @@ int32_t ma_group_handoff(ma_group* group) {
     if (!group) return -1;
     std::lock_guard<std::recursive_mutex> lock(group->mu);
     if (!group->overlap || !group->use_rccl) return -1;
-    if (group->handoff != MA_GROUP_HANDOFF_STAMP || (group->ctxs[0]->variant & 4096)) return MA_GROUP_HANDOFF_EVENT;
+    if (group->handoff != MA_GROUP_HANDOFF_STAMP || (tuning_variant(group->ctxs[0]) & 4096)) return MA_GROUP_HANDOFF_EVENT;
     for (int k = 0; k < 2; ++k) {
         if (group->stamp[k].size() != group->ctxs.size()) return MA_GROUP_HANDOFF_EVENT;
         for (uint64_t* w : group->stamp[k])
@@ -834,7 +834,7 @@ ma_status ma_group_selftest(ma_group* group, uint32_t what, double timeout_ms, m
     const int had_handoff = g->handoff;
     if (st == MA_OK && (what & (MA_SELFTEST_EXCHANGE | MA_SELFTEST_EXCHANGE_ALL_FORMS))) {
         const bool all = (what & MA_SELFTEST_EXCHANGE_ALL_FORMS) != 0;
-        bool stamps = g->overlap && !(g->ctxs[0]->variant & 4096);
+        bool stamps = g->overlap && !(tuning_variant(g->ctxs[0]) & 4096);
         for (int k = 0; k < 2 && stamps; ++k) {
             stamps = g->stamp[k].size() == n;
             for (size_t i = 0; stamps && i < n; ++i) stamps = g->stamp[k][i] != nullptr;

@@ -419,8 +419,15 @@ __global__ __launch_bounds__(kBlock) void sum_kernel(SumArgs a) {
 // Host side
 // ------------------------------------------------------------------------------------------------
 
+// Idle cycles between a wave's consecutive loads in the dense scans, swept per type at 10^9 rows (enqueue_sum).
+template <typename T>
+constexpr int dense_pace() {
+    return std::is_same<T, float>::value ? 24 : std::is_same<T, double>::value ? 20 : (sizeof(T) == 8 ? 24 : 16);
+}
+
 template <typename T, int UNROLL, bool MASKED, bool NT>
 static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
+#if MA_TUNING
     if constexpr (!MASKED && NT && UNROLL == 8) {
         if (a.interleave) {  // tuning variant only (ctx variant bit 4)
             hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
@@ -437,6 +444,16 @@ static void launch_sum(ma_ctx* ctx, const SumArgs& a, int grid) {
             default: break;
         }
     }
+#else
+    // the shipped build: ONE pacing per type (the swept default of enqueue_sum), dense scans of 4- and 8-byte types only
+    if constexpr (NT && !MASKED && sizeof(T) > 2) {
+        constexpr int kPace = dense_pace<T>();
+        if (a.pace == kPace) {
+            hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false, kPace>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+            return;
+        }
+    }
+#endif
     hipLaunchKernelGGL((sum_kernel<T, UNROLL, MASKED, NT, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
 }
 
@@ -454,7 +471,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     // loads (validity bits, 4 rows per lane) wants two waves per SIMD to overlap it.
     // ctx->variant: bit 0 = plain (temporal) loads instead of non-temporal; bits 1-3 = unroll
     // {0: auto, 1: 2, 2: 4, 3: 8, 4: 16}. ctx->blocks_per_cu: 0 = auto.
-    const int variant = ctx->variant;
+    const int variant = tuning_variant(ctx);  // every bit this launch reads is a tuning bit: 0 in the shipped build
     const bool nt = (variant & 1) == 0;
     // 32-bit columns (profiles/r01_sweep_sum_32bit.txt, 2 x 10^9 rows): dense integers behave like the 8-byte scans
     // (7.15 vs 6.98 TB/s); f32 — widened to f64 and accumulated in double-double, 4 rows per load — wants two waves per
@@ -510,7 +527,7 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     {
         static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
         const int sel = kPace[(variant >> 5) & 7];
-        const int dense_default = std::is_same<T, float>::value ? 24 : std::is_same<T, double>::value ? 20 : (R == 2 ? 24 : 16);
+        const int dense_default = dense_pace<T>();
         a.pace = sel >= 0 ? sel : ((masked || R >= 8) ? 0 : dense_default);
     }
     // Mid-size columns (up to ~24 tiles per CU: 2^24 8-byte rows — the chunk sizes the reference actually runs at,
@@ -526,13 +543,18 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
     }
     int grid = grid_for(ctx, work, bpc);
 
+#if MA_TUNING
 #define MA_LAUNCH_U(U, M)                                     \
     do {                                                      \
         if (nt) launch_sum<T, U, M, true>(ctx, a, grid);      \
         else launch_sum<T, U, M, false>(ctx, a, grid);        \
     } while (0)
+#else  // non-temporal loads only (plain loads are a tuning form)
+#define MA_LAUNCH_U(U, M) launch_sum<T, U, M, true>(ctx, a, grid)
+#endif
     if constexpr (R >= 8) {  // narrow types: masked = the one shape per width chosen above (deeper overflows the validity run)
         constexpr int U = R == 8 ? 4 : 2;
+        (void)U;
         bool deep = false;
         if constexpr (R == 16) {
             if (masked && unroll == 8) {
@@ -541,23 +563,34 @@ static ma_status enqueue_sum(ma_ctx* ctx, SumArgs a, bool masked) {
             }
         }
         if (deep) {
-        } else if (masked) MA_LAUNCH_U(U, true);
+        }
+#if MA_TUNING
+        else if (masked) MA_LAUNCH_U(U, true);
         else if (unroll == 2) MA_LAUNCH_U(2, false);
         else if (unroll == 4) MA_LAUNCH_U(4, false);
+#else  // the shapes the shipped build chooses: masked 2-byte rows 4 loads (1-byte rows took `deep`), dense 8
+        else if (masked) {
+            if constexpr (R == 8) MA_LAUNCH_U(4, true);
+        }
+#endif
         else MA_LAUNCH_U(8, false);
     } else if (masked) {
         switch (unroll) {
+#if MA_TUNING
             case 2: MA_LAUNCH_U(2, true); break;
+#endif
             case 8: MA_LAUNCH_U(8, true); break;
             default: MA_LAUNCH_U(4, true); break;
         }
     } else {
         switch (unroll) {
+#if MA_TUNING
             case 2: MA_LAUNCH_U(2, false); break;
-            case 8: MA_LAUNCH_U(8, false); break;
             case 16:
                 if constexpr (R * 16 < 64) { MA_LAUNCH_U(16, false); } else { MA_LAUNCH_U(8, false); }
                 break;
+#endif
+            case 8: MA_LAUNCH_U(8, false); break;
             default: MA_LAUNCH_U(4, false); break;
         }
     }

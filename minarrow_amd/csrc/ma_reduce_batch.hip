@@ -260,9 +260,20 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __r
 // waits on PCIe.
 // TOTAL: the columns are chunks of ONE column (ma_sum_chunks) — nothing is reduced per chunk; the wave's accumulators run on
 // and its one partial goes to partials[wave].
+// DIRECT (per-column form only): a column is ONE wave's work here, so what its flush holds is the column's result — it goes
+// straight to the caller's arrays (three 8-byte stores; an array the caller did not ask for points into `partials`, unused in this
+// form) instead of into a Partial that a second launch turns into the same three values: that launch cost 19.5 us per 60 000
+// columns (a wave per column, seven dependent round trips each: profiles/r06_column_waves.md) on a 280-us scan.
+struct ColOut {
+    double* f64;
+    uint64_t* i64;
+    uint64_t* cnt;
+    int direct, is_signed;
+};
+
 template <typename T, int UNROLL, bool TOTAL>
 __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __restrict__ table, size_t n_cols_,
-                                                              Partial* __restrict__ partials, int stagger = 1) {
+                                                              Partial* __restrict__ partials, int stagger, ColOut out) {
     typedef typename std::conditional<(sizeof(T) <= 2), MaU4, typename Vec16<T>::type>::type V;
     typedef typename AccOf<T>::type Acc;
     constexpr int R = 16 / (int)sizeof(T);
@@ -343,11 +354,23 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
             cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
         }
         if (lane == 0) {
-            Partial p;
-            acc[0].to_partial(p);
-            p.cnt = cnt;
-            p.pad = 0;
-            partials[slot] = p;
+            if (!TOTAL && out.direct) {
+                if constexpr (std::is_same<Acc, DDAcc>::value) {
+                    acc[0].normalise();
+                    out.f64[slot] = acc[0].hi;
+                    out.i64[slot] = 0;  // (points into `partials`: float formats have no integer sums)
+                } else {
+                    out.i64[slot] = acc[0].s;
+                    out.f64[slot] = out.is_signed ? (double)(int64_t)acc[0].s : (double)acc[0].s;
+                }
+                out.cnt[slot] = cnt;
+            } else {
+                Partial p;
+                acc[0].to_partial(p);
+                p.cnt = cnt;
+                p.pad = 0;
+                partials[slot] = p;
+            }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r].init();
@@ -627,7 +650,8 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         n_short = n_segs;
     }
     size_t n_short_partials = n_short;  // short form: partial c = entry c, or (total) partial w = wave w
-    if (short_table && (expand_to || !(ctx->variant & 4096))) {
+    bool direct = false;                // the waves wrote the per-column results themselves (column_waves_kernel's ColOut)
+    if (short_table && (expand_to || !(tuning_variant(ctx) & 4096))) {
         // one or two waves per SIMD with ~8 KiB of loads each in flight AND a tile requested ahead (column_waves_kernel);
         // ctx->variant bits 1-3 / blocks_per_cu override the shape for sweeps (tools/probe_sum_chunks.py)
         // Swept at 60 000 x 8192 rows (profiles/r03_sweep_sum_chunks*.jsonl): ONE wave per SIMD with eight loads per tile — sixteen
@@ -636,26 +660,39 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         // SIMD: 6.4-6.7; the round's first shape, eight workgroups per CU and no tile ahead: 6.3-6.4, i32 5.8). The 1- and 2-byte
         // types keep their shallower tiles (the validity words of a tile must fit one load instruction) on two waves per SIMD.
         constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
-        const int sel = (ctx->variant >> 1) & 7;
+        const int sel = (tuning_variant(ctx) >> 1) & 7;
         const bool deep = sizeof(T) >= 4 && sel != 2;
         // (f32 with validity — widened to f64, four double-double accumulators per load — is ALU-bound on one wave: 5.2 -> 5.9)
         const bool two = sizeof(T) < 4 || (std::is_same<T, float>::value && any_masked);
         const int bpc = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : two ? 2 : 1;
-        const int stagger = (ctx->variant & 32768) ? 0 : 1;
+        const int stagger = (tuning_variant(ctx) & 32768) ? 0 : 1;
         const int grid1 = grid_for(ctx, (n_short + kWaves - 1) / kWaves, bpc);
         if (total) n_short_partials = (size_t)grid1 * kWaves;
-        if (deep) {
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
-        } else {
-            constexpr int U1 = sizeof(T) == 8 ? 4 : UNROLL;
-            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
-            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger);
+        // entry c = column c (no pieces): the waves write the columns' results themselves — no second launch
+        ColOut out{};
+        if (!total && !expand_to) {
+            uint64_t* spare = (uint64_t*)partials;  // n_short x 32 bytes, unused in this form: three arrays of n_short words fit
+            out.f64 = of ? of : (double*)spare;
+            out.i64 = (oi && !std::is_same<typename AccOf<T>::type, DDAcc>::value) ? oi : spare + n_short;
+            out.cnt = oc ? oc : spare + 2 * n_short;
+            out.direct = 1;
+            out.is_signed = is_signed ? 1 : 0;
+            direct = true;
+        }
+        constexpr int U1 = sizeof(T) == 8 ? 4 : UNROLL;  // the shallower shape: what the 1- and 2-byte types run (U2 == U1 for them)
+        if (deep || !MA_TUNING) {  // (shipped build: the deep shape for 4- and 8-byte rows; U2 == U1 for the narrow types)
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U2, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger, out);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U2, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger, out);
+        } else if constexpr (MA_TUNING != 0) {
+            if (total) hipLaunchKernelGGL((column_waves_kernel<T, U1, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger, out);
+            else hipLaunchKernelGGL((column_waves_kernel<T, U1, false>), dim3(grid1), dim3(kBlock), 0, ctx->stream, short_table, n_short, partials, stagger, out);
         }
     } else if (short_table) {  // variant bit 4096: round 3's first shape (eight workgroups per CU, no tile ahead), for A/B
-        const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8);
-        hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream,
-                           (const void*)short_table, (int)n_cols, n_cols, partials);
+        if constexpr (MA_TUNING != 0) {
+            const int grid1 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : 8);
+            hipLaunchKernelGGL((column_segments_kernel<T, UNROLL, true>), dim3(grid1), dim3(kBlock), 0, ctx->stream,
+                               (const void*)short_table, (int)n_cols, n_cols, partials);
+        }
     } else {
         // 1-byte rows: two loads in flight per lane, more waves (ma_reduce.hip)
         const int grid1 = grid_for(ctx, n_segs, ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : sizeof(T) == 1 ? 3 : 2);
@@ -677,6 +714,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         hipLaunchKernelGGL((total_fold_kernel<T>), dim3(1), dim3(kBlock), 0, ctx->stream, src, n, is_signed ? 1 : 0, of, oi, oc, olo);
         return;
     }
+    if (direct) return;
     const int grid2 = grid_for(ctx, (n_cols + kWaves - 1) / kWaves, 8);
     hipLaunchKernelGGL((column_fold_kernel<T>), dim3(grid2), dim3(kBlock), 0, ctx->stream, d, (int)n_cols, n_segs,
                        (const Partial*)partials, is_signed ? 1 : 0, of, oi, oc, (short_table && !expand_to) ? 1 : 0);
@@ -738,7 +776,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     // rows 6.85 -> 7.15.
     // Each launch leaves one Partial per column; the folds below are the general path's. variant bit 16384: general path (A/B);
     // bit 65536: the fused scan whatever the total size (tests of the multi-launch form at sizes a CPU check can follow).
-    if (elem == 8 && n_cols <= 16 && !(ctx->variant & 16384)) {
+    if (elem == 8 && n_cols <= 16 && !(form_variant(ctx) & 16384)) {
         bool few_long = true;
         size_t total_rows = 0;
         for (size_t i = 0; i < n_cols && few_long; ++i) {
@@ -749,7 +787,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
         // a fused launch costs ~4.5 us beyond its bytes and reads them 5 % faster than the two launches of the segment path
         // (~6 us): one launch (<= 4 columns) always pays, more only from ~384 MiB per launch
         const size_t launches = (n_cols + MA_FUSED_MAX_COLUMNS - 1) / MA_FUSED_MAX_COLUMNS;
-        if (launches > 1 && total_rows * 8 < launches * ((size_t)384 << 20) && !(ctx->variant & 65536)) few_long = false;  // bit 65536: tests
+        if (launches > 1 && total_rows * 8 < launches * ((size_t)384 << 20) && !(form_variant(ctx) & 65536)) few_long = false;  // bit 65536: tests
         if (few_long) {
             void *of = nullptr, *oi = nullptr, *oc = nullptr, *olo = nullptr;
             const size_t n_out = total ? 1 : n_cols;
@@ -806,8 +844,8 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     size_t n_pieces = 0, n_long_segs = 0;
     // variant bit 8192, A/B: pieces for 4- and 8-byte rows and for few very long columns too (1000 x 537 k rows: i64 / f64 6.6 TB/s
     // either way, i32 6.47 -> 6.2 dense, 5.87 -> 6.08 with validity; 8 x 67 M rows: the same picture)
-    const bool any_width = (ctx->variant & 8192) != 0;
-    if (!all_short && (elem <= 2 || any_width) && !(ctx->variant & 4096))
+    const bool any_width = (tuning_variant(ctx) & 8192) != 0;
+    if (!all_short && (elem <= 2 || any_width) && !(tuning_variant(ctx) & 4096))
         for (size_t i = 0; i < n_cols; ++i) {
             n_pieces += (col_lens[i] + piece_rows(elem) - 1) / piece_rows(elem);
             n_long_segs += (col_lens[i] + seg_rows(elem) - 1) / seg_rows(elem);

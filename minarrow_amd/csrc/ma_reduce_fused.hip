@@ -419,11 +419,15 @@ static void launch_fused(ma_ctx* ctx, const FusedArgs& a, int grid, int pace) {
     if constexpr (ANY_MASKED) {
         hipLaunchKernelGGL((sum_fused_kernel<UNROLL, true, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     } else {
+#if MA_TUNING
         switch (pace) {
-            case 0: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
-            case 24: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 24>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 20>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); break;
+            case 0: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            case 24: hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 24>), dim3(grid), dim3(kBlock), 0, ctx->stream, a); return;
+            default: break;
         }
+#endif
+        (void)pace;  // the shipped build: the swept pacing (20 idle cycles between a wave's loads)
+        hipLaunchKernelGGL((sum_fused_kernel<UNROLL, false, 20>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     }
 }
 
@@ -522,13 +526,13 @@ ma_status ma::sum_fused_impl(ma_ctx* ctx, size_t n_cols, const ma_fused_column* 
     a.partials = ctx->partials;
     a.ticket = ctx->ticket;
     static const int kPace[8] = {-1, 0, 16, 20, 24, 32, 0, 0};
-    const int sel = kPace[(ctx->variant >> 5) & 7];
+    const int sel = kPace[(tuning_variant(ctx) >> 5) & 7];
     const int pace = sel >= 0 ? sel : 20;
     a.done_word = stamp;  // stored (system-scope release) by the launch's final thread behind its results
     a.done_seq = stamp_value;
     a.early_word = early_stamp;
     {   // FusedArgs::early_mode; ctx variant bits 19-21 override (tuning): 0 = the default, v = mode v - 1
-        const unsigned sel = ((unsigned)ctx->variant >> 19) & 7u;
+        const unsigned sel = ((unsigned)tuning_variant(ctx) >> 19) & 7u;
         a.early_mode = grid > (int)kFShardFrom ? (sel ? sel - 1 : 5u) : 0u;
     }
     if (any_masked) launch_fused<4, true>(ctx, a, grid, 0);

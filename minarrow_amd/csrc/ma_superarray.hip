@@ -502,7 +502,7 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
         // ahead of its use) unless variant bit 512 asks for the device copy.
         const void* tab = nullptr;
         TableSlotGuard guard(ctx);  // releases the mapped slot behind the launch on every way out
-        if (ctx->variant & 512) {
+        if (tuning_variant(ctx) & 512) {
             MA_TRY(table_commit(ctx, host, bytes, dev_tab));
             tab = dev_tab;
         } else {
@@ -534,7 +534,7 @@ static ma_status batched_segment(ma_ctx* ctx, CallScope& scope, PairRoles& roles
     const ChunkMaskDesc* dmd = any_mask ? (const ChunkMaskDesc*)(dev_tab + off_md) : nullptr;
     const uint64_t* dt0 = (const uint64_t*)(dev_tab + off_t0);
     const uint64_t* dw0 = any_mask ? (const uint64_t*)(dev_tab + off_w0) : nullptr;
-    const bool fuse = any_mask && !masked_head && (dv || !(ctx->variant & 64));  // variant bit 64: always the separate bitmap launch
+    const bool fuse = any_mask && !masked_head && (dv || !(tuning_variant(ctx) & 64));  // variant bit 64: always the separate bitmap launch
     MA_REQUIRE(!dv || fuse, MA_ERR_DEVICE, "internal: data-dependent validity needs every masked chunk's output on a 16-byte boundary");
     if (any_mask && !fuse) {
         int grid = grid_for(ctx, (n_words + kBlock - 1) / kBlock, 8);
@@ -579,7 +579,7 @@ static ma_status batched_impl_u(ma_ctx* ctx, int op, size_t n_chunks, const void
     constexpr size_t kPerChunk = sizeof(ChunkPair) + sizeof(ChunkMaskDesc) + 16;
     const size_t per_round = (size_t)grid_for(ctx, (size_t)1 << 30, 6);  // segments are whole rounds of the chunk kernel's grid
     const size_t kFirst = 4 * per_round, kMax = 21 * per_round;
-    const bool segmented = n_chunks > 2 * kFirst && !(ctx->variant & 1024);
+    const bool segmented = n_chunks > 2 * kFirst && !(tuning_variant(ctx) & 1024);
     char* dev_tab = nullptr;
     size_t n_segments = 1;
     if (segmented)
@@ -636,14 +636,14 @@ static ma_status batched_impl(ma_ctx* ctx, int op, size_t n_chunks, const void* 
     // (runs must start on validity words). Everything else — a few long chunks above all — is dealt out tile by tile.
     // variant bit 128 forces the tile form, bit 256 the chunk form (tuning / tests).
     bool by_chunk = n_chunks >= (size_t)4 * (size_t)ctx->num_cus && avg <= ((size_t)1 << 16) && longest <= 8 * (avg ? avg : 1);
-    if (ctx->variant & 128) by_chunk = false;
-    if (ctx->variant & 256) by_chunk = true;
+    if (form_variant(ctx) & 128) by_chunk = false;
+    if (form_variant(ctx) & 256) by_chunk = true;
     by_chunk = by_chunk && !masked_head && n_chunks < ((size_t)1 << 31);
     // 8 x 16 bytes per lane when the tiles that gives are filled: 8-byte types in the chunk form (two 4096-row tiles per
     // 8192-row chunk; 4-byte types are faster with two 4 x 16-byte tiles), long chunks in the tile form.
     bool wide = by_chunk ? (sizeof(T) >= 8 && avg >= kWideTileRows) : avg >= 16 * kWideTileRows;
-    if (ctx->variant & 16) wide = false;
-    if (ctx->variant & 32) wide = true;
+    if (form_variant(ctx) & 16) wide = false;
+    if (form_variant(ctx) & 32) wide = true;
     if (wide)
         return batched_impl_u<T, 8>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk, smode, sbits);
     return batched_impl_u<T, 4>(ctx, op, n_chunks, lhs_data, lens, lhs_masks, rhs_data, rhs_masks, override_mask, out_data, out_masks, out_has_mask, any_mask, by_chunk, smode, sbits);

@@ -12,7 +12,9 @@ import re
 from pathlib import Path
 
 _ROOT = Path(__file__).resolve().parent
-LIB_PATH = _ROOT / "lib" / "libminarrow_hip.so"
+# MINARROW_HIP_LIB: another build of the same library — the tuning build (make -C minarrow_amd/csrc TUNING=1 -> build/tuning/), whose
+# ma_ctx_set_variant takes every bit; tools/ sweeps and the variant A/B tests use it. Unset: the shipped in-tree library.
+LIB_PATH = Path(os.environ["MINARROW_HIP_LIB"]) if os.environ.get("MINARROW_HIP_LIB") else _ROOT / "lib" / "libminarrow_hip.so"
 HEADER_PATH = _ROOT.parent / "include" / "minarrow_hip.h"
 TESTING_HEADER_PATH = _ROOT.parent / "include" / "minarrow_hip_testing.h"  # the fault hooks: inert unless MINARROW_HIP_TEST_HOOKS=1 at load
 

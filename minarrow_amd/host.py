@@ -240,6 +240,8 @@ class Context:
         ffi.check(self.lib.ma_ctx_set_grid(self.handle, int(workgroups)))
 
     def set_variant(self, v: int) -> None:
+        """ma_ctx_set_variant: FORM bits (FORM_BITS: they force one of two product paths, for tests) in every build; any other bit
+        is a tuning form that only a library built with TUNING=1 has — the shipped one refuses it (MA_ERR_UNSUPPORTED)."""
         ffi.check(self.lib.ma_ctx_set_variant(self.handle, int(v)))
 
     @property
@@ -722,6 +724,20 @@ class SelftestReport(C.Structure):
                 "stamp_waits": self.stamp_waits, "stamp_waits_ok": self.stamp_waits_ok, "stamp_us_max": round(self.stamp_us_max, 1),
                 "failed_form": self.FORM_NAMES[self.failed_form] if 0 <= self.failed_form < len(self.FORM_NAMES) else None,
                 "failed_member": self.failed_member if self.failed_member >= 0 else None, "timed_out": bool(self.timed_out)}
+
+
+FORM_BITS = 16 | 32 | 128 | 256 | 16384 | 65536  # ma_common.hpp kFormBits: the ctx variant bits every build of the library takes
+
+
+def tuning_build() -> bool:
+    """True when the loaded library is the tuning build (MINARROW_HIP_LIB=build/tuning/libminarrow_hip.so: make -C minarrow_amd/csrc
+    TUNING=1), whose ma_ctx_set_variant takes every bit."""
+    return "tuning" in str(ffi.LIB_PATH)
+
+
+def live_variants(variants):
+    """Those of `variants` this build's ma_ctx_set_variant accepts: form bits always, tuning bits on the tuning build only."""
+    return [v for v in variants if tuning_build() or (v & ~FORM_BITS) == 0]
 
 
 SELFTEST_EXCHANGE, SELFTEST_EXCHANGE_ALL_FORMS, SELFTEST_PEER_COPIES, SELFTEST_STAMPS = 1, 2, 4, 8

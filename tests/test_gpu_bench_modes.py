@@ -97,7 +97,7 @@ def test_one_process_group_mode_with_rccl():
     assert weak["result"]["i64_sum"] == out["result"]["i64_sum"]
 
 
-@pytest.mark.parametrize("exchange, extra", [("native", []), ("native", ["--overlap"]), ("host", [])])
+@pytest.mark.parametrize("exchange, extra", [("native", ["--overlap"]), ("host", [])])
 def test_launcher_mode_one_rank(exchange, extra):
     """One process per GPU under torch.distributed.run: the GPU path is torch-free (gloo carries the rendezvous only) and the
     exchange is the library's own communicator (ma_comm_*) or, as its fall-back, the records over host memory."""
@@ -242,10 +242,7 @@ def test_launcher_rehearsal_partitions_the_column_over_several_ranks(ranks):
     assert out["result"]["i64_sum"] == rows * (rows - 1) // 2 and out["result"]["f64_ulps_from_exact"] <= 1.0
     assert "REHEARSAL" in out["config"]["parallelism"] and out["config"]["rccl_ranks"] == 0
     assert out["n1_same_process"]["rows_per_column"] == rows and out["efficiency_vs_n1"] > 0
-    weak = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-                "127.0.0.1", "--master-port", str(29660 + ranks), "bench.py", "--rows", str(1 << 22), "--steps", "2", "--warmup", "1",
-                "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline", "--scaling", "weak"])
-    assert weak["parity_ok"] and weak["scaling"] == "weak" and weak["result"]["rows"] == ranks << 22
+
 
 
 # ---- REHEARSAL: both N > 1 modes with PEERS, on this box's one GPU, through the loopback collective double ---------------------

@@ -8,6 +8,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from minarrow_amd.host import live_variants
+
 from minarrow_amd import ffi
 
 pytestmark = pytest.mark.gpu
@@ -90,8 +92,9 @@ def test_random_chunks(ctx, oracle, dt):
                 np.testing.assert_array_equal(mask, want_mask[:nbytes(sum(lens))])
 
 
-@pytest.mark.parametrize("k,dt,variant", [(700, np.int32, 0), (700, np.int32, 256), (700, np.float64, 256), (9000, np.int32, 0),
-                                          (9000, np.int64, 0), (9000, np.int64, 1024), (9000, np.int32, 128)])
+@pytest.mark.parametrize("k,dt,variant", [p for p in [(700, np.int32, 0), (700, np.int32, 256), (700, np.float64, 256), (9000, np.int32, 0),
+                                                     (9000, np.int64, 0), (9000, np.int64, 1024), (9000, np.int32, 128)]
+                                          if live_variants([p[2]])])  # 1024 (one segment) is a tuning form
 def test_many_small_chunks(ctx, oracle, k, dt, variant):
     """700 chunks (more than the validity kernel stages in LDS), ragged lengths incl. empty ones, masks at odd bit
     offsets on two thirds of them; values and validity vs the oracle; and the Boolean column twin.
@@ -132,7 +135,7 @@ def test_many_small_chunks(ctx, oracle, k, dt, variant):
 
 @pytest.mark.parametrize("dt", [np.int8, np.int16, np.int32, np.float64])
 @pytest.mark.parametrize("shape", ["aligned", "aligned_tail", "few_joins", "tail_in_join", "tiny_runs"])
-@pytest.mark.parametrize("variant", [256, 256 + 1024])  # the chunk form forced; in segments | as one segment
+@pytest.mark.parametrize("variant", live_variants([256, 256 + 1024]))  # the chunk form forced; in segments | as one segment (a tuning form)
 def test_chunk_form_validity_words(ctx, oracle, dt, shape, variant):
     """The chunk-per-workgroup consolidate writes a chunk's validity words from the chunk's own workgroup and leaves only
     the words a chunk STARTS inside to a join pass (launched only when there is such a word). Shapes: every chunk a

@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 import pytest
+
+from minarrow_amd.host import live_variants
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
@@ -256,7 +258,7 @@ SHORT = [0, 0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 
 @settings(**COMMON)
 @given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g", "c", "C", "s", "S"]), n_cols=st.integers(256, 700),
        gap=st.integers(0, 3), mask_mode=st.sampled_from(["none", "some", "all"]), grid=st.sampled_from([0, 0, 1, 2, 7]),
-       variant=st.sampled_from([0, 0, 4, 6, 32768]), seed=st.integers(0, 2**31))
+       variant=st.sampled_from(live_variants([0, 0, 4, 6, 32768])), seed=st.integers(0, 2**31))
 def test_sum_short_columns(ctx, fmt, n_cols, gap, mask_mode, grid, variant, seed):
     """From 256 columns of a segment or less each: a WAVE per column with the next tile requested ahead, across columns
     (`column_waves_kernel`) — per column (ma_sum_columns) and as one total (ma_sum_chunks), on grids so small that a wave
@@ -409,7 +411,7 @@ def test_consolidate_boolean(ctx, lens, with_masks, seed):
 @given(fmt=st.sampled_from(["i", "l", "f", "g"]), op=st.sampled_from([0, 1, 2]),
        lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
        mask_mode=st.sampled_from(["none", "mixed", "override"]), seed=st.integers(0, 2**31),
-       variant=st.sampled_from([0, 32, 64, 96, 256, 256 | 32, 256 | 16]), out_off=st.integers(0, 3))
+       variant=st.sampled_from(live_variants([0, 32, 64, 96, 256, 256 | 32, 256 | 16])), out_off=st.integers(0, 3))
 def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed, variant, out_off):
     """variant: 32 = the 8 x 16-byte tile also for short chunks, 64 = output bitmaps by the second launch instead of the
     computing wave, 256 = the chunk-per-workgroup kernel (RechunkStrategy-sized chunks) with either tile width; out_off: outputs start out_off elements past a 16-byte boundary (a masked chunk off the boundary
@@ -468,7 +470,7 @@ def test_route_super_array_broadcast(ctx, fmt, op, lens, mask_mode, seed, varian
 @settings(**COMMON)
 @given(fmt=st.sampled_from(["i", "I", "l", "L", "f", "g"]), op=st.sampled_from([0, 1, 2]), side=st.booleans(),
        lens=st.lists(st.one_of(st.sampled_from(EDGES[:24]), st.integers(0, 50_000)), min_size=1, max_size=10),
-       masked=st.booleans(), seed=st.integers(0, 2**31), variant=st.sampled_from([0, 32, 64, 256, 256 | 32]),
+       masked=st.booleans(), seed=st.integers(0, 2**31), variant=st.sampled_from(live_variants([0, 32, 64, 256, 256 | 32])),
        in_off=st.integers(0, 3), out_off=st.integers(0, 3))
 def test_broadcast_super_array_scalar(ctx, fmt, op, side, lens, masked, seed, variant, in_off, out_off):
     """SuperArray (op) Scalar / Scalar (op) SuperArray (super_array.rs:87-116, scalar.rs:214-243) in one launch: chunks on

@@ -116,8 +116,7 @@ def test_group_over_distinct_devices(oracle, exchange, issue):
 
 
 @pytest.mark.rehearsal
-@pytest.mark.parametrize("members", [2, 4, 8])
-@pytest.mark.parametrize("issue", ["threads", "caller"])
+@pytest.mark.parametrize("members, issue", [(2, "threads"), (4, "threads"), (8, "threads"), (3, "caller"), (8, "caller")])
 @pytest.mark.parametrize("exchange", ["rccl", "rccl-overlap", "rccl-overlap-lanes"])
 def test_rehearsal_group_of_members_sharing_the_device(oracle, members, exchange, issue):
     """The same job with 2 / 4 / 8 members on device 0 through the loopback collective double: every member's all-gather waits
@@ -510,7 +509,7 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
 
         def caller(seed):
             r = np.random.default_rng(seed)
-            t_end = time.time() + float(os.environ.get("MA_STRESS_SECONDS", "6"))
+            t_end = time.time() + float(os.environ.get("MA_STRESS_SECONDS", "4"))
             k = 0
             while time.time() < t_end and not errors:
                 lens = [int(x) for x in r.integers(0, 4096, size=8)]
@@ -527,17 +526,17 @@ def test_group_issue_thread_handshake_spinning_and_sleeping():
 
         threads = [threading.Thread(target=caller, args=(s,)) for s in (1, 2)]
         [t.start() for t in threads]
-        [t.join(timeout=120 + float(os.environ.get("MA_STRESS_SECONDS", "6"))) for t in threads]
+        [t.join(timeout=120 + float(os.environ.get("MA_STRESS_SECONDS", "4"))) for t in threads]
         assert not any(t.is_alive() for t in threads), "a group call never returned (lost wake-up?)"
     assert not errors, errors[:3]
     assert sum(done) > 500, done
     print(f"{sum(done)} group calls from two threads checked, 0 errors")
 
 
-@pytest.mark.parametrize("members,exchange", [(1, "rccl"), (1, "rccl-overlap"), (4, "host"), (8, "host"),
-                                              pytest.param(4, "rccl", marks=pytest.mark.rehearsal),
-                                              pytest.param(8, "rccl-overlap", marks=pytest.mark.rehearsal)])
-@pytest.mark.parametrize("issue", ["threads", "caller"])
+@pytest.mark.parametrize("members,exchange,issue", [(1, "rccl", "threads"), (1, "rccl-overlap", "caller"), (4, "host", "caller"),
+                                                    (8, "host", "threads"),
+                                                    pytest.param(4, "rccl", "caller", marks=pytest.mark.rehearsal),
+                                                    pytest.param(8, "rccl-overlap", "threads", marks=pytest.mark.rehearsal)])
 def test_group_sum_of_a_chunked_column(ctx, oracle, members, exchange, issue):
     """ma_group_enqueue_sum_chunks: ONE column held as 3000 chunks (ragged, some empty, validity at odd bit offsets on two
     thirds), chunk i on member i % size; every member sums its chunks in one pass, one exchange: the total equals the sum

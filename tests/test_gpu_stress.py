@@ -19,7 +19,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SECONDS = float(os.environ.get("MA_STRESS_SECONDS", "6"))  # a longer soak: MA_STRESS_SECONDS=300 pytest -s tests/test_gpu_stress.py
+SECONDS = float(os.environ.get("MA_STRESS_SECONDS", "4"))  # a longer soak: MA_STRESS_SECONDS=300 pytest -s tests/test_gpu_stress.py
 N_MAX = 3_000_000
 
 
@@ -68,7 +68,7 @@ def test_sharded_ticket_handoff_under_uneven_load(oracle):
         slots = PinnedBuffer(64 * 64)
         vi, vf = slots.view(np.int64, 512), slots.view(np.float64, 512)
         ctx.set_async(True)
-        ctx.set_variant(256 if seed % 4 == 3 else 0)  # one of the four contexts uses the fenced publish form
+        ctx.set_variant(256 if seed % 4 == 3 else 0)  # one of the four contexts forces the chunk forms (and, on the tuning build, the fenced publish)
         t_end = time.time() + SECONDS
         done = 0
         while time.time() < t_end and not errors:

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=str, default="")
     args = ap.parse_args()
-    from minarrow_amd.host import Context
+    from minarrow_amd.host import Context, tuning_build
 
     ctx = Context(0)
     print(json.dumps({"hip_runtime": [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1]}), flush=True)
@@ -294,6 +294,8 @@ def main():
                                        (256 | 32, " [chunk-per-workgroup kernel on a pinned-host table, 8 x 16 B per lane]")):
                     if k < 2048 and variant & (256 | 1024):
                         continue  # shapes the library never picks for 8 chunks
+                    if variant and not tuning_build():
+                        continue  # the default matrix reports the forms the library picks; forced forms: the tuning build
                     ctx.set_variant(variant)
                     ms = timed(lambda: call(False), prime=True)
                     emit("route_super_array_broadcast", tag, f"add dense, {k} x {per}-row {label}{vname}", ms, 3 * rows * sz, rows)
@@ -328,7 +330,7 @@ def main():
                 ctx.synchronize()
                 for variant, vname in ((0, ""), (1024, " [one segment]"), (128, " [tile-search kernel on an uploaded table]"),
                                        (256 | 16, " [chunk-per-workgroup kernel, 4 x 16 B]"), (256 | 32, " [chunk-per-workgroup kernel, 8 x 16 B]")):
-                    if k < 2048 and variant:
+                    if variant and (k < 2048 or not tuning_build()):
                         continue
                     ctx.set_variant(variant)
                     shot = []
