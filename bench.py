@@ -1028,12 +1028,7 @@ def run_native(args, result_fd) -> int:
             raise _Downgrade("two scan lanes need stamps in plain device words")
         if S.lanes and S.ctx2 is None:
             # (an ordinary stream, like the group's second lanes: ma_group.hip setup_rccl has the measurements behind that)
-            if os.environ.get("MINARROW_HIP_SCAN_LANE_CLASS", "normal")[0] == "h":  # A/B: the lane's stream in the high priority class
-                os.environ["MINARROW_HIP_STREAM_PRIORITY"] = "high"
-            try:
-                S.ctx2 = Context(device_index)
-            finally:
-                os.environ.pop("MINARROW_HIP_STREAM_PRIORITY", None)
+            S.ctx2 = Context(device_index)
             S.ctx2.set_variant(args.variant)
             S.ctx2.set_blocks_per_cu(args.blocks_per_cu)
             S.ctx2.set_async(True)

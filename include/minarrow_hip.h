@@ -225,16 +225,16 @@ ma_status ma_dev_alloc(ma_ctx* ctx, size_t bytes, void** out_dev_ptr);
  * process, a negative value only queries; returns the previous setting. With the search on: on MI355X the write
  * rate of a region of HBM is a property of where the driver placed it: ~three quarters of the regions write at 5.4-5.8
  * TB/s under the kernels' store pattern, the rest at 6.3-6.8, while all of them read at 7.1-7.3. For
- * blocks of 256 MiB and more (MINARROW_HIP_OUTPUT_MIN_BYTES) this entry point tries 6 candidate blocks
- * (MINARROW_HIP_OUTPUT_CANDIDATES; 1 = off; parked blocks of the size class first, then fresh ones), and up to 6 more
+ * blocks of 256 MiB and more this entry point tries 6 candidate blocks
+ * (parked blocks of the size class first, then fresh ones), and up to 6 more
  * while the best is still below the good rate. Candidates are held while the search runs (a block given back would be the
  * next one handed out), so the search is BOUNDED: the blocks alive at one time never exceed 25 % of the HBM that is free
- * when the call starts (MINARROW_HIP_OUTPUT_HOLD_PERCENT), the search stops at that many, and a request two of which do not
+ * when the call starts, the search stops at that many, and a request two of which do not
  * fit the bound — a 64-GB consolidated column on a 288-GB device — is served by the plain allocator without measuring
  * anything. Each candidate's write rate is measured once with three launches of the store pattern (~1.3 ms each per 8 GB;
  * the rate is remembered for as long as the library owns the block); the search stops at the first block that reaches the
  * good rate = 0.97 x the device's own write ceiling (the placement-independent tight-front pattern, measured once per device;
- * MINARROW_HIP_OUTPUT_GOOD_GBPS overrides), returns the fastest and parks the others in the block cache, where ma_dev_alloc
+ * the tuning build reads the four figures from MINARROW_HIP_OUTPUT_*), returns the fastest and parks the others in the block cache, where ma_dev_alloc
  * picks them up as inputs. The probe tells the two classes apart but is no promise: on boxes where every candidate was a slow
  * region the best block wrote at 5.8 TB/s. The block's contents are undefined (the probe writes zeros). out_write_gbps (may
  * be NULL) receives the chosen block's measured rate, 0 when nothing was measured. Free with ma_dev_free.
@@ -420,7 +420,7 @@ ma_status ma_sum_fused_stamped_early(ma_ctx* ctx, size_t n_cols, const ma_fused_
                                      uint64_t* early_stamp);
 /* A zeroed word on the context's device that a stream can be made to wait on (hipStreamWaitValue64) and a kernel's
  * system-scope store reaches. A plain 64-byte device line by default: the wait is then a one-wave kernel that spins, which
- * leaves the other streams' dispatches alone; MINARROW_HIP_STAMP_SIGNAL=1 asks for the runtime's signal memory instead (8 bytes,
+ * leaves the other streams' dispatches alone; the tuning build's MINARROW_HIP_STAMP_SIGNAL=1 asks for the runtime's signal memory instead (8 bytes,
  * host memory; the wait becomes a packet the command processor polls — measured to hold up the scan stream of an overlapped
  * step by 19-25 %, profiles/r05_share_1gpu.txt — but a host store can release it). Free with ma_stamp_free. */
 ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp);

@@ -2,6 +2,8 @@
 // Nothing here is part of the C ABI (include/minarrow_hip.h is).
 #pragma once
 
+#include "ma_env.hpp"  // the environment surface, one documented line per variable
+
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -173,6 +175,9 @@ bool nosync_active();
 #define MA_TUNING 0
 #endif
 constexpr int kFormBits = 16 | 32 | 128 | 256 | 16384 | 65536;
+// Environment variables that only ever served an A/B (MINARROW_HIP_STAMP_SIGNAL, _SCAN_LANE_CLASS, _STREAM_PRIORITY, the tunables of
+// the opt-in output search): read in the tuning build only, through this.
+inline const char* tuning_env(const char* name) { return MA_TUNING ? getenv(name) : nullptr; }
 inline int form_variant(const ma_ctx* ctx) { return ctx->variant & kFormBits; }
 #if MA_TUNING
 inline int tuning_variant(const ma_ctx* ctx) { return ctx->variant; }

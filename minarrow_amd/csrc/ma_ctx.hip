@@ -862,9 +862,9 @@ static ma_status ctx_create_impl(int32_t device, void* stream, bool borrow, ma_c
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
     } else {
-        // MINARROW_HIP_STREAM_PRIORITY=high|low (read at every creation): the context's stream in that priority class — the
+        // (tuning build only) MINARROW_HIP_STREAM_PRIORITY=high|low (read at every creation): the context's stream in that priority class — the
         // runtime keeps a hardware-queue pool per class, so a "high" context never shares a hardware queue with ordinary ones
-        const char* prio = getenv("MINARROW_HIP_STREAM_PRIORITY");
+        const char* prio = tuning_env("MINARROW_HIP_STREAM_PRIORITY");
         const int cls = t_stream_class ? t_stream_class : (prio && prio[0] == 'h') ? 1 : (prio && prio[0] == 'l') ? -1 : 0;
         int least = 0, greatest = 0;
         if (cls != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
@@ -1355,10 +1355,11 @@ ma_status ma_dev_alloc_output(ma_ctx* ctx, size_t bytes, void** out_dev_ptr, flo
     MA_NO_CAPTURE(ctx, "ma_dev_alloc_output");
     MA_HIP(hipSetDevice(ctx->device));
     // Small blocks, or the feature switched off: the plain allocator.
-    static const size_t kMinBytes = env_bytes("MINARROW_HIP_OUTPUT_MIN_BYTES", (size_t)256 << 20);
-    static const size_t kCandidates = env_bytes("MINARROW_HIP_OUTPUT_CANDIDATES", 6);
-    static const float kGoodEnv = (float)env_bytes("MINARROW_HIP_OUTPUT_GOOD_GBPS", 0);  // 0 = calibrate (below)
-    static const size_t kHoldPercent = env_bytes("MINARROW_HIP_OUTPUT_HOLD_PERCENT", 25);
+    // (the four tunables below are read in the tuning build only; the shipped library keeps their defaults)
+    static const size_t kMinBytes = MA_TUNING ? env_bytes("MINARROW_HIP_OUTPUT_MIN_BYTES", (size_t)256 << 20) : (size_t)256 << 20;
+    static const size_t kCandidates = MA_TUNING ? env_bytes("MINARROW_HIP_OUTPUT_CANDIDATES", 6) : 6;
+    static const float kGoodEnv = MA_TUNING ? (float)env_bytes("MINARROW_HIP_OUTPUT_GOOD_GBPS", 0) : 0.0f;  // 0 = calibrate (below)
+    static const size_t kHoldPercent = MA_TUNING ? env_bytes("MINARROW_HIP_OUTPUT_HOLD_PERCENT", 25) : 25;
     const int dev = ctx->device;
     if (!output_search_enabled() || bytes < kMinBytes || kCandidates <= 1 || dev < 0 || dev >= kMaxPooledDevices) {
         MA_HIP(dev_block_alloc(dev, bytes, out_dev_ptr));
@@ -1503,7 +1504,7 @@ ma_status ma_stamp_alloc(ma_ctx* ctx, uint64_t** out_stamp) {
 // use (testing hooks): a host store releases them with no GPU queue involved.
 bool ma::stamp_default_is_signal() {
     static const bool on = [] {
-        const char* e = getenv("MINARROW_HIP_STAMP_SIGNAL");
+        const char* e = tuning_env("MINARROW_HIP_STAMP_SIGNAL");
         return e && e[0] && e[0] != '0';
     }();
     return on;

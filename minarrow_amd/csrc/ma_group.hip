@@ -264,8 +264,10 @@ ma_status setup_rccl(ma_group* g, bool overlap, bool lanes) {
             // makes the bare scans gain every time (tools/probe_early_stamp.py high) but loses the gain once the exchange stream
             // is in the picture (tools/run_share_lanes.sh: 0.287 against 0.275-0.279) — so: the ordinary class, and a host that
             // MEASURES both forms before it settles on one (ma_group_set_scan_lanes; bench.py's un-timed trial).
-            const char* cls = getenv("MINARROW_HIP_SCAN_LANE_CLASS");
-            MA_TRY(create_ctx_in_class(g->ctxs[i]->ordinal, (cls && cls[0] == 'h') ? +1 : 0, &g->scan2[i]));
+            // (a rehearsal — members sharing one device, their own streams in the high class, ma_group_create_ex — puts the second
+            // lanes there too: in a lower class than the first lanes they would only run when those are idle)
+            const char* cls = tuning_env("MINARROW_HIP_SCAN_LANE_CLASS");
+            MA_TRY(create_ctx_in_class(g->ctxs[i]->ordinal, g->carrier_class ? g->carrier_class : (cls && cls[0] == 'h') ? +1 : 0, &g->scan2[i]));
             MA_TRY(ma_ctx_set_async(g->scan2[i], 1));
             MA_HIP(hipSetDevice(devs[i]));
             MA_HIP(hipEventCreateWithFlags(&g->ev_lane[i], hipEventDisableTiming | hipEventReleaseToDevice));

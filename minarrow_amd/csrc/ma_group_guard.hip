@@ -724,7 +724,7 @@ ma_status ma_group_set_scan_lanes(ma_group* group, int32_t on) {
         // the lanes no faster than one stream
         for (size_t i = 0; i < group->ctxs.size(); ++i) {
             ma_ctx* fresh = nullptr;
-            MA_TRY(create_ctx_in_class(group->ctxs[i]->ordinal, 0, &fresh));
+            MA_TRY(create_ctx_in_class(group->ctxs[i]->ordinal, group->carrier_class, &fresh));
             const ma_status st = ma_ctx_set_async(fresh, 1);
             if (st != MA_OK) {
                 ma_ctx_destroy(fresh);

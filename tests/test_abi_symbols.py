@@ -163,3 +163,15 @@ def test_environment_surface_is_read(tmp_path):
                        cwd=str(ffi.LIB_PATH.parent.parent.parent))
     # defaults = the measured crossovers of a ~12 us synchronous call against one host thread
     assert r.stdout.split()[0] == str(1 << 18) and r.stdout.split()[2] == str(1 << 15)
+
+
+def test_environment_table_is_generated_from_the_source():
+    """INTEGRATION.md section 5's table comes from minarrow_amd/csrc/ma_env.hpp (tools/gen_env_table.py): every MINARROW_HIP_* variable
+    the product's sources read is documented there, nothing documented is unread, and the committed table is the generated one."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "gen_env_table.py"), "--check"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr

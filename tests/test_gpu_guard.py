@@ -412,8 +412,8 @@ def _same_on_every_member(g, want):
 
 
 @pytest.mark.rehearsal
-@pytest.mark.parametrize("members, stalled", [(8, 3), (2, 1)])
-@pytest.mark.parametrize("exchange, issue", REHEARSAL_FORMS)
+@pytest.mark.parametrize("members, stalled, exchange, issue", [(8, 3, x, i) for x, i in REHEARSAL_FORMS] +
+                         [(2, 1, "rccl", "threads"), (2, 0, "rccl-overlap-lanes", "caller")])
 def test_rehearsal_a_stalled_member_among_peers(members, stalled, exchange, issue):
     """Member 3 of 8 never starts its all-gather: the seven others' collectives are on the GPU, waiting for it — what a lost peer
     looks like over xGMI. ma_group_synchronize_for names the member within its deadline, the abort ends all eight communicators,

@@ -27,11 +27,6 @@ jobs = {
     "sum_u8_dense": lambda: ctx.sum_into("u8", a, B, out_sum=r, out_count=r + 8),
     "sum_u8_gated": lambda: ctx.sum_into("u8", a, B, out_sum=r, out_count=r + 8, mask=mask, mask_bit_offset=13),
     "sum_i8_gated": lambda: ctx.sum_into("i8", a, B, out_sum=r, out_count=r + 8, mask=mask, mask_bit_offset=13),
-    # round 4's shape of the same two (2 loads per lane, three workgroups per CU: ctx variant unroll = 2), same process
-    "sum_u8_gated_round4_shape": lambda: (ctx.set_variant(2), ctx.sum_into("u8", a, B, out_sum=r, out_count=r + 8, mask=mask, mask_bit_offset=13),
-                                          ctx.set_variant(0)),
-    "sum_i8_gated_round4_shape": lambda: (ctx.set_variant(2), ctx.sum_into("i8", a, B, out_sum=r, out_count=r + 8, mask=mask, mask_bit_offset=13),
-                                          ctx.set_variant(0)),
     "sum_i64_gated": lambda: ctx.sum_into("i64", a, B // 8, out_sum=r, out_count=r + 8, mask=mask, mask_bit_offset=13),
     "eq_mask_u8": lambda: ctx.simd_eq_mask("u8", a, B, 0x7, 0x3, out),
     "eq_mask_u16": lambda: ctx.simd_eq_mask("u16", a, B // 2, 0x7, 0x3, out),
