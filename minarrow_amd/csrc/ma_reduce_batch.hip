@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r].init();
     uint64_t cnt = 0;
-    auto flush = [&](unsigned slot) {  // lanes and slots -> one partial; the accumulators start over
+    auto flush = [&](unsigned slot) {  // (TOTAL only) lanes and slots -> the wave's one partial; the accumulators start over
 #pragma unroll
         for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
 #pragma unroll
@@ -354,27 +354,89 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
             cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
         }
         if (lane == 0) {
-            if (!TOTAL && out.direct) {
-                if constexpr (std::is_same<Acc, DDAcc>::value) {
-                    acc[0].normalise();
-                    out.f64[slot] = acc[0].hi;
-                    out.i64[slot] = 0;  // (points into `partials`: float formats have no integer sums)
-                } else {
-                    out.i64[slot] = acc[0].s;
-                    out.f64[slot] = out.is_signed ? (double)(int64_t)acc[0].s : (double)acc[0].s;
-                }
-                out.cnt[slot] = cnt;
-            } else {
-                Partial p;
-                acc[0].to_partial(p);
-                p.cnt = cnt;
-                p.pad = 0;
-                partials[slot] = p;
-            }
+            Partial p;
+            acc[0].to_partial(p);
+            p.cnt = cnt;
+            p.pad = 0;
+            partials[slot] = p;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r].init();
         cnt = 0;
+    };
+
+    // ---- per-column results without a cross-lane reduction per column (round 6) ---------------------------------------------------
+    // A column of 8192 rows is four tiles; reducing it across the wave the moment it ends is six dependent shuffle stages (twice, for
+    // the valid count) in front of the next column's first tile — on ONE wave per SIMD, with nobody to cover. Instead a lane PARKS
+    // its partial of the column in the wave's own LDS rows (one 8-byte store per word: no dependency, no wait) and goes on; every
+    // kBatch columns the wave reduces the batch transposed: lane l adds up 64 / G of column l / G's 64 parked partials (G = 64 /
+    // kBatch lanes per column), log2(G) shuffle stages finish kBatch columns at once, and G-th lanes write the results. A wave's
+    // columns are col, col + n_w, ...: the batch's first column and a count describe it.
+    constexpr int kBatch = 8;
+    constexpr bool kDD = std::is_same<Acc, DDAcc>::value;
+    __shared__ uint64_t park_a[TOTAL ? 1 : kWaves][TOTAL ? 1 : kBatch][TOTAL ? 1 : 64];
+    __shared__ uint64_t park_b[(TOTAL || !kDD) ? 1 : kWaves][(TOTAL || !kDD) ? 1 : kBatch][(TOTAL || !kDD) ? 1 : 64];
+    __shared__ uint64_t park_c[TOTAL ? 1 : kWaves][TOTAL ? 1 : kBatch][TOTAL ? 1 : 64];
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned in_batch = 0, batch_first = 0;
+    auto park = [&](unsigned column) {
+        if (in_batch == 0) batch_first = column;
+#pragma unroll
+        for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+        Partial p;
+        acc[0].to_partial(p);
+        park_a[TOTAL ? 0 : wave][TOTAL ? 0 : in_batch][TOTAL ? 0 : lane] = p.a;
+        if constexpr (kDD && !TOTAL) park_b[wave][in_batch][lane] = p.b;
+        park_c[TOTAL ? 0 : wave][TOTAL ? 0 : in_batch][TOTAL ? 0 : lane] = cnt;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r].init();
+        cnt = 0;
+        ++in_batch;
+    };
+    auto reduce_batch = [&]() {
+        constexpr unsigned G = 64 / kBatch, kPer = 64 / G;  // G lanes per column, kPer parked partials per lane
+        __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations complete in order; this keeps the compiler from moving the reads up)
+        const unsigned jj = lane / G, part = lane % G;
+        Acc t;
+        t.init();
+        uint64_t n = 0;
+#pragma unroll
+        for (unsigned i = 0; i < kPer; ++i) {
+            const unsigned idx = part * kPer + ((i + lane) & (kPer - 1));  // rotated: the G lanes of a column start on different banks
+            Acc o;
+            uint64_t b = 0;
+            if constexpr (kDD && !TOTAL) b = park_b[wave][jj][idx];
+            o.from_words(park_a[TOTAL ? 0 : wave][TOTAL ? 0 : jj][TOTAL ? 0 : idx], b);
+            t.merge(o);
+            n += park_c[TOTAL ? 0 : wave][TOTAL ? 0 : jj][TOTAL ? 0 : idx];
+        }
+#pragma unroll
+        for (int off = (int)G / 2; off > 0; off >>= 1) {
+            t.shfl_down_merge(off);
+            n += (uint64_t)__shfl_down((unsigned long long)n, off, 64);
+        }
+        if (part == 0 && jj < in_batch) {
+            const unsigned slot = batch_first + jj * n_w;
+            if (out.direct) {
+                if constexpr (kDD) {
+                    t.normalise();
+                    out.f64[slot] = t.hi;
+                    out.i64[slot] = 0;  // (points into `partials`: float formats have no integer sums)
+                } else {
+                    out.i64[slot] = t.s;
+                    out.f64[slot] = out.is_signed ? (double)(int64_t)t.s : (double)t.s;
+                }
+                out.cnt[slot] = n;
+            } else {
+                Partial p;
+                t.to_partial(p);
+                p.cnt = n;
+                p.pad = 0;
+                partials[slot] = p;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the rows are written again from here on
+        in_batch = 0;
     };
 
     unsigned col = w_id;
@@ -457,7 +519,10 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
                     acc[0].add(x);
                 }
                 if (!c.words && lane == 0) cnt += c.len;
-                if (!TOTAL) flush(col);
+                if constexpr (!TOTAL) {
+                    park(col);
+                    if (in_batch == (unsigned)kBatch || col_n >= n_cols) reduce_batch();  // a full batch, or the wave's last column
+                }
             }
             if (col_n >= n_cols) {
                 finished = true;

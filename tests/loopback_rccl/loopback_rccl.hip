@@ -244,12 +244,26 @@ void init_control(Control* c, uint32_t n_ranks, uint32_t slot_bytes) {
     c->magic = kMagic;
 }
 
+// Blocks of one-process worlds that are no longer in use, by size: handed out again instead of freed. hipHostFree waits for the
+// DEVICE to run empty, and a communicator is often dropped exactly when some stream of its host is stuck (an abort).
+std::mutex g_blocks_mu;
+std::vector<std::pair<size_t, void*>> g_blocks;
+
 std::shared_ptr<World> make_local_world(int n_ranks) {
     auto w = std::make_shared<World>();
     const uint32_t slot = slot_bytes_from_env();
     w->bytes = world_bytes((uint32_t)n_ranks, slot);
     void* p = nullptr;
-    if (hipHostMalloc(&p, w->bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    {
+        std::lock_guard<std::mutex> lock(g_blocks_mu);
+        for (size_t i = 0; i < g_blocks.size(); ++i)
+            if (g_blocks[i].first == w->bytes) {
+                p = g_blocks[i].second;
+                g_blocks.erase(g_blocks.begin() + (long)i);
+                break;
+            }
+    }
+    if (!p && hipHostMalloc(&p, w->bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -363,7 +377,8 @@ void drop(ncclComm* comm) {
                 (void)hipHostUnregister(w->host);
                 munmap(w->host, w->bytes);
             } else {
-                (void)hipHostFree(w->host);
+                std::lock_guard<std::mutex> lock(g_blocks_mu);  // kept for the next world of this size (never hipHostFree: it waits for the device)
+                g_blocks.emplace_back(w->bytes, (void*)w->host);
             }
             (void)hipGetLastError();
         }

@@ -587,3 +587,51 @@ def test_rehearsal_a_stalled_rank_and_a_vanished_rank():
     for o in outs:
         assert o["timed_out"] and o["broken"] == 1 and o["waited_s"] < 8.0 and o["ctx_ok"] and o["second_comm_ok"], o
     assert outs[0]["vanished_peer_timed_out"] and outs[0]["vanished_waited_s"] < 8.0 and outs[0]["ctx_ok_after_vanish"], outs[0]
+
+
+@pytest.mark.rehearsal
+@pytest.mark.parametrize("exchange, issue", [("rccl-overlap-lanes", "threads"), ("rccl-overlap", "caller"), ("rccl", "threads")])
+def test_rehearsal_soak_of_steps_with_a_jittery_host(exchange, issue):
+    """Ordering under a host that does not keep time: 8 members, 240 steps over THREE different tables in turn (a step served by the
+    wrong record set, started before its input was ready, or folded from a peer's stale block shows as a wrong total), random
+    pauses between enqueue, exchange and the occasional bounded wait, columns rewritten in place between steps on some members,
+    the finals read on a random member every few steps."""
+    rng = np.random.default_rng(len(exchange) * 7 + len(issue))
+    g = _rccl_group(exchange, issue, 8)
+    try:
+        ctxs = [g.member_ctx(m) for m in range(8)]
+        n = 1 << 18
+        tables = []
+        for k in range(3):
+            ci, cf = [c.alloc(n * 8) for c in ctxs], [c.alloc(n * 8) for c in ctxs]
+            for m, c in enumerate(ctxs):
+                c.synth_iota("i64", ci[m], n, 10 * k + m)
+                c.synth_iota("f64", cf[m], n, 10 * k + m)
+            tables.append([ci, cf, [10 * k + m for m in range(8)]])
+
+        def want(starts):
+            s = sum(n * (n - 1) // 2 + st * n for st in starts)
+            return (s, 8 * n, float(s), 8 * n)
+
+        checked = 0
+        for step in range(240):
+            ci, cf, starts = tables[step % 3]
+            if step % 17 == 16:  # the host rewrites one member's chunk of the table the NEXT use of which is three steps away ...
+                m = int(rng.integers(0, 8))
+                g.join_lanes()  # ... behind whatever lane still reads it
+                starts[m] += 1000
+                ctxs[m].synth_iota("i64", ci[m], n, starts[m])
+                ctxs[m].synth_iota("f64", cf[m], n, starts[m])
+            if rng.random() < 0.3:
+                time.sleep(float(rng.choice([0.0001, 0.0005, 0.002])))
+            g.enqueue_sum_table([("l", 0, ci, [n] * 8), ("g", 0, cf, [n] * 8)])
+            if rng.random() < 0.3:
+                time.sleep(float(rng.choice([0.0001, 0.001])))
+            g.exchange()
+            if rng.random() < 0.2 or step == 239:
+                g.synchronize_for(20_000)
+                assert g.result(0, int(rng.integers(0, 8))) == want(starts), step
+                checked += 1
+        assert checked >= 20 and g.is_broken == 0
+    finally:
+        g.close()
