@@ -119,9 +119,9 @@ def test_sharded_table_checks_in_a_torch_first_process():
 
 @pytest.mark.gpu
 @pytest.mark.rehearsal
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3])  # (with the two pytest sessions that is 5 processes on the card: the pool allows 6)
 def test_rehearsal_sharded_table_records_across_rank_processes(world):
-    """The same per-(batch, column) records with PEERS: 2 / 4 rank processes on this box's one GPU, 3 batches x 2 columns of records
+    """The same per-(batch, column) records with PEERS: 2 / 3 rank processes on this box's one GPU, 3 batches x 2 columns of records
     per rank in ONE ma_comm_sum_exchange through the loopback collective double (tests/loopback_rccl), folded per column over
     (rank, batch) in that order on every rank: i64 bit-exact, f64 within 1 ULP of the exactly rounded sum, the same bits everywhere."""
     from conftest import run_rank_processes

@@ -28,8 +28,8 @@ step "one process, group API, RCCL exchange (1 GPU)"; timeout -k 10 300 python3 
 step "launcher, one rank, native communicator, torch-free GPU path"; timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-dist --no-cpu-baseline > $O/${R}_bench_ranks_1gpu_native_comm.json 2> $O/${R}_bench_ranks.err || exit 1
 step "REHEARSAL (loopback collective double): 8 members in one process, then 2 rank processes, on this one GPU"
 DBL="MINARROW_HIP_RCCL_PATH=$GRAFT_REPO_ROOT/tests/loopback_rccl/libloopback_rccl.so"
-env $DBL GPU_MAX_HW_QUEUES=8 timeout -k 10 300 python3 bench.py --gpus 8 --rows 1000000000 --no-cpu-baseline --no-other-configs > $O/${R}_bench_rehearsal_group_8_members_one_gpu.json 2> $O/${R}_bench_rehearsal_group.err
-env $DBL timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --rows 1000000000 --no-cpu-baseline --no-other-configs > $O/${R}_bench_rehearsal_ranks_2_processes_one_gpu.json 2> $O/${R}_bench_rehearsal_ranks.err
+env $DBL GPU_MAX_HW_QUEUES=8 timeout -k 10 300 python3 bench.py --gpus 8 --rows 1000000000 --scan-lanes on --no-cpu-baseline --no-other-configs > $O/${R}_bench_rehearsal_group_8_members_one_gpu.json 2> $O/${R}_bench_rehearsal_group.err
+env $DBL timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --rows 1000000000 --scan-lanes on --no-cpu-baseline --no-other-configs > $O/${R}_bench_rehearsal_ranks_2_processes_one_gpu.json 2> $O/${R}_bench_rehearsal_ranks.err
 step "the 8192-row chunk regime by counters (60 000 columns, then 10^9 rows)"; bash tools/pmc_column_waves.sh $R 60000 > $O/${R}_column_waves.log 2>&1
 timeout -k 10 200 python3 tools/pmc_column_waves.py 20 122070 > $O/${R}_column_waves_wall_1e9_rows.json 2>/dev/null
 step "write-side counters of the library's read + write kernels"; bash tools/pmc_write_lib.sh $R > $O/${R}_pmc_write_lib.log 2>&1
