@@ -275,11 +275,9 @@ void write_word(ma_scan_lanes* lanes, uint64_t* word, const uint64_t* value) {
 // Everything a stream of the pipeline can be held behind gets the value that ends the wait: the hold hook's word, and all-ones
 // in both words of both stamp lines (word 1, the early stamp, is what the gates wait on).
 void release_gates(ma_scan_lanes* lanes) {
-    static const uint64_t kAll = ~(uint64_t)0;
-    static uint64_t hold_release;  // storage that outlives a copy on the rescue stream
+    static const uint64_t kAll = ~(uint64_t)0;  // (static: the source of a copy on the rescue stream must outlive this call)
     if (lanes->hold_armed && lanes->hold_word) {
-        hold_release = ++lanes->hold_seq;
-        write_word(lanes, lanes->hold_word, &hold_release);
+        write_word(lanes, lanes->hold_word, &kAll);  // the pipeline takes no more scans after a release: the word need not hold again
         lanes->hold_armed = false;
     }
     for (int k = 0; k < 2; ++k) {

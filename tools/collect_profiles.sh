@@ -44,4 +44,4 @@ for a in "8192 20000" "65536 2000" "1000000 128"; do timeout -k 10 200 python3 t
 for a in "8192 5000" "65536 1000" "1000000 64"; do timeout -k 10 200 python3 tools/bench_stream_op.py $a 2>/dev/null | tail -1; done > $O/${R}_stream_op.jsonl
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_fetch_fused $O/pmc_write_fused
 ls -la $O
-head -c 1500 $O/${R}_bench.json
+[ -f $O/${R}_bench.json ] && head -c 1500 $O/${R}_bench.json || true
