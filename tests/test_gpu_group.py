@@ -90,11 +90,19 @@ def test_device_fold_of_records_equals_the_host_fold(ctx):
         np.testing.assert_array_equal(dout.download(np.uint64, 4), out)
 
 
+def _uploaders(ctxs):
+    """The context each member's chunk is uploaded through: its own — or, when the members share ONE device (a rehearsal), member 0's
+    for all: an upload grows a context two copy streams, and a process should not keep more hardware queues alive on a device
+    than it runs at a time (23: DESIGN.md section 6)."""
+    return [ctxs[0]] * len(ctxs) if len({c.hip_device for c in ctxs}) == 1 else list(ctxs)
+
+
 def _chunk_tables(ctxs, ints, flts, bits, chunks):
     """Uploads chunk i to member i's device; returns the per-member buffers."""
-    di = [c.to_device(ints[a:b], 64) for c, (a, b) in zip(ctxs, chunks)]
-    df = [c.to_device(flts[a:b], 64) for c, (a, b) in zip(ctxs, chunks)]
-    dm = [c.to_device(bits, 16) for c in ctxs]  # every device holds the un-windowed validity buffer
+    up = _uploaders(ctxs)
+    di = [c.to_device(ints[a:b], 64) for c, (a, b) in zip(up, chunks)]
+    df = [c.to_device(flts[a:b], 64) for c, (a, b) in zip(up, chunks)]
+    dm = [c.to_device(bits, 16) for c in up]  # every device holds the un-windowed validity buffer
     return di, df, dm
 
 
@@ -603,10 +611,10 @@ def test_group_fused_table_step_equals_the_per_column_steps(ctx, oracle, members
         ctxs = [g.member_ctx(i) for i in range(members)]
         chunks = row_chunks(n, members)
         lens = [b - a for a, b in chunks]
-        # every member's chunks live in its own context's allocations (same device here)
-        di = [ctxs[i].to_device(ints[a:b], 64) for i, (a, b) in enumerate(chunks)]
-        df = [ctxs[i].to_device(flts[a:b], 64) for i, (a, b) in enumerate(chunks)]
-        dm = [ctxs[i].to_device(bits, 16) for i in range(members)]
+        up = _uploaders(ctxs)  # (the members share device 0 here)
+        di = [up[i].to_device(ints[a:b], 64) for i, (a, b) in enumerate(chunks)]
+        df = [up[i].to_device(flts[a:b], 64) for i, (a, b) in enumerate(chunks)]
+        dm = [up[i].to_device(bits, 16) for i in range(members)]
         offs = [a for a, _ in chunks]
         for masks in (None, dm):
             for _ in range(3):  # overlapped exchanges alternate between two record sets
