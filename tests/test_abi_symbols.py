@@ -175,3 +175,33 @@ def test_environment_table_is_generated_from_the_source():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tools" / "gen_env_table.py"), "--check"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr
+
+
+def test_the_collective_library_can_be_named_and_a_stand_in_says_what_it_is():
+    """MINARROW_HIP_RCCL_PATH: the library opens the collective library the host names and no other — a path that does not open is an
+    error (no silent fall-back to the system's RCCL), and the loopback collective double of tests/loopback_rccl (test infrastructure:
+    the twelve entry points load_rccl() resolves, liveness semantics on one device) is reported as a REHEARSAL by ma_rccl_path and
+    ma_rccl_version. No GPU needed: nothing is initialised by opening it."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    double = root / "tests" / "loopback_rccl" / "libloopback_rccl.so"
+    assert double.exists(), f"{double} is missing: make -C tests/cpp"
+    out = subprocess.run(["nm", "-D", "--defined-only", str(double)], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    resolved = {"ncclGetVersion", "ncclGetUniqueId", "ncclCommInitRank", "ncclCommInitAll", "ncclCommDestroy", "ncclCommCount", "ncclCommAbort",
+                "ncclAllGather", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"}  # ma_rccl.hip: load_rccl()
+    assert resolved | {"ncclLoopbackDoubleInfo"} <= exported, sorted(resolved - exported)
+    code = "from minarrow_amd import ffi; l = ffi.load_library(); print(repr(l.ma_rccl_path().decode()), l.ma_rccl_version())"
+    env = {k: v for k, v in os.environ.items() if k != "MINARROW_HIP_RCCL_PATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(root),
+                       env=dict(env, MINARROW_HIP_RCCL_PATH=str(double)))
+    assert r.returncode == 0, r.stderr
+    path, version = r.stdout.strip().rsplit(" ", 1)
+    assert path.startswith("'REHEARSAL") and str(double) in path and version == "9900", r.stdout
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(root),
+                       env=dict(env, MINARROW_HIP_RCCL_PATH="/nonexistent/librccl.so"))
+    assert r.returncode == 0 and r.stdout.strip() == "'' 0", r.stdout + r.stderr  # an error, not the system's RCCL
