@@ -51,14 +51,18 @@ int main(int argc, char** argv) {
     const size_t rows = argc > 1 ? (size_t)strtoull(argv[1], NULL, 10) : ((size_t)1 << 26);
     const int steps = argc > 2 ? atoi(argv[2]) : 8;
     const double deadline_ms = argc > 3 ? atof(argv[3]) : 500.0;
-    int n = ma_device_count();
+    const int visible = ma_device_count();
+    int n = visible;
     if (n <= 0) {
         printf("no HIP device is visible\n");
         return 2;
     }
     if (n > MAX_GPUS) n = MAX_GPUS;
+    /* argv[4] = members: more members than GPUs makes them share devices (member i on GPU i mod visible) — what only the loopback
+     * collective double takes (MINARROW_HIP_RCCL_PATH, a rehearsal on a one-GPU box); with RCCL itself the group falls back to the host fold */
+    if (argc > 4 && atoi(argv[4]) > 0 && atoi(argv[4]) <= MAX_GPUS) n = atoi(argv[4]);
     int32_t devices[MAX_GPUS];
-    for (int i = 0; i < n; ++i) devices[i] = i;
+    for (int i = 0; i < n; ++i) devices[i] = i % visible;
 
     ma_group* g = NULL;
     CHECK(ma_group_create_ex(devices, n,

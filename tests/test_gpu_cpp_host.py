@@ -74,6 +74,20 @@ def test_c_example_of_the_partitioned_sums_with_bounded_waits(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.rehearsal
+def test_rehearsal_c_host_with_eight_members_on_one_gpu(tmp_path):
+    """The same C99 host with EIGHT members on this box's one GPU through the loopback collective double: the self-test with
+    peers, a stalled last member whose seven peers' all-gathers really wait for it, the error naming it after the deadline, the
+    rebuild one notch down, every member's totals against the closed forms."""
+    exe = _build_example(tmp_path, "partitioned_sum")
+    r = subprocess.run([str(exe), str((1 << 22) + 77), "6", "400", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "group of 8 GPU(s)" in r.stdout and "REHEARSAL" in r.stdout and "self-test: PASS: 8 members on 1 device(s)" in r.stdout, r.stdout
+    assert "did not finish within 400 ms" in r.stdout and "member 7 " in r.stdout and "one notch down" in r.stdout, r.stdout
+    assert r.stdout.strip().splitlines()[-1].startswith("ok: 6 steps"), r.stdout
+
+
+@pytest.mark.gpu
 def test_c_example_of_the_hot_loop_of_sums_on_one_stream_and_on_two_scan_lanes(tmp_path):
     """examples/hot_loop_sums.c: the reference's hot loop (one sum call per pass over the same arrays) from a C99 host — every
     pass one fused launch on the context's stream, then the same passes through ma_scan_lanes_*; every pass's record against the

@@ -42,5 +42,5 @@ def test_every_multi_rank_path_through_the_loopback_double():
     tail = r.stdout[-6000:] + r.stderr[-3000:]
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) >= 65, tail
+    assert m and int(m.group(1)) >= 68, tail
     print(r.stdout.strip().splitlines()[-1])
