@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "ma_common.hpp"
 
@@ -30,6 +31,41 @@ struct IntAcc {
         p.b = 0;
     }
     __device__ __forceinline__ void from_words(uint64_t a, uint64_t) { s = a; }
+};
+
+// 32-bit integers, for a FEW THOUSAND adds at most (one chunk of a chunked column): the halves of a value go to two 32-bit words
+// — `lo` takes bits 0..15 (zero-extended), `hi` bits 16..31 (sign- or zero-extended as T is) — two
+// full-rate adds with a sub-dword operand (v_add_u32_sdwa ... src1_sel:WORD_0 / sext(WORD_1)) where IntAcc::add is a shift, a
+// register copy and a 64-bit add per value. 65 535 adds cannot overflow either word (65 535 x 65 535 < 2^32, 65 535 x 32 768 < 2^31);
+// the owner widens (and starts over) long before: ma_reduce_batch.hip's column_waves_kernel, per chunk.
+template <typename T>
+struct SplitAcc {
+    static_assert(sizeof(T) == 4 && std::is_integral<T>::value, "32-bit integers");
+    typedef typename std::conditional<std::is_signed<T>::value, int32_t, uint32_t>::type Hi;
+    uint32_t lo;
+    Hi hi;
+    __device__ __forceinline__ void init() {
+        lo = 0;
+        hi = 0;
+    }
+    __device__ __forceinline__ void add(T v) {
+        // lo += v & 0xffff; hi += v >> 16 (arithmetic for a signed T) — said in the instruction's own words: left to itself the
+        // compiler extracts both halves first (v_and, v_ashrrev) and pairs the adds (v_add3), three instructions per value again
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(lo) : "v"(lo), "v"(v));
+        if constexpr (std::is_signed<T>::value)
+            asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi) : "v"(hi), "v"(v));
+        else
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi) : "v"(hi), "v"(v));
+    }
+    __device__ __forceinline__ void merge(const SplitAcc& o) {
+        lo += o.lo;
+        hi += o.hi;
+    }
+    __device__ __forceinline__ IntAcc widen() const {
+        IntAcc a;
+        a.s = (uint64_t)(int64_t)hi * 65536u + lo;  // wrapping; (int64_t) of an unsigned Hi is its zero extension
+        return a;
+    }
 };
 
 // Double-double accumulator: hi + lo carries the running sum to ~106 bits.

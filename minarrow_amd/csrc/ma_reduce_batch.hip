@@ -341,27 +341,45 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
         raw = as_global(masked ? c.words : (const uint64_t*)partials)[masked ? idx : 0];
     };
 
-    Acc acc[R];
+    // 32-bit integers accumulate in halves (SplitAcc: two full-rate adds per value instead of a shift, a copy and a 64-bit add —
+    // this loop's issue time is what bounds it: profiles/r06_column_waves.md) and are widened once per column: a column is at most
+    // 65 536 rows here, 256 adds per accumulator.
+    constexpr bool kSplit = sizeof(T) == 4 && std::is_integral<T>::value;
+    typedef typename std::conditional<kSplit, SplitAcc<typename std::conditional<kSplit, T, int32_t>::type>, Acc>::type TileAcc;
+    TileAcc acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r].init();
     uint64_t cnt = 0;
-    auto flush = [&](unsigned slot) {  // (TOTAL only) lanes and slots -> the wave's one partial; the accumulators start over
+    Acc run;  // (TOTAL with SplitAcc only) the columns so far
+    run.init();
+    auto widened = [&]() -> Acc {  // the R accumulators as one; they start over
 #pragma unroll
         for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+        Acc w;
+        if constexpr (kSplit) w = acc[0].widen();
+        else w = acc[0];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r].init();
+        return w;
+    };
+    auto flush = [&](unsigned slot) {  // (TOTAL only) lanes and slots -> the wave's one partial; the accumulators start over
+        Acc w = widened();
+        if constexpr (kSplit) {
+            w.merge(run);
+            run.init();
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            acc[0].shfl_down_merge(off);
+            w.shfl_down_merge(off);
             cnt += (uint64_t)__shfl_down((unsigned long long)cnt, off, 64);
         }
         if (lane == 0) {
             Partial p;
-            acc[0].to_partial(p);
+            w.to_partial(p);
             p.cnt = cnt;
             p.pad = 0;
             partials[slot] = p;
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r].init();
         cnt = 0;
     };
 
@@ -381,15 +399,12 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
     unsigned in_batch = 0, batch_first = 0;
     auto park = [&](unsigned column) {
         if (in_batch == 0) batch_first = column;
-#pragma unroll
-        for (int r = 1; r < R; ++r) acc[0].merge(acc[r]);
+        const Acc w = widened();
         Partial p;
-        acc[0].to_partial(p);
+        w.to_partial(p);
         park_a[TOTAL ? 0 : wave][TOTAL ? 0 : in_batch][TOTAL ? 0 : lane] = p.a;
         if constexpr (kDD && !TOTAL) park_b[wave][in_batch][lane] = p.b;
         park_c[TOTAL ? 0 : wave][TOTAL ? 0 : in_batch][TOTAL ? 0 : lane] = cnt;
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r].init();
         cnt = 0;
         ++in_batch;
     };
@@ -522,6 +537,8 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
                 if constexpr (!TOTAL) {
                     park(col);
                     if (in_batch == (unsigned)kBatch || col_n >= n_cols) reduce_batch();  // a full batch, or the wave's last column
+                } else if constexpr (kSplit) {
+                    run.merge(widened());  // the halves hold one chunk at most
                 }
             }
             if (col_n >= n_cols) {
@@ -812,9 +829,25 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     if (n_cols == 0 && !total) return MA_OK;
     MA_REQUIRE(n_cols < ((size_t)1 << 30), MA_ERR_INVALID_ARGUMENT, "too many columns");
     MA_REQUIRE(n_cols == 0 || (col_data != nullptr && col_lens != nullptr), MA_ERR_INVALID_ARGUMENT, "NULL column table");
-    for (size_t i = 0; i < n_cols; ++i) {
-        MA_REQUIRE(col_lens[i] == 0 || col_data[i] != nullptr, MA_ERR_INVALID_ARGUMENT, "column %zu data is NULL", i);
-        MA_REQUIRE(((uintptr_t)col_data[i] % elem) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu is misaligned", i);
+    // One pass over the caller's table for everything that is decided per column in front of the launch (a chunked column at
+    // RechunkStrategy::Auto is 122 000 "columns" per 10^9 rows, and a 32-KB chunk is scanned in 4.7 ns: the host's time per
+    // column is on the critical path of i32 and narrower rows — profiles/r06_column_waves.md).
+    size_t longest = 0;
+    {
+        const uintptr_t mis = (uintptr_t)elem - 1;  // elem is 1, 2, 4 or 8
+        uintptr_t bad_align = 0;
+        size_t first_null = n_cols;
+        for (size_t i = 0; i < n_cols; ++i) {
+            const size_t len = col_lens[i];
+            const uintptr_t a = (uintptr_t)col_data[i];
+            bad_align |= a & mis;
+            if (len != 0 && a == 0 && first_null == n_cols) first_null = i;
+            longest = len > longest ? len : longest;
+        }
+        MA_REQUIRE(first_null == n_cols, MA_ERR_INVALID_ARGUMENT, "column %zu data is NULL", first_null);
+        if (bad_align)
+            for (size_t i = 0; i < n_cols; ++i)
+                MA_REQUIRE(((uintptr_t)col_data[i] & mis) == 0, MA_ERR_INVALID_ARGUMENT, "column %zu is misaligned", i);
     }
     MA_ENTER(ctx);
     MA_NO_CAPTURE(ctx, "ma_sum_columns (descriptor upload)");
@@ -902,8 +935,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
         }
     }
     // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
-    bool all_short = n_cols >= 256;  // below that the table copy is a few microseconds and the segment form is as good
-    for (size_t i = 0; i < n_cols && all_short; ++i) all_short = col_lens[i] <= seg_rows(elem);
+    const bool all_short = n_cols >= 256 && longest <= seg_rows(elem);  // below 256 the table copy is a few microseconds and the segment form is as good
     // Long columns, enough of them for every wave to take many pieces: described per column, cut into pieces on the device and
     // summed by the same wave kernel (expand_pieces_kernel). variant bit 4096: segments and workgroups, for A/B.
     size_t n_pieces = 0, n_long_segs = 0;

@@ -114,6 +114,42 @@ def test_many_short_columns_take_the_wave_per_column_form(ctx, fmt):
     np.testing.assert_array_equal(dense_c, np.array(lens, dtype=np.uint64))
 
 
+@pytest.mark.parametrize("fmt", ["i", "I"])
+def test_whole_segments_of_extreme_32_bit_values_cannot_overflow_the_half_word_accumulators(ctx, fmt):
+    """The wave-per-column form adds 32-bit integers in halves (two 32-bit words per accumulator, widened once per column): 300
+    columns of 65 536 rows — the longest a column of this form gets — of nothing but the type's minimum, maximum, -1 / 2^16 - 1
+    patterns, dense and with validity, per column and as ONE total (where the words are widened per chunk)."""
+    dt = NP[fmt]
+    info = np.iinfo(dt)
+    fills = [info.min, info.max, dt(-1) if fmt == "i" else dt(0xFFFF), dt(0x7FFF8000 if fmt == "i" else 0xFFFF0000), dt(0x8000)]
+    rng = np.random.default_rng(77)
+    n, k = 65_536, 300
+    lens = [n] * k
+    lens[7], lens[100] = n - 1, n - 2049
+    cols = [np.full(m, fills[i % len(fills)], dtype=dt) for i, m in enumerate(lens)]
+    arena = np.concatenate(cols)
+    starts = np.cumsum([0] + [c.size for c in cols[:-1]])
+    dev = ctx.to_device(arena, 64)
+    ptrs = [dev.ptr + int(s) * arena.itemsize for s in starts]
+    bits = rng.integers(0, 256, size=n // 8 + 32, dtype=np.uint8)
+    bits[:64] = 0xFF
+    d_bits = ctx.to_device(bits, 16)
+    valid = np.unpackbits(bits, bitorder="little")
+    for masks, offs in ((None, None), ([d_bits] * k, [5] * k)):
+        f, i64, cnt = ctx.sum_columns(fmt, ptrs, lens, masks, offs)
+        total = 0
+        for j, (c, m) in enumerate(zip(cols, lens)):
+            v = valid[5:5 + m].astype(bool) if masks else np.ones(m, dtype=bool)
+            want = int(c[0]) * int(v.sum())
+            total += want
+            assert cnt[j] == v.sum(), j
+            assert (int(i64[j]) - want) % (1 << 64) == 0, (j, int(i64[j]), want)
+            assert f[j] == float(want), j
+        tf, ti, tc = ctx.sum_chunks(fmt, ptrs, lens, masks, offs)
+        assert (int(ti) - total) % (1 << 64) == 0, (ti, total)
+        assert tc == (sum(int(valid[5:5 + m].sum()) for m in lens) if masks else sum(lens))
+
+
 def test_thousand_small_columns(ctx):
     """1000 columns of 1000 rows (the launch-bound shape): iota data, closed forms."""
     k, n = 1000, 1000
