@@ -57,6 +57,14 @@ struct SplitAcc {
         else
             asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi) : "v"(hi), "v"(v));
     }
+    // add(valid ? v : 0) for a validity bit `valid` (0 or 1) without the select: the bit is the other factor of two 16-bit
+    // multiply-adds (lo += v.lo16 * valid; hi += v.hi16 * valid) — a bit extract and two instructions per value where a mask
+    // and two adds are four
+    __device__ __forceinline__ void add_if(T v, unsigned valid) {
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(lo) : "v"(v), "v"(valid), "v"(lo));
+        if constexpr (std::is_signed<T>::value) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(v), "v"(valid), "v"(hi));
+        else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(v), "v"(valid), "v"(hi));
+    }
     __device__ __forceinline__ void merge(const SplitAcc& o) {
         lo += o.lo;
         hi += o.hi;

@@ -130,6 +130,17 @@ struct ma_ctx {
     std::vector<void*> table_garbage;     // outgrown staging buffers: freed with the context (hipHostFree drains the device)
     int table_next = 0;
     int table_cur = -1;                   // the slot table_begin handed out, until it is committed
+    // Device copies of tables that go up BESIDE the stream's work (ma::TableUpload): a stream of its own for the copies, a few
+    // device buffers used in turn, per buffer the event of its copy and the event behind its last reader's launch.
+    static constexpr int kDevTables = 4;
+    hipStream_t upload_stream = nullptr;  // made on first use
+    void* dev_table[kDevTables] = {};
+    size_t dev_table_bytes[kDevTables] = {};
+    hipEvent_t dev_table_up[kDevTables] = {};    // recorded on upload_stream behind the buffer's copy
+    hipEvent_t dev_table_read[kDevTables] = {};  // recorded on `stream` behind the last launch that reads the buffer
+    bool dev_table_has_reader[kDevTables] = {};
+    std::vector<void*> dev_table_garbage;        // outgrown buffers: a launched kernel may still read them — freed with the context
+    int dev_table_next = 0;
 };
 
 // Entry points that must talk to the host (a result copied back, a staging copy, an allocation) cannot be recorded.
@@ -335,6 +346,29 @@ struct TableSlotGuard {
     }
     TableSlotGuard(const TableSlotGuard&) = delete;
     TableSlotGuard& operator=(const TableSlotGuard&) = delete;
+};
+
+// Instead of table_commit / table_commit_mapped, for a table that a SHORT kernel walks (60 000 chunk descriptors under a 0.29-ms
+// scan): the table built by table_begin goes to a device buffer of the context on the context's UPLOAD stream — beside whatever
+// ctx->stream is still running, and in pieces while the host is still writing the rest; the host waits for the last piece
+// (microseconds) and launches. Read in place, every descriptor is a PCIe read of its own (200 M/s for 32-KB chunks) whose latency depends
+// on where the pinned buffer sits: the same kernel took 288 us on one staging slot and 310-370 on the next
+// (profiles/r06_column_waves.md); copied on ctx->stream, the 40-us copy sits between the kernels.
+//   TableUpload up(ctx); up.begin(host, bytes); [up.push(bytes_final_so_far) ...]; up.finish(&dev); launches on ctx->stream;
+// the destructor records the readers' event (the buffer is overwritten only behind it) on every way out.
+struct TableUpload {
+    ma_ctx* ctx;
+    const char* host = nullptr;
+    size_t total = 0, sent = 0;
+    int dslot = -1;
+    bool handed_over = false;
+    explicit TableUpload(ma_ctx* c) : ctx(c) {}
+    ~TableUpload();
+    TableUpload(const TableUpload&) = delete;
+    TableUpload& operator=(const TableUpload&) = delete;
+    ma_status begin(const void* host_table, size_t bytes);  // host_table: what table_begin handed out
+    ma_status push(size_t upto);                            // bytes [sent, upto) are final: their copy starts now
+    ma_status finish(const void** out_dev);                 // the rest, and waits for it: launches may follow at once
 };
 
 // Host side, used where small Arrow batches are gathered into pinned tiles (ma_stream.hip, ma_stream_op.hip).

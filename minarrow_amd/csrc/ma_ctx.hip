@@ -522,6 +522,75 @@ ma_status table_release(ma_ctx* ctx, int slot) {
     return MA_OK;
 }
 
+ma_status TableUpload::begin(const void* host_table, size_t bytes) {
+    const int k = ctx->table_cur;
+    MA_REQUIRE(k >= 0 && host_table == ctx->table_stage[k], MA_ERR_INVALID_ARGUMENT, "TableUpload::begin without table_begin");
+    if (!ctx->upload_stream) MA_HIP(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    const int j = ctx->dev_table_next;
+    ctx->dev_table_next = (j + 1) % ma_ctx::kDevTables;
+    if (!ctx->dev_table_up[j]) MA_HIP(hipEventCreateWithFlags(&ctx->dev_table_up[j], hipEventDisableTiming));
+    if (!ctx->dev_table_read[j]) MA_HIP(hipEventCreateWithFlags(&ctx->dev_table_read[j], hipEventDisableTiming));
+    if (bytes > ctx->dev_table_bytes[j]) {
+        // replaced, not freed: a kernel launched four calls ago may still read the old one, and hipFree drains the device
+        if (ctx->dev_table[j]) ctx->dev_table_garbage.push_back(ctx->dev_table[j]);
+        ctx->dev_table[j] = nullptr;
+        ctx->dev_table_bytes[j] = 0;
+        ctx->dev_table_has_reader[j] = false;
+        const size_t base = bytes > ctx->table_high_water ? bytes : ctx->table_high_water;
+        const size_t want = (base + base / 2 + 4095) & ~(size_t)4095;
+        MA_HIP(dev_malloc_retry(ctx->device, &ctx->dev_table[j], want));
+        ctx->dev_table_bytes[j] = want;
+    }
+    // The buffer's last readers were launched kDevTables calls ago. The HOST waits for them (normally they are long done): that
+    // is also what keeps a host that describes tables faster than the GPU scans them from running ahead without bound — left
+    // to a device-side wait it queued ten calls' copies, events and waits and then stood still for 8 ms at a time while the
+    // GPU ran dry (profiles/r06_column_waves.md).
+    if (ctx->dev_table_has_reader[j]) MA_HIP(hipEventSynchronize(ctx->dev_table_read[j]));
+    host = (const char*)host_table;
+    total = bytes;
+    sent = 0;
+    dslot = j;
+    return MA_OK;
+}
+
+ma_status TableUpload::push(size_t upto) {
+    if (dslot < 0 || upto <= sent) return MA_OK;
+    if (upto > total) upto = total;
+    MA_HIP(hipMemcpyAsync((char*)ctx->dev_table[dslot] + sent, host + sent, upto - sent, hipMemcpyHostToDevice, ctx->upload_stream));
+    sent = upto;
+    return MA_OK;
+}
+
+ma_status TableUpload::finish(const void** out_dev) {
+    MA_REQUIRE(dslot >= 0, MA_ERR_INVALID_ARGUMENT, "TableUpload::finish without begin");
+    MA_TRY(push(total));
+    const int k = ctx->table_cur;
+    // The HOST waits for the last piece (~15 us; the earlier ones ran while the table was still being written), not ctx->stream:
+    // a cross-stream wait in front of every launch is a barrier packet the queue works through only after the kernel before it
+    // has ended — 10-12 us between back-to-back scans where a plain launch leaves 4 (profiles/r06_column_waves.md). With the
+    // GPU still busy with the call before, the wait costs the pipeline nothing.
+    MA_HIP(hipEventRecord(ctx->dev_table_up[dslot], ctx->upload_stream));
+    MA_HIP(hipEventSynchronize(ctx->dev_table_up[dslot]));
+    ctx->table_busy[k] = false;  // copied: the pinned staging slot is free
+    ctx->table_next = (k + 1) % ma_ctx::kTableSlots;
+    ctx->table_cur = -1;
+    handed_over = true;
+    *out_dev = ctx->dev_table[dslot];
+    return MA_OK;
+}
+
+TableUpload::~TableUpload() {
+    if (dslot < 0) return;
+    if (!handed_over) {
+        // begun, never finished (an error on the way): pieces may be in flight out of the pinned slot — wait for them
+        if (sent > 0 && hipStreamSynchronize(ctx->upload_stream) != hipSuccess) (void)hipGetLastError();
+        return;
+    }
+    // behind the last launch that reads the buffer (launched or not: the event covers whatever the stream holds by now)
+    if (hipEventRecord(ctx->dev_table_read[dslot], ctx->stream) == hipSuccess) ctx->dev_table_has_reader[dslot] = true;
+    else (void)hipGetLastError();
+}
+
 ma_status upload_table(ma_ctx* ctx, const void* src, size_t bytes, void* dev_dst) {
     if (bytes == 0) return MA_OK;
     void* host = nullptr;
@@ -952,6 +1021,17 @@ void ma_ctx_destroy(ma_ctx* ctx) {
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->upload_stream) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        (void)hipStreamDestroy(ctx->upload_stream);
+    }
+    for (int j = 0; j < ma_ctx::kDevTables; ++j) {
+        if (ctx->dev_table[j]) (void)hipFree(ctx->dev_table[j]);
+        if (ctx->dev_table_up[j]) (void)hipEventDestroy(ctx->dev_table_up[j]);
+        if (ctx->dev_table_read[j]) (void)hipEventDestroy(ctx->dev_table_read[j]);
+    }
+    for (void* g : ctx->dev_table_garbage) (void)hipFree(g);
+    ctx->dev_table_garbage.clear();
     for (void* g : ctx->table_garbage) (void)hipHostFree(g);
     ctx->table_garbage.clear();
     for (int k = 0; k < ma_ctx::kTableSlots; ++k) {

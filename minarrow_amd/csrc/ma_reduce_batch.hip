@@ -27,9 +27,10 @@ struct ColDesc {
     size_t seg0;            // index of this column's first segment (prefix sum)
 };
 
-// Columns of a segment or less each: 32 bytes, read where the host built them (pinned staging buffer, wave-uniform loads a
-// column ahead of their use) — column c IS partial c, nothing to search, no table copy on the stream in front of the kernel
-// (2.9 MB = 0.1 ms of a 0.7-ms call for 60 000 columns).
+// Columns of a segment or less each: 32 bytes, wave-uniform loads a column ahead of their use — column c IS partial c, nothing
+// to search. The table reaches the device on the context's upload stream, beside the stream's work (TableUpload): no copy on the
+// stream in front of the kernel (0.1 ms of a 0.7-ms call for 60 000 columns), no PCIe read per column either (rounds 3-5 read
+// it in place).
 struct ShortCol {
     const void* data;
     size_t len;
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void column_segments_kernel(const void* __r
 // one at 6.7: tools/probe_sum_chunks.py) — but with so few waves nobody covers for a wave that has drained its loads at a
 // column's end. So every wave keeps the NEXT tile's loads in flight while it accumulates this one, across column boundaries
 // too: the first tile of column c + W is requested before column c is reduced and stored. Descriptors come a column ahead
-// from the pinned table (wave-uniform loads), requested right after a column's result is out so that no cross-lane step
-// waits on PCIe.
+// from the table (wave-uniform loads), requested right after a column's result is out so that no cross-lane step
+// waits for them.
 // TOTAL: the columns are chunks of ONE column (ma_sum_chunks) — nothing is reduced per chunk; the wave's accumulators run on
 // and its one partial goes to partials[wave].
 // DIRECT (per-column form only): a column is ONE wave's work here, so what its flush holds is the column's result — it goes
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
         return c;
     };
     // always a load (the index is clamped instead of the load being skipped): a conditional one ends in register moves that
-    // wait for the value where it was requested — ~2 us of PCIe per column
+    // wait for the value where it was requested
     auto fetch = [&](unsigned col) -> ShortCol {
         const unsigned i = col < n_cols ? col : n_cols - 1;
         return table[i];
@@ -496,7 +497,10 @@ __global__ __launch_bounds__(kBlock) void column_waves_kernel(const ShortCol* __
                         acc[0].add(narrow_vec_sum<T>(cv[u], bits));
                     } else {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r].add(((bits >> r) & 1u) ? (T)cv[u][r] : (T)0);
+                        for (int r = 0; r < R; ++r) {
+                            if constexpr (kSplit) acc[r].add_if((T)cv[u][r], (bits >> r) & 1u);
+                            else acc[r].add(((bits >> r) & 1u) ? (T)cv[u][r] : (T)0);
+                        }
                     }
                 }
             } else {
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(kBlock) void expand_pieces_kernel(const ColDesc* __
     out[s] = e;
 }
 
-// short_table != nullptr: every column is a segment or less — a wave per column on the ShortCol table (read in place),
+// short_table != nullptr: every column is a segment or less — a wave per column on the ShortCol table,
 // partial c = column c; otherwise a workgroup per segment on the uploaded ColDesc table.
 // total: one {sum, count} over all columns (they are the chunks of ONE logical column) instead of one per column;
 // `partials2` then has room for 4096 partials.
@@ -741,6 +745,7 @@ static void launch_columns(ma_ctx* ctx, const ColDesc* d, const ShortCol* short_
         // to end, against 7.2-7.3 for the plain sum of the same bytes; 122 000 chunks: 7.1 = 0.97 of the plain sum (two waves per
         // SIMD: 6.4-6.7; the round's first shape, eight workgroups per CU and no tile ahead: 6.3-6.4, i32 5.8). The 1- and 2-byte
         // types keep their shallower tiles (the validity words of a tile must fit one load instruction) on two waves per SIMD.
+        // Sixteen loads per tile (thirty-two in flight) read no faster: i32 289.8 -> 291.7 us, i64 566.7 -> 571.2 (profiles/r06_column_waves.md).
         constexpr int U2 = sizeof(T) >= 4 ? 8 : UNROLL;  // the deeper of the two shapes of 4- and 8-byte types
         const int sel = (tuning_variant(ctx) >> 1) & 7;
         const bool deep = sizeof(T) >= 4 && sel != 2;
@@ -934,7 +939,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
             return end_call(ctx, scope);
         }
     }
-    // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol, read in place).
+    // Every column a segment or less (a chunked column handed over chunk by chunk): the short form (ShortCol).
     const bool all_short = n_cols >= 256 && longest <= seg_rows(elem);  // below 256 the table copy is a few microseconds and the segment form is as good
     // Long columns, enough of them for every wave to take many pieces: described per column, cut into pieces on the device and
     // summed by the same wave kernel (expand_pieces_kernel). variant bit 4096: segments and workgroups, for A/B.
@@ -952,8 +957,19 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     const size_t rows_per_seg = expand ? piece_rows(elem) : seg_rows(elem);
     ColDesc* desc = nullptr;  // either table is built in the context's pinned staging buffer: no second copy of 60 000 entries
     ShortCol* sdesc = nullptr;
-    if (all_short) MA_TRY(table_begin(ctx, sizeof(ShortCol) * n_cols, (void**)&sdesc));
-    else MA_TRY(table_begin(ctx, sizeof(ColDesc) * n_cols, (void**)&desc));
+    // The short table goes to the device on the context's upload stream, in pieces while this loop still writes the rest and beside
+    // the kernels of the call before (TableUpload, ma_common.hpp): read in place — a PCIe read per chunk, 200 M/s under an i32 scan —
+    // the same kernel ran 288 us or 310-370, by the staging slot the table happened to sit in (profiles/r06_column_waves.md).
+    // A table of a few thousand columns is still read where it was built: its kernel is over before a copy has been waited for.
+    TableUpload upload(ctx);
+    constexpr size_t kUploadPiece = 16384;  // columns per piece (512 KiB: ~10 us of copy, ~4 us of host time)
+    const bool uploaded = all_short && n_cols >= kUploadPiece / 2;
+    if (all_short) {
+        MA_TRY(table_begin(ctx, sizeof(ShortCol) * n_cols, (void**)&sdesc));
+        if (uploaded) MA_TRY(upload.begin(sdesc, sizeof(ShortCol) * n_cols));
+    } else {
+        MA_TRY(table_begin(ctx, sizeof(ColDesc) * n_cols, (void**)&desc));
+    }
     size_t n_segs = 0;
     // the chunks of a chunked column (one "column" each: 122 000 per 10^9 rows at RechunkStrategy::Auto) run through a few
     // allocations: each role remembers the device range of its last pointer — two compares instead of a classification
@@ -981,6 +997,7 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
         any_masked |= words != nullptr;
         if (all_short) {
             sdesc[i] = ShortCol{data, col_lens[i], words, bit_off};
+            if (uploaded && (i + 1) % kUploadPiece == 0 && n_cols - (i + 1) >= kUploadPiece / 2) MA_TRY(upload.push(sizeof(ShortCol) * (i + 1)));
         } else {
             ColDesc& d = desc[i];
             d.data = data;
@@ -1009,10 +1026,11 @@ static ma_status sum_columns_impl(ma_ctx* ctx, int32_t format_code, size_t n_col
     const ColDesc* d = nullptr;
     const ShortCol* sd = nullptr;
     ShortCol* pieces = expand ? (ShortCol*)((char*)scratch + col_bytes) : nullptr;
-    TableSlotGuard guard(ctx);  // a mapped table's slot is released behind the launches on every way out
+    TableSlotGuard guard(ctx);  // a table read in place: its slot is released behind the launches on every way out
     if (all_short) {
         const void* alias = nullptr;
-        MA_TRY(table_commit_mapped(ctx, sdesc, &alias, &guard.slot));
+        if (uploaded) MA_TRY(upload.finish(&alias));  // (its last piece, waited for)
+        else MA_TRY(table_commit_mapped(ctx, sdesc, &alias, &guard.slot));
         sd = (const ShortCol*)alias;
     } else {
         MA_TRY(table_commit(ctx, desc, sizeof(ColDesc) * n_cols, scratch));

@@ -150,6 +150,57 @@ def test_whole_segments_of_extreme_32_bit_values_cannot_overflow_the_half_word_a
         assert tc == (sum(int(valid[5:5 + m].sum()) for m in lens) if masks else sum(lens))
 
 
+@pytest.mark.parametrize("total", [False, True])
+def test_back_to_back_async_calls_on_long_chunk_lists_each_read_their_own_table(ctx, total):
+    """From 8192 short columns the descriptor table goes to a device buffer on the context's upload stream (four buffers used in turn,
+    pieces copied while the host still writes the rest): twelve asynchronous calls in a row, each over a DIFFERENT selection of
+    20 000-40 000 chunks of one arena with validity on every other call, results left in device memory — every call's results must be
+    those of its own table, whatever the host and the copies were doing meanwhile."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    per, k_all = 1024, 40_000
+    arena = rng.integers(-(1 << 30), 1 << 30, size=per * k_all, dtype=np.int32)
+    bits = rng.integers(0, 256, size=per * k_all // 8 + 64, dtype=np.uint8)
+    dev = ctx.to_device(arena, 64)
+    d_bits = ctx.to_device(bits, 64)
+    col_sums = arena.reshape(k_all, per).astype(np.int64).sum(axis=1)
+    valid = np.unpackbits(bits, bitorder="little")[:per * k_all].reshape(k_all, per).astype(bool)
+    masked_sums = np.where(valid, arena.reshape(k_all, per).astype(np.int64), 0).sum(axis=1)
+    masked_cnts = valid.sum(axis=1)
+    calls, keep = [], []
+    n_calls = 12
+    outs = ctx.alloc(n_calls * 3 * 8 * k_all)
+    ctx.set_async(True)
+    try:
+        for c in range(n_calls):
+            k = 20_000 + 1_667 * c
+            sel = rng.permutation(k_all)[:k]
+            masked = c % 2 == 1
+            ptrs = (C.c_void_p * k)(*[dev.ptr + int(j) * per * 4 for j in sel])
+            lens = (C.c_size_t * k)(*([per] * k))
+            mks = (C.c_void_p * k)(*[d_bits.ptr + int(j) * (per // 8) for j in sel]) if masked else None
+            keep.append((ptrs, lens, mks))
+            base = outs.ptr + c * 3 * 8 * k_all
+            fn = ctx.lib.ma_sum_chunks if total else ctx.lib.ma_sum_columns
+            ffi.check(fn(ctx.handle, ord("i"), k, C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p),
+                         C.cast(mks, C.c_void_p) if mks is not None else None, None, base, base + 8 * k_all, base + 16 * k_all))
+            calls.append((sel, masked, k))
+        ctx.synchronize()
+    finally:
+        ctx.set_async(False)
+    for c, (sel, masked, k) in enumerate(calls):
+        n_out = 1 if total else k
+        got_i = outs.download(np.int64, n_out, c * 3 * 8 * k_all + 8 * k_all)
+        got_c = outs.download(np.uint64, n_out, c * 3 * 8 * k_all + 16 * k_all)
+        want_i = (masked_sums if masked else col_sums)[sel]
+        want_c = masked_cnts[sel] if masked else np.full(k, per)
+        if total:
+            assert int(got_i[0]) == int(want_i.sum()) and int(got_c[0]) == int(want_c.sum()), c
+        else:
+            np.testing.assert_array_equal(got_i, want_i, err_msg=f"call {c}")
+            np.testing.assert_array_equal(got_c, want_c.astype(np.uint64), err_msg=f"call {c}")
+
+
 def test_thousand_small_columns(ctx):
     """1000 columns of 1000 rows (the launch-bound shape): iota data, closed forms."""
     k, n = 1000, 1000
