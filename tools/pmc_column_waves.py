@@ -4,7 +4,9 @@ per-column sums see it, launched a few times for rocprofv3 passes (tools/pmc_col
 rows through ma_sum_columns (column_waves_kernel<T, 8, false>: a {sum, count} per column), the SAME chunk list as one column
 through ma_sum_chunks (column_waves_kernel<T, 8, true>: the same loop without the per-column epilogue), and the same bytes as ONE
 contiguous column through ma_<t>_sum — each dense and with 10 % nulls. argv[2] = columns (default 60000; 122070 = 10^9 rows),
-argv[3] = "dense" / "gated" to launch only those.
+argv[3] = a substring of the job names ("dense", "gated", "columns_i32_gated" ...) to launch only those. With 20 or more
+repetitions the process's first timed job is preceded by 0.4 s of the same calls (clock ramp; CW_NO_RAMP=1 leaves it out, for
+per-launch traces).
 Prints one JSON line of wall-clock figures (the judged ones are the profiler's)."""
 import ctypes as C
 import json
