@@ -201,6 +201,47 @@ def test_back_to_back_async_calls_on_long_chunk_lists_each_read_their_own_table(
             np.testing.assert_array_equal(got_c, want_c.astype(np.uint64), err_msg=f"call {c}")
 
 
+@pytest.mark.parametrize("k", [8191, 8192, 8193, 16384 + 8191, 16384 + 8192, 50_001])
+def test_chunk_lists_either_side_of_the_upload_threshold_and_of_a_piece(ctx, k):
+    """Below 8192 columns the descriptor table is read where it was built, from there on it is uploaded in pieces of 16 384
+    descriptors (a last piece of less than half a piece rides with the one before): the sizes either side of both edges, ragged
+    lengths incl. empty columns, validity on every third column, twice in a row on the same context."""
+    rng = np.random.default_rng(k)
+    lens = rng.choice([0, 1, 63, 64, 100, 257, 1024], size=k).astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    arena = rng.integers(-(1 << 31), 1 << 31, size=int(lens.sum()) + 8, dtype=np.int32)
+    bits = rng.integers(0, 256, size=arena.size // 8 + 64, dtype=np.uint8)
+    dev, d_bits = ctx.to_device(arena, 64), ctx.to_device(bits, 64)
+    valid = np.unpackbits(bits, bitorder="little")[:arena.size].astype(bool)
+    ptrs = [dev.ptr + int(s) * 4 for s in starts]
+    masks = [d_bits if i % 3 == 0 else None for i in range(k)]
+    offs = [int(s) if i % 3 == 0 else 0 for i, s in enumerate(starts)]
+    csum = np.concatenate([[0], np.cumsum(arena.astype(np.int64))])
+    gated = np.concatenate([[0], np.cumsum(np.where(valid, arena.astype(np.int64), 0))])
+    vcnt = np.concatenate([[0], np.cumsum(valid)])
+    e = starts + lens
+    third = np.arange(k) % 3 == 0
+    want_i = np.where(third, gated[e] - gated[starts], csum[e] - csum[starts])
+    want_c = np.where(third, vcnt[e] - vcnt[starts], lens)
+    for _ in range(2):
+        f, i64, cnt = ctx.sum_columns("i", ptrs, [int(n) for n in lens], masks, offs)
+        np.testing.assert_array_equal(i64, want_i)
+        np.testing.assert_array_equal(cnt, want_c.astype(np.uint64))
+        np.testing.assert_array_equal(f, want_i.astype(np.float64))
+
+
+def test_a_long_chunk_list_in_pageable_host_memory_is_staged_while_its_table_is_being_uploaded(ctx):
+    """9000 chunks that live in ordinary host memory: every chunk is staged through the call's scope while the descriptor table's
+    upload has begun — the two must not step on each other's staging."""
+    rng = np.random.default_rng(5)
+    cols = [rng.integers(-1000, 1000, size=int(n), dtype=np.int64) for n in rng.integers(1, 200, size=9000)]
+    f, i64, cnt = ctx.sum_columns("l", cols, [c.size for c in cols])
+    np.testing.assert_array_equal(i64, np.array([int(c.sum()) for c in cols], dtype=np.int64))
+    np.testing.assert_array_equal(cnt, np.array([c.size for c in cols], dtype=np.uint64))
+    tf, ti, tc = ctx.sum_chunks("l", cols, [c.size for c in cols])
+    assert ti == sum(int(c.sum()) for c in cols) and tc == sum(c.size for c in cols)
+
+
 def test_thousand_small_columns(ctx):
     """1000 columns of 1000 rows (the launch-bound shape): iota data, closed forms."""
     k, n = 1000, 1000
