@@ -361,7 +361,11 @@ ma_status ma_f32_mean(ma_ctx* ctx, const float* data, size_t n, const uint8_t* m
  * of the exactly rounded sum, as ma_f64_sum). An empty column yields {0, 0}. Like every other entry point it
  * waits for the results unless the context is in async mode and all buffers are device-reachable.
  * (A FEW LONG device-resident 8-byte columns — up to 16 of 2^21 rows or more, e.g. the batches of a SuperTable column on one
- * GPU — run through ma_sum_fused's kernel, four columns per launch, instead of the segment kernel: same results.) */
+ * GPU — run through ma_sum_fused's kernel, four columns per launch, instead of the segment kernel: same results.)
+ * The four tables are read before the call returns (the caller may reuse them at once). From 8192 columns of a segment or
+ * less each — a chunked column handed over chunk by chunk — the description of the columns is copied to the device on a stream
+ * of the context's own while the stream still runs the call before; in async mode the call then holds the host at most four such
+ * calls ahead of the GPU. */
 ma_status ma_sum_columns(ma_ctx* ctx, int32_t format_code, size_t n_cols, const void* const* col_data,
                          const size_t* col_lens, const uint8_t* const* col_masks, const size_t* col_mask_offsets,
                          double* out_sums_f64, int64_t* out_sums_i64, uint64_t* out_valid_counts);
